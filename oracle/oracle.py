@@ -1,0 +1,172 @@
+"""ctypes front-end of the C oracle (oracle/*.c).  TEST INFRASTRUCTURE ONLY.
+
+Builds oracle/_build/liboracle.so with gcc on first use if it is missing or does not load.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    try:
+        _lib = C.CDLL(_LIB_PATH)
+    except OSError:
+        build(force=True)
+        _lib = C.CDLL(_LIB_PATH)
+    _declare(_lib)
+    return _lib
+
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def _declare(L: C.CDLL) -> None:
+    L.bao_create.restype = C.c_void_p
+    L.bao_create.argtypes = [C.c_int]
+    L.bao_destroy.argtypes = [C.c_void_p]
+    for n in ("bao_alloc_cameras", "bao_alloc_points", "bao_alloc_observations"):
+        getattr(L, n).argtypes = [C.c_void_p, C.c_size_t]
+    L.bao_set_camera.argtypes = [C.c_void_p, C.c_size_t, _f32p, _f32p, _f32p, C.c_int]
+    L.bao_fix_camera.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    L.bao_set_point.argtypes = [C.c_void_p, C.c_size_t, _f32p]
+    L.bao_set_observation.argtypes = [C.c_void_p, C.c_size_t, _f32p, C.c_size_t, C.c_size_t, C.c_float]
+    L.bao_set_lambda.argtypes = [C.c_void_p, C.c_float]
+    L.bao_get_lambda.restype = C.c_float
+    L.bao_get_lambda.argtypes = [C.c_void_p]
+    L.bao_step.restype = C.c_float
+    L.bao_step.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_float, _u32p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.bao_get_pose.argtypes = [C.c_void_p, C.c_size_t, _f32p, _f32p]
+    L.bao_get_point.argtypes = [C.c_void_p, C.c_size_t, _f32p]
+    L.bao_get_pose_f64.argtypes = [C.c_void_p, C.c_size_t, _f64p]
+    L.bao_get_point_f64.argtypes = [C.c_void_p, C.c_size_t, _f64p]
+    L.bao_trace_count.restype = C.c_int
+    L.bao_trace_count.argtypes = [C.c_void_p]
+    L.bao_trace_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.bao_lambda_f64.restype = C.c_double
+    L.bao_lambda_f64.argtypes = [C.c_void_p]
+    L.bao_get_errors.argtypes = [C.c_void_p, _f64p]
+    L.bao_test_se3_exp.argtypes = [_f64p, _f64p]
+    L.bao_test_ldlt.restype = C.c_int
+    L.bao_test_ldlt.argtypes = [_f64p, C.c_int, _f64p, _f64p]
+
+
+class OracleBundler:
+    """Same call surface as mage::BundlerLib (BundlerLib.h:20-66), backed by oracle/ba_oracle.c."""
+
+    def __init__(self, points_fixed: bool = False):
+        self._L = lib()
+        self._h = C.c_void_p(self._L.bao_create(int(points_fixed)))
+        self.n_obs = 0
+
+    def close(self):
+        if self._h:
+            self._L.bao_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def AllocateCameras(self, n): self._L.bao_alloc_cameras(self._h, n); self.n_cams = n
+    def AllocateMapPoints(self, n): self._L.bao_alloc_points(self._h, n); self.n_pts = n
+    def AllocateObservations(self, n): self._L.bao_alloc_observations(self._h, n); self.n_obs = n
+
+    def SetCameraPose(self, idx, position, orientation_colmajor, intrinsics, is_fixed):
+        self._L.bao_set_camera(self._h, idx, np.ascontiguousarray(position, np.float32),
+                               np.ascontiguousarray(orientation_colmajor, np.float32).reshape(9),
+                               np.ascontiguousarray(intrinsics, np.float32), int(is_fixed))
+
+    def FixCameraPose(self, idx, value): self._L.bao_fix_camera(self._h, idx, int(value))
+    def SetMapPoint(self, idx, p): self._L.bao_set_point(self._h, idx, np.ascontiguousarray(p, np.float32))
+
+    def SetObservation(self, idx, uv, cam, pt, info):
+        self._L.bao_set_observation(self._h, idx, np.ascontiguousarray(uv, np.float32), int(cam), int(pt), float(info))
+
+    def SetCurrentLambda(self, l): self._L.bao_set_lambda(self._h, float(l))
+    def GetCurrentLambda(self): return float(self._L.bao_get_lambda(self._h))
+
+    def StepBundleAdjustment(self, huber_widths, max_err_sq, outliers: list):
+        hw = np.ascontiguousarray(huber_widths, np.float32)
+        buf = np.zeros(max(self.n_obs, 1), np.uint32)
+        n = C.c_size_t(0)
+        r = self._L.bao_step(self._h, hw, hw.size, float(max_err_sq), buf, buf.size, C.byref(n))
+        outliers.extend(int(x) for x in buf[: min(n.value, buf.size)])
+        return float(r)
+
+    def GetPose(self, idx):
+        t = np.zeros(3, np.float32); R = np.zeros(9, np.float32)
+        self._L.bao_get_pose(self._h, idx, t, R)
+        return t, R
+
+    def GetPoint(self, idx):
+        p = np.zeros(3, np.float32)
+        self._L.bao_get_point(self._h, idx, p)
+        return p
+
+    # --- test-only extras
+    def poses_f64(self):
+        out = np.zeros((self.n_cams, 7))
+        for i in range(self.n_cams):
+            self._L.bao_get_pose_f64(self._h, i, out[i])
+        return out
+
+    def points_f64(self):
+        out = np.zeros((self.n_pts, 3))
+        for i in range(self.n_pts):
+            self._L.bao_get_point_f64(self._h, i, out[i])
+        return out
+
+    def trace(self):
+        res = []
+        for i in range(self._L.bao_trace_count(self._h)):
+            code, trials = C.c_int(), C.c_int()
+            a, b, lam = C.c_double(), C.c_double(), C.c_double()
+            self._L.bao_trace_get(self._h, i, C.byref(code), C.byref(trials), C.byref(a), C.byref(b), C.byref(lam))
+            res.append(dict(code=code.value, trials=trials.value, chi_before=a.value, chi_after=b.value, lam=lam.value))
+        return res
+
+    def lambda_f64(self): return float(self._L.bao_lambda_f64(self._h))
+
+    def errors(self):
+        e = np.zeros((self.n_obs, 2))
+        self._L.bao_get_errors(self._h, e)
+        return e
+
+
+def load_scene(bundler, scene) -> None:
+    """Feed a mageslam_amd.scene.Scene through the BundlerLib call protocol
+    (order of BundleAdjust.cpp:25-193: cameras, map points, observations)."""
+    bundler.AllocateCameras(scene.n_cams)
+    Rcm = scene.cam_R_colmajor()
+    for i in range(scene.n_cams):
+        bundler.SetCameraPose(i, scene.cam_t[i], Rcm[i], scene.cam_K[i], bool(scene.cam_fixed[i]))
+    bundler.AllocateMapPoints(scene.n_pts)
+    for i in range(scene.n_pts):
+        bundler.SetMapPoint(i, scene.points[i])
+    bundler.AllocateObservations(scene.n_obs)
+    for i in range(scene.n_obs):
+        bundler.SetObservation(i, scene.obs_uv[i], scene.obs_cam[i], scene.obs_pt[i], scene.obs_info[i])
