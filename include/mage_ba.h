@@ -1,0 +1,138 @@
+/*
+ * mage_ba.h -- C ABI of the MI355X bundle-adjustment back-end (libmageslam_hip.so).
+ *
+ * Drop-in boundary for the reference's BundlerLib facade:
+ *     Dependencies/BundlerLib/Include/BundlerLib.h:20-66   (class mage::BundlerLib)
+ *     Dependencies/BundlerLib/Source/BundlerLib.cpp        (behaviour; cited per entry point)
+ * Every entry point below replaces exactly one BundlerLib method; include/BundlerLib.h is the C++
+ * shim with the reference's class name and method names that forwards to these symbols, and
+ * INTEGRATION.md shows the binding a MAGE-SLAM maintainer would add.
+ *
+ * Conventions (same as the reference): poses are world->camera; `R_colmajor` is a 3x3 rotation in
+ * column-major order (Eigen::Map<const Matrix3f>); intrinsics are (cx, cy, fx, fy) and -- like the
+ * reference, BundlerLib.cpp:266 -- only fx, cx, cy are used.  All inputs are float32 and are widened
+ * to float64 on entry; all arithmetic on the device is float64.
+ *
+ * Error behaviour: the reference has no error channel (asserts, gsl::narrow throws).  Here every
+ * function returns a mage_status; nothing throws, nothing aborts.  A handle is confined to one
+ * host thread at a time; distinct handles may be used concurrently (each owns a HIP stream).
+ */
+#ifndef MAGE_BA_H
+#define MAGE_BA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum mage_status {
+    MAGE_OK = 0,
+    MAGE_ERR_INVALID_ARGUMENT = 1,   /* null handle/pointer, index out of range, allocate-twice */
+    MAGE_ERR_OUT_OF_MEMORY = 2,
+    MAGE_ERR_DEVICE = 3,             /* HIP runtime error; see mage_last_error() */
+    MAGE_ERR_UNSUPPORTED = 4,        /* part of the surface that is not built yet (tether edges) */
+    MAGE_ERR_NO_DEVICE = 5           /* no gfx950 device visible: the HIP path never falls back to a CPU */
+} mage_status;
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char* mage_last_error(void);
+
+typedef struct mage_ba mage_ba;
+
+/* mage::BundlerParameters (BundlerLib.h:15-18) + device placement. */
+typedef struct mage_ba_params {
+    int are_points_fixed;   /* BundlerParameters::ArePointsFixed */
+    int device;             /* HIP device ordinal; -1 = the calling thread's current device */
+} mage_ba_params;
+
+/* BundlerLib::BundlerLib / ~BundlerLib  (BundlerLib.cpp:184-196, :352) */
+mage_status mage_ba_create(const mage_ba_params* params, mage_ba** out);
+void        mage_ba_destroy(mage_ba* h);
+
+/* AllocateCameras / SetCameraPose / FixCameraPose  (BundlerLib.cpp:198-207, 261-281) */
+mage_status mage_ba_alloc_cameras(mage_ba* h, size_t count);
+mage_status mage_ba_set_camera(mage_ba* h, size_t idx, const float position[3], const float R_colmajor[9],
+                               const float cx_cy_fx_fy[4], int is_fixed);
+mage_status mage_ba_fix_camera(mage_ba* h, size_t idx, int is_fixed);
+
+/* AllocateMapPoints / SetMapPoint  (BundlerLib.cpp:209-217, 283-292) */
+mage_status mage_ba_alloc_points(mage_ba* h, size_t count);
+mage_status mage_ba_set_point(mage_ba* h, size_t idx, const float xyz[3]);
+
+/* AllocateObservations / SetObservation  (BundlerLib.cpp:219-229, 294-309) */
+mage_status mage_ba_alloc_observations(mage_ba* h, size_t count);
+mage_status mage_ba_set_observation(mage_ba* h, size_t idx, const float uv[2], uint64_t camera_index,
+                                    uint64_t point_index, float information_scalar);
+
+/* Bulk forms of the three setters (same semantics as calling the scalar setter for idx = 0..count-1);
+ * they exist because BuildDataForG2O (BundleAdjust.cpp:25-193) makes one call per element, which
+ * dominates once the solve is fast. */
+mage_status mage_ba_set_cameras_bulk(mage_ba* h, size_t count, const float* positions3, const float* R_colmajor9,
+                                     const float* cx_cy_fx_fy4, const uint8_t* is_fixed);
+mage_status mage_ba_set_points_bulk(mage_ba* h, size_t count, const float* xyz3);
+mage_status mage_ba_set_observations_bulk(mage_ba* h, size_t count, const float* uv2, const uint32_t* camera_index,
+                                          const uint32_t* point_index, const float* information_scalar);
+
+/* Tether edges (BundlerLib.cpp:231-259, 311-350): SURVEY.md section 8f rank 1, not built yet.
+ * Allocating zero constraints succeeds (that is what BuildDataForG2O does for monocular maps);
+ * a non-zero count returns MAGE_ERR_UNSUPPORTED. */
+mage_status mage_ba_alloc_fixed_distance_constraints(mage_ba* h, size_t count);
+mage_status mage_ba_alloc_relative_rotation_constraints(mage_ba* h, size_t count);
+mage_status mage_ba_alloc_relative_transform_constraints(mage_ba* h, size_t count);
+
+/* SetCurrentLambda / GetCurrentLambda  (BundlerLib.cpp:123-130, 354-362) */
+mage_status mage_ba_set_lambda(mage_ba* h, float user_lambda);
+mage_status mage_ba_get_lambda(const mage_ba* h, float* lambda_out);
+
+/* StepBundleAdjustment  (BundlerLib.cpp:364-447): one Levenberg-Marquardt iteration per Huber width,
+ * then classification of every active observation (behind the camera, or squared reprojection error
+ * above max_error_square -> removed and reported).  Outlier observation indices are written in
+ * ascending order to outliers[0..min(*n_outliers, capacity)); *n_outliers is the full count
+ * (the reference appends to a std::vector).  *mean_square_error is the reference's return value
+ * (NaN when no inlier remains). */
+mage_status mage_ba_step(mage_ba* h, const float* huber_width_per_iteration, size_t n_iterations,
+                         float max_error_square, uint32_t* outliers, size_t capacity, size_t* n_outliers,
+                         float* mean_square_error);
+
+/* GetPose / GetPoint  (BundlerLib.cpp:457-471) */
+mage_status mage_ba_get_pose(const mage_ba* h, size_t idx, float position[3], float R_colmajor[9]);
+mage_status mage_ba_get_point(const mage_ba* h, size_t idx, float xyz[3]);
+mage_status mage_ba_get_poses_bulk(const mage_ba* h, size_t count, float* positions3, float* R_colmajor9);
+mage_status mage_ba_get_points_bulk(const mage_ba* h, size_t count, float* xyz3);
+
+/* ---- Diagnostics (no counterpart in the reference; used by tests and bench.py) ---- */
+
+/* float64 state as the solver holds it: poses as (qx,qy,qz,qw,tx,ty,tz), points as (x,y,z). */
+mage_status mage_ba_get_state_f64(const mage_ba* h, double* poses7, double* points3);
+
+typedef struct mage_ba_iter_stats {
+    int    code;          /* 0 OK, 1 Terminate, 2 Fail (g2o SolverResult) */
+    int    trials;        /* damped trials taken in this iteration */
+    double chi2_before;   /* robustified chi2 at linearisation */
+    double chi2_after;    /* robustified chi2 of the kept state */
+    double lambda;        /* lambda after the iteration */
+} mage_ba_iter_stats;
+
+/* Statistics of the iterations run by the most recent mage_ba_step (up to 64 kept). */
+mage_status mage_ba_get_iter_stats(const mage_ba* h, mage_ba_iter_stats* out, size_t capacity, size_t* count);
+
+/* Timing of the dense reduced-camera factorisation, measured with HIP events on the handle's own
+ * stream when enabled (adds one event pair per factorisation). */
+typedef struct mage_ba_profile {
+    uint64_t n_factorizations;
+    double   factor_ms_total;      /* sum of event-timed factorisation spans */
+    double   factor_flops_each;    /* n^3/3 for the padded order n */
+    uint64_t schur_launches;
+    double   schur_ms_total;
+    int      system_order;         /* 6 * free cameras */
+    int      padded_order;
+} mage_ba_profile;
+mage_status mage_ba_enable_profiling(mage_ba* h, int enable);
+mage_status mage_ba_get_profile(const mage_ba* h, mage_ba_profile* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGE_BA_H */

@@ -1,0 +1,820 @@
+// ba_host.hip -- host side of the bundle-adjustment back-end: the mage_ba_* C ABI (include/mage_ba.h).
+//
+// Mirrors the control flow of the reference facade and of the g2o pieces it drives:
+//   * call protocol and StepOptimizer (dirty / useless / iteration)   BundlerLib.cpp:92-167, 198-309
+//   * OptimizationAlgorithmLevenberg::solve (lambda policy, <=10 trials) SURVEY.md appendix A.4
+//   * SparseOptimizer::initializeOptimization + index mapping          SURVEY.md appendix A.5
+//   * StepBundleAdjustment post-pass (outliers, mean square error)     BundlerLib.cpp:364-447
+// All arithmetic over observations, landmarks and the reduced camera system runs in the HIP kernels
+// of ba_kernels.hip / chol_kernels.hip; the host only builds the (static between outlier removals)
+// graph structure, sequences launches, and reads back three scalars per LM trial.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <memory>
+#include <vector>
+
+#include "ba_kernels.h"
+#include "chol_kernels.h"
+#include "mage_common.h"
+
+namespace mage {
+
+std::string& last_error_ref()
+{
+    thread_local std::string s;
+    return s;
+}
+
+mage_status select_device(int requested, int* chosen)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(MAGE_ERR_NO_DEVICE, "no HIP device visible (%s)", e != hipSuccess ? hipGetErrorString(e) : "count = 0");
+    int dev = requested;
+    if (dev < 0) MAGE_HIP(hipGetDevice(&dev));
+    if (dev >= n) return fail(MAGE_ERR_INVALID_ARGUMENT, "device %d out of range (%d visible)", dev, n);
+    hipDeviceProp_t prop;
+    MAGE_HIP(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MAGE_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName);
+    *chosen = dev;
+    return MAGE_OK;
+}
+
+namespace {
+
+struct HostCam {
+    double q[4] = { 0, 0, 0, 1 }, t[3] = { 0, 0, 0 };
+    double f = 1, cx = 0, cy = 0;
+    uint8_t fixed = 0, set = 0;
+};
+struct HostObs {
+    float u = 0, v = 0, info = 0;
+    uint32_t cam = 0, pt = 0;
+    uint8_t set = 0, removed = 0;
+};
+
+// float32 rotation matrix (column-major) -> float32 quaternion -> normalise -> float64 -> SE3Quat
+// normalisation; the chain BundlerLib.cpp:270-273 runs through Eigen.
+void pose_from_f32(const float* Rcm, const float* t, HostCam& c)
+{
+    auto M = [&](int r, int col) { return Rcm[col * 3 + r]; };
+    float q[4];
+    float tr = M(0, 0) + M(1, 1) + M(2, 2);
+    if (tr > 0.f) {
+        float s = std::sqrt(tr + 1.0f);
+        q[3] = 0.5f * s;
+        s = 0.5f / s;
+        q[0] = (M(2, 1) - M(1, 2)) * s; q[1] = (M(0, 2) - M(2, 0)) * s; q[2] = (M(1, 0) - M(0, 1)) * s;
+    } else {
+        int i = 0;
+        if (M(1, 1) > M(0, 0)) i = 1;
+        if (M(2, 2) > M(i, i)) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        float s = std::sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0f);
+        q[i] = 0.5f * s;
+        s = 0.5f / s;
+        q[3] = (M(k, j) - M(j, k)) * s;
+        q[j] = (M(j, i) + M(i, j)) * s;
+        q[k] = (M(k, i) + M(i, k)) * s;
+    }
+    float nf = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    double d[4] = { (double)(q[0] / nf), (double)(q[1] / nf), (double)(q[2] / nf), (double)(q[3] / nf) };
+    if (d[3] < 0) { d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; d[3] = -d[3]; }
+    double n = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
+    for (int a = 0; a < 4; ++a) c.q[a] = d[a] / n;
+    c.t[0] = t[0]; c.t[1] = t[1]; c.t[2] = t[2];
+}
+
+}  // namespace
+}  // namespace mage
+
+using namespace mage;
+
+struct mage_ba {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool points_fixed = false;
+
+    // ---- problem as set through the surface (host copy)
+    std::vector<HostCam> cams;
+    std::vector<double> pts;            // n x 3
+    std::vector<uint8_t> pt_set;
+    std::vector<HostObs> obs;
+    bool cams_allocated = false, pts_allocated = false, obs_allocated = false;
+
+    // ---- StepOptimizer / LM state
+    bool dirty = true, useless = false;
+    int iteration = 0;
+    double lambda = -1.0, user_lambda = 0.0, ni = 2.0;
+
+    // ---- where the truth about poses/points lives
+    bool state_on_device = false;       // device buffers hold the current estimate
+    mutable bool host_state_fresh = true;  // host copy equals the device estimate
+
+    // ---- device storage
+    DevBuf<double> d_pose[2], d_pt[2], d_camK;
+    int cur = 0;                        // index of the "current" state buffer
+    DevBuf<int> d_cam2hc, d_hc2cam;
+    DevBuf<float2> d_L_uv; DevBuf<float> d_L_info; DevBuf<uint32_t> d_L_cam, d_L_pt, d_L_edge; DevBuf<int> d_L_slot;
+    DevBuf<int> d_lm_ptr, d_lm_pt, d_lm_wptr, d_w_hc, d_w_lm, d_camE_ptr, d_camE, d_camS_ptr, d_camS, d_blk_ptr;
+    DevBuf<int2> d_blk_ij, d_con;
+    DevBuf<double> d_errL, d_U, d_bc, d_V, d_bp, d_W, d_Dinv, d_db, d_S, d_y, d_xc, d_xl, d_partial, d_scal, d_Ld, d_invdiag;
+    DevBuf<uint8_t> d_flagL;
+    double* h_scal = nullptr;           // pinned mirror of d_scal
+    BaDeviceView view{};
+    std::vector<uint32_t> L_edge_host;  // landmark-order position -> observation index
+    std::vector<uint8_t> flag_host;
+
+    // ---- diagnostics
+    std::vector<mage_ba_iter_stats> stats;
+    bool profiling = false;
+    mage_ba_profile prof{};
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+
+    ~mage_ba()
+    {
+        (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (h_scal) (void)hipHostFree(h_scal);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+mage_status download_state(const mage_ba* hc)
+{
+    mage_ba* h = const_cast<mage_ba*>(hc);
+    if (!h->state_on_device || h->host_state_fresh) return MAGE_OK;
+    MAGE_HIP(hipSetDevice(h->device));
+    std::vector<double> pose(h->cams.size() * 8), pts(h->pt_set.size() * 4);
+    if (!pose.empty()) MAGE_HIP(hipMemcpyAsync(pose.data(), h->d_pose[h->cur].p, pose.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (!pts.empty()) MAGE_HIP(hipMemcpyAsync(pts.data(), h->d_pt[h->cur].p, pts.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MAGE_HIP(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < h->cams.size(); ++i) {
+        for (int a = 0; a < 4; ++a) h->cams[i].q[a] = pose[i * 8 + a];
+        for (int a = 0; a < 3; ++a) h->cams[i].t[a] = pose[i * 8 + 4 + a];
+    }
+    for (size_t i = 0; i < h->pt_set.size(); ++i)
+        for (int a = 0; a < 3; ++a) h->pts[i * 3 + a] = pts[i * 4 + a];
+    h->host_state_fresh = true;
+    return MAGE_OK;
+}
+
+// A setter that arrives after stepping started: pull the estimate back so the host copy is the truth again.
+mage_status before_host_edit(mage_ba* h)
+{
+    if (h->state_on_device) {
+        MAGE_TRY(download_state(h));
+        h->state_on_device = false;
+    }
+    h->dirty = true;
+    return MAGE_OK;
+}
+
+mage_status upload_state(mage_ba* h)
+{
+    const size_t nc = h->cams.size(), np = h->pt_set.size();
+    std::vector<double> pose(nc * 8, 0.0), K(nc * 4, 0.0), pts(np * 4, 0.0);
+    for (size_t i = 0; i < nc; ++i) {
+        const HostCam& c = h->cams[i];
+        for (int a = 0; a < 4; ++a) pose[i * 8 + a] = c.q[a];
+        for (int a = 0; a < 3; ++a) pose[i * 8 + 4 + a] = c.t[a];
+        K[i * 4] = c.f; K[i * 4 + 1] = c.cx; K[i * 4 + 2] = c.cy;
+    }
+    for (size_t i = 0; i < np; ++i)
+        for (int a = 0; a < 3; ++a) pts[i * 4 + a] = h->pts[i * 3 + a];
+    for (int b = 0; b < 2; ++b) {
+        MAGE_TRY(h->d_pose[b].upload(pose.data(), pose.size(), h->stream));
+        MAGE_TRY(h->d_pt[b].upload(pts.data(), pts.size(), h->stream));
+    }
+    MAGE_TRY(h->d_camK.upload(K.data(), K.size(), h->stream));
+    MAGE_HIP(hipStreamSynchronize(h->stream));
+    h->cur = 0;
+    h->state_on_device = true;
+    h->host_state_fresh = true;
+    return MAGE_OK;
+}
+
+void refresh_view_state(mage_ba* h)
+{
+    h->view.pose_cur = h->d_pose[h->cur].p; h->view.pose_trial = h->d_pose[h->cur ^ 1].p;
+    h->view.pt_cur = h->d_pt[h->cur].p; h->view.pt_trial = h->d_pt[h->cur ^ 1].p;
+}
+
+struct Contrib { int i, j, sa, sb; };
+
+// SparseOptimizer::initializeOptimization + BlockSolver::buildStructure, re-expressed as flat CSR arrays.
+mage_status initialize_optimization(mage_ba* h)
+{
+    MAGE_HIP(hipSetDevice(h->device));
+    if (!h->state_on_device) MAGE_TRY(upload_state(h));
+    const int nc = (int)h->cams.size(), np = (int)h->pt_set.size();
+    const size_t no = h->obs.size();
+
+    // active observations: set, not removed, not (camera fixed and points fixed)
+    std::vector<uint32_t> active;
+    active.reserve(no);
+    std::vector<int> cam_deg(nc, 0), pt_deg(np, 0);
+    for (size_t e = 0; e < no; ++e) {
+        const HostObs& o = h->obs[e];
+        if (!o.set || o.removed) continue;
+        if (h->cams[o.cam].fixed && h->points_fixed) continue;
+        active.push_back((uint32_t)e);
+        cam_deg[o.cam]++; pt_deg[o.pt]++;
+    }
+    const int nL = (int)active.size();
+    std::vector<int> cam2hc(nc, -1), hc2cam;
+    for (int i = 0; i < nc; ++i)
+        if (cam_deg[i] > 0 && !h->cams[i].fixed) { cam2hc[i] = (int)hc2cam.size(); hc2cam.push_back(i); }
+    const int nfc = (int)hc2cam.size();
+    std::vector<int> pt2lm(np, -1), lm_pt;
+    for (int i = 0; i < np; ++i)
+        if (pt_deg[i] > 0) { pt2lm[i] = (int)lm_pt.size(); lm_pt.push_back(i); }
+    const int nlm = (int)lm_pt.size();
+    const bool points_free = !h->points_fixed;
+    h->useless = (nfc + (points_free ? nlm : 0)) == 0;
+
+    // landmark-ordered observation list
+    std::vector<int> lm_ptr(nlm + 1, 0);
+    for (int a = 0; a < nL; ++a) lm_ptr[pt2lm[h->obs[active[a]].pt] + 1]++;
+    for (int l = 0; l < nlm; ++l) lm_ptr[l + 1] += lm_ptr[l];
+    std::vector<uint32_t> L_edge(nL);
+    {
+        std::vector<int> fill(lm_ptr.begin(), lm_ptr.end() - 1);
+        for (int a = 0; a < nL; ++a) L_edge[fill[pt2lm[h->obs[active[a]].pt]]++] = active[a];
+    }
+    // inside a landmark: free cameras ascending (ties by observation index), then fixed cameras
+    auto key = [&](uint32_t e) -> uint64_t {
+        int hcv = cam2hc[h->obs[e].cam];
+        return ((uint64_t)(hcv < 0 ? 0x7fffffff : hcv) << 32) | e;
+    };
+    for (int l = 0; l < nlm; ++l) {
+        auto b = L_edge.begin() + lm_ptr[l], en = L_edge.begin() + lm_ptr[l + 1];
+        std::sort(b, en, [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
+    }
+    std::vector<float2> L_uv(nL); std::vector<float> L_info(nL); std::vector<uint32_t> L_cam(nL), L_pt(nL); std::vector<int> L_slot(nL, -1);
+    std::vector<int> lm_wptr(nlm + 1, 0), w_hc, w_lm;
+    for (int l = 0; l < nlm; ++l) {
+        int prev = -1;
+        for (int i = lm_ptr[l]; i < lm_ptr[l + 1]; ++i) {
+            const HostObs& o = h->obs[L_edge[i]];
+            L_uv[i] = make_float2(o.u, o.v); L_info[i] = o.info; L_cam[i] = o.cam; L_pt[i] = o.pt;
+            const int hcv = cam2hc[o.cam];
+            if (points_free && hcv >= 0) {
+                if (hcv != prev) { w_hc.push_back(hcv); w_lm.push_back(l); prev = hcv; }
+                L_slot[i] = (int)w_hc.size() - 1;
+            }
+        }
+        lm_wptr[l + 1] = (int)w_hc.size();
+    }
+    const int nw = (int)w_hc.size();
+
+    // per-camera lists
+    std::vector<int> camE_ptr(nfc + 1, 0), camS_ptr(nfc + 1, 0);
+    std::vector<int> pos_of(nL);
+    {
+        // positions in ascending observation index: sort (edge, pos) pairs by edge
+        std::vector<std::pair<uint32_t, int>> ep(nL);
+        for (int i = 0; i < nL; ++i) ep[i] = { L_edge[i], i };
+        std::sort(ep.begin(), ep.end());
+        for (int i = 0; i < nL; ++i) pos_of[i] = ep[i].second;
+    }
+    for (int i = 0; i < nL; ++i) { int hcv = cam2hc[L_cam[i]]; if (hcv >= 0) camE_ptr[hcv + 1]++; }
+    for (int c = 0; c < nfc; ++c) camE_ptr[c + 1] += camE_ptr[c];
+    std::vector<int> camE(camE_ptr[nfc]);
+    {
+        std::vector<int> fill(camE_ptr.begin(), camE_ptr.end() - 1);
+        for (int a = 0; a < nL; ++a) { int i = pos_of[a]; int hcv = cam2hc[L_cam[i]]; if (hcv >= 0) camE[fill[hcv]++] = i; }
+    }
+    for (int s = 0; s < nw; ++s) camS_ptr[w_hc[s] + 1]++;
+    for (int c = 0; c < nfc; ++c) camS_ptr[c + 1] += camS_ptr[c];
+    std::vector<int> camS(nw);
+    {
+        std::vector<int> fill(camS_ptr.begin(), camS_ptr.end() - 1);
+        for (int s = 0; s < nw; ++s) camS[fill[w_hc[s]]++] = s;
+    }
+
+    // reduced-camera-matrix blocks: contributions (slot_a, slot_b), a <= b inside a landmark, ordered by
+    // (i, j) with landmark order preserved inside a block (two stable counting sorts).
+    size_t ncon = 0;
+    for (int l = 0; l < nlm; ++l) { size_t k = (size_t)(lm_wptr[l + 1] - lm_wptr[l]); ncon += k * (k + 1) / 2; }
+    std::vector<Contrib> E(ncon), E2(ncon);
+    {
+        size_t p = 0;
+        for (int l = 0; l < nlm; ++l)
+            for (int a = lm_wptr[l]; a < lm_wptr[l + 1]; ++a)
+                for (int b = a; b < lm_wptr[l + 1]; ++b) E[p++] = { w_hc[a], w_hc[b], a, b };
+        std::vector<size_t> cnt((size_t)nfc + 1, 0);
+        for (size_t q = 0; q < ncon; ++q) cnt[E[q].j + 1]++;
+        for (int c = 0; c < nfc; ++c) cnt[c + 1] += cnt[c];
+        for (size_t q = 0; q < ncon; ++q) E2[cnt[E[q].j]++] = E[q];
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (size_t q = 0; q < ncon; ++q) cnt[E2[q].i + 1]++;
+        for (int c = 0; c < nfc; ++c) cnt[c + 1] += cnt[c];
+        for (size_t q = 0; q < ncon; ++q) E[cnt[E2[q].i]++] = E2[q];
+    }
+    E2.clear(); E2.shrink_to_fit();
+    std::vector<int> blk_ptr; std::vector<int2> blk_ij; std::vector<int2> con(ncon);
+    blk_ptr.reserve(ncon / 8 + nfc + 2);
+    {
+        size_t q = 0;
+        for (int i = 0; i < nfc; ++i) {
+            // the diagonal block of every free camera exists even with no landmark contribution
+            if (!(q < ncon && E[q].i == i && E[q].j == i)) { blk_ptr.push_back((int)q); blk_ij.push_back(make_int2(i, i)); }
+            while (q < ncon && E[q].i == i) {
+                const int j = E[q].j;
+                blk_ptr.push_back((int)q); blk_ij.push_back(make_int2(i, j));
+                while (q < ncon && E[q].i == i && E[q].j == j) { con[q] = make_int2(E[q].sa, E[q].sb); ++q; }
+            }
+        }
+        blk_ptr.push_back((int)ncon);
+    }
+    const int nblk = (int)blk_ij.size();
+    E.clear(); E.shrink_to_fit();
+
+    const int n = nfc * 6;
+    const int n_pad = std::max(CHOL_TILE, ((n + CHOL_TILE - 1) / CHOL_TILE) * CHOL_TILE);
+
+    hipStream_t st = h->stream;
+    MAGE_TRY(h->d_cam2hc.upload(cam2hc.data(), cam2hc.size(), st));
+    MAGE_TRY(h->d_hc2cam.upload(hc2cam.data(), hc2cam.size(), st));
+    MAGE_TRY(h->d_L_uv.upload(L_uv.data(), L_uv.size(), st));
+    MAGE_TRY(h->d_L_info.upload(L_info.data(), L_info.size(), st));
+    MAGE_TRY(h->d_L_cam.upload(L_cam.data(), L_cam.size(), st));
+    MAGE_TRY(h->d_L_pt.upload(L_pt.data(), L_pt.size(), st));
+    MAGE_TRY(h->d_L_slot.upload(L_slot.data(), L_slot.size(), st));
+    MAGE_TRY(h->d_L_edge.upload(L_edge.data(), L_edge.size(), st));
+    MAGE_TRY(h->d_lm_ptr.upload(lm_ptr.data(), lm_ptr.size(), st));
+    MAGE_TRY(h->d_lm_pt.upload(lm_pt.data(), lm_pt.size(), st));
+    MAGE_TRY(h->d_lm_wptr.upload(lm_wptr.data(), lm_wptr.size(), st));
+    MAGE_TRY(h->d_w_hc.upload(w_hc.data(), w_hc.size(), st));
+    MAGE_TRY(h->d_w_lm.upload(w_lm.data(), w_lm.size(), st));
+    MAGE_TRY(h->d_camE_ptr.upload(camE_ptr.data(), camE_ptr.size(), st));
+    MAGE_TRY(h->d_camE.upload(camE.data(), camE.size(), st));
+    MAGE_TRY(h->d_camS_ptr.upload(camS_ptr.data(), camS_ptr.size(), st));
+    MAGE_TRY(h->d_camS.upload(camS.data(), camS.size(), st));
+    MAGE_TRY(h->d_blk_ptr.upload(blk_ptr.data(), blk_ptr.size(), st));
+    MAGE_TRY(h->d_blk_ij.upload(blk_ij.data(), blk_ij.size(), st));
+    MAGE_TRY(h->d_con.upload(con.data(), con.size(), st));
+
+    const int nb_l = (nlm + 255) / 256, nb_c = (nfc + 255) / 256;
+    MAGE_TRY(h->d_errL.reserve((size_t)nL * 2 + 2));
+    MAGE_TRY(h->d_U.reserve((size_t)nfc * 36 + 1));
+    MAGE_TRY(h->d_bc.reserve((size_t)nfc * 6 + 1));
+    MAGE_TRY(h->d_V.reserve((size_t)nlm * 6 + 1));
+    MAGE_TRY(h->d_bp.reserve((size_t)nlm * 4 + 1));
+    MAGE_TRY(h->d_W.reserve((size_t)nw * 18 + 1));
+    MAGE_TRY(h->d_Dinv.reserve((size_t)nlm * 6 + 1));
+    MAGE_TRY(h->d_db.reserve((size_t)nlm * 4 + 1));
+    MAGE_TRY(h->d_S.reserve((size_t)n_pad * n_pad));
+    MAGE_TRY(h->d_y.reserve(n_pad));
+    MAGE_TRY(h->d_xc.reserve(n_pad));
+    MAGE_TRY(h->d_xl.reserve((size_t)nlm * 4 + 1));
+    MAGE_TRY(h->d_partial.reserve(std::max<size_t>(3 * 1024, (size_t)nb_l + nb_c) + 16));
+    MAGE_TRY(h->d_scal.reserve(SC_COUNT));
+    MAGE_TRY(h->d_Ld.reserve((size_t)CHOL_TILE * CHOL_TILE));
+    MAGE_TRY(h->d_invdiag.reserve(CHOL_TILE));
+    MAGE_TRY(h->d_flagL.reserve((size_t)nL + 1));
+    if (!h->h_scal) MAGE_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), SC_COUNT * sizeof(double)));
+    MAGE_HIP(hipMemsetAsync(h->d_errL.p, 0, ((size_t)nL * 2 + 2) * sizeof(double), st));
+    MAGE_HIP(hipStreamSynchronize(st));   // the host vectors above go out of scope
+
+    BaDeviceView& v = h->view;
+    v.n_cams = nc; v.n_pts = np; v.n_L = nL; v.n_lm = nlm; v.n_fc = nfc; v.n_w = nw; v.n_blk = nblk;
+    v.points_free = points_free ? 1 : 0; v.n_pad = n_pad;
+    v.camK = h->d_camK.p; v.cam2hc = h->d_cam2hc.p; v.hc2cam = h->d_hc2cam.p;
+    v.L_uv = h->d_L_uv.p; v.L_info = h->d_L_info.p; v.L_cam = h->d_L_cam.p; v.L_pt = h->d_L_pt.p; v.L_slot = h->d_L_slot.p; v.L_edge = h->d_L_edge.p;
+    v.lm_ptr = h->d_lm_ptr.p; v.lm_pt = h->d_lm_pt.p; v.lm_wptr = h->d_lm_wptr.p; v.w_hc = h->d_w_hc.p; v.w_lm = h->d_w_lm.p;
+    v.camE_ptr = h->d_camE_ptr.p; v.camE = h->d_camE.p; v.camS_ptr = h->d_camS_ptr.p; v.camS = h->d_camS.p;
+    v.blk_ptr = h->d_blk_ptr.p; v.blk_ij = h->d_blk_ij.p; v.con = h->d_con.p;
+    v.errL = h->d_errL.p; v.U = h->d_U.p; v.bc = h->d_bc.p; v.V = h->d_V.p; v.bp = h->d_bp.p; v.W = h->d_W.p;
+    v.Dinv = h->d_Dinv.p; v.db = h->d_db.p; v.S = h->d_S.p; v.y = h->d_y.p; v.xc = h->d_xc.p; v.xl = h->d_xl.p;
+    v.partial = h->d_partial.p; v.scal = h->d_scal.p;
+    refresh_view_state(h);
+    h->L_edge_host.swap(L_edge);
+    h->prof.system_order = n; h->prof.padded_order = n_pad;
+    h->prof.factor_flops_each = (double)n_pad * n_pad * n_pad / 3.0;
+    h->iteration = 0;
+    h->dirty = false;
+    return MAGE_OK;
+}
+
+mage_status read_scalars(mage_ba* h)
+{
+    MAGE_HIP(hipMemcpyAsync(h->h_scal, h->d_scal.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MAGE_HIP(hipStreamSynchronize(h->stream));
+    return MAGE_OK;
+}
+
+enum { LM_OK = 0, LM_TERMINATE = 1, LM_FAIL = 2 };
+
+// OptimizationAlgorithmLevenberg::solve (appendix A.4); scalars only cross PCIe.
+mage_status lm_solve(mage_ba* h, double huber, int* result)
+{
+    hipStream_t st = h->stream;
+    BaDeviceView& v = h->view;
+    mage_ba_iter_stats tr{};
+    ba_launch_error(v, false, huber, st);
+    ba_launch_linearize(v, huber, st);
+    if (h->iteration == 0) ba_launch_maxdiag(v, st);
+    MAGE_TRY(read_scalars(h));
+    double currentChi = h->h_scal[SC_CHI];
+    tr.chi2_before = currentChi;
+    if (h->iteration == 0) {
+        h->lambda = h->user_lambda > 0 ? h->user_lambda : 1e-5 * h->h_scal[SC_MAXDIAG];
+        h->ni = 2;
+    }
+    double rho = 0;
+    int qmax = 0;
+    CholWorkspace ws{ h->d_Ld.p, h->d_invdiag.p };
+    do {
+        const double lambda = h->lambda;
+        if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[0], st));
+        ba_launch_schur(v, lambda, st);
+        if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[1], st));
+        chol_factor_solve(v.S, v.y, v.xc, v.n_pad, ws, v.scal + SC_CHOL_OK, st);
+        if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[2], st));
+        ba_launch_update(v, lambda, st);
+        ba_launch_error(v, true, huber, st);
+        MAGE_TRY(read_scalars(h));
+        if (h->profiling) {
+            float ms = 0;
+            MAGE_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+            h->prof.schur_ms_total += ms; h->prof.schur_launches++;
+            MAGE_HIP(hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
+            h->prof.factor_ms_total += ms; h->prof.n_factorizations++;
+        }
+        const bool ok2 = h->h_scal[SC_CHOL_OK] != 0.0;
+        double tempChi = h->h_scal[SC_CHI];
+        if (!ok2) { tempChi = DBL_MAX; rho = -1.0; }       // the reference's failed-solve branch: always rejected
+        else {
+            const double scale = h->h_scal[SC_SCALE] + 1e-3;
+            rho = (currentChi - tempChi) / scale;
+        }
+        if (ok2 && rho > 0 && std::isfinite(tempChi)) {
+            double alpha = 1. - std::pow((2 * rho - 1), 3);
+            alpha = std::min(alpha, 2. / 3.);
+            h->lambda *= std::max(1. / 3., alpha);
+            h->ni = 2;
+            currentChi = tempChi;
+            h->cur ^= 1;                 // discardTop: the trial becomes the estimate
+            refresh_view_state(h);
+        } else {
+            h->lambda *= h->ni;
+            h->ni *= 2;                  // pop: the estimate buffers were never touched
+        }
+        qmax++;
+    } while (rho < 0 && qmax < 10);
+    h->host_state_fresh = false;
+    tr.chi2_after = currentChi; tr.lambda = h->lambda; tr.trials = qmax;
+    tr.code = (qmax == 10 || rho == 0) ? LM_TERMINATE : LM_OK;
+    if (h->stats.size() < 64) h->stats.push_back(tr);
+    *result = tr.code;
+    return MAGE_OK;
+}
+
+// StepOptimizer::Step  (BundlerLib.cpp:132-149)
+mage_status step_optimizer(mage_ba* h, double huber, bool* cont)
+{
+    if (h->dirty) MAGE_TRY(initialize_optimization(h));
+    if (h->useless) { *cont = false; return MAGE_OK; }
+    int r = LM_OK;
+    MAGE_TRY(lm_solve(h, huber, &r));
+    h->iteration++;
+    *cont = (r == LM_OK);
+    return MAGE_OK;
+}
+
+template <typename F>
+mage_status guarded(F&& f)
+{
+    try { return f(); }
+    catch (const std::bad_alloc&) { return fail(MAGE_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    catch (const std::exception& e) { return fail(MAGE_ERR_DEVICE, "unexpected exception: %s", e.what()); }
+    catch (...) { return fail(MAGE_ERR_DEVICE, "unexpected exception"); }
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+MAGE_EXPORT const char* mage_last_error(void) { return last_error_ref().c_str(); }
+
+MAGE_EXPORT mage_status mage_ba_create(const mage_ba_params* params, mage_ba** out)
+{
+    return guarded([&]() -> mage_status {
+        if (!out) return fail(MAGE_ERR_INVALID_ARGUMENT, "out is null");
+        *out = nullptr;
+        int dev = 0;
+        MAGE_TRY(select_device(params ? params->device : -1, &dev));
+        std::unique_ptr<mage_ba> h(new mage_ba());
+        h->device = dev;
+        h->points_fixed = params ? params->are_points_fixed != 0 : false;
+        MAGE_HIP(hipSetDevice(dev));
+        MAGE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        for (auto& e : h->ev) MAGE_HIP(hipEventCreate(&e));
+        *out = h.release();
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT void mage_ba_destroy(mage_ba* h) { delete h; }
+
+MAGE_EXPORT mage_status mage_ba_alloc_cameras(mage_ba* h, size_t count)
+{
+    return guarded([&]() -> mage_status {
+        if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+        if (h->cams_allocated) return fail(MAGE_ERR_INVALID_ARGUMENT, "cameras can only be allocated once");   // BundlerLib.cpp:200
+        h->cams.assign(count, HostCam());
+        h->cams_allocated = true;
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_set_camera(mage_ba* h, size_t idx, const float position[3], const float R_colmajor[9],
+                                           const float K[4], int is_fixed)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !position || !R_colmajor || !K) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (idx >= h->cams.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "camera index %zu out of range (%zu)", idx, h->cams.size());
+        MAGE_TRY(before_host_edit(h));
+        HostCam& c = h->cams[idx];
+        pose_from_f32(R_colmajor, position, c);
+        c.f = K[2]; c.cx = K[0]; c.cy = K[1];        // fy (K[3]) unused, BundlerLib.cpp:266
+        c.fixed = is_fixed ? 1 : 0; c.set = 1;
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_set_cameras_bulk(mage_ba* h, size_t count, const float* positions3, const float* R9,
+                                                 const float* K4, const uint8_t* is_fixed)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !positions3 || !R9 || !K4) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (count > h->cams.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "count %zu exceeds allocated cameras %zu", count, h->cams.size());
+        MAGE_TRY(before_host_edit(h));
+        for (size_t i = 0; i < count; ++i) {
+            HostCam& c = h->cams[i];
+            pose_from_f32(R9 + i * 9, positions3 + i * 3, c);
+            c.f = K4[i * 4 + 2]; c.cx = K4[i * 4]; c.cy = K4[i * 4 + 1];
+            c.fixed = (is_fixed && is_fixed[i]) ? 1 : 0; c.set = 1;
+        }
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_fix_camera(mage_ba* h, size_t idx, int is_fixed)
+{
+    return guarded([&]() -> mage_status {
+        if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+        if (idx >= h->cams.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "camera index %zu out of range", idx);
+        const uint8_t nv = is_fixed ? 1 : 0;
+        if (h->cams[idx].fixed != nv) { h->cams[idx].fixed = nv; h->dirty = true; }
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_alloc_points(mage_ba* h, size_t count)
+{
+    return guarded([&]() -> mage_status {
+        if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+        if (h->pts_allocated) return fail(MAGE_ERR_INVALID_ARGUMENT, "map points can only be allocated once");
+        h->pts.assign(count * 3, 0.0);
+        h->pt_set.assign(count, 0);
+        h->pts_allocated = true;
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_set_point(mage_ba* h, size_t idx, const float xyz[3])
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !xyz) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (idx >= h->pt_set.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "point index %zu out of range (%zu)", idx, h->pt_set.size());
+        MAGE_TRY(before_host_edit(h));
+        for (int a = 0; a < 3; ++a) h->pts[idx * 3 + a] = xyz[a];
+        h->pt_set[idx] = 1;
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_set_points_bulk(mage_ba* h, size_t count, const float* xyz3)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !xyz3) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (count > h->pt_set.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "count %zu exceeds allocated points %zu", count, h->pt_set.size());
+        MAGE_TRY(before_host_edit(h));
+        for (size_t i = 0; i < count * 3; ++i) h->pts[i] = xyz3[i];
+        std::fill(h->pt_set.begin(), h->pt_set.begin() + count, 1);
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_alloc_observations(mage_ba* h, size_t count)
+{
+    return guarded([&]() -> mage_status {
+        if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+        if (h->obs_allocated) return fail(MAGE_ERR_INVALID_ARGUMENT, "observations can only be allocated once");
+        if (count > 0x7fffffffull) return fail(MAGE_ERR_INVALID_ARGUMENT, "too many observations");
+        h->obs.assign(count, HostObs());
+        h->obs_allocated = true;
+        return MAGE_OK;
+    });
+}
+
+static mage_status set_obs(mage_ba* h, size_t idx, float u, float v, uint64_t cam, uint64_t pt, float info)
+{
+    if (cam >= h->cams.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "observation %zu: camera index %llu out of range", idx, (unsigned long long)cam);
+    if (pt >= h->pt_set.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "observation %zu: point index %llu out of range", idx, (unsigned long long)pt);
+    HostObs& o = h->obs[idx];
+    o.u = u; o.v = v; o.info = info; o.cam = (uint32_t)cam; o.pt = (uint32_t)pt; o.set = 1; o.removed = 0;
+    return MAGE_OK;
+}
+
+MAGE_EXPORT mage_status mage_ba_set_observation(mage_ba* h, size_t idx, const float uv[2], uint64_t cam, uint64_t pt, float info)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !uv) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (idx >= h->obs.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "observation index %zu out of range (%zu)", idx, h->obs.size());
+        h->dirty = true;
+        return set_obs(h, idx, uv[0], uv[1], cam, pt, info);
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_set_observations_bulk(mage_ba* h, size_t count, const float* uv2, const uint32_t* cam,
+                                                      const uint32_t* pt, const float* info)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !uv2 || !cam || !pt || !info) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (count > h->obs.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "count %zu exceeds allocated observations %zu", count, h->obs.size());
+        h->dirty = true;
+        for (size_t i = 0; i < count; ++i) MAGE_TRY(set_obs(h, i, uv2[i * 2], uv2[i * 2 + 1], cam[i], pt[i], info[i]));
+        return MAGE_OK;
+    });
+}
+
+static mage_status tether_alloc(mage_ba* h, size_t count, const char* what)
+{
+    if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+    if (count == 0) return MAGE_OK;
+    return fail(MAGE_ERR_UNSUPPORTED, "%s constraints are not built yet (SURVEY.md 8f rank 1)", what);
+}
+MAGE_EXPORT mage_status mage_ba_alloc_fixed_distance_constraints(mage_ba* h, size_t n) { return tether_alloc(h, n, "fixed-distance"); }
+MAGE_EXPORT mage_status mage_ba_alloc_relative_rotation_constraints(mage_ba* h, size_t n) { return tether_alloc(h, n, "relative-rotation"); }
+MAGE_EXPORT mage_status mage_ba_alloc_relative_transform_constraints(mage_ba* h, size_t n) { return tether_alloc(h, n, "relative-transform"); }
+
+MAGE_EXPORT mage_status mage_ba_set_lambda(mage_ba* h, float user_lambda)
+{
+    if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+    h->iteration = 0;                       // BundlerLib.cpp:123-130
+    h->user_lambda = (double)user_lambda;
+    return MAGE_OK;
+}
+
+MAGE_EXPORT mage_status mage_ba_get_lambda(const mage_ba* h, float* out)
+{
+    if (!h || !out) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+    *out = (float)h->lambda;
+    return MAGE_OK;
+}
+
+MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_iter, float max_err_sq, uint32_t* outliers,
+                                     size_t capacity, size_t* n_outliers, float* mean_sq_err)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || (n_iter && !huber)) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (n_outliers) *n_outliers = 0;
+        if (mean_sq_err) *mean_sq_err = NAN;
+        MAGE_HIP(hipSetDevice(h->device));
+        h->stats.clear();
+        for (size_t it = 0; it < n_iter; ++it) {
+            if (huber[it] < 0.f) return fail(MAGE_ERR_INVALID_ARGUMENT, "Huber widths must be nonnegative");
+            bool cont = true;
+            MAGE_TRY(step_optimizer(h, (double)huber[it], &cont));
+            if (!cont) break;
+        }
+        // post-pass over the active observations of the last initialisation
+        const BaDeviceView& v = h->view;
+        if (v.n_L == 0 || h->L_edge_host.empty()) return MAGE_OK;     // count == 0 -> NaN
+        ba_launch_classify(v, (double)max_err_sq, h->d_flagL.p, h->stream);
+        MAGE_TRY(read_scalars(h));
+        const double err_sum = h->h_scal[SC_ERRSUM], cnt = h->h_scal[SC_ERRCNT];
+        const size_t nout = (size_t)h->h_scal[SC_NOUT];
+        if (mean_sq_err) *mean_sq_err = (float)(err_sum / cnt);
+        if (nout > 0) {
+            h->flag_host.resize(v.n_L);
+            MAGE_HIP(hipMemcpyAsync(h->flag_host.data(), h->d_flagL.p, (size_t)v.n_L, hipMemcpyDeviceToHost, h->stream));
+            MAGE_HIP(hipStreamSynchronize(h->stream));
+            std::vector<uint32_t> ids;
+            ids.reserve(nout);
+            for (int i = 0; i < v.n_L; ++i) if (h->flag_host[i]) ids.push_back(h->L_edge_host[i]);
+            std::sort(ids.begin(), ids.end());
+            for (size_t i = 0; i < ids.size(); ++i) {
+                h->obs[ids[i]].removed = 1;                                  // removeEdge
+                if (outliers && i < capacity) outliers[i] = ids[i];
+            }
+            h->dirty = true;
+        }
+        if (n_outliers) *n_outliers = nout;
+        return MAGE_OK;
+    });
+}
+
+static void pose_to_f32(const HostCam& c, float t[3], float Rcm[9])
+{
+    // q.normalized().toRotationMatrix() in float64, then cast (BundlerLib.cpp:463-464)
+    double n = std::sqrt(c.q[0] * c.q[0] + c.q[1] * c.q[1] + c.q[2] * c.q[2] + c.q[3] * c.q[3]);
+    double x = c.q[0] / n, y = c.q[1] / n, z = c.q[2] / n, w = c.q[3] / n;
+    double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    double R[9] = { 1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy) };
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) Rcm[cc * 3 + r] = (float)R[r * 3 + cc];
+    t[0] = (float)c.t[0]; t[1] = (float)c.t[1]; t[2] = (float)c.t[2];
+}
+
+MAGE_EXPORT mage_status mage_ba_get_pose(const mage_ba* h, size_t idx, float position[3], float R_colmajor[9])
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !position || !R_colmajor) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (idx >= h->cams.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "camera index %zu out of range", idx);
+        MAGE_TRY(download_state(h));
+        pose_to_f32(h->cams[idx], position, R_colmajor);
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_get_point(const mage_ba* h, size_t idx, float xyz[3])
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !xyz) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (idx >= h->pt_set.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "point index %zu out of range", idx);
+        MAGE_TRY(download_state(h));
+        for (int a = 0; a < 3; ++a) xyz[a] = (float)h->pts[idx * 3 + a];
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_get_poses_bulk(const mage_ba* h, size_t count, float* positions3, float* R9)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !positions3 || !R9) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (count > h->cams.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "count out of range");
+        MAGE_TRY(download_state(h));
+        for (size_t i = 0; i < count; ++i) pose_to_f32(h->cams[i], positions3 + i * 3, R9 + i * 9);
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_get_points_bulk(const mage_ba* h, size_t count, float* xyz3)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !xyz3) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (count > h->pt_set.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "count out of range");
+        MAGE_TRY(download_state(h));
+        for (size_t i = 0; i < count * 3; ++i) xyz3[i] = (float)h->pts[i];
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_get_state_f64(const mage_ba* h, double* poses7, double* points3)
+{
+    return guarded([&]() -> mage_status {
+        if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+        MAGE_TRY(download_state(h));
+        if (poses7)
+            for (size_t i = 0; i < h->cams.size(); ++i) {
+                for (int a = 0; a < 4; ++a) poses7[i * 7 + a] = h->cams[i].q[a];
+                for (int a = 0; a < 3; ++a) poses7[i * 7 + 4 + a] = h->cams[i].t[a];
+            }
+        if (points3) std::copy(h->pts.begin(), h->pts.end(), points3);
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_get_iter_stats(const mage_ba* h, mage_ba_iter_stats* out, size_t capacity, size_t* count)
+{
+    if (!h || !count) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+    *count = h->stats.size();
+    for (size_t i = 0; out && i < h->stats.size() && i < capacity; ++i) out[i] = h->stats[i];
+    return MAGE_OK;
+}
+
+MAGE_EXPORT mage_status mage_ba_enable_profiling(mage_ba* h, int enable)
+{
+    if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+    h->profiling = enable != 0;
+    h->prof.n_factorizations = 0; h->prof.factor_ms_total = 0; h->prof.schur_launches = 0; h->prof.schur_ms_total = 0;
+    return MAGE_OK;
+}
+
+MAGE_EXPORT mage_status mage_ba_get_profile(const mage_ba* h, mage_ba_profile* out)
+{
+    if (!h || !out) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+    *out = h->prof;
+    return MAGE_OK;
+}

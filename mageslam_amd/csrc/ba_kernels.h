@@ -1,0 +1,71 @@
+// ba_kernels.h -- device-side data layout and kernel launchers of the bundle-adjustment path.
+//
+// Everything the kernels touch lives in HBM as struct-of-arrays, float64 for state and
+// accumulators, float32/u32 for the observation records exactly as they cross the BundlerLib
+// surface (BundlerLib.h:28-39).  Observations are kept in LANDMARK ORDER (all observations of a
+// map point contiguous, free cameras first and ascending) -- the CSR-by-landmark graph of
+// DESIGN.md section 4; per-camera index lists give the CSR-by-camera view.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mage {
+
+struct BaDeviceView {
+    // ---- sizes
+    int n_cams, n_pts;        // allocated cameras / points
+    int n_L;                  // active observations (landmark order)
+    int n_lm;                 // landmarks with >= 1 active observation
+    int n_fc;                 // free cameras in the system (hessian-indexed)
+    int n_w;                  // W slots: distinct (free camera, free landmark) pairs
+    int n_blk;                // non-empty upper 6x6 blocks of the reduced camera matrix
+    int points_free;          // 0 when BundlerParameters::ArePointsFixed
+    int n_pad;                // padded order of the reduced camera system (multiple of the tile)
+
+    // ---- state (current = accepted estimate, trial = LM candidate; swapped on accept)
+    double* pose_cur;   double* pose_trial;   // n_cams x 8 : qx qy qz qw tx ty tz pad
+    double* pt_cur;     double* pt_trial;     // n_pts  x 4 : x y z pad
+    const double* camK;                        // n_cams x 4 : f cx cy pad
+    const int* cam2hc;                         // n_cams : hessian index or -1
+    const int* hc2cam;                         // n_fc
+
+    // ---- observations, landmark order
+    const float2* L_uv; const float* L_info; const uint32_t* L_cam; const uint32_t* L_pt;
+    const int* L_slot;                         // W slot of the observation or -1
+    const uint32_t* L_edge;                    // original observation index
+    const int* lm_ptr;                         // n_lm + 1 offsets into L_*
+    const int* lm_pt;                          // n_lm : point index of the landmark
+    const int* lm_wptr;                        // n_lm + 1 offsets into the slot arrays
+    const int* w_hc; const int* w_lm;          // n_w : camera hessian index / landmark of a slot
+    // ---- camera views
+    const int* camE_ptr; const int* camE;      // per free camera: positions (in L order) of its observations
+    const int* camS_ptr; const int* camS;      // per free camera: its W slots
+    // ---- reduced-camera-matrix structure
+    const int* blk_ptr; const int2* blk_ij; const int2* con;   // contributions (slot_a, slot_b) per block
+
+    // ---- linear system
+    double* errL;          // n_L x 2   residual of the last error evaluation
+    double* U; double* bc; // n_fc x 36, n_fc x 6
+    double* V; double* bp; // n_lm x 6 (sym: 00 01 02 11 12 22), n_lm x 4
+    double* W;             // n_w x 18  (6x3 row-major)
+    double* Dinv; double* db;  // n_lm x 6, n_lm x 4
+    double* S;             // n_pad x n_pad column-major, lower triangle valid
+    double* y;             // n_pad : reduced rhs b_s (forward-substituted in place by the factorisation)
+    double* xc;            // n_pad : camera increments x_c
+    double* xl;            // n_lm x 4 landmark increments
+    // ---- scalars / scratch
+    double* partial;       // scratch for two-level reductions (>= 4096 doubles)
+    double* scal;          // device scalars, see enum Scal
+};
+
+enum Scal { SC_CHI = 0, SC_SCALE = 1, SC_MAXDIAG = 2, SC_CHOL_OK = 3, SC_ERRSUM = 4, SC_ERRCNT = 5, SC_NOUT = 6, SC_COUNT = 8 };
+
+// All launchers enqueue on `st` and return immediately.
+void ba_launch_error(const BaDeviceView& v, bool trial, double huber_delta, hipStream_t st);         // -> scal[SC_CHI]
+void ba_launch_linearize(const BaDeviceView& v, double huber_delta, hipStream_t st);                 // U,bc,V,bp,W
+void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st);                                       // -> scal[SC_MAXDIAG]
+void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st);                          // Dinv,db,S,y
+void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st);                         // xl, trial state, scal[SC_SCALE]
+void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flag_by_edge, hipStream_t st); // scal[SC_ERRSUM..SC_NOUT]
+
+}  // namespace mage

@@ -1,0 +1,630 @@
+// ba_kernels.hip -- HIP kernels (gfx950) for the bundle-adjustment hot path.
+//
+// What each kernel computes, and the reference code it replaces (g2o is not vendored in the
+// reference tree; semantics per SURVEY.md appendix A, call sites in
+// Dependencies/BundlerLib/Source/BundlerLib.cpp):
+//
+//   k_error            EdgeProjectXYZ2UV::computeError + RobustKernelHuber (A.2, A.3)  -> chi2
+//   k_linearize_lm     linearizeOplus + constructQuadraticForm, landmark side: V, b_p, W (A.2, A.3)
+//   k_linearize_cam    same, camera side: U, b_c, one wavefront per camera, shuffle reduction
+//   k_lm_invert        BlockSolver::solve, (V + lambda I)^-1 and D^-1 b_p (A.5)
+//   k_schur_block      S_ij = [i==j](U_i + lambda I) - sum W_i D^-1 W_j^T, one wavefront per 6x6 block
+//   k_schur_rhs        b_s = b_c - sum W D^-1 b_p, one wavefront per camera
+//   k_backsub          x_l = D^-1 (b_p - sum W^T x_c), point update, scale term (A.4, A.5)
+//   k_pose_update      VertexSE3Expmap::oplusImpl: pose <- exp(x_c) * pose (A.1)
+//   k_classify         StepBundleAdjustment post-pass, BundlerLib.cpp:384-427
+//
+// All accumulations use a fixed order (per-lane strided partial sums, xor-butterfly across the
+// 64 lanes, ordered combination of wave partials), so results are bit-reproducible run to run --
+// the property the reference checks with mira::determinator (BundleAdjust.cpp:43-44,250,320,389).
+// HBM-bound integer/f64 streaming work: no MFMA here (the dense factorisation is in chol_kernels.hip).
+#include "ba_kernels.h"
+
+namespace mage {
+namespace {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, WAVE));
+    return v;
+}
+
+// Deterministic block sum: butterfly inside each wave, then wave partials added in wave order.
+template <int NW>
+__device__ __forceinline__ double block_sum(double v, double* sm /* NW doubles */)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    double r = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r += sm[i];
+    return r;
+}
+
+struct PoseD { double qx, qy, qz, qw, tx, ty, tz; };
+
+__device__ __forceinline__ PoseD load_pose(const double* __restrict__ p, int cam)
+{
+    const double2* q = reinterpret_cast<const double2*>(p + (size_t)cam * 8);
+    double2 a = q[0], b = q[1], c = q[2], d = q[3];
+    PoseD P = { a.x, a.y, b.x, b.y, c.x, c.y, d.x };
+    return P;
+}
+__device__ __forceinline__ void store_pose(double* __restrict__ p, int cam, const PoseD& P)
+{
+    double2* q = reinterpret_cast<double2*>(p + (size_t)cam * 8);
+    q[0] = make_double2(P.qx, P.qy); q[1] = make_double2(P.qz, P.qw);
+    q[2] = make_double2(P.tx, P.ty); q[3] = make_double2(P.tz, 0.0);
+}
+
+// v' = q v q^-1  (Eigen QuaternionBase::_transformVector form)
+__device__ __forceinline__ void q_rot(double qx, double qy, double qz, double qw, double vx, double vy, double vz,
+                                      double& ox, double& oy, double& oz)
+{
+    double ux = qy * vz - qz * vy, uy = qz * vx - qx * vz, uz = qx * vy - qy * vx;
+    ux += ux; uy += uy; uz += uz;
+    ox = vx + qw * ux + (qy * uz - qz * uy);
+    oy = vy + qw * uy + (qz * ux - qx * uz);
+    oz = vz + qw * uz + (qx * uy - qy * ux);
+}
+
+__device__ __forceinline__ void q_to_R(double qx, double qy, double qz, double qw, double R[9])
+{
+    double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    double twx = tx * qw, twy = ty * qw, twz = tz * qw;
+    double txx = tx * qx, txy = ty * qx, txz = tz * qx;
+    double tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+__device__ __forceinline__ void huber(double chi2, double delta, double& rho0, double& rho1)
+{
+    double d2 = delta * delta;
+    if (chi2 <= d2) { rho0 = chi2; rho1 = 1.0; }
+    else { double s = sqrt(chi2); rho0 = 2 * s * delta - d2; rho1 = delta / s; }
+}
+
+struct EdgeGeom { double x, y, z, e0, e1; };
+
+__device__ __forceinline__ EdgeGeom edge_geom(const PoseD& P, const double* __restrict__ camK, int cam,
+                                               double X, double Y, double Z, float2 uv)
+{
+    EdgeGeom g;
+    q_rot(P.qx, P.qy, P.qz, P.qw, X, Y, Z, g.x, g.y, g.z);
+    g.x += P.tx; g.y += P.ty; g.z += P.tz;
+    const double f = camK[cam * 4 + 0], cx = camK[cam * 4 + 1], cy = camK[cam * 4 + 2];
+    g.e0 = (double)uv.x - (g.x / g.z * f + cx);
+    g.e1 = (double)uv.y - (g.y / g.z * f + cy);
+    return g;
+}
+
+// 2x6 pose Jacobian (columns omega then upsilon), appendix A.2
+__device__ __forceinline__ void jac_pose(const EdgeGeom& g, double f, double Jc[12])
+{
+    const double x = g.x, y = g.y, z = g.z, z2 = z * z;
+    Jc[0] = x * y / z2 * f;        Jc[1] = -(1 + (x * x / z2)) * f; Jc[2] = y / z * f;
+    Jc[3] = -1.0 / z * f;          Jc[4] = 0;                       Jc[5] = x / z2 * f;
+    Jc[6] = (1 + y * y / z2) * f;  Jc[7] = -x * y / z2 * f;         Jc[8] = -x / z * f;
+    Jc[9] = 0;                     Jc[10] = -1.0 / z * f;           Jc[11] = y / z2 * f;
+}
+// 2x3 point Jacobian: -1/z * [[f,0,-f x/z],[0,f,-f y/z]] * R
+__device__ __forceinline__ void jac_point(const EdgeGeom& g, double f, const double R[9], double Jp[6])
+{
+    const double t02 = -g.x / g.z * f, t12 = -g.y / g.z * f, iz = -1.0 / g.z;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Jp[c] = iz * (f * R[c] + t02 * R[6 + c]);
+        Jp[3 + c] = iz * (f * R[3 + c] + t12 * R[6 + c]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// final stage of the two-level reductions: one block, fixed strided order
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reduce_sum(const double* __restrict__ in, int n, int stride_out,
+                                                    double* __restrict__ out, int n_out)
+{
+    // in is laid out [n_out][n] ; out[o * stride_out]
+    __shared__ double sm[4];
+    for (int o = 0; o < n_out; ++o) {
+        double acc = 0;
+        for (int i = threadIdx.x; i < n; i += 256) acc += in[(size_t)o * n + i];
+        double r = block_sum<4>(acc, sm);
+        if (threadIdx.x == 0) out[o * stride_out] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// residual + robustified chi2  (one thread per observation, landmark order => coalesced records)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_error(BaDeviceView v, int trial, double delta, int n_part)
+{
+    __shared__ double sm[4];
+    const double* pose = trial ? v.pose_trial : v.pose_cur;
+    const double* pts = trial ? v.pt_trial : v.pt_cur;
+    double acc = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n_L; i += gridDim.x * 256) {
+        const int cam = v.L_cam[i], pt = v.L_pt[i];
+        PoseD P = load_pose(pose, cam);
+        const double2 xy = *reinterpret_cast<const double2*>(pts + (size_t)pt * 4);
+        const double Z = pts[(size_t)pt * 4 + 2];
+        EdgeGeom g = edge_geom(P, v.camK, cam, xy.x, xy.y, Z, v.L_uv[i]);
+        *reinterpret_cast<double2*>(v.errL + (size_t)i * 2) = make_double2(g.e0, g.e1);
+        double rho0, rho1;
+        huber((double)v.L_info[i] * (g.e0 * g.e0 + g.e1 * g.e1), delta, rho0, rho1);
+        acc += rho0;
+    }
+    double r = block_sum<4>(acc, sm);
+    if (threadIdx.x == 0) v.partial[blockIdx.x] = r;
+    (void)n_part;
+}
+
+// ---------------------------------------------------------------------------------------------
+// landmark side of the linearisation: one thread per landmark, observations in order
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_linearize_lm(BaDeviceView v, double delta)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= v.n_lm) return;
+    const int pt = v.lm_pt[l];
+    const double X = v.pt_cur[(size_t)pt * 4], Y = v.pt_cur[(size_t)pt * 4 + 1], Z = v.pt_cur[(size_t)pt * 4 + 2];
+    double V[6] = { 0, 0, 0, 0, 0, 0 }, bp[3] = { 0, 0, 0 };
+    double Wacc[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) Wacc[k] = 0;
+    const int beg = v.lm_ptr[l], end = v.lm_ptr[l + 1];
+    int cur_slot = -1;
+    for (int i = beg; i < end; ++i) {
+        const int cam = v.L_cam[i];
+        PoseD P = load_pose(v.pose_cur, cam);
+        EdgeGeom g = edge_geom(P, v.camK, cam, X, Y, Z, v.L_uv[i]);
+        const double f = v.camK[cam * 4];
+        const double info = (double)v.L_info[i];
+        double rho0, rho1;
+        huber(info * (g.e0 * g.e0 + g.e1 * g.e1), delta, rho0, rho1);
+        const double w = info * rho1;
+        const double r0 = -info * g.e0 * rho1, r1 = -info * g.e1 * rho1;
+        double R[9], Jp[6];
+        q_to_R(P.qx, P.qy, P.qz, P.qw, R);
+        jac_point(g, f, R, Jp);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) bp[a] += Jp[a] * r0 + Jp[3 + a] * r1;
+        V[0] += Jp[0] * w * Jp[0] + Jp[3] * w * Jp[3];
+        V[1] += Jp[0] * w * Jp[1] + Jp[3] * w * Jp[4];
+        V[2] += Jp[0] * w * Jp[2] + Jp[3] * w * Jp[5];
+        V[3] += Jp[1] * w * Jp[1] + Jp[4] * w * Jp[4];
+        V[4] += Jp[1] * w * Jp[2] + Jp[4] * w * Jp[5];
+        V[5] += Jp[2] * w * Jp[2] + Jp[5] * w * Jp[5];
+        const int slot = v.L_slot[i];
+        if (slot != cur_slot) {
+            if (cur_slot >= 0) {
+#pragma unroll
+                for (int k = 0; k < 18; ++k) { v.W[(size_t)cur_slot * 18 + k] = Wacc[k]; Wacc[k] = 0; }
+            }
+            cur_slot = slot;
+        }
+        if (slot >= 0) {
+            double Jc[12];
+            jac_pose(g, f, Jc);
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) Wacc[a * 3 + b] += Jc[a] * w * Jp[b] + Jc[6 + a] * w * Jp[3 + b];
+        }
+    }
+    if (cur_slot >= 0) {
+#pragma unroll
+        for (int k = 0; k < 18; ++k) v.W[(size_t)cur_slot * 18 + k] = Wacc[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v.V[(size_t)l * 6 + k] = V[k];
+    v.bp[(size_t)l * 4 + 0] = bp[0]; v.bp[(size_t)l * 4 + 1] = bp[1]; v.bp[(size_t)l * 4 + 2] = bp[2]; v.bp[(size_t)l * 4 + 3] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// camera side: one wavefront per free camera, lanes stride over its observations
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_linearize_cam(BaDeviceView v, double delta)
+{
+    const int hc = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (hc >= v.n_fc) return;
+    const int cam = v.hc2cam[hc];
+    PoseD P = load_pose(v.pose_cur, cam);
+    const double f = v.camK[cam * 4];
+    double A[21], b[6];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) A[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b[k] = 0;
+    for (int idx = v.camE_ptr[hc] + lane; idx < v.camE_ptr[hc + 1]; idx += WAVE) {
+        const int i = v.camE[idx];
+        const int pt = v.L_pt[i];
+        const double2 xy = *reinterpret_cast<const double2*>(v.pt_cur + (size_t)pt * 4);
+        const double Z = v.pt_cur[(size_t)pt * 4 + 2];
+        EdgeGeom g = edge_geom(P, v.camK, cam, xy.x, xy.y, Z, v.L_uv[i]);
+        const double info = (double)v.L_info[i];
+        double rho0, rho1;
+        huber(info * (g.e0 * g.e0 + g.e1 * g.e1), delta, rho0, rho1);
+        const double w = info * rho1;
+        const double r0 = -info * g.e0 * rho1, r1 = -info * g.e1 * rho1;
+        double Jc[12];
+        jac_pose(g, f, Jc);
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            b[a] += Jc[a] * r0 + Jc[6 + a] * r1;
+#pragma unroll
+            for (int c = 0; c <= a; ++c) A[k++] += Jc[a] * w * Jc[c] + Jc[6 + a] * w * Jc[6 + c];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 21; ++k) A[k] = wave_sum(A[k]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b[k] = wave_sum(b[k]);
+    if (lane == 0) {
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = 0; c <= a; ++c) { v.U[(size_t)hc * 36 + a * 6 + c] = A[k]; v.U[(size_t)hc * 36 + c * 6 + a] = A[k]; ++k; }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v.bc[(size_t)hc * 6 + a] = b[a];
+    }
+}
+
+// max |diagonal| over pose and landmark blocks (computeLambdaInit, A.4)
+__global__ __launch_bounds__(256) void k_maxdiag(BaDeviceView v)
+{
+    __shared__ double sm[4];
+    double m = 0;
+    const int nU = v.n_fc * 6, nV = v.points_free ? v.n_lm * 3 : 0;
+    for (int i = threadIdx.x; i < nU; i += 256) m = fmax(m, fabs(v.U[(size_t)(i / 6) * 36 + (i % 6) * 7]));
+    for (int i = threadIdx.x; i < nV; i += 256) {
+        const int l = i / 3, d = i % 3;
+        m = fmax(m, fabs(v.V[(size_t)l * 6 + (d == 0 ? 0 : d == 1 ? 3 : 5)]));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) v.scal[SC_MAXDIAG] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Schur complement
+// ---------------------------------------------------------------------------------------------
+// (V + lambda I)^-1 in the cofactor form Eigen uses for fixed 3x3 (the inverse of a symmetric matrix
+// computed that way is bitwise symmetric, so 6 values are stored), and D^-1 b_p.
+__global__ __launch_bounds__(256) void k_lm_invert(BaDeviceView v, double lambda)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= v.n_lm) return;
+    const double* Vl = v.V + (size_t)l * 6;
+    const double m00 = Vl[0] + lambda, m01 = Vl[1], m02 = Vl[2], m11 = Vl[3] + lambda, m12 = Vl[4], m22 = Vl[5] + lambda;
+    const double c00 = m11 * m22 - m12 * m12;
+    const double c10 = m12 * m02 - m22 * m01;     // cofactor(1,0)
+    const double c20 = m01 * m12 - m02 * m11;     // cofactor(2,0)
+    const double det = c00 * m00 + c10 * m01 + c20 * m02;
+    const double id = 1.0 / det;
+    const double i00 = c00 * id, i01 = c10 * id, i02 = c20 * id;
+    const double i11 = (m22 * m00 - m02 * m02) * id;
+    const double i12 = (m02 * m01 - m00 * m12) * id;
+    const double i22 = (m00 * m11 - m01 * m01) * id;
+    double* D = v.Dinv + (size_t)l * 6;
+    D[0] = i00; D[1] = i01; D[2] = i02; D[3] = i11; D[4] = i12; D[5] = i22;
+    const double b0 = v.bp[(size_t)l * 4], b1 = v.bp[(size_t)l * 4 + 1], b2 = v.bp[(size_t)l * 4 + 2];
+    double* db = v.db + (size_t)l * 4;
+    db[0] = i00 * b0 + i01 * b1 + i02 * b2;
+    db[1] = i01 * b0 + i11 * b1 + i12 * b2;
+    db[2] = i02 * b0 + i12 * b1 + i22 * b2;
+    db[3] = 0;
+}
+
+// identity on the padded tail of the diagonal so the padded system stays SPD
+__global__ void k_pad_diag(double* S, int n, int n_pad)
+{
+    const int i = n + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pad) S[(size_t)i * n_pad + i] = 1.0;
+}
+
+// One wavefront per non-empty upper block (i <= j).  Each lane owns a strided subset of the block's
+// landmark contributions, forms (W_a D^-1) W_b^T in registers, then the 36 partial sums are combined
+// with a butterfly.  The block is written to the lower triangle of S (column-major), i.e. as the
+// transposed (j, i) block, plus the full diagonal block.
+__global__ __launch_bounds__(256) void k_schur_block(BaDeviceView v, double lambda)
+{
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= v.n_blk) return;
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = 0;
+    for (int c = v.blk_ptr[b] + lane; c < v.blk_ptr[b + 1]; c += WAVE) {
+        const int2 sab = v.con[c];
+        const double* Wa = v.W + (size_t)sab.x * 18;
+        const double* Wb = v.W + (size_t)sab.y * 18;
+        const double* D = v.Dinv + (size_t)v.w_lm[sab.x] * 6;
+        const double d00 = D[0], d01 = D[1], d02 = D[2], d11 = D[3], d12 = D[4], d22 = D[5];
+        double wb[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) wb[k] = Wb[k];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const double a0 = Wa[r * 3], a1 = Wa[r * 3 + 1], a2 = Wa[r * 3 + 2];
+            const double t0 = a0 * d00 + a1 * d01 + a2 * d02;
+            const double t1 = a0 * d01 + a1 * d11 + a2 * d12;
+            const double t2 = a0 * d02 + a1 * d12 + a2 * d22;
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) acc[r * 6 + cc] += t0 * wb[cc * 3] + t1 * wb[cc * 3 + 1] + t2 * wb[cc * 3 + 2];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = wave_sum(acc[k]);
+    const int2 ij = v.blk_ij[b];
+    // lane k < 36 writes entry (r, c) of the block
+    double val = 0;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) if (lane == k) val = acc[k];
+    if (lane < 36) {
+        const int r = lane / 6, c = lane % 6;
+        if (ij.x == ij.y) {
+            double u = v.U[(size_t)ij.x * 36 + r * 6 + c] + (r == c ? lambda : 0.0);
+            v.S[(size_t)(ij.x * 6 + c) * v.n_pad + (ij.x * 6 + r)] = u - val;
+        } else {
+            // S(row = 6j + c, col = 6i + r) = block(i,j)(r,c)
+            v.S[(size_t)(ij.x * 6 + r) * v.n_pad + (ij.y * 6 + c)] = -val;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_schur_rhs(BaDeviceView v)
+{
+    const int hc = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (hc >= v.n_fc) return;
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int idx = v.camS_ptr[hc] + lane; idx < v.camS_ptr[hc + 1]; idx += WAVE) {
+        const int s = v.camS[idx];
+        const double* W = v.W + (size_t)s * 18;
+        const double* db = v.db + (size_t)v.w_lm[s] * 4;
+        const double d0 = db[0], d1 = db[1], d2 = db[2];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[r] += W[r * 3] * d0 + W[r * 3 + 1] * d1 + W[r * 3 + 2] * d2;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc[r] = wave_sum(acc[r]);
+    if (lane < 6) {
+        double a = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) if (lane == r) a = acc[r];
+        v.y[hc * 6 + lane] = v.bc[(size_t)hc * 6 + lane] - a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// back substitution, state update, scale = sum x (lambda x + b)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_backsub(BaDeviceView v, double lambda)
+{
+    __shared__ double sm[4];
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    double sc = 0;
+    if (l < v.n_lm) {
+        const double b0 = v.bp[(size_t)l * 4], b1 = v.bp[(size_t)l * 4 + 1], b2 = v.bp[(size_t)l * 4 + 2];
+        double c0 = b0, c1 = b1, c2 = b2;
+        for (int s = v.lm_wptr[l]; s < v.lm_wptr[l + 1]; ++s) {
+            const double* W = v.W + (size_t)s * 18;
+            const double* x = v.xc + (size_t)v.w_hc[s] * 6;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const double mx = -x[r];
+                c0 += W[r * 3] * mx; c1 += W[r * 3 + 1] * mx; c2 += W[r * 3 + 2] * mx;
+            }
+        }
+        const double* D = v.Dinv + (size_t)l * 6;
+        const double x0 = D[0] * c0 + D[1] * c1 + D[2] * c2;
+        const double x1 = D[1] * c0 + D[3] * c1 + D[4] * c2;
+        const double x2 = D[2] * c0 + D[4] * c1 + D[5] * c2;
+        double* xl = v.xl + (size_t)l * 4;
+        xl[0] = x0; xl[1] = x1; xl[2] = x2; xl[3] = 0;
+        const int pt = v.lm_pt[l];
+        const double* pc = v.pt_cur + (size_t)pt * 4;
+        double* pt_t = v.pt_trial + (size_t)pt * 4;
+        pt_t[0] = pc[0] + x0; pt_t[1] = pc[1] + x1; pt_t[2] = pc[2] + x2;
+        sc = x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
+    }
+    double r = block_sum<4>(sc, sm);
+    if (threadIdx.x == 0) v.partial[blockIdx.x] = r;
+}
+
+__device__ __forceinline__ void m3mul(const double A[9], const double B[9], double C[9])
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) C[r * 3 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c];
+}
+
+// Eigen matrix -> quaternion
+__device__ __forceinline__ void R_to_q(const double m[9], double c[4])
+{
+    double t = m[0] + m[4] + m[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        c[3] = 0.5 * t;
+        t = 0.5 / t;
+        c[0] = (m[7] - m[5]) * t; c[1] = (m[2] - m[6]) * t; c[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[i * 4]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m[i * 4] - m[j * 4] - m[k * 4] + 1.0);
+        double ci = 0.5 * t;
+        t = 0.5 / t;
+        double cw = (m[k * 3 + j] - m[j * 3 + k]) * t;
+        double cj = (m[j * 3 + i] + m[i * 3 + j]) * t;
+        double ck = (m[k * 3 + i] + m[i * 3 + k]) * t;
+        c[3] = cw;
+        c[0] = i == 0 ? ci : (j == 0 ? cj : ck);
+        c[1] = i == 1 ? ci : (j == 1 ? cj : ck);
+        c[2] = i == 2 ? ci : (j == 2 ? cj : ck);
+    }
+}
+
+// pose <- exp(x) * pose for every free camera; one thread per camera; scale partials
+__global__ __launch_bounds__(256) void k_pose_update(BaDeviceView v, double lambda, int part_off)
+{
+    __shared__ double sm[4];
+    const int hc = blockIdx.x * 256 + threadIdx.x;
+    double sc = 0;
+    if (hc < v.n_fc) {
+        const int cam = v.hc2cam[hc];
+        const double* u = v.xc + (size_t)hc * 6;
+        const double* b = v.bc + (size_t)hc * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sc += u[k] * (lambda * u[k] + b[k]);
+        const double w0 = u[0], w1 = u[1], w2 = u[2];
+        const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+        const double Om[9] = { 0, -w2, w1, w2, 0, -w0, -w1, w0, 0 };
+        double Om2[9], R[9], Vm[9];
+        m3mul(Om, Om, Om2);
+        double a, bb, d;
+        if (theta < 0.00001) { a = 1.0; bb = 0.5; d = 1.0 / 6.0; }
+        else {
+            const double s = sin(theta), c = cos(theta);
+            a = s / theta; bb = (1 - c) / (theta * theta); d = (theta - s) / (theta * theta * theta);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const double I = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
+            R[k] = I + a * Om[k] + bb * Om2[k];
+            Vm[k] = I + bb * Om[k] + d * Om2[k];
+        }
+        double q[4];
+        R_to_q(R, q);
+        double ex = Vm[0] * u[3] + Vm[1] * u[4] + Vm[2] * u[5];
+        double ey = Vm[3] * u[3] + Vm[4] * u[4] + Vm[5] * u[5];
+        double ez = Vm[6] * u[3] + Vm[7] * u[4] + Vm[8] * u[5];
+        // SE3Quat(q, t) ctor normalises
+        if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+        double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+        PoseD P = load_pose(v.pose_cur, cam);
+        // result = E * P : t = E.t + E.r * P.t ; r = E.r * P.r ; normalise
+        double rx, ry, rz;
+        q_rot(q[0], q[1], q[2], q[3], P.tx, P.ty, P.tz, rx, ry, rz);
+        PoseD O;
+        O.tx = ex + rx; O.ty = ey + ry; O.tz = ez + rz;
+        O.qw = q[3] * P.qw - q[0] * P.qx - q[1] * P.qy - q[2] * P.qz;
+        O.qx = q[3] * P.qx + q[0] * P.qw + q[1] * P.qz - q[2] * P.qy;
+        O.qy = q[3] * P.qy + q[1] * P.qw + q[2] * P.qx - q[0] * P.qz;
+        O.qz = q[3] * P.qz + q[2] * P.qw + q[0] * P.qy - q[1] * P.qx;
+        if (O.qw < 0) { O.qx = -O.qx; O.qy = -O.qy; O.qz = -O.qz; O.qw = -O.qw; }
+        n = sqrt(O.qx * O.qx + O.qy * O.qy + O.qz * O.qz + O.qw * O.qw);
+        O.qx /= n; O.qy /= n; O.qz /= n; O.qw /= n;
+        store_pose(v.pose_trial, cam, O);
+    }
+    double r = block_sum<4>(sc, sm);
+    if (threadIdx.x == 0) v.partial[part_off + blockIdx.x] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// outlier classification (BundlerLib.cpp:384-427): uses the residuals of the LAST error evaluation
+// (errL) and the KEPT estimates for the in-front-of-camera test, exactly as the reference does.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_classify(BaDeviceView v, double max_err_sq, uint8_t* __restrict__ flagL, int nb)
+{
+    __shared__ double sm[4];
+    double es = 0, ec = 0, no = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n_L; i += gridDim.x * 256) {
+        const double2 e = *reinterpret_cast<const double2*>(v.errL + (size_t)i * 2);
+        const double ss = e.x * e.x + e.y * e.y;
+        const int cam = v.L_cam[i], pt = v.L_pt[i];
+        PoseD P = load_pose(v.pose_cur, cam);
+        double wx, wy, wz, fx, fy, fz;
+        q_rot(-P.qx, -P.qy, -P.qz, P.qw, -P.tx, -P.ty, -P.tz, wx, wy, wz);   // camera centre
+        q_rot(-P.qx, -P.qy, -P.qz, P.qw, 0.0, 0.0, 1.0, fx, fy, fz);        // forward axis in world
+        const double* X = v.pt_cur + (size_t)pt * 4;
+        const double dot = (X[0] - wx) * fx + (X[1] - wy) * fy + (X[2] - wz) * fz;
+        const bool out = (dot <= 0) || (ss > max_err_sq);
+        flagL[i] = out ? 1 : 0;
+        if (out) no += 1.0; else { es += ss; ec += 1.0; }
+    }
+    double r0 = block_sum<4>(es, sm);
+    double r1 = block_sum<4>(ec, sm);
+    double r2 = block_sum<4>(no, sm);
+    if (threadIdx.x == 0) { v.partial[blockIdx.x] = r0; v.partial[nb + blockIdx.x] = r1; v.partial[2 * nb + blockIdx.x] = r2; }
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+constexpr int RED_BLOCKS = 1024;   // grid-stride blocks for the streaming reductions (<= partial capacity / 3)
+
+}  // namespace
+
+void ba_launch_error(const BaDeviceView& v, bool trial, double delta, hipStream_t st)
+{
+    int nb = v.n_L > 0 ? (cdiv(v.n_L, 256) < RED_BLOCKS ? cdiv(v.n_L, 256) : RED_BLOCKS) : 1;
+    hipLaunchKernelGGL(k_error, dim3(nb), dim3(256), 0, st, v, trial ? 1 : 0, delta, nb);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_CHI, 1);
+}
+
+void ba_launch_linearize(const BaDeviceView& v, double delta, hipStream_t st)
+{
+    if (v.points_free && v.n_lm > 0) hipLaunchKernelGGL(k_linearize_lm, dim3(cdiv(v.n_lm, 256)), dim3(256), 0, st, v, delta);
+    if (v.n_fc > 0) hipLaunchKernelGGL(k_linearize_cam, dim3(cdiv(v.n_fc, 4)), dim3(256), 0, st, v, delta);
+}
+
+void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_maxdiag, dim3(1), dim3(256), 0, st, v);
+}
+
+void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st)
+{
+    const int n = v.n_fc * 6;
+    (void)hipMemsetAsync(v.S, 0, (size_t)v.n_pad * v.n_pad * sizeof(double), st);
+    (void)hipMemsetAsync(v.y, 0, (size_t)v.n_pad * sizeof(double), st);
+    if (v.n_pad > n) hipLaunchKernelGGL(k_pad_diag, dim3(cdiv(v.n_pad - n, 128)), dim3(128), 0, st, v.S, n, v.n_pad);
+    if (v.points_free && v.n_lm > 0) hipLaunchKernelGGL(k_lm_invert, dim3(cdiv(v.n_lm, 256)), dim3(256), 0, st, v, lambda);
+    if (v.n_blk > 0) hipLaunchKernelGGL(k_schur_block, dim3(cdiv(v.n_blk, 4)), dim3(256), 0, st, v, lambda);
+    if (v.n_fc > 0) hipLaunchKernelGGL(k_schur_rhs, dim3(cdiv(v.n_fc, 4)), dim3(256), 0, st, v);
+}
+
+void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st)
+{
+    int nb_l = 0;
+    if (v.points_free && v.n_lm > 0) {
+        nb_l = cdiv(v.n_lm, 256);
+        hipLaunchKernelGGL(k_backsub, dim3(nb_l), dim3(256), 0, st, v, lambda);
+    }
+    int nb_c = 0;
+    if (v.n_fc > 0) {
+        nb_c = cdiv(v.n_fc, 256);
+        hipLaunchKernelGGL(k_pose_update, dim3(nb_c), dim3(256), 0, st, v, lambda, nb_l);
+    }
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb_l + nb_c, 1, v.scal + SC_SCALE, 1);
+}
+
+void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flagL, hipStream_t st)
+{
+    int nb = v.n_L > 0 ? (cdiv(v.n_L, 256) < RED_BLOCKS ? cdiv(v.n_L, 256) : RED_BLOCKS) : 1;
+    hipLaunchKernelGGL(k_classify, dim3(nb), dim3(256), 0, st, v, max_err_sq, flagL, nb);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
+}
+
+}  // namespace mage
