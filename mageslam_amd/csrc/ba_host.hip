@@ -211,8 +211,15 @@ struct Contrib { int i, j, sa, sb; };
 mage_status initialize_optimization(mage_ba* h)
 {
     MAGE_HIP(hipSetDevice(h->device));
-    if (!h->state_on_device) MAGE_TRY(upload_state(h));
     const int nc = (int)h->cams.size(), np = (int)h->pt_set.size();
+    if (!h->state_on_device) MAGE_TRY(upload_state(h));
+    else {
+        // Trials only write the entities that are in the system, and accepting a trial swaps the two
+        // state buffers; an entity that just left the system (all its observations removed) must
+        // therefore hold its kept estimate in BOTH buffers.
+        if (nc) MAGE_HIP(hipMemcpyAsync(h->d_pose[h->cur ^ 1].p, h->d_pose[h->cur].p, (size_t)nc * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if (np) MAGE_HIP(hipMemcpyAsync(h->d_pt[h->cur ^ 1].p, h->d_pt[h->cur].p, (size_t)np * 4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
     const size_t no = h->obs.size();
 
     // active observations: set, not removed, not (camera fixed and points fixed)

@@ -888,3 +888,17 @@ BAO_API int bao_test_ldlt(double* A_colmajor, int n, const double* rhs, double* 
     free(tr); free(tmp);
     return ok;
 }
+
+/* bulk forms of the setters (same semantics as the scalar ones, idx = 0..n-1); test/bench convenience */
+BAO_API void bao_set_cameras_bulk(ba_oracle* b, size_t n, const float* t3, const float* R9, const float* K4, const uint8_t* fixed)
+{
+    for (size_t i = 0; i < n; ++i) bao_set_camera(b, i, t3 + i * 3, R9 + i * 9, K4 + i * 4, fixed[i]);
+}
+BAO_API void bao_set_points_bulk(ba_oracle* b, size_t n, const float* p3)
+{
+    for (size_t i = 0; i < n; ++i) bao_set_point(b, i, p3 + i * 3);
+}
+BAO_API void bao_set_observations_bulk(ba_oracle* b, size_t n, const float* uv2, const uint32_t* cam, const uint32_t* pt, const float* info)
+{
+    for (size_t i = 0; i < n; ++i) bao_set_observation(b, i, uv2 + i * 2, cam[i], pt[i], info[i]);
+}

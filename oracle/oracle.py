@@ -70,6 +70,9 @@ def _declare(L: C.CDLL) -> None:
     L.bao_lambda_f64.restype = C.c_double
     L.bao_lambda_f64.argtypes = [C.c_void_p]
     L.bao_get_errors.argtypes = [C.c_void_p, _f64p]
+    L.bao_set_cameras_bulk.argtypes = [C.c_void_p, C.c_size_t, _f32p, _f32p, _f32p, _u8p]
+    L.bao_set_points_bulk.argtypes = [C.c_void_p, C.c_size_t, _f32p]
+    L.bao_set_observations_bulk.argtypes = [C.c_void_p, C.c_size_t, _f32p, _u32p, _u32p, _f32p]
     L.bao_test_se3_exp.argtypes = [_f64p, _f64p]
     L.bao_test_ldlt.restype = C.c_int
     L.bao_test_ldlt.argtypes = [_f64p, C.c_int, _f64p, _f64p]
@@ -170,3 +173,18 @@ def load_scene(bundler, scene) -> None:
     bundler.AllocateObservations(scene.n_obs)
     for i in range(scene.n_obs):
         bundler.SetObservation(i, scene.obs_uv[i], scene.obs_cam[i], scene.obs_pt[i], scene.obs_info[i])
+
+
+def load_scene_bulk(bundler: OracleBundler, scene) -> None:
+    """Same as load_scene but through the oracle's bulk setters (1M observations in one call)."""
+    L = bundler._L
+    bundler.AllocateCameras(scene.n_cams)
+    L.bao_set_cameras_bulk(bundler._h, scene.n_cams, np.ascontiguousarray(scene.cam_t, np.float32).reshape(-1),
+                           scene.cam_R_colmajor().reshape(-1), np.ascontiguousarray(scene.cam_K, np.float32).reshape(-1),
+                           np.ascontiguousarray(scene.cam_fixed, np.uint8))
+    bundler.AllocateMapPoints(scene.n_pts)
+    L.bao_set_points_bulk(bundler._h, scene.n_pts, np.ascontiguousarray(scene.points, np.float32).reshape(-1))
+    bundler.AllocateObservations(scene.n_obs)
+    L.bao_set_observations_bulk(bundler._h, scene.n_obs, np.ascontiguousarray(scene.obs_uv, np.float32).reshape(-1),
+                                np.ascontiguousarray(scene.obs_cam, np.uint32), np.ascontiguousarray(scene.obs_pt, np.uint32),
+                                np.ascontiguousarray(scene.obs_info, np.float32))

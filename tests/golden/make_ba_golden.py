@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ba_*.npz -- run in the development container only.
+
+The expected values come from the INDEPENDENT numpy/scipy implementation (oracle/indep/ba_numpy.py),
+not from the C oracle and not from the HIP path, so a fixture pins both.  The reference itself
+cannot be run, hence "parity unpinned" still applies to the reference proper.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from mageslam_amd import scene  # noqa: E402
+from oracle.indep.ba_numpy import NumpyBundler  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CASES = {
+    # name: (scene kwargs, points_fixed, huber schedule per call, max_err_sq per call)
+    "ba_tiny_clean": (dict(scene.CONFIGS["tiny"]), False, [[1.8]] * 10, [1e30] * 10),
+    "ba_tiny_outliers": (dict(scene.CONFIGS["tiny"], outlier_frac=0.02), False, [[1.8]] * 8,
+                         [7.25 * 0.95 ** (2 * i) for i in range(8)]),          # BundleAdjust.cpp:303-332 schedule
+    "ba_tiny_pose_only": (dict(scene.CONFIGS["tiny"], fixed=()), True, [[4.0, 4.0, 4.0], [0.9, 0.9, 0.9, 0.9]], [20.25, 20.25]),
+    "ba_small_fixedcams": (dict(n_cams=12, n_pts=400, n_obs=3200, seed=0x5EED0A01, fixed=(0, 1, 9, 10, 11)), False,
+                           [[0.9]] * 6, [1e30] * 6),
+}
+
+
+def main():
+    for name, (kw, pf, hubers, thrs) in CASES.items():
+        s = scene.make_scene(**kw)
+        nb = NumpyBundler(s, points_fixed=pf)
+        mse, trace, outl, n_out = [], [], [], []
+        for hw, thr in zip(hubers, thrs):
+            o = []
+            mse.append(nb.StepBundleAdjustment(hw, thr, o))
+            for t in nb.trace:
+                trace.append([t["code"], t["trials"], t["chi_before"], t["chi_after"], t["lam"]])
+            outl.extend(o); n_out.append(len(o))
+        # rotation matrices -> keep R and t in float64
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            kw=np.array(repr(kw)), points_fixed=pf,
+            hubers=np.array([np.array(h, np.float32) for h in hubers], dtype=object), thrs=np.array(thrs, np.float32),
+            cam_t=s.cam_t, cam_R=s.cam_R, cam_K=s.cam_K, cam_fixed=s.cam_fixed, points=s.points,
+            obs_uv=s.obs_uv, obs_cam=s.obs_cam, obs_pt=s.obs_pt, obs_info=s.obs_info,
+            exp_mse=np.array(mse, np.float32), exp_trace=np.array(trace, np.float64),
+            exp_outliers=np.array(outl, np.uint32), exp_n_out=np.array(n_out),
+            exp_R=nb.R, exp_t=nb.t, exp_X=nb.X)
+        print(name, "mse", mse[-1], "outliers", len(outl), "trace rows", len(trace))
+
+
+if __name__ == "__main__":
+    main()
