@@ -120,7 +120,7 @@ struct mage_ba {
     DevBuf<float2> d_L_uv; DevBuf<float> d_L_info; DevBuf<uint32_t> d_L_cam, d_L_pt, d_L_edge; DevBuf<int> d_L_slot;
     DevBuf<int> d_lm_ptr, d_lm_pt, d_lm_wptr, d_w_hc, d_w_lm, d_camE_ptr, d_camE, d_camS_ptr, d_camS, d_blk_ptr;
     DevBuf<int2> d_blk_ij, d_con;
-    DevBuf<double> d_errL, d_U, d_bc, d_V, d_bp, d_W, d_Dinv, d_db, d_S, d_y, d_xc, d_xl, d_partial, d_scal, d_Ld, d_invdiag;
+    DevBuf<double> d_errL, d_U, d_bc, d_V, d_bp, d_W, d_Dinv, d_db, d_S, d_y, d_xc, d_xl, d_partial, d_scal, d_Linv;
     DevBuf<uint8_t> d_flagL;
     double* h_scal = nullptr;           // pinned mirror of d_scal
     BaDeviceView view{};
@@ -383,8 +383,7 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(h->d_xl.reserve((size_t)nlm * 4 + 1));
     MAGE_TRY(h->d_partial.reserve(std::max<size_t>(3 * 1024, (size_t)nb_l + nb_c) + 16));
     MAGE_TRY(h->d_scal.reserve(SC_COUNT));
-    MAGE_TRY(h->d_Ld.reserve((size_t)CHOL_TILE * CHOL_TILE));
-    MAGE_TRY(h->d_invdiag.reserve(CHOL_TILE));
+    MAGE_TRY(h->d_Linv.reserve(chol_workspace_doubles(n_pad)));
     MAGE_TRY(h->d_flagL.reserve((size_t)nL + 1));
     if (!h->h_scal) MAGE_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), SC_COUNT * sizeof(double)));
     MAGE_HIP(hipMemsetAsync(h->d_errL.p, 0, ((size_t)nL * 2 + 2) * sizeof(double), st));
@@ -437,7 +436,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
     }
     double rho = 0;
     int qmax = 0;
-    CholWorkspace ws{ h->d_Ld.p, h->d_invdiag.p };
+    CholWorkspace ws{ h->d_Linv.p };
     do {
         const double lambda = h->lambda;
         if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[0], st));

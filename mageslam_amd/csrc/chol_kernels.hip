@@ -6,16 +6,21 @@
 // unpivoted Cholesky S = L L^T gives the same solution up to rounding; a non-positive pivot is
 // reported through *ok = 0 (the reference's "solve failed" branch).
 //
-// Layout: S is n_pad x n_pad, column-major, lower triangle referenced, n_pad a multiple of TILE.
+// Layout: S is n_pad x n_pad, column-major, lower triangle referenced, n_pad a multiple of TILE = 128.
 // Right-looking tile algorithm, one panel of TILE columns per step k:
-//     k_potrf_diag   : L_kk = chol(S_kk)                          (one workgroup, LDS resident)
+//     k_potrf_diag   : L_kk = chol(S_kk), plus the inverses of its eight 16x16 diagonal blocks
 //     k_trsm_panel   : L_ik = S_ik L_kk^-T for i > k, and the rhs row  y_k = L_kk^-1 y_k
-//     k_syrk_update  : S_ij -= L_ik L_jk^T  (i >= j > k)  on v_mfma_f64_16x16x4_f64, and  y_i -= L_ik y_k
-// so the forward substitution rides along with the factorisation (the rhs is treated as one more row
-// of the matrix).  The backward substitution L^T x = y is k_bsolve_step, one launch per tile column.
+//     k_syrk_update  : S_ij -= L_ik L_jk^T  (i >= j > k), and  y_i -= L_ik y_k
+// so the forward substitution rides along with the factorisation (the rhs is one more matrix row).
+// The backward substitution L^T x = y is k_bsolve_step, one launch per tile column.
 //
-// This is the only MFMA-bound stage of the path (n^3/3 = 72 GFLOP at 1000 poses): f64 MFMA peak on
-// MI355X is 78.6 TFLOP/s (= the f64 vector peak; one 16x16x4 instruction = 2048 flop per 64 cycles/SIMD).
+// All O(n^3) work is on the f64 matrix cores (v_mfma_f64_16x16x4_f64, 64 cycles / instruction / SIMD).
+// Two properties of that instruction shape the kernels:
+//   * operand A is lane -> A[i = lane & 15][k = lane >> 4], operand B is lane -> B[k = lane >> 4][j = lane & 15],
+//     and the result register r of lane holds D[row = (lane >> 4) + 4 r][col = lane & 15];
+//   * hence a 16x16 result D, taken register by register, IS the B operand of the next product
+//     (register r = rows 4r..4r+3 = the r-th K-chunk).  Every triangular solve below is written on the
+//     transposed unknown (Y = X^T) so that results chain from MFMA to MFMA without leaving registers.
 #include <hip/hip_runtime.h>
 #include "chol_kernels.h"
 
@@ -23,240 +28,432 @@ namespace mage {
 namespace {
 
 constexpr int TILE = CHOL_TILE;      // 128
-constexpr int LDT = TILE + 1;        // padded LDS leading dimension for row/column walks
+constexpr int NB = 16;               // inner block (one MFMA tile)
+constexpr int NBLK = TILE / NB;      // 8
+constexpr int LDC = TILE + 16;       // LDS column pitch (doubles): consecutive k columns land 32 banks apart
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// ---------------------------------------------------------------------------------------------
-// diagonal tile: unblocked right-looking Cholesky in LDS.  Also exports a read-only copy of L_kk
-// (row-major, dense TILE x TILE, zeros above the diagonal) and 1/diag for the panel solve.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int ld, int k, double* __restrict__ Ld,
-                                                    double* __restrict__ inv_diag, double* __restrict__ ok)
+__device__ __forceinline__ double readlane_d(double v, int lane)
 {
-    extern __shared__ double A[];   // TILE x LDT, A[r * LDT + c]
-    __shared__ int fail;
-    const int tid = threadIdx.x;
-    double* T = S + (size_t)(k * TILE) * ld + (size_t)k * TILE;
-    if (tid == 0) fail = 0;
-    // coalesced load: column c of the tile is contiguous in rows
-    for (int e = tid; e < TILE * TILE; e += 256) {
-        const int c = e / TILE, r = e % TILE;
-        A[r * LDT + c] = (r >= c) ? T[(size_t)c * ld + r] : 0.0;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+// sqrt(d) and 1/sqrt(d) by v_rsq_f64 + two Goldschmidt steps (full double precision for d > 0)
+__device__ __forceinline__ void sqrt_rsqrt(double d, double& s, double& rs)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    s = g; rs = h + h;
+}
+
+// Global (column-major, pitch ld) -> LDS (column-major, pitch LDC) copy of one 128x128 tile by 256 threads.
+// Loads are issued 16 at a time per thread (16-byte each) so that the L2/HBM latency is paid 4 times, not 64.
+template <int PITCH>
+__device__ __forceinline__ void load_tile(double* __restrict__ dst, const double* __restrict__ src, int ld, int tid)
+{
+    constexpr int BATCH = 16;
+#pragma unroll
+    for (int b0 = 0; b0 < (TILE * TILE / 2) / 256; b0 += BATCH) {
+        double2 v[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e = ((b0 + u) * 256 + tid) * 2;
+            v[u] = *reinterpret_cast<const double2*>(src + (size_t)(e / TILE) * ld + (e % TILE));
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e = ((b0 + u) * 256 + tid) * 2;
+            *reinterpret_cast<double2*>(dst + (e / TILE) * PITCH + (e % TILE)) = v[u];
+        }
     }
+}
+
+// 16x16 diagonal block at A(p0, p0): Cholesky in registers by one wavefront (lane l owns row l,
+// broadcasts through v_readlane), then the inverse of the factor (lane l owns column l).
+// Writes L over the block (zeros above the diagonal are not needed), the inverse row-major to Li and Linv_out.
+__device__ __noinline__ bool factor_block16(double* __restrict__ A, int p0, int lane, double* __restrict__ Li, double* __restrict__ Linv_out)
+{
+    const int l = lane & 15;
+    bool failed = false;
+    // Column step j finalises column j of L (lane r holds L[r][j] in a[j]).  The broadcast L[c][j] that
+    // drives the update of column c is also the coefficient of the forward substitution for the inverse
+    // (lane l owns column l of L^-1), so both recurrences share every v_readlane.
+    double a[NB], x[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) { a[c] = A[(p0 + c) * LDC + p0 + l]; x[c] = (l == c) ? 1.0 : 0.0; }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        double d = readlane_d(a[j], j);
+        if (!(d > 0.0)) { failed = true; d = 1.0; }
+        double sq, rs;
+        sqrt_rsqrt(d, sq, rs);
+        a[j] = (l == j) ? sq : a[j] * rs;
+        x[j] = (j >= l) ? x[j] * rs : 0.0;                 // x_j = (delta_jl - sum_{c<j} L[j][c] x_c) / L[j][j]
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) {
+            const double lcj = readlane_d(a[j], c);         // L[c][j], wave-uniform (SGPR pair)
+            // both recurrences consume the broadcast straight from the SGPR pair (one asm block so the compiler
+            // cannot split the two uses and park the value in a VGPR lane in between)
+            asm volatile("v_fma_f64 %0, -%2, %4, %0\n\tv_fma_f64 %1, -%3, %4, %1"
+                         : "+v"(a[c]), "+v"(x[c]) : "v"(a[j]), "v"(x[j]), "s"(lcj));
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep each column's broadcasts next to their uses (else they spill out of the SGPR file)
+    }
+    if (lane < NB) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) A[(p0 + c) * LDC + p0 + l] = (c <= l) ? a[c] : 0.0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { Li[i * NB + l] = x[i]; Linv_out[i * NB + l] = x[i]; }
+    }
+    return failed;
+}
+
+// one 16x16 tile of the in-LDS trailing update: C(ri.., cj..) -= X(ri.., p0..p0+15) X(cj.., p0..p0+15)^T.
+// D[m][n] = C[row ri + n][col cj + m]: the accumulator's lane&15 direction is the LDS-contiguous one.
+__device__ __forceinline__ void lds_update_tile(double* __restrict__ A, int ri, int cj, int p0, int lane)
+{
+    double4_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = A[(cj + (lane >> 4) + 4 * r) * LDC + ri + (lane & 15)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double aop = -A[(p0 + 4 * r + (lane >> 4)) * LDC + cj + (lane & 15)];
+        const double bop = A[(p0 + 4 * r + (lane >> 4)) * LDC + ri + (lane & 15)];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) A[(cj + (lane >> 4) + 4 * r) * LDC + ri + (lane & 15)] = acc[r];
+}
+
+// ---------------------------------------------------------------------------------------------
+// diagonal tile, LDS-resident, blocked by 16.  Per block s: the rows below are solved on the matrix
+// cores with the block inverse (Y = Linv A^T); then wavefront 0 updates only the NEXT diagonal block and
+// factors it while wavefronts 1-3 apply the rest of the trailing update (look-ahead inside the tile).
+// ---------------------------------------------------------------------------------------------
+// Factor the LDS-resident tile A (column-major, pitch LDC) in place; Li = 2 x 256 doubles of LDS scratch.
+__device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __restrict__ Li, double* __restrict__ Linv_k, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    bool failed = false;
+    if (wave == 0) failed = factor_block16(A, 0, lane, Li, Linv_k);
     __syncthreads();
-    for (int j = 0; j < TILE; ++j) {
-        if (tid == 0) {
-            const double d = A[j * LDT + j];
-            if (!(d > 0.0)) fail = 1;
-            A[j * LDT + j] = sqrt(d);
-        }
-        __syncthreads();
-        const double inv = 1.0 / A[j * LDT + j];
-        for (int r = j + 1 + tid; r < TILE; r += 256) A[r * LDT + j] *= inv;
-        __syncthreads();
-        // trailing rank-1 update of the lower triangle: (r, c), j < c <= r
-        const int m = TILE - 1 - j;               // trailing order
-        for (int e = tid; e < m * m; e += 256) {
-            const int rr = e / m, cc = e % m;
-            if (cc <= rr) {
-                const int r = j + 1 + rr, c = j + 1 + cc;
-                A[r * LDT + c] -= A[r * LDT + j] * A[c * LDT + j];
-            }
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < TILE * TILE; e += 256) {
-        const int c = e / TILE, r = e % TILE;
-        if (r >= c) T[(size_t)c * ld + r] = A[r * LDT + c];
-    }
-    for (int e = tid; e < TILE * TILE; e += 256) {
-        const int r = e / TILE, c = e % TILE;
-        Ld[e] = A[r * LDT + c];
-    }
-    if (tid < TILE) inv_diag[tid] = 1.0 / A[tid * LDT + tid];
-    if (tid == 0 && fail) *ok = 0.0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// panel solve X L_kk^T = A, one matrix row per lane (64 rows per workgroup); the row's solution is
-// kept in LDS as xs[j][lane] (conflict-free), L_kk comes through the scalar cache from the
-// read-only copy.  The last workgroup solves the rhs row (y_k) the same way.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
-                                                   const double* __restrict__ Ld, const double* __restrict__ inv_diag)
-{
-    __shared__ double xs[TILE * 64];
-    const int lane = threadIdx.x;
-    const int n_row_blocks = (nt - k - 1) * (TILE / 64);
-    const bool is_rhs = (int)blockIdx.x == n_row_blocks;
-    double* rowbase;       // element j of this lane's row lives at rowbase[j * stride]
-    size_t stride;
-    bool active = true;
-    if (!is_rhs) {
-        const int row = (k + 1) * TILE + blockIdx.x * 64 + lane;
-        rowbase = S + (size_t)(k * TILE) * ld + row;
-        stride = (size_t)ld;
-    } else {
-        rowbase = y + (size_t)k * TILE;
-        stride = 1;
-        active = lane == 0;
-    }
-    for (int j = 0; j < TILE; ++j) {
-        double a = active ? rowbase[(size_t)j * stride] : 0.0;
-        const double* Lj = Ld + (size_t)j * TILE;
-        double acc0 = 0, acc1 = 0;
-        int c = 0;
-        for (; c + 1 < j; c += 2) {
-            acc0 += xs[c * 64 + lane] * Lj[c];
-            acc1 += xs[(c + 1) * 64 + lane] * Lj[c + 1];
-        }
-        if (c < j) acc0 += xs[c * 64 + lane] * Lj[c];
-        const double x = (a - (acc0 + acc1)) * inv_diag[j];
-        xs[j * 64 + lane] = x;
-        if (active) rowbase[(size_t)j * stride] = x;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// trailing update on the f64 matrix cores.  One workgroup = one 128x128 tile of the lower triangle,
-// 4 wavefronts as 2x2, each owning 64x64 = 4x4 MFMA tiles (128 accumulator VGPRs).  The MFMA "M"
-// index runs over tile COLUMNS and "N" over tile ROWS so that the accumulator's lane&15 direction is
-// the memory-contiguous one and the read-modify-write of S is done in 128-byte row segments.
-// ---------------------------------------------------------------------------------------------
-constexpr int KC = 32;               // panel columns staged per LDS round
-constexpr int LDP = TILE + 16;       // LDS row pitch (doubles): +32 banks between consecutive k rows
-
-__global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt)
-{
-    __shared__ double Ps[2][KC * LDP];   // [0]: panel rows of tile i (N side), [1]: panel rows of tile j (M side)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m = nt - k - 1;
-    const int n_tiles = m * (m + 1) / 2;
-    if ((int)blockIdx.x >= n_tiles) {
-        // rhs row: y_i -= L_ik y_k
-        const int i = k + 1 + (blockIdx.x - n_tiles);
-        double* red = &Ps[0][0];
-        const int r = tid & 127, half = tid >> 7;
-        const double* Lik = S + (size_t)(k * TILE) * ld + (size_t)i * TILE;
-        const double* yk = y + (size_t)k * TILE;
-        double acc = 0;
-        for (int c = half * 64; c < half * 64 + 64; ++c) acc += Lik[(size_t)c * ld + r] * yk[c];
-        red[tid] = acc;
-        __syncthreads();
-        if (tid < 128) y[(size_t)i * TILE + tid] -= red[tid] + red[tid + 128];
-        return;
-    }
-    // linear tile index -> (row tile, col tile) of the trailing lower triangle
-    int t = blockIdx.x;
-    int rt = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((rt + 1) * (rt + 2) / 2 <= t) ++rt;
-    while (rt * (rt + 1) / 2 > t) --rt;
-    const int ct = t - rt * (rt + 1) / 2;
-    const int ti = k + 1 + rt, tj = k + 1 + ct;
-    const double* Pi = S + (size_t)(k * TILE) * ld + (size_t)ti * TILE;   // L_ik : rows of tile i, panel columns
-    const double* Pj = S + (size_t)(k * TILE) * ld + (size_t)tj * TILE;
-
-    const int wn = wave & 1, wm = wave >> 1;     // wave's 64-row (N) / 64-col (M) half
-    double4_t acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){ 0, 0, 0, 0 };
-
-    for (int kc = 0; kc < TILE; kc += KC) {
-        // stage KC panel columns of both tiles: each column is 128 contiguous rows (1 KiB)
-#pragma unroll
-        for (int it = 0; it < (KC * TILE) / (256 * 2); ++it) {
-            const int e = (it * 256 + tid) * 2;
-            const int kk = e / TILE, r = e % TILE;
-            const double2 vi = *reinterpret_cast<const double2*>(Pi + (size_t)(kc + kk) * ld + r);
-            const double2 vj = *reinterpret_cast<const double2*>(Pj + (size_t)(kc + kk) * ld + r);
-            *reinterpret_cast<double2*>(&Ps[0][kk * LDP + r]) = vi;
-            *reinterpret_cast<double2*>(&Ps[1][kk * LDP + r]) = vj;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k4 = 0; k4 < KC; k4 += 4) {
-            const int kk = k4 + (lane >> 4);
-            double bn[4], am[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                bn[q] = Ps[0][kk * LDP + wn * 64 + q * 16 + (lane & 15)];   // B[k][n] : row n of tile i
-                am[q] = Ps[1][kk * LDP + wm * 64 + q * 16 + (lane & 15)];   // A[m][k] : row m of tile j
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[a], bn[b], acc[a][b], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    // D[m][n]: n = lane & 15 (matrix row, contiguous), m = (lane >> 4) + 4 * reg (matrix column)
-    double* C = S + (size_t)(tj * TILE) * ld + (size_t)ti * TILE;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
+    for (int s = 0; s < NBLK - 1; ++s) {
+        const int p0 = s * NB;
+        const double* Lc = Li + (s & 1) * NB * NB;
+        // rows below block s:  Y = Linv * A^T per 16-row strip; Y[m][n] = X[row r0 + n][col p0 + m]
+        const int nstrips = NBLK - 1 - s;
+        for (int t = wave; t < nstrips; t += 4) {
+            const int r0 = p0 + NB + t * NB;
+            double4_t acc = { 0, 0, 0, 0 };
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int col = wm * 64 + a * 16 + (lane >> 4) + 4 * r;
-                const int row = wn * 64 + b * 16 + (lane & 15);
-                C[(size_t)col * ld + row] -= acc[a][b][r];
+                const double aop = Lc[(lane & 15) * NB + 4 * r + (lane >> 4)];
+                const double bop = A[(p0 + 4 * r + (lane >> 4)) * LDC + r0 + (lane & 15)];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
             }
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): all operand reads of this strip are done before it is overwritten
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(p0 + (lane >> 4) + 4 * r) * LDC + r0 + (lane & 15)] = acc[r];
+        }
+        __syncthreads();
+        // trailing update; tile 0 is the next diagonal block: wave 0 takes it and goes on to factor it
+        const int ntr = nstrips * (nstrips + 1) / 2;
+        if (wave == 0) {
+            lds_update_tile(A, p0 + NB, p0 + NB, p0, lane);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            failed |= factor_block16(A, p0 + NB, lane, Li + ((s + 1) & 1) * NB * NB, Linv_k + (s + 1) * NB * NB);
+        } else {
+            for (int t = wave; t < ntr; t += 3) {
+                int ti = 0;
+                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+                const int tj = t - ti * (ti + 1) / 2;
+                lds_update_tile(A, p0 + NB + ti * NB, p0 + NB + tj * NB, p0, lane);
+            }
+        }
+        __syncthreads();
+    }
+    return failed;
+}
+
+// LDS tile -> global (the block row of the diagonal and everything below it; the strict upper part of S is never read)
+__device__ __forceinline__ void store_tile_lower(double* __restrict__ T, const double* __restrict__ A, int ld, int tid)
+{
+#pragma unroll 4
+    for (int b0 = 0; b0 < (TILE * TILE / 2) / 256; ++b0) {
+        const int e = (b0 * 256 + tid) * 2;
+        const int c = e / TILE, r = e % TILE;
+        if (r + 1 >= c) *reinterpret_cast<double2*>(T + (size_t)c * ld + r) = *reinterpret_cast<const double2*>(A + c * LDC + r);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward substitution, tile column k: every workgroup solves x_k = L_kk^-T y_k with one wavefront
-// (two unknowns per lane, broadcasts through readlane, no barriers), then workgroup j < k applies
-// y_j -= L_kj^T x_k; workgroup k stores x_k.
+// diagonal tile, LDS-resident, blocked by 16.  Per block s: the rows below are solved on the matrix
+// cores with the block inverse (Y = Linv A^T); then wavefront 0 updates only the NEXT diagonal block and
+// factors it while wavefronts 1-3 apply the rest of the trailing update (look-ahead inside the tile).
+// Stand-alone form (first tile); later tiles are factored inside k_syrk_update (see there).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int ld, int k, double* __restrict__ Linv_k,
+                                                    double* __restrict__ ok)
+{
+    extern __shared__ double sm[];
+    double* A = sm;                       // column-major: A[c * LDC + r]
+    double* Li = sm + TILE * LDC;         // 2 x (16 x 16): inverse of the current / next diagonal block
+    const int tid = threadIdx.x;
+    double* T = S + (size_t)(k * TILE) * ld + (size_t)k * TILE;
+    load_tile<LDC>(A, T, ld, tid);
+    __syncthreads();
+    const bool failed = potrf_tile_lds(A, Li, Linv_k, tid);
+    store_tile_lower(T, A, ld, tid);
+    if (tid == 0 && failed) *ok = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// panel solve  X L_kk^T = A  on the matrix cores.  One wavefront (= one workgroup) per 16-row strip,
+// working on Y = X^T block by block:  Y_c = Linv_cc (A_c^T - sum_{j<c} L_cj Y_j).  L_kk and the block
+// inverses are read straight from global memory (L2-resident, 128-byte segments in operand shape);
+// Y stays in registers (result -> B operand identity).  No LDS, no barriers.  The last workgroup
+// solves the rhs row y_k with the same code (a strip with one live row).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
+                                                   const double* __restrict__ Linv_k)
+{
+    const int lane = threadIdx.x;
+    const int n_strips = (nt - k - 1) * NBLK;
+    const bool is_rhs = (int)blockIdx.x == n_strips;
+    double* base;          // element (n = strip row, col) lives at base[col * cstride]; for the rhs strip only n == 0 exists
+    size_t cstride;
+    bool live;
+    if (!is_rhs) {
+        base = S + (size_t)(k * TILE) * ld + (size_t)(k + 1) * TILE + blockIdx.x * NB + (lane & 15);
+        cstride = (size_t)ld;
+        live = true;
+    } else {
+        base = y + (size_t)k * TILE;
+        cstride = 1;
+        live = (lane & 15) == 0;
+    }
+    double4_t Acc[NBLK];
+#pragma unroll
+    for (int c = 0; c < NBLK; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Acc[c][r] = live ? base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] : 0.0;
+    // operand (row = 16c + (lane&15), col = 16j + 4r + (lane>>4)) of L_kk
+    const double* Lop = S + (size_t)(k * TILE + (lane >> 4)) * ld + (size_t)k * TILE + (lane & 15);
+    const double* Lio = Linv_k + (lane & 15) * NB + (lane >> 4);
+    // every operand is known up front: issue all loads, then run the MFMA chain
+    double lop[NBLK][NBLK][4], lio[NBLK][4];
+#pragma unroll
+    for (int c = 0; c < NBLK; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lio[c][r] = Lio[c * NB * NB + 4 * r];
+#pragma unroll
+        for (int j = 0; j < c; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lop[c][j][r] = -Lop[(size_t)(j * NB + 4 * r) * ld + c * NB];
+    }
+    double4_t Y[NBLK];
+#pragma unroll
+    for (int c = 0; c < NBLK; ++c) {
+        double4_t acc = Acc[c];
+#pragma unroll
+        for (int j = 0; j < c; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lop[c][j][r], Y[j][r], acc, 0, 0, 0);
+        double4_t yc = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yc = __builtin_amdgcn_mfma_f64_16x16x4f64(lio[c][r], acc[r], yc, 0, 0, 0);
+        Y[c] = yc;
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] = yc[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// trailing update.  One workgroup = one 128x128 tile of the lower triangle, 4 wavefronts as 2x2,
+// each owning 64x64 = 4x4 MFMA tiles (128 accumulator registers).  Operands go straight from
+// global memory to registers in MFMA fragment shape (16 consecutive rows x 4 panel columns per load:
+// four 128-byte segments), prefetched one 32-column chunk ahead; no LDS, no barriers, every
+// wavefront independent.  The MFMA "M" index runs over tile COLUMNS and "N" over tile ROWS so the
+// accumulator's lane&15 direction is the memory-contiguous one; the accumulators are initialised
+// with the C tile and the panel enters negated, so the epilogue is a plain store.
+// ---------------------------------------------------------------------------------------------
+// WAVES = 4, SUB = 4: one workgroup per 128x128 tile, 64x64 per wavefront (bulk of the update).
+// WAVES = 1, SUB = 2: one single-wave workgroup per 32x32 sub-block (16 per tile), whole K range loaded
+// up front -- used for the look-ahead update of the next panel's block column, where only a few tiles
+// exist and latency matters more than operand sharing.
+// Tiles covered: single_col ? {(i, j0) : j0 <= i < nt} : {(i, j) : j0 <= j <= i < nt}.  Extra blocks at the
+// end of the grid apply the rhs update y_i -= L_ik y_k for i = k+1 ..
+template <int WAVES, int SUB, int KSTEPS>
+__global__ __launch_bounds__(WAVES * 64) void k_syrk_update(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
+                                                            int j0, int single_col, double* __restrict__ Linv_next, double* __restrict__ ok)
+{
+    // Linv_next != nullptr (WAVES == 4 only): workgroup 0 owns tile (j0, j0) -- the NEXT diagonal tile.  It keeps
+    // the updated tile on chip (registers -> LDS) and factors it right there, so the next panel's sequential
+    // diagonal factorisation overlaps with the other workgroups' share of this update instead of following it.
+    extern __shared__ double sm[];
+    constexpr int SPAN = SUB * 16;                                        // rows / cols per wavefront
+    constexpr int PER_TILE = (WAVES == 4) ? 1 : (TILE / SPAN) * (TILE / SPAN);   // workgroups per tile
+    static_assert(WAVES == 1 || (WAVES == 4 && SUB == 4), "unsupported decomposition");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int mt = nt - j0;
+    const int n_tiles = single_col ? mt : mt * (mt + 1) / 2;
+    const int n_blocks = n_tiles * PER_TILE;
+    if ((int)blockIdx.x >= n_blocks) {
+        // rhs row: y_i -= L_ik y_k
+        const int i = k + 1 + (blockIdx.x - n_blocks);
+        if (i >= nt) return;
+        const double* Lik = S + (size_t)(k * TILE) * ld + (size_t)i * TILE;
+        const double* yk = y + (size_t)k * TILE;
+        for (int r = tid; r < TILE; r += WAVES * 64) {
+            double acc = 0;
+#pragma unroll 8
+            for (int c = 0; c < TILE; ++c) acc = __builtin_fma(Lik[(size_t)c * ld + r], yk[c], acc);
+            y[(size_t)i * TILE + r] -= acc;
+        }
+        return;
+    }
+    const int t = blockIdx.x / PER_TILE;
+    const int sub = (WAVES == 4) ? (tid >> 6) : (blockIdx.x % PER_TILE);
+    int rt, ct;
+    if (single_col) { rt = t; ct = 0; }
+    else {
+        rt = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((rt + 1) * (rt + 2) / 2 <= t) ++rt;
+        while (rt * (rt + 1) / 2 > t) --rt;
+        ct = t - rt * (rt + 1) / 2;
+    }
+    const int ti = j0 + rt, tj = j0 + ct;
+    constexpr int PER_DIM = TILE / SPAN;
+    const int wn = sub % PER_DIM, wm = sub / PER_DIM;
+    // per-lane operand bases: element (panel column kk, row) at P[kk * ld + row]
+    const double* Pn = S + (size_t)(k * TILE + (lane >> 4)) * ld + (size_t)ti * TILE + wn * SPAN + (lane & 15);
+    const double* Pm = S + (size_t)(k * TILE + (lane >> 4)) * ld + (size_t)tj * TILE + wm * SPAN + (lane & 15);
+    double* C = S + (size_t)(tj * TILE + wm * SPAN + (lane >> 4)) * ld + (size_t)ti * TILE + wn * SPAN + (lane & 15);
+
+    constexpr int NCH = TILE / (4 * KSTEPS);
+    constexpr int NBUF = NCH > 1 ? 2 : 1;
+    double av[NBUF][KSTEPS][SUB], bv[NBUF][KSTEPS][SUB];
+    auto load_chunk = [&](int buf, int kc) {
+#pragma unroll
+        for (int s4 = 0; s4 < KSTEPS; ++s4) {
+            const size_t off = (size_t)(kc + s4 * 4) * ld;
+#pragma unroll
+            for (int q = 0; q < SUB; ++q) {
+                av[buf][s4][q] = Pm[off + q * 16];
+                bv[buf][s4][q] = Pn[off + q * 16];
+            }
+        }
+    };
+    load_chunk(0, 0);
+    double4_t acc[SUB][SUB], cv[SUB][SUB];
+#pragma unroll
+    for (int a = 0; a < SUB; ++a)
+#pragma unroll
+        for (int b = 0; b < SUB; ++b) acc[a][b] = (double4_t){ 0, 0, 0, 0 };
+
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int buf = ch % NBUF;
+        if (ch + 1 < NCH) load_chunk((ch + 1) % NBUF, (ch + 1) * 4 * KSTEPS);
+        else {
+            // last chunk: the C tile streams in behind the final MFMAs instead of in front of the first ones
+#pragma unroll
+            for (int a = 0; a < SUB; ++a)
+#pragma unroll
+                for (int b = 0; b < SUB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cv[a][b][r] = C[(size_t)(a * 16 + 4 * r) * ld + b * 16];
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < KSTEPS; ++s4)
+#pragma unroll
+            for (int a = 0; a < SUB; ++a)
+#pragma unroll
+                for (int b = 0; b < SUB; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[buf][s4][a], bv[buf][s4][b], acc[a][b], 0, 0, 0);
+    }
+    if (WAVES == 4 && Linv_next != nullptr && blockIdx.x == 0) {
+        double* A = sm;
+        double* Li = sm + TILE * LDC;
+#pragma unroll
+        for (int a = 0; a < SUB; ++a)
+#pragma unroll
+            for (int b = 0; b < SUB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    A[(wm * SPAN + a * 16 + (lane >> 4) + 4 * r) * LDC + wn * SPAN + b * 16 + (lane & 15)] = cv[a][b][r] + acc[a][b][r];
+        __syncthreads();
+        const bool failed = potrf_tile_lds(A, Li, Linv_next, tid);
+        store_tile_lower(S + (size_t)(tj * TILE) * ld + (size_t)ti * TILE, A, ld, tid);
+        if (tid == 0 && failed) *ok = 0.0;
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < SUB; ++a)
+#pragma unroll
+        for (int b = 0; b < SUB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = cv[a][b][r] + acc[a][b][r];
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward substitution, tile column k.  Every workgroup first solves x_k = L_kk^-T y_k (blocked by 16
+// with the stored block inverses), then workgroup j < k applies y_j -= L_kj^T x_k; workgroup k stores x_k.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bsolve_step(const double* __restrict__ S, double* __restrict__ y, double* __restrict__ x,
-                                                     int ld, int k)
+                                                     int ld, int k, const double* __restrict__ Linv_k)
 {
-    extern __shared__ double T[];     // TILE x LDT
-    __shared__ double xk[TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double* Lkk = S + (size_t)(k * TILE) * ld + (size_t)k * TILE;
-    for (int e = tid; e < TILE * TILE; e += 256) {
-        const int c = e / TILE, r = e % TILE;
-        T[r * LDT + c] = (r >= c) ? Lkk[(size_t)c * ld + r] : 0.0;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        double y0 = y[(size_t)k * TILE + lane], y1 = y[(size_t)k * TILE + 64 + lane];
-        for (int c = TILE - 1; c >= 0; --c) {
-            // x_c = y_c / L[c][c] ; y_j -= L[c][j] x_c for j < c
-            const double yc = __shfl(c < 64 ? y0 : y1, c & 63, 64);
-            const double xc = yc / T[c * LDT + c];
-            if (lane == (c & 63)) { if (c < 64) y0 = xc; else y1 = xc; }
-            if (lane < c) y0 -= T[c * LDT + lane] * xc;
-            if (lane + 64 < c) y1 -= T[c * LDT + 64 + lane] * xc;
-        }
-        xk[lane] = y0; xk[64 + lane] = y1;
-    }
-    __syncthreads();
+    extern __shared__ double sm[];
+    constexpr int LDB = TILE + 2;          // column pitch: column walks (thread = column) spread over 16 banks
+    double* T = sm;                        // column-major tile
+    __shared__ double Li[NBLK * NB * NB];
+    __shared__ double ys[TILE], xk[TILE], red[256];
+    const int tid = threadIdx.x;
     const int j = blockIdx.x;
+    load_tile<LDB>(T, S + (size_t)(k * TILE) * ld + (size_t)k * TILE, ld, tid);
+    for (int e = tid; e < NBLK * NB * NB; e += 256) Li[e] = Linv_k[e];
+    if (tid < TILE) ys[tid] = y[(size_t)k * TILE + tid];
+    __syncthreads();
+    for (int c = NBLK - 1; c >= 0; --c) {
+        if (tid < NB) {                    // x_c = Linv_cc^T ys_c
+            double acc = 0;
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc = __builtin_fma(Li[c * NB * NB + n * NB + tid], ys[c * NB + n], acc);
+            xk[c * NB + tid] = acc;
+        }
+        __syncthreads();
+        if (tid < c * NB) {                // ys[q] -= sum_n L[16c + n][q] x_c[n]   for q < 16 c
+            double acc = ys[tid];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc = __builtin_fma(-T[tid * LDB + c * NB + n], xk[c * NB + n], acc);
+            ys[tid] = acc;
+        }
+        __syncthreads();
+    }
     if (j == k) {
         if (tid < TILE) x[(size_t)k * TILE + tid] = xk[tid];
         return;
     }
     // y_j[c] -= sum_r L(k-block row r, j-block col c) * x_k[r]
-    const double* Lkj = S + (size_t)(j * TILE) * ld + (size_t)k * TILE;
-    __syncthreads();
-    for (int e = tid; e < TILE * TILE; e += 256) {
-        const int c = e / TILE, r = e % TILE;
-        T[r * LDT + c] = Lkj[(size_t)c * ld + r];
-    }
+    load_tile<LDB>(T, S + (size_t)(j * TILE) * ld + (size_t)k * TILE, ld, tid);
     __syncthreads();
     {
-        const int c = tid & 127, half = tid >> 7;
+        const int c = tid >> 1, half = tid & 1;
         double acc = 0;
-        for (int r = half * 64; r < half * 64 + 64; ++r) acc += T[r * LDT + c] * xk[r];
+#pragma unroll 8
+        for (int r = half * 64; r < half * 64 + 64; ++r) acc = __builtin_fma(T[c * LDB + r], xk[r], acc);
+        red[tid] = acc;
         __syncthreads();
-        T[tid] = acc;
-        __syncthreads();
-        if (tid < 128) y[(size_t)j * TILE + tid] -= T[tid] + T[tid + 128];
+        if (tid < 128) y[(size_t)j * TILE + tid] -= red[2 * tid] + red[2 * tid + 1];
     }
 }
 
@@ -264,26 +461,35 @@ __global__ void k_set_scalar(double* p, double v) { *p = v; }
 
 }  // namespace
 
+size_t chol_workspace_doubles(int n_pad) { return (size_t)(n_pad / TILE) * NBLK * NB * NB; }
+
+// Right-looking factorisation.  Step k = one k_trsm_panel launch + one k_syrk_update launch; the diagonal
+// factorisation of step k+1 is done by workgroup 0 of step k's update (tile (k+1, k+1) is the first tile of
+// the grid), which hides most of the sequential diagonal work behind the bulk of the update.
 void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWorkspace& ws, double* ok, hipStream_t st)
 {
     const int nt = n_pad / TILE;
-    const size_t lds_tile = (size_t)TILE * LDT * sizeof(double);
+    const size_t lds_diag = ((size_t)TILE * LDC + 2 * NB * NB) * sizeof(double);
+    const size_t lds_panel = (size_t)TILE * (TILE + 2) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bsolve_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update<4, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bsolve_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_panel);
         attr_set = true;
     }
+    const size_t linv_stride = (size_t)NBLK * NB * NB;
     hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, st, ok, 1.0);
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), lds_diag, st, S, n_pad, 0, ws.Linv, ok);
     for (int k = 0; k < nt; ++k) {
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), lds_tile, st, S, n_pad, k, ws.Ld, ws.inv_diag, ok);
-        const int n_row_blocks = (nt - k - 1) * (TILE / 64);
-        hipLaunchKernelGGL(k_trsm_panel, dim3(n_row_blocks + 1), dim3(64), 0, st, S, y, n_pad, k, nt, ws.Ld, ws.inv_diag);
-        const int m = nt - k - 1;
-        if (m > 0) hipLaunchKernelGGL(k_syrk_update, dim3(m * (m + 1) / 2 + m), dim3(256), 0, st, S, y, n_pad, k, nt);
+        const int m = nt - k - 1;             // tile rows below panel k
+        hipLaunchKernelGGL(k_trsm_panel, dim3(m * NBLK + 1), dim3(64), 0, st, S, y, n_pad, k, nt, ws.Linv + (size_t)k * linv_stride);
+        if (m > 0)
+            hipLaunchKernelGGL((k_syrk_update<4, 4, 8>), dim3(m * (m + 1) / 2 + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt, k + 1, 0,
+                               ws.Linv + (size_t)(k + 1) * linv_stride, ok);
     }
     for (int k = nt - 1; k >= 0; --k)
-        hipLaunchKernelGGL(k_bsolve_step, dim3(k + 1), dim3(256), lds_tile, st, S, y, x, n_pad, k);
+        hipLaunchKernelGGL(k_bsolve_step, dim3(k + 1), dim3(256), lds_panel, st, S, y, x, n_pad, k, ws.Linv + (size_t)k * linv_stride);
 }
 
 }  // namespace mage
