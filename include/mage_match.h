@@ -1,0 +1,67 @@
+/*
+ * mage_match.h -- C ABI of the MI355X brute-force Hamming matcher (libmageslam_hip.so).
+ *
+ * Drop-in boundary for the reference's free functions:
+ *     Core/MAGESLAM/Source/Tracking/FeatureMatcher.h:100-109 / FeatureMatcher.cpp:61-190   Match
+ *     Core/MAGESLAM/Source/Tracking/FeatureMatcher.cpp:448-504                            GetDescriptorDistance
+ * Match = two-way radius match (cv::BFMatcher NORM_HAMMING, distance <= maxHammingDist), reject a query when
+ * second-best minus best < minHammingDifference, keep mutual best pairs, emit cv::DMatch in ascending query order.
+ * Masks are applied by gathering (FeatureMatcher.cpp:88-110) and indices are mapped back (:160-163); both are
+ * done by mage_match_masked below so a caller can pass its std::vector<bool>-derived byte masks directly.
+ * IndexedMatch / RadiusMatch (FeatureMatcher.cpp:192-446) are the "next" rows of SURVEY.md 8f and are not built.
+ */
+#ifndef MAGE_MATCH_H
+#define MAGE_MATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mage_ba.h"   /* mage_status */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cv::DMatch */
+typedef struct mage_dmatch {
+    int   queryIdx, trainIdx, imgIdx;   /* imgIdx = -1 */
+    float distance;
+} mage_dmatch;
+
+/* GetDescriptorDistance on two 32-byte descriptors in host memory (host-side helper: one pair is not GPU work). */
+int mage_hamming256(const uint8_t* d0, const uint8_t* d1);
+
+typedef struct mage_matcher mage_matcher;
+mage_status mage_matcher_create(int device, mage_matcher** out);
+void        mage_matcher_destroy(mage_matcher* h);
+
+/* Match on two gathered descriptor sets (host memory, nA x 32 and nB x 32 bytes).  Indices in the result refer
+ * to the given sets.  Up to `capacity` matches are written; *count is the full number found. */
+mage_status mage_match_bf(mage_matcher* h, const uint8_t* descA, int nA, const uint8_t* descB, int nB, int max_hamming_dist,
+                          int min_hamming_difference, mage_dmatch* out, int capacity, int* count);
+
+/* The reference's full signature: descriptor sets + byte masks (non-zero = use); result indices are the ORIGINAL
+ * indices into descA / descB.  maskA / maskB may be NULL (= all). */
+mage_status mage_match_masked(mage_matcher* h, const uint8_t* descA, int nDescA, const uint8_t* maskA, const uint8_t* descB,
+                              int nDescB, const uint8_t* maskB, int max_hamming_dist, int min_hamming_difference,
+                              mage_dmatch* out, int capacity, int* count);
+
+/* Batched over independent pairs.  Pair p matches set A_p (countsA[p] descriptors at descA + p * capA * 32) against
+ * B_p likewise; results go to out + p * cap_out, counts[p].  Host pointers. */
+mage_status mage_match_bf_batch(mage_matcher* h, int n_pairs, const uint8_t* descA, const int* countsA, int capA,
+                                const uint8_t* descB, const int* countsB, int capB, int max_hamming_dist,
+                                int min_hamming_difference, mage_dmatch* out, int cap_out, int* counts);
+
+/* Same with every buffer already in the handle's HBM (e.g. straight from mage_orb_detect_batch_device);
+ * out / counts are device pointers owned by the handle, valid until its next call. */
+mage_status mage_match_bf_batch_device(mage_matcher* h, int n_pairs, const uint8_t* descA_dev, const int* countsA_dev, int capA,
+                                       const uint8_t* descB_dev, const int* countsB_dev, int capB, int max_hamming_dist,
+                                       int min_hamming_difference, int cap_out, const mage_dmatch** out_dev, const int** counts_dev);
+
+/* HIP-event time of the most recent batched call's kernel, in milliseconds. */
+mage_status mage_matcher_last_kernel_ms(const mage_matcher* h, double* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGE_MATCH_H */

@@ -1,0 +1,97 @@
+/*
+ * mage_orb.h -- C ABI of the MI355X ORB front-end (libmageslam_hip.so).
+ *
+ * Drop-in boundary for the reference's detector:
+ *     Core/MAGESLAM/Source/Image/OpenCVModified.h:64-173   class OrbDetector (ctor :68-82, DetectAndCompute :85-88)
+ *     Core/MAGESLAM/Source/Image/OpenCVModified.cpp:771-886 DetectAndCompute  (FAST-9/16 + 3x3 NMS, border cull,
+ *                                                           RetainBestFeatures, ANMS, GaussianBlur, BRIEF-256)
+ *     Core/MAGESLAM/Source/Image/OrbFeatureDetector.cpp:84-100 Process (the caller; undistortion stays host-side)
+ * Output records are bit-compatible with cv::KeyPoint (28 bytes) and mage::ORBDescriptor (32 bytes,
+ * Image/ORBDescriptor.h:12-23), written into caller-owned fixed-capacity buffers exactly as
+ * ImageData::Insert does (Image/ImageData.h:65-70: truncation to the capacity).
+ *
+ * Where the reference's result is implementation-defined (std::nth_element order) the order is pinned:
+ * keypoints that survive without suppression stay in raster order; after ANMS they are ordered by
+ * (suppression radius desc, response desc, raster index asc).  See DESIGN.md section 6.
+ */
+#ifndef MAGE_ORB_H
+#define MAGE_ORB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mage_ba.h"   /* mage_status, mage_last_error */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cv::KeyPoint */
+typedef struct mage_keypoint {
+    float x, y;        /* pt */
+    float size;        /* patchSize * layerScale */
+    float angle;       /* 0 when UseOrientation is off */
+    float response;    /* FAST score */
+    int   octave;
+    int   class_id;    /* -1 */
+} mage_keypoint;
+
+/* OrbDetector ctor arguments (OpenCVModified.h:68-82) = FeatureExtractorSettings (MageSettings.h:151-167) + device. */
+typedef struct mage_orb_params {
+    unsigned gaussian_kernel_size;   /* 7 */
+    unsigned nfeatures;              /* 440 */
+    float    scale_factor;           /* 1.5 (unused with one level) */
+    unsigned nlevels;                /* 1; > 1 -> MAGE_ERR_UNSUPPORTED (cv::resize pyramid) */
+    unsigned patch_size;             /* 15 or 31 (pre-rotated tables); others -> MAGE_ERR_UNSUPPORTED */
+    unsigned fast_threshold;         /* 4 */
+    int      use_orientation;        /* 0; 1 -> MAGE_ERR_UNSUPPORTED (ICAngles / fastAtan2) */
+    float    feature_factor_anms;    /* 1.5 */
+    float    feature_strength_anms;  /* 0.9 */
+    int      strong_response_anms;   /* 20 */
+    float    min_robust_factor;      /* 1.1 */
+    float    max_robust_factor;      /* 2.0 */
+    int      num_cells_x, num_cells_y; /* 32, 32 */
+    int      device;                 /* HIP ordinal, -1 = current */
+} mage_orb_params;
+
+typedef struct mage_orb mage_orb;
+
+mage_status mage_orb_default_params(mage_orb_params* p);
+mage_status mage_orb_create(const mage_orb_params* params, mage_orb** out);
+void        mage_orb_destroy(mage_orb* h);
+
+/* OrbDetector::DetectAndCompute on one CV_8UC1 image held in HOST memory (row pitch `stride` bytes).
+ * Writes up to `capacity` keypoints / 32-byte descriptors; *count receives the number written. */
+mage_status mage_orb_detect(mage_orb* h, const uint8_t* image, int width, int height, int stride,
+                            mage_keypoint* keypoints, uint8_t* descriptors32, int capacity, int* count);
+
+/* Batched form: n_frames images of identical size.  `images` may be a host pointer (images_on_device = 0) or a
+ * device pointer in the handle's HBM (images_on_device = 1), frames packed with pitch `stride` and
+ * `frame_stride` bytes between frames.  Outputs are host buffers of n_frames x capacity records;
+ * counts[n_frames].  Every frame is processed independently (stereo pairs, frame queues). */
+mage_status mage_orb_detect_batch(mage_orb* h, const uint8_t* images, int images_on_device, int n_frames, int width, int height,
+                                  int stride, size_t frame_stride, mage_keypoint* keypoints, uint8_t* descriptors32,
+                                  int capacity, int* counts);
+
+/* Same, but the results stay in HBM: pointers are device pointers owned by the handle, valid until the next
+ * call on the handle (keypoints: n_frames x capacity mage_keypoint; descriptors: n_frames x capacity x 32;
+ * counts: n_frames int).  Used to chain into mage_match_bf_batch_device without a host round trip. */
+mage_status mage_orb_detect_batch_device(mage_orb* h, const uint8_t* images_device, int n_frames, int width, int height,
+                                         int stride, size_t frame_stride, int capacity, const mage_keypoint** keypoints_device,
+                                         const uint8_t** descriptors_device, const int** counts_device);
+
+/* Stage outputs of the most recent single-frame / first frame of a batch, for parity tests:
+ * FAST score map (width x height u8) and blurred image (width x height u8). */
+mage_status mage_orb_debug_read(mage_orb* h, uint8_t* score_map, uint8_t* blurred);
+
+/* Per-stage HIP-event timings of the most recent batch call (milliseconds). */
+typedef struct mage_orb_profile {
+    double fast_ms, select_ms, blur_ms, brief_ms, total_ms;
+    int    n_frames;
+} mage_orb_profile;
+mage_status mage_orb_get_profile(const mage_orb* h, mage_orb_profile* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGE_ORB_H */

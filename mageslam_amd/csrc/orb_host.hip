@@ -1,0 +1,431 @@
+// orb_host.hip -- host side of the ORB front-end and the Hamming matcher: the mage_orb_* / mage_match_* C ABI.
+//
+// Mirrors OrbDetector::DetectAndCompute (Core/MAGESLAM/Source/Image/OpenCVModified.cpp:771-886) as a fixed
+// sequence of kernel launches per batch of frames: FAST score map -> NMS + raster compaction -> selection
+// (RetainBestFeatures + ANMS) -> Gaussian blur -> BRIEF; and Match (Tracking/FeatureMatcher.cpp:61-190) as one
+// launch per batch of pairs.  The host computes nothing but the blur taps and the rotated sampling pattern.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <vector>
+
+#include "../../include/mage_brief_patterns.h"
+#include "mage_common.h"
+#include "orb_kernels.h"
+
+using namespace mage;
+
+namespace {
+
+template <typename F>
+mage_status guarded(F&& f)
+{
+    try { return f(); }
+    catch (const std::bad_alloc&) { return fail(MAGE_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    catch (const std::exception& e) { return fail(MAGE_ERR_DEVICE, "unexpected exception: %s", e.what()); }
+    catch (...) { return fail(MAGE_ERR_DEVICE, "unexpected exception"); }
+}
+
+// cvRound(256 * getGaussianKernel(k, 2, CV_32F)[i]) -- OpenCV 3.4.0's 8-bit separable path
+OrbTaps gaussian_taps(unsigned ksize)
+{
+    OrbTaps t{};
+    if (ksize <= 1) { t.radius = 0; t.t[0] = 256; return t; }
+    float cf[15];
+    double sum = 0;
+    const double sigma = 2.0, scale2X = -0.5 / (sigma * sigma);
+    for (unsigned i = 0; i < ksize; ++i) {
+        const double x = i - (ksize - 1) * 0.5;
+        cf[i] = (float)std::exp(scale2X * x * x);
+        sum += cf[i];
+    }
+    sum = 1.0 / sum;
+    for (unsigned i = 0; i < ksize; ++i) { cf[i] = (float)(cf[i] * sum); t.t[i] = (int)std::nearbyint((double)cf[i] * 256.0); }
+    t.radius = (int)ksize / 2;
+    return t;
+}
+
+// rotation rows of the pre-rotated sampling pattern (include/mage_brief_patterns.h explains the rule)
+void expand_pattern(unsigned patch, std::vector<signed char>& out)
+{
+    const signed char* base = patch == 31 ? MAGE_BRIEF_BASE_31 : MAGE_BRIEF_BASE_15;
+    out.resize(MAGE_BRIEF_ROTATIONS * 1024);
+    const double pi = 3.14159265358979323846;
+    for (int k = 0; k < MAGE_BRIEF_ROTATIONS; ++k) {
+        const double a = k * 12.0 * pi / 180.0, c = std::cos(a), s = std::sin(a);
+        for (int p = 0; p < 512; ++p) {
+            const double bx = base[p * 2], by = base[p * 2 + 1];
+            double v[2] = { bx * c - by * s, bx * s + by * c };
+            for (int q = 0; q < 2; ++q) {
+                const double hh = std::nearbyint(v[q] * 2.0) / 2.0;
+                if (std::fabs(v[q] - hh) < 1e-9) v[q] = hh;
+                out[k * 1024 + p * 2 + q] = (signed char)std::nearbyint(v[q]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+struct mage_orb {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mage_orb_params P{};
+    OrbTaps taps{};
+    DevBuf<signed char> d_pattern;
+    DevBuf<uint8_t> d_img, d_score, d_blur, d_desc;
+    DevBuf<int> d_wg_count, d_wg_off, d_hist, d_n_raw, d_cell_start, d_cell_fill, d_cell_members, d_radius, d_count;
+    DevBuf<int2> d_raw, d_cand;
+    DevBuf<mage_keypoint> d_kp;
+    hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    mage_orb_profile prof{};
+    int last_w = 0, last_h = 0;
+    ~mage_orb()
+    {
+        (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+MAGE_EXPORT mage_status mage_orb_default_params(mage_orb_params* p)
+{
+    if (!p) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+    // FeatureExtractorSettings defaults, Core/MAGESLAM/Source/MageSettings.h:151-167
+    *p = mage_orb_params{ 7, 440, 1.5f, 1, 15, 4, 0, 1.5f, 0.9f, 20, 1.1f, 2.0f, 32, 32, -1 };
+    return MAGE_OK;
+}
+
+MAGE_EXPORT mage_status mage_orb_create(const mage_orb_params* params, mage_orb** out)
+{
+    return guarded([&]() -> mage_status {
+        if (!out || !params) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        *out = nullptr;
+        const mage_orb_params& p = *params;
+        if (p.nlevels != 1) return fail(MAGE_ERR_UNSUPPORTED, "NumLevels = %u: the cv::resize pyramid is not built yet (SURVEY.md 8f rank 4)", p.nlevels);
+        if (p.use_orientation) return fail(MAGE_ERR_UNSUPPORTED, "UseOrientation: ICAngles/fastAtan2 are not built yet (SURVEY.md 8f rank 4)");
+        if (p.patch_size != 15 && p.patch_size != 31) return fail(MAGE_ERR_UNSUPPORTED, "patch size %u: only the pre-rotated 15 / 31 tables are built", p.patch_size);
+        if (p.gaussian_kernel_size > 15 || (p.gaussian_kernel_size > 1 && p.gaussian_kernel_size % 2 == 0))
+            return fail(MAGE_ERR_INVALID_ARGUMENT, "Gaussian kernel size must be odd and <= 15");
+        if (p.nfeatures < 2 || p.num_cells_x < 1 || p.num_cells_y < 1 || p.fast_threshold < 1)
+            return fail(MAGE_ERR_INVALID_ARGUMENT, "nfeatures >= 2, cells >= 1 and FAST threshold >= 1 are required (asserts at OpenCVModified.cpp:177-178, :582)");
+        int dev = 0;
+        MAGE_TRY(select_device(p.device, &dev));
+        std::unique_ptr<mage_orb> h(new mage_orb());
+        h->device = dev; h->P = p;
+        h->taps = gaussian_taps(p.gaussian_kernel_size);
+        MAGE_HIP(hipSetDevice(dev));
+        MAGE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        for (auto& e : h->ev) MAGE_HIP(hipEventCreate(&e));
+        std::vector<signed char> pat;
+        expand_pattern(p.patch_size, pat);
+        MAGE_TRY(h->d_pattern.upload(pat.data(), pat.size(), h->stream));
+        MAGE_HIP(hipStreamSynchronize(h->stream));
+        *out = h.release();
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT void mage_orb_destroy(mage_orb* h) { delete h; }
+
+namespace {
+
+constexpr int NMS_ROWS = 8;
+
+// runs the five stages on n_frames images that are already in HBM; leaves keypoints / descriptors / counts in HBM
+mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w, int h_img, int stride, size_t frame_stride, int capacity)
+{
+    const mage_orb_params& P = h->P;
+    if (w < 1 || h_img < 1 || w > 65535 || h_img > 32767) return fail(MAGE_ERR_INVALID_ARGUMENT, "image size %dx%d out of range", w, h_img);
+    if (capacity < 0 || n_frames < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative capacity / frame count");
+    hipStream_t st = h->stream;
+    const size_t npx = (size_t)w * h_img;
+    const size_t raw_cap = npx / 4 + 16;
+    const int n_wg = (h_img + NMS_ROWS - 1) / NMS_ROWS;
+    const int ncells = P.num_cells_x * P.num_cells_y;
+    const size_t nf = (size_t)std::max(n_frames, 1), cap = (size_t)std::max(capacity, 1);
+    MAGE_TRY(h->d_score.reserve(nf * npx));
+    MAGE_TRY(h->d_blur.reserve(nf * npx));
+    MAGE_TRY(h->d_wg_count.reserve(nf * n_wg));
+    MAGE_TRY(h->d_wg_off.reserve(nf * n_wg));
+    MAGE_TRY(h->d_hist.reserve(nf * 256));
+    MAGE_TRY(h->d_n_raw.reserve(nf));
+    MAGE_TRY(h->d_raw.reserve(nf * raw_cap));
+    MAGE_TRY(h->d_cand.reserve(nf * raw_cap));
+    MAGE_TRY(h->d_cell_start.reserve(nf * (ncells + 1)));
+    MAGE_TRY(h->d_cell_fill.reserve(nf * (ncells + 1)));
+    MAGE_TRY(h->d_cell_members.reserve(nf * raw_cap));
+    MAGE_TRY(h->d_radius.reserve(nf * raw_cap));
+    MAGE_TRY(h->d_kp.reserve(nf * cap));
+    MAGE_TRY(h->d_desc.reserve(nf * cap * 32));
+    MAGE_TRY(h->d_count.reserve(nf));
+    h->last_w = w; h->last_h = h_img;
+    h->prof = mage_orb_profile{};
+    h->prof.n_frames = n_frames;
+    if (n_frames == 0) return MAGE_OK;
+
+    MAGE_HIP(hipEventRecord(h->ev[0], st));
+    orb_launch_fast(d_images, w, h_img, stride, frame_stride, n_frames, (int)std::min(P.fast_threshold, 255u), h->d_score.p, st);
+    MAGE_HIP(hipEventRecord(h->ev[1], st));
+    orb_launch_collect(h->d_score.p, w, h_img, n_frames, (int)P.patch_size / 2, NMS_ROWS, n_wg, h->d_wg_count.p, h->d_wg_off.p, h->d_hist.p,
+                       h->d_n_raw.p, h->d_raw.p, raw_cap, st);
+    OrbSelectArgs a{};
+    a.raw = h->d_raw.p; a.n_raw = h->d_n_raw.p; a.hist = h->d_hist.p;
+    a.cand = h->d_cand.p; a.cell_start = h->d_cell_start.p; a.cell_fill = h->d_cell_fill.p; a.cell_members = h->d_cell_members.p; a.radius = h->d_radius.p;
+    a.out_kp = h->d_kp.p; a.out_count = h->d_count.p;
+    a.raw_cap = raw_cap; a.ncells = ncells; a.cells_x = P.num_cells_x; a.cells_y = P.num_cells_y;
+    a.nfeatures = (int)P.nfeatures; a.max_num = (int)((float)P.nfeatures * P.feature_factor_anms);
+    a.fast_threshold = (int)P.fast_threshold; a.strong_response = P.strong_response_anms; a.capacity = capacity; a.patch_size = (int)P.patch_size;
+    a.feature_strength = P.feature_strength_anms; a.min_robust = P.min_robust_factor; a.max_robust = P.max_robust_factor;
+    orb_launch_select(a, n_frames, st);
+    MAGE_HIP(hipEventRecord(h->ev[2], st));
+    orb_launch_blur(d_images, w, h_img, stride, frame_stride, n_frames, h->taps, h->d_blur.p, st);
+    MAGE_HIP(hipEventRecord(h->ev[3], st));
+    if (capacity > 0) orb_launch_brief(h->d_blur.p, w, h_img, n_frames, h->d_kp.p, h->d_count.p, capacity, h->d_pattern.p, h->d_desc.p, st);
+    MAGE_HIP(hipEventRecord(h->ev[4], st));
+    return MAGE_OK;
+}
+
+mage_status collect_profile(mage_orb* h)
+{
+    float ms = 0;
+    MAGE_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); h->prof.fast_ms = ms;
+    MAGE_HIP(hipEventElapsedTime(&ms, h->ev[1], h->ev[2])); h->prof.select_ms = ms;
+    MAGE_HIP(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); h->prof.blur_ms = ms;
+    MAGE_HIP(hipEventElapsedTime(&ms, h->ev[3], h->ev[4])); h->prof.brief_ms = ms;
+    MAGE_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[4])); h->prof.total_ms = ms;
+    return MAGE_OK;
+}
+
+}  // namespace
+
+MAGE_EXPORT mage_status mage_orb_detect_batch(mage_orb* h, const uint8_t* images, int images_on_device, int n_frames, int width, int height,
+                                              int stride, size_t frame_stride, mage_keypoint* keypoints, uint8_t* descriptors32, int capacity,
+                                              int* counts)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || (n_frames > 0 && (!images || !counts))) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (capacity > 0 && (!keypoints || !descriptors32)) return fail(MAGE_ERR_INVALID_ARGUMENT, "null output buffer");
+        if (stride < width) return fail(MAGE_ERR_INVALID_ARGUMENT, "stride < width");
+        MAGE_HIP(hipSetDevice(h->device));
+        const uint8_t* dimg = images;
+        if (!images_on_device && n_frames > 0) {
+            const size_t bytes = (size_t)(n_frames - 1) * frame_stride + (size_t)(height - 1) * stride + width;
+            MAGE_TRY(h->d_img.reserve(bytes));
+            MAGE_HIP(hipMemcpyAsync(h->d_img.p, images, bytes, hipMemcpyHostToDevice, h->stream));
+            dimg = h->d_img.p;
+        }
+        MAGE_TRY(run_batch(h, dimg, n_frames, width, height, stride, frame_stride, capacity));
+        if (n_frames == 0) return MAGE_OK;
+        MAGE_HIP(hipMemcpyAsync(counts, h->d_count.p, sizeof(int) * (size_t)n_frames, hipMemcpyDeviceToHost, h->stream));
+        if (capacity > 0) {
+            MAGE_HIP(hipMemcpyAsync(keypoints, h->d_kp.p, sizeof(mage_keypoint) * (size_t)n_frames * capacity, hipMemcpyDeviceToHost, h->stream));
+            MAGE_HIP(hipMemcpyAsync(descriptors32, h->d_desc.p, (size_t)n_frames * capacity * 32, hipMemcpyDeviceToHost, h->stream));
+        }
+        MAGE_HIP(hipStreamSynchronize(h->stream));
+        return collect_profile(h);
+    });
+}
+
+MAGE_EXPORT mage_status mage_orb_detect(mage_orb* h, const uint8_t* image, int width, int height, int stride, mage_keypoint* keypoints,
+                                        uint8_t* descriptors32, int capacity, int* count)
+{
+    return mage_orb_detect_batch(h, image, 0, 1, width, height, stride, (size_t)stride * (size_t)(height > 0 ? height : 0), keypoints,
+                                 descriptors32, capacity, count);
+}
+
+MAGE_EXPORT mage_status mage_orb_detect_batch_device(mage_orb* h, const uint8_t* images_device, int n_frames, int width, int height, int stride,
+                                                     size_t frame_stride, int capacity, const mage_keypoint** keypoints_device,
+                                                     const uint8_t** descriptors_device, const int** counts_device)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !images_device || !keypoints_device || !descriptors_device || !counts_device) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (stride < width) return fail(MAGE_ERR_INVALID_ARGUMENT, "stride < width");
+        MAGE_HIP(hipSetDevice(h->device));
+        MAGE_TRY(run_batch(h, images_device, n_frames, width, height, stride, frame_stride, capacity));
+        MAGE_HIP(hipStreamSynchronize(h->stream));
+        *keypoints_device = h->d_kp.p; *descriptors_device = h->d_desc.p; *counts_device = h->d_count.p;
+        return n_frames > 0 ? collect_profile(h) : MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_orb_debug_read(mage_orb* h, uint8_t* score_map, uint8_t* blurred)
+{
+    return guarded([&]() -> mage_status {
+        if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+        const size_t npx = (size_t)h->last_w * h->last_h;
+        if (npx == 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "no frame has been processed yet");
+        MAGE_HIP(hipSetDevice(h->device));
+        if (score_map) MAGE_HIP(hipMemcpy(score_map, h->d_score.p, npx, hipMemcpyDeviceToHost));
+        if (blurred) MAGE_HIP(hipMemcpy(blurred, h->d_blur.p, npx, hipMemcpyDeviceToHost));
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_orb_get_profile(const mage_orb* h, mage_orb_profile* out)
+{
+    if (!h || !out) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+    *out = h->prof;
+    return MAGE_OK;
+}
+
+// ================================================================================================
+// matcher
+// ================================================================================================
+struct mage_matcher {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevBuf<uint8_t> d_A, d_B;
+    DevBuf<int> d_cA, d_cB, d_scratch, d_counts;
+    DevBuf<mage_dmatch> d_out;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double last_ms = 0;
+    ~mage_matcher()
+    {
+        (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+// FeatureMatcher.cpp:489-500 (8 x 32-bit SWAR popcount); one pair of descriptors is host work
+MAGE_EXPORT int mage_hamming256(const uint8_t* d0, const uint8_t* d1)
+{
+    int result = 0;
+    for (int i = 0; i < 8; ++i) {
+        uint32_t a, b;
+        std::memcpy(&a, d0 + 4 * i, 4); std::memcpy(&b, d1 + 4 * i, 4);
+        uint32_t bits = a ^ b;
+        bits = bits - ((bits >> 1) & 0x55555555u);
+        bits = (bits & 0x33333333u) + ((bits >> 2) & 0x33333333u);
+        result += (int)((((bits + (bits >> 4)) & 0x0F0F0F0Fu) * 0x01010101u) >> 24);
+    }
+    return result;
+}
+
+MAGE_EXPORT mage_status mage_matcher_create(int device, mage_matcher** out)
+{
+    return guarded([&]() -> mage_status {
+        if (!out) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        *out = nullptr;
+        int dev = 0;
+        MAGE_TRY(select_device(device, &dev));
+        std::unique_ptr<mage_matcher> h(new mage_matcher());
+        h->device = dev;
+        MAGE_HIP(hipSetDevice(dev));
+        MAGE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        MAGE_HIP(hipEventCreate(&h->e0)); MAGE_HIP(hipEventCreate(&h->e1));
+        *out = h.release();
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT void mage_matcher_destroy(mage_matcher* h) { delete h; }
+
+namespace {
+
+mage_status run_match(mage_matcher* h, int n_pairs, const uint8_t* dA, const int* dcA, int capA, const uint8_t* dB, const int* dcB, int capB,
+                      int max_dist, int min_diff, int cap_out)
+{
+    if (n_pairs < 0 || capA < 0 || capB < 0 || cap_out < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative size");
+    const size_t np = (size_t)std::max(n_pairs, 1);
+    MAGE_TRY(h->d_scratch.reserve(np * (size_t)(capA + capB) * 2 + 4));
+    MAGE_TRY(h->d_out.reserve(np * (size_t)std::max(cap_out, 1)));
+    MAGE_TRY(h->d_counts.reserve(np));
+    if (n_pairs == 0) return MAGE_OK;
+    MAGE_HIP(hipEventRecord(h->e0, h->stream));
+    match_launch(n_pairs, dA, dcA, capA, dB, dcB, capB, max_dist, min_diff, h->d_scratch.p, h->d_out.p, cap_out, h->d_counts.p, h->stream);
+    MAGE_HIP(hipEventRecord(h->e1, h->stream));
+    return MAGE_OK;
+}
+
+}  // namespace
+
+MAGE_EXPORT mage_status mage_match_bf_batch(mage_matcher* h, int n_pairs, const uint8_t* descA, const int* countsA, int capA,
+                                            const uint8_t* descB, const int* countsB, int capB, int max_dist, int min_diff,
+                                            mage_dmatch* out, int cap_out, int* counts)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || (n_pairs > 0 && (!countsA || !countsB || !counts))) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (n_pairs > 0 && ((capA > 0 && !descA) || (capB > 0 && !descB) || (cap_out > 0 && !out))) return fail(MAGE_ERR_INVALID_ARGUMENT, "null buffer");
+        for (int p = 0; p < n_pairs; ++p)
+            if (countsA[p] < 0 || countsA[p] > capA || countsB[p] < 0 || countsB[p] > capB) return fail(MAGE_ERR_INVALID_ARGUMENT, "pair %d: count exceeds capacity", p);
+        MAGE_HIP(hipSetDevice(h->device));
+        const size_t np = (size_t)std::max(n_pairs, 1);
+        MAGE_TRY(h->d_A.reserve(np * (size_t)capA * 32 + 32)); MAGE_TRY(h->d_B.reserve(np * (size_t)capB * 32 + 32));
+        MAGE_TRY(h->d_cA.reserve(np)); MAGE_TRY(h->d_cB.reserve(np));
+        if (n_pairs == 0) return MAGE_OK;
+        hipStream_t st = h->stream;
+        if (capA) MAGE_HIP(hipMemcpyAsync(h->d_A.p, descA, (size_t)n_pairs * capA * 32, hipMemcpyHostToDevice, st));
+        if (capB) MAGE_HIP(hipMemcpyAsync(h->d_B.p, descB, (size_t)n_pairs * capB * 32, hipMemcpyHostToDevice, st));
+        MAGE_HIP(hipMemcpyAsync(h->d_cA.p, countsA, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, st));
+        MAGE_HIP(hipMemcpyAsync(h->d_cB.p, countsB, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, st));
+        MAGE_TRY(run_match(h, n_pairs, h->d_A.p, h->d_cA.p, capA, h->d_B.p, h->d_cB.p, capB, max_dist, min_diff, cap_out));
+        MAGE_HIP(hipMemcpyAsync(counts, h->d_counts.p, sizeof(int) * (size_t)n_pairs, hipMemcpyDeviceToHost, st));
+        if (cap_out) MAGE_HIP(hipMemcpyAsync(out, h->d_out.p, sizeof(mage_dmatch) * (size_t)n_pairs * cap_out, hipMemcpyDeviceToHost, st));
+        MAGE_HIP(hipStreamSynchronize(st));
+        float ms = 0;
+        MAGE_HIP(hipEventElapsedTime(&ms, h->e0, h->e1));
+        h->last_ms = ms;
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_match_bf(mage_matcher* h, const uint8_t* descA, int nA, const uint8_t* descB, int nB, int max_dist, int min_diff,
+                                      mage_dmatch* out, int capacity, int* count)
+{
+    if (!count) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+    // FeatureMatcher.cpp:72-77: an empty side yields no matches
+    if (nA <= 0 || nB <= 0) { *count = 0; return h ? MAGE_OK : fail(MAGE_ERR_INVALID_ARGUMENT, "null handle"); }
+    mage_status s = mage_match_bf_batch(h, 1, descA, &nA, nA, descB, &nB, nB, max_dist, min_diff, out, capacity, count);
+    return s;
+}
+
+MAGE_EXPORT mage_status mage_match_masked(mage_matcher* h, const uint8_t* descA, int nDescA, const uint8_t* maskA, const uint8_t* descB,
+                                          int nDescB, const uint8_t* maskB, int max_dist, int min_diff, mage_dmatch* out, int capacity,
+                                          int* count)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !count || (nDescA > 0 && !descA) || (nDescB > 0 && !descB)) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        // gather the unmasked descriptors in ascending original index (FeatureMatcher.cpp:88-110)
+        std::vector<uint8_t> A, B;
+        std::vector<int> ia, ib;
+        for (int i = 0; i < nDescA; ++i) if (!maskA || maskA[i]) { ia.push_back(i); A.insert(A.end(), descA + (size_t)i * 32, descA + (size_t)i * 32 + 32); }
+        for (int i = 0; i < nDescB; ++i) if (!maskB || maskB[i]) { ib.push_back(i); B.insert(B.end(), descB + (size_t)i * 32, descB + (size_t)i * 32 + 32); }
+        *count = 0;
+        if (ia.empty() || ib.empty()) return MAGE_OK;
+        std::vector<mage_dmatch> tmp(ia.size());
+        int n = 0;
+        MAGE_TRY(mage_match_bf(h, A.data(), (int)ia.size(), B.data(), (int)ib.size(), max_dist, min_diff, tmp.data(), (int)tmp.size(), &n));
+        for (int i = 0; i < n; ++i) {
+            if (out && i < capacity) { out[i] = tmp[i]; out[i].queryIdx = ia[tmp[i].queryIdx]; out[i].trainIdx = ib[tmp[i].trainIdx]; }   // :160-163
+        }
+        *count = n;
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_match_bf_batch_device(mage_matcher* h, int n_pairs, const uint8_t* descA_dev, const int* countsA_dev, int capA,
+                                                   const uint8_t* descB_dev, const int* countsB_dev, int capB, int max_dist, int min_diff,
+                                                   int cap_out, const mage_dmatch** out_dev, const int** counts_dev)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !descA_dev || !descB_dev || !countsA_dev || !countsB_dev || !out_dev || !counts_dev) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        MAGE_HIP(hipSetDevice(h->device));
+        MAGE_TRY(run_match(h, n_pairs, descA_dev, countsA_dev, capA, descB_dev, countsB_dev, capB, max_dist, min_diff, cap_out));
+        MAGE_HIP(hipStreamSynchronize(h->stream));
+        if (n_pairs > 0) { float ms = 0; MAGE_HIP(hipEventElapsedTime(&ms, h->e0, h->e1)); h->last_ms = ms; }
+        *out_dev = h->d_out.p; *counts_dev = h->d_counts.p;
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_matcher_last_kernel_ms(const mage_matcher* h, double* ms)
+{
+    if (!h || !ms) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+    *ms = h->last_ms;
+    return MAGE_OK;
+}

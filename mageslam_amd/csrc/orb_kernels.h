@@ -1,0 +1,36 @@
+// orb_kernels.h -- launchers of the ORB front-end kernels (orb_kernels.hip) and of the Hamming matcher (match_kernels.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mage_match.h"
+#include "../../include/mage_orb.h"
+
+namespace mage {
+
+struct OrbTaps { int radius; int t[15]; };          // 8-bit fixed-point Gaussian taps (sum ~ 256), radius <= 7
+
+struct OrbSelectArgs {
+    const int2* raw; const int* n_raw; const int* hist;      // per frame: raster-ordered (x | y << 16, response), count, 256-bin histogram
+    int2* cand; int* cell_start; int* cell_fill; int* cell_members; int* radius;   // scratch, per frame
+    mage_keypoint* out_kp; int* out_count;
+    size_t raw_cap;
+    int ncells, cells_x, cells_y;
+    int nfeatures, max_num, fast_threshold, strong_response, capacity, patch_size;
+    float feature_strength, min_robust, max_robust;
+};
+
+void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, uint8_t* score, hipStream_t st);
+void orb_launch_collect(const uint8_t* score, int w, int h, int n_frames, int border, int rows_per_wg, int n_wg, int* wg_count, int* wg_off,
+                        int* hist, int* n_raw, int2* raw, size_t raw_cap, hipStream_t st);
+void orb_launch_select(const OrbSelectArgs& a, int n_frames, hipStream_t st);
+void orb_launch_blur(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, const OrbTaps& taps, uint8_t* out, hipStream_t st);
+void orb_launch_brief(const uint8_t* blurred, int w, int h, int n_frames, const mage_keypoint* kps, const int* counts, int capacity,
+                      const signed char* pattern, uint8_t* desc, hipStream_t st);
+
+// Hamming brute-force two-way matcher: one workgroup per pair.
+void match_launch(int n_pairs, const uint8_t* descA, const int* countsA, int capA, const uint8_t* descB, const int* countsB, int capB,
+                  int max_dist, int min_diff, int* scratch /* n_pairs x (capA + capB) x 2 ints */, mage_dmatch* out, int cap_out, int* counts,
+                  hipStream_t st);
+
+}  // namespace mage

@@ -1,0 +1,451 @@
+// orb_kernels.hip -- HIP kernels (gfx950) of the ORB front-end; byte/integer HBM-bound work, no MFMA.
+//
+// Reference code replaced (Core/MAGESLAM/Source/Image/OpenCVModified.cpp):
+//   k_fast_score     FAST_t<16> segment test + cornerScore<16>            :926-1071, :1224-1486
+//   k_nms_count/emit 3x3 strict NMS in raster order + RunByImageBorder    :1488-1510, :619-639
+//   k_select         RetainBestFeatures + AdaptiveNonMaximalSuppresion    :571-617, :144-360
+//   k_blur           cv::GaussianBlur(k x k, sigma 2, REFLECT_101) on u8  :853-865 (OpenCV 3.4.0 fixed-point path)
+//   k_brief          ComputeOrbDescriptorsPrerotated                      :502-549
+// Frames are independent: every kernel takes the frame index from blockIdx.y (batched over frames).
+// All outputs are integers and must equal the CPU oracle bit for bit; float arithmetic that feeds comparisons
+// (ANMS robustness factor) uses explicitly rounded operations so that no FMA contraction can change a result.
+#include "orb_kernels.h"
+
+namespace mage {
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// FAST-9/16 score map.  32x8 pixel tile per workgroup, LDS tile with a 3-pixel halo.
+// score = max over the 16 arcs of 9 contiguous ring pixels of the arc's minimum margin, for darker and for
+// brighter rings; a pixel is a corner iff that maximum exceeds the threshold, and its score is maximum - 1
+// (identical to the reference's threshold-table pre-test + min/max ladder, which computes the same quantity).
+// ---------------------------------------------------------------------------------------------
+constexpr int FT_W = 32, FT_H = 8, HALO = 3;
+
+__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride,
+                                                    int threshold, uint8_t* __restrict__ score)
+{
+    __shared__ uint8_t tile[(FT_H + 2 * HALO) * (FT_W + 2 * HALO + 2)];
+    constexpr int TP = FT_W + 2 * HALO + 2;
+    const int f = blockIdx.z;
+    const uint8_t* I = img + (size_t)f * frame_stride;
+    uint8_t* Sc = score + (size_t)f * w * h;
+    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    for (int e = threadIdx.x; e < (FT_H + 2 * HALO) * (FT_W + 2 * HALO); e += 256) {
+        const int ty = e / (FT_W + 2 * HALO), tx = e % (FT_W + 2 * HALO);
+        const int gx = x0 + tx - HALO, gy = y0 + ty - HALO;
+        tile[ty * TP + tx] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? I[(size_t)gy * stride + gx] : 0;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % FT_W, ly = threadIdx.x / FT_W;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= w || y >= h) return;
+    int out = 0;
+    if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
+        const uint8_t* c = &tile[(ly + HALO) * TP + lx + HALO];
+        const int v = c[0];
+        const int ox[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
+        const int oy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
+        int d[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k] = v - (int)c[oy[k] * TP + ox[k]];
+        // high-speed pre-test (a 9-arc always contains one pixel of every opposite pair)
+        const int t = threshold;
+        bool dark = true, bright = true;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            dark = dark && (d[k] > t || d[k + 8] > t);
+            bright = bright && (d[k] < -t || d[k + 8] < -t);
+        }
+        if (dark || bright) {
+            int m = -1000;
+            // windowed minima by doubling: 2, 4, 8, then 9
+            int a2[16], a4[16], a8[16], b2[16], b4[16], b8[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { a2[k] = min(d[k], d[(k + 1) & 15]); b2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { a4[k] = min(a2[k], a2[(k + 2) & 15]); b4[k] = max(b2[k], b2[(k + 2) & 15]); }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { a8[k] = min(a4[k], a4[(k + 4) & 15]); b8[k] = max(b4[k], b4[(k + 4) & 15]); }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                m = max(m, min(a8[k], d[(k + 8) & 15]));        // darker ring: min of (v - ring) over the arc
+                m = max(m, -max(b8[k], d[(k + 8) & 15]));       // brighter ring: min of (ring - v) over the arc
+            }
+            if (m > t) out = m - 1;
+        }
+    }
+    Sc[(size_t)y * w + x] = (uint8_t)out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NMS + border cull + raster-order compaction.  A workgroup owns NMS_ROWS full image rows (a contiguous
+// raster segment); pass 1 counts (and builds the response histogram), pass 2 writes at the scanned offsets.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int nms_value(const uint8_t* __restrict__ Sc, int w, int h, int x, int y, int border)
+{
+    // returns the response if (x, y) is a kept keypoint, else -1
+    const int lo = border > 3 ? border : 3;
+    if (x < lo || y < lo || x >= w - lo || y >= h - lo) return -1;
+    const uint8_t* p = Sc + (size_t)y * w + x;
+    const int s = p[0];
+    if (s > p[1] && s > p[-1] && s > p[-w - 1] && s > p[-w] && s > p[-w + 1] && s > p[w - 1] && s > p[w] && s > p[w + 1]) return s;
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void k_nms_count(const uint8_t* __restrict__ score, int w, int h, int border, int rows_per_wg,
+                                                   int* __restrict__ wg_count, int* __restrict__ hist)
+{
+    __shared__ int lh[256];
+    __shared__ int cnt;
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const uint8_t* Sc = score + (size_t)f * w * h;
+    lh[tid] = 0;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    const int y0 = blockIdx.x * rows_per_wg;
+    const int y1 = min(y0 + rows_per_wg, h);
+    int c = 0;
+    for (int p = y0 * w + tid; p < y1 * w; p += 256) {
+        const int v = nms_value(Sc, w, h, p % w, p / w, border);
+        if (v >= 0) { ++c; atomicAdd(&lh[v], 1); }
+    }
+    atomicAdd(&cnt, c);
+    __syncthreads();
+    if (lh[tid]) atomicAdd(&hist[f * 256 + tid], lh[tid]);
+    if (tid == 0) wg_count[f * gridDim.x + blockIdx.x] = cnt;
+}
+
+// exclusive scan of the per-workgroup counts of one frame (single wavefront per frame; n_wg is small)
+__global__ __launch_bounds__(64) void k_scan_counts(const int* __restrict__ wg_count, int n_wg, int* __restrict__ wg_off, int* __restrict__ n_raw)
+{
+    const int f = blockIdx.x, lane = threadIdx.x;
+    int base = 0;
+    for (int b = 0; b < n_wg; b += 64) {
+        const int i = b + lane;
+        int v = i < n_wg ? wg_count[f * n_wg + i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (i < n_wg) wg_off[f * n_wg + i] = base + incl - v;
+        base += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) n_raw[f] = base;
+}
+
+__global__ __launch_bounds__(256) void k_nms_emit(const uint8_t* __restrict__ score, int w, int h, int border, int rows_per_wg,
+                                                  const int* __restrict__ wg_off, int2* __restrict__ raw, size_t raw_cap)
+{
+    __shared__ int wave_cnt[4];
+    __shared__ int base_s;
+    const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t* Sc = score + (size_t)f * w * h;
+    int2* out = raw + (size_t)f * raw_cap;
+    if (tid == 0) base_s = wg_off[f * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const int y0 = blockIdx.x * rows_per_wg;
+    const int y1 = min(y0 + rows_per_wg, h);
+    for (int p0 = y0 * w; p0 < y1 * w; p0 += 256) {
+        const int p = p0 + tid;
+        int v = -1, x = 0, y = 0;
+        if (p < y1 * w) { x = p % w; y = p / w; v = nms_value(Sc, w, h, x, y, border); }
+        const unsigned long long bal = __ballot(v >= 0);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base_s;
+        for (int q = 0; q < wave; ++q) off += wave_cnt[q];
+        if (v >= 0) out[off + before] = make_int2(x | (y << 16), v);
+        __syncthreads();
+        if (tid == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// selection: one workgroup (1024 threads) per frame.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_scan_excl(int v, int* sh /* 17 ints */, int& total)
+{
+    // exclusive scan over 1024 threads (16 waves) in thread order
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    __syncthreads();
+    if (lane == 63) sh[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int q = 0; q < 16; ++q) { if (q < wave) woff += sh[q]; tot += sh[q]; }
+    total = tot;
+    return woff + incl - v;
+}
+
+__global__ __launch_bounds__(1024) void k_select(OrbSelectArgs a)
+{
+    __shared__ int sh[32];
+    __shared__ int s_cut;
+    __shared__ int s_minX, s_maxX, s_minY, s_maxY, s_minS;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int2* raw = a.raw + (size_t)f * a.raw_cap;
+    int2* cand = a.cand + (size_t)f * a.raw_cap;
+    int* cellcnt = a.cell_start + (size_t)f * (a.ncells + 1);
+    int* cellfill = a.cell_fill + (size_t)f * (a.ncells + 1);
+    int* cellmem = a.cell_members + (size_t)f * a.raw_cap;
+    int* rad = a.radius + (size_t)f * a.raw_cap;
+    mage_keypoint* okp = a.out_kp + (size_t)f * a.capacity;
+    const int n_raw = a.n_raw[f];
+    const float size_f = (float)a.patch_size * 1.0f;
+    if (n_raw <= a.nfeatures) {
+        const int n = min(n_raw, a.capacity);
+        for (int i = tid; i < n; i += 1024) {
+            const int2 r = raw[i];
+            mage_keypoint k = { (float)(r.x & 0xffff), (float)(r.x >> 16), size_f, 0.0f, (float)r.y, 0, -1 };
+            okp[i] = k;
+        }
+        if (tid == 0) a.out_count[f] = n;
+        return;
+    }
+    // ---- RetainBestFeatures: whole histogram bins from 255 downwards
+    if (tid == 0) {
+        const int* hist = a.hist + f * 256;
+        const int min_thr = a.fast_threshold;
+        int mnt = min_thr, num = 0;
+        for (int i = 255; i >= min_thr; --i) { num += hist[i]; if (num >= a.nfeatures) { mnt = i; break; } }
+        const int lower = max((int)__fmul_rn((float)mnt, a.feature_strength), min_thr);
+        int cut = lower;
+        num = 0;
+        for (int i = 255; i >= lower; --i) { num += hist[i]; if (num >= a.max_num) { cut = i; break; } }
+        s_cut = cut;
+        s_minX = 1 << 30; s_maxX = -1; s_minY = 1 << 30; s_maxY = -1; s_minS = 1 << 30;
+    }
+    __syncthreads();
+    const int cut = s_cut;
+    int mbase = 0;
+    for (int i0 = 0; i0 < n_raw; i0 += 1024) {          // ordered compaction (raster order is kept: choice C1)
+        const int i = i0 + tid;
+        int2 r = make_int2(0, -1);
+        if (i < n_raw) r = raw[i];
+        const int keep = (i < n_raw && r.y >= cut) ? 1 : 0;
+        int tot;
+        const int off = block_scan_excl(keep, sh, tot);
+        if (keep) {
+            cand[mbase + off] = r;
+            atomicMin(&s_minX, r.x & 0xffff); atomicMax(&s_maxX, r.x & 0xffff);
+            atomicMin(&s_minY, r.x >> 16); atomicMax(&s_maxY, r.x >> 16);
+            atomicMin(&s_minS, r.y);
+        }
+        mbase += tot;
+        __syncthreads();
+    }
+    const int M = mbase;
+    const int N = a.nfeatures;
+    __threadfence_block();
+    __syncthreads();
+    if (N > M) {                                         // ANMS returns early: keep all (cannot happen: M >= N by construction)
+        const int n = min(M, a.capacity);
+        for (int i = tid; i < n; i += 1024) {
+            const int2 r = cand[i];
+            mage_keypoint k = { (float)(r.x & 0xffff), (float)(r.x >> 16), size_f, 0.0f, (float)r.y, 0, -1 };
+            okp[i] = k;
+        }
+        if (tid == 0) a.out_count[f] = n;
+        return;
+    }
+    // ---- AdaptiveNonMaximalSuppresion
+    const int minX = s_minX, maxX = s_maxX, minY = s_minY, maxY = s_maxY;
+    const int numX = a.cells_x, numY = a.cells_y, thr = a.fast_threshold;
+    float rf;
+    {
+        const float hi = __fsub_rn((float)a.strong_response, (float)thr);
+        float val = __fsub_rn((float)s_minS, (float)thr);
+        val = val < 0.0f ? 0.0f : (val > hi ? hi : val);
+        float range = __fsub_rn(a.max_robust, a.min_robust);
+        if (range < 0.0f) range = 0.0f;
+        rf = __fsub_rn(a.max_robust, __fmul_rn(__fdiv_rn(val, (float)(a.strong_response - thr)), range));
+    }
+    for (int c = tid; c <= a.ncells; c += 1024) { cellcnt[c] = 0; cellfill[c] = 0; }
+    __syncthreads();
+    for (int i = tid; i < M; i += 1024) {
+        const int2 r = cand[i];
+        const int cx = ((r.x & 0xffff) - minX) * numX / (maxX + 1 - minX), cy = ((r.x >> 16) - minY) * numY / (maxY + 1 - minY);
+        atomicAdd(&cellcnt[cy * numX + cx + 1], 1);
+    }
+    __syncthreads();
+    if (tid == 0) { for (int c = 0; c < a.ncells; ++c) cellcnt[c + 1] += cellcnt[c]; }      // cell_start (<= 1024 cells by default)
+    __syncthreads();
+    for (int i = tid; i < M; i += 1024) {
+        const int2 r = cand[i];
+        const int cx = ((r.x & 0xffff) - minX) * numX / (maxX + 1 - minX), cy = ((r.x >> 16) - minY) * numY / (maxY + 1 - minY);
+        const int c = cy * numX + cx;
+        cellmem[cellcnt[c] + atomicAdd(&cellfill[c], 1)] = i;     // member order inside a cell does not affect a minimum
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int globalMaxR2 = (int)(((double)(maxX - minX)) * ((double)(maxY - minY)) / (double)N);
+    int minCellDelta2;
+    {
+        const int dx = max((maxX - minX) / numX, 1), dy = max((maxY - minY) / numY, 1);
+        const int m = min(dx, dy);
+        minCellDelta2 = m * m;
+    }
+    for (int i = tid; i < M; i += 1024) {
+        const int2 r = cand[i];
+        const int x = r.x & 0xffff, y = r.x >> 16;
+        const int cx = (x - minX) * numX / (maxX + 1 - minX), cy = (y - minY) * numY / (maxY + 1 - minY);
+        const float strength = (float)r.y;
+        const float s = __fadd_rn(__fmul_rn(strength, rf), 0.002f);          // strength >= 0 always (FAST score)
+        int minR2 = globalMaxR2;
+        for (int d = 0; max(0, d - 1) * max(0, d - 1) * minCellDelta2 < minR2; ++d)
+            for (int yy = -d; yy <= d; ++yy) {
+                const int cYY = yy + cy;
+                if (cYY < 0 || cYY >= numY) continue;
+                for (int xx = -d; xx <= d; ++xx) {
+                    const int cXX = xx + cx;
+                    if (cXX < 0 || cXX >= numX || max(abs(xx), abs(yy)) != d) continue;
+                    const int c = cYY * numX + cXX;
+                    for (int q = cellcnt[c]; q < cellcnt[c + 1]; ++q) {
+                        const int2 o = cand[cellmem[q]];
+                        if ((float)o.y > s) {
+                            const int ddx = x - (o.x & 0xffff), ddy = y - (o.x >> 16);
+                            const int rr = ddx * ddx + ddy * ddy;
+                            if (rr < minR2) minR2 = rr;
+                        }
+                    }
+                }
+            }
+        rad[i] = minR2;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- keep the N first in the total order (radius desc, strength desc, index asc); rank = output position (choice C2)
+    for (int i = tid; i < M; i += 1024) {
+        const int ri = rad[i], si = cand[i].y;
+        int rank = 0;
+        for (int j = 0; j < M; ++j) {
+            const int rj = rad[j], sj = cand[j].y;
+            rank += (rj > ri) || (rj == ri && (sj > si || (sj == si && j < i)));
+        }
+        if (rank < N && rank < a.capacity) {
+            const int2 r = cand[i];
+            mage_keypoint k = { (float)(r.x & 0xffff), (float)(r.x >> 16), size_f, 0.0f, (float)r.y, 0, -1 };
+            okp[rank] = k;
+        }
+    }
+    if (tid == 0) a.out_count[f] = min(N, a.capacity);
+}
+
+// ---------------------------------------------------------------------------------------------
+// separable integer Gaussian, REFLECT_101, 64x16 output tile per workgroup
+// ---------------------------------------------------------------------------------------------
+constexpr int BT_W = 64, BT_H = 16, MAXR = 7;
+
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride,
+                                              OrbTaps taps, uint8_t* __restrict__ out)
+{
+    __shared__ int hrow[(BT_H + 2 * MAXR) * BT_W];
+    const int f = blockIdx.z, r = taps.radius;
+    const uint8_t* I = img + (size_t)f * frame_stride;
+    uint8_t* O = out + (size_t)f * w * h;
+    const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
+    // horizontal pass for rows y0 - r .. y0 + BT_H + r - 1 (reflected)
+    for (int e = threadIdx.x; e < (BT_H + 2 * r) * BT_W; e += 256) {
+        const int ty = e / BT_W, tx = e % BT_W;
+        const int x = x0 + tx;
+        int acc = 0;
+        if (x < w) {
+            const int gy = reflect101(y0 + ty - r, h);
+            const uint8_t* row = I + (size_t)gy * stride;
+            for (int t = -r; t <= r; ++t) acc += taps.t[t + r] * (int)row[reflect101(x + t, w)];
+        }
+        hrow[ty * BT_W + tx] = acc;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < BT_H * BT_W; e += 256) {
+        const int ty = e / BT_W, tx = e % BT_W;
+        const int x = x0 + tx, y = y0 + ty;
+        if (x >= w || y >= h) continue;
+        int acc = 0;
+        for (int t = 0; t <= 2 * r; ++t) acc += taps.t[t] * hrow[(ty + t) * BT_W + tx];
+        const int v = (acc + (1 << 15)) >> 16;
+        O[(size_t)y * w + x] = (uint8_t)(v > 255 ? 255 : v);
+    }
+}
+
+// plain copy when gaussian_kernel_size <= 1
+__global__ void k_copy_image(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride, uint8_t* __restrict__ out)
+{
+    const int f = blockIdx.y;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < w * h; p += gridDim.x * blockDim.x)
+        out[(size_t)f * w * h + p] = img[(size_t)f * frame_stride + (size_t)(p / w) * stride + (p % w)];
+}
+
+// ---------------------------------------------------------------------------------------------
+// BRIEF-256: one wavefront per keypoint; lane l evaluates pairs 4l..4l+3, two lanes make a byte.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blurred, int w, int h, const mage_keypoint* __restrict__ kps,
+                                               const int* __restrict__ counts, int capacity, const signed char* __restrict__ pattern,
+                                               uint8_t* __restrict__ desc)
+{
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= counts[f]) return;
+    const mage_keypoint kp = kps[(size_t)f * capacity + k];
+    // cvRound of an integer-valued float; angle 0 -> rotation row 0
+    const int cx = (int)rintf(kp.x), cy = (int)rintf(kp.y);
+    const uint8_t* c = blurred + (size_t)f * w * h + (size_t)cy * w + cx;
+    const signed char* p = pattern + lane * 16;
+    int nib = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int t0 = c[p[4 * b + 1] * w + p[4 * b]];
+        const int t1 = c[p[4 * b + 3] * w + p[4 * b + 2]];
+        nib |= (t0 < t1) << b;
+    }
+    const int hi = __shfl_down(nib, 1, 64);
+    if ((lane & 1) == 0) desc[((size_t)f * capacity + k) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, uint8_t* score, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fast_score, dim3(cdiv(w, FT_W), cdiv(h, FT_H), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, threshold, score);
+}
+
+void orb_launch_collect(const uint8_t* score, int w, int h, int n_frames, int border, int rows_per_wg, int n_wg, int* wg_count, int* wg_off,
+                        int* hist, int* n_raw, int2* raw, size_t raw_cap, hipStream_t st)
+{
+    (void)hipMemsetAsync(hist, 0, sizeof(int) * 256 * (size_t)n_frames, st);
+    hipLaunchKernelGGL(k_nms_count, dim3(n_wg, n_frames), dim3(256), 0, st, score, w, h, border, rows_per_wg, wg_count, hist);
+    hipLaunchKernelGGL(k_scan_counts, dim3(n_frames), dim3(64), 0, st, wg_count, n_wg, wg_off, n_raw);
+    hipLaunchKernelGGL(k_nms_emit, dim3(n_wg, n_frames), dim3(256), 0, st, score, w, h, border, rows_per_wg, wg_off, raw, raw_cap);
+}
+
+void orb_launch_select(const OrbSelectArgs& a, int n_frames, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_select, dim3(n_frames), dim3(1024), 0, st, a);
+}
+
+void orb_launch_blur(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, const OrbTaps& taps, uint8_t* out, hipStream_t st)
+{
+    if (taps.radius == 0) hipLaunchKernelGGL(k_copy_image, dim3(cdiv(w * h, 256 * 8), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, out);
+    else hipLaunchKernelGGL(k_blur, dim3(cdiv(w, BT_W), cdiv(h, BT_H), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, taps, out);
+}
+
+void orb_launch_brief(const uint8_t* blurred, int w, int h, int n_frames, const mage_keypoint* kps, const int* counts, int capacity,
+                      const signed char* pattern, uint8_t* desc, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_brief, dim3(cdiv(capacity, 4), n_frames), dim3(256), 0, st, blurred, w, h, kps, counts, capacity, pattern, desc);
+}
+
+}  // namespace mage

@@ -1,0 +1,180 @@
+"""ctypes bindings of the ORB front-end and the brute-force matcher (include/mage_orb.h, include/mage_match.h).
+
+``OrbDetector`` mirrors the reference's class of the same name (Image/OpenCVModified.h:64-173): the constructor takes
+the FeatureExtractorSettings scalars, ``DetectAndCompute`` returns keypoints (cv::KeyPoint records) and 32-byte
+descriptors.  ``Match`` mirrors Tracking/FeatureMatcher.h:100-109.  These are bindings only; all work is in the shared library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4"), ("class_id", "<i4")])      # cv::KeyPoint, 28 bytes
+DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])   # cv::DMatch
+
+_u8 = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_i32 = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("gaussian_kernel_size", C.c_uint), ("nfeatures", C.c_uint), ("scale_factor", C.c_float), ("nlevels", C.c_uint),
+                ("patch_size", C.c_uint), ("fast_threshold", C.c_uint), ("use_orientation", C.c_int), ("feature_factor_anms", C.c_float),
+                ("feature_strength_anms", C.c_float), ("strong_response_anms", C.c_int), ("min_robust_factor", C.c_float),
+                ("max_robust_factor", C.c_float), ("num_cells_x", C.c_int), ("num_cells_y", C.c_int), ("device", C.c_int)]
+
+
+class OrbProfile(C.Structure):
+    _fields_ = [("fast_ms", C.c_double), ("select_ms", C.c_double), ("blur_ms", C.c_double), ("brief_ms", C.c_double),
+                ("total_ms", C.c_double), ("n_frames", C.c_int)]
+
+
+_declared = False
+
+
+def _declare():
+    global _declared
+    if _declared:
+        return
+    L = lib()
+    vp = C.c_void_p
+    L.mage_orb_default_params.argtypes = [C.POINTER(OrbParams)]
+    L.mage_orb_create.argtypes = [C.POINTER(OrbParams), C.POINTER(vp)]
+    L.mage_orb_destroy.argtypes = [vp]; L.mage_orb_destroy.restype = None
+    L.mage_orb_detect.argtypes = [vp, _u8, C.c_int, C.c_int, C.c_int, vp, _u8, C.c_int, C.POINTER(C.c_int)]
+    L.mage_orb_detect_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, _u8, C.c_int, _i32]
+    L.mage_orb_detect_batch_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.mage_orb_debug_read.argtypes = [vp, vp, vp]
+    L.mage_orb_get_profile.argtypes = [vp, C.POINTER(OrbProfile)]
+    L.mage_hamming256.argtypes = [_u8, _u8]; L.mage_hamming256.restype = C.c_int
+    L.mage_matcher_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.mage_matcher_destroy.argtypes = [vp]; L.mage_matcher_destroy.restype = None
+    L.mage_match_bf.argtypes = [vp, _u8, C.c_int, _u8, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
+    L.mage_match_masked.argtypes = [vp, _u8, C.c_int, vp, _u8, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
+    L.mage_match_bf_batch.argtypes = [vp, C.c_int, _u8, _i32, C.c_int, _u8, _i32, C.c_int, C.c_int, C.c_int, vp, C.c_int, _i32]
+    L.mage_match_bf_batch_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp)]
+    L.mage_matcher_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double)]
+    _declared = True
+
+
+def default_params(**kw) -> OrbParams:
+    _declare()
+    p = OrbParams()
+    check(lib().mage_orb_default_params(C.byref(p)))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class OrbDetector:
+    def __init__(self, params: OrbParams = None, **kw):
+        _declare()
+        self._L = lib()
+        self.params = params or default_params(**kw)
+        self._h = C.c_void_p()
+        check(self._L.mage_orb_create(C.byref(self.params), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mage_orb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def DetectAndCompute(self, image: np.ndarray, capacity: int = None):
+        """One CV_8UC1 image -> (keypoints[KEYPOINT_DTYPE], descriptors[n, 32])."""
+        img = np.ascontiguousarray(image, np.uint8)
+        h, w = img.shape
+        cap = int(self.params.nfeatures) if capacity is None else capacity
+        kps = np.zeros(max(cap, 1), KEYPOINT_DTYPE); desc = np.zeros((max(cap, 1), 32), np.uint8)
+        n = C.c_int(0)
+        check(self._L.mage_orb_detect(self._h, img.reshape(-1), w, h, w, kps.ctypes.data_as(C.c_void_p), desc.reshape(-1), cap, C.byref(n)))
+        return kps[: n.value].copy(), desc[: n.value].copy()
+
+    def DetectAndComputeBatch(self, images: np.ndarray, capacity: int = None):
+        """images: (n, h, w) uint8 -> (keypoints[n, cap], descriptors[n, cap, 32], counts[n])."""
+        imgs = np.ascontiguousarray(images, np.uint8)
+        n, h, w = imgs.shape
+        cap = int(self.params.nfeatures) if capacity is None else capacity
+        kps = np.zeros((n, max(cap, 1)), KEYPOINT_DTYPE); desc = np.zeros((n, max(cap, 1), 32), np.uint8); cnt = np.zeros(max(n, 1), np.int32)
+        check(self._L.mage_orb_detect_batch(self._h, imgs.ctypes.data_as(C.c_void_p), 0, n, w, h, w, w * h, kps.ctypes.data_as(C.c_void_p),
+                                            desc.reshape(-1), cap, cnt))
+        return kps, desc, cnt[:n]
+
+    def detect_batch_device(self, images_ptr: int, n: int, w: int, h: int, capacity: int = None):
+        """Device-resident in and out (raw device pointers as ints): returns (kp_ptr, desc_ptr, counts_ptr)."""
+        cap = int(self.params.nfeatures) if capacity is None else capacity
+        kp, de, cn = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(self._L.mage_orb_detect_batch_device(self._h, C.c_void_p(images_ptr), n, w, h, w, w * h, cap, C.byref(kp), C.byref(de), C.byref(cn)))
+        return kp.value, de.value, cn.value
+
+    def debug_read(self, w: int, h: int):
+        s = np.zeros((h, w), np.uint8); b = np.zeros((h, w), np.uint8)
+        check(self._L.mage_orb_debug_read(self._h, s.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
+        return s, b
+
+    def profile(self) -> OrbProfile:
+        p = OrbProfile()
+        check(self._L.mage_orb_get_profile(self._h, C.byref(p)))
+        return p
+
+
+def GetDescriptorDistance(d0: np.ndarray, d1: np.ndarray) -> int:
+    _declare()
+    return int(lib().mage_hamming256(np.ascontiguousarray(d0, np.uint8).reshape(32), np.ascontiguousarray(d1, np.uint8).reshape(32)))
+
+
+class Matcher:
+    def __init__(self, device: int = -1):
+        _declare()
+        self._L = lib()
+        self._h = C.c_void_p()
+        check(self._L.mage_matcher_create(device, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mage_matcher_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def Match(self, descA, descB, maskA=None, maskB=None, max_hamming_dist=30, min_hamming_difference=1) -> np.ndarray:
+        """FeatureMatcher::Match: returns DMATCH_DTYPE records with ORIGINAL indices, ascending in A."""
+        A = np.ascontiguousarray(descA, np.uint8).reshape(-1, 32); B = np.ascontiguousarray(descB, np.uint8).reshape(-1, 32)
+        out = np.zeros(max(len(A), 1), DMATCH_DTYPE)
+        n = C.c_int(0)
+        ma = None if maskA is None else np.ascontiguousarray(maskA, np.uint8)
+        mb = None if maskB is None else np.ascontiguousarray(maskB, np.uint8)
+        a_arr = A.reshape(-1) if len(A) else np.zeros(32, np.uint8)
+        b_arr = B.reshape(-1) if len(B) else np.zeros(32, np.uint8)
+        check(self._L.mage_match_masked(self._h, a_arr, len(A), None if ma is None else ma.ctypes.data_as(C.c_void_p), b_arr, len(B),
+                                        None if mb is None else mb.ctypes.data_as(C.c_void_p), int(max_hamming_dist),
+                                        int(min_hamming_difference), out.ctypes.data_as(C.c_void_p), len(out), C.byref(n)))
+        return out[: min(n.value, len(out))].copy()
+
+    def MatchBatch(self, descA, countsA, descB, countsB, max_hamming_dist=30, min_hamming_difference=1):
+        """descA: (n_pairs, capA, 32), descB: (n_pairs, capB, 32) -> (matches[n_pairs, capA], counts[n_pairs])."""
+        A = np.ascontiguousarray(descA, np.uint8); B = np.ascontiguousarray(descB, np.uint8)
+        npairs, capA, _ = A.shape; capB = B.shape[1]
+        out = np.zeros((npairs, max(capA, 1)), DMATCH_DTYPE); cnt = np.zeros(max(npairs, 1), np.int32)
+        check(self._L.mage_match_bf_batch(self._h, npairs, A.reshape(-1), np.ascontiguousarray(countsA, np.int32), capA, B.reshape(-1),
+                                          np.ascontiguousarray(countsB, np.int32), capB, int(max_hamming_dist), int(min_hamming_difference),
+                                          out.ctypes.data_as(C.c_void_p), capA, cnt))
+        return out, cnt[:npairs]
+
+    def match_batch_device(self, n_pairs, dA, cA, capA, dB, cB, capB, max_hamming_dist=30, min_hamming_difference=1, cap_out=None):
+        o, c = C.c_void_p(), C.c_void_p()
+        check(self._L.mage_match_bf_batch_device(self._h, n_pairs, C.c_void_p(dA), C.c_void_p(cA), capA, C.c_void_p(dB), C.c_void_p(cB), capB,
+                                                 int(max_hamming_dist), int(min_hamming_difference), capA if cap_out is None else cap_out,
+                                                 C.byref(o), C.byref(c)))
+        return o.value, c.value
+
+    def last_kernel_ms(self) -> float:
+        v = C.c_double(0)
+        check(self._L.mage_matcher_last_kernel_ms(self._h, C.byref(v)))
+        return float(v.value)

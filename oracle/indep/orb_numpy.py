@@ -1,0 +1,181 @@
+"""Independent numpy restatement of the ORB front-end and the brute-force matcher -- TEST INFRASTRUCTURE ONLY.
+
+Pins oracle/orb_oracle.c and oracle/match_oracle.c.  Different routes on purpose:
+  * FAST from its definition: "9 contiguous ring pixels all brighter than I+t or all darker than I-t", with the
+    score as max over the 16 arcs of the arc's minimum margin (no threshold table, no min/max ladder);
+  * NMS with shifted arrays; selection with numpy masks / lexsort; ANMS radii by the same grid-ring search but
+    over Python dicts (the ring search is part of the behaviour being pinned: brute force is NOT equivalent when the
+    bounding box is smaller than the grid);
+  * blur with scipy.ndimage.correlate1d(mode="mirror"); BRIEF as one fancy-indexing gather;
+  * Hamming through np.unpackbits.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.ndimage import correlate1d
+
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+DEFAULTS = dict(gaussian_kernel_size=7, nfeatures=440, nlevels=1, patch_size=15, fast_threshold=4, feature_factor=1.5,
+                feature_strength=0.9, strong_response=20, min_robust=1.1, max_robust=2.0, cells_x=32, cells_y=32)
+
+
+def fast_score_map(img: np.ndarray, t: int) -> np.ndarray:
+    img = img.astype(np.int32)
+    h, w = img.shape
+    score = np.zeros((h, w), np.uint8)
+    if h < 7 or w < 7:
+        return score
+    c = img[3:h - 3, 3:w - 3]
+    d = np.stack([c - img[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] for dx, dy in RING])          # centre minus ring
+    d2 = np.concatenate([d, d[:8]])                                                           # wrap for arcs of 9
+    arc_min = np.stack([d2[k:k + 9].min(axis=0) for k in range(16)]).max(axis=0)              # darker-ring margin
+    arc_max = np.stack([(-d2[k:k + 9]).min(axis=0) for k in range(16)]).max(axis=0)           # brighter-ring margin
+    m = np.maximum(arc_min, arc_max)
+    corner = m > t
+    score[3:h - 3, 3:w - 3] = np.where(corner, m - 1, 0).astype(np.uint8)
+    return score
+
+
+def fast_keypoints(img: np.ndarray, t: int) -> np.ndarray:
+    s = fast_score_map(img, t).astype(np.int32)
+    h, w = s.shape
+    p = np.pad(s, 1)
+    nb = [p[1 + dy:1 + dy + h, 1 + dx:1 + dx + w] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dy, dx) != (0, 0)]
+    keep = np.ones_like(s, bool)
+    for n in nb:
+        keep &= s > n
+    keep[:3] = False; keep[h - 3:] = False; keep[:, :3] = False; keep[:, w - 3:] = False
+    ys, xs = np.nonzero(keep)                      # raster order
+    return np.stack([xs, ys, s[ys, xs]], axis=1).astype(np.int32)
+
+
+def retain_best(k: np.ndarray, min_thr: int, max_num: int, min_num: int, factor: float) -> np.ndarray:
+    hist = np.bincount(np.clip(k[:, 2], 0, 255), minlength=256)
+    cum = np.cumsum(hist[::-1])[::-1]              # cum[i] = #{resp >= i}
+    mnt = min_thr
+    for i in range(255, min_thr - 1, -1):
+        if cum[i] >= min_num:
+            mnt = i
+            break
+    lower = max(int(np.float32(mnt) * np.float32(factor)), min_thr)
+    cut = lower
+    for i in range(255, lower - 1, -1):
+        if cum[i] >= max_num:
+            cut = i
+            break
+    return k[k[:, 2] >= cut]
+
+
+def anms(k: np.ndarray, keep: int, thr: int, P: dict) -> np.ndarray:
+    n = len(k)
+    if keep > n:
+        return k
+    x, y, s = k[:, 0].astype(int), k[:, 1].astype(int), k[:, 2].astype(np.float32)
+    minX, maxX, minY, maxY = x.min(), x.max(), y.min(), y.max()
+    nx, ny = P["cells_x"], P["cells_y"]
+    hi = np.float32(P["strong_response"]) - np.float32(thr)
+    val = np.clip(np.float32(s.min()) - np.float32(thr), np.float32(0), hi)
+    rng = max(np.float32(0), np.float32(P["max_robust"]) - np.float32(P["min_robust"]))
+    rf = np.float32(P["max_robust"]) - (val / np.float32(P["strong_response"] - thr)) * rng
+    cells: dict = {}
+    cxs = (x - minX) * nx // (maxX + 1 - minX); cys = (y - minY) * ny // (maxY + 1 - minY)
+    for i in range(n):
+        cells.setdefault((cxs[i], cys[i]), []).append(i)
+    gmax = int(float(maxX - minX) * float(maxY - minY) / float(keep))
+    md = min(max((maxX - minX) // nx, 1), max((maxY - minY) // ny, 1)) ** 2
+    r = np.zeros(n, np.int64)
+    for i in range(n):
+        si = np.float32(s[i] * rf + np.float32(0.002))
+        minr = gmax
+        d = 0
+        while max(0, d - 1) ** 2 * md < minr:
+            for yy in range(-d, d + 1):
+                for xx in range(-d, d + 1):
+                    if max(abs(xx), abs(yy)) != d:
+                        continue
+                    for j in cells.get((cxs[i] + xx, cys[i] + yy), ()):
+                        if s[j] > si:
+                            minr = min(minr, (x[i] - x[j]) ** 2 + (y[i] - y[j]) ** 2)
+            d += 1
+        r[i] = minr
+    order = np.lexsort((np.arange(n), -s, -r))     # r desc, strength desc, idx asc
+    return k[order[:keep]]
+
+
+def gaussian_taps(ksize: int) -> np.ndarray:
+    xs = np.arange(ksize) - (ksize - 1) * 0.5
+    cf = np.exp(-0.5 / 4.0 * xs * xs).astype(np.float32)
+    inv = 1.0 / float(np.sum(cf.astype(np.float64)))
+    cf = (cf.astype(np.float64) * inv).astype(np.float32)
+    return np.rint(cf.astype(np.float64) * 256.0).astype(np.int64)
+
+
+def blur(img: np.ndarray, ksize: int) -> np.ndarray:
+    t = gaussian_taps(ksize)
+    a = correlate1d(img.astype(np.int64), t, axis=1, mode="mirror")
+    b = correlate1d(a, t, axis=0, mode="mirror")
+    return np.minimum((b + 32768) >> 16, 255).astype(np.uint8)
+
+
+def expand_pattern(base: np.ndarray) -> np.ndarray:
+    out = np.zeros((30, 512, 2), np.int64)
+    b = base.reshape(512, 2).astype(np.float64)
+    for k in range(30):
+        a = np.deg2rad(12.0 * k)
+        v = np.stack([b[:, 0] * np.cos(a) - b[:, 1] * np.sin(a), b[:, 0] * np.sin(a) + b[:, 1] * np.cos(a)], axis=1)
+        hv = np.rint(v * 2) / 2
+        v = np.where(np.abs(v - hv) < 1e-9, hv, v)
+        out[k] = np.rint(v)
+    return out
+
+
+def detect(img: np.ndarray, base_pattern: np.ndarray, **kw):
+    P = dict(DEFAULTS); P.update(kw)
+    h, w = img.shape
+    k = fast_keypoints(img, P["fast_threshold"])
+    b = P["patch_size"] // 2
+    if h <= 2 * b or w <= 2 * b:
+        k = k[:0]
+    else:
+        k = k[(k[:, 0] >= b) & (k[:, 0] < w - b) & (k[:, 1] >= b) & (k[:, 1] < h - b)]
+    if len(k) > P["nfeatures"]:
+        k = retain_best(k, P["fast_threshold"], int(np.float32(P["nfeatures"]) * np.float32(P["feature_factor"])), P["nfeatures"], P["feature_strength"])
+        k = anms(k, P["nfeatures"], P["fast_threshold"], P)
+    bl = blur(img, P["gaussian_kernel_size"]) if P["gaussian_kernel_size"] > 1 else img
+    pat = expand_pattern(base_pattern)[0].reshape(256, 4)
+    xs, ys = k[:, 0][:, None], k[:, 1][:, None]
+    t0 = bl[ys + pat[None, :, 1], xs + pat[None, :, 0]]
+    t1 = bl[ys + pat[None, :, 3], xs + pat[None, :, 2]]
+    bits = (t0 < t1).astype(np.uint8).reshape(len(k), 32, 8)
+    desc = np.packbits(bits, axis=2, bitorder="little").reshape(len(k), 32)
+    return k, desc, bl
+
+
+def hamming_matrix(A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    a = np.unpackbits(A.reshape(-1, 32), axis=1).astype(np.int32)
+    b = np.unpackbits(B.reshape(-1, 32), axis=1).astype(np.int32)
+    return a @ (1 - b).T + (1 - a) @ b.T
+
+
+def match(A: np.ndarray, B: np.ndarray, max_dist=30, min_diff=1):
+    if len(A) == 0 or len(B) == 0:
+        return np.zeros((0, 3), np.int64)
+    D = hamming_matrix(A, B)
+
+    def oneway(D):
+        best = np.full(D.shape[0], -1)
+        dist = np.zeros(D.shape[0], np.int64)
+        for q in range(D.shape[0]):
+            cand = np.nonzero(D[q] <= max_dist)[0]
+            if cand.size == 0:
+                continue
+            order = cand[np.argsort(D[q, cand], kind="stable")]
+            if cand.size > 1 and D[q, order[1]] - D[q, order[0]] < min_diff:
+                continue
+            best[q] = order[0]; dist[q] = D[q, order[0]]
+        return best, dist
+    f, fd = oneway(D)
+    g, _ = oneway(D.T)
+    out = [(q, f[q], fd[q]) for q in range(len(A)) if f[q] >= 0 and g[f[q]] == q]
+    return np.array(out, np.int64).reshape(-1, 3)

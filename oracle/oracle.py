@@ -44,6 +44,27 @@ _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 
+class OrbParams(C.Structure):
+    """OrbDetector ctor arguments (OpenCVModified.h:68-82); defaults = MageSettings.h:151-167."""
+    _fields_ = [("gaussian_kernel_size", C.c_uint), ("nfeatures", C.c_uint), ("scale_factor", C.c_float), ("nlevels", C.c_uint),
+                ("patch_size", C.c_uint), ("fast_threshold", C.c_uint), ("use_orientation", C.c_int), ("feature_factor", C.c_float),
+                ("feature_strength", C.c_float), ("strong_response", C.c_int), ("min_robust", C.c_float), ("max_robust", C.c_float),
+                ("cells_x", C.c_int), ("cells_y", C.c_int)]
+
+    @classmethod
+    def defaults(cls, **kw):
+        d = dict(gaussian_kernel_size=7, nfeatures=440, scale_factor=1.5, nlevels=1, patch_size=15, fast_threshold=4,
+                 use_orientation=0, feature_factor=1.5, feature_strength=0.9, strong_response=20, min_robust=1.1, max_robust=2.0,
+                 cells_x=32, cells_y=32)
+        d.update(kw)
+        return cls(**d)
+
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4"), ("class_id", "<i4")])      # cv::KeyPoint, 28 bytes
+DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])   # cv::DMatch
+
+
 def _declare(L: C.CDLL) -> None:
     L.bao_create.restype = C.c_void_p
     L.bao_create.argtypes = [C.c_int]
@@ -73,6 +94,21 @@ def _declare(L: C.CDLL) -> None:
     L.bao_set_cameras_bulk.argtypes = [C.c_void_p, C.c_size_t, _f32p, _f32p, _f32p, _u8p]
     L.bao_set_points_bulk.argtypes = [C.c_void_p, C.c_size_t, _f32p]
     L.bao_set_observations_bulk.argtypes = [C.c_void_p, C.c_size_t, _f32p, _u32p, _u32p, _f32p]
+    # ---- ORB / matching oracles
+    L.orbo_pattern_expand.argtypes = [C.c_int, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]
+    L.orbo_fast_score_map.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p]
+    L.orbo_fast_keypoints.restype = C.c_int
+    L.orbo_fast_keypoints.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, C.c_int]
+    L.orbo_select.restype = C.c_int
+    L.orbo_select.argtypes = [C.POINTER(OrbParams), _i32p, C.c_int, _i32p]
+    L.orbo_gaussian_taps.argtypes = [C.c_int, _i32p]
+    L.orbo_blur.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p]
+    L.orbo_detect.restype = C.c_int
+    L.orbo_detect.argtypes = [C.POINTER(OrbParams), _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, _u8p, C.c_int, C.POINTER(C.c_int), C.c_void_p]
+    L.mto_hamming256.restype = C.c_int
+    L.mto_hamming256.argtypes = [_u8p, _u8p]
+    L.mto_match.restype = C.c_int
+    L.mto_match.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.bao_test_se3_exp.argtypes = [_f64p, _f64p]
     L.bao_test_ldlt.restype = C.c_int
     L.bao_test_ldlt.argtypes = [_f64p, C.c_int, _f64p, _f64p]
@@ -188,3 +224,32 @@ def load_scene_bulk(bundler: OracleBundler, scene) -> None:
     L.bao_set_observations_bulk(bundler._h, scene.n_obs, np.ascontiguousarray(scene.obs_uv, np.float32).reshape(-1),
                                 np.ascontiguousarray(scene.obs_cam, np.uint32), np.ascontiguousarray(scene.obs_pt, np.uint32),
                                 np.ascontiguousarray(scene.obs_info, np.float32))
+
+
+def orb_detect(img: np.ndarray, params: OrbParams = None, cap: int = None, want_blur: bool = False):
+    """oracle/orb_oracle.c orbo_detect: returns (keypoints[KEYPOINT_DTYPE], descriptors[n,32] u8[, blurred])."""
+    L = lib()
+    params = params or OrbParams.defaults()
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = cap if cap is not None else int(params.nfeatures)
+    kps = np.zeros(max(cap, 1), KEYPOINT_DTYPE)
+    desc = np.zeros((max(cap, 1), 32), np.uint8)
+    blur = np.zeros((h, w), np.uint8) if want_blur else None
+    n = C.c_int(0)
+    rc = L.orbo_detect(C.byref(params), img, w, h, w, kps.ctypes.data_as(C.c_void_p), desc.reshape(-1), cap, C.byref(n),
+                       blur.ctypes.data_as(C.c_void_p) if want_blur else None)
+    if rc != 0:
+        raise NotImplementedError(f"orbo_detect rc={rc}")
+    out = (kps[: n.value].copy(), desc[: n.value].copy())
+    return out + (blur,) if want_blur else out
+
+
+def match(A: np.ndarray, B: np.ndarray, max_dist: int = 30, min_diff: int = 1) -> np.ndarray:
+    """oracle/match_oracle.c mto_match on gathered descriptor sets; returns DMATCH_DTYPE array."""
+    L = lib()
+    A = np.ascontiguousarray(A, np.uint8).reshape(-1, 32); B = np.ascontiguousarray(B, np.uint8).reshape(-1, 32)
+    out = np.zeros(max(len(A), 1), DMATCH_DTYPE)
+    n = L.mto_match(A.reshape(-1) if len(A) else np.zeros(1, np.uint8), len(A), B.reshape(-1) if len(B) else np.zeros(1, np.uint8), len(B),
+                    int(max_dist), int(min_diff), out.ctypes.data_as(C.c_void_p), len(out))
+    return out[:n].copy()

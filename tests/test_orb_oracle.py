@@ -1,0 +1,123 @@
+"""CPU tests (no GPU): the C ORB / matcher oracles against the golden fixtures (independent numpy implementation),
+the pattern-table hashes, and definition-level known answers."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from mageslam_amd import frames
+from oracle import oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_frames.npz")
+CASES = ["orb_64x48", "orb_160x120", "orb_640x480_a", "orb_640x480_b"]
+PATTERN_SHA = {31: "88c8c823934e8e0e2ad52ec5ebe2fc190e88b6a37454425c0c8ae89e12ea6fc4",
+               15: "3f89de51d9a4f90721503b1467310d1aac4180c727231013b613a991f5763c61"}
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLDEN)
+
+
+def kp_xyr(k):
+    return np.stack([k["x"], k["y"], k["response"]], axis=1).astype(np.int64)
+
+
+@pytest.mark.parametrize("patch", [15, 31])
+def test_expanded_pattern_tables_match_reference_hash(patch):
+    """30 x 1024 pre-rotated table regenerated from the 0-degree row == the reference's table (SHA-256 taken in-container)."""
+    t = np.zeros(30720, np.int8)
+    O.lib().orbo_pattern_expand(patch, t)
+    assert hashlib.sha256(t.tobytes()).hexdigest() == PATTERN_SHA[patch]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_golden(gold, name):
+    img = gold[name + "_img"]
+    k, d, bl = O.orb_detect(img, want_blur=True)
+    assert np.array_equal(kp_xyr(k), gold[name + "_kp"])
+    assert np.array_equal(d, gold[name + "_desc"])
+    assert hashlib.sha256(bl.tobytes()).hexdigest() == str(gold[name + "_blursha"])
+    assert np.all(k["angle"] == 0) and np.all(k["size"] == 15) and np.all(k["octave"] == 0) and np.all(k["class_id"] == -1)
+
+
+def test_matcher_oracle_matches_golden(gold):
+    m = O.match(gold["orb_640x480_a_desc"], gold["orb_640x480_b_desc"], 30, 1)
+    got = np.stack([m["queryIdx"], m["trainIdx"], m["distance"].astype(np.int64)], axis=1)
+    assert np.array_equal(got, gold["matches_ab"])
+    assert np.all(np.diff(m["queryIdx"]) > 0) and np.all(m["imgIdx"] == -1)
+
+
+def test_fast_against_literal_definition():
+    """Brute force: corner iff some 9 contiguous ring pixels are all > I+t or all < I-t; score = largest t' keeping it a corner."""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (24, 31)).astype(np.uint8)
+    img[8:16, 10:20] = 200                                    # some structure
+    t = 12
+    score = np.zeros_like(img)
+    O.lib().orbo_fast_score_map(img, 31, 24, 31, t, score)
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+    def is_corner(y, x, thr):
+        v = int(img[y, x]); r = [int(img[y + dy, x + dx]) for dx, dy in ring]
+        for s in range(16):
+            arc = [r[(s + i) % 16] for i in range(9)]
+            if all(a > v + thr for a in arc) or all(a < v - thr for a in arc):
+                return True
+        return False
+    for y in range(24):
+        for x in range(31):
+            inside = 3 <= y < 24 - 3 and 3 <= x < 31 - 3
+            if not inside or not is_corner(y, x, t):
+                assert score[y, x] == 0
+            else:
+                best = max(tt for tt in range(t, 256) if is_corner(y, x, tt))
+                assert score[y, x] == best
+
+
+def test_hamming_swar_equals_bit_count():
+    rng = np.random.default_rng(5)
+    L = O.lib()
+    for _ in range(200):
+        a = rng.integers(0, 256, 32).astype(np.uint8); b = rng.integers(0, 256, 32).astype(np.uint8)
+        ref = sum(bin(int(x) ^ int(y)).count("1") for x, y in zip(a, b))
+        assert L.mto_hamming256(a, b) == ref
+    z = np.zeros(32, np.uint8); o = np.full(32, 255, np.uint8)
+    assert L.mto_hamming256(z, z) == 0 and L.mto_hamming256(z, o) == 256
+
+
+def test_blur_taps_and_constant_image():
+    taps = np.zeros(7, np.int32)
+    O.lib().orbo_gaussian_taps(7, taps)
+    assert taps.tolist() == [18, 34, 49, 55, 49, 34, 18]
+    img = np.full((20, 33), 100, np.uint8)
+    out = np.zeros_like(img)
+    O.lib().orbo_blur(img, 33, 20, 33, 7, out)
+    assert np.all(out == (100 * 257 * 257 + 32768) >> 16)     # taps sum to 257: a known, documented gain of the 8-bit path
+
+
+def test_edge_cases():
+    # image smaller than the FAST ring / the patch border: no keypoints, no crash
+    for shape in ((5, 5), (14, 40), (40, 14), (1, 1)):
+        k, d = O.orb_detect(np.zeros(shape, np.uint8))
+        assert len(k) == 0
+    # capacity truncation (ImageData::Insert)
+    a = frames.make_frame(7)
+    k, d = O.orb_detect(a, cap=100)
+    k2, d2 = O.orb_detect(a)
+    assert len(k) == 100 and np.array_equal(kp_xyr(k), kp_xyr(k2)[:100]) and np.array_equal(d, d2[:100])
+    # matcher: empty sides, ties reject, minDiff = 0 takes the lowest index
+    e = np.zeros((0, 32), np.uint8)
+    d = np.zeros((3, 32), np.uint8)
+    assert len(O.match(e, d)) == 0 and len(O.match(d, e)) == 0
+    assert len(O.match(d, d, 30, 1)) == 0                      # all distances tie at 0 -> every query rejected
+    m = O.match(d, d, 30, 0)
+    assert m["queryIdx"].tolist() == [0] and m["trainIdx"].tolist() == [0]
+
+
+def test_unsupported_settings_are_refused():
+    a = np.zeros((64, 64), np.uint8)
+    for kw in (dict(nlevels=2), dict(use_orientation=1), dict(patch_size=21)):
+        with pytest.raises(NotImplementedError):
+            O.orb_detect(a, O.OrbParams.defaults(**kw))
