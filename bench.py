@@ -65,25 +65,22 @@ def main() -> int:
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from mageslam_amd import dist as D
+    info = D.rank_info()
+    rank, local_rank, world = info.rank, info.local_rank, info.world
     if args.gpus != world and world > 1:
         print(f"--gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X: torch.cuda.is_available() is False", file=sys.stderr)
         return 2
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dist = D.init("nccl", info)                     # "nccl" is RCCL on ROCm; None when world == 1
 
     from mageslam_amd import scene
     from mageslam_amd.bundler import BundlerLib, load_scene
 
     kw = dict(WORKLOADS[args.workload])
-    kw["seed"] = kw["seed"] + 0x100 * rank          # independent sub-map per rank
+    kw["seed"] = D.submap_seed(kw["seed"], rank)    # independent sub-map per rank (weak scaling, no data-path collective)
     s = scene.make_scene(**kw)
     b = BundlerLib(False, device=local_rank)
     load_scene(b, s, bulk=True)
@@ -106,14 +103,11 @@ def main() -> int:
         trials += sum(t["trials"] for t in b.trace())
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, total_steps, worst_rmse = D.reduce_stats(dist, elapsed, args.steps, float(np.sqrt(mse)), device="cuda")
     prof = b.profile()
 
     if rank == 0:
-        value = world * args.steps / elapsed
+        value = total_steps / elapsed
         nfac = max(int(prof.n_factorizations), 1)
         fac_ms = prof.factor_ms_total / nfac
         flops = prof.factor_flops_each
@@ -123,7 +117,7 @@ def main() -> int:
             "value": value, "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "final_reproj_rmse_px": float(np.sqrt(mse)),
+            "final_reproj_rmse_px": worst_rmse,
             "trials_per_iteration": trials / max(args.steps, 1),
             "config": {"workload": f"{args.workload}: {kw['n_cams']} poses / {kw['n_pts']} points / {kw['n_obs']} observations, "
                                    f"Huber {HUBER}, poses 0,1 fixed, one independent sub-map per GPU",
@@ -138,7 +132,7 @@ def main() -> int:
                 "schur_ms_per_launch": prof.schur_ms_total / max(int(prof.schur_launches), 1),
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0, N = 1 only
             try:
                 line["cpu_baseline"] = cpu_baseline(args.workload)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number

@@ -1,0 +1,125 @@
+// BundlerLib.h -- C++ shim with the reference's class name and method names over the MI355X C ABI (mage_ba.h).
+//
+// Drop-in for Dependencies/BundlerLib/Include/BundlerLib.h:15-66: MAGE-SLAM's callers
+// (Core/MAGESLAM/Source/BundleAdjustment/BundleAdjust.cpp:25-236, Tracking/TrackLocalMap.cpp:439-494) compile against
+// this header unchanged and link libmageslam_hip.so instead of BundlerLib + g2o.  The reference passes
+// Eigen::Map<> / gsl::span<> views; those types are templates over raw pointers, so the shim takes anything that
+// exposes .data() (Eigen::Map, gsl::span, std::array, std::vector) plus .size() for spans -- when Eigen / GSL are on the
+// include path the original call sites bind to these overloads as written; without them the raw-pointer overloads work.
+//
+// Error behaviour: the reference asserts / throws gsl::narrowing_error; the shim throws std::runtime_error carrying
+// mage_last_error() when the C ABI reports a failure.  Tether constraints (BundlerLib.h:40-47) are accepted with a
+// count of zero and otherwise throw (MAGE_ERR_UNSUPPORTED): SURVEY.md section 8f rank 1.
+#pragma once
+
+#include <cstddef>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mage_ba.h"
+
+namespace mage
+{
+    struct BundlerParameters
+    {
+        bool ArePointsFixed{ false };        // True if map points should not be optimized
+    };
+
+    class BundlerLib
+    {
+    public:
+        explicit BundlerLib(const BundlerParameters& bundlerParameters, int device = -1)
+            : m_bundlerParameters(bundlerParameters)
+        {
+            mage_ba_params p{ bundlerParameters.ArePointsFixed ? 1 : 0, device };
+            mage_ba* h = nullptr;
+            Check(mage_ba_create(&p, &h));
+            m_impl.reset(h);
+        }
+        ~BundlerLib() = default;
+        BundlerLib(const BundlerLib&) = delete;
+        BundlerLib& operator=(const BundlerLib&) = delete;
+
+        void AllocateCameras(size_t count) { Check(mage_ba_alloc_cameras(m_impl.get(), count)); }
+
+        // position: 3 floats; orientation: 3x3 column-major rotation (world -> camera); intrinsics: cx, cy, fx, fy
+        template <typename V3, typename M3, typename V4>
+        void SetCameraPose(size_t idx, const V3& position, const M3& orientation, const V4& intrinsics, bool isFixed)
+        {
+            Check(mage_ba_set_camera(m_impl.get(), idx, position.data(), orientation.data(), intrinsics.data(), isFixed ? 1 : 0));
+        }
+        void SetCameraPose(size_t idx, const float* position, const float* orientationColMajor, const float* intrinsics, bool isFixed)
+        {
+            Check(mage_ba_set_camera(m_impl.get(), idx, position, orientationColMajor, intrinsics, isFixed ? 1 : 0));
+        }
+
+        void FixCameraPose(size_t idx, bool value) { Check(mage_ba_fix_camera(m_impl.get(), idx, value ? 1 : 0)); }
+
+        void AllocateMapPoints(size_t count) { Check(mage_ba_alloc_points(m_impl.get(), count)); }
+        template <typename V3>
+        void SetMapPoint(size_t idx, const V3& point) { Check(mage_ba_set_point(m_impl.get(), idx, point.data())); }
+        void SetMapPoint(size_t idx, const float* point) { Check(mage_ba_set_point(m_impl.get(), idx, point)); }
+
+        void AllocateObservations(size_t count) { Check(mage_ba_alloc_observations(m_impl.get(), count)); }
+        template <typename V2>
+        void SetObservation(size_t idx, const V2& position, size_t cameraIndex, size_t mapPointIndex, float informationMatrixScalar)
+        {
+            Check(mage_ba_set_observation(m_impl.get(), idx, position.data(), cameraIndex, mapPointIndex, informationMatrixScalar));
+        }
+        void SetObservation(size_t idx, const float* position, size_t cameraIndex, size_t mapPointIndex, float informationMatrixScalar)
+        {
+            Check(mage_ba_set_observation(m_impl.get(), idx, position, cameraIndex, mapPointIndex, informationMatrixScalar));
+        }
+
+        void AllocateFixedDistanceConstraints(size_t count) { Check(mage_ba_alloc_fixed_distance_constraints(m_impl.get(), count)); }
+        void AllocateRelativeRotationConstraints(size_t count) { Check(mage_ba_alloc_relative_rotation_constraints(m_impl.get(), count)); }
+        void AllocateRelativeTransformConstraints(size_t count) { Check(mage_ba_alloc_relative_transform_constraints(m_impl.get(), count)); }
+
+        void SetCurrentLambda(float userLambda) { Check(mage_ba_set_lambda(m_impl.get(), userLambda)); }
+        float GetCurrentLambda() const { float v = 0; Check(mage_ba_get_lambda(m_impl.get(), &v)); return v; }
+
+        // Runs an iteration of the solver for each provided Huber width.  Returns the average square error.
+        // `huberWidthPerIteration` is anything with data()/size() (gsl::span<const float>, std::vector<float>).
+        template <typename Span>
+        float StepBundleAdjustment(const Span& huberWidthPerIteration, float maxErrorSquare, std::vector<unsigned int>& outliers)
+        {
+            return StepBundleAdjustment(huberWidthPerIteration.data(), static_cast<size_t>(huberWidthPerIteration.size()), maxErrorSquare, outliers);
+        }
+        float StepBundleAdjustment(const float* huberWidths, size_t count, float maxErrorSquare, std::vector<unsigned int>& outliers)
+        {
+            // the reference appends to `outliers`; the number of new entries is only known after the call
+            size_t n = 0;
+            float mse = 0;
+            const size_t old = outliers.size();
+            std::vector<uint32_t> buf(m_scratch < 64 ? 64 : m_scratch);
+            Check(mage_ba_step(m_impl.get(), huberWidths, count, maxErrorSquare, buf.data(), buf.size(), &n, &mse));
+            if (n > buf.size()) throw std::runtime_error("BundlerLib: outlier buffer too small; call ReserveOutliers(n_observations) first");
+            outliers.resize(old + n);
+            for (size_t i = 0; i < n; ++i) outliers[old + i] = buf[i];
+            return mse;
+        }
+        // capacity hint for the outlier list of one StepBundleAdjustment call (= the observation count is always enough)
+        void ReserveOutliers(size_t count) { m_scratch = count; }
+
+        template <typename V3, typename M3>
+        void GetPose(size_t idx, V3&& position, M3&& orientation) const { Check(mage_ba_get_pose(m_impl.get(), idx, position.data(), orientation.data())); }
+        void GetPose(size_t idx, float* position, float* orientationColMajor) const { Check(mage_ba_get_pose(m_impl.get(), idx, position, orientationColMajor)); }
+        template <typename V3>
+        void GetPoint(size_t idx, V3&& position) const { Check(mage_ba_get_point(m_impl.get(), idx, position.data())); }
+        void GetPoint(size_t idx, float* position) const { Check(mage_ba_get_point(m_impl.get(), idx, position)); }
+
+        mage_ba* Handle() const { return m_impl.get(); }   // for the bulk setters of mage_ba.h
+
+    private:
+        static void Check(mage_status s)
+        {
+            if (s != MAGE_OK) throw std::runtime_error(std::string("mage::BundlerLib: ") + mage_last_error());
+        }
+        struct Deleter { void operator()(mage_ba* h) const { mage_ba_destroy(h); } };
+        std::unique_ptr<mage_ba, Deleter> m_impl;
+        BundlerParameters m_bundlerParameters;
+        size_t m_scratch{ 0 };
+    };
+}

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Config 2 of BASELINE.json: ORB FAST+BRIEF extraction and 256-bit Hamming brute-force matching on 640x480 synthetic
+frames, 1x MI355X vs the CPU oracle.  Frames / descriptors are resident in HBM when the timed region starts.
+Prints one JSON line per batch size."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from mageslam_amd import frames  # noqa: E402
+from mageslam_amd.orb import Matcher, OrbDetector  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+W, H, CAP = 640, 480, 440
+HBM_PEAK = 8.0e12
+
+
+def main():
+    base = [frames.frame_pair(500 + i) for i in range(8)]
+    a_set = np.stack([p[0] for p in base]); b_set = np.stack([p[1] for p in base])
+    det, mt = OrbDetector(), Matcher()
+    # CPU oracle baseline (1 thread)
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < 3.0:
+        O.orb_detect(a_set[n % 8]); n += 1
+    cpu_fps = n / (time.perf_counter() - t0)
+    ka, da = O.orb_detect(a_set[0]); kb, db = O.orb_detect(b_set[0])
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < 3.0:
+        O.match(da, db); n += 1
+    cpu_pps = n / (time.perf_counter() - t0)
+    for batch in (1, 64, 1024):
+        imgs = torch.from_numpy(np.concatenate([a_set, b_set])[np.arange(2 * batch) % 16]).cuda().contiguous()   # 2*batch frames: A then B interleaved by 8s
+        torch.cuda.synchronize()
+        for _ in range(2):
+            kp, de, cn = det.detect_batch_device(imgs.data_ptr(), 2 * batch, W, H, CAP)
+        reps = 20 if batch < 1024 else 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            kp, de, cn = det.detect_batch_device(imgs.data_ptr(), 2 * batch, W, H, CAP)
+        wall = (time.perf_counter() - t0) / reps
+        p = det.profile()
+        fps = 2 * batch / wall
+        alg_bytes = 2 * batch * (W * H * 3 + CAP * 512 + CAP * 60)      # FAST read, blur read+write, BRIEF gathers, outputs
+        # matching: first `batch` frames against the second `batch` frames, descriptors stay in HBM
+        dA, cA = de, cn
+        dB, cB = de + batch * CAP * 32, cn + batch * 4
+        for _ in range(2):
+            mt.match_batch_device(batch, dA, cA, CAP, dB, cB, CAP, 30, 1)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            mt.match_batch_device(batch, dA, cA, CAP, dB, cB, CAP, 30, 1)
+        mwall = (time.perf_counter() - t0) / reps
+        line = {"config": f"ORB+match 640x480, batch {batch} pairs", "frames_per_s": fps, "orb_ms_per_batch": wall * 1e3,
+                "orb_stage_ms": {"fast": p.fast_ms, "nms_select": p.select_ms, "blur": p.blur_ms, "brief": p.brief_ms, "total_events": p.total_ms},
+                "orb_hbm_frac_algorithmic": alg_bytes / (p.total_ms * 1e-3) / HBM_PEAK,
+                "pairs_per_s": batch / mwall, "match_kernel_ms": mt.last_kernel_ms(), "match_gdist_per_s": batch * 2 * CAP * CAP / (mt.last_kernel_ms() * 1e-3) / 1e9,
+                "cpu_oracle_frames_per_s": cpu_fps, "cpu_oracle_pairs_per_s": cpu_pps, "cpu_cores": 1}
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()
