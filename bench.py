@@ -112,6 +112,13 @@ def main() -> int:
         fac_ms = prof.factor_ms_total / nfac
         flops = prof.factor_flops_each
         achieved = flops / (fac_ms * 1e-3) / 1e12 if fac_ms > 0 else 0.0
+        traffic = None
+        try:   # HBM bytes per factorisation from the committed PMC passes (tools/pmc_to_traffic.py); same padded order only
+            tj = json.load(open(os.path.join(ROOT, "profiles", "chol_traffic.json")))
+            if int(tj.get("n_pad", -1)) == int(prof.padded_order):
+                traffic = float(tj["bytes_per_factorization"])
+        except Exception:
+            traffic = None
         line = {
             "metric": "LM iterations/sec + final reproj RMSE, 1k poses / 100k pts / 1M obs synthetic BA",
             "value": value, "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -126,7 +133,8 @@ def main() -> int:
                 "kernel": "dense reduced-camera Cholesky (k_potrf_diag + k_trsm_panel + k_syrk_update[f64 MFMA] + k_bsolve_step), "
                           "HIP-event span per factorisation on the solver stream",
                 "bound": "mfma", "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_note": "HBM bytes per factorisation, (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/chol_traffic.json)",
                 "flops_per_launch": flops, "ms_per_launch": fac_ms, "launches": int(prof.n_factorizations),
                 "system_order": int(prof.system_order), "padded_order": int(prof.padded_order),
                 "schur_ms_per_launch": prof.schur_ms_total / max(int(prof.schur_launches), 1),
