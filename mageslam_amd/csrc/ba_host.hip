@@ -122,6 +122,7 @@ struct mage_ba {
     DevBuf<int2> d_blk_ij, d_con;
     DevBuf<double> d_errL, d_U, d_bc, d_V, d_bp, d_W, d_Dinv, d_db, d_S, d_y, d_xc, d_xl, d_partial, d_scal, d_Linv;
     DevBuf<uint8_t> d_flagL;
+    DevBuf<int> d_queue;
     double* h_scal = nullptr;           // pinned mirror of d_scal
     BaDeviceView view{};
     std::vector<uint32_t> L_edge_host;  // landmark-order position -> observation index
@@ -384,6 +385,8 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(h->d_partial.reserve(std::max<size_t>(3 * 1024, (size_t)nb_l + nb_c) + 16));
     MAGE_TRY(h->d_scal.reserve(SC_COUNT));
     MAGE_TRY(h->d_Linv.reserve(chol_workspace_doubles(n_pad)));
+    if (n_pad > CHOL_MAX_ORDER) return fail(MAGE_ERR_UNSUPPORTED, "reduced camera system of order %d exceeds %d (one resident workgroup per tile column)", n_pad, CHOL_MAX_ORDER);
+    MAGE_TRY(h->d_queue.reserve(chol_sync_ints(n_pad)));
     MAGE_TRY(h->d_flagL.reserve((size_t)nL + 1));
     if (!h->h_scal) MAGE_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), SC_COUNT * sizeof(double)));
     MAGE_HIP(hipMemsetAsync(h->d_errL.p, 0, ((size_t)nL * 2 + 2) * sizeof(double), st));
@@ -436,7 +439,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
     }
     double rho = 0;
     int qmax = 0;
-    CholWorkspace ws{ h->d_Linv.p };
+    CholWorkspace ws{ h->d_Linv.p, h->d_queue.p };
     do {
         const double lambda = h->lambda;
         if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[0], st));
@@ -524,6 +527,7 @@ MAGE_EXPORT mage_status mage_ba_create(const mage_ba_params* params, mage_ba** o
         MAGE_HIP(hipSetDevice(dev));
         MAGE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         for (auto& e : h->ev) MAGE_HIP(hipEventCreate(&e));
+        chol_init_device();
         *out = h.release();
         return MAGE_OK;
     });

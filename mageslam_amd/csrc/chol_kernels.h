@@ -8,8 +8,12 @@ constexpr int CHOL_TILE = 128;
 
 struct CholWorkspace {
     double* Linv;      // chol_workspace_doubles(n_pad): inverses of the 16x16 diagonal blocks of L, per tile
+    int* sync;         // chol_sync_ints(n_pad) ints: [0] arrival counter of the split diagonal tile, [1..nt] x_k-ready flags
 };
 size_t chol_workspace_doubles(int n_pad);
+inline size_t chol_sync_ints(int n_pad) { return (size_t)(n_pad / CHOL_TILE) + 2; }
+constexpr int CHOL_MAX_ORDER = 256 * CHOL_TILE;   // the persistent backward solve needs one resident workgroup per tile column
+void chol_init_device();   // once per device (after hipSetDevice): opt the LDS-heavy kernels in
 
 // Factor S = L L^T in place (lower triangle, column-major, n_pad multiple of CHOL_TILE) and solve
 // S x = y.  y is overwritten by the forward-substituted rhs, x receives the solution.  *ok (device

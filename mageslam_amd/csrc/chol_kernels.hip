@@ -12,7 +12,7 @@
 //     k_trsm_panel   : L_ik = S_ik L_kk^-T for i > k, and the rhs row  y_k = L_kk^-1 y_k
 //     k_syrk_update  : S_ij -= L_ik L_jk^T  (i >= j > k), and  y_i -= L_ik y_k
 // so the forward substitution rides along with the factorisation (the rhs is one more matrix row).
-// The backward substitution L^T x = y is k_bsolve_step, one launch per tile column.
+// The backward substitution L^T x = y is k_bsolve_persist, one persistent launch.
 //
 // All O(n^3) work is on the f64 matrix cores (v_mfma_f64_16x16x4_f64, 64 cycles / instruction / SIMD).
 // Two properties of that instruction shape the kernels:
@@ -22,6 +22,7 @@
 //     (register r = rows 4r..4r+3 = the r-th K-chunk).  Every triangular solve below is written on the
 //     transposed unknown (Y = X^T) so that results chain from MFMA to MFMA without leaving registers.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "chol_kernels.h"
 
 namespace mage {
@@ -222,9 +223,10 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int 
 // solves the rhs row y_k with the same code (a strip with one live row).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
-                                                   const double* __restrict__ Linv_k)
+                                                   const double* __restrict__ Linv_k, int* __restrict__ queue, int queue_start)
 {
     const int lane = threadIdx.x;
+    if (blockIdx.x == 0 && lane == 0) *queue = queue_start;     // work queue of the trailing update that follows this launch
     const int n_strips = (nt - k - 1) * NBLK;
     const bool is_rhs = (int)blockIdx.x == n_strips;
     double* base;          // element (n = strip row, col) lives at base[col * cstride]; for the rhs strip only n == 0 exists
@@ -286,59 +288,14 @@ __global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, doubl
 // accumulator's lane&15 direction is the memory-contiguous one; the accumulators are initialised
 // with the C tile and the panel enters negated, so the epilogue is a plain store.
 // ---------------------------------------------------------------------------------------------
-// WAVES = 4, SUB = 4: one workgroup per 128x128 tile, 64x64 per wavefront (bulk of the update).
-// WAVES = 1, SUB = 2: one single-wave workgroup per 32x32 sub-block (16 per tile), whole K range loaded
-// up front -- used for the look-ahead update of the next panel's block column, where only a few tiles
-// exist and latency matters more than operand sharing.
-// Tiles covered: single_col ? {(i, j0) : j0 <= i < nt} : {(i, j) : j0 <= j <= i < nt}.  Extra blocks at the
-// end of the grid apply the rhs update y_i -= L_ik y_k for i = k+1 ..
-template <int WAVES, int SUB, int KSTEPS>
-__global__ __launch_bounds__(WAVES * 64) void k_syrk_update(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
-                                                            int j0, int single_col, double* __restrict__ Linv_next, double* __restrict__ ok)
+// out[a][b][r] = C - sum_k L(col0.., k) L(row0.., k)^T for the (16 SUB) x (16 SUB) block whose first element is
+// S(row0, col0); D layout: element (row0 + 16 b + (lane & 15), col0 + 16 a + (lane >> 4) + 4 r).
+template <int SUB, int KSTEPS>
+__device__ __forceinline__ void update_block(const double* __restrict__ S, int ld, int k, int row0, int col0, int lane, double4_t (&out)[SUB][SUB])
 {
-    // Linv_next != nullptr (WAVES == 4 only): workgroup 0 owns tile (j0, j0) -- the NEXT diagonal tile.  It keeps
-    // the updated tile on chip (registers -> LDS) and factors it right there, so the next panel's sequential
-    // diagonal factorisation overlaps with the other workgroups' share of this update instead of following it.
-    extern __shared__ double sm[];
-    constexpr int SPAN = SUB * 16;                                        // rows / cols per wavefront
-    constexpr int PER_TILE = (WAVES == 4) ? 1 : (TILE / SPAN) * (TILE / SPAN);   // workgroups per tile
-    static_assert(WAVES == 1 || (WAVES == 4 && SUB == 4), "unsupported decomposition");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int mt = nt - j0;
-    const int n_tiles = single_col ? mt : mt * (mt + 1) / 2;
-    const int n_blocks = n_tiles * PER_TILE;
-    if ((int)blockIdx.x >= n_blocks) {
-        // rhs row: y_i -= L_ik y_k
-        const int i = k + 1 + (blockIdx.x - n_blocks);
-        if (i >= nt) return;
-        const double* Lik = S + (size_t)(k * TILE) * ld + (size_t)i * TILE;
-        const double* yk = y + (size_t)k * TILE;
-        for (int r = tid; r < TILE; r += WAVES * 64) {
-            double acc = 0;
-#pragma unroll 8
-            for (int c = 0; c < TILE; ++c) acc = __builtin_fma(Lik[(size_t)c * ld + r], yk[c], acc);
-            y[(size_t)i * TILE + r] -= acc;
-        }
-        return;
-    }
-    const int t = blockIdx.x / PER_TILE;
-    const int sub = (WAVES == 4) ? (tid >> 6) : (blockIdx.x % PER_TILE);
-    int rt, ct;
-    if (single_col) { rt = t; ct = 0; }
-    else {
-        rt = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while ((rt + 1) * (rt + 2) / 2 <= t) ++rt;
-        while (rt * (rt + 1) / 2 > t) --rt;
-        ct = t - rt * (rt + 1) / 2;
-    }
-    const int ti = j0 + rt, tj = j0 + ct;
-    constexpr int PER_DIM = TILE / SPAN;
-    const int wn = sub % PER_DIM, wm = sub / PER_DIM;
-    // per-lane operand bases: element (panel column kk, row) at P[kk * ld + row]
-    const double* Pn = S + (size_t)(k * TILE + (lane >> 4)) * ld + (size_t)ti * TILE + wn * SPAN + (lane & 15);
-    const double* Pm = S + (size_t)(k * TILE + (lane >> 4)) * ld + (size_t)tj * TILE + wm * SPAN + (lane & 15);
-    double* C = S + (size_t)(tj * TILE + wm * SPAN + (lane >> 4)) * ld + (size_t)ti * TILE + wn * SPAN + (lane & 15);
-
+    const double* Pn = S + (size_t)(k * TILE + (lane >> 4)) * ld + row0 + (lane & 15);
+    const double* Pm = S + (size_t)(k * TILE + (lane >> 4)) * ld + col0 + (lane & 15);
+    const double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
     constexpr int NCH = TILE / (4 * KSTEPS);
     constexpr int NBUF = NCH > 1 ? 2 : 1;
     double av[NBUF][KSTEPS][SUB], bv[NBUF][KSTEPS][SUB];
@@ -347,10 +304,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_syrk_update(double* __restrict__
         for (int s4 = 0; s4 < KSTEPS; ++s4) {
             const size_t off = (size_t)(kc + s4 * 4) * ld;
 #pragma unroll
-            for (int q = 0; q < SUB; ++q) {
-                av[buf][s4][q] = Pm[off + q * 16];
-                bv[buf][s4][q] = Pn[off + q * 16];
-            }
+            for (int q = 0; q < SUB; ++q) { av[buf][s4][q] = Pm[off + q * 16]; bv[buf][s4][q] = Pn[off + q * 16]; }
         }
     };
     load_chunk(0, 0);
@@ -359,13 +313,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_syrk_update(double* __restrict__
     for (int a = 0; a < SUB; ++a)
 #pragma unroll
         for (int b = 0; b < SUB; ++b) acc[a][b] = (double4_t){ 0, 0, 0, 0 };
-
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int buf = ch % NBUF;
         if (ch + 1 < NCH) load_chunk((ch + 1) % NBUF, (ch + 1) * 4 * KSTEPS);
         else {
-            // last chunk: the C tile streams in behind the final MFMAs instead of in front of the first ones
+            // last chunk: the C block streams in behind the final MFMAs instead of in front of the first ones
 #pragma unroll
             for (int a = 0; a < SUB; ++a)
 #pragma unroll
@@ -381,80 +334,185 @@ __global__ __launch_bounds__(WAVES * 64) void k_syrk_update(double* __restrict__
                 for (int b = 0; b < SUB; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[buf][s4][a], bv[buf][s4][b], acc[a][b], 0, 0, 0);
     }
-    if (WAVES == 4 && Linv_next != nullptr && blockIdx.x == 0) {
-        double* A = sm;
-        double* Li = sm + TILE * LDC;
-#pragma unroll
-        for (int a = 0; a < SUB; ++a)
-#pragma unroll
-            for (int b = 0; b < SUB; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    A[(wm * SPAN + a * 16 + (lane >> 4) + 4 * r) * LDC + wn * SPAN + b * 16 + (lane & 15)] = cv[a][b][r] + acc[a][b][r];
-        __syncthreads();
-        const bool failed = potrf_tile_lds(A, Li, Linv_next, tid);
-        store_tile_lower(S + (size_t)(tj * TILE) * ld + (size_t)ti * TILE, A, ld, tid);
-        if (tid == 0 && failed) *ok = 0.0;
-        return;
-    }
 #pragma unroll
     for (int a = 0; a < SUB; ++a)
 #pragma unroll
-        for (int b = 0; b < SUB; ++b)
+        for (int b = 0; b < SUB; ++b) out[a][b] = cv[a][b] + acc[a][b];
+}
+
+// Grid of the trailing update of step k (tiles (i, j), j0 = k + 1 <= j <= i < nt):
+//   blocks 0..2   the three lower 64x64 quadrants of the NEXT diagonal tile (j0, j0), one 32x32 block per wavefront.
+//                 Block 0 keeps its quadrant in LDS, waits for the other two (release/acquire on `flag`), pulls them
+//                 into LDS and factors the tile in place -- the sequential diagonal factorisation of step k + 1
+//                 overlaps the rest of this update, and its own update is spread over three compute units.
+//   blocks 3..    one 128x128 tile each (tile index 1..), 64x64 per wavefront.
+//   last m blocks rhs update y_i -= L_ik y_k.
+__global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
+                                                     double* __restrict__ Linv_next, double* __restrict__ ok, int* __restrict__ flag)
+{
+    extern __shared__ double sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j0 = k + 1, mt = nt - j0;
+    const int n_tiles = mt * (mt + 1) / 2;
+    const int n_blocks = n_tiles + 2;                 // tile 0 is split over blocks 0..2
+    const int bid = blockIdx.x;
+    if (bid >= n_blocks) {
+        const int i = k + 1 + (bid - n_blocks);
+        if (i >= nt) return;
+        const double* Lik = S + (size_t)(k * TILE) * ld + (size_t)i * TILE;
+        const double* yk = y + (size_t)k * TILE;
+        for (int r = tid; r < TILE; r += 256) {
+            double acc = 0;
+#pragma unroll 8
+            for (int c = 0; c < TILE; ++c) acc = __builtin_fma(Lik[(size_t)c * ld + r], yk[c], acc);
+            y[(size_t)i * TILE + r] -= acc;
+        }
+        return;
+    }
+    if (bid < 3) {
+        // quadrant (qr, qc) of the diagonal tile: (0,0), (1,0), (1,1); wavefront = 32x32 sub-block
+        const int qr = bid == 0 ? 0 : 1, qc = bid == 2 ? 1 : 0;
+        const int row0 = j0 * TILE + qr * 64 + (wave & 1) * 32, col0 = j0 * TILE + qc * 64 + (wave >> 1) * 32;
+        double4_t out[2][2];
+        update_block<2, 32>(S, ld, k, row0, col0, lane, out);
+        if (bid == 0) {
+            double* A = sm;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = cv[a][b][r] + acc[a][b][r];
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        A[((wave >> 1) * 32 + a * 16 + (lane >> 4) + 4 * r) * LDC + (wave & 1) * 32 + b * 16 + (lane & 15)] = out[a][b][r];
+            // wait for the two other quadrants (bounded spin; relaxed polls, one acquire)
+            if (tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2 && ++spins < (1 << 26)) __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            // pull quadrants (1,0) and (1,1) (rows 64..127 of the tile) into LDS
+            const double* T = S + (size_t)(j0 * TILE) * ld + (size_t)j0 * TILE;
+#pragma unroll 8
+            for (int e = tid; e < TILE * 32; e += 256) {          // 128 columns x 32 double2 per column
+                const int c = e / 32, r = 64 + (e % 32) * 2;
+                *reinterpret_cast<double2*>(A + c * LDC + r) = *reinterpret_cast<const double2*>(T + (size_t)c * ld + r);
+            }
+            __syncthreads();
+            const bool failed = potrf_tile_lds(A, sm + TILE * LDC, Linv_next, tid);
+            store_tile_lower(S + (size_t)(j0 * TILE) * ld + (size_t)j0 * TILE, A, ld, tid);
+            if (tid == 0 && failed) *ok = 0.0;
+        } else {
+            double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = out[a][b][r];
+            // publish: all stores of the workgroup done -> agent-scope release -> count
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    const int t = bid - 2;
+    int rt = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((rt + 1) * (rt + 2) / 2 <= t) ++rt;
+    while (rt * (rt + 1) / 2 > t) --rt;
+    const int ct = t - rt * (rt + 1) / 2;
+    const int row0 = (j0 + rt) * TILE + (wave & 1) * 64, col0 = (j0 + ct) * TILE + (wave >> 1) * 64;
+    double4_t out[4][4];
+    update_block<4, 8>(S, ld, k, row0, col0, lane, out);
+    double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = out[a][b][r];
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward substitution, tile column k.  Every workgroup first solves x_k = L_kk^-T y_k (blocked by 16
-// with the stored block inverses), then workgroup j < k applies y_j -= L_kj^T x_k; workgroup k stores x_k.
+// backward substitution  L^T x = y  as ONE persistent launch: workgroup j owns tile column j.  It keeps
+// L_jj (LDS) and y_j, consumes x_k for k = nt-1 .. j+1 as they are published (flag[k], agent-scope
+// release/acquire), applying y_j -= L_kj^T x_k from a register-resident copy of the tile that was prefetched
+// while it waited, then solves x_j = L_jj^-T y_j (blocked by 16 with the stored block inverses) and publishes
+// it.  nt <= 256 workgroups are all resident (one per CU), so a consumer never waits for an unscheduled producer.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bsolve_step(const double* __restrict__ S, double* __restrict__ y, double* __restrict__ x,
-                                                     int ld, int k, const double* __restrict__ Linv_k)
+__global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict__ S, const double* __restrict__ y, double* __restrict__ x,
+                                                        int ld, int nt, const double* __restrict__ Linv, int* __restrict__ flags)
 {
     extern __shared__ double sm[];
-    constexpr int LDB = TILE + 2;          // column pitch: column walks (thread = column) spread over 16 banks
-    double* T = sm;                        // column-major tile
+    constexpr int LDB = TILE + 2;
+    double* T = sm;                        // L_jj, column-major
     __shared__ double Li[NBLK * NB * NB];
     __shared__ double ys[TILE], xk[TILE], red[256];
     const int tid = threadIdx.x;
-    const int j = blockIdx.x;
-    load_tile<LDB>(T, S + (size_t)(k * TILE) * ld + (size_t)k * TILE, ld, tid);
-    for (int e = tid; e < NBLK * NB * NB; e += 256) Li[e] = Linv_k[e];
-    if (tid < TILE) ys[tid] = y[(size_t)k * TILE + tid];
+    const int j = nt - 1 - (int)blockIdx.x;                     // the last tile column is dispatched first
+    load_tile<LDB>(T, S + (size_t)(j * TILE) * ld + (size_t)j * TILE, ld, tid);
+    for (int e = tid; e < NBLK * NB * NB; e += 256) Li[e] = Linv[(size_t)j * NBLK * NB * NB + e];
+    if (tid < TILE) ys[tid] = y[(size_t)j * TILE + tid];
+    // thread (c, half) owns rows half*64 .. +63 of column c of the current off-diagonal tile
+    const int c = tid >> 1, half = tid & 1;
+    double2 tile[32];
+    auto prefetch = [&](int k) {
+        const double* src = S + (size_t)(j * TILE + c) * ld + (size_t)k * TILE + half * 64;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) tile[u] = *reinterpret_cast<const double2*>(src + 2 * u);
+    };
+    if (j < nt - 1) prefetch(nt - 1);
     __syncthreads();
-    for (int c = NBLK - 1; c >= 0; --c) {
+    for (int k = nt - 1; k > j; --k) {
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 26)) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (tid < TILE) xk[tid] = __builtin_nontemporal_load(x + (size_t)k * TILE + tid);
+        __syncthreads();
+        double acc = 0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            acc = __builtin_fma(tile[u].x, xk[half * 64 + 2 * u], acc);
+            acc = __builtin_fma(tile[u].y, xk[half * 64 + 2 * u + 1], acc);
+        }
+        if (k - 1 > j) prefetch(k - 1);
+        acc += __shfl_xor(acc, 1, 64);
+        if (half == 0) ys[c] -= acc;
+        __syncthreads();
+    }
+    for (int cb = NBLK - 1; cb >= 0; --cb) {
         if (tid < NB) {                    // x_c = Linv_cc^T ys_c
             double acc = 0;
 #pragma unroll
-            for (int n = 0; n < NB; ++n) acc = __builtin_fma(Li[c * NB * NB + n * NB + tid], ys[c * NB + n], acc);
-            xk[c * NB + tid] = acc;
+            for (int n = 0; n < NB; ++n) acc = __builtin_fma(Li[cb * NB * NB + n * NB + tid], ys[cb * NB + n], acc);
+            xk[cb * NB + tid] = acc;
         }
         __syncthreads();
-        if (tid < c * NB) {                // ys[q] -= sum_n L[16c + n][q] x_c[n]   for q < 16 c
+        if (tid < cb * NB) {               // ys[q] -= sum_n L[16c + n][q] x_c[n]   for q < 16 c
             double acc = ys[tid];
 #pragma unroll
-            for (int n = 0; n < NB; ++n) acc = __builtin_fma(-T[tid * LDB + c * NB + n], xk[c * NB + n], acc);
+            for (int n = 0; n < NB; ++n) acc = __builtin_fma(-T[tid * LDB + cb * NB + n], xk[cb * NB + n], acc);
             ys[tid] = acc;
         }
         __syncthreads();
     }
-    if (j == k) {
-        if (tid < TILE) x[(size_t)k * TILE + tid] = xk[tid];
-        return;
-    }
-    // y_j[c] -= sum_r L(k-block row r, j-block col c) * x_k[r]
-    load_tile<LDB>(T, S + (size_t)(j * TILE) * ld + (size_t)k * TILE, ld, tid);
+    if (tid < TILE) x[(size_t)j * TILE + tid] = xk[tid];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    {
-        const int c = tid >> 1, half = tid & 1;
-        double acc = 0;
-#pragma unroll 8
-        for (int r = half * 64; r < half * 64 + 64; ++r) acc = __builtin_fma(T[c * LDB + r], xk[r], acc);
-        red[tid] = acc;
-        __syncthreads();
-        if (tid < 128) y[(size_t)j * TILE + tid] -= red[2 * tid] + red[2 * tid + 1];
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(flags + j, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    (void)red;
 }
 
 __global__ void k_set_scalar(double* p, double v) { *p = v; }
@@ -462,6 +520,17 @@ __global__ void k_set_scalar(double* p, double v) { *p = v; }
 }  // namespace
 
 size_t chol_workspace_doubles(int n_pad) { return (size_t)(n_pad / TILE) * NBLK * NB * NB; }
+
+// Kernels that need more than the default dynamic-LDS limit must be opted in once per device (function attributes
+// are per device); called from mage_ba_create after hipSetDevice.
+void chol_init_device()
+{
+    const size_t lds_diag = ((size_t)TILE * LDC + 2 * NB * NB) * sizeof(double);
+    const size_t lds_panel = (size_t)TILE * (TILE + 2) * sizeof(double);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bsolve_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_panel);
+}
 
 // Right-looking factorisation.  Step k = one k_trsm_panel launch + one k_syrk_update launch; the diagonal
 // factorisation of step k+1 is done by workgroup 0 of step k's update (tile (k+1, k+1) is the first tile of
@@ -471,25 +540,19 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
     const int nt = n_pad / TILE;
     const size_t lds_diag = ((size_t)TILE * LDC + 2 * NB * NB) * sizeof(double);
     const size_t lds_panel = (size_t)TILE * (TILE + 2) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update<4, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bsolve_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_panel);
-        attr_set = true;
-    }
     const size_t linv_stride = (size_t)NBLK * NB * NB;
     hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, st, ok, 1.0);
     hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), lds_diag, st, S, n_pad, 0, ws.Linv, ok);
     for (int k = 0; k < nt; ++k) {
         const int m = nt - k - 1;             // tile rows below panel k
-        hipLaunchKernelGGL(k_trsm_panel, dim3(m * NBLK + 1), dim3(64), 0, st, S, y, n_pad, k, nt, ws.Linv + (size_t)k * linv_stride);
+        hipLaunchKernelGGL(k_trsm_panel, dim3(m * NBLK + 1), dim3(64), 0, st, S, y, n_pad, k, nt, ws.Linv + (size_t)k * linv_stride, ws.sync, 0);
         if (m > 0)
-            hipLaunchKernelGGL((k_syrk_update<4, 4, 8>), dim3(m * (m + 1) / 2 + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt, k + 1, 0,
-                               ws.Linv + (size_t)(k + 1) * linv_stride, ok);
+            hipLaunchKernelGGL(k_syrk_update, dim3(m * (m + 1) / 2 + 2 + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
+                               ws.Linv + (size_t)(k + 1) * linv_stride, ok, ws.sync);
     }
-    for (int k = nt - 1; k >= 0; --k)
-        hipLaunchKernelGGL(k_bsolve_step, dim3(k + 1), dim3(256), lds_panel, st, S, y, x, n_pad, k, ws.Linv + (size_t)k * linv_stride);
+    // backward substitution: one persistent launch (needs every workgroup resident: nt <= 256 compute units)
+    (void)hipMemsetAsync(ws.sync + 1, 0, sizeof(int) * (size_t)nt, st);
+    hipLaunchKernelGGL(k_bsolve_persist, dim3(nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, ws.sync + 1);
 }
 
 }  // namespace mage

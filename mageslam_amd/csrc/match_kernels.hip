@@ -81,13 +81,16 @@ __global__ __launch_bounds__(MT) void k_match(const uint8_t* __restrict__ descA,
 
 }  // namespace
 
+void match_init_device()
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_DESC * 32);
+}
+
 void match_launch(int n_pairs, const uint8_t* descA, const int* countsA, int capA, const uint8_t* descB, const int* countsB, int capB,
                   int max_dist, int min_diff, int* scratch, mage_dmatch* out, int cap_out, int* counts, hipStream_t st)
 {
     const int use_lds = (capA + capB) <= 2 * LDS_DESC ? 1 : 0;
     const size_t lds = use_lds ? (size_t)(capA + capB) * 32 : 0;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_DESC * 32); attr = true; }
     hipLaunchKernelGGL(k_match, dim3(n_pairs), dim3(MT), lds, st, descA, countsA, capA, descB, countsB, capB, max_dist, min_diff, scratch, out,
                        cap_out, counts, use_lds);
 }

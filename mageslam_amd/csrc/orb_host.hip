@@ -318,6 +318,7 @@ MAGE_EXPORT mage_status mage_matcher_create(int device, mage_matcher** out)
         MAGE_HIP(hipSetDevice(dev));
         MAGE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         MAGE_HIP(hipEventCreate(&h->e0)); MAGE_HIP(hipEventCreate(&h->e1));
+        match_init_device();
         *out = h.release();
         return MAGE_OK;
     });

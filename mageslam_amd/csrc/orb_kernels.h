@@ -29,6 +29,7 @@ void orb_launch_brief(const uint8_t* blurred, int w, int h, int n_frames, const 
                       const signed char* pattern, uint8_t* desc, hipStream_t st);
 
 // Hamming brute-force two-way matcher: one workgroup per pair.
+void match_init_device();   // once per device: opt k_match into its LDS staging size
 void match_launch(int n_pairs, const uint8_t* descA, const int* countsA, int capA, const uint8_t* descB, const int* countsB, int capB,
                   int max_dist, int min_diff, int* scratch /* n_pairs x (capA + capB) x 2 ints */, mage_dmatch* out, int cap_out, int* counts,
                   hipStream_t st);

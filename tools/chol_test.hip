@@ -13,6 +13,7 @@ int main(int argc, char** argv)
     int reps = argc > 2 ? atoi(argv[2]) : 5;
     std::vector<int> sizes = { 128, 256, 640, 6016 };
     if (argc > 1 && atoi(argv[1]) > 0) sizes = { atoi(argv[1]) };
+    chol_init_device();
     for (int n : sizes) {
         // banded-ish SPD: A = B B^T + n I with random B entries in a band, dense storage
         std::vector<double> A((size_t)n * n, 0.0), b(n), x(n);
@@ -30,7 +31,8 @@ int main(int argc, char** argv)
         CK(hipMemcpy(dy0, b.data(), sizeof(double) * n, hipMemcpyHostToDevice));
         hipStream_t st; CK(hipStreamCreate(&st));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        CholWorkspace ws{ dws };
+        int* dq; CK(hipMalloc(&dq, sizeof(int) * chol_sync_ints(n)));
+        CholWorkspace ws{ dws, dq };
         float best = 1e30f;
         for (int r = 0; r < reps; ++r) {
             CK(hipMemcpyAsync(dS, dS0, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
