@@ -20,62 +20,67 @@ namespace {
 // brighter rings; a pixel is a corner iff that maximum exceeds the threshold, and its score is maximum - 1
 // (identical to the reference's threshold-table pre-test + min/max ladder, which computes the same quantity).
 // ---------------------------------------------------------------------------------------------
-constexpr int FT_W = 32, FT_H = 8, HALO = 3;
+constexpr int FT_W = 64, FT_H = 32, HALO = 3;   // 2048 pixels per workgroup, 8 per thread (few, fat workgroups: dispatch is not free)
+
+__device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ c, int TP, int t)
+{
+    const int v = c[0];
+    const int ox[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
+    const int oy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = v - (int)c[oy[k] * TP + ox[k]];
+    // high-speed pre-test (a 9-arc always contains one pixel of every opposite pair)
+    bool dark = true, bright = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        dark = dark && (d[k] > t || d[k + 8] > t);
+        bright = bright && (d[k] < -t || d[k + 8] < -t);
+    }
+    if (!(dark || bright)) return 0;
+    int m = -1000;
+    // windowed minima / maxima by doubling: 2, 4, 8, then 9
+    int a2[16], a4[16], a8[16], b2[16], b4[16], b8[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { a2[k] = min(d[k], d[(k + 1) & 15]); b2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { a4[k] = min(a2[k], a2[(k + 2) & 15]); b4[k] = max(b2[k], b2[(k + 2) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { a8[k] = min(a4[k], a4[(k + 4) & 15]); b8[k] = max(b4[k], b4[(k + 4) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        m = max(m, min(a8[k], d[(k + 8) & 15]));        // darker ring: min of (v - ring) over the arc
+        m = max(m, -max(b8[k], d[(k + 8) & 15]));       // brighter ring: min of (ring - v) over the arc
+    }
+    return m > t ? m - 1 : 0;
+}
 
 __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride,
                                                     int threshold, uint8_t* __restrict__ score)
 {
-    __shared__ uint8_t tile[(FT_H + 2 * HALO) * (FT_W + 2 * HALO + 2)];
-    constexpr int TP = FT_W + 2 * HALO + 2;
+    constexpr int TW = FT_W + 2 * HALO, TH = FT_H + 2 * HALO, TP = TW + 2;
+    __shared__ uint8_t tile[TH * TP];
     const int f = blockIdx.z;
     const uint8_t* I = img + (size_t)f * frame_stride;
     uint8_t* Sc = score + (size_t)f * w * h;
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
-    for (int e = threadIdx.x; e < (FT_H + 2 * HALO) * (FT_W + 2 * HALO); e += 256) {
-        const int ty = e / (FT_W + 2 * HALO), tx = e % (FT_W + 2 * HALO);
+    for (int e = threadIdx.x; e < TH * TW; e += 256) {
+        const int ty = e / TW, tx = e % TW;
         const int gx = x0 + tx - HALO, gy = y0 + ty - HALO;
         tile[ty * TP + tx] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? I[(size_t)gy * stride + gx] : 0;
     }
     __syncthreads();
-    const int lx = threadIdx.x % FT_W, ly = threadIdx.x / FT_W;
-    const int x = x0 + lx, y = y0 + ly;
-    if (x >= w || y >= h) return;
-    int out = 0;
-    if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
-        const uint8_t* c = &tile[(ly + HALO) * TP + lx + HALO];
-        const int v = c[0];
-        const int ox[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
-        const int oy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
-        int d[16];
+    const int lx = threadIdx.x % FT_W, ly0 = threadIdx.x / FT_W;         // 64 x 4 threads, 8 rows each
+    const int x = x0 + lx;
+    if (x >= w) return;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) d[k] = v - (int)c[oy[k] * TP + ox[k]];
-        // high-speed pre-test (a 9-arc always contains one pixel of every opposite pair)
-        const int t = threshold;
-        bool dark = true, bright = true;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            dark = dark && (d[k] > t || d[k + 8] > t);
-            bright = bright && (d[k] < -t || d[k + 8] < -t);
-        }
-        if (dark || bright) {
-            int m = -1000;
-            // windowed minima by doubling: 2, 4, 8, then 9
-            int a2[16], a4[16], a8[16], b2[16], b4[16], b8[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { a2[k] = min(d[k], d[(k + 1) & 15]); b2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { a4[k] = min(a2[k], a2[(k + 2) & 15]); b4[k] = max(b2[k], b2[(k + 2) & 15]); }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { a8[k] = min(a4[k], a4[(k + 4) & 15]); b8[k] = max(b4[k], b4[(k + 4) & 15]); }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                m = max(m, min(a8[k], d[(k + 8) & 15]));        // darker ring: min of (v - ring) over the arc
-                m = max(m, -max(b8[k], d[(k + 8) & 15]));       // brighter ring: min of (ring - v) over the arc
-            }
-            if (m > t) out = m - 1;
-        }
+    for (int i = 0; i < FT_H / 4; ++i) {
+        const int ly = ly0 + 4 * i, y = y0 + ly;
+        if (y >= h) break;
+        int out = 0;
+        if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) out = fast_score_at(&tile[(ly + HALO) * TP + lx + HALO], TP, threshold);
+        Sc[(size_t)y * w + x] = (uint8_t)out;
     }
-    Sc[(size_t)y * w + x] = (uint8_t)out;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -184,6 +189,7 @@ __device__ __forceinline__ int block_scan_excl(int v, int* sh /* 17 ints */, int
 __global__ __launch_bounds__(1024) void k_select(OrbSelectArgs a)
 {
     __shared__ int sh[32];
+    __shared__ int lhist[256];
     __shared__ int s_cut;
     __shared__ int s_minX, s_maxX, s_minY, s_maxY, s_minS;
     const int f = blockIdx.x, tid = threadIdx.x;
@@ -207,8 +213,10 @@ __global__ __launch_bounds__(1024) void k_select(OrbSelectArgs a)
         return;
     }
     // ---- RetainBestFeatures: whole histogram bins from 255 downwards
+    if (tid < 256) lhist[tid] = a.hist[f * 256 + tid];
+    __syncthreads();
     if (tid == 0) {
-        const int* hist = a.hist + f * 256;
+        const int* hist = lhist;
         const int min_thr = a.fast_threshold;
         int mnt = min_thr, num = 0;
         for (int i = 255; i >= min_thr; --i) { num += hist[i]; if (num >= a.nfeatures) { mnt = i; break; } }
@@ -272,7 +280,16 @@ __global__ __launch_bounds__(1024) void k_select(OrbSelectArgs a)
         atomicAdd(&cellcnt[cy * numX + cx + 1], 1);
     }
     __syncthreads();
-    if (tid == 0) { for (int c = 0; c < a.ncells; ++c) cellcnt[c + 1] += cellcnt[c]; }      // cell_start (<= 1024 cells by default)
+    {   // cell_start = inclusive scan of the counts, in place: thread t owns cells [t*per, (t+1)*per)
+        const int per = (a.ncells + 1023) / 1024;
+        const int c0 = tid * per, c1 = min(c0 + per, a.ncells);
+        int local = 0;
+        for (int c = c0; c < c1; ++c) local += cellcnt[c + 1];
+        int tot;
+        int run = block_scan_excl(local, sh, tot);
+        for (int c = c0; c < c1; ++c) { run += cellcnt[c + 1]; cellcnt[c + 1] = run; }
+    }
+    __threadfence_block();
     __syncthreads();
     for (int i = tid; i < M; i += 1024) {
         const int2 r = cand[i];
@@ -338,7 +355,7 @@ __global__ __launch_bounds__(1024) void k_select(OrbSelectArgs a)
 // ---------------------------------------------------------------------------------------------
 // separable integer Gaussian, REFLECT_101, 64x16 output tile per workgroup
 // ---------------------------------------------------------------------------------------------
-constexpr int BT_W = 64, BT_H = 16, MAXR = 7;
+constexpr int BT_W = 64, BT_H = 64, MAXR = 7;
 
 __device__ __forceinline__ int reflect101(int p, int n)
 {
@@ -350,21 +367,26 @@ __device__ __forceinline__ int reflect101(int p, int n)
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride,
                                               OrbTaps taps, uint8_t* __restrict__ out)
 {
-    __shared__ int hrow[(BT_H + 2 * MAXR) * BT_W];
+    constexpr int SW = BT_W + 2 * MAXR, SH = BT_H + 2 * MAXR;
+    __shared__ uint8_t src[SH * (SW + 2)];
+    __shared__ int hrow[SH * BT_W];
+    constexpr int SP = SW + 2;
     const int f = blockIdx.z, r = taps.radius;
     const uint8_t* I = img + (size_t)f * frame_stride;
     uint8_t* O = out + (size_t)f * w * h;
     const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
-    // horizontal pass for rows y0 - r .. y0 + BT_H + r - 1 (reflected)
-    for (int e = threadIdx.x; e < (BT_H + 2 * r) * BT_W; e += 256) {
+    const int sw = BT_W + 2 * r, sh = BT_H + 2 * r;
+    // source tile with the reflected border
+    for (int e = threadIdx.x; e < sh * sw; e += 256) {
+        const int ty = e / sw, tx = e % sw;
+        src[ty * SP + tx] = I[(size_t)reflect101(y0 + ty - r, h) * stride + reflect101(x0 + tx - r, w)];
+    }
+    __syncthreads();
+    // horizontal pass for every staged row
+    for (int e = threadIdx.x; e < sh * BT_W; e += 256) {
         const int ty = e / BT_W, tx = e % BT_W;
-        const int x = x0 + tx;
         int acc = 0;
-        if (x < w) {
-            const int gy = reflect101(y0 + ty - r, h);
-            const uint8_t* row = I + (size_t)gy * stride;
-            for (int t = -r; t <= r; ++t) acc += taps.t[t + r] * (int)row[reflect101(x + t, w)];
-        }
+        for (int t = 0; t <= 2 * r; ++t) acc += taps.t[t] * (int)src[ty * SP + tx + t];
         hrow[ty * BT_W + tx] = acc;
     }
     __syncthreads();
