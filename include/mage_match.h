@@ -8,7 +8,8 @@
  * second-best minus best < minHammingDifference, keep mutual best pairs, emit cv::DMatch in ascending query order.
  * Masks are applied by gathering (FeatureMatcher.cpp:88-110) and indices are mapped back (:160-163); both are
  * done by mage_match_masked below so a caller can pass its std::vector<bool>-derived byte masks directly.
- * IndexedMatch / RadiusMatch (FeatureMatcher.cpp:192-446) are the "next" rows of SURVEY.md 8f and are not built.
+ * RadiusMatch (FeatureMatcher.cpp:294-446) is mage_match_radius below; IndexedMatch (:192-292, BoW-driven)
+ * is the remaining "next" row and is not built.
  */
 #ifndef MAGE_MATCH_H
 #define MAGE_MATCH_H
@@ -17,6 +18,7 @@
 #include <stdint.h>
 
 #include "mage_ba.h"   /* mage_status */
+#include "mage_orb.h"  /* mage_keypoint */
 
 #ifdef __cplusplus
 extern "C" {
@@ -57,6 +59,21 @@ mage_status mage_match_bf_batch(mage_matcher* h, int n_pairs, const uint8_t* des
 mage_status mage_match_bf_batch_device(mage_matcher* h, int n_pairs, const uint8_t* descA_dev, const int* countsA_dev, int capA,
                                        const uint8_t* descB_dev, const int* countsB_dev, int capB, int max_hamming_dist,
                                        int min_hamming_difference, int cap_out, const mage_dmatch** out_dev, const int** counts_dev);
+
+/* RadiusMatch, multi-query form (Tracking/FeatureMatcher.cpp:294-378, built on the single-query form :386-446 and on
+ * KeypointSpatialIndex::Query, Image/KeypointSpatialIndex.cpp:89-97).  For every unmasked query keypoint: candidates are the
+ * target keypoints inside the closed box [x - radius, x + radius] x [y - radius, y + radius] around the query position
+ * (query_position_override, nQ x 2 floats, replaces the keypoint's own position when non-NULL) on the same octave; the
+ * best Hamming distance must be <= max_hamming_dist and beat the PREVIOUS best at its last improvement by more than
+ * min_hamming_difference (the reference's running "second best", not the true one); a target claimed by several queries
+ * keeps only a strictly smallest claim.  Results: cv::DMatch(queryIdx, trainIdx, imgIdx = 0, distance), ascending query.
+ * The reference visits candidates in boost R*-tree order (implementation-defined); this implementation and its oracle use
+ * ASCENDING TARGET INDEX -- the accept/reject outcome can depend on that order, parity with the reference is unpinned there.
+ * All pointers are host pointers; masks may be NULL (= all). */
+mage_status mage_match_radius(mage_matcher* h, const mage_keypoint* query_keypoints, int nQ, const float* query_position_override,
+                              const uint8_t* query_mask, const uint8_t* query_descriptors, const mage_keypoint* target_keypoints, int nT,
+                              const uint8_t* target_mask, const uint8_t* target_descriptors, float radius, int max_hamming_dist,
+                              int min_hamming_difference, mage_dmatch* out, int capacity, int* count);
 
 /* HIP-event time of the most recent batched call's kernel, in milliseconds. */
 mage_status mage_matcher_last_kernel_ms(const mage_matcher* h, double* ms);

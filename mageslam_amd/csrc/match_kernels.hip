@@ -79,7 +79,101 @@ __global__ __launch_bounds__(MT) void k_match(const uint8_t* __restrict__ descA,
     if (tid == 0) counts[p] = base_s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// RadiusMatch (Tracking/FeatureMatcher.cpp:294-446; candidates of KeypointSpatialIndex::Query in ascending target
+// index -- the canonical order, see include/mage_match.h).  One workgroup per (query set, target set) problem:
+// thread per query for the windowed best / "previous best" search, then the per-target uniqueness pass and an
+// ordered compaction.  With ~440 targets a linear scan with the box test beats building any spatial index.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MT) void k_radius_match(const mage_keypoint* __restrict__ qk, int nq, const float2* __restrict__ qpos,
+                                                     const uint8_t* __restrict__ qmask, const uint8_t* __restrict__ qdesc,
+                                                     const mage_keypoint* __restrict__ tk, int nt, const uint8_t* __restrict__ tmask,
+                                                     const uint8_t* __restrict__ tdesc, float radius, int max_dist, int min_diff,
+                                                     int* __restrict__ scratch /* nq x 2 + nt x 2 ints */, mage_dmatch* __restrict__ out, int cap,
+                                                     int* __restrict__ count)
+{
+    __shared__ int wave_cnt[MT / 64];
+    __shared__ int base_s, n_almost;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* a_train = scratch;            // nq : best target of query q or -1
+    int* a_dist = scratch + nq;        // nq
+    int* b1 = scratch + 2 * nq;        // nt : smallest claimed distance per target (Hamming distances are integers: atomicMin is exact)
+    int* cnt = b1 + nt;                // nt : number of claims equal to that minimum
+    const ulonglong4* Q = reinterpret_cast<const ulonglong4*>(qdesc);
+    const ulonglong4* T = reinterpret_cast<const ulonglong4*>(tdesc);
+    if (tid == 0) { base_s = 0; n_almost = 0; }
+    for (int t = tid; t < nt; t += MT) { b1[t] = 0x7fffffff; cnt[t] = 0; }
+    __syncthreads();
+    int mine = 0;
+    for (int q = tid; q < nq; q += MT) {
+        int train = -1, best = max_dist + 1, second = 0x7fffffff;
+        if (!qmask || qmask[q]) {
+            const mage_keypoint k = qk[q];
+            const float px = qpos ? qpos[q].x : k.x, py = qpos ? qpos[q].y : k.y;
+            const float x0 = __fsub_rn(px, radius), x1 = __fadd_rn(px, radius), y0 = __fsub_rn(py, radius), y1 = __fadd_rn(py, radius);
+            const float z0 = __fsub_rn(__fmul_rn((float)k.octave, 100.0f), 1.0f), z1 = __fadd_rn(__fmul_rn((float)k.octave, 100.0f), 1.0f);
+            const ulonglong4 qd = Q[q];
+            for (int t = 0; t < nt; ++t) {
+                const mage_keypoint c = tk[t];
+                const float tz = __fmul_rn((float)c.octave, 100.0f);
+                if (!(c.x >= x0 && c.x <= x1 && c.y >= y0 && c.y <= y1 && tz >= z0 && tz <= z1)) continue;
+                if (tmask && !tmask[t]) continue;
+                const ulonglong4 v = T[t];
+                const int d = __popcll(qd.x ^ v.x) + __popcll(qd.y ^ v.y) + __popcll(qd.z ^ v.z) + __popcll(qd.w ^ v.w);
+                if (d < best) { train = t; second = best; best = d; }
+            }
+            if (!(train != -1 && (second - best) > min_diff)) train = -1;
+        }
+        a_train[q] = train; a_dist[q] = best;
+        if (train >= 0) ++mine;
+    }
+    atomicAdd(&n_almost, mine);
+    __threadfence_block();
+    __syncthreads();
+    // With more than one accepted query (FeatureMatcher.cpp:344-373) a target keeps a claim only if it is the strictly
+    // smallest one: claim == minimum and no second claim with that same distance (bestDistance < secondBestDistance).
+    const bool filter = n_almost > 1;
+    if (filter) {
+        for (int q = tid; q < nq; q += MT) if (a_train[q] >= 0) atomicMin(&b1[a_train[q]], a_dist[q]);
+        __threadfence_block();
+        __syncthreads();
+        for (int q = tid; q < nq; q += MT) { const int t = a_train[q]; if (t >= 0 && a_dist[q] == b1[t]) atomicAdd(&cnt[t], 1); }
+        __threadfence_block();
+    }
+    __syncthreads();
+    for (int q0 = 0; q0 < nq; q0 += MT) {
+        const int q = q0 + tid;
+        int t = -1;
+        if (q < nq) {
+            t = a_train[q];
+            if (t >= 0 && filter && !(a_dist[q] == b1[t] && cnt[t] == 1)) t = -1;
+        }
+        const unsigned long long bal = __ballot(t >= 0);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (t >= 0 && off + before < cap) {
+            mage_dmatch m = { q, t, 0, (float)a_dist[q] };
+            out[off + before] = m;
+        }
+        __syncthreads();
+        if (tid == 0) { int s2 = 0; for (int w = 0; w < MT / 64; ++w) s2 += wave_cnt[w]; base_s += s2; }
+        __syncthreads();
+    }
+    if (tid == 0) *count = base_s;
+}
+
 }  // namespace
+
+void radius_match_launch(const mage_keypoint* qk, int nq, const float2* qpos, const uint8_t* qmask, const uint8_t* qdesc, const mage_keypoint* tk,
+                         int nt, const uint8_t* tmask, const uint8_t* tdesc, float radius, int max_dist, int min_diff, int* scratch,
+                         mage_dmatch* out, int cap, int* count, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_radius_match, dim3(1), dim3(MT), 0, st, qk, nq, qpos, qmask, qdesc, tk, nt, tmask, tdesc, radius, max_dist, min_diff,
+                       scratch, out, cap, count);
+}
 
 void match_init_device()
 {

@@ -6,6 +6,7 @@
 // launch per batch of pairs.  The host computes nothing but the blur taps and the rotated sampling pattern.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <memory>
 #include <vector>
 
@@ -420,6 +421,51 @@ MAGE_EXPORT mage_status mage_match_bf_batch_device(mage_matcher* h, int n_pairs,
         MAGE_HIP(hipStreamSynchronize(h->stream));
         if (n_pairs > 0) { float ms = 0; MAGE_HIP(hipEventElapsedTime(&ms, h->e0, h->e1)); h->last_ms = ms; }
         *out_dev = h->d_out.p; *counts_dev = h->d_counts.p;
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_match_radius(mage_matcher* h, const mage_keypoint* qk, int nQ, const float* qpos, const uint8_t* qmask,
+                                          const uint8_t* qdesc, const mage_keypoint* tk, int nT, const uint8_t* tmask, const uint8_t* tdesc,
+                                          float radius, int max_dist, int min_diff, mage_dmatch* out, int capacity, int* count)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !count) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        *count = 0;
+        if (nQ < 0 || nT < 0 || capacity < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative size");
+        if (nQ == 0 || nT == 0) return MAGE_OK;
+        if (!qk || !qdesc || !tk || !tdesc || (capacity > 0 && !out)) return fail(MAGE_ERR_INVALID_ARGUMENT, "null buffer");
+        MAGE_HIP(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        // one staging buffer: [qk | tk | qpos | qdesc | tdesc | qmask | tmask], 16-byte aligned pieces
+        auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        const size_t o_qk = 0, o_tk = al(o_qk + sizeof(mage_keypoint) * nQ), o_qp = al(o_tk + sizeof(mage_keypoint) * nT),
+                     o_qd = al(o_qp + 8 * (size_t)nQ), o_td = al(o_qd + 32 * (size_t)nQ), o_qm = al(o_td + 32 * (size_t)nT), o_tm = al(o_qm + nQ),
+                     total = al(o_tm + nT);
+        std::vector<uint8_t> stage(total, 0);
+        std::memcpy(stage.data() + o_qk, qk, sizeof(mage_keypoint) * nQ); std::memcpy(stage.data() + o_tk, tk, sizeof(mage_keypoint) * nT);
+        if (qpos) std::memcpy(stage.data() + o_qp, qpos, 8 * (size_t)nQ);
+        std::memcpy(stage.data() + o_qd, qdesc, 32 * (size_t)nQ); std::memcpy(stage.data() + o_td, tdesc, 32 * (size_t)nT);
+        if (qmask) std::memcpy(stage.data() + o_qm, qmask, nQ);
+        if (tmask) std::memcpy(stage.data() + o_tm, tmask, nT);
+        MAGE_TRY(h->d_A.reserve(total));
+        MAGE_TRY(h->d_scratch.reserve(2 * (size_t)nQ + 2 * (size_t)nT + 4));
+        MAGE_TRY(h->d_out.reserve((size_t)std::max(capacity, 1)));
+        MAGE_TRY(h->d_counts.reserve(1));
+        MAGE_HIP(hipMemcpyAsync(h->d_A.p, stage.data(), total, hipMemcpyHostToDevice, st));
+        const uint8_t* d = h->d_A.p;
+        MAGE_HIP(hipEventRecord(h->e0, st));
+        radius_match_launch(reinterpret_cast<const mage_keypoint*>(d + o_qk), nQ, qpos ? reinterpret_cast<const float2*>(d + o_qp) : nullptr,
+                            qmask ? d + o_qm : nullptr, d + o_qd, reinterpret_cast<const mage_keypoint*>(d + o_tk), nT, tmask ? d + o_tm : nullptr,
+                            d + o_td, radius, max_dist, min_diff, h->d_scratch.p, h->d_out.p, capacity, h->d_counts.p, st);
+        MAGE_HIP(hipEventRecord(h->e1, st));
+        MAGE_HIP(hipMemcpyAsync(count, h->d_counts.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        MAGE_HIP(hipStreamSynchronize(st));
+        const int n = std::min(*count, capacity);
+        if (n > 0) MAGE_HIP(hipMemcpy(out, h->d_out.p, sizeof(mage_dmatch) * (size_t)n, hipMemcpyDeviceToHost));
+        float ms = 0;
+        MAGE_HIP(hipEventElapsedTime(&ms, h->e0, h->e1));
+        h->last_ms = ms;
         return MAGE_OK;
     });
 }

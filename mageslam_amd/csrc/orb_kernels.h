@@ -34,4 +34,9 @@ void match_launch(int n_pairs, const uint8_t* descA, const int* countsA, int cap
                   int max_dist, int min_diff, int* scratch /* n_pairs x (capA + capB) x 2 ints */, mage_dmatch* out, int cap_out, int* counts,
                   hipStream_t st);
 
+// RadiusMatch: one (query set, target set) problem per launch.
+void radius_match_launch(const mage_keypoint* qk, int nq, const float2* qpos, const uint8_t* qmask, const uint8_t* qdesc, const mage_keypoint* tk,
+                         int nt, const uint8_t* tmask, const uint8_t* tdesc, float radius, int max_dist, int min_diff, int* scratch,
+                         mage_dmatch* out, int cap, int* count, hipStream_t st);
+
 }  // namespace mage

@@ -56,6 +56,7 @@ def _declare():
     L.mage_match_masked.argtypes = [vp, _u8, C.c_int, vp, _u8, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     L.mage_match_bf_batch.argtypes = [vp, C.c_int, _u8, _i32, C.c_int, _u8, _i32, C.c_int, C.c_int, C.c_int, vp, C.c_int, _i32]
     L.mage_match_bf_batch_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp)]
+    L.mage_match_radius.argtypes = [vp, vp, C.c_int, vp, vp, _u8, vp, C.c_int, vp, _u8, C.c_float, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     L.mage_matcher_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double)]
     _declared = True
 
@@ -173,6 +174,23 @@ class Matcher:
                                                  int(max_hamming_dist), int(min_hamming_difference), capA if cap_out is None else cap_out,
                                                  C.byref(o), C.byref(c)))
         return o.value, c.value
+
+    def RadiusMatch(self, query_keypoints, query_descriptors, target_keypoints, target_descriptors, radius, max_hamming_dist=30,
+                    min_hamming_difference=1, query_position_overrides=None, query_mask=None, target_mask=None) -> np.ndarray:
+        """FeatureMatcher::RadiusMatch (multi-query form, FeatureMatcher.cpp:294-378); keypoints are KEYPOINT_DTYPE arrays."""
+        qk = np.ascontiguousarray(query_keypoints, KEYPOINT_DTYPE); tk = np.ascontiguousarray(target_keypoints, KEYPOINT_DTYPE)
+        qd = np.ascontiguousarray(query_descriptors, np.uint8).reshape(-1); td = np.ascontiguousarray(target_descriptors, np.uint8).reshape(-1)
+        if qd.size == 0: qd = np.zeros(32, np.uint8)
+        if td.size == 0: td = np.zeros(32, np.uint8)
+        ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        qp = None if query_position_overrides is None else np.ascontiguousarray(query_position_overrides, np.float32)
+        qm = None if query_mask is None else np.ascontiguousarray(query_mask, np.uint8)
+        tm = None if target_mask is None else np.ascontiguousarray(target_mask, np.uint8)
+        out = np.zeros(max(len(qk), 1), DMATCH_DTYPE)
+        n = C.c_int(0)
+        check(self._L.mage_match_radius(self._h, ptr(qk), len(qk), ptr(qp), ptr(qm), qd, ptr(tk), len(tk), ptr(tm), td, float(radius),
+                                        int(max_hamming_dist), int(min_hamming_difference), ptr(out), len(out), C.byref(n)))
+        return out[: min(n.value, len(out))].copy()
 
     def last_kernel_ms(self) -> float:
         v = C.c_double(0)

@@ -179,3 +179,34 @@ def match(A: np.ndarray, B: np.ndarray, max_dist=30, min_diff=1):
     g, _ = oneway(D.T)
     out = [(q, f[q], fd[q]) for q in range(len(A)) if f[q] >= 0 and g[f[q]] == q]
     return np.array(out, np.int64).reshape(-1, 3)
+
+
+def radius_match(qxy, qoct, qdesc, txy, toct, tdesc, radius, max_dist=30, min_diff=1, qmask=None, tmask=None):
+    """Independent restatement of RadiusMatch (FeatureMatcher.cpp:294-446) with candidates in ascending target index."""
+    qxy = np.asarray(qxy, np.float32); txy = np.asarray(txy, np.float32); r = np.float32(radius)
+    D = hamming_matrix(qdesc, tdesc) if len(qdesc) and len(tdesc) else np.zeros((len(qdesc), len(tdesc)), np.int64)
+    almost = []
+    for q in range(len(qxy)):
+        if qmask is not None and not qmask[q]:
+            continue
+        inside = ((txy[:, 0] >= qxy[q, 0] - r) & (txy[:, 0] <= qxy[q, 0] + r) & (txy[:, 1] >= qxy[q, 1] - r) & (txy[:, 1] <= qxy[q, 1] + r)
+                  & (np.abs(np.asarray(toct) - qoct[q]) * 100 <= 1))
+        if tmask is not None:
+            inside &= np.asarray(tmask, bool)
+        best, second, train = max_dist + 1, 2 ** 31 - 1, -1
+        for t in np.nonzero(inside)[0]:
+            if D[q, t] < best:
+                train, second, best = t, best, int(D[q, t])
+        if train >= 0 and second - best > min_diff:
+            almost.append((q, train, best))
+    if len(almost) > 1:
+        by_t = {}
+        for q, t, d in almost:
+            by_t.setdefault(t, []).append(d)
+        keep = []
+        for q, t, d in almost:
+            ds = sorted(by_t[t])
+            if d == ds[0] and (len(ds) == 1 or ds[0] < ds[1]):
+                keep.append((q, t, d))
+        almost = keep
+    return np.array(almost, np.int64).reshape(-1, 3)

@@ -76,3 +76,60 @@ MTO_API int mto_match(const uint8_t* A, int nA, const uint8_t* B, int nB, int ma
     free(f); free(g);
     return n;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * RadiusMatch  (Tracking/FeatureMatcher.cpp:294-446) + KeypointSpatialIndex::Query (Image/KeypointSpatialIndex.cpp:89-97):
+ * per query, candidates = target keypoints inside the closed box [x-r, x+r] x [y-r, y+r] with
+ * |octave_t - octave_q| * 100 <= 1; best Hamming distance below maxHammingDist + 1, "second best" = the previous best at
+ * the time the best was last improved (NOT the true second smallest -- FeatureMatcher.cpp:423-434), accepted when
+ * second - best > minHammingDifference; then a target claimed by several queries keeps only a strictly best one.
+ * The candidate order comes from a boost R*-tree traversal in the reference (implementation-defined, boost is not
+ * vendored): the canonical order here (and in the HIP path) is ASCENDING TARGET INDEX.  PARITY UNPINNED for that order.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { float x, y, size, angle, response; int octave, class_id; } mto_keypoint;
+
+MTO_API int mto_radius_match(const mto_keypoint* qk, int nq, const float* qpos_override /* nq x 2 or NULL */, const uint8_t* qmask,
+                             const uint8_t* qdesc, const mto_keypoint* tk, int nt, const uint8_t* tmask, const uint8_t* tdesc,
+                             float radius, int max_dist, int min_diff, mto_dmatch* out, int cap)
+{
+    mto_dmatch* almost = (mto_dmatch*)malloc(sizeof(mto_dmatch) * (size_t)(nq > 0 ? nq : 1));
+    int na = 0;
+    for (int q = 0; q < nq; ++q) {
+        if (qmask && !qmask[q]) continue;
+        const float px = qpos_override ? qpos_override[2 * q] : qk[q].x, py = qpos_override ? qpos_override[2 * q + 1] : qk[q].y;
+        const float x0 = px - radius, x1 = px + radius, y0 = py - radius, y1 = py + radius;
+        const float z0 = qk[q].octave * 100.0f - 1.0f, z1 = qk[q].octave * 100.0f + 1.0f;
+        int best = max_dist + 1, second = 2147483647, train = -1;
+        for (int t = 0; t < nt; ++t) {
+            const float tz = tk[t].octave * 100.0f;
+            if (!(tk[t].x >= x0 && tk[t].x <= x1 && tk[t].y >= y0 && tk[t].y <= y1 && tz >= z0 && tz <= z1)) continue;
+            if (tmask && !tmask[t]) continue;
+            const int d = mto_hamming256(qdesc + (size_t)q * 32, tdesc + (size_t)t * 32);
+            if (d < best) { train = t; second = best; best = d; }
+        }
+        if (train != -1 && (second - best) > min_diff) {
+            almost[na].queryIdx = q; almost[na].trainIdx = train; almost[na].imgIdx = 0; almost[na].distance = (float)best;
+            ++na;
+        }
+    }
+    int n = 0;
+    if (na > 1) {
+        float* b1 = (float*)malloc(sizeof(float) * (size_t)nt * 2);
+        float* b2 = b1 + nt;
+        for (int t = 0; t < nt; ++t) { b1[t] = 3.402823466e+38f; b2[t] = 3.402823466e+38f; }
+        for (int i = 0; i < na; ++i) {
+            const int t = almost[i].trainIdx; const float d = almost[i].distance;
+            if (d < b1[t]) { b2[t] = b1[t]; b1[t] = d; }
+            else if (d < b2[t]) b2[t] = d;
+        }
+        for (int i = 0; i < na; ++i) {
+            const int t = almost[i].trainIdx;
+            if (almost[i].distance == b1[t] && b1[t] < b2[t]) { if (n < cap) out[n] = almost[i]; ++n; }
+        }
+        free(b1);
+    } else {
+        for (int i = 0; i < na; ++i) { if (n < cap) out[n] = almost[i]; ++n; }
+    }
+    free(almost);
+    return n;
+}

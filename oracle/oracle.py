@@ -109,6 +109,8 @@ def _declare(L: C.CDLL) -> None:
     L.mto_hamming256.argtypes = [_u8p, _u8p]
     L.mto_match.restype = C.c_int
     L.mto_match.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.mto_radius_match.restype = C.c_int
+    L.mto_radius_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_int, C.c_void_p, _u8p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.bao_test_se3_exp.argtypes = [_f64p, _f64p]
     L.bao_test_ldlt.restype = C.c_int
     L.bao_test_ldlt.argtypes = [_f64p, C.c_int, _f64p, _f64p]
@@ -252,4 +254,21 @@ def match(A: np.ndarray, B: np.ndarray, max_dist: int = 30, min_diff: int = 1) -
     out = np.zeros(max(len(A), 1), DMATCH_DTYPE)
     n = L.mto_match(A.reshape(-1) if len(A) else np.zeros(1, np.uint8), len(A), B.reshape(-1) if len(B) else np.zeros(1, np.uint8), len(B),
                     int(max_dist), int(min_diff), out.ctypes.data_as(C.c_void_p), len(out))
+    return out[:n].copy()
+
+
+def radius_match(qk, qdesc, tk, tdesc, radius, max_dist=30, min_diff=1, qpos=None, qmask=None, tmask=None) -> np.ndarray:
+    """oracle/match_oracle.c mto_radius_match (FeatureMatcher.cpp:294-446); keypoints are KEYPOINT_DTYPE arrays."""
+    L = lib()
+    qk = np.ascontiguousarray(qk, KEYPOINT_DTYPE); tk = np.ascontiguousarray(tk, KEYPOINT_DTYPE)
+    qd = np.ascontiguousarray(qdesc, np.uint8).reshape(-1); td = np.ascontiguousarray(tdesc, np.uint8).reshape(-1)
+    if qd.size == 0: qd = np.zeros(32, np.uint8)
+    if td.size == 0: td = np.zeros(32, np.uint8)
+    ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    qp = None if qpos is None else np.ascontiguousarray(qpos, np.float32)
+    qm = None if qmask is None else np.ascontiguousarray(qmask, np.uint8)
+    tm = None if tmask is None else np.ascontiguousarray(tmask, np.uint8)
+    out = np.zeros(max(len(qk), 1), DMATCH_DTYPE)
+    n = L.mto_radius_match(ptr(qk), len(qk), ptr(qp), ptr(qm), qd, ptr(tk), len(tk), ptr(tm), td, float(radius), int(max_dist), int(min_diff),
+                           ptr(out), len(out))
     return out[:n].copy()

@@ -39,7 +39,17 @@ def main():
         print(name, img.shape, "keypoints", len(k), "blur sha", h[:12])
     m = N.match(out["orb_640x480_a"][2], out["orb_640x480_b"][2], 30, 1)
     print("matches", len(m))
-    np.savez_compressed(os.path.join(HERE, "orb_frames.npz"),
+    # RadiusMatch cases on the 640x480 pair: (radius, position override = A's keypoints mapped through the true homography)
+    H = frames.small_homography(7)
+    ka, kb = out["orb_640x480_a"][1], out["orb_640x480_b"][1]
+    p3 = np.stack([ka[:, 0], ka[:, 1], np.ones(len(ka))], 0).astype(np.float64)
+    q3 = H @ p3
+    qpos = (q3[:2] / q3[2]).T.astype(np.float32)
+    zo = np.zeros(len(ka), np.int64)
+    rm_plain = N.radius_match(ka[:, :2], zo, out["orb_640x480_a"][2], kb[:, :2], np.zeros(len(kb), np.int64), out["orb_640x480_b"][2], 20.0, 30, 1)
+    rm_over = N.radius_match(qpos, zo, out["orb_640x480_a"][2], kb[:, :2], np.zeros(len(kb), np.int64), out["orb_640x480_b"][2], 4.0, 40, 2)
+    print("radius matches", len(rm_plain), len(rm_over))
+    np.savez_compressed(os.path.join(HERE, "orb_frames.npz"), radius_qpos=qpos, radius_plain=rm_plain, radius_override=rm_over,
                         **{f"{n}_img": v[0] for n, v in out.items()}, **{f"{n}_kp": v[1] for n, v in out.items()},
                         **{f"{n}_desc": v[2] for n, v in out.items()}, **{f"{n}_blursha": np.array(v[3]) for n, v in out.items()},
                         matches_ab=m)

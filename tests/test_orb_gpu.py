@@ -148,3 +148,31 @@ def test_full_size_properties():
     m = Matcher().Match(d1, d1, None, None, 0, 1)
     uniq = np.array([np.sum(np.all(d1 == d1[i], axis=1)) == 1 for i in range(len(d1))])
     assert np.array_equal(m["queryIdx"], m["trainIdx"]) and set(m["queryIdx"]) == set(np.nonzero(uniq)[0])
+
+
+def _kp_array(xyr):
+    k = np.zeros(len(xyr), O.KEYPOINT_DTYPE)
+    k["x"], k["y"], k["response"], k["size"], k["class_id"] = xyr[:, 0], xyr[:, 1], xyr[:, 2], 15, -1
+    return k
+
+
+def test_radius_match_golden_and_oracle(gold):
+    """SURVEY.md 8f rank 2 ("next" row M-5): RadiusMatch, bit-exact against the fixture and the oracle."""
+    ka, kb = _kp_array(gold["orb_640x480_a_kp"]), _kp_array(gold["orb_640x480_b_kp"])
+    da, db = gold["orb_640x480_a_desc"], gold["orb_640x480_b_desc"]
+    as3 = lambda m: np.stack([m["queryIdx"], m["trainIdx"], m["distance"].astype(np.int64)], axis=1)
+    mt = Matcher()
+    m = mt.RadiusMatch(ka, da, kb, db, 20.0, 30, 1)
+    assert np.array_equal(as3(m), gold["radius_plain"]) and np.all(m["imgIdx"] == 0)
+    m = mt.RadiusMatch(ka, da, kb, db, 4.0, 40, 2, query_position_overrides=gold["radius_qpos"])
+    assert np.array_equal(as3(m), gold["radius_override"])
+    rng = np.random.default_rng(8)
+    for radius, md, mdiff in ((1.0, 30, 1), (35.5, 60, 0), (640.0, 256, 3), (0.0, 30, 1)):
+        qm = rng.random(len(ka)) < 0.8; tm = rng.random(len(kb)) < 0.8
+        m = mt.RadiusMatch(ka, da, kb, db, radius, md, mdiff, query_mask=qm, target_mask=tm)
+        mo = O.radius_match(ka, da, kb, db, radius, md, mdiff, qmask=qm, tmask=tm)
+        assert np.array_equal(m, mo)
+    assert len(mt.RadiusMatch(ka[:0], da[:0], kb, db, 5.0)) == 0 and len(mt.RadiusMatch(ka, da, kb[:0], db[:0], 5.0)) == 0
+    # a single accepted query skips the uniqueness pass (FeatureMatcher.cpp:374-377)
+    m = mt.RadiusMatch(ka[:1], da[:1], kb, db, 30.0, 256, 0)
+    assert np.array_equal(m, O.radius_match(ka[:1], da[:1], kb, db, 30.0, 256, 0))

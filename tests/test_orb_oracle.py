@@ -121,3 +121,50 @@ def test_unsupported_settings_are_refused():
     for kw in (dict(nlevels=2), dict(use_orientation=1), dict(patch_size=21)):
         with pytest.raises(NotImplementedError):
             O.orb_detect(a, O.OrbParams.defaults(**kw))
+
+
+def _kp_array(xyr):
+    k = np.zeros(len(xyr), O.KEYPOINT_DTYPE)
+    k["x"], k["y"], k["response"], k["size"], k["class_id"] = xyr[:, 0], xyr[:, 1], xyr[:, 2], 15, -1
+    return k
+
+
+def test_radius_match_oracle_matches_golden(gold):
+    ka, kb = _kp_array(gold["orb_640x480_a_kp"]), _kp_array(gold["orb_640x480_b_kp"])
+    da, db = gold["orb_640x480_a_desc"], gold["orb_640x480_b_desc"]
+    as3 = lambda m: np.stack([m["queryIdx"], m["trainIdx"], m["distance"].astype(np.int64)], axis=1)
+    m = O.radius_match(ka, da, kb, db, 20.0, 30, 1)
+    assert np.array_equal(as3(m), gold["radius_plain"]) and np.all(m["imgIdx"] == 0)
+    m = O.radius_match(ka, da, kb, db, 4.0, 40, 2, qpos=gold["radius_qpos"])
+    assert np.array_equal(as3(m), gold["radius_override"])
+
+
+def test_radius_match_semantics():
+    """Running 'second best' (previous best at the last improvement), closed box, octave gate, per-target uniqueness."""
+    d = np.zeros((4, 32), np.uint8)
+    d[1, 0] = 0b1; d[2, 0] = 0b111; d[3, :2] = 255                       # distances to d[0]: 1, 3, 16
+    q = _kp_array(np.array([[50, 50, 9]])); qd = d[:1]
+    # candidates visited in index order 0:(dist 3), 1:(dist 1): best 1, previous best 3 -> diff 2 > 1 accepted
+    t = _kp_array(np.array([[52, 50, 9], [48, 51, 9]]))
+    m = O.radius_match(q, qd, t, d[[2, 1]], 5.0, 30, 1)
+    assert m["trainIdx"].tolist() == [1] and m["distance"].tolist() == [1.0]
+    # same candidates in the other order: best 1 first, the worse one never updates 'second' -> diff = 31 - 1
+    m = O.radius_match(q, qd, t, d[[1, 2]], 5.0, 30, 1)
+    assert m["trainIdx"].tolist() == [0]
+    # order (3 then 1) with minDiff 2: diff 2 is not > 2 -> rejected
+    assert len(O.radius_match(q, qd, t, d[[2, 1]], 5.0, 30, 2)) == 0
+    # box is closed: a target exactly radius away is a candidate; just outside is not
+    t1 = _kp_array(np.array([[55, 50, 9]]))
+    assert len(O.radius_match(q, qd, t1, d[1:2], 5.0, 30, 1)) == 1 and len(O.radius_match(q, qd, t1, d[1:2], 4.999, 30, 1)) == 0
+    # other octave never matches
+    t2 = t1.copy(); t2["octave"] = 1
+    assert len(O.radius_match(q, qd, t2, d[1:2], 5.0, 30, 1)) == 0
+    # two queries claiming one target with equal distance: both dropped; a strictly better claim wins
+    q2 = _kp_array(np.array([[50, 50, 9], [51, 50, 9]]))
+    assert len(O.radius_match(q2, d[[1, 1]], t1, d[:1], 9.0, 30, 1)) == 0
+    m = O.radius_match(q2, d[[1, 2]], t1, d[:1], 9.0, 30, 1)
+    assert m["queryIdx"].tolist() == [0]
+    # masks and empties
+    assert len(O.radius_match(q2, d[[1, 2]], t1, d[:1], 9.0, 30, 1, qmask=[0, 1])) == 1
+    assert len(O.radius_match(q2, d[[1, 2]], t1, d[:1], 9.0, 30, 1, tmask=[0])) == 0
+    assert len(O.radius_match(q2[:0], d[:0], t1, d[:1], 9.0)) == 0
