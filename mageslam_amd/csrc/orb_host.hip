@@ -141,8 +141,9 @@ mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     if (w < 1 || h_img < 1 || w > 65535 || h_img > 32767) return fail(MAGE_ERR_INVALID_ARGUMENT, "image size %dx%d out of range", w, h_img);
     if (capacity < 0 || n_frames < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative capacity / frame count");
     hipStream_t st = h->stream;
-    const size_t npx = (size_t)w * h_img;
-    const size_t raw_cap = npx / 4 + 16;
+    const int wp = (w + 3) & ~3;                     // internal row pitch (score map, blurred image)
+    const size_t npx = (size_t)wp * h_img;
+    const size_t raw_cap = (size_t)w * h_img / 4 + 16;
     const int n_wg = (h_img + NMS_ROWS - 1) / NMS_ROWS;
     const int ncells = P.num_cells_x * P.num_cells_y;
     const size_t nf = (size_t)std::max(n_frames, 1), cap = (size_t)std::max(capacity, 1);
@@ -167,9 +168,9 @@ mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     if (n_frames == 0) return MAGE_OK;
 
     MAGE_HIP(hipEventRecord(h->ev[0], st));
-    orb_launch_fast(d_images, w, h_img, stride, frame_stride, n_frames, (int)std::min(P.fast_threshold, 255u), h->d_score.p, st);
+    orb_launch_fast(d_images, w, h_img, stride, frame_stride, n_frames, (int)std::min(P.fast_threshold, 255u), h->d_score.p, wp, st);
     MAGE_HIP(hipEventRecord(h->ev[1], st));
-    orb_launch_collect(h->d_score.p, w, h_img, n_frames, (int)P.patch_size / 2, NMS_ROWS, n_wg, h->d_wg_count.p, h->d_wg_off.p, h->d_hist.p,
+    orb_launch_collect(h->d_score.p, w, h_img, wp, n_frames, (int)P.patch_size / 2, NMS_ROWS, n_wg, h->d_wg_count.p, h->d_wg_off.p, h->d_hist.p,
                        h->d_n_raw.p, h->d_raw.p, raw_cap, st);
     OrbSelectArgs a{};
     a.raw = h->d_raw.p; a.n_raw = h->d_n_raw.p; a.hist = h->d_hist.p;
@@ -181,9 +182,9 @@ mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     a.feature_strength = P.feature_strength_anms; a.min_robust = P.min_robust_factor; a.max_robust = P.max_robust_factor;
     orb_launch_select(a, n_frames, st);
     MAGE_HIP(hipEventRecord(h->ev[2], st));
-    orb_launch_blur(d_images, w, h_img, stride, frame_stride, n_frames, h->taps, h->d_blur.p, st);
+    orb_launch_blur(d_images, w, h_img, stride, frame_stride, n_frames, h->taps, h->d_blur.p, wp, st);
     MAGE_HIP(hipEventRecord(h->ev[3], st));
-    if (capacity > 0) orb_launch_brief(h->d_blur.p, w, h_img, n_frames, h->d_kp.p, h->d_count.p, capacity, h->d_pattern.p, h->d_desc.p, st);
+    if (capacity > 0) orb_launch_brief(h->d_blur.p, wp, h_img, n_frames, h->d_kp.p, h->d_count.p, capacity, h->d_pattern.p, h->d_desc.p, st);
     MAGE_HIP(hipEventRecord(h->ev[4], st));
     return MAGE_OK;
 }
@@ -255,11 +256,11 @@ MAGE_EXPORT mage_status mage_orb_debug_read(mage_orb* h, uint8_t* score_map, uin
 {
     return guarded([&]() -> mage_status {
         if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
-        const size_t npx = (size_t)h->last_w * h->last_h;
-        if (npx == 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "no frame has been processed yet");
+        const size_t w = (size_t)h->last_w, rows = (size_t)h->last_h, wp = (w + 3) & ~(size_t)3;
+        if (w * rows == 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "no frame has been processed yet");
         MAGE_HIP(hipSetDevice(h->device));
-        if (score_map) MAGE_HIP(hipMemcpy(score_map, h->d_score.p, npx, hipMemcpyDeviceToHost));
-        if (blurred) MAGE_HIP(hipMemcpy(blurred, h->d_blur.p, npx, hipMemcpyDeviceToHost));
+        if (score_map) MAGE_HIP(hipMemcpy2D(score_map, w, h->d_score.p, wp, w, rows, hipMemcpyDeviceToHost));
+        if (blurred) MAGE_HIP(hipMemcpy2D(blurred, w, h->d_blur.p, wp, w, rows, hipMemcpyDeviceToHost));
         return MAGE_OK;
     });
 }

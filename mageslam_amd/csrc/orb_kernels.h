@@ -20,12 +20,13 @@ struct OrbSelectArgs {
     float feature_strength, min_robust, max_robust;
 };
 
-void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, uint8_t* score, hipStream_t st);
-void orb_launch_collect(const uint8_t* score, int w, int h, int n_frames, int border, int rows_per_wg, int n_wg, int* wg_count, int* wg_off,
+// wp = internal row pitch of the score map / blurred image (w rounded up to 4)
+void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, uint8_t* score, int wp, hipStream_t st);
+void orb_launch_collect(const uint8_t* score, int w, int h, int wp, int n_frames, int border, int rows_per_wg, int n_wg, int* wg_count, int* wg_off,
                         int* hist, int* n_raw, int2* raw, size_t raw_cap, hipStream_t st);
 void orb_launch_select(const OrbSelectArgs& a, int n_frames, hipStream_t st);
-void orb_launch_blur(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, const OrbTaps& taps, uint8_t* out, hipStream_t st);
-void orb_launch_brief(const uint8_t* blurred, int w, int h, int n_frames, const mage_keypoint* kps, const int* counts, int capacity,
+void orb_launch_blur(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, const OrbTaps& taps, uint8_t* out, int wp, hipStream_t st);
+void orb_launch_brief(const uint8_t* blurred, int wp, int h, int n_frames, const mage_keypoint* kps, const int* counts, int capacity,
                       const signed char* pattern, uint8_t* desc, hipStream_t st);
 
 // Hamming brute-force two-way matcher: one workgroup per pair.

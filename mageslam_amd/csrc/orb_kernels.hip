@@ -55,65 +55,126 @@ __device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ c, int 
     return m > t ? m - 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride,
-                                                    int threshold, uint8_t* __restrict__ score)
+// Stage a (TH x TW)-byte window of the source image, top-left at (gx0, gy0) with gx0 a multiple of 4, into LDS with
+// 32-bit loads when the source allows it (row pitch and base 4-byte aligned), bytes otherwise.  `fill(gx, gy)` maps
+// out-of-image coordinates (zero padding for FAST, reflection for the blur).
+template <int TW, int TH, int TP, bool REFLECT>
+__device__ __forceinline__ void stage_window(uint8_t* __restrict__ tile, const uint8_t* __restrict__ I, int w, int h, int stride, int gx0, int gy0,
+                                             int tw, int th)
 {
-    constexpr int TW = FT_W + 2 * HALO, TH = FT_H + 2 * HALO, TP = TW + 2;
-    __shared__ uint8_t tile[TH * TP];
+    auto rx = [&](int p, int n) { if (n == 1) return 0; while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p; return p; };
+    const bool aligned = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(I) & 3) == 0);
+    const int nq = tw / 4;                              // tw is a multiple of 4
+    for (int e = threadIdx.x; e < th * nq; e += 256) {
+        const int ty = e / nq, tq = e % nq;
+        const int gx = gx0 + 4 * tq;
+        int gy = gy0 + ty;
+        uint32_t v = 0;
+        const bool row_ok = REFLECT || (gy >= 0 && gy < h);
+        if (REFLECT) gy = rx(gy, h);
+        if (row_ok) {
+            if (aligned && gx >= 0 && gx + 3 < w) v = *reinterpret_cast<const uint32_t*>(I + (size_t)gy * stride + gx);
+            else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    int x = gx + b;
+                    uint32_t px = 0;
+                    if (REFLECT) px = I[(size_t)gy * stride + rx(x, w)];
+                    else if (x >= 0 && x < w) px = I[(size_t)gy * stride + x];
+                    v |= px << (8 * b);
+                }
+            }
+        }
+        *reinterpret_cast<uint32_t*>(tile + ty * TP + 4 * tq) = v;
+    }
+}
+
+// Internal images (score map, blurred image) use a row pitch wp = w rounded up to 4 so every kernel below moves 4 pixels
+// per 32-bit access; pixels in [w, wp) are written as 0.
+__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride,
+                                                    int threshold, uint8_t* __restrict__ score, int wp)
+{
+    constexpr int TW = FT_W + 8, TH = FT_H + 2 * HALO, TP = TW;      // window starts 4 pixels left of the tile (aligned), halo 3 used
+    __shared__ __attribute__((aligned(4))) uint8_t tile[TH * TP];
     const int f = blockIdx.z;
     const uint8_t* I = img + (size_t)f * frame_stride;
-    uint8_t* Sc = score + (size_t)f * w * h;
+    uint8_t* Sc = score + (size_t)f * wp * h;
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
-    for (int e = threadIdx.x; e < TH * TW; e += 256) {
-        const int ty = e / TW, tx = e % TW;
-        const int gx = x0 + tx - HALO, gy = y0 + ty - HALO;
-        tile[ty * TP + tx] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? I[(size_t)gy * stride + gx] : 0;
-    }
+    stage_window<TW, TH, TP, false>(tile, I, w, h, stride, x0 - 4, y0 - HALO, TW, TH);
     __syncthreads();
-    const int lx = threadIdx.x % FT_W, ly0 = threadIdx.x / FT_W;         // 64 x 4 threads, 8 rows each
-    const int x = x0 + lx;
-    if (x >= w) return;
+    // thread -> quads of 4 horizontally adjacent pixels: 16 quads per tile row, 32 rows = 512 quads, 2 per thread
 #pragma unroll
-    for (int i = 0; i < FT_H / 4; ++i) {
-        const int ly = ly0 + 4 * i, y = y0 + ly;
-        if (y >= h) break;
-        int out = 0;
-        if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) out = fast_score_at(&tile[(ly + HALO) * TP + lx + HALO], TP, threshold);
-        Sc[(size_t)y * w + x] = (uint8_t)out;
+    for (int i = 0; i < 2; ++i) {
+        const int qi = threadIdx.x + 256 * i;
+        const int ly = qi / (FT_W / 4), lq = qi % (FT_W / 4);
+        const int y = y0 + ly, xq = x0 + 4 * lq;
+        if (y >= h || xq >= wp) continue;
+        uint32_t packed = 0;
+        if (y >= 3 && y < h - 3) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int x = xq + b;
+                if (x >= 3 && x < w - 3) packed |= (uint32_t)fast_score_at(&tile[(ly + HALO) * TP + 4 + 4 * lq + b], TP, threshold) << (8 * b);
+            }
+        }
+        *reinterpret_cast<uint32_t*>(Sc + (size_t)y * wp + xq) = packed;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // NMS + border cull + raster-order compaction.  A workgroup owns NMS_ROWS full image rows (a contiguous
 // raster segment); pass 1 counts (and builds the response histogram), pass 2 writes at the scanned offsets.
+// A thread examines 4 adjacent pixels from nine 32-bit loads.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int nms_value(const uint8_t* __restrict__ Sc, int w, int h, int x, int y, int border)
+__device__ __forceinline__ int nms_quad(const uint8_t* __restrict__ Sc, int w, int h, int wp, int xq, int y, int border, int resp[4])
 {
-    // returns the response if (x, y) is a kept keypoint, else -1
+    // returns the 4-bit mask of kept keypoints among pixels xq..xq+3 of row y; resp[b] = their responses
     const int lo = border > 3 ? border : 3;
-    if (x < lo || y < lo || x >= w - lo || y >= h - lo) return -1;
-    const uint8_t* p = Sc + (size_t)y * w + x;
-    const int s = p[0];
-    if (s > p[1] && s > p[-1] && s > p[-w - 1] && s > p[-w] && s > p[-w + 1] && s > p[w - 1] && s > p[w] && s > p[w + 1]) return s;
-    return -1;
+    resp[0] = resp[1] = resp[2] = resp[3] = 0;
+    if (y < lo || y >= h - lo) return 0;
+    const uint8_t* row = Sc + (size_t)y * wp + xq;
+    const uint32_t c = *reinterpret_cast<const uint32_t*>(row);
+    if (c == 0) return 0;
+    const uint32_t l = xq > 0 ? *reinterpret_cast<const uint32_t*>(row - 4) : 0u;
+    const uint32_t r = xq + 4 < wp ? *reinterpret_cast<const uint32_t*>(row + 4) : 0u;
+    const uint32_t cu = *reinterpret_cast<const uint32_t*>(row - wp), cd = *reinterpret_cast<const uint32_t*>(row + wp);
+    const uint32_t lu = xq > 0 ? *reinterpret_cast<const uint32_t*>(row - wp - 4) : 0u, ld_ = xq > 0 ? *reinterpret_cast<const uint32_t*>(row + wp - 4) : 0u;
+    const uint32_t ru = xq + 4 < wp ? *reinterpret_cast<const uint32_t*>(row - wp + 4) : 0u, rd = xq + 4 < wp ? *reinterpret_cast<const uint32_t*>(row + wp + 4) : 0u;
+    // 6 pixels per row: [l.b3, c.b0..b3, r.b0]
+    auto px = [](uint32_t lw, uint32_t cw, uint32_t rw, int i) -> int { return i == 0 ? (int)(lw >> 24) : i == 5 ? (int)(rw & 0xff) : (int)((cw >> (8 * (i - 1))) & 0xff); };
+    int mask = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int x = xq + b;
+        const int s = (int)((c >> (8 * b)) & 0xff);
+        if (s == 0 || x < lo || x >= w - lo) continue;
+        bool keep = s > px(l, c, r, b) && s > px(l, c, r, b + 2);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) keep = keep && s > px(lu, cu, ru, b + i) && s > px(ld_, cd, rd, b + i);
+        if (keep) { mask |= 1 << b; resp[b] = s; }
+    }
+    return mask;
 }
 
-__global__ __launch_bounds__(256) void k_nms_count(const uint8_t* __restrict__ score, int w, int h, int border, int rows_per_wg,
+__global__ __launch_bounds__(256) void k_nms_count(const uint8_t* __restrict__ score, int w, int h, int wp, int border, int rows_per_wg,
                                                    int* __restrict__ wg_count, int* __restrict__ hist)
 {
     __shared__ int lh[256];
     __shared__ int cnt;
     const int f = blockIdx.y, tid = threadIdx.x;
-    const uint8_t* Sc = score + (size_t)f * w * h;
+    const uint8_t* Sc = score + (size_t)f * wp * h;
     lh[tid] = 0;
     if (tid == 0) cnt = 0;
     __syncthreads();
     const int y0 = blockIdx.x * rows_per_wg;
     const int y1 = min(y0 + rows_per_wg, h);
+    const int qpr = wp / 4;
     int c = 0;
-    for (int p = y0 * w + tid; p < y1 * w; p += 256) {
-        const int v = nms_value(Sc, w, h, p % w, p / w, border);
-        if (v >= 0) { ++c; atomicAdd(&lh[v], 1); }
+    for (int q = y0 * qpr + tid; q < y1 * qpr; q += 256) {
+        int resp[4];
+        const int m = nms_quad(Sc, w, h, wp, 4 * (q % qpr), q / qpr, border, resp);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) if (m & (1 << b)) { ++c; atomicAdd(&lh[resp[b]], 1); }
     }
     atomicAdd(&cnt, c);
     __syncthreads();
@@ -138,29 +199,34 @@ __global__ __launch_bounds__(64) void k_scan_counts(const int* __restrict__ wg_c
     if (lane == 0) n_raw[f] = base;
 }
 
-__global__ __launch_bounds__(256) void k_nms_emit(const uint8_t* __restrict__ score, int w, int h, int border, int rows_per_wg,
+__global__ __launch_bounds__(256) void k_nms_emit(const uint8_t* __restrict__ score, int w, int h, int wp, int border, int rows_per_wg,
                                                   const int* __restrict__ wg_off, int2* __restrict__ raw, size_t raw_cap)
 {
     __shared__ int wave_cnt[4];
     __shared__ int base_s;
     const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint8_t* Sc = score + (size_t)f * w * h;
+    const uint8_t* Sc = score + (size_t)f * wp * h;
     int2* out = raw + (size_t)f * raw_cap;
     if (tid == 0) base_s = wg_off[f * gridDim.x + blockIdx.x];
     __syncthreads();
     const int y0 = blockIdx.x * rows_per_wg;
     const int y1 = min(y0 + rows_per_wg, h);
-    for (int p0 = y0 * w; p0 < y1 * w; p0 += 256) {
-        const int p = p0 + tid;
-        int v = -1, x = 0, y = 0;
-        if (p < y1 * w) { x = p % w; y = p / w; v = nms_value(Sc, w, h, x, y, border); }
-        const unsigned long long bal = __ballot(v >= 0);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    const int qpr = wp / 4;
+    for (int q0 = y0 * qpr; q0 < y1 * qpr; q0 += 256) {
+        const int q = q0 + tid;
+        int m = 0, resp[4] = { 0, 0, 0, 0 }, xq = 0, y = 0;
+        if (q < y1 * qpr) { xq = 4 * (q % qpr); y = q / qpr; m = nms_quad(Sc, w, h, wp, xq, y, border, resp); }
+        const int mine = __popc(m);
+        // exclusive prefix of `mine` over the wavefront (thread order = raster order of the quads)
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) wave_cnt[wave] = incl;
         __syncthreads();
-        int off = base_s;
-        for (int q = 0; q < wave; ++q) off += wave_cnt[q];
-        if (v >= 0) out[off + before] = make_int2(x | (y << 16), v);
+        int off = base_s + incl - mine;
+        for (int w2 = 0; w2 < wave; ++w2) off += wave_cnt[w2];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) if (m & (1 << b)) out[off++] = make_int2((xq + b) | (y << 16), resp[b]);
         __syncthreads();
         if (tid == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         __syncthreads();
@@ -365,54 +431,82 @@ __device__ __forceinline__ int reflect101(int p, int n)
 }
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride,
-                                              OrbTaps taps, uint8_t* __restrict__ out)
+                                              OrbTaps taps, uint8_t* __restrict__ out, int wp)
 {
-    constexpr int SW = BT_W + 2 * MAXR, SH = BT_H + 2 * MAXR;
-    __shared__ uint8_t src[SH * (SW + 2)];
-    __shared__ int hrow[SH * BT_W];
-    constexpr int SP = SW + 2;
+    constexpr int SW = BT_W + 16, SH = BT_H + 2 * MAXR, SP = SW;       // window starts 8 pixels left of the tile (aligned), radius <= 7 used
+    __shared__ __attribute__((aligned(4))) uint8_t src[SH * SP];
+    __shared__ __attribute__((aligned(16))) int hrow[SH * BT_W];
     const int f = blockIdx.z, r = taps.radius;
     const uint8_t* I = img + (size_t)f * frame_stride;
-    uint8_t* O = out + (size_t)f * w * h;
+    uint8_t* O = out + (size_t)f * wp * h;
     const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
-    const int sw = BT_W + 2 * r, sh = BT_H + 2 * r;
-    // source tile with the reflected border
-    for (int e = threadIdx.x; e < sh * sw; e += 256) {
-        const int ty = e / sw, tx = e % sw;
-        src[ty * SP + tx] = I[(size_t)reflect101(y0 + ty - r, h) * stride + reflect101(x0 + tx - r, w)];
-    }
+    const int sh = BT_H + 2 * r;
+    stage_window<SW, SH, SP, true>(src, I, w, h, stride, x0 - 8, y0 - r, SW, sh);
     __syncthreads();
+    // taps into registers; products fit 24 bits (tap <= 256, pixel <= 255, row sum < 2^17), so the full-rate 24-bit
+    // multiply-add is exact
+    int tp[2 * MAXR + 1];
+#pragma unroll
+    for (int t = 0; t < 2 * MAXR + 1; ++t) tp[t] = t <= 2 * r ? taps.t[t] : 0;
     // horizontal pass for every staged row
     for (int e = threadIdx.x; e < sh * BT_W; e += 256) {
         const int ty = e / BT_W, tx = e % BT_W;
+        const uint8_t* sp = &src[ty * SP + 8 - r + tx];
         int acc = 0;
-        for (int t = 0; t <= 2 * r; ++t) acc += taps.t[t] * (int)src[ty * SP + tx + t];
+        if (r == 3) {
+#pragma unroll
+            for (int t = 0; t < 7; ++t) acc = (__mul24(tp[t], (int)sp[t]) + acc);
+        } else {
+            for (int t = 0; t <= 2 * r; ++t) acc = (__mul24(taps.t[t], (int)sp[t]) + acc);
+        }
         hrow[ty * BT_W + tx] = acc;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < BT_H * BT_W; e += 256) {
-        const int ty = e / BT_W, tx = e % BT_W;
-        const int x = x0 + tx, y = y0 + ty;
-        if (x >= w || y >= h) continue;
-        int acc = 0;
-        for (int t = 0; t <= 2 * r; ++t) acc += taps.t[t] * hrow[(ty + t) * BT_W + tx];
-        const int v = (acc + (1 << 15)) >> 16;
-        O[(size_t)y * w + x] = (uint8_t)(v > 255 ? 255 : v);
+    // vertical pass, 4 pixels per thread, one 32-bit store
+    for (int e = threadIdx.x; e < BT_H * (BT_W / 4); e += 256) {
+        const int ty = e / (BT_W / 4), tq = e % (BT_W / 4);
+        const int xq = x0 + 4 * tq, y = y0 + ty;
+        if (xq >= wp || y >= h) continue;
+        int acc4[4] = { 0, 0, 0, 0 };
+        if (r == 3) {
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                const int4 hv = *reinterpret_cast<const int4*>(&hrow[(ty + t) * BT_W + 4 * tq]);
+                acc4[0] = (__mul24(tp[t], hv.x) + acc4[0]); acc4[1] = (__mul24(tp[t], hv.y) + acc4[1]);
+                acc4[2] = (__mul24(tp[t], hv.z) + acc4[2]); acc4[3] = (__mul24(tp[t], hv.w) + acc4[3]);
+            }
+        } else {
+            for (int t = 0; t <= 2 * r; ++t) {
+                const int4 hv = *reinterpret_cast<const int4*>(&hrow[(ty + t) * BT_W + 4 * tq]);
+                acc4[0] = (__mul24(taps.t[t], hv.x) + acc4[0]); acc4[1] = (__mul24(taps.t[t], hv.y) + acc4[1]);
+                acc4[2] = (__mul24(taps.t[t], hv.z) + acc4[2]); acc4[3] = (__mul24(taps.t[t], hv.w) + acc4[3]);
+            }
+        }
+        uint32_t packed = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (xq + b >= w) continue;
+            const int v = (acc4[b] + (1 << 15)) >> 16;
+            packed |= (uint32_t)(v > 255 ? 255 : v) << (8 * b);
+        }
+        *reinterpret_cast<uint32_t*>(O + (size_t)y * wp + xq) = packed;
     }
 }
 
 // plain copy when gaussian_kernel_size <= 1
-__global__ void k_copy_image(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride, uint8_t* __restrict__ out)
+__global__ void k_copy_image(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride, uint8_t* __restrict__ out, int wp)
 {
     const int f = blockIdx.y;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < w * h; p += gridDim.x * blockDim.x)
-        out[(size_t)f * w * h + p] = img[(size_t)f * frame_stride + (size_t)(p / w) * stride + (p % w)];
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < wp * h; p += gridDim.x * blockDim.x) {
+        const int x = p % wp, y = p / wp;
+        out[(size_t)f * wp * h + p] = x < w ? img[(size_t)f * frame_stride + (size_t)y * stride + x] : 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // BRIEF-256: one wavefront per keypoint; lane l evaluates pairs 4l..4l+3, two lanes make a byte.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blurred, int w, int h, const mage_keypoint* __restrict__ kps,
+__global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blurred, int wp, int h, const mage_keypoint* __restrict__ kps,
                                                const int* __restrict__ counts, int capacity, const signed char* __restrict__ pattern,
                                                uint8_t* __restrict__ desc)
 {
@@ -422,13 +516,13 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blurr
     const mage_keypoint kp = kps[(size_t)f * capacity + k];
     // cvRound of an integer-valued float; angle 0 -> rotation row 0
     const int cx = (int)rintf(kp.x), cy = (int)rintf(kp.y);
-    const uint8_t* c = blurred + (size_t)f * w * h + (size_t)cy * w + cx;
+    const uint8_t* c = blurred + (size_t)f * wp * h + (size_t)cy * wp + cx;
     const signed char* p = pattern + lane * 16;
     int nib = 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const int t0 = c[p[4 * b + 1] * w + p[4 * b]];
-        const int t1 = c[p[4 * b + 3] * w + p[4 * b + 2]];
+        const int t0 = c[p[4 * b + 1] * wp + p[4 * b]];
+        const int t1 = c[p[4 * b + 3] * wp + p[4 * b + 2]];
         nib |= (t0 < t1) << b;
     }
     const int hi = __shfl_down(nib, 1, 64);
@@ -439,18 +533,18 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
 
-void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, uint8_t* score, hipStream_t st)
+void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, uint8_t* score, int wp, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_fast_score, dim3(cdiv(w, FT_W), cdiv(h, FT_H), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, threshold, score);
+    hipLaunchKernelGGL(k_fast_score, dim3(cdiv(wp, FT_W), cdiv(h, FT_H), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, threshold, score, wp);
 }
 
-void orb_launch_collect(const uint8_t* score, int w, int h, int n_frames, int border, int rows_per_wg, int n_wg, int* wg_count, int* wg_off,
+void orb_launch_collect(const uint8_t* score, int w, int h, int wp, int n_frames, int border, int rows_per_wg, int n_wg, int* wg_count, int* wg_off,
                         int* hist, int* n_raw, int2* raw, size_t raw_cap, hipStream_t st)
 {
     (void)hipMemsetAsync(hist, 0, sizeof(int) * 256 * (size_t)n_frames, st);
-    hipLaunchKernelGGL(k_nms_count, dim3(n_wg, n_frames), dim3(256), 0, st, score, w, h, border, rows_per_wg, wg_count, hist);
+    hipLaunchKernelGGL(k_nms_count, dim3(n_wg, n_frames), dim3(256), 0, st, score, w, h, wp, border, rows_per_wg, wg_count, hist);
     hipLaunchKernelGGL(k_scan_counts, dim3(n_frames), dim3(64), 0, st, wg_count, n_wg, wg_off, n_raw);
-    hipLaunchKernelGGL(k_nms_emit, dim3(n_wg, n_frames), dim3(256), 0, st, score, w, h, border, rows_per_wg, wg_off, raw, raw_cap);
+    hipLaunchKernelGGL(k_nms_emit, dim3(n_wg, n_frames), dim3(256), 0, st, score, w, h, wp, border, rows_per_wg, wg_off, raw, raw_cap);
 }
 
 void orb_launch_select(const OrbSelectArgs& a, int n_frames, hipStream_t st)
@@ -458,16 +552,16 @@ void orb_launch_select(const OrbSelectArgs& a, int n_frames, hipStream_t st)
     hipLaunchKernelGGL(k_select, dim3(n_frames), dim3(1024), 0, st, a);
 }
 
-void orb_launch_blur(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, const OrbTaps& taps, uint8_t* out, hipStream_t st)
+void orb_launch_blur(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, const OrbTaps& taps, uint8_t* out, int wp, hipStream_t st)
 {
-    if (taps.radius == 0) hipLaunchKernelGGL(k_copy_image, dim3(cdiv(w * h, 256 * 8), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, out);
-    else hipLaunchKernelGGL(k_blur, dim3(cdiv(w, BT_W), cdiv(h, BT_H), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, taps, out);
+    if (taps.radius == 0) hipLaunchKernelGGL(k_copy_image, dim3(cdiv(wp * h, 256 * 8), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, out, wp);
+    else hipLaunchKernelGGL(k_blur, dim3(cdiv(wp, BT_W), cdiv(h, BT_H), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, taps, out, wp);
 }
 
-void orb_launch_brief(const uint8_t* blurred, int w, int h, int n_frames, const mage_keypoint* kps, const int* counts, int capacity,
+void orb_launch_brief(const uint8_t* blurred, int wp, int h, int n_frames, const mage_keypoint* kps, const int* counts, int capacity,
                       const signed char* pattern, uint8_t* desc, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_brief, dim3(cdiv(capacity, 4), n_frames), dim3(256), 0, st, blurred, w, h, kps, counts, capacity, pattern, desc);
+    hipLaunchKernelGGL(k_brief, dim3(cdiv(capacity, 4), n_frames), dim3(256), 0, st, blurred, wp, h, kps, counts, capacity, pattern, desc);
 }
 
 }  // namespace mage
