@@ -106,6 +106,8 @@ struct mage_ba {
 
     // ---- StepOptimizer / LM state
     bool dirty = true, useless = false;
+    bool soft_dirty = false;            // observations were removed on the device since the last LM iteration
+    long long n_active_remaining = 0;
     int iteration = 0;
     double lambda = -1.0, user_lambda = 0.0, ni = 2.0;
 
@@ -121,7 +123,7 @@ struct mage_ba {
     DevBuf<int> d_lm_ptr, d_lm_pt, d_lm_wptr, d_w_hc, d_w_lm, d_camE_ptr, d_camE, d_camS_ptr, d_camS, d_blk_ptr;
     DevBuf<int2> d_blk_ij, d_con;
     DevBuf<double> d_errL, d_U, d_bc, d_V, d_bp, d_W, d_Dinv, d_db, d_S, d_y, d_xc, d_xl, d_partial, d_scal, d_Linv;
-    DevBuf<uint8_t> d_flagL;
+    DevBuf<uint8_t> d_flagL, d_L_active;
     DevBuf<int> d_queue;
     double* h_scal = nullptr;           // pinned mirror of d_scal
     BaDeviceView view{};
@@ -388,6 +390,8 @@ mage_status initialize_optimization(mage_ba* h)
     if (n_pad > CHOL_MAX_ORDER) return fail(MAGE_ERR_UNSUPPORTED, "reduced camera system of order %d exceeds %d (one resident workgroup per tile column)", n_pad, CHOL_MAX_ORDER);
     MAGE_TRY(h->d_queue.reserve(chol_sync_ints(n_pad)));
     MAGE_TRY(h->d_flagL.reserve((size_t)nL + 1));
+    MAGE_TRY(h->d_L_active.reserve((size_t)nL + 1));
+    MAGE_HIP(hipMemsetAsync(h->d_L_active.p, 1, (size_t)nL + 1, st));
     if (!h->h_scal) MAGE_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), SC_COUNT * sizeof(double)));
     MAGE_HIP(hipMemsetAsync(h->d_errL.p, 0, ((size_t)nL * 2 + 2) * sizeof(double), st));
     MAGE_HIP(hipStreamSynchronize(st));   // the host vectors above go out of scope
@@ -396,7 +400,7 @@ mage_status initialize_optimization(mage_ba* h)
     v.n_cams = nc; v.n_pts = np; v.n_L = nL; v.n_lm = nlm; v.n_fc = nfc; v.n_w = nw; v.n_blk = nblk;
     v.points_free = points_free ? 1 : 0; v.n_pad = n_pad;
     v.camK = h->d_camK.p; v.cam2hc = h->d_cam2hc.p; v.hc2cam = h->d_hc2cam.p;
-    v.L_uv = h->d_L_uv.p; v.L_info = h->d_L_info.p; v.L_cam = h->d_L_cam.p; v.L_pt = h->d_L_pt.p; v.L_slot = h->d_L_slot.p; v.L_edge = h->d_L_edge.p;
+    v.L_uv = h->d_L_uv.p; v.L_info = h->d_L_info.p; v.L_cam = h->d_L_cam.p; v.L_pt = h->d_L_pt.p; v.L_slot = h->d_L_slot.p; v.L_edge = h->d_L_edge.p; v.L_active = h->d_L_active.p;
     v.lm_ptr = h->d_lm_ptr.p; v.lm_pt = h->d_lm_pt.p; v.lm_wptr = h->d_lm_wptr.p; v.w_hc = h->d_w_hc.p; v.w_lm = h->d_w_lm.p;
     v.camE_ptr = h->d_camE_ptr.p; v.camE = h->d_camE.p; v.camS_ptr = h->d_camS_ptr.p; v.camS = h->d_camS.p;
     v.blk_ptr = h->d_blk_ptr.p; v.blk_ij = h->d_blk_ij.p; v.con = h->d_con.p;
@@ -409,6 +413,8 @@ mage_status initialize_optimization(mage_ba* h)
     h->prof.factor_flops_each = (double)n_pad * n_pad * n_pad / 3.0;
     h->iteration = 0;
     h->dirty = false;
+    h->soft_dirty = false;
+    h->n_active_remaining = nL;
     return MAGE_OK;
 }
 
@@ -490,6 +496,16 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
 mage_status step_optimizer(mage_ba* h, double huber, bool* cont)
 {
     if (h->dirty) MAGE_TRY(initialize_optimization(h));
+    else if (h->soft_dirty) {
+        // Outliers were removed since the last iteration.  The reference re-initialises the optimiser here
+        // (BundlerLib.cpp:135-138, 156-166): iteration 0 again, hence lambda re-seeded.  The graph arrays are NOT rebuilt:
+        // removed observations are masked on the device (L_active) and contribute nothing; a vertex left without
+        // observations keeps a lambda-only diagonal block and a zero right-hand side, i.e. it does not move, exactly
+        // as if it had been dropped from the index map.
+        h->iteration = 0;
+        h->soft_dirty = false;
+        if (h->n_active_remaining <= 0) h->useless = true;
+    }
     if (h->useless) { *cont = false; return MAGE_OK; }
     int r = LM_OK;
     MAGE_TRY(lm_solve(h, huber, &r));
@@ -728,7 +744,8 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
                 h->obs[ids[i]].removed = 1;                                  // removeEdge
                 if (outliers && i < capacity) outliers[i] = ids[i];
             }
-            h->dirty = true;
+            h->soft_dirty = true;
+            h->n_active_remaining -= (long long)ids.size();
         }
         if (n_outliers) *n_outliers = nout;
         return MAGE_OK;

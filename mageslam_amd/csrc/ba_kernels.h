@@ -32,6 +32,7 @@ struct BaDeviceView {
     // ---- observations, landmark order
     const float2* L_uv; const float* L_info; const uint32_t* L_cam; const uint32_t* L_pt;
     const int* L_slot;                         // W slot of the observation or -1
+    uint8_t* L_active;                         // 0 once the observation was removed as an outlier (soft removal, no rebuild)
     const uint32_t* L_edge;                    // original observation index
     const int* lm_ptr;                         // n_lm + 1 offsets into L_*
     const int* lm_pt;                          // n_lm : point index of the landmark

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256) void k_error(BaDeviceView v, int trial, double
     const double* pts = trial ? v.pt_trial : v.pt_cur;
     double acc = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n_L; i += gridDim.x * 256) {
+        if (!v.L_active[i]) continue;                      // removed observation (outlier): not part of the graph any more
         const int cam = v.L_cam[i], pt = v.L_pt[i];
         PoseD P = load_pose(pose, cam);
         const double2 xy = *reinterpret_cast<const double2*>(pts + (size_t)pt * 4);
@@ -189,6 +190,15 @@ __global__ __launch_bounds__(256) void k_linearize_lm(BaDeviceView v, double del
     const int beg = v.lm_ptr[l], end = v.lm_ptr[l + 1];
     int cur_slot = -1;
     for (int i = beg; i < end; ++i) {
+        const int slot = v.L_slot[i];
+        if (slot != cur_slot) {
+            if (cur_slot >= 0) {
+#pragma unroll
+                for (int k = 0; k < 18; ++k) { v.W[(size_t)cur_slot * 18 + k] = Wacc[k]; Wacc[k] = 0; }
+            }
+            cur_slot = slot;
+        }
+        if (!v.L_active[i]) continue;                      // removed observation: contributes nothing (its slot may end up all-zero)
         const int cam = v.L_cam[i];
         PoseD P = load_pose(v.pose_cur, cam);
         EdgeGeom g = edge_geom(P, v.camK, cam, X, Y, Z, v.L_uv[i]);
@@ -209,14 +219,6 @@ __global__ __launch_bounds__(256) void k_linearize_lm(BaDeviceView v, double del
         V[3] += Jp[1] * w * Jp[1] + Jp[4] * w * Jp[4];
         V[4] += Jp[1] * w * Jp[2] + Jp[4] * w * Jp[5];
         V[5] += Jp[2] * w * Jp[2] + Jp[5] * w * Jp[5];
-        const int slot = v.L_slot[i];
-        if (slot != cur_slot) {
-            if (cur_slot >= 0) {
-#pragma unroll
-                for (int k = 0; k < 18; ++k) { v.W[(size_t)cur_slot * 18 + k] = Wacc[k]; Wacc[k] = 0; }
-            }
-            cur_slot = slot;
-        }
         if (slot >= 0) {
             double Jc[12];
             jac_pose(g, f, Jc);
@@ -253,6 +255,7 @@ __global__ __launch_bounds__(256) void k_linearize_cam(BaDeviceView v, double de
     for (int k = 0; k < 6; ++k) b[k] = 0;
     for (int idx = v.camE_ptr[hc] + lane; idx < v.camE_ptr[hc + 1]; idx += WAVE) {
         const int i = v.camE[idx];
+        if (!v.L_active[i]) continue;
         const int pt = v.L_pt[i];
         const double2 xy = *reinterpret_cast<const double2*>(v.pt_cur + (size_t)pt * 4);
         const double Z = v.pt_cur[(size_t)pt * 4 + 2];
@@ -552,6 +555,7 @@ __global__ __launch_bounds__(256) void k_classify(BaDeviceView v, double max_err
     __shared__ double sm[4];
     double es = 0, ec = 0, no = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n_L; i += gridDim.x * 256) {
+        if (!v.L_active[i]) { flagL[i] = 0; continue; }
         const double2 e = *reinterpret_cast<const double2*>(v.errL + (size_t)i * 2);
         const double ss = e.x * e.x + e.y * e.y;
         const int cam = v.L_cam[i], pt = v.L_pt[i];
@@ -563,7 +567,8 @@ __global__ __launch_bounds__(256) void k_classify(BaDeviceView v, double max_err
         const double dot = (X[0] - wx) * fx + (X[1] - wy) * fy + (X[2] - wz) * fz;
         const bool out = (dot <= 0) || (ss > max_err_sq);
         flagL[i] = out ? 1 : 0;
-        if (out) no += 1.0; else { es += ss; ec += 1.0; }
+        if (out) { no += 1.0; v.L_active[i] = 0; }          // removeEdge: the observation leaves the graph on the device right here
+        else { es += ss; ec += 1.0; }
     }
     double r0 = block_sum<4>(es, sm);
     double r1 = block_sum<4>(ec, sm);
