@@ -73,8 +73,11 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X: torch.cuda.is_available() is False", file=sys.stderr)
         return 2
-    torch.cuda.set_device(local_rank)
-    dist = D.init("nccl", info)                     # "nccl" is RCCL on ROCm; None when world == 1
+    n_dev = torch.cuda.device_count()
+    device = local_rank % max(n_dev, 1)             # one GPU per rank on the node; the modulo only matters for the single-GPU plumbing test
+    torch.cuda.set_device(device)
+    # "nccl" is RCCL on ROCm.  MAGE_DIST_BACKEND=gloo lets the N > 1 plumbing be exercised on a box with fewer GPUs than ranks.
+    dist = D.init(os.environ.get("MAGE_DIST_BACKEND", "nccl"), info)
 
     from mageslam_amd import scene
     from mageslam_amd.bundler import BundlerLib, load_scene
@@ -82,7 +85,7 @@ def main() -> int:
     kw = dict(WORKLOADS[args.workload])
     kw["seed"] = D.submap_seed(kw["seed"], rank)    # independent sub-map per rank (weak scaling, no data-path collective)
     s = scene.make_scene(**kw)
-    b = BundlerLib(False, device=local_rank)
+    b = BundlerLib(False, device=device)
     load_scene(b, s, bulk=True)
     outl: list = []
     trials = 0
