@@ -8,8 +8,7 @@
 // include path the original call sites bind to these overloads as written; without them the raw-pointer overloads work.
 //
 // Error behaviour: the reference asserts / throws gsl::narrowing_error; the shim throws std::runtime_error carrying
-// mage_last_error() when the C ABI reports a failure.  Tether constraints (BundlerLib.h:40-47) are accepted with a
-// count of zero and otherwise throw (MAGE_ERR_UNSUPPORTED): SURVEY.md section 8f rank 1.
+// mage_last_error() when the C ABI reports a failure.
 #pragma once
 
 #include <cstddef>
@@ -76,6 +75,31 @@ namespace mage
         void AllocateFixedDistanceConstraints(size_t count) { Check(mage_ba_alloc_fixed_distance_constraints(m_impl.get(), count)); }
         void AllocateRelativeRotationConstraints(size_t count) { Check(mage_ba_alloc_relative_rotation_constraints(m_impl.get(), count)); }
         void AllocateRelativeTransformConstraints(size_t count) { Check(mage_ba_alloc_relative_transform_constraints(m_impl.get(), count)); }
+
+        // Tether edges (BundlerLib.h:40-47).  Q is anything with coeffs().data() in x, y, z, w order (Eigen::Quaternionf);
+        // the const float* overloads take the four coefficients directly.
+        void SetFixedDistanceConstraint(size_t idx, size_t cameraIndex1, size_t cameraIndex2, float distance = 1.0f, float weight = 1.0f)
+        {
+            Check(mage_ba_set_fixed_distance_constraint(m_impl.get(), idx, cameraIndex1, cameraIndex2, distance, weight));
+        }
+        template <typename Q>
+        void SetRelativeRotationConstraint(size_t idx, size_t cameraIndex1, size_t cameraIndex2, const Q& deltaRotation, float weight = 1.0f)
+        {
+            Check(mage_ba_set_relative_rotation_constraint(m_impl.get(), idx, cameraIndex1, cameraIndex2, deltaRotation.coeffs().data(), weight));
+        }
+        void SetRelativeRotationConstraint(size_t idx, size_t cameraIndex1, size_t cameraIndex2, const float* deltaRotationXYZW, float weight = 1.0f)
+        {
+            Check(mage_ba_set_relative_rotation_constraint(m_impl.get(), idx, cameraIndex1, cameraIndex2, deltaRotationXYZW, weight));
+        }
+        template <typename V3, typename Q>
+        void SetRelativeTransformConstraint(size_t idx, size_t cameraIndex1, size_t cameraIndex2, const V3& deltaPosition, const Q& deltaRotation, float weight)
+        {
+            Check(mage_ba_set_relative_transform_constraint(m_impl.get(), idx, cameraIndex1, cameraIndex2, deltaPosition.data(), deltaRotation.coeffs().data(), weight));
+        }
+        void SetRelativeTransformConstraint(size_t idx, size_t cameraIndex1, size_t cameraIndex2, const float* deltaPosition, const float* deltaRotationXYZW, float weight)
+        {
+            Check(mage_ba_set_relative_transform_constraint(m_impl.get(), idx, cameraIndex1, cameraIndex2, deltaPosition, deltaRotationXYZW, weight));
+        }
 
         void SetCurrentLambda(float userLambda) { Check(mage_ba_set_lambda(m_impl.get(), userLambda)); }
         float GetCurrentLambda() const { float v = 0; Check(mage_ba_get_lambda(m_impl.get(), &v)); return v; }

@@ -32,7 +32,7 @@ typedef enum mage_status {
     MAGE_ERR_INVALID_ARGUMENT = 1,   /* null handle/pointer, index out of range, allocate-twice */
     MAGE_ERR_OUT_OF_MEMORY = 2,
     MAGE_ERR_DEVICE = 3,             /* HIP runtime error; see mage_last_error() */
-    MAGE_ERR_UNSUPPORTED = 4,        /* part of the surface that is not built yet (tether edges) */
+    MAGE_ERR_UNSUPPORTED = 4,        /* part of the surface that is not built (none of the BundlerLib surface at present; ORB/match variants) */
     MAGE_ERR_NO_DEVICE = 5           /* no gfx950 device visible: the HIP path never falls back to a CPU */
 } mage_status;
 
@@ -75,12 +75,26 @@ mage_status mage_ba_set_points_bulk(mage_ba* h, size_t count, const float* xyz3)
 mage_status mage_ba_set_observations_bulk(mage_ba* h, size_t count, const float* uv2, const uint32_t* camera_index,
                                           const uint32_t* point_index, const float* information_scalar);
 
-/* Tether edges (BundlerLib.cpp:231-259, 311-350): SURVEY.md section 8f rank 1, not built yet.
- * Allocating zero constraints succeeds (that is what BuildDataForG2O does for monocular maps);
- * a non-zero count returns MAGE_ERR_UNSUPPORTED. */
+/* Tether edges: pose-pose constraints between two cameras (stereo rigs, inertial fusion; gathered by
+ * BundleAdjust.cpp:57-112, handed over at :155-192).  Allocate* once each (BundlerLib.cpp:231-259; a count of zero is
+ * what monocular maps pass), then one Set* per index.  Quaternions are Eigen::Quaternionf coefficient order x, y, z, w.
+ *   fixed distance      BundlerLib.cpp:24-54, 311-322   e = (distance - |t_2 - t_1|) * weight, t = pose translation
+ *   relative rotation   BundlerLib.cpp:56-90, 324-336   e = angle between (T_1^-1 T_2).rotation and delta_rotation, * weight
+ *   relative transform  BundlerLib.cpp:338-350          g2o EdgeSE3Expmap: e = log(T_2^-1 * SE3(delta_rotation, delta_position) * T_1),
+ *                                                       information weight * I6
+ * The first two are differentiated numerically exactly as g2o's BaseMultiEdge does (central differences, step 1e-9).
+ * A tether is active unless both cameras are fixed; it takes no part in the outlier pass or the returned mean error
+ * (the reference walks tether edges there through a mis-typed vertex cast, BundlerLib.cpp:402-403 -- undefined behaviour
+ * that is not reproduced).  camera_index_1 == camera_index_2 is rejected with MAGE_ERR_INVALID_ARGUMENT. */
 mage_status mage_ba_alloc_fixed_distance_constraints(mage_ba* h, size_t count);
 mage_status mage_ba_alloc_relative_rotation_constraints(mage_ba* h, size_t count);
 mage_status mage_ba_alloc_relative_transform_constraints(mage_ba* h, size_t count);
+mage_status mage_ba_set_fixed_distance_constraint(mage_ba* h, size_t idx, size_t camera_index_1, size_t camera_index_2,
+                                                  float distance, float weight);
+mage_status mage_ba_set_relative_rotation_constraint(mage_ba* h, size_t idx, size_t camera_index_1, size_t camera_index_2,
+                                                     const float delta_rotation_xyzw[4], float weight);
+mage_status mage_ba_set_relative_transform_constraint(mage_ba* h, size_t idx, size_t camera_index_1, size_t camera_index_2,
+                                                      const float delta_position[3], const float delta_rotation_xyzw[4], float weight);
 
 /* SetCurrentLambda / GetCurrentLambda  (BundlerLib.cpp:123-130, 354-362) */
 mage_status mage_ba_set_lambda(mage_ba* h, float user_lambda);

@@ -54,6 +54,9 @@ def _declare():
     L.mage_ba_set_cameras_bulk.argtypes = [vp, sz, _f32, _f32, _f32, _u8]
     L.mage_ba_set_points_bulk.argtypes = [vp, sz, _f32]
     L.mage_ba_set_observations_bulk.argtypes = [vp, sz, _f32, _u32, _u32, _f32]
+    L.mage_ba_set_fixed_distance_constraint.argtypes = [vp, sz, sz, sz, C.c_float, C.c_float]
+    L.mage_ba_set_relative_rotation_constraint.argtypes = [vp, sz, sz, sz, _f32, C.c_float]
+    L.mage_ba_set_relative_transform_constraint.argtypes = [vp, sz, sz, sz, _f32, _f32, C.c_float]
     L.mage_ba_set_lambda.argtypes = [vp, C.c_float]
     L.mage_ba_get_lambda.argtypes = [vp, C.POINTER(C.c_float)]
     L.mage_ba_step.argtypes = [vp, _f32, sz, C.c_float, _u32, sz, C.POINTER(sz), C.POINTER(C.c_float)]
@@ -107,6 +110,19 @@ class BundlerLib:
     def AllocateFixedDistanceConstraints(self, count): check(self._L.mage_ba_alloc_fixed_distance_constraints(self._h, count))
     def AllocateRelativeRotationConstraints(self, count): check(self._L.mage_ba_alloc_relative_rotation_constraints(self._h, count))
     def AllocateRelativeTransformConstraints(self, count): check(self._L.mage_ba_alloc_relative_transform_constraints(self._h, count))
+
+    # quaternions: Eigen::Quaternionf coefficient order x, y, z, w (BundlerLib.h:40-47)
+    def SetFixedDistanceConstraint(self, idx, camera_index_1, camera_index_2, distance=1.0, weight=1.0):
+        check(self._L.mage_ba_set_fixed_distance_constraint(self._h, idx, int(camera_index_1), int(camera_index_2), float(distance), float(weight)))
+
+    def SetRelativeRotationConstraint(self, idx, camera_index_1, camera_index_2, delta_rotation_xyzw, weight=1.0):
+        check(self._L.mage_ba_set_relative_rotation_constraint(self._h, idx, int(camera_index_1), int(camera_index_2),
+                                                               np.ascontiguousarray(delta_rotation_xyzw, np.float32), float(weight)))
+
+    def SetRelativeTransformConstraint(self, idx, camera_index_1, camera_index_2, delta_position, delta_rotation_xyzw, weight):
+        check(self._L.mage_ba_set_relative_transform_constraint(self._h, idx, int(camera_index_1), int(camera_index_2),
+                                                                np.ascontiguousarray(delta_position, np.float32),
+                                                                np.ascontiguousarray(delta_rotation_xyzw, np.float32), float(weight)))
 
     # --- bulk setters (mage_ba_set_*_bulk)
     def SetCamerasBulk(self, positions, R_colmajor, intrinsics, fixed):
@@ -196,6 +212,7 @@ def load_scene(bundler, scene, bulk: bool = False) -> None:
         bundler.SetMapPointsBulk(scene.points)
         bundler.AllocateObservations(scene.n_obs)
         bundler.SetObservationsBulk(scene.obs_uv, scene.obs_cam, scene.obs_pt, scene.obs_info)
+        _feed_tethers(bundler, scene)
         return
     for i in range(scene.n_cams):
         bundler.SetCameraPose(i, scene.cam_t[i], Rcm[i], scene.cam_K[i], bool(scene.cam_fixed[i]))
@@ -205,3 +222,10 @@ def load_scene(bundler, scene, bulk: bool = False) -> None:
     bundler.AllocateObservations(scene.n_obs)
     for i in range(scene.n_obs):
         bundler.SetObservation(i, scene.obs_uv[i], scene.obs_cam[i], scene.obs_pt[i], scene.obs_info[i])
+    _feed_tethers(bundler, scene)
+
+
+def _feed_tethers(bundler, scene) -> None:
+    if getattr(scene, "tethers", None) is not None:
+        from .scene import feed_tethers
+        feed_tethers(bundler, scene.tethers)

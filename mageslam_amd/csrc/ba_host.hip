@@ -49,6 +49,11 @@ struct HostCam {
     double f = 1, cx = 0, cy = 0;
     uint8_t fixed = 0, set = 0;
 };
+struct HostTether {                 // one EdgeScaleConstraint / EdgeRotationConstraint / EdgeSE3Expmap
+    uint32_t c0 = 0, c1 = 0;
+    double q[4] = { 0, 0, 0, 1 }, t[3] = { 0, 0, 0 }, dist = 0, w = 0;
+    uint8_t set = 0;
+};
 struct HostObs {
     float u = 0, v = 0, info = 0;
     uint32_t cam = 0, pt = 0;
@@ -102,7 +107,8 @@ struct mage_ba {
     std::vector<double> pts;            // n x 3
     std::vector<uint8_t> pt_set;
     std::vector<HostObs> obs;
-    bool cams_allocated = false, pts_allocated = false, obs_allocated = false;
+    std::vector<HostTether> teth[3];    // FixedDistance / RelativeRotation / RelativeTransform constraints
+    bool cams_allocated = false, pts_allocated = false, obs_allocated = false, teth_allocated[3] = { false, false, false };
 
     // ---- StepOptimizer / LM state
     bool dirty = true, useless = false;
@@ -124,6 +130,10 @@ struct mage_ba {
     DevBuf<int2> d_blk_ij, d_con;
     DevBuf<double> d_errL, d_U, d_bc, d_V, d_bp, d_W, d_Dinv, d_db, d_S, d_y, d_xc, d_xl, d_partial, d_scal, d_Linv;
     DevBuf<uint8_t> d_flagL, d_L_active;
+    DevBuf<int> d_T_kind, d_tc_hc, d_tc_ptr, d_tc_item, d_tp_ptr, d_tp_item;
+    DevBuf<int2> d_T_cam, d_T_fixed, d_tp_ij;
+    DevBuf<double> d_T_meas, d_T_w, d_T_out;
+    int n_active_tethers = 0;
     DevBuf<int> d_queue;
     double* h_scal = nullptr;           // pinned mirror of d_scal
     BaDeviceView view{};
@@ -236,6 +246,23 @@ mage_status initialize_optimization(mage_ba* h)
         active.push_back((uint32_t)e);
         cam_deg[o.cam]++; pt_deg[o.pt]++;
     }
+    // tether edges: active unless both endpoints are fixed (OptimizableGraph::Edge::allVerticesFixed); they keep a
+    // free camera in the system even when it has no observation
+    std::vector<int> T_kind; std::vector<int2> T_cam, T_fixed; std::vector<double> T_meas, T_w;
+    for (int k = 0; k < 3; ++k)
+        for (const HostTether& t : h->teth[k]) {
+            if (!t.set) continue;
+            if (h->cams[t.c0].fixed && h->cams[t.c1].fixed) continue;
+            T_kind.push_back(k);
+            T_cam.push_back(make_int2((int)t.c0, (int)t.c1));
+            T_fixed.push_back(make_int2(h->cams[t.c0].fixed ? 1 : 0, h->cams[t.c1].fixed ? 1 : 0));
+            for (int a = 0; a < 4; ++a) T_meas.push_back(t.q[a]);
+            for (int a = 0; a < 3; ++a) T_meas.push_back(t.t[a]);
+            T_meas.push_back(t.dist);
+            T_w.push_back(t.w);
+            cam_deg[t.c0]++; cam_deg[t.c1]++;
+        }
+    const int nT = (int)T_kind.size();
     const int nL = (int)active.size();
     std::vector<int> cam2hc(nc, -1), hc2cam;
     for (int i = 0; i < nc; ++i)
@@ -346,6 +373,37 @@ mage_status initialize_optimization(mage_ba* h)
     const int nblk = (int)blk_ij.size();
     E.clear(); E.shrink_to_fit();
 
+    // tether gather lists: per camera (tether, side) and per free-camera pair i < j (tether, transposed), tether order kept
+    std::vector<int> tc_hc, tc_ptr{ 0 }, tc_item, tp_ptr{ 0 }, tp_item; std::vector<int2> tp_ij;
+    if (nT > 0) {
+        std::vector<std::pair<int, int>> ci;                    // (hc, item)
+        std::vector<std::pair<uint64_t, int>> pi;               // ((i << 32) | j, item)
+        for (int t = 0; t < nT; ++t) {
+            const int h0 = cam2hc[T_cam[t].x], h1 = cam2hc[T_cam[t].y];
+            if (h0 >= 0) ci.push_back({ h0, t * 2 });
+            if (h1 >= 0) ci.push_back({ h1, t * 2 + 1 });
+            if (h0 >= 0 && h1 >= 0) {
+                if (h0 < h1) pi.push_back({ ((uint64_t)h0 << 32) | (uint32_t)h1, t * 2 });
+                else pi.push_back({ ((uint64_t)h1 << 32) | (uint32_t)h0, t * 2 + 1 });
+            }
+        }
+        std::stable_sort(ci.begin(), ci.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+        std::stable_sort(pi.begin(), pi.end(), [](const std::pair<uint64_t, int>& a, const std::pair<uint64_t, int>& b) { return a.first < b.first; });
+        for (size_t k = 0; k < ci.size(); ++k) {
+            if (k == 0 || ci[k].first != ci[k - 1].first) { if (k) tc_ptr.push_back((int)k); tc_hc.push_back(ci[k].first); }
+            tc_item.push_back(ci[k].second);
+        }
+        if (!ci.empty()) tc_ptr.push_back((int)ci.size());
+        for (size_t k = 0; k < pi.size(); ++k) {
+            if (k == 0 || pi[k].first != pi[k - 1].first) {
+                if (k) tp_ptr.push_back((int)k);
+                tp_ij.push_back(make_int2((int)(pi[k].first >> 32), (int)(pi[k].first & 0xffffffffu)));
+            }
+            tp_item.push_back(pi[k].second);
+        }
+        if (!pi.empty()) tp_ptr.push_back((int)pi.size());
+    }
+
     const int n = nfc * 6;
     const int n_pad = std::max(CHOL_TILE, ((n + CHOL_TILE - 1) / CHOL_TILE) * CHOL_TILE);
 
@@ -370,6 +428,18 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(h->d_blk_ptr.upload(blk_ptr.data(), blk_ptr.size(), st));
     MAGE_TRY(h->d_blk_ij.upload(blk_ij.data(), blk_ij.size(), st));
     MAGE_TRY(h->d_con.upload(con.data(), con.size(), st));
+    MAGE_TRY(h->d_T_kind.upload(T_kind.data(), T_kind.size(), st));
+    MAGE_TRY(h->d_T_cam.upload(T_cam.data(), T_cam.size(), st));
+    MAGE_TRY(h->d_T_fixed.upload(T_fixed.data(), T_fixed.size(), st));
+    MAGE_TRY(h->d_T_meas.upload(T_meas.data(), T_meas.size(), st));
+    MAGE_TRY(h->d_T_w.upload(T_w.data(), T_w.size(), st));
+    MAGE_TRY(h->d_tc_hc.upload(tc_hc.data(), tc_hc.size(), st));
+    MAGE_TRY(h->d_tc_ptr.upload(tc_ptr.data(), tc_ptr.size(), st));
+    MAGE_TRY(h->d_tc_item.upload(tc_item.data(), tc_item.size(), st));
+    MAGE_TRY(h->d_tp_ij.upload(tp_ij.data(), tp_ij.size(), st));
+    MAGE_TRY(h->d_tp_ptr.upload(tp_ptr.data(), tp_ptr.size(), st));
+    MAGE_TRY(h->d_tp_item.upload(tp_item.data(), tp_item.size(), st));
+    MAGE_TRY(h->d_T_out.reserve((size_t)nT * TETHER_OUT_STRIDE + 1));
 
     const int nb_l = (nlm + 255) / 256, nb_c = (nfc + 255) / 256;
     MAGE_TRY(h->d_errL.reserve((size_t)nL * 2 + 2));
@@ -404,6 +474,11 @@ mage_status initialize_optimization(mage_ba* h)
     v.lm_ptr = h->d_lm_ptr.p; v.lm_pt = h->d_lm_pt.p; v.lm_wptr = h->d_lm_wptr.p; v.w_hc = h->d_w_hc.p; v.w_lm = h->d_w_lm.p;
     v.camE_ptr = h->d_camE_ptr.p; v.camE = h->d_camE.p; v.camS_ptr = h->d_camS_ptr.p; v.camS = h->d_camS.p;
     v.blk_ptr = h->d_blk_ptr.p; v.blk_ij = h->d_blk_ij.p; v.con = h->d_con.p;
+    v.n_T = nT; v.n_tc = (int)tc_hc.size(); v.n_tp = (int)tp_ij.size();
+    v.T_kind = h->d_T_kind.p; v.T_cam = h->d_T_cam.p; v.T_fixed = h->d_T_fixed.p; v.T_meas = h->d_T_meas.p; v.T_w = h->d_T_w.p; v.T_out = h->d_T_out.p;
+    v.tc_hc = h->d_tc_hc.p; v.tc_ptr = h->d_tc_ptr.p; v.tc_item = h->d_tc_item.p;
+    v.tp_ij = h->d_tp_ij.p; v.tp_ptr = h->d_tp_ptr.p; v.tp_item = h->d_tp_item.p;
+    h->n_active_tethers = nT;
     v.errL = h->d_errL.p; v.U = h->d_U.p; v.bc = h->d_bc.p; v.V = h->d_V.p; v.bp = h->d_bp.p; v.W = h->d_W.p;
     v.Dinv = h->d_Dinv.p; v.db = h->d_db.p; v.S = h->d_S.p; v.y = h->d_y.p; v.xc = h->d_xc.p; v.xl = h->d_xl.p;
     v.partial = h->d_partial.p; v.scal = h->d_scal.p;
@@ -504,7 +579,7 @@ mage_status step_optimizer(mage_ba* h, double huber, bool* cont)
         // as if it had been dropped from the index map.
         h->iteration = 0;
         h->soft_dirty = false;
-        if (h->n_active_remaining <= 0) h->useless = true;
+        if (h->n_active_remaining <= 0 && h->n_active_tethers == 0) h->useless = true;
     }
     if (h->useless) { *cont = false; return MAGE_OK; }
     int r = LM_OK;
@@ -684,15 +759,73 @@ MAGE_EXPORT mage_status mage_ba_set_observations_bulk(mage_ba* h, size_t count, 
     });
 }
 
-static mage_status tether_alloc(mage_ba* h, size_t count, const char* what)
+static mage_status tether_alloc(mage_ba* h, size_t count, int kind)
+{
+    return guarded([&]() -> mage_status {
+        if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+        if (h->teth_allocated[kind]) return fail(MAGE_ERR_INVALID_ARGUMENT, "constraints of this kind can only be allocated once");   // BundlerLib.cpp:233-258
+        h->teth[kind].assign(count, HostTether());
+        h->teth_allocated[kind] = true;
+        return MAGE_OK;
+    });
+}
+MAGE_EXPORT mage_status mage_ba_alloc_fixed_distance_constraints(mage_ba* h, size_t n) { return tether_alloc(h, n, TETHER_DISTANCE); }
+MAGE_EXPORT mage_status mage_ba_alloc_relative_rotation_constraints(mage_ba* h, size_t n) { return tether_alloc(h, n, TETHER_ROTATION); }
+MAGE_EXPORT mage_status mage_ba_alloc_relative_transform_constraints(mage_ba* h, size_t n) { return tether_alloc(h, n, TETHER_TRANSFORM); }
+
+static mage_status tether_slot(mage_ba* h, int kind, size_t idx, size_t c1, size_t c2, HostTether** out)
 {
     if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
-    if (count == 0) return MAGE_OK;
-    return fail(MAGE_ERR_UNSUPPORTED, "%s constraints are not built yet (SURVEY.md 8f rank 1)", what);
+    if (idx >= h->teth[kind].size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "constraint index %zu out of range (%zu allocated)", idx, h->teth[kind].size());
+    if (c1 >= h->cams.size() || c2 >= h->cams.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "constraint %zu: camera index out of range", idx);
+    if (c1 == c2) return fail(MAGE_ERR_INVALID_ARGUMENT, "constraint %zu joins camera %zu to itself", idx, c1);
+    MAGE_TRY(before_host_edit(h));
+    HostTether& t = h->teth[kind][idx];
+    t = HostTether();
+    t.c0 = (uint32_t)c1; t.c1 = (uint32_t)c2; t.set = 1;
+    *out = &t;
+    return MAGE_OK;
 }
-MAGE_EXPORT mage_status mage_ba_alloc_fixed_distance_constraints(mage_ba* h, size_t n) { return tether_alloc(h, n, "fixed-distance"); }
-MAGE_EXPORT mage_status mage_ba_alloc_relative_rotation_constraints(mage_ba* h, size_t n) { return tether_alloc(h, n, "relative-rotation"); }
-MAGE_EXPORT mage_status mage_ba_alloc_relative_transform_constraints(mage_ba* h, size_t n) { return tether_alloc(h, n, "relative-transform"); }
+
+MAGE_EXPORT mage_status mage_ba_set_fixed_distance_constraint(mage_ba* h, size_t idx, size_t c1, size_t c2, float distance, float weight)
+{
+    return guarded([&]() -> mage_status {
+        HostTether* t = nullptr;
+        MAGE_TRY(tether_slot(h, TETHER_DISTANCE, idx, c1, c2, &t));
+        t->dist = (double)distance; t->w = (double)weight;             // BundlerLib.cpp:315-319
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_set_relative_rotation_constraint(mage_ba* h, size_t idx, size_t c1, size_t c2, const float* q, float weight)
+{
+    return guarded([&]() -> mage_status {
+        if (!q) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        HostTether* t = nullptr;
+        MAGE_TRY(tether_slot(h, TETHER_ROTATION, idx, c1, c2, &t));
+        for (int a = 0; a < 4; ++a) t->q[a] = (double)q[a];            // deltaRotation.cast<number_t>(), not normalised (BundlerLib.cpp:333)
+        t->w = (double)weight;
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_set_relative_transform_constraint(mage_ba* h, size_t idx, size_t c1, size_t c2, const float* p,
+                                                                  const float* q, float weight)
+{
+    return guarded([&]() -> mage_status {
+        if (!q || !p) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        HostTether* t = nullptr;
+        MAGE_TRY(tether_slot(h, TETHER_TRANSFORM, idx, c1, c2, &t));
+        // setMeasurement({q, p}) builds an SE3Quat, whose constructor normalises the rotation (BundlerLib.cpp:348)
+        double d[4] = { (double)q[0], (double)q[1], (double)q[2], (double)q[3] };
+        if (d[3] < 0) { d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; d[3] = -d[3]; }
+        const double n = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
+        for (int a = 0; a < 4; ++a) t->q[a] = d[a] / n;
+        for (int a = 0; a < 3; ++a) t->t[a] = (double)p[a];
+        t->w = (double)weight;                                         // information = Identity * weight
+        return MAGE_OK;
+    });
+}
 
 MAGE_EXPORT mage_status mage_ba_set_lambda(mage_ba* h, float user_lambda)
 {

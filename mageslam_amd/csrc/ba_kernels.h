@@ -44,6 +44,15 @@ struct BaDeviceView {
     // ---- reduced-camera-matrix structure
     const int* blk_ptr; const int2* blk_ij; const int2* con;   // contributions (slot_a, slot_b) per block
 
+    // ---- tether edges (pose-pose constraints; active ones only, all three kinds in one list)
+    int n_T, n_tc, n_tp;                       // tethers / cameras carrying tethers / free-camera pairs joined by tethers
+    const int* T_kind; const int2* T_cam; const int2* T_fixed;   // kind, (camera a, camera b), (a fixed, b fixed)
+    const double* T_meas;                      // n_T x 8 : measurement q(x y z w) t(x y z) distance
+    const double* T_w;                         // n_T : weight
+    double* T_out;                             // n_T x TETHER_OUT_STRIDE : H_aa(36) H_bb(36) H_ab(36) b_a(6) b_b(6)
+    const int* tc_hc; const int* tc_ptr; const int* tc_item;     // per camera: (tether << 1 | side) in tether order
+    const int2* tp_ij; const int* tp_ptr; const int* tp_item;    // per pair i < j: (tether << 1 | transposed)
+
     // ---- linear system
     double* errL;          // n_L x 2   residual of the last error evaluation
     double* U; double* bc; // n_fc x 36, n_fc x 6
@@ -59,6 +68,9 @@ struct BaDeviceView {
     double* scal;          // device scalars, see enum Scal
 };
 
+enum TetherKind { TETHER_DISTANCE = 0, TETHER_ROTATION = 1, TETHER_TRANSFORM = 2 };
+constexpr int TETHER_OUT_STRIDE = 120;
+
 enum Scal { SC_CHI = 0, SC_SCALE = 1, SC_MAXDIAG = 2, SC_CHOL_OK = 3, SC_ERRSUM = 4, SC_ERRCNT = 5, SC_NOUT = 6, SC_COUNT = 8 };
 
 // All launchers enqueue on `st` and return immediately.
@@ -68,5 +80,10 @@ void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st);                  
 void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st);                          // Dinv,db,S,y
 void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st);                         // xl, trial state, scal[SC_SCALE]
 void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flag_by_edge, hipStream_t st); // scal[SC_ERRSUM..SC_NOUT]
+
+// tether_kernels.hip (called by the launchers above when the problem carries tethers)
+void tether_launch_error(const BaDeviceView& v, bool trial, hipStream_t st);      // scal[SC_CHI] += tether chi2
+void tether_launch_linearize(const BaDeviceView& v, hipStream_t st);              // U, bc += tether blocks
+void tether_launch_schur(const BaDeviceView& v, hipStream_t st);                  // S += pose-pose blocks
 
 }  // namespace mage

@@ -586,12 +586,14 @@ void ba_launch_error(const BaDeviceView& v, bool trial, double delta, hipStream_
     int nb = v.n_L > 0 ? (cdiv(v.n_L, 256) < RED_BLOCKS ? cdiv(v.n_L, 256) : RED_BLOCKS) : 1;
     hipLaunchKernelGGL(k_error, dim3(nb), dim3(256), 0, st, v, trial ? 1 : 0, delta, nb);
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_CHI, 1);
+    tether_launch_error(v, trial, st);
 }
 
 void ba_launch_linearize(const BaDeviceView& v, double delta, hipStream_t st)
 {
     if (v.points_free && v.n_lm > 0) hipLaunchKernelGGL(k_linearize_lm, dim3(cdiv(v.n_lm, 256)), dim3(256), 0, st, v, delta);
     if (v.n_fc > 0) hipLaunchKernelGGL(k_linearize_cam, dim3(cdiv(v.n_fc, 4)), dim3(256), 0, st, v, delta);
+    tether_launch_linearize(v, st);
 }
 
 void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st)
@@ -607,6 +609,7 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st)
     if (v.n_pad > n) hipLaunchKernelGGL(k_pad_diag, dim3(cdiv(v.n_pad - n, 128)), dim3(128), 0, st, v.S, n, v.n_pad);
     if (v.points_free && v.n_lm > 0) hipLaunchKernelGGL(k_lm_invert, dim3(cdiv(v.n_lm, 256)), dim3(256), 0, st, v, lambda);
     if (v.n_blk > 0) hipLaunchKernelGGL(k_schur_block, dim3(cdiv(v.n_blk, 4)), dim3(256), 0, st, v, lambda);
+    tether_launch_schur(v, st);
     if (v.n_fc > 0) hipLaunchKernelGGL(k_schur_rhs, dim3(cdiv(v.n_fc, 4)), dim3(256), 0, st, v);
 }
 

@@ -95,10 +95,102 @@ class Scene:
     gt_cam_R: np.ndarray = field(default=None)
     gt_points: np.ndarray = field(default=None)
     outlier_mask: np.ndarray = field(default=None)
+    tethers: "Tethers" = field(default=None)      # optional pose-pose constraints (stereo rigs, sensor fusion)
 
     def cam_R_colmajor(self) -> np.ndarray:
         """(n_cams, 9) f32, column-major 3x3 as Eigen::Map<const Matrix3f> expects."""
         return np.ascontiguousarray(self.cam_R.transpose(0, 2, 1).reshape(self.n_cams, 9))
+
+
+@dataclass
+class Tethers:
+    """Pose-pose constraints in the float32 form of BundlerLib.h:40-47 (quaternions x, y, z, w as Eigen stores them).
+
+    distance : (d - |t_b - t_a|) * w                       BundlerLib.cpp:45-51
+    rotation : angle((T_a^-1 T_b).rotation, q) * w          BundlerLib.cpp:76-87
+    transform: log(T_b^-1 * SE3(q, p) * T_a), info w * I6   g2o EdgeSE3Expmap, BundlerLib.cpp:338-350
+    """
+    dist_cams: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.uint32))
+    dist_d: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+    dist_w: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+    rot_cams: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.uint32))
+    rot_q: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.float32))
+    rot_w: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+    xf_cams: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.uint32))
+    xf_p: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+    xf_q: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.float32))
+    xf_w: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+
+
+def quat_from_R(R: np.ndarray) -> np.ndarray:
+    """(n, 3, 3) rotation matrices -> (n, 4) unit quaternions x, y, z, w with w >= 0 (Shepperd's method)."""
+    R = np.asarray(R, np.float64).reshape(-1, 3, 3)
+    q = np.zeros((R.shape[0], 4))
+    for i, m in enumerate(R):
+        c = np.array([m[0, 0], m[1, 1], m[2, 2], m[0, 0] + m[1, 1] + m[2, 2]])
+        k = int(np.argmax(c))
+        if k == 3:
+            w = 0.5 * np.sqrt(1 + c[3])
+            v = np.array([m[2, 1] - m[1, 2], m[0, 2] - m[2, 0], m[1, 0] - m[0, 1]]) / (4 * w)
+            q[i] = [v[0], v[1], v[2], w]
+        else:
+            a, b, d = k, (k + 1) % 3, (k + 2) % 3
+            s = 2 * np.sqrt(1 + m[a, a] - m[b, b] - m[d, d])
+            q[i, a] = 0.25 * s
+            q[i, b] = (m[b, a] + m[a, b]) / s
+            q[i, d] = (m[d, a] + m[a, d]) / s
+            q[i, 3] = (m[d, b] - m[b, d]) / s
+        if q[i, 3] < 0:
+            q[i] = -q[i]
+    return q / np.linalg.norm(q, axis=1, keepdims=True)
+
+
+def make_tethers(scene: Scene, n_dist: int = 0, n_rot: int = 0, n_xf: int = 0, *, seed: int = 0x7E7E0001,
+                 stride: int = 1, step: int = 3, weight: float = 30.0, noise: float = 1e-3) -> Tethers:
+    """Tethers between cameras (i, i + stride) measured on the ground-truth poses plus a little noise, the way a
+    stereo rig / inertial fuser would produce them (BundleAdjust.cpp:57-112).  Kinds cycle over the camera rail."""
+    nc = scene.n_cams
+    R, t = scene.gt_cam_R, scene.gt_cam_t
+    S_T = np.uint64(9)
+
+    def pairs(n, off):
+        a = (off + np.arange(n) * step) % max(nc - stride, 1)
+        return np.stack([a, a + stride], axis=1).astype(np.uint32)
+
+    T = Tethers()
+    if n_dist:
+        c = pairs(n_dist, 0)
+        d = np.linalg.norm(t[c[:, 1]] - t[c[:, 0]], axis=1) + noise * normal(seed, S_T, np.arange(n_dist), 0)
+        T.dist_cams, T.dist_d, T.dist_w = c, d.astype(np.float32), np.full(n_dist, weight, np.float32)
+    if n_rot:
+        c = pairs(n_rot, 1)
+        dw = noise * np.stack([normal(seed, S_T, 1000 + np.arange(n_rot), k) for k in range(3)], axis=1)
+        Rrel = so3_exp(dw) @ (R[c[:, 0]].transpose(0, 2, 1) @ R[c[:, 1]])           # (T_a^-1 T_b).rotation
+        T.rot_cams, T.rot_q, T.rot_w = c, quat_from_R(Rrel).astype(np.float32), np.full(n_rot, weight, np.float32)
+    if n_xf:
+        c = pairs(n_xf, 2)
+        # C = T_b * T_a^-1 makes the error log(T_b^-1 C T_a) vanish on the ground truth
+        Rc = R[c[:, 1]] @ R[c[:, 0]].transpose(0, 2, 1)
+        pc = t[c[:, 1]] - np.einsum("nij,nj->ni", Rc, t[c[:, 0]])
+        dw = noise * np.stack([normal(seed, S_T, 2000 + np.arange(n_xf), k) for k in range(3)], axis=1)
+        dp = noise * np.stack([normal(seed, S_T, 2000 + np.arange(n_xf), 3 + k) for k in range(3)], axis=1)
+        T.xf_cams, T.xf_p, T.xf_q = c, (pc + dp).astype(np.float32), quat_from_R(so3_exp(dw) @ Rc).astype(np.float32)
+        T.xf_w = np.full(n_xf, weight * weight, np.float32)
+    return T
+
+
+def feed_tethers(bundler, T: "Tethers") -> None:
+    """The BundlerLib call sequence of BundleAdjust.cpp:155-192 for a Tethers record (None = monocular map: three empty allocations)."""
+    T = T if T is not None else Tethers()
+    bundler.AllocateFixedDistanceConstraints(len(T.dist_d))
+    for i in range(len(T.dist_d)):
+        bundler.SetFixedDistanceConstraint(i, int(T.dist_cams[i, 0]), int(T.dist_cams[i, 1]), float(T.dist_d[i]), float(T.dist_w[i]))
+    bundler.AllocateRelativeRotationConstraints(len(T.rot_w))
+    for i in range(len(T.rot_w)):
+        bundler.SetRelativeRotationConstraint(i, int(T.rot_cams[i, 0]), int(T.rot_cams[i, 1]), T.rot_q[i], float(T.rot_w[i]))
+    bundler.AllocateRelativeTransformConstraints(len(T.xf_w))
+    for i in range(len(T.xf_w)):
+        bundler.SetRelativeTransformConstraint(i, int(T.xf_cams[i, 0]), int(T.xf_cams[i, 1]), T.xf_p[i], T.xf_q[i], float(T.xf_w[i]))
 
 
 WIDTH, HEIGHT, FOCAL, CX, CY = 640, 480, 500.0, 320.0, 240.0

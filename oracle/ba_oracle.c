@@ -321,6 +321,20 @@ typedef struct {
     int wblk;                  /* index of its Hpl block (both endpoints free) or -1 */
 } obs_t;
 
+/* Tether edges, BundlerLib.cpp:24-90 (EdgeScaleConstraint, EdgeRotationConstraint) and g2o EdgeSE3Expmap. */
+enum { TETHER_DISTANCE = 0, TETHER_ROTATION = 1, TETHER_TRANSFORM = 2 };
+typedef struct {
+    uint32_t c0, c1;           /* setVertex(0, cameraIndex1), setVertex(1, cameraIndex2) */
+    double dist;               /* EdgeScaleConstraint measurement */
+    quat_t q;                  /* rotation measurement (rotation: as given; transform: normalised by the SE3Quat ctor) */
+    double t[3];               /* transform measurement translation */
+    double w;                  /* m_weight (distance, rotation) or the scalar of the information matrix w*I6 (transform) */
+    int set, active;
+    double err[6];             /* _error of the last computeError */
+    double J0[36], J1[36];     /* _jacobianOplus[0/1], dim x 6 row-major */
+} tether_t;
+static const int tether_dim[3] = { 1, 1, 6 };
+
 typedef struct { int code, trials; double chi_before, chi_after, lambda; } bao_trace_t;
 
 typedef struct ba_oracle {
@@ -328,6 +342,7 @@ typedef struct ba_oracle {
     cam_t* cams; size_t n_cams;
     pt_t* pts; size_t n_pts;
     obs_t* obs; size_t n_obs;
+    tether_t* teth[3]; size_t n_teth[3];   /* FixedDistance / RelativeRotation / RelativeTransform constraints */
     /* StepOptimizer state  BundlerLib.cpp:92-167 */
     int dirty, useless, iteration;
     /* LM state (A.4) */
@@ -372,6 +387,7 @@ BAO_API void bao_destroy(ba_oracle* b)
     if (!b) return;
     free_structure(b);
     free(b->cams); free(b->pts); free(b->obs);
+    for (int k = 0; k < 3; ++k) free(b->teth[k]);
     free(b);
 }
 
@@ -420,6 +436,39 @@ BAO_API void bao_set_observation(ba_oracle* b, size_t idx, const float uv[2], si
     b->dirty = 1;
 }
 
+/* BundlerLib.cpp:231-259 */
+BAO_API void bao_alloc_tethers(ba_oracle* b, int kind, size_t n) { b->teth[kind] = (tether_t*)calloc(n ? n : 1, sizeof(tether_t)); b->n_teth[kind] = n; }
+/* BundlerLib.cpp:311-322 */
+BAO_API void bao_set_distance_tether(ba_oracle* b, size_t idx, size_t cam1, size_t cam2, float distance, float weight)
+{
+    tether_t* t = &b->teth[TETHER_DISTANCE][idx];
+    memset(t, 0, sizeof(*t));
+    t->c0 = (uint32_t)cam1; t->c1 = (uint32_t)cam2; t->dist = (double)distance; t->w = (double)weight; t->set = 1;
+    b->dirty = 1;
+}
+/* BundlerLib.cpp:324-336; q = Eigen::Quaternionf coefficients x,y,z,w, cast to double, NOT normalised */
+BAO_API void bao_set_rotation_tether(ba_oracle* b, size_t idx, size_t cam1, size_t cam2, const float q[4], float weight)
+{
+    tether_t* t = &b->teth[TETHER_ROTATION][idx];
+    memset(t, 0, sizeof(*t));
+    t->c0 = (uint32_t)cam1; t->c1 = (uint32_t)cam2; t->w = (double)weight; t->set = 1;
+    t->q.x = q[0]; t->q.y = q[1]; t->q.z = q[2]; t->q.w = q[3];
+    b->dirty = 1;
+}
+/* BundlerLib.cpp:338-350; measurement = SE3Quat(q, p) (ctor normalises), information = weight * I6 */
+BAO_API void bao_set_transform_tether(ba_oracle* b, size_t idx, size_t cam1, size_t cam2, const float p[3], const float q[4], float weight)
+{
+    tether_t* t = &b->teth[TETHER_TRANSFORM][idx];
+    memset(t, 0, sizeof(*t));
+    t->c0 = (uint32_t)cam1; t->c1 = (uint32_t)cam2; t->w = (double)weight; t->set = 1;
+    se3_t M;
+    M.r.x = q[0]; M.r.y = q[1]; M.r.z = q[2]; M.r.w = q[3];
+    M.t[0] = p[0]; M.t[1] = p[1]; M.t[2] = p[2];
+    se3_normalize(&M);
+    t->q = M.r; t->t[0] = M.t[0]; t->t[1] = M.t[1]; t->t[2] = M.t[2];
+    b->dirty = 1;
+}
+
 /* BundlerLib.cpp:123-130, 354-362 */
 BAO_API void bao_set_lambda(ba_oracle* b, float l) { b->iteration = 0; b->user_lambda_init = (double)l; }
 BAO_API float bao_get_lambda(const ba_oracle* b) { return (float)b->lambda; }
@@ -453,6 +502,16 @@ static void initialize_optimization(ba_oracle* b)
         b->active[b->n_active++] = (int)e;
         cam_deg[o->cam]++; pt_deg[o->pt]++;
     }
+    /* tether edges are active unless both endpoints are fixed (OptimizableGraph::Edge::allVerticesFixed) */
+    for (int k = 0; k < 3; ++k)
+        for (size_t i = 0; i < b->n_teth[k]; ++i) {
+            tether_t* t = &b->teth[k][i];
+            t->active = 0;
+            if (!t->set) continue;
+            if (b->cams[t->c0].fixed && b->cams[t->c1].fixed) continue;
+            t->active = 1;
+            cam_deg[t->c0]++; cam_deg[t->c1]++;
+        }
     /* index map: free poses ascending id, then free landmarks ascending id (= descending point idx,
        ids are INT_MAX-2-idx, BundlerLib.cpp:215) */
     b->hc2cam = (int*)malloc((nc ? nc : 1) * sizeof(int));
@@ -549,9 +608,135 @@ static void huber(double e2, double delta, double rho[3])
     }
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* Tether edges: BundlerLib.cpp:24-90 + g2o EdgeSE3Expmap / SE3Quat::{inverse,log,adj} /      */
+/* BaseMultiEdge::linearizeOplus (central differences, delta = 1e-9)                          */
+/* ------------------------------------------------------------------------------------------ */
+static se3_t se3_inverse(const se3_t* T)            /* SE3Quat::inverse: r' = conj(r), t' = r' * (t * -1) */
+{
+    se3_t r;
+    r.r.x = -T->r.x; r.r.y = -T->r.y; r.r.z = -T->r.z; r.r.w = T->r.w;
+    double nt[3] = { T->t[0] * -1., T->t[1] * -1., T->t[2] * -1. };
+    q_rot(r.r, nt, r.t);
+    return r;
+}
+
+static void se3_log(const se3_t* T, double out[6])  /* SE3Quat::log: [omega | upsilon] */
+{
+    double R[9];
+    q_to_R(T->r, R);
+    double d = 0.5 * (R[0] + R[4] + R[8] - 1);
+    double dR[3] = { R[7] - R[5], R[2] - R[6], R[3] - R[1] };
+    double om[3], Om[9], Om2[9], Vi[9];
+    static const double I3[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    if (fabs(d) > 0.99999) {
+        for (int i = 0; i < 3; ++i) om[i] = 0.5 * dR[i];
+        double O[9] = { 0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0 };
+        memcpy(Om, O, sizeof(O));
+        m3_mul(Om, Om, Om2);
+        for (int i = 0; i < 9; ++i) Vi[i] = I3[i] - 0.5 * Om[i] + (1. / 12.) * Om2[i];
+    } else {
+        double theta = acos(d);
+        double k = theta / (2 * sqrt(1 - d * d));
+        for (int i = 0; i < 3; ++i) om[i] = k * dR[i];
+        double O[9] = { 0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0 };
+        memcpy(Om, O, sizeof(O));
+        m3_mul(Om, Om, Om2);
+        double c = (1 - theta / (2 * tan(theta / 2))) / (theta * theta);
+        for (int i = 0; i < 9; ++i) Vi[i] = I3[i] - 0.5 * Om[i] + c * Om2[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+        out[i] = om[i];
+        out[3 + i] = Vi[i * 3 + 0] * T->t[0] + Vi[i * 3 + 1] * T->t[1] + Vi[i * 3 + 2] * T->t[2];
+    }
+}
+
+static void se3_adj(const se3_t* T, double A[36])   /* SE3Quat::adj: [R 0; skew(t) R  R], row-major 6x6 */
+{
+    double R[9], tx[9] = { 0, -T->t[2], T->t[1], T->t[2], 0, -T->t[0], -T->t[1], T->t[0], 0 }, tR[9];
+    q_to_R(T->r, R);
+    m3_mul(tx, R, tR);
+    memset(A, 0, 36 * sizeof(double));
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) { A[r * 6 + c] = R[r * 3 + c]; A[(3 + r) * 6 + 3 + c] = R[r * 3 + c]; A[(3 + r) * 6 + c] = tR[r * 3 + c]; }
+}
+
+/* computeError of the three tether kinds, poses passed explicitly so the numeric differentiation can perturb them */
+static void tether_error(int kind, const tether_t* t, const se3_t* T0, const se3_t* T1, double err[6])
+{
+    if (kind == TETHER_DISTANCE) {                       /* BundlerLib.cpp:45-51 */
+        double dx = T1->t[0] - T0->t[0], dy = T1->t[1] - T0->t[1], dz = T1->t[2] - T0->t[2];
+        err[0] = (t->dist - sqrt(dx * dx + (dy * dy + dz * dz))) * t->w;
+    } else if (kind == TETHER_ROTATION) {                /* BundlerLib.cpp:76-87: angularDistance((T0^-1 T1).rotation(), meas) * w */
+        se3_t inv0 = se3_inverse(T0);
+        se3_t rel = se3_mul(&inv0, T1);
+        quat_t mc = { -t->q.x, -t->q.y, -t->q.z, t->q.w };
+        quat_t d = q_mul(rel.r, mc);                     /* Eigen 3.3 angularDistance: d = this * other.conjugate() */
+        double vn = sqrt(d.x * d.x + (d.y * d.y + d.z * d.z));
+        err[0] = 2.0 * atan2(vn, fabs(d.w)) * t->w;
+    } else {                                             /* g2o EdgeSE3Expmap::computeError: log(T1^-1 * C * T0) */
+        se3_t C; C.r = t->q; C.t[0] = t->t[0]; C.t[1] = t->t[1]; C.t[2] = t->t[2];
+        se3_t inv1 = se3_inverse(T1);
+        se3_t a = se3_mul(&inv1, &C);
+        se3_t e = se3_mul(&a, T0);
+        se3_log(&e, err);
+    }
+}
+
+static void tether_linearize(ba_oracle* b, int kind, tether_t* t)
+{
+    const cam_t* c0 = &b->cams[t->c0]; const cam_t* c1 = &b->cams[t->c1];
+    const int dim = tether_dim[kind];
+    memset(t->J0, 0, sizeof(t->J0)); memset(t->J1, 0, sizeof(t->J1));
+    if (kind == TETHER_TRANSFORM) {                      /* g2o EdgeSE3Expmap::linearizeOplus (analytic) */
+        se3_t Tij; Tij.r = t->q; Tij.t[0] = t->t[0]; Tij.t[1] = t->t[1]; Tij.t[2] = t->t[2];
+        se3_t invTij = se3_inverse(&Tij);
+        se3_t invTj = se3_inverse(&c1->est), invTi = se3_inverse(&c0->est);
+        se3_t a = se3_mul(&invTj, &Tij), bq = se3_mul(&invTi, &invTij);
+        se3_adj(&a, t->J0);
+        se3_adj(&bq, t->J1);
+        for (int i = 0; i < 36; ++i) t->J1[i] = -t->J1[i];
+        return;
+    }
+    /* BaseMultiEdge::linearizeOplus: central differences through oplus (exp(u) * estimate), fixed vertices skipped */
+    const double delta = 1e-9, scalar = 1 / (2 * delta);
+    for (int side = 0; side < 2; ++side) {
+        const cam_t* cv = side ? c1 : c0;
+        if (cv->fixed) continue;
+        double* J = side ? t->J1 : t->J0;
+        for (int d = 0; d < 6; ++d) {
+            double u[6] = { 0, 0, 0, 0, 0, 0 }, ep[6], em[6];
+            u[d] = delta;
+            se3_t E = se3_exp(u);
+            se3_t Tp = se3_mul(&E, &cv->est);
+            tether_error(kind, t, side ? &c0->est : &Tp, side ? &Tp : &c1->est, ep);
+            u[d] = -delta;
+            E = se3_exp(u);
+            se3_t Tm = se3_mul(&E, &cv->est);
+            tether_error(kind, t, side ? &c0->est : &Tm, side ? &Tm : &c1->est, em);
+            for (int k = 0; k < dim; ++k) J[k * 6 + d] = scalar * (ep[k] - em[k]);
+        }
+    }
+}
+
+/* chi2 of a tether: e^T Omega e, Omega = I (distance, rotation) or w*I6 (transform); no robust kernel */
+static double tether_chi2(int kind, const tether_t* t)
+{
+    if (kind != TETHER_TRANSFORM) return t->err[0] * t->err[0];
+    double s = 0;
+    for (int i = 0; i < 6; ++i) s += t->err[i] * (t->w * t->err[i]);
+    return s;
+}
+
 static void compute_active_errors(ba_oracle* b)
 {
     for (size_t a = 0; a < b->n_active; ++a) compute_error(b, &b->obs[b->active[a]]);
+    for (int k = 0; k < 3; ++k)
+        for (size_t i = 0; i < b->n_teth[k]; ++i) {
+            tether_t* t = &b->teth[k][i];
+            if (t->active) tether_error(k, t, &b->cams[t->c0].est, &b->cams[t->c1].est, t->err);
+        }
 }
 
 static double active_robust_chi2(ba_oracle* b)
@@ -564,6 +749,9 @@ static double active_robust_chi2(ba_oracle* b)
         huber(chi2, o->delta, rho);
         chi += rho[0];
     }
+    for (int k = 0; k < 3; ++k)
+        for (size_t i = 0; i < b->n_teth[k]; ++i)
+            if (b->teth[k][i].active) chi += tether_chi2(k, &b->teth[k][i]);
     return chi;
 }
 
@@ -625,6 +813,54 @@ static void build_system(ba_oracle* b)
             }
         }
     }
+    /* tether edges: BaseMultiEdge / BaseBinaryEdge::constructQuadraticForm without a robust kernel:
+       H_ii += Ji^T Omega Ji, b_i += Ji^T (-Omega e), H_01 += J0^T Omega J1 (kept per tether, added to Hpp in solver_solve) */
+    for (int k = 0; k < 3; ++k)
+        for (size_t i = 0; i < b->n_teth[k]; ++i) {
+            tether_t* t = &b->teth[k][i];
+            if (!t->active) continue;
+            tether_linearize(b, k, t);
+            const int dim = tether_dim[k];
+            const double om = (k == TETHER_TRANSFORM) ? t->w : 1.0;
+            for (int side = 0; side < 2; ++side) {
+                int hc = b->cams[side ? t->c1 : t->c0].hidx;
+                if (hc < 0) continue;
+                const double* J = side ? t->J1 : t->J0;
+                double* bc = &b->bc[hc * 6];
+                double* U = &b->U[hc * 36];
+                for (int r = 0; r < 6; ++r) {
+                    double acc = 0;
+                    for (int d = 0; d < dim; ++d) acc += J[d * 6 + r] * (-(om * t->err[d]));
+                    bc[r] += acc;
+                    for (int c = 0; c < 6; ++c) {
+                        double h = 0;
+                        for (int d = 0; d < dim; ++d) h += J[d * 6 + r] * om * J[d * 6 + c];
+                        U[r * 6 + c] += h;
+                    }
+                }
+            }
+        }
+}
+
+/* Hpp off-diagonal blocks of the tether edges, added to both triangles of the dense column-major matrix */
+static void add_tether_offdiag(ba_oracle* b, int n)
+{
+    for (int k = 0; k < 3; ++k)
+        for (size_t i = 0; i < b->n_teth[k]; ++i) {
+            const tether_t* t = &b->teth[k][i];
+            if (!t->active) continue;
+            int h0 = b->cams[t->c0].hidx, h1 = b->cams[t->c1].hidx;
+            if (h0 < 0 || h1 < 0) continue;
+            const int dim = tether_dim[k];
+            const double om = (k == TETHER_TRANSFORM) ? t->w : 1.0;
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) {
+                    double h = 0;
+                    for (int d = 0; d < dim; ++d) h += t->J0[d * 6 + r] * om * t->J1[d * 6 + c];
+                    b->S[(size_t)(h1 * 6 + c) * n + (h0 * 6 + r)] += h;
+                    b->S[(size_t)(h0 * 6 + r) * n + (h1 * 6 + c)] += h;
+                }
+        }
 }
 
 /* BlockSolver::solve with lambda applied (setLambda + solve + restoreDiagonal folded)  A.5/A.6 */
@@ -640,6 +876,7 @@ static int solver_solve(ba_oracle* b, double lambda)
             for (int i = 0; i < 6; ++i)
                 for (int j = 0; j < 6; ++j)
                     b->S[(size_t)(c * 6 + j) * n + (c * 6 + i)] = b->U[c * 36 + i * 6 + j] + (i == j ? lambda : 0.0);
+        add_tether_offdiag(b, n);
         if (!ldlt_factor(b->S, n, b->transp, b->temp)) return 0;
         ldlt_solve(b->S, n, b->transp, b->bc, x);
         return 1;
@@ -650,6 +887,7 @@ static int solver_solve(ba_oracle* b, double lambda)
         for (int i = 0; i < 6; ++i)
             for (int j = 0; j < 6; ++j)
                 b->S[(size_t)(c * 6 + j) * n + (c * 6 + i)] = b->U[c * 36 + i * 6 + j] + (i == j ? lambda : 0.0);
+    add_tether_offdiag(b, n);           /* _Hschur starts as Hpp, tether pose-pose blocks included */
     memset(b->coeff, 0, (size_t)n * sizeof(double));
     for (int l = 0; l < nfp; ++l) {
         double D[9], db[3];

@@ -79,8 +79,95 @@ def _quatf_from_R(Rf):
     return R
 
 
+def _rot_from_quat(q):
+    """x, y, z, w (any norm) -> rotation matrix."""
+    q = np.asarray(q, np.float64)
+    q = q / np.linalg.norm(q)
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _rot_angle(M):
+    """Rotation angle in [0, pi], atan2 form (well conditioned near 0, unlike acos of the trace)."""
+    v = np.array([M[2, 1] - M[1, 2], M[0, 2] - M[2, 0], M[1, 0] - M[0, 1]])
+    return np.arctan2(0.5 * np.linalg.norm(v), 0.5 * (np.trace(M) - 1.0))
+
+
+def _se3_log(R, t):
+    """[omega | upsilon] of the rigid transform (R, t): axis-angle, then V^-1 t."""
+    v = 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])   # sin(theta) * axis
+    c = 0.5 * (np.trace(R) - 1.0)
+    if abs(c) > 0.99999:
+        w = v
+        K = _skew(w)
+        Vi = np.eye(3) - 0.5 * K + K @ K / 12.0
+    else:
+        th = np.arccos(c)
+        w = v * th / np.sqrt(1 - c * c)
+        K = _skew(w)
+        Vi = np.eye(3) - 0.5 * K + (1 - th / (2 * np.tan(th / 2))) / th ** 2 * (K @ K)
+    return np.concatenate([w, Vi @ t])
+
+
+def _adj(R, t):
+    A = np.zeros((6, 6))
+    A[:3, :3] = R; A[3:, 3:] = R; A[3:, :3] = _skew(t) @ R
+    return A
+
+
+class _Tether:
+    """One pose-pose constraint; residual as a function of the two poses, 4x4-matrix algebra throughout."""
+    def __init__(self, kind, a, b, w, dist=0.0, q=None, p=None):
+        self.kind, self.a, self.b, self.w, self.dist = kind, int(a), int(b), float(w), float(dist)
+        if kind == "rot":
+            self.Rm = _rot_from_quat(q)
+        if kind == "xf":
+            self.C = np.eye(4); self.C[:3, :3] = _rot_from_quat(q); self.C[:3, 3] = np.asarray(p, np.float64)
+        self.dim = 6 if kind == "xf" else 1
+        self.omega = self.w if kind == "xf" else 1.0       # information: w * I6 for the transform edge, 1 otherwise
+
+    def residual(self, Ra, ta, Rb, tb):
+        if self.kind == "dist":
+            return np.array([(self.dist - np.linalg.norm(tb - ta)) * self.w])
+        if self.kind == "rot":
+            return np.array([_rot_angle(Ra.T @ Rb @ self.Rm.T) * self.w])
+        Ta = np.eye(4); Ta[:3, :3] = Ra; Ta[:3, 3] = ta
+        Tb = np.eye(4); Tb[:3, :3] = Rb; Tb[:3, 3] = tb
+        E = np.linalg.inv(Tb) @ self.C @ Ta
+        return _se3_log(E[:3, :3], E[:3, 3])
+
+    def jacobians(self, Ra, ta, Rb, tb, fixed_a, fixed_b):
+        Ja, Jb = np.zeros((self.dim, 6)), np.zeros((self.dim, 6))
+        if self.kind == "xf":       # g2o's closed form: Adj(Tb^-1 C), -Adj(Ta^-1 C^-1)
+            Ta = np.eye(4); Ta[:3, :3] = Ra; Ta[:3, 3] = ta
+            Tb = np.eye(4); Tb[:3, :3] = Rb; Tb[:3, 3] = tb
+            A = np.linalg.inv(Tb) @ self.C
+            B = np.linalg.inv(Ta) @ np.linalg.inv(self.C)
+            return _adj(A[:3, :3], A[:3, 3]), -_adj(B[:3, :3], B[:3, 3])
+        h = 1e-9                    # g2o BaseMultiEdge: central differences through the manifold update, fixed vertices skipped
+        for k in range(6):
+            u = np.zeros(6); u[k] = h
+            dRp, dtp = _se3_exp(u); dRm, dtm = _se3_exp(-u)
+            if not fixed_a:
+                Ja[:, k] = (self.residual(dRp @ Ra, dRp @ ta + dtp, Rb, tb) - self.residual(dRm @ Ra, dRm @ ta + dtm, Rb, tb)) / (2 * h)
+            if not fixed_b:
+                Jb[:, k] = (self.residual(Ra, ta, dRp @ Rb, dRp @ tb + dtp) - self.residual(Ra, ta, dRm @ Rb, dRm @ tb + dtm)) / (2 * h)
+        return Ja, Jb
+
+
 class NumpyBundler:
     def __init__(self, scene, points_fixed=False):
+        self.tethers = []
+        T = getattr(scene, "tethers", None)
+        if T is not None:
+            for i in range(len(T.dist_d)):
+                self.tethers.append(_Tether("dist", T.dist_cams[i, 0], T.dist_cams[i, 1], np.float32(T.dist_w[i]), dist=np.float32(T.dist_d[i])))
+            for i in range(len(T.rot_w)):
+                self.tethers.append(_Tether("rot", T.rot_cams[i, 0], T.rot_cams[i, 1], np.float32(T.rot_w[i]), q=T.rot_q[i].astype(np.float32)))
+            for i in range(len(T.xf_w)):
+                self.tethers.append(_Tether("xf", T.xf_cams[i, 0], T.xf_cams[i, 1], np.float32(T.xf_w[i]), q=T.xf_q[i].astype(np.float32), p=T.xf_p[i].astype(np.float32)))
         self.R = _quatf_from_R(scene.cam_R)                       # (nc,3,3) world->camera
         self.t = scene.cam_t.astype(np.float64)
         self.f = scene.cam_K[:, 2].astype(np.float64)
@@ -113,6 +200,9 @@ class NumpyBundler:
         self.act = np.nonzero(act)[0]
         nc, npnt = self.R.shape[0], self.X.shape[0]
         cam_deg = np.bincount(self.cam[self.act], minlength=nc)
+        self.act_teth = [T for T in self.tethers if not (self.cam_fixed[T.a] and self.cam_fixed[T.b])]
+        for T in self.act_teth:
+            cam_deg[T.a] += 1; cam_deg[T.b] += 1
         pt_deg = np.bincount(self.pt[self.act], minlength=npnt)
         free_c = (~self.cam_fixed) & (cam_deg > 0)
         free_p = (pt_deg > 0) & (not self.points_fixed)
@@ -138,11 +228,15 @@ class NumpyBundler:
         rho1 = np.where(chi2 <= d2, 1.0, delta / s)
         return rho0.sum(), rho1
 
+    def _teth_chi(self, R, t):
+        return sum(T.omega * float(np.sum(T.residual(R[T.a], t[T.a], R[T.b], t[T.b]) ** 2)) for T in self.act_teth)
+
     def _lm(self, delta):
         e = self.act
         r, Xc = self._residuals(self.R, self.t, self.X)
         self.err[e] = r
         cur, rho1 = self._chi(r, delta)
+        cur += self._teth_chi(self.R, self.t)
         chi_before = cur
         f = self.f[self.cam[e]]
         x, y, z = Xc[:, 0], Xc[:, 1], Xc[:, 2]
@@ -170,6 +264,20 @@ class NumpyBundler:
         J = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(2 * e.size, n))
         H = (J.T @ J).tocsc()
         g = -(J.T @ (sw[:, None] * r).reshape(-1))     # b = -J^T W r
+        if self.act_teth:                               # dense rows of the pose-pose constraints
+            H = H.tolil()
+            for T in self.act_teth:
+                res = T.residual(self.R[T.a], self.t[T.a], self.R[T.b], self.t[T.b])
+                Ja, Jb = T.jacobians(self.R[T.a], self.t[T.a], self.R[T.b], self.t[T.b], self.cam_fixed[T.a], self.cam_fixed[T.b])
+                ha, hb = self.hc[T.a], self.hc[T.b]
+                for (hi, Ji) in ((ha, Ja), (hb, Jb)):
+                    if hi >= 0:
+                        H[6 * hi:6 * hi + 6, 6 * hi:6 * hi + 6] += T.omega * (Ji.T @ Ji)
+                        g[6 * hi:6 * hi + 6] -= T.omega * (Ji.T @ res)
+                if ha >= 0 and hb >= 0:
+                    H[6 * ha:6 * ha + 6, 6 * hb:6 * hb + 6] += T.omega * (Ja.T @ Jb)
+                    H[6 * hb:6 * hb + 6, 6 * ha:6 * ha + 6] += T.omega * (Jb.T @ Ja)
+            H = H.tocsc()
         if self.iteration == 0:
             self.lam = self.user_lambda if self.user_lambda > 0 else 1e-5 * np.abs(H.diagonal()).max()
             self.ni = 2.0
@@ -193,6 +301,7 @@ class NumpyBundler:
             rn, _ = self._residuals(Rn, tn, Xn)
             self.err[e] = rn
             tmp, _ = self._chi(rn, delta)
+            tmp += self._teth_chi(Rn, tn)
             if not ok:
                 tmp = np.finfo(np.float64).max
             scale = float(np.sum(dx * (self.lam * dx + g))) + 1e-3

@@ -75,6 +75,10 @@ def _declare(L: C.CDLL) -> None:
     L.bao_fix_camera.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
     L.bao_set_point.argtypes = [C.c_void_p, C.c_size_t, _f32p]
     L.bao_set_observation.argtypes = [C.c_void_p, C.c_size_t, _f32p, C.c_size_t, C.c_size_t, C.c_float]
+    L.bao_alloc_tethers.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    L.bao_set_distance_tether.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_float]
+    L.bao_set_rotation_tether.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, _f32p, C.c_float]
+    L.bao_set_transform_tether.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, _f32p, _f32p, C.c_float]
     L.bao_set_lambda.argtypes = [C.c_void_p, C.c_float]
     L.bao_get_lambda.restype = C.c_float
     L.bao_get_lambda.argtypes = [C.c_void_p]
@@ -147,6 +151,21 @@ class OracleBundler:
     def SetObservation(self, idx, uv, cam, pt, info):
         self._L.bao_set_observation(self._h, idx, np.ascontiguousarray(uv, np.float32), int(cam), int(pt), float(info))
 
+    # tether edges (BundlerLib.h:40-47); quaternions are Eigen coefficient order x, y, z, w
+    def AllocateFixedDistanceConstraints(self, n): self._L.bao_alloc_tethers(self._h, 0, n)
+    def AllocateRelativeRotationConstraints(self, n): self._L.bao_alloc_tethers(self._h, 1, n)
+    def AllocateRelativeTransformConstraints(self, n): self._L.bao_alloc_tethers(self._h, 2, n)
+
+    def SetFixedDistanceConstraint(self, idx, cam1, cam2, distance=1.0, weight=1.0):
+        self._L.bao_set_distance_tether(self._h, idx, cam1, cam2, float(distance), float(weight))
+
+    def SetRelativeRotationConstraint(self, idx, cam1, cam2, q_xyzw, weight=1.0):
+        self._L.bao_set_rotation_tether(self._h, idx, cam1, cam2, np.ascontiguousarray(q_xyzw, np.float32), float(weight))
+
+    def SetRelativeTransformConstraint(self, idx, cam1, cam2, position, q_xyzw, weight):
+        self._L.bao_set_transform_tether(self._h, idx, cam1, cam2, np.ascontiguousarray(position, np.float32),
+                                         np.ascontiguousarray(q_xyzw, np.float32), float(weight))
+
     def SetCurrentLambda(self, l): self._L.bao_set_lambda(self._h, float(l))
     def GetCurrentLambda(self): return float(self._L.bao_get_lambda(self._h))
 
@@ -198,6 +217,13 @@ class OracleBundler:
         return e
 
 
+def _feed_tethers(bundler, scene) -> None:
+    T = getattr(scene, "tethers", None)
+    if T is not None:
+        from mageslam_amd.scene import feed_tethers
+        feed_tethers(bundler, T)
+
+
 def load_scene(bundler, scene) -> None:
     """Feed a mageslam_amd.scene.Scene through the BundlerLib call protocol
     (order of BundleAdjust.cpp:25-193: cameras, map points, observations)."""
@@ -211,6 +237,7 @@ def load_scene(bundler, scene) -> None:
     bundler.AllocateObservations(scene.n_obs)
     for i in range(scene.n_obs):
         bundler.SetObservation(i, scene.obs_uv[i], scene.obs_cam[i], scene.obs_pt[i], scene.obs_info[i])
+    _feed_tethers(bundler, scene)
 
 
 def load_scene_bulk(bundler: OracleBundler, scene) -> None:
@@ -226,6 +253,7 @@ def load_scene_bulk(bundler: OracleBundler, scene) -> None:
     L.bao_set_observations_bulk(bundler._h, scene.n_obs, np.ascontiguousarray(scene.obs_uv, np.float32).reshape(-1),
                                 np.ascontiguousarray(scene.obs_cam, np.uint32), np.ascontiguousarray(scene.obs_pt, np.uint32),
                                 np.ascontiguousarray(scene.obs_info, np.float32))
+    _feed_tethers(bundler, scene)
 
 
 def orb_detect(img: np.ndarray, params: OrbParams = None, cap: int = None, want_blur: bool = False):

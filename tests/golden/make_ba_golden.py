@@ -25,12 +25,33 @@ CASES = {
     "ba_tiny_pose_only": (dict(scene.CONFIGS["tiny"], fixed=()), True, [[4.0, 4.0, 4.0], [0.9, 0.9, 0.9, 0.9]], [20.25, 20.25]),
     "ba_small_fixedcams": (dict(n_cams=12, n_pts=400, n_obs=3200, seed=0x5EED0A01, fixed=(0, 1, 9, 10, 11)), False,
                            [[0.9]] * 6, [1e30] * 6),
+    # tether edges (BundlerLib.cpp:24-90, 311-350): three of each kind on the tiny scene, strong enough to matter
+    "ba_tiny_tethers": (dict(scene.CONFIGS["tiny"], tethers=dict(n_dist=3, n_rot=3, n_xf=3, weight=300.0, noise=1e-2)), False,
+                        [[1.8]] * 6, [1e30] * 6),
+    # camera 5 has no observation at all and camera 6 is fixed: both stay tied to the rail through tethers only
+    "ba_tethered_blind_camera": (dict(n_cams=12, n_pts=300, n_obs=2400, seed=0x5EED0A02, fixed=(0, 1, 6), blind=(5,),
+                                      tethers=dict(n_dist=11, n_rot=11, n_xf=0, weight=100.0, noise=1e-3, stride=1, step=1)), False,
+                                 [[0.9]] * 6, [9.0] * 6),
 }
+
+
+def build_scene(kw):
+    kw = dict(kw)
+    teth = kw.pop("tethers", None)
+    blind = kw.pop("blind", ())
+    s = scene.make_scene(**kw)
+    if blind:
+        keep = ~np.isin(s.obs_cam, np.array(blind, np.uint32))
+        s.obs_uv, s.obs_cam, s.obs_pt, s.obs_info = s.obs_uv[keep], s.obs_cam[keep], s.obs_pt[keep], s.obs_info[keep]
+        s.n_obs = int(keep.sum())
+    if teth:
+        s.tethers = scene.make_tethers(s, **teth)
+    return s
 
 
 def main():
     for name, (kw, pf, hubers, thrs) in CASES.items():
-        s = scene.make_scene(**kw)
+        s = build_scene(kw)
         nb = NumpyBundler(s, points_fixed=pf)
         mse, trace, outl, n_out = [], [], [], []
         for hw, thr in zip(hubers, thrs):
@@ -48,7 +69,8 @@ def main():
             obs_uv=s.obs_uv, obs_cam=s.obs_cam, obs_pt=s.obs_pt, obs_info=s.obs_info,
             exp_mse=np.array(mse, np.float32), exp_trace=np.array(trace, np.float64),
             exp_outliers=np.array(outl, np.uint32), exp_n_out=np.array(n_out),
-            exp_R=nb.R, exp_t=nb.t, exp_X=nb.X)
+            exp_R=nb.R, exp_t=nb.t, exp_X=nb.X,
+            **({} if s.tethers is None else {"teth_" + k: v for k, v in vars(s.tethers).items()}))
         print(name, "mse", mse[-1], "outliers", len(outl), "trace rows", len(trace))
 
 

@@ -9,7 +9,7 @@ from mageslam_amd import scene
 from mageslam_amd.bundler import BundlerLib, load_scene
 from oracle.oracle import OracleBundler, load_scene_bulk
 
-from ba_cases import BA_CASES, run_case
+from ba_cases import BA_CASES, BA_TETHER_CASES, load_case, run_case
 
 pytestmark = pytest.mark.gpu
 
@@ -23,6 +23,35 @@ def _bulk(b, s):
 def test_hip_matches_golden(name, bulk):
     pf = name == "ba_tiny_pose_only"
     run_case(BundlerLib(pf), _bulk if bulk else load_scene, name)
+
+
+@pytest.mark.parametrize("name", BA_TETHER_CASES)
+def test_hip_matches_golden_with_tethers(name):
+    """Fixtures from the independent numpy implementation; tolerance as explained in ba_cases.py."""
+    run_case(BundlerLib(False), load_scene, name, rtol_state=1e-6, rtol_chi=1e-7)
+
+
+@pytest.mark.parametrize("name", BA_TETHER_CASES)
+def test_hip_tethers_match_oracle_tightly(name):
+    """HIP and the C oracle spell the tether arithmetic in the same order with contraction off, so the numerically
+    differentiated Jacobians agree far better than two unrelated implementations do."""
+    s, z = load_case(name)
+    calls = [(np.asarray(hw, np.float32), float(thr)) for hw, thr in zip(z["hubers"], z["thrs"])]
+    _compare_with_oracle(s, False, calls, rtol=1e-8)
+
+
+def test_pose_graph_without_observations():
+    """Tethers only: no landmark, no observation edge.  The reduced camera system IS the tether Hessian."""
+    s = scene.make_scene(n_cams=6, n_pts=12, n_obs=24, seed=11, fixed=(0,))
+    s.obs_uv, s.obs_cam, s.obs_pt, s.obs_info, s.n_obs = s.obs_uv[:0], s.obs_cam[:0], s.obs_pt[:0], s.obs_info[:0], 0
+    s.tethers = scene.make_tethers(s, n_dist=0, n_rot=0, n_xf=5, step=1, weight=10.0, noise=1e-3)
+    g, o = _compare_with_oracle(s, False, [([1.0], 1e30)] * 2, rtol=1e-8)      # chi2 3.35 -> 2.4e-3 -> 3.2e-10
+    out = []
+    for _ in range(2):                                                          # beyond that chi2 is rounding noise
+        assert np.isnan(g.StepBundleAdjustment([1.0], 1e30, out)) and out == []    # no observation edge: mean error is 0/0
+    assert g.trace()[-1]["chi_after"] < 1e-15
+    # the chain of relative transforms was measured on the ground truth (plus 1e-3 noise): the cameras return to it
+    np.testing.assert_allclose(g.poses_f64()[:, 4:], s.gt_cam_t, atol=1e-2)
 
 
 def _compare_with_oracle(s, points_fixed, calls, rtol=1e-9):
@@ -136,9 +165,16 @@ def test_argument_errors_are_status_codes():
         g.AllocateCameras(2)                        # "can only allocate once", BundlerLib.cpp:200
     with pytest.raises(MageError):
         g.SetCameraPose(5, np.zeros(3), np.eye(3).reshape(9), np.ones(4), False)
+    g.AllocateFixedDistanceConstraints(0)           # monocular maps allocate zero tethers of each kind
     with pytest.raises(MageError):
-        g.AllocateFixedDistanceConstraints(3)       # tether edges: MAGE_ERR_UNSUPPORTED (next row)
-    g.AllocateFixedDistanceConstraints(0)
+        g.AllocateFixedDistanceConstraints(1)       # once only, like the other Allocate* calls
+    g.AllocateRelativeRotationConstraints(2)
+    with pytest.raises(MageError):
+        g.SetRelativeRotationConstraint(2, 0, 1, [0, 0, 0, 1])      # index out of range
+    with pytest.raises(MageError):
+        g.SetRelativeRotationConstraint(0, 0, 7, [0, 0, 0, 1])      # camera out of range
+    with pytest.raises(MageError):
+        g.SetRelativeRotationConstraint(0, 1, 1, [0, 0, 0, 1])      # a tether joins two different cameras
 
 
 def test_global_size_properties_and_one_iteration_vs_oracle():

@@ -8,13 +8,67 @@ from mageslam_amd import scene
 from oracle.indep.ba_numpy import NumpyBundler
 from oracle.oracle import OracleBundler, lib, load_scene
 
-from ba_cases import BA_CASES, run_case
+from ba_cases import BA_CASES, BA_TETHER_CASES, run_case
 
 
 @pytest.mark.parametrize("name", BA_CASES)
 def test_oracle_matches_golden(name):
     pf = name == "ba_tiny_pose_only"
     run_case(OracleBundler(pf), load_scene, name)
+
+
+@pytest.mark.parametrize("name", BA_TETHER_CASES)
+def test_oracle_matches_golden_with_tethers(name):
+    """Fixtures made by the independent numpy implementation (its own central differences, 4x4-matrix algebra)."""
+    run_case(OracleBundler(False), load_scene, name, rtol_state=1e-6, rtol_chi=1e-7)
+
+
+def test_tether_edges_pull_the_poses_they_join():
+    """Known-answer behaviour of the three tether kinds on a two-camera pose graph (no observations at all): one
+    Levenberg-Marquardt step with a tiny lambda lands on the constraint, because each error is (near) linear in the update."""
+    s = scene.make_scene(n_cams=2, n_pts=10, n_obs=20, seed=3, fixed=(0,), cam_sigma=0.0, rot_sigma=0.0)
+    s.obs_uv, s.obs_cam, s.obs_pt, s.obs_info, s.n_obs = s.obs_uv[:0], s.obs_cam[:0], s.obs_pt[:0], s.obs_info[:0], 0
+    base = np.linalg.norm(s.cam_t[1].astype(np.float64) - s.cam_t[0].astype(np.float64))
+    # distance: camera 1 slides along the baseline until |t1 - t0| equals the measurement
+    s.tethers = scene.Tethers(dist_cams=np.array([[0, 1]], np.uint32), dist_d=np.array([2 * base], np.float32), dist_w=np.array([10.0], np.float32))
+    o = OracleBundler(); load_scene(o, s); o.SetCurrentLambda(1e-9)
+    out = []
+    for _ in range(3):
+        assert np.isnan(o.StepBundleAdjustment([1.0], 1e30, out))      # no observation edge: the mean error is 0/0
+    P = o.poses_f64()
+    assert abs(np.linalg.norm(P[1, 4:] - P[0, 4:]) - np.float32(2 * base)) < 1e-6
+    assert o.trace()[-1]["chi_after"] < 1e-10
+    # rotation: the relative rotation takes the measured angle; transform: T_1 = C * T_0 exactly
+    ang = 0.2
+    q = np.array([0, np.sin(ang / 2), 0, np.cos(ang / 2)], np.float32)
+    s.tethers = scene.Tethers(rot_cams=np.array([[0, 1]], np.uint32), rot_q=q[None], rot_w=np.array([5.0], np.float32))
+    o = OracleBundler(); load_scene(o, s); o.SetCurrentLambda(1e-9)
+    for _ in range(6):
+        o.StepBundleAdjustment([1.0], 1e30, out)
+    from ba_cases import quat_to_R
+    R = quat_to_R(o.poses_f64()[:, :4])
+    Rrel = R[0].T @ R[1]
+    assert abs(np.arccos(np.clip((np.trace(Rrel @ quat_to_R(q[None].astype(np.float64))[0].T) - 1) / 2, -1, 1))) < 1e-5
+    p = np.array([0.3, -0.1, 0.2], np.float32)
+    s.tethers = scene.Tethers(xf_cams=np.array([[0, 1]], np.uint32), xf_p=p[None], xf_q=q[None], xf_w=np.array([4.0], np.float32))
+    o = OracleBundler(); load_scene(o, s); o.SetCurrentLambda(1e-9)
+    for _ in range(8):
+        o.StepBundleAdjustment([1.0], 1e30, out)
+    P = o.poses_f64(); R = quat_to_R(P[:, :4])
+    Rc = quat_to_R((q / np.linalg.norm(q))[None].astype(np.float64))[0]
+    np.testing.assert_allclose(R[1], Rc @ R[0], atol=1e-6)               # log(T1^-1 C T0) = 0  <=>  T1 = C T0
+    np.testing.assert_allclose(P[1, 4:], Rc @ P[0, 4:] + p.astype(np.float64), atol=1e-6)
+
+
+def test_tethers_between_fixed_cameras_are_inactive():
+    s = scene.make_config("tiny")
+    ref = OracleBundler(); load_scene(ref, s)
+    s.tethers = scene.Tethers(dist_cams=np.array([[0, 1]], np.uint32), dist_d=np.array([5.0], np.float32), dist_w=np.array([1e3], np.float32))
+    o = OracleBundler(); load_scene(o, s)                                # cameras 0 and 1 are the fixed gauge of the tiny scene
+    a, b = [], []
+    assert ref.StepBundleAdjustment([1.8], 1e30, a) == o.StepBundleAdjustment([1.8], 1e30, b)
+    assert ref.trace()[0]["chi_before"] == o.trace()[0]["chi_before"]
+    np.testing.assert_array_equal(ref.poses_f64(), o.poses_f64())
 
 
 def test_oracle_matches_independent_numpy_live():
