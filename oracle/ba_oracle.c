@@ -15,6 +15,8 @@
  *       LinearSolverDense::solve, SparseOptimizer::{initializeOptimization,push,pop,update},
  *       SE3Quat, VertexSE3Expmap, VertexSBAPointXYZ, EdgeProjectXYZ2UV, RobustKernelHuber,
  *       BaseBinaryEdge::constructQuadraticForm          
+ *       tether edges: EdgeSE3Expmap::{computeError,linearizeOplus}, SE3Quat::{inverse,log,adj},
+ *       BaseMultiEdge::{linearizeOplus (central differences, 1e-9), constructQuadraticForm}
  *   Eigen 3.3.x (unpinned): LDLT<MatrixXd> (pivoted, unblocked, left-looking),
  *       Quaternion<->Matrix3 conversions, Matrix3::inverse (cofactor form).
  *

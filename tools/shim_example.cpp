@@ -26,6 +26,13 @@ int main()
                 const std::array<float, 2> uv{ 500 * x / z + 320 + 0.3f * (float)c, 500 * P[p][1] / z + 240 };
                 bundler.SetObservation(o++, uv, c, p, 0.9f);
             }
+        // tethers as a stereo rig hands them over (BundleAdjust.cpp:155-192): a fixed baseline and a relative rotation
+        struct Quat { std::array<float, 4> c; const std::array<float, 4>& coeffs() const { return c; } };   // stands in for Eigen::Quaternionf
+        bundler.AllocateFixedDistanceConstraints(1);
+        bundler.SetFixedDistanceConstraint(0, 1, 2, 0.2f, 10.0f);
+        bundler.AllocateRelativeRotationConstraints(1);
+        bundler.SetRelativeRotationConstraint(0, 1, 2, Quat{ { 0, 0, 0, 1 } }, 10.0f);
+        bundler.AllocateRelativeTransformConstraints(0);
         std::vector<unsigned int> outliers;
         bundler.ReserveOutliers(12);
         const std::vector<float> huber(3, 1.8f);
