@@ -76,44 +76,149 @@ __device__ __forceinline__ void load_tile(double* __restrict__ dst, const double
     }
 }
 
-// 16x16 diagonal block at A(p0, p0): Cholesky in registers by one wavefront (lane l owns row l,
-// broadcasts through v_readlane), then the inverse of the factor (lane l owns column l).
-// Writes L over the block (zeros above the diagonal are not needed), the inverse row-major to Li and Linv_out.
+// ---------------------------------------------------------------------------------------------
+// 16x16 diagonal block at A(p0, p0): Cholesky in registers by one wavefront, together with the inverse of the factor.
+// Lane l (mod 16; the four 16-lane rows of the wavefront run identical copies) owns ROW l of the block (a[c] = A[l][c])
+// and COLUMN l of L^-1 (x[c] = Linv[c][l]).  Both recurrences are
+//     a[c] -= a[j] * L[c][j],   x[c] -= x[j] * L[c][j]      (c > j),        a[j], x[j] *= 1 / L[j][j]
+// and the coefficient L[c][j] is lane c's a[j]: it enters the FMA as a DPP operand (row_newbcast:c -- the only DPP
+// control gfx90a+ allows on 64-bit operations, and exactly the one needed), so an update is ONE v_fmac_f64_dpp with no
+// trip through the SGPR file (the v_readlane form stalled on the VALU->SGPR->VALU round trip: 490 cycles per pivot).
+//
+// The pivot recurrence is the critical path of the whole factorisation (128 sequential pivots per tile; a dependent f64
+// operation costs ~25 cycles on a lone wavefront), so it is cut to the bone -- 8 dependent operations per pivot:
+//     d_p = e0_p - q4_p * h_{p-1}^2          e0_p = A[p][p] after the updates of columns <= p-2            (off the chain)
+//                                            q4_p = (2 A[p][p-1])^2, same state, i.e. L[p][p-1] = sqrt(q4_p) h_{p-1}
+//     h_p = 1 / (2 sqrt(d_p))                v_rsq_f64 + two Goldschmidt steps
+// Column scaling (a[j] = 2 a[j] * h_j; the diagonal entry becomes d * rsqrt(d), no select), the DPP updates and the
+// broadcasts that prepare e0 / q4 of the pivot after next are independent work, issued BETWEEN the chain's operations
+// (a lone in-order wavefront hides latency no other way).  sched_barriers pin that interleaving.
+// Inline asm is invisible to the hazard recogniser: "VALU writes VGPR -> DPP reads it" needs 2 wait states, supplied by
+// explicit s_nop where a DPP source was written just before.
+// A non-positive pivot is reported (ballot) and leaves NaNs behind; the caller discards the factorisation.
+// Writes L over the block, the inverse row-major to Li and Linv_out.
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void dpp_fnma(double& acc, double bsrc, double mul)        // acc -= bsrc[lane C of the row] * mul
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(mul), "n"(C));
+}
+template <int C>
+__device__ __forceinline__ void dpp_fnma_nop(double& acc, double bsrc, double mul)    // same, bsrc written just before
+{
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(mul), "n"(C));
+}
+template <int C>
+__device__ __forceinline__ double dpp_bcast(double v)                                  // v[lane C of the row]
+{
+    double r;
+    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(C));
+    return r;
+}
+template <int C>
+__device__ __forceinline__ double dpp_bcast_nop(double v)                              // same, v written just before
+{
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(C));
+    return r;
+}
+
+template <int J, int C>
+__device__ __forceinline__ void fb_update(double (&a)[NB], double (&x)[NB])
+{
+    if constexpr (C < NB) {
+        dpp_fnma<C>(a[C], a[J], a[J]);
+        dpp_fnma<C>(x[C], a[J], x[J]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int J, int C>
+__device__ __forceinline__ void fb_update_rest(double (&a)[NB], double (&x)[NB])
+{
+    if constexpr (C < NB) {
+        fb_update<J, C>(a, x);
+        fb_update_rest<J, C + 1>(a, x);
+    }
+}
+
+// Column J.  In: h = h_J, (q4, e0) of pivot J + 1, a2 / x2 = twice the final unscaled column J.  Out: the same for J + 1.
+template <int J>
+__device__ __forceinline__ void fb_column(double (&a)[NB], double (&x)[NB], double& h, double& q4, double& e0, double& a2, double& x2, double& dmin)
+{
+    double a2n = 0, x2n = 0, q4n = 0, e0n = 0, hn = h;
+    // chain step 1                                   | side: scale column J
+    const double hh = h * h;
+    a[J] = a2 * h;                                     // L[:, J]  (lane J: d * rsqrt(d) = sqrt(d))
+    x[J] = x2 * h;                                     // Linv[J][:] (exactly 0 for lanes l > J: x2 is)
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (J + 1 < NB) {
+        // chain step 2: next pivot                    | side: the two updates the pivot after next depends on
+        double dn = __builtin_fma(-q4, hh, e0);
+        dpp_fnma_nop<J + 1>(a[J + 1], a[J], a[J]);
+        dpp_fnma<J + 1>(x[J + 1], a[J], x[J]);
+        __builtin_amdgcn_sched_barrier(0);
+        double y = __builtin_amdgcn_rsq(dn);
+        if constexpr (J + 2 < NB) {
+            dpp_fnma<J + 2>(a[J + 2], a[J], a[J]);
+            dpp_fnma<J + 2>(x[J + 2], a[J], x[J]);
+        }
+        dmin = fmin(dmin, dn);                         // a non-positive pivot is caught at the end (NaNs only follow one)
+        __builtin_amdgcn_sched_barrier(0);
+        double g = dn * y; hn = 0.5 * y;
+        a2n = a[J + 1] + a[J + 1];                     // column J + 1 is final (unscaled) now
+        x2n = x[J + 1] + x[J + 1];
+        __builtin_amdgcn_sched_barrier(0);
+        double r = __builtin_fma(-hn, g, 0.5);
+        double t2 = 0;
+        if constexpr (J + 2 < NB) {
+            t2 = dpp_bcast_nop<J + 2>(a2n);            // 2 A[J+2][J+1]
+            e0n = dpp_bcast<J + 2>(a[J + 2]);          // A[J+2][J+2] after the updates of columns <= J
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        g = __builtin_fma(g, r, g); hn = __builtin_fma(hn, r, hn);
+        q4n = t2 * t2;
+        fb_update<J, J + 3>(a, x);
+        r = __builtin_fma(-hn, g, 0.5);
+        __builtin_amdgcn_sched_barrier(0);
+        fb_update<J, J + 4>(a, x);
+        g = __builtin_fma(g, r, g); hn = __builtin_fma(hn, r, hn);
+        __builtin_amdgcn_sched_barrier(0);
+        fb_update_rest<J, J + 5>(a, x);
+    }
+    h = hn; q4 = q4n; e0 = e0n; a2 = a2n; x2 = x2n;
+}
+
 __device__ __noinline__ bool factor_block16(double* __restrict__ A, int p0, int lane, double* __restrict__ Li, double* __restrict__ Linv_out)
 {
     const int l = lane & 15;
-    bool failed = false;
-    // Column step j finalises column j of L (lane r holds L[r][j] in a[j]).  The broadcast L[c][j] that
-    // drives the update of column c is also the coefficient of the forward substitution for the inverse
-    // (lane l owns column l of L^-1), so both recurrences share every v_readlane.
     double a[NB], x[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) { a[c] = A[(p0 + c) * LDC + p0 + l]; x[c] = (l == c) ? 1.0 : 0.0; }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        double d = readlane_d(a[j], j);
-        if (!(d > 0.0)) { failed = true; d = 1.0; }
-        double sq, rs;
-        sqrt_rsqrt(d, sq, rs);
-        a[j] = (l == j) ? sq : a[j] * rs;
-        x[j] = (j >= l) ? x[j] * rs : 0.0;                 // x_j = (delta_jl - sum_{c<j} L[j][c] x_c) / L[j][j]
-#pragma unroll
-        for (int c = j + 1; c < NB; ++c) {
-            const double lcj = readlane_d(a[j], c);         // L[c][j], wave-uniform (SGPR pair)
-            // both recurrences consume the broadcast straight from the SGPR pair (one asm block so the compiler
-            // cannot split the two uses and park the value in a VGPR lane in between)
-            asm volatile("v_fma_f64 %0, -%2, %4, %0\n\tv_fma_f64 %1, -%3, %4, %1"
-                         : "+v"(a[c]), "+v"(x[c]) : "v"(a[j]), "v"(x[j]), "s"(lcj));
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep each column's broadcasts next to their uses (else they spill out of the SGPR file)
-    }
+    const double d0 = dpp_bcast_nop<0>(a[0]);
+    double dmin = d0;
+    double sq, rs;
+    sqrt_rsqrt(d0, sq, rs);
+    double h = 0.5 * rs, a2 = a[0] + a[0], x2 = x[0] + x[0];
+    const double t2 = dpp_bcast_nop<1>(a2);
+    double e0 = dpp_bcast<1>(a[1]);
+    double q4 = t2 * t2;
+    (void)sq;
+    fb_column<0>(a, x, h, q4, e0, a2, x2, dmin);   fb_column<1>(a, x, h, q4, e0, a2, x2, dmin);   fb_column<2>(a, x, h, q4, e0, a2, x2, dmin);
+    fb_column<3>(a, x, h, q4, e0, a2, x2, dmin);   fb_column<4>(a, x, h, q4, e0, a2, x2, dmin);   fb_column<5>(a, x, h, q4, e0, a2, x2, dmin);
+    fb_column<6>(a, x, h, q4, e0, a2, x2, dmin);   fb_column<7>(a, x, h, q4, e0, a2, x2, dmin);   fb_column<8>(a, x, h, q4, e0, a2, x2, dmin);
+    fb_column<9>(a, x, h, q4, e0, a2, x2, dmin);   fb_column<10>(a, x, h, q4, e0, a2, x2, dmin);  fb_column<11>(a, x, h, q4, e0, a2, x2, dmin);
+    fb_column<12>(a, x, h, q4, e0, a2, x2, dmin);  fb_column<13>(a, x, h, q4, e0, a2, x2, dmin);  fb_column<14>(a, x, h, q4, e0, a2, x2, dmin);
+    fb_column<15>(a, x, h, q4, e0, a2, x2, dmin);
+    // The strict upper triangle of the block is left holding partial sums: nothing reads it (the panel solves use the
+    // stored inverse for diagonal blocks, the updates only touch blocks below them, S's upper triangle is never referenced).
     if (lane < NB) {
 #pragma unroll
-        for (int c = 0; c < NB; ++c) A[(p0 + c) * LDC + p0 + l] = (c <= l) ? a[c] : 0.0;
+        for (int c = 0; c < NB; ++c) A[(p0 + c) * LDC + p0 + l] = a[c];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) { Li[i * NB + l] = x[i]; Linv_out[i * NB + l] = x[i]; }
+        for (int i = 0; i < NB; ++i) Li[i * NB + l] = x[i];
     }
-    return failed;
+    (void)Linv_out;    // copied from Li by the caller's other wavefronts, off the critical path
+    return __builtin_amdgcn_ballot_w64(!(dmin > 0.0)) != 0;
 }
 
 // one 16x16 tile of the in-LDS trailing update: C(ri.., cj..) -= X(ri.., p0..p0+15) X(cj.., p0..p0+15)^T.
@@ -145,9 +250,14 @@ __device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __re
     bool failed = false;
     if (wave == 0) failed = factor_block16(A, 0, lane, Li, Linv_k);
     __syncthreads();
-    for (int s = 0; s < NBLK - 1; ++s) {
+    for (int s = 0; s < NBLK; ++s) {
         const int p0 = s * NB;
         const double* Lc = Li + (s & 1) * NB * NB;
+        if (wave == 3) {                           // block inverse s -> global workspace (read by k_trsm_panel / k_bsolve_persist)
+            const double4_t v = *reinterpret_cast<const double4_t*>(Lc + lane * 4);
+            *reinterpret_cast<double4_t*>(Linv_k + s * NB * NB + lane * 4) = v;
+        }
+        if (s == NBLK - 1) break;
         // rows below block s:  Y = Linv * A^T per 16-row strip; Y[m][n] = X[row r0 + n][col p0 + m]
         const int nstrips = NBLK - 1 - s;
         for (int t = wave; t < nstrips; t += 4) {
