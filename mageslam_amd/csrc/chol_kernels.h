@@ -8,7 +8,8 @@ constexpr int CHOL_TILE = 128;
 
 struct CholWorkspace {
     double* Linv;      // chol_workspace_doubles(n_pad): inverses of the 16x16 diagonal blocks of L, per tile
-    int* sync;         // chol_sync_ints(n_pad) ints: [0] arrival counter of the split diagonal tile, [1..nt] x_k-ready flags
+    int* sync;         // chol_sync_ints(n_pad) ints: [0] arrival counter of the split diagonal tile
+    long long* dbg = nullptr;   // development only: 4 x nt time stamps of the backward solve (tools/chol_test.hip)
 };
 size_t chol_workspace_doubles(int n_pad);
 inline size_t chol_sync_ints(int n_pad) { return (size_t)(n_pad / CHOL_TILE) + 2; }

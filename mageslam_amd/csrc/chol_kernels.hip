@@ -450,24 +450,45 @@ __device__ __forceinline__ void update_block(const double* __restrict__ S, int l
         for (int b = 0; b < SUB; ++b) out[a][b] = cv[a][b] + acc[a][b];
 }
 
-// Grid of the trailing update of step k (tiles (i, j), j0 = k + 1 <= j <= i < nt):
-//   blocks 0..2   the three lower 64x64 quadrants of the NEXT diagonal tile (j0, j0), one 32x32 block per wavefront.
-//                 Block 0 keeps its quadrant in LDS, waits for the other two (release/acquire on `flag`), pulls them
-//                 into LDS and factors the tile in place -- the sequential diagonal factorisation of step k + 1
-//                 overlaps the rest of this update, and its own update is spread over three compute units.
-//   blocks 3..    one 128x128 tile each (tile index 1..), 64x64 per wavefront.
+// Grid of the trailing update of step k (tiles (i, j), j0 = k + 1 <= j <= i < nt), in dispatch order:
+//   blocks 0..8   the NEXT diagonal tile (j0, j0): its 36 lower 16x16 blocks, one per wavefront (32 dependent MFMAs
+//                 each instead of one wavefront grinding through a 64x64 quadrant: the tile is on the critical path).
+//                 All write to S; blocks 1..8 then count up `flag` (agent-scope release), block 0 waits for 8 (acquire),
+//                 pulls the tile into LDS and factors it in place -- the sequential diagonal factorisation of step
+//                 k + 1 overlaps the rest of this update.
+//   whole tiles   one 128x128 tile per block (tile index 1..), 64x64 per wavefront.
+//   quarter tiles when the last round of whole tiles would occupy at most half of the compute units (n_q4 tiles), those
+//                 tiles are cut into four 64x64 blocks, 32x32 per wavefront, so the round ends in a quarter of the time.
 //   last m blocks rhs update y_i -= L_ik y_k.
+constexpr int NDIAG = 9;           // workgroups on the next diagonal tile: 36 lower 16x16 blocks / 4 wavefronts
+
+__host__ __device__ inline int syrk_quartered_tiles(int n_tiles /* incl. the diagonal one */, int n_cu)
+{
+    const int whole = n_tiles - 1;
+    const int rem = whole % n_cu;
+    return (rem > 0 && rem * 2 <= n_cu) ? rem : 0;
+}
+
+__device__ __forceinline__ void tile_of_index(int t, int& rt, int& ct)
+{
+    rt = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((rt + 1) * (rt + 2) / 2 <= t) ++rt;
+    while (rt * (rt + 1) / 2 > t) --rt;
+    ct = t - rt * (rt + 1) / 2;
+}
+
 __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
-                                                     double* __restrict__ Linv_next, double* __restrict__ ok, int* __restrict__ flag)
+                                                     double* __restrict__ Linv_next, double* __restrict__ ok, int* __restrict__ flag, int n_q4)
 {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j0 = k + 1, mt = nt - j0;
     const int n_tiles = mt * (mt + 1) / 2;
-    const int n_blocks = n_tiles + 2;                 // tile 0 is split over blocks 0..2
+    const int n_whole = n_tiles - 1 - n_q4;                       // tile indices 1 .. n_whole
+    const int first_q4 = NDIAG + n_whole, first_rhs = first_q4 + 4 * n_q4;
     const int bid = blockIdx.x;
-    if (bid >= n_blocks) {
-        const int i = k + 1 + (bid - n_blocks);
+    if (bid >= first_rhs) {
+        const int i = k + 1 + (bid - first_rhs);
         if (i >= nt) return;
         const double* Lik = S + (size_t)(k * TILE) * ld + (size_t)i * TILE;
         const double* yk = y + (size_t)k * TILE;
@@ -479,63 +500,64 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
         }
         return;
     }
-    if (bid < 3) {
-        // quadrant (qr, qc) of the diagonal tile: (0,0), (1,0), (1,1); wavefront = 32x32 sub-block
-        const int qr = bid == 0 ? 0 : 1, qc = bid == 2 ? 1 : 0;
-        const int row0 = j0 * TILE + qr * 64 + (wave & 1) * 32, col0 = j0 * TILE + qc * 64 + (wave >> 1) * 32;
-        double4_t out[2][2];
-        update_block<2, 32>(S, ld, k, row0, col0, lane, out);
-        if (bid == 0) {
-            double* A = sm;
+    if (bid < NDIAG) {
+        // 16x16 block u = 4 bid + wave of the lower triangle of the diagonal tile, (bi, bj), bi >= bj
+        const int u = bid * 4 + wave;
+        int bi, bj;
+        tile_of_index(u, bi, bj);
+        const int row0 = j0 * TILE + bi * NB, col0 = j0 * TILE + bj * NB;
+        double4_t out[1][1];
+        update_block<1, 32>(S, ld, k, row0, col0, lane, out);
+        double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        A[((wave >> 1) * 32 + a * 16 + (lane >> 4) + 4 * r) * LDC + (wave & 1) * 32 + b * 16 + (lane & 15)] = out[a][b][r];
-            // wait for the two other quadrants (bounded spin; relaxed polls, one acquire)
-            if (tid == 0) {
-                int spins = 0;
-                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2 && ++spins < (1 << 26)) __builtin_amdgcn_s_sleep(2);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            __syncthreads();
-            // pull quadrants (1,0) and (1,1) (rows 64..127 of the tile) into LDS
-            const double* T = S + (size_t)(j0 * TILE) * ld + (size_t)j0 * TILE;
-#pragma unroll 8
-            for (int e = tid; e < TILE * 32; e += 256) {          // 128 columns x 32 double2 per column
-                const int c = e / 32, r = 64 + (e % 32) * 2;
-                *reinterpret_cast<double2*>(A + c * LDC + r) = *reinterpret_cast<const double2*>(T + (size_t)c * ld + r);
-            }
-            __syncthreads();
-            const bool failed = potrf_tile_lds(A, sm + TILE * LDC, Linv_next, tid);
-            store_tile_lower(S + (size_t)(j0 * TILE) * ld + (size_t)j0 * TILE, A, ld, tid);
-            if (tid == 0 && failed) *ok = 0.0;
-        } else {
-            double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = out[a][b][r];
+        for (int r = 0; r < 4; ++r) C[(size_t)(4 * r) * ld] = out[0][0][r];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (bid != 0) {
             // publish: all stores of the workgroup done -> agent-scope release -> count
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            return;
         }
+        // block 0: wait for the eight others (bounded spin; relaxed polls, one acquire), pull the tile, factor it
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NDIAG - 1 && ++spins < (1 << 26)) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        double* A = sm;
+        double* T = S + (size_t)(j0 * TILE) * ld + (size_t)j0 * TILE;
+        load_tile<LDC>(A, T, ld, tid);
+        __syncthreads();
+        const bool failed = potrf_tile_lds(A, sm + TILE * LDC, Linv_next, tid);
+        store_tile_lower(T, A, ld, tid);
+        if (tid == 0 && failed) *ok = 0.0;
         return;
     }
-    const int t = bid - 2;
-    int rt = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((rt + 1) * (rt + 2) / 2 <= t) ++rt;
-    while (rt * (rt + 1) / 2 > t) --rt;
-    const int ct = t - rt * (rt + 1) / 2;
+    if (bid >= first_q4) {
+        // quarter of tile index n_whole + 1 + (bid - first_q4) / 4
+        const int q = bid - first_q4;
+        int rt, ct;
+        tile_of_index(n_whole + 1 + (q >> 2), rt, ct);
+        const int row0 = (j0 + rt) * TILE + ((q >> 0) & 1) * 64 + (wave & 1) * 32;
+        const int col0 = (j0 + ct) * TILE + ((q >> 1) & 1) * 64 + (wave >> 1) * 32;
+        double4_t out[2][2];
+        update_block<2, 32>(S, ld, k, row0, col0, lane, out);
+        double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = out[a][b][r];
+        return;
+    }
+    int rt, ct;
+    tile_of_index(bid - NDIAG + 1, rt, ct);
     const int row0 = (j0 + rt) * TILE + (wave & 1) * 64, col0 = (j0 + ct) * TILE + (wave >> 1) * 64;
     double4_t out[4][4];
     update_block<4, 8>(S, ld, k, row0, col0, lane, out);
@@ -549,20 +571,34 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward substitution  L^T x = y  as ONE persistent launch: workgroup j owns tile column j.  It keeps
-// L_jj (LDS) and y_j, consumes x_k for k = nt-1 .. j+1 as they are published (flag[k], agent-scope
-// release/acquire), applying y_j -= L_kj^T x_k from a register-resident copy of the tile that was prefetched
-// while it waited, then solves x_j = L_jj^-T y_j (blocked by 16 with the stored block inverses) and publishes
-// it.  nt <= 256 workgroups are all resident (one per CU), so a consumer never waits for an unscheduled producer.
+// backward substitution  L^T x = y  as ONE persistent launch: workgroup j owns tile column j.  It keeps L_jj (LDS) and
+// y_j, consumes x_k for k = nt-1 .. j+1 as they appear, applying y_j -= L_kj^T x_k from a register-resident copy of
+// the tile that was prefetched while it waited, then solves x_j = L_jj^-T y_j (blocked by 16 with the stored block
+// inverses) and publishes it.  The tile-to-tile chain is pure latency, so there is no flag: x is pre-filled with a
+// signalling-NaN pattern no computation produces, the producer stores its 128 values with agent-scope atomics and the
+// consumers poll the VALUES (one L2 round trip per hop instead of flag + data: 6.1 -> 4.8 us per hop, measured with
+// CHOL_DBG=1 tools/chol_test).  Inverting L_jj in LDS beforehand (one matrix-vector product at the end) was tried: the
+// 50 us it takes do not fit in the slack of any column, and the hop stayed at 4.7 us; pinning the chain to one XCD did
+// not shorten it either.  nt <= 256 workgroups are all resident (one per CU, dispatched last column first), so a
+// consumer never waits for an unscheduled producer; polls are bounded, a time-out only yields garbage in an already
+// failed solve.
 // ---------------------------------------------------------------------------------------------
+constexpr unsigned long long X_SENTINEL = 0x7FF4DEADBEEF0001ull;
+
+__global__ void k_fill_u64(unsigned long long* __restrict__ p, int n, unsigned long long v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict__ S, const double* __restrict__ y, double* __restrict__ x,
-                                                        int ld, int nt, const double* __restrict__ Linv, int* __restrict__ flags)
+                                                        int ld, int nt, const double* __restrict__ Linv, long long* __restrict__ dbg)
 {
     extern __shared__ double sm[];
     constexpr int LDB = TILE + 2;
-    double* T = sm;                        // L_jj, column-major
+    double* T = sm;                        // L_jj, column-major (T[c * LDB + r])
     __shared__ double Li[NBLK * NB * NB];
-    __shared__ double ys[TILE], xk[TILE], red[256];
+    __shared__ double ys[TILE], xk[TILE];
     const int tid = threadIdx.x;
     const int j = nt - 1 - (int)blockIdx.x;                     // the last tile column is dispatched first
     load_tile<LDB>(T, S + (size_t)(j * TILE) * ld + (size_t)j * TILE, ld, tid);
@@ -578,14 +614,18 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
     };
     if (j < nt - 1) prefetch(nt - 1);
     __syncthreads();
+    if (dbg && tid == 0) dbg[j * 4 + 0] = wall_clock64();
+
+    if (dbg && tid == 0) dbg[j * 4 + 1] = wall_clock64();
     for (int k = nt - 1; k > j; --k) {
-        if (tid == 0) {
+        if (k == j + 1 && dbg && tid == 0) dbg[j * 4 + 2] = wall_clock64();
+        if (tid < TILE) {
+            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(x + (size_t)k * TILE + tid);
+            unsigned long long v;
             int spins = 0;
-            while (__hip_atomic_load(flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 26)) __builtin_amdgcn_s_sleep(1);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            while ((v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == X_SENTINEL && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(1);
+            xk[tid] = __longlong_as_double((long long)v);
         }
-        __syncthreads();
-        if (tid < TILE) xk[tid] = __builtin_nontemporal_load(x + (size_t)k * TILE + tid);
         __syncthreads();
         double acc = 0;
 #pragma unroll
@@ -598,31 +638,29 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
         if (half == 0) ys[c] -= acc;
         __syncthreads();
     }
-    for (int cb = NBLK - 1; cb >= 0; --cb) {
-        if (tid < NB) {                    // x_c = Linv_cc^T ys_c
-            double acc = 0;
+    // x_j = L_jj^-T ys: eight blocked steps with the stored 16x16 block inverses
+    {
+        for (int cb = NBLK - 1; cb >= 0; --cb) {
+            if (tid < NB) {                    // x_c = Linv_cc^T ys_c
+                double acc = 0;
 #pragma unroll
-            for (int n = 0; n < NB; ++n) acc = __builtin_fma(Li[cb * NB * NB + n * NB + tid], ys[cb * NB + n], acc);
-            xk[cb * NB + tid] = acc;
-        }
-        __syncthreads();
-        if (tid < cb * NB) {               // ys[q] -= sum_n L[16c + n][q] x_c[n]   for q < 16 c
-            double acc = ys[tid];
+                for (int n = 0; n < NB; ++n) acc = __builtin_fma(Li[cb * NB * NB + n * NB + tid], ys[cb * NB + n], acc);
+                xk[cb * NB + tid] = acc;
+            }
+            __syncthreads();
+            if (tid < cb * NB) {               // ys[q] -= sum_n L[16 cb + n][q] x_c[n]   for q < 16 cb
+                double acc = ys[tid];
 #pragma unroll
-            for (int n = 0; n < NB; ++n) acc = __builtin_fma(-T[tid * LDB + cb * NB + n], xk[cb * NB + n], acc);
-            ys[tid] = acc;
+                for (int n = 0; n < NB; ++n) acc = __builtin_fma(-T[tid * LDB + cb * NB + n], xk[cb * NB + n], acc);
+                ys[tid] = acc;
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        if (tid < TILE)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(x + (size_t)j * TILE + tid), (unsigned long long)__double_as_longlong(xk[tid]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid < TILE) x[(size_t)j * TILE + tid] = xk[tid];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(flags + j, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    (void)red;
+    if (dbg && tid == 0) dbg[j * 4 + 3] = wall_clock64();
 }
 
 __global__ void k_set_scalar(double* p, double v) { *p = v; }
@@ -633,8 +671,14 @@ size_t chol_workspace_doubles(int n_pad) { return (size_t)(n_pad / TILE) * NBLK 
 
 // Kernels that need more than the default dynamic-LDS limit must be opted in once per device (function attributes
 // are per device); called from mage_ba_create after hipSetDevice.
+int g_n_cu = 256;        // compute units of the device the library was initialised on (gfx950: 256)
+
 void chol_init_device()
 {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        g_n_cu = prop.multiProcessorCount;
     const size_t lds_diag = ((size_t)TILE * LDC + 2 * NB * NB) * sizeof(double);
     const size_t lds_panel = (size_t)TILE * (TILE + 2) * sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
@@ -652,17 +696,20 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
     const size_t lds_panel = (size_t)TILE * (TILE + 2) * sizeof(double);
     const size_t linv_stride = (size_t)NBLK * NB * NB;
     hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, st, ok, 1.0);
+    hipLaunchKernelGGL(k_fill_u64, dim3((n_pad + 255) / 256), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(x), n_pad, X_SENTINEL);
     hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), lds_diag, st, S, n_pad, 0, ws.Linv, ok);
     for (int k = 0; k < nt; ++k) {
         const int m = nt - k - 1;             // tile rows below panel k
         hipLaunchKernelGGL(k_trsm_panel, dim3(m * NBLK + 1), dim3(64), 0, st, S, y, n_pad, k, nt, ws.Linv + (size_t)k * linv_stride, ws.sync, 0);
-        if (m > 0)
-            hipLaunchKernelGGL(k_syrk_update, dim3(m * (m + 1) / 2 + 2 + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
-                               ws.Linv + (size_t)(k + 1) * linv_stride, ok, ws.sync);
+        if (m > 0) {
+            const int n_tiles = m * (m + 1) / 2;
+            const int n_q4 = syrk_quartered_tiles(n_tiles, g_n_cu);
+            hipLaunchKernelGGL(k_syrk_update, dim3(NDIAG + (n_tiles - 1 - n_q4) + 4 * n_q4 + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
+                               ws.Linv + (size_t)(k + 1) * linv_stride, ok, ws.sync, n_q4);
+        }
     }
     // backward substitution: one persistent launch (needs every workgroup resident: nt <= 256 compute units)
-    (void)hipMemsetAsync(ws.sync + 1, 0, sizeof(int) * (size_t)nt, st);
-    hipLaunchKernelGGL(k_bsolve_persist, dim3(nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, ws.sync + 1);
+    hipLaunchKernelGGL(k_bsolve_persist, dim3(nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, ws.dbg);
 }
 
 }  // namespace mage

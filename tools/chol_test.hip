@@ -32,7 +32,8 @@ int main(int argc, char** argv)
         hipStream_t st; CK(hipStreamCreate(&st));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         int* dq; CK(hipMalloc(&dq, sizeof(int) * chol_sync_ints(n)));
-        CholWorkspace ws{ dws, dq };
+        long long* ddbg; CK(hipMalloc(&ddbg, sizeof(long long) * 4 * (n / 128 + 1)));
+        CholWorkspace ws{ dws, dq, getenv("CHOL_DBG") ? ddbg : nullptr };
         float best = 1e30f;
         for (int r = 0; r < reps; ++r) {
             CK(hipMemcpyAsync(dS, dS0, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
@@ -52,6 +53,15 @@ int main(int argc, char** argv)
             double s = 0;
             for (int j = 0; j < n; ++j) s += A[(size_t)j * n + i] * x[j];
             rn += (s - b[i]) * (s - b[i]); bn += b[i] * b[i];
+        }
+        if (getenv("CHOL_DBG")) {
+            int nt = n / 128;
+            std::vector<long long> d(4 * nt);
+            CK(hipMemcpy(d.data(), ddbg, sizeof(long long) * 4 * nt, hipMemcpyDeviceToHost));
+            long long t0 = d[(nt - 1) * 4];
+            for (int j = nt - 1; j >= 0; --j)
+                printf("  col %2d: start %8.2f us  precompute done %8.2f  last wait begins %8.2f  published %8.2f\n", j, (d[j * 4] - t0) * 0.01, (d[j * 4 + 1] - t0) * 0.01,
+                       (d[j * 4 + 2] - t0) * 0.01, (d[j * 4 + 3] - t0) * 0.01);
         }
         printf("n=%5d ok=%g  |Ax-b|/|b| = %.3e   best %.3f ms  -> %.2f TFLOP/s (n^3/3)\n", n, ok, sqrt(rn / bn), best,
                (double)n * n * n / 3.0 / (best * 1e-3) / 1e12);
