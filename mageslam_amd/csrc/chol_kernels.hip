@@ -238,6 +238,46 @@ __device__ __forceinline__ void lds_update_tile(double* __restrict__ A, int ri, 
     for (int r = 0; r < 4; ++r) A[(cj + (lane >> 4) + 4 * r) * LDC + ri + (lane & 15)] = acc[r];
 }
 
+// Left-looking form of the same update: C(ri.., cj..) -= sum over the nk column blocks 0, 16, .., 16 (nk - 1) of
+// X(ri.., p..p+15) X(cj.., p..p+15)^T, accumulator loaded and stored once, operand reads of block k + 1 in flight
+// while block k's MFMAs run.
+__device__ __forceinline__ void lds_update_tile_left(double* __restrict__ A, int ri, int cj, int nk, int lane)
+{
+    double4_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = A[(cj + (lane >> 4) + 4 * r) * LDC + ri + (lane & 15)];
+    double aop[2][4], bop[2][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        aop[0][r] = -A[(4 * r + (lane >> 4)) * LDC + cj + (lane & 15)];
+        bop[0][r] = A[(4 * r + (lane >> 4)) * LDC + ri + (lane & 15)];
+    }
+    for (int kb = 0; kb < nk; kb += 2) {
+        if (kb + 1 < nk) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                aop[1][r] = -A[((kb + 1) * NB + 4 * r + (lane >> 4)) * LDC + cj + (lane & 15)];
+                bop[1][r] = A[((kb + 1) * NB + 4 * r + (lane >> 4)) * LDC + ri + (lane & 15)];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[0][r], bop[0][r], acc, 0, 0, 0);
+        if (kb + 1 < nk) {
+            if (kb + 2 < nk) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    aop[0][r] = -A[((kb + 2) * NB + 4 * r + (lane >> 4)) * LDC + cj + (lane & 15)];
+                    bop[0][r] = A[((kb + 2) * NB + 4 * r + (lane >> 4)) * LDC + ri + (lane & 15)];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[1][r], bop[1][r], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) A[(cj + (lane >> 4) + 4 * r) * LDC + ri + (lane & 15)] = acc[r];
+}
+
 // ---------------------------------------------------------------------------------------------
 // diagonal tile, LDS-resident, blocked by 16.  Per block s: the rows below are solved on the matrix
 // cores with the block inverse (Y = Linv A^T); then wavefront 0 updates only the NEXT diagonal block and
@@ -258,34 +298,61 @@ __device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __re
             *reinterpret_cast<double4_t*>(Linv_k + s * NB * NB + lane * 4) = v;
         }
         if (s == NBLK - 1) break;
-        // rows below block s:  Y = Linv * A^T per 16-row strip; Y[m][n] = X[row r0 + n][col p0 + m]
+        // rows below block s:  Y = Linv * A^T per 16-row strip; Y[m][n] = X[row r0 + n][col p0 + m].
+        // Wavefront 0 is the critical path: it solves only the strip it needs (the rows of the next diagonal block) and
+        // updates that block before the barrier, while the other three share the remaining strips.
         const int nstrips = NBLK - 1 - s;
-        for (int t = wave; t < nstrips; t += 4) {
-            const int r0 = p0 + NB + t * NB;
-            double4_t acc = { 0, 0, 0, 0 };
+        if (wave == 0) {
+            // strip 0 and the next diagonal block in one go: the strip's result registers ARE both MFMA operands of
+            // D -= Y^T Y (register r of a lane is element [4r + (lane >> 4)][lane & 15] of Y = operand chunk r of either side)
+            const int r0 = p0 + NB;
+            double4_t acc = { 0, 0, 0, 0 }, dg;
+            double aop[4], bop[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double aop = Lc[(lane & 15) * NB + 4 * r + (lane >> 4)];
-                const double bop = A[(p0 + 4 * r + (lane >> 4)) * LDC + r0 + (lane & 15)];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+                aop[r] = Lc[(lane & 15) * NB + 4 * r + (lane >> 4)];
+                bop[r] = A[(p0 + 4 * r + (lane >> 4)) * LDC + r0 + (lane & 15)];
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): all operand reads of this strip are done before it is overwritten
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dg[r] = A[(r0 + (lane >> 4) + 4 * r) * LDC + r0 + (lane & 15)];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[r], bop[r], acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) A[(p0 + (lane >> 4) + 4 * r) * LDC + r0 + (lane & 15)] = acc[r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dg = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[r], acc[r], dg, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(r0 + (lane >> 4) + 4 * r) * LDC + r0 + (lane & 15)] = dg[r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        } else {
+            for (int t = wave; t < nstrips; t += 3) {
+                const int r0 = p0 + NB + t * NB;
+                double4_t acc = { 0, 0, 0, 0 };
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double aop = Lc[(lane & 15) * NB + 4 * r + (lane >> 4)];
+                    const double bop = A[(p0 + 4 * r + (lane >> 4)) * LDC + r0 + (lane & 15)];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): all operand reads of this strip are done before it is overwritten
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[(p0 + (lane >> 4) + 4 * r) * LDC + r0 + (lane & 15)] = acc[r];
+            }
         }
         __syncthreads();
-        // trailing update; tile 0 is the next diagonal block: wave 0 takes it and goes on to factor it
-        const int ntr = nstrips * (nstrips + 1) / 2;
+        // Trailing update, scheduled so that it never outlasts the factorisation it runs beside (a right-looking update
+        // front-loads 27 of the 77 tile updates into step 0; wavefront 0 then waited ~10k cycles per tile at this barrier):
+        //   wavefront 0     factors the next diagonal block (updated just above);
+        //   wavefronts 1-3  block column s+1 below the diagonal, LEFT-looking: tile (i, s+1) -= sum_{k <= s} Y_ik Y_{s+1,k}^T
+        //                   (these are the strips of the next step), and the later diagonal blocks (i, i) -= Y_is Y_is^T.
         if (wave == 0) {
-            lds_update_tile(A, p0 + NB, p0 + NB, p0, lane);
-            __builtin_amdgcn_s_waitcnt(0xc07f);
             failed |= factor_block16(A, p0 + NB, lane, Li + ((s + 1) & 1) * NB * NB, Linv_k + (s + 1) * NB * NB);
         } else {
-            for (int t = wave; t < ntr; t += 3) {
-                int ti = 0;
-                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-                const int tj = t - ti * (ti + 1) / 2;
-                lds_update_tile(A, p0 + NB + ti * NB, p0 + NB + tj * NB, p0, lane);
+            const int nrow = NBLK - 2 - s;                 // block rows s+2 .. 7
+            for (int t = wave - 1; t < 2 * nrow; t += 3) {
+                const int i = s + 2 + (t >> 1);
+                if ((t & 1) == 0) lds_update_tile_left(A, i * NB, p0 + NB, s + 1, lane);
+                else lds_update_tile(A, i * NB, i * NB, p0, lane);
             }
         }
         __syncthreads();
