@@ -88,6 +88,15 @@ def test_local_ba_config_matches_oracle():
     _compare_with_oracle(s, False, calls)
 
 
+@pytest.mark.parametrize("n_cams", [45, 150])
+def test_medium_reduced_systems_match_oracle(n_cams):
+    """Reduced camera systems of a few 128-column tiles (258 -> 3 tiles, 888 -> 7 tiles): every role of the tiled
+    factorisation runs (split diagonal update, whole and quartered trailing tiles, multi-hop backward solve) at a size the
+    CPU oracle still finishes in seconds."""
+    s = scene.make_scene(n_cams=n_cams, n_pts=100 * n_cams, n_obs=1000 * n_cams, seed=0x5EED0B00 + n_cams, outlier_frac=0.01)
+    _compare_with_oracle(s, False, [([1.8], 25.0), ([0.9], 16.0), ([0.9], 9.0)])
+
+
 def test_multi_step_calls_and_lambda_persistence():
     s = scene.make_config("tiny", seed=123)
     g, o = BundlerLib(), OracleBundler()
