@@ -8,8 +8,8 @@
  * second-best minus best < minHammingDifference, keep mutual best pairs, emit cv::DMatch in ascending query order.
  * Masks are applied by gathering (FeatureMatcher.cpp:88-110) and indices are mapped back (:160-163); both are
  * done by mage_match_masked below so a caller can pass its std::vector<bool>-derived byte masks directly.
- * RadiusMatch (FeatureMatcher.cpp:294-446) is mage_match_radius below; IndexedMatch (:192-292, BoW-driven)
- * is the remaining "next" row and is not built.
+ * RadiusMatch (FeatureMatcher.cpp:294-446) is mage_match_radius below; IndexedMatch (:192-292) is
+ * mage_match_indexed: its candidate lists are whatever the caller's vocabulary index (BoW QueryFeatures, out of scope) returned.
  */
 #ifndef MAGE_MATCH_H
 #define MAGE_MATCH_H
@@ -74,6 +74,21 @@ mage_status mage_match_radius(mage_matcher* h, const mage_keypoint* query_keypoi
                               const uint8_t* query_mask, const uint8_t* query_descriptors, const mage_keypoint* target_keypoints, int nT,
                               const uint8_t* target_mask, const uint8_t* target_descriptors, float radius, int max_hamming_dist,
                               int min_hamming_difference, mage_dmatch* out, int capacity, int* count);
+
+/* IndexedMatch (Tracking/FeatureMatcher.cpp:192-292; TrackMatch :28-54): the two-way best / second-best test of Match, but every
+ * descriptor is compared only with the candidates a vocabulary index returned for it (BaseBow::QueryFeatures(descriptor, keyframe) or
+ * BaseFeatureMatcher::QueryFeatures(descriptor), BoW/*.h -- out of scope: the caller passes the lists).
+ *   cand_b_offsets[nA + 1], cand_b[]  CSR: candidates (indices into B) of each A descriptor, in the order QueryFeatures returned them
+ *   cand_a_offsets[nB + 1], cand_a[]  CSR: candidates (indices into A) of each B descriptor, used for the reverse check
+ * Forward: an unmasked A descriptor keeps its best unmasked candidate when best < max_hamming_dist + 1 and either no second
+ * candidate is below that limit or second - best >= min_hamming_difference (strict '<' updates in list order: the first of
+ * equal distances wins, a duplicated candidate becomes its own second best).  Reverse: the chosen B descriptor must choose
+ * that A descriptor back under the same test.  Results: cv::DMatch(queryIdx = index in A, trainIdx = index in B, 0, distance),
+ * ascending queryIdx.  Returns without matches when either mask selects nothing (:208).  Masks may be NULL (= all); all
+ * pointers are host pointers; candidate indices outside the other image are rejected with MAGE_ERR_INVALID_ARGUMENT. */
+mage_status mage_match_indexed(mage_matcher* h, const uint8_t* descriptors_a, int nA, const uint8_t* mask_a, const int32_t* cand_b_offsets,
+                               const int32_t* cand_b, const uint8_t* descriptors_b, int nB, const uint8_t* mask_b, const int32_t* cand_a_offsets,
+                               const int32_t* cand_a, int max_hamming_dist, int min_hamming_difference, mage_dmatch* out, int capacity, int* count);
 
 /* HIP-event time of the most recent batched call's kernel, in milliseconds. */
 mage_status mage_matcher_last_kernel_ms(const mage_matcher* h, double* ms);

@@ -165,7 +165,81 @@ __global__ __launch_bounds__(MT) void k_radius_match(const mage_keypoint* __rest
     if (tid == 0) *count = base_s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// IndexedMatch (Tracking/FeatureMatcher.cpp:192-292, TrackMatch :28-54).  Candidates come from a vocabulary index
+// (QueryFeatures: out of scope) as CSR lists and are visited in the order given.  One workgroup per problem, thread per
+// A descriptor: forward pass over its candidates, then -- if it passed -- the reverse pass over the candidates of the B
+// descriptor it chose; accepted pairs are compacted in ascending A index.  Integer work, a few dozen 32-byte gathers per
+// thread: latency-bound at 440 features, there is nothing to tile.
+// ---------------------------------------------------------------------------------------------
+struct Track { int idx, dist; };
+
+__device__ __forceinline__ void track_match(const ulonglong4& left, const ulonglong4* __restrict__ right, int idx, const uint8_t* __restrict__ mask,
+                                            Track& best, Track& second, int max_hamming)
+{
+    if (mask && !mask[idx]) return;
+    const ulonglong4 v = right[idx];
+    const int d = __popcll(left.x ^ v.x) + __popcll(left.y ^ v.y) + __popcll(left.z ^ v.z) + __popcll(left.w ^ v.w);
+    if (d < max_hamming) {
+        if (d < best.dist) { second = best; best.idx = idx; best.dist = d; }
+        else if (d < second.dist) { second.idx = idx; second.dist = d; }
+    }
+}
+
+__global__ __launch_bounds__(MT) void k_indexed_match(const uint8_t* __restrict__ descA, int nA, const uint8_t* __restrict__ maskA,
+                                                      const int* __restrict__ cb_off, const int* __restrict__ cb,
+                                                      const uint8_t* __restrict__ descB, const uint8_t* __restrict__ maskB,
+                                                      const int* __restrict__ ca_off, const int* __restrict__ ca, int max_dist, int min_diff,
+                                                      mage_dmatch* __restrict__ out, int cap, int* __restrict__ count)
+{
+    __shared__ int wave_cnt[MT / 64];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const ulonglong4* A = reinterpret_cast<const ulonglong4*>(descA);
+    const ulonglong4* B = reinterpret_cast<const ulonglong4*>(descB);
+    const int max_hamming = max_dist + 1;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int a0 = 0; a0 < nA; a0 += MT) {
+        const int a = a0 + tid;
+        int train = -1, dist = 0;
+        if (a < nA && (!maskA || maskA[a])) {
+            const ulonglong4 da = A[a];
+            Track best = { -1, max_hamming }, second = { -1, max_hamming };
+            for (int k = cb_off[a]; k < cb_off[a + 1]; ++k) track_match(da, B, cb[k], maskB, best, second, max_hamming);
+            if (best.dist < max_hamming && (second.dist >= max_hamming || second.dist - best.dist >= min_diff)) {
+                const int b = best.idx;
+                const ulonglong4 db = B[b];
+                Track rb = { -1, max_hamming }, rs = { -1, max_hamming };
+                for (int k = ca_off[b]; k < ca_off[b + 1]; ++k) track_match(db, A, ca[k], maskA, rb, rs, max_hamming);
+                if (rb.dist < max_hamming && rb.idx == a && (rs.dist >= max_hamming || rs.dist - rb.dist >= min_diff)) { train = b; dist = rb.dist; }
+            }
+        }
+        const unsigned long long bal = __ballot(train >= 0);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (train >= 0 && off + before < cap) {
+            mage_dmatch m = { a, train, 0, (float)dist };
+            out[off + before] = m;
+        }
+        __syncthreads();
+        if (tid == 0) { int s2 = 0; for (int w = 0; w < MT / 64; ++w) s2 += wave_cnt[w]; base_s += s2; }
+        __syncthreads();
+    }
+    if (tid == 0) *count = base_s;
+}
+
 }  // namespace
+
+void indexed_match_launch(const uint8_t* descA, int nA, const uint8_t* maskA, const int* cb_off, const int* cb, const uint8_t* descB,
+                          const uint8_t* maskB, const int* ca_off, const int* ca, int max_dist, int min_diff, mage_dmatch* out, int cap, int* count,
+                          hipStream_t st)
+{
+    hipLaunchKernelGGL(k_indexed_match, dim3(1), dim3(MT), 0, st, descA, nA, maskA, cb_off, cb, descB, maskB, ca_off, ca, max_dist, min_diff, out, cap, count);
+}
 
 void radius_match_launch(const mage_keypoint* qk, int nq, const float2* qpos, const uint8_t* qmask, const uint8_t* qdesc, const mage_keypoint* tk,
                          int nt, const uint8_t* tmask, const uint8_t* tdesc, float radius, int max_dist, int min_diff, int* scratch,

@@ -471,6 +471,63 @@ MAGE_EXPORT mage_status mage_match_radius(mage_matcher* h, const mage_keypoint* 
     });
 }
 
+MAGE_EXPORT mage_status mage_match_indexed(mage_matcher* h, const uint8_t* descA, int nA, const uint8_t* maskA, const int32_t* cb_off, const int32_t* cb,
+                                           const uint8_t* descB, int nB, const uint8_t* maskB, const int32_t* ca_off, const int32_t* ca,
+                                           int max_dist, int min_diff, mage_dmatch* out, int capacity, int* count)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !count) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        *count = 0;
+        if (nA < 0 || nB < 0 || capacity < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative size");
+        if (nA == 0 || nB == 0) return MAGE_OK;
+        if (!descA || !descB || !cb_off || !ca_off || (capacity > 0 && !out)) return fail(MAGE_ERR_INVALID_ARGUMENT, "null buffer");
+        // FeatureMatcher.cpp:208: nothing to do when either mask is empty
+        size_t cntA = 0, cntB = 0;
+        for (int i = 0; i < nA; ++i) cntA += (!maskA || maskA[i]);
+        for (int i = 0; i < nB; ++i) cntB += (!maskB || maskB[i]);
+        if (cntA == 0 || cntB == 0) return MAGE_OK;
+        // the candidate lists index into the other image: validate once on the host (the reference would read out of bounds)
+        if (cb_off[0] != 0 || ca_off[0] != 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "candidate offsets must start at 0");
+        for (int i = 0; i < nA; ++i) if (cb_off[i + 1] < cb_off[i]) return fail(MAGE_ERR_INVALID_ARGUMENT, "candidate offsets of A are not monotone");
+        for (int i = 0; i < nB; ++i) if (ca_off[i + 1] < ca_off[i]) return fail(MAGE_ERR_INVALID_ARGUMENT, "candidate offsets of B are not monotone");
+        const size_t ncb = (size_t)cb_off[nA], nca = (size_t)ca_off[nB];
+        if ((ncb && !cb) || (nca && !ca)) return fail(MAGE_ERR_INVALID_ARGUMENT, "null candidate list");
+        for (size_t k = 0; k < ncb; ++k) if (cb[k] < 0 || cb[k] >= nB) return fail(MAGE_ERR_INVALID_ARGUMENT, "candidate %zu of A is outside B", k);
+        for (size_t k = 0; k < nca; ++k) if (ca[k] < 0 || ca[k] >= nA) return fail(MAGE_ERR_INVALID_ARGUMENT, "candidate %zu of B is outside A", k);
+        MAGE_HIP(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        // one staging buffer: [descA | descB | cb_off | ca_off | cb | ca | maskA | maskB], 16-byte aligned pieces
+        auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        const size_t o_da = 0, o_db = al(o_da + 32 * (size_t)nA), o_bo = al(o_db + 32 * (size_t)nB), o_ao = al(o_bo + 4 * ((size_t)nA + 1)),
+                     o_cb = al(o_ao + 4 * ((size_t)nB + 1)), o_ca = al(o_cb + 4 * ncb), o_ma = al(o_ca + 4 * nca), o_mb = al(o_ma + nA), total = al(o_mb + nB);
+        std::vector<uint8_t> stage(total, 0);
+        std::memcpy(stage.data() + o_da, descA, 32 * (size_t)nA); std::memcpy(stage.data() + o_db, descB, 32 * (size_t)nB);
+        std::memcpy(stage.data() + o_bo, cb_off, 4 * ((size_t)nA + 1)); std::memcpy(stage.data() + o_ao, ca_off, 4 * ((size_t)nB + 1));
+        if (ncb) std::memcpy(stage.data() + o_cb, cb, 4 * ncb);
+        if (nca) std::memcpy(stage.data() + o_ca, ca, 4 * nca);
+        if (maskA) std::memcpy(stage.data() + o_ma, maskA, nA);
+        if (maskB) std::memcpy(stage.data() + o_mb, maskB, nB);
+        MAGE_TRY(h->d_A.reserve(total));
+        MAGE_TRY(h->d_out.reserve((size_t)std::max(capacity, 1)));
+        MAGE_TRY(h->d_counts.reserve(1));
+        MAGE_HIP(hipMemcpyAsync(h->d_A.p, stage.data(), total, hipMemcpyHostToDevice, st));
+        const uint8_t* d = h->d_A.p;
+        MAGE_HIP(hipEventRecord(h->e0, st));
+        indexed_match_launch(d + o_da, nA, maskA ? d + o_ma : nullptr, reinterpret_cast<const int*>(d + o_bo), reinterpret_cast<const int*>(d + o_cb),
+                             d + o_db, maskB ? d + o_mb : nullptr, reinterpret_cast<const int*>(d + o_ao), reinterpret_cast<const int*>(d + o_ca),
+                             max_dist, min_diff, h->d_out.p, capacity, h->d_counts.p, st);
+        MAGE_HIP(hipEventRecord(h->e1, st));
+        MAGE_HIP(hipMemcpyAsync(count, h->d_counts.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        MAGE_HIP(hipStreamSynchronize(st));
+        const int n = std::min(*count, capacity);
+        if (n > 0) MAGE_HIP(hipMemcpy(out, h->d_out.p, sizeof(mage_dmatch) * (size_t)n, hipMemcpyDeviceToHost));
+        float ms = 0;
+        MAGE_HIP(hipEventElapsedTime(&ms, h->e0, h->e1));
+        h->last_ms = ms;
+        return MAGE_OK;
+    });
+}
+
 MAGE_EXPORT mage_status mage_matcher_last_kernel_ms(const mage_matcher* h, double* ms)
 {
     if (!h || !ms) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");

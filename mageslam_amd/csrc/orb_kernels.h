@@ -39,5 +39,8 @@ void match_launch(int n_pairs, const uint8_t* descA, const int* countsA, int cap
 void radius_match_launch(const mage_keypoint* qk, int nq, const float2* qpos, const uint8_t* qmask, const uint8_t* qdesc, const mage_keypoint* tk,
                          int nt, const uint8_t* tmask, const uint8_t* tdesc, float radius, int max_dist, int min_diff, int* scratch,
                          mage_dmatch* out, int cap, int* count, hipStream_t st);
+void indexed_match_launch(const uint8_t* descA, int nA, const uint8_t* maskA, const int* cb_off, const int* cb, const uint8_t* descB,
+                          const uint8_t* maskB, const int* ca_off, const int* ca, int max_dist, int min_diff, mage_dmatch* out, int cap, int* count,
+                          hipStream_t st);
 
 }  // namespace mage

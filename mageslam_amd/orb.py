@@ -57,6 +57,7 @@ def _declare():
     L.mage_match_bf_batch.argtypes = [vp, C.c_int, _u8, _i32, C.c_int, _u8, _i32, C.c_int, C.c_int, C.c_int, vp, C.c_int, _i32]
     L.mage_match_bf_batch_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     L.mage_match_radius.argtypes = [vp, vp, C.c_int, vp, vp, _u8, vp, C.c_int, vp, _u8, C.c_float, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
+    L.mage_match_indexed.argtypes = [vp, _u8, C.c_int, vp, vp, vp, _u8, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     L.mage_matcher_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double)]
     _declared = True
 
@@ -190,6 +191,25 @@ class Matcher:
         n = C.c_int(0)
         check(self._L.mage_match_radius(self._h, ptr(qk), len(qk), ptr(qp), ptr(qm), qd, ptr(tk), len(tk), ptr(tm), td, float(radius),
                                         int(max_hamming_dist), int(min_hamming_difference), ptr(out), len(out), C.byref(n)))
+        return out[: min(n.value, len(out))].copy()
+
+    def IndexedMatch(self, descriptors_a, cand_b_offsets, cand_b, descriptors_b, cand_a_offsets, cand_a, max_hamming_dist=30,
+                     min_hamming_difference=1, mask_a=None, mask_b=None) -> np.ndarray:
+        """FeatureMatcher::IndexedMatch (FeatureMatcher.cpp:192-292) with the vocabulary index's candidate lists in CSR form
+        (cand_b: indices into B per A descriptor; cand_a: indices into A per B descriptor, for the reverse check)."""
+        A = np.ascontiguousarray(descriptors_a, np.uint8).reshape(-1); B = np.ascontiguousarray(descriptors_b, np.uint8).reshape(-1)
+        nA, nB = A.size // 32, B.size // 32
+        if A.size == 0: A = np.zeros(32, np.uint8)
+        if B.size == 0: B = np.zeros(32, np.uint8)
+        ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        bo = np.ascontiguousarray(cand_b_offsets, np.int32); bc = np.ascontiguousarray(cand_b, np.int32)
+        ao = np.ascontiguousarray(cand_a_offsets, np.int32); ac = np.ascontiguousarray(cand_a, np.int32)
+        ma = None if mask_a is None else np.ascontiguousarray(mask_a, np.uint8)
+        mb = None if mask_b is None else np.ascontiguousarray(mask_b, np.uint8)
+        out = np.zeros(max(nA, 1), DMATCH_DTYPE)
+        n = C.c_int(0)
+        check(self._L.mage_match_indexed(self._h, A, nA, ptr(ma), ptr(bo), ptr(bc) if bc.size else None, B, nB, ptr(mb), ptr(ao), ptr(ac) if ac.size else None,
+                                         int(max_hamming_dist), int(min_hamming_difference), ptr(out), len(out), C.byref(n)))
         return out[: min(n.value, len(out))].copy()
 
     def last_kernel_ms(self) -> float:

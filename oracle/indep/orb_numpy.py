@@ -210,3 +210,41 @@ def radius_match(qxy, qoct, qdesc, txy, toct, tdesc, radius, max_dist=30, min_di
                 keep.append((q, t, d))
         almost = keep
     return np.array(almost, np.int64).reshape(-1, 3)
+
+
+def indexed_match(descA, cand_b, descB, cand_a, max_dist=30, min_diff=1, maskA=None, maskB=None):
+    """Independent restatement of IndexedMatch (FeatureMatcher.cpp:192-292): cand_b[a] / cand_a[b] are python lists of candidate
+    indices in the order the vocabulary index returned them.  Returns rows (queryIdx, trainIdx, distance)."""
+    nA, nB = len(descA), len(descB)
+    mA = np.ones(nA, bool) if maskA is None else np.asarray(maskA, bool)
+    mB = np.ones(nB, bool) if maskB is None else np.asarray(maskB, bool)
+    if not mA.any() or not mB.any():
+        return np.zeros((0, 3), np.int64)
+    D = hamming_matrix(descA, descB)
+    limit = max_dist + 1
+
+    def two_best(dist_of, cands, mask):
+        ranked = []                      # (distance, arrival order, index): strict '<' updates = stable order on distance
+        for order, c in enumerate(cands):
+            if mask[c] and dist_of(c) < limit:
+                ranked.append((int(dist_of(c)), order, int(c)))
+        ranked.sort()
+        best = ranked[0] if ranked else None
+        second = ranked[1] if len(ranked) > 1 else None
+        return best, second
+
+    def passes(best, second):
+        return best is not None and (second is None or second[0] - best[0] >= min_diff)
+
+    out = []
+    for a in range(nA):
+        if not mA[a]:
+            continue
+        best, second = two_best(lambda b: D[a, b], cand_b[a], mB)
+        if not passes(best, second):
+            continue
+        b = best[2]
+        rbest, rsecond = two_best(lambda a2: D[a2, b], cand_a[b], mA)
+        if passes(rbest, rsecond) and rbest[2] == a:
+            out.append((a, b, rbest[0]))
+    return np.array(out, np.int64).reshape(-1, 3)

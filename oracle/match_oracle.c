@@ -133,3 +133,48 @@ MTO_API int mto_radius_match(const mto_keypoint* qk, int nq, const float* qpos_o
     free(almost);
     return n;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * IndexedMatch (Tracking/FeatureMatcher.cpp:192-292) with TrackMatch (:28-54).  The candidate lists are what
+ * BaseBow::QueryFeatures / BaseFeatureMatcher::QueryFeatures returned for each descriptor (vocabulary index: out of scope),
+ * handed over in CSR form and visited in the order given.  maxHamming = maxHammingDist + 1 with strict comparisons.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { int idx, dist; } mto_track;
+
+static void mto_track_match(const uint8_t* left, const uint8_t* right_descs, int idx_right, const uint8_t* right_mask, mto_track* best,
+                            mto_track* second, int max_hamming)
+{
+    if (right_mask && !right_mask[idx_right]) return;                       /* :37 */
+    const int d = mto_hamming256(left, right_descs + (size_t)idx_right * 32);
+    if (d < max_hamming) {
+        if (d < best->dist) { *second = *best; best->idx = idx_right; best->dist = d; }
+        else if (d < second->dist) { second->idx = idx_right; second->dist = d; }
+    }
+}
+
+MTO_API int mto_indexed_match(const uint8_t* descA, int nA, const uint8_t* maskA, const int32_t* cb_off, const int32_t* cb,
+                              const uint8_t* descB, int nB, const uint8_t* maskB, const int32_t* ca_off, const int32_t* ca,
+                              int max_dist, int min_diff, mto_dmatch* out, int cap)
+{
+    int cntA = 0, cntB = 0;
+    for (int i = 0; i < nA; ++i) cntA += (!maskA || maskA[i]);
+    for (int i = 0; i < nB; ++i) cntB += (!maskB || maskB[i]);
+    if (cntA == 0 || cntB == 0) return 0;                                   /* :208 */
+    const int max_hamming = max_dist + 1;                                   /* :210 */
+    int n = 0;
+    for (int a = 0; a < nA; ++a) {
+        if (maskA && !maskA[a]) continue;
+        mto_track best = { -1, max_hamming }, second = { -1, max_hamming };
+        for (int k = cb_off[a]; k < cb_off[a + 1]; ++k) mto_track_match(descA + (size_t)a * 32, descB, cb[k], maskB, &best, &second, max_hamming);
+        if (!(best.dist < max_hamming && (second.dist >= max_hamming || second.dist - best.dist >= min_diff))) continue;     /* :239-240 */
+        const int b = best.idx;
+        mto_track rb = { -1, max_hamming }, rs = { -1, max_hamming };
+        for (int k = ca_off[b]; k < ca_off[b + 1]; ++k) mto_track_match(descB + (size_t)b * 32, descA, ca[k], maskA, &rb, &rs, max_hamming);
+        if (rb.dist < max_hamming && rb.idx == a && (rs.dist >= max_hamming || rs.dist - rb.dist >= min_diff)) {              /* :269-271 */
+            if (n < cap) { out[n].queryIdx = rb.idx; out[n].trainIdx = b; out[n].imgIdx = 0; out[n].distance = (float)rb.dist; }
+            ++n;
+        }
+    }
+    return n;
+}

@@ -115,6 +115,8 @@ def _declare(L: C.CDLL) -> None:
     L.mto_match.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.mto_radius_match.restype = C.c_int
     L.mto_radius_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_int, C.c_void_p, _u8p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.mto_indexed_match.restype = C.c_int
+    L.mto_indexed_match.argtypes = [_u8p, C.c_int, C.c_void_p, _i32p, _i32p, _u8p, C.c_int, C.c_void_p, _i32p, _i32p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.bao_test_se3_exp.argtypes = [_f64p, _f64p]
     L.bao_test_ldlt.restype = C.c_int
     L.bao_test_ldlt.argtypes = [_f64p, C.c_int, _f64p, _f64p]
@@ -300,3 +302,18 @@ def radius_match(qk, qdesc, tk, tdesc, radius, max_dist=30, min_diff=1, qpos=Non
     n = L.mto_radius_match(ptr(qk), len(qk), ptr(qp), ptr(qm), qd, ptr(tk), len(tk), ptr(tm), td, float(radius), int(max_dist), int(min_diff),
                            ptr(out), len(out))
     return out[:n].copy()
+
+
+def indexed_match(A, cand_b_off, cand_b, B, cand_a_off, cand_a, max_dist=30, min_diff=1, maskA=None, maskB=None) -> np.ndarray:
+    """oracle/match_oracle.c mto_indexed_match: IndexedMatch with CSR candidate lists; returns DMATCH_DTYPE records."""
+    L = lib()
+    A = np.ascontiguousarray(A, np.uint8).reshape(-1, 32); B = np.ascontiguousarray(B, np.uint8).reshape(-1, 32)
+    out = np.zeros(max(len(A), 1), DMATCH_DTYPE)
+    ma = None if maskA is None else np.ascontiguousarray(maskA, np.uint8)
+    mb = None if maskB is None else np.ascontiguousarray(maskB, np.uint8)
+    n = L.mto_indexed_match(A.reshape(-1) if len(A) else np.zeros(1, np.uint8), len(A), None if ma is None else ma.ctypes.data_as(C.c_void_p),
+                            np.ascontiguousarray(cand_b_off, np.int32), np.ascontiguousarray(cand_b, np.int32) if len(cand_b) else np.zeros(1, np.int32),
+                            B.reshape(-1) if len(B) else np.zeros(1, np.uint8), len(B), None if mb is None else mb.ctypes.data_as(C.c_void_p),
+                            np.ascontiguousarray(cand_a_off, np.int32), np.ascontiguousarray(cand_a, np.int32) if len(cand_a) else np.zeros(1, np.int32),
+                            int(max_dist), int(min_diff), out.ctypes.data_as(C.c_void_p), len(out))
+    return out[:n]

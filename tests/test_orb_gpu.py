@@ -176,3 +176,28 @@ def test_radius_match_golden_and_oracle(gold):
     # a single accepted query skips the uniqueness pass (FeatureMatcher.cpp:374-377)
     m = mt.RadiusMatch(ka[:1], da[:1], kb, db, 30.0, 256, 0)
     assert np.array_equal(m, O.radius_match(ka[:1], da[:1], kb, db, 30.0, 256, 0))
+
+
+def test_indexed_match_golden_and_oracle(gold):
+    """SURVEY.md 8f rank 4 ("next" row M-4): IndexedMatch over caller-supplied candidate lists, bit-exact against the fixture,
+    the oracle on random masks / thresholds, and its argument checks."""
+    import os
+    from mageslam_amd._lib import MageError
+    ix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_indexed.npz"))
+    da, db = gold["orb_640x480_a_desc"], gold["orb_640x480_b_desc"]
+    as3 = lambda m: np.stack([m["queryIdx"], m["trainIdx"], m["distance"].astype(np.int64)], axis=1)
+    mt = Matcher()
+    args = (ix["cand_b_off"], ix["cand_b"], db, ix["cand_a_off"], ix["cand_a"])
+    for case, (ka, kb) in {"plain": (None, None), "loose": (None, None), "masked": ("mask_a", "mask_b"), "nodiff": (None, "mask_b")}.items():
+        md, mn = (int(v) for v in ix["par_" + case])
+        m = mt.IndexedMatch(da, *args, md, mn, None if ka is None else ix[ka], None if kb is None else ix[kb])
+        assert np.array_equal(as3(m), ix["exp_" + case]) and np.all(m["imgIdx"] == 0)
+    rng = np.random.default_rng(21)
+    for md, mn in ((10, 0), (45, 3), (255, 1), (0, 1)):
+        ma = rng.random(len(da)) < 0.7; mb = rng.random(len(db)) < 0.7
+        assert np.array_equal(mt.IndexedMatch(da, *args, md, mn, ma, mb), O.indexed_match(da, args[0], args[1], db, args[3], args[4], md, mn, ma, mb))
+    assert len(mt.IndexedMatch(da, *args, 30, 1, np.zeros(len(da), bool), None)) == 0           # empty mask: FeatureMatcher.cpp:208
+    assert len(mt.IndexedMatch(da[:0], [0], [], db, np.zeros(len(db) + 1, np.int32), [], 30, 1)) == 0
+    bad = ix["cand_b"].copy(); bad[3] = len(db)
+    with pytest.raises(MageError):
+        mt.IndexedMatch(da, ix["cand_b_off"], bad, db, ix["cand_a_off"], ix["cand_a"], 30, 1)

@@ -168,3 +168,43 @@ def test_radius_match_semantics():
     assert len(O.radius_match(q2, d[[1, 2]], t1, d[:1], 9.0, 30, 1, qmask=[0, 1])) == 1
     assert len(O.radius_match(q2, d[[1, 2]], t1, d[:1], 9.0, 30, 1, tmask=[0])) == 0
     assert len(O.radius_match(q2[:0], d[:0], t1, d[:1], 9.0)) == 0
+
+
+INDEXED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_indexed.npz")
+INDEXED_CASES = {"plain": (None, None), "loose": (None, None), "masked": ("mask_a", "mask_b"), "nodiff": (None, "mask_b")}
+
+
+@pytest.mark.parametrize("case", sorted(INDEXED_CASES))
+def test_indexed_match_oracle_matches_golden(gold, case):
+    """IndexedMatch ("next" row M-4): fixtures from the independent numpy restatement, candidate lists = a toy vocabulary index."""
+    ix = np.load(INDEXED)
+    da, db = gold["orb_640x480_a_desc"], gold["orb_640x480_b_desc"]
+    md, mn = (int(v) for v in ix["par_" + case])
+    ka, kb = INDEXED_CASES[case]
+    m = O.indexed_match(da, ix["cand_b_off"], ix["cand_b"], db, ix["cand_a_off"], ix["cand_a"], md, mn,
+                        None if ka is None else ix[ka], None if kb is None else ix[kb])
+    got = np.stack([m["queryIdx"], m["trainIdx"], m["distance"].astype(np.int64)], axis=1)
+    assert np.array_equal(got, ix["exp_" + case]) and np.all(m["imgIdx"] == 0)
+
+
+def test_indexed_match_semantics():
+    """Known answers of the TrackMatch rules (FeatureMatcher.cpp:28-54, 239-240, 269-271)."""
+    d = np.zeros((4, 32), np.uint8)
+    d[1, 0] = 0x01            # distance 1 from d[0]
+    d[2, 0] = 0x03            # distance 2 from d[0]
+    d[3, :2] = 0xFF           # distance 16 from d[0]
+    A, B = d[[0]], d[[1, 2, 3]]
+    one = lambda cb, ca, **kw: O.indexed_match(A, [0, len(cb)], cb, B, [0, len(ca[0]), len(ca[0]) + len(ca[1]), len(ca[0]) + len(ca[1]) + len(ca[2])],
+                                               ca[0] + ca[1] + ca[2], **kw)
+    back = ([0], [0], [0])
+    m = one([0, 1, 2], back, max_dist=30, min_diff=1)
+    assert len(m) == 1 and (m[0]["queryIdx"], m[0]["trainIdx"], m[0]["distance"]) == (0, 0, 1.0)
+    assert len(one([0, 1, 2], back, max_dist=30, min_diff=2)) == 0                 # second - best = 1 < 2
+    assert len(one([0, 2], back, max_dist=15, min_diff=2)) == 1                    # the second candidate is beyond maxHamming: no ratio test
+    assert len(one([0, 2], back, max_dist=0, min_diff=0)) == 0                     # best must be < maxHammingDist + 1
+    assert len(one([0, 0], back, max_dist=30, min_diff=1)) == 0                    # a duplicated candidate is its own second best
+    assert len(one([0, 0], back, max_dist=30, min_diff=0)) == 1
+    assert len(one([1, 2], back, max_dist=30, min_diff=1)) == 1                    # only listed candidates are seen: B[1] wins without B[0]
+    assert len(one([0, 1, 2], ([], [0], [0]), max_dist=30, min_diff=1)) == 0       # reverse list of B[0] empty: no mutual choice
+    assert len(one([0, 1, 2], back, max_dist=30, min_diff=1, maskB=[0, 1, 1])[0:1]) == 1 and one([0, 1, 2], back, max_dist=30, min_diff=1, maskB=[0, 1, 1])[0]["trainIdx"] == 1
+    assert len(one([0, 1, 2], back, max_dist=30, min_diff=1, maskA=[0])) == 0 and len(one([0, 1, 2], back, max_dist=30, min_diff=1, maskB=[0, 0, 0])) == 0
