@@ -80,6 +80,26 @@ mage_status mage_orb_detect_batch_device(mage_orb* h, const uint8_t* images_devi
                                          int stride, size_t frame_stride, int capacity, const mage_keypoint** keypoints_device,
                                          const uint8_t** descriptors_device, const int** counts_device);
 
+/* OrbFeatureDetector::UndistortKeypoints (Image/OrbFeatureDetector.cpp:30-62): cv::undistortPoints(points, cameraMatrix,
+ * distCoeffs, noArray(), newCameraMatrix) of OpenCV 3.4.0 on the keypoint coordinates -- normalise with the distorted
+ * camera matrix, five fixed-point iterations of the inverse radial / tangential model in float64, re-project with the
+ * undistorted camera matrix, round to float32.  Matrices are row-major 3x3 (cv::Matx33f memory order); coefficients in
+ * OpenCV order k1 k2 p1 p2 k3 [k4 k5 k6], n_dist in {4, 5, 8} (the reference passes 5 for Poly3k, 8 for Rational6k:
+ * Device/CameraCalibration.cpp:110-125).  Only x and y of each keypoint change.  Thin-prism / tilt terms (12, 14
+ * coefficients) are not in the reference's calibration models and are refused. */
+typedef struct mage_undistort_params {
+    float camera_matrix[9];
+    float dist_coeffs[8];
+    int   n_dist;
+    float new_camera_matrix[9];
+} mage_undistort_params;
+/* keypoints: HOST array of `count` records, rewritten in place. */
+mage_status mage_orb_undistort_keypoints(mage_orb* h, mage_keypoint* keypoints, int count, const mage_undistort_params* params);
+/* keypoints_device / counts_device: the buffers mage_orb_detect_batch_device returned (n_frames x capacity records, n_frames counts);
+ * rewritten in place in HBM, asynchronously on the handle's stream (the next call on the handle orders after it). */
+mage_status mage_orb_undistort_keypoints_device(mage_orb* h, const mage_keypoint* keypoints_device, const int* counts_device, int n_frames,
+                                                int capacity, const mage_undistort_params* params);
+
 /* Stage outputs of the most recent single-frame / first frame of a batch, for parity tests:
  * FAST score map (width x height u8) and blurred image (width x height u8). */
 mage_status mage_orb_debug_read(mage_orb* h, uint8_t* score_map, uint8_t* blurred);

@@ -77,7 +77,7 @@ struct mage_orb {
     DevBuf<uint8_t> d_img, d_score, d_blur, d_desc;
     DevBuf<int> d_wg_count, d_wg_off, d_hist, d_n_raw, d_cell_start, d_cell_fill, d_cell_members, d_radius, d_count;
     DevBuf<int2> d_raw, d_cand;
-    DevBuf<mage_keypoint> d_kp;
+    DevBuf<mage_keypoint> d_kp, d_undist;
     hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     mage_orb_profile prof{};
     int last_w = 0, last_h = 0;
@@ -261,6 +261,58 @@ MAGE_EXPORT mage_status mage_orb_debug_read(mage_orb* h, uint8_t* score_map, uin
         MAGE_HIP(hipSetDevice(h->device));
         if (score_map) MAGE_HIP(hipMemcpy2D(score_map, w, h->d_score.p, wp, w, rows, hipMemcpyDeviceToHost));
         if (blurred) MAGE_HIP(hipMemcpy2D(blurred, w, h->d_blur.p, wp, w, rows, hipMemcpyDeviceToHost));
+        return MAGE_OK;
+    });
+}
+
+static mage_status undistort_consts(const mage_undistort_params* p, UndistortConsts* U)
+{
+    if (!p) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+    if (p->n_dist != 4 && p->n_dist != 5 && p->n_dist != 8)
+        return fail(p->n_dist == 12 || p->n_dist == 14 ? MAGE_ERR_UNSUPPORTED : MAGE_ERR_INVALID_ARGUMENT,
+                    "%d distortion coefficients: the reference's calibration models carry 5 (Poly3k) or 8 (Rational6k)", p->n_dist);
+    const double fx = (double)p->camera_matrix[0], fy = (double)p->camera_matrix[4];
+    if (!(fx != 0.0) || !(fy != 0.0)) return fail(MAGE_ERR_INVALID_ARGUMENT, "camera matrix has a zero focal length");
+    U->cx = (double)p->camera_matrix[2]; U->cy = (double)p->camera_matrix[5];
+    U->ifx = 1. / fx; U->ify = 1. / fy;
+    for (int i = 0; i < 8; ++i) U->k[i] = i < p->n_dist ? (double)p->dist_coeffs[i] : 0.0;
+    for (int i = 0; i < 9; ++i) U->RR[i] = (double)p->new_camera_matrix[i];          // P * R with R = identity
+    return MAGE_OK;
+}
+
+MAGE_EXPORT mage_status mage_orb_undistort_keypoints(mage_orb* h, mage_keypoint* keypoints, int count, const mage_undistort_params* params)
+{
+    return guarded([&]() -> mage_status {
+        if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+        UndistortConsts U;
+        MAGE_TRY(undistort_consts(params, &U));
+        if (count < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative count");
+        if (count == 0) return MAGE_OK;                                              // OrbFeatureDetector.cpp:39-42
+        if (!keypoints) return fail(MAGE_ERR_INVALID_ARGUMENT, "null buffer");
+        MAGE_HIP(hipSetDevice(h->device));
+        MAGE_TRY(h->d_undist.reserve((size_t)count));
+        MAGE_HIP(hipMemcpyAsync(h->d_undist.p, keypoints, sizeof(mage_keypoint) * (size_t)count, hipMemcpyHostToDevice, h->stream));
+        undistort_launch(h->d_undist.p, nullptr, 1, count, count, U, h->stream);
+        MAGE_HIP(hipMemcpyAsync(keypoints, h->d_undist.p, sizeof(mage_keypoint) * (size_t)count, hipMemcpyDeviceToHost, h->stream));
+        MAGE_HIP(hipStreamSynchronize(h->stream));
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_orb_undistort_keypoints_device(mage_orb* h, const mage_keypoint* keypoints_device, const int* counts_device, int n_frames,
+                                                            int capacity, const mage_undistort_params* params)
+{
+    return guarded([&]() -> mage_status {
+        if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+        UndistortConsts U;
+        MAGE_TRY(undistort_consts(params, &U));
+        if (n_frames < 0 || capacity < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative size");
+        if (n_frames == 0 || capacity == 0) return MAGE_OK;
+        if (!keypoints_device || !counts_device) return fail(MAGE_ERR_INVALID_ARGUMENT, "null buffer");
+        MAGE_HIP(hipSetDevice(h->device));
+        // the buffers belong to the handle (mage_orb_detect_batch_device hands them out as const views)
+        undistort_launch(const_cast<mage_keypoint*>(keypoints_device), counts_device, n_frames, capacity, 0, U, h->stream);
+        MAGE_HIP(hipGetLastError());
         return MAGE_OK;
     });
 }

@@ -36,6 +36,10 @@ void match_launch(int n_pairs, const uint8_t* descA, const int* countsA, int cap
                   hipStream_t st);
 
 // RadiusMatch: one (query set, target set) problem per launch.
+// cv::undistortPoints constants in float64 (camera matrix entries, 1/fx, 1/fy, k1 k2 p1 p2 k3 k4 k5 k6, P row-major)
+struct UndistortConsts { double cx, cy, ifx, ify, k[8], RR[9]; };
+void undistort_launch(mage_keypoint* kp, const int* counts, int n_frames, int capacity, int count_single, const UndistortConsts& U, hipStream_t st);
+
 void radius_match_launch(const mage_keypoint* qk, int nq, const float2* qpos, const uint8_t* qmask, const uint8_t* qdesc, const mage_keypoint* tk,
                          int nt, const uint8_t* tmask, const uint8_t* tdesc, float radius, int max_dist, int min_diff, int* scratch,
                          mage_dmatch* out, int cap, int* count, hipStream_t st);

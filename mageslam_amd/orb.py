@@ -49,6 +49,8 @@ def _declare():
     L.mage_orb_detect_batch_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.mage_orb_debug_read.argtypes = [vp, vp, vp]
     L.mage_orb_get_profile.argtypes = [vp, C.POINTER(OrbProfile)]
+    L.mage_orb_undistort_keypoints.argtypes = [vp, vp, C.c_int, C.POINTER(UndistortParams)]
+    L.mage_orb_undistort_keypoints_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(UndistortParams)]
     L.mage_hamming256.argtypes = [_u8, _u8]; L.mage_hamming256.restype = C.c_int
     L.mage_matcher_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.mage_matcher_destroy.argtypes = [vp]; L.mage_matcher_destroy.restype = None
@@ -69,6 +71,21 @@ def default_params(**kw) -> OrbParams:
     for k, v in kw.items():
         setattr(p, k, v)
     return p
+
+
+class UndistortParams(C.Structure):
+    """mage_undistort_params: camera matrix (row-major 3x3), k1 k2 p1 p2 k3 [k4 k5 k6], count, new camera matrix."""
+    _fields_ = [("camera_matrix", C.c_float * 9), ("dist_coeffs", C.c_float * 8), ("n_dist", C.c_int), ("new_camera_matrix", C.c_float * 9)]
+
+    @classmethod
+    def make(cls, K, dist, P):
+        u = cls()
+        u.camera_matrix[:] = [float(v) for v in np.asarray(K, np.float32).reshape(9)]
+        d = [float(v) for v in np.asarray(dist, np.float32).reshape(-1)]
+        u.dist_coeffs[:] = (d + [0.0] * 8)[:8]
+        u.n_dist = len(d)
+        u.new_camera_matrix[:] = [float(v) for v in np.asarray(P, np.float32).reshape(9)]
+        return u
 
 
 class OrbDetector:
@@ -113,6 +130,16 @@ class OrbDetector:
         kp, de, cn = C.c_void_p(), C.c_void_p(), C.c_void_p()
         check(self._L.mage_orb_detect_batch_device(self._h, C.c_void_p(images_ptr), n, w, h, w, w * h, cap, C.byref(kp), C.byref(de), C.byref(cn)))
         return kp.value, de.value, cn.value
+
+    def UndistortKeypoints(self, keypoints: np.ndarray, params: "UndistortParams") -> np.ndarray:
+        """OrbFeatureDetector::UndistortKeypoints (OrbFeatureDetector.cpp:30-62) on a copy of a KEYPOINT_DTYPE array."""
+        out = np.ascontiguousarray(keypoints, KEYPOINT_DTYPE).copy()
+        check(self._L.mage_orb_undistort_keypoints(self._h, out.ctypes.data_as(C.c_void_p) if len(out) else None, len(out), C.byref(params)))
+        return out
+
+    def undistort_device(self, kp_ptr: int, counts_ptr: int, n_frames: int, capacity: int, params: "UndistortParams") -> None:
+        """In place on the device buffers detect_batch_device returned."""
+        check(self._L.mage_orb_undistort_keypoints_device(self._h, C.c_void_p(kp_ptr), C.c_void_p(counts_ptr), n_frames, capacity, C.byref(params)))
 
     def debug_read(self, w: int, h: int):
         s = np.zeros((h, w), np.uint8); b = np.zeros((h, w), np.uint8)

@@ -248,3 +248,25 @@ def indexed_match(descA, cand_b, descB, cand_a, max_dist=30, min_diff=1, maskA=N
         if passes(rbest, rsecond) and rbest[2] == a:
             out.append((a, b, rbest[0]))
     return np.array(out, np.int64).reshape(-1, 3)
+
+
+def undistort_points(xy, K, dist, P, iterations=5):
+    """Independent restatement of cv::undistortPoints (OpenCV 3.4.0) for float32 points: vectorised numpy, homogeneous matrices for
+    the normalisation and the re-projection, radial terms by np.polyval -- same mathematics, different arithmetic route."""
+    xy = np.asarray(xy, np.float32).astype(np.float64)
+    K = np.asarray(K, np.float32).astype(np.float64).reshape(3, 3); P = np.asarray(P, np.float32).astype(np.float64).reshape(3, 3)
+    d = np.zeros(8); dd = np.asarray(dist, np.float32).astype(np.float64).reshape(-1); d[:len(dd)] = dd
+    k1, k2, p1, p2, k3, k4, k5, k6 = d
+    x0 = (xy[:, 0] - K[0, 2]) / K[0, 0]
+    y0 = (xy[:, 1] - K[1, 2]) / K[1, 1]
+    x, y = x0.copy(), y0.copy()
+    for _ in range(iterations):
+        r2 = x * x + y * y
+        num = np.polyval([k6, k5, k4, 1.0], r2)
+        den = np.polyval([k3, k2, k1, 1.0], r2)
+        dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        x = (x0 - dx) * num / den
+        y = (y0 - dy) * num / den
+    h = P @ np.stack([x, y, np.ones_like(x)])
+    return (h[:2] / h[2]).T.astype(np.float32)

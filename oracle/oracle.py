@@ -65,6 +65,22 @@ KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle"
 DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])   # cv::DMatch
 
 
+class UndistortParams(C.Structure):
+    """cv::undistortPoints arguments of OrbFeatureDetector::UndistortKeypoints: camera matrix (row-major 3x3), distortion
+    coefficients k1 k2 p1 p2 k3 [k4 k5 k6] (n_dist = 5 or 8, 4 also accepted), new camera matrix."""
+    _fields_ = [("K", C.c_float * 9), ("dist", C.c_float * 8), ("n_dist", C.c_int), ("P", C.c_float * 9)]
+
+    @classmethod
+    def make(cls, K, dist, P):
+        u = cls()
+        u.K[:] = [float(v) for v in np.asarray(K, np.float32).reshape(9)]
+        d = [float(v) for v in np.asarray(dist, np.float32).reshape(-1)]
+        u.dist[:] = d + [0.0] * (8 - len(d))
+        u.n_dist = len(d)
+        u.P[:] = [float(v) for v in np.asarray(P, np.float32).reshape(9)]
+        return u
+
+
 def _declare(L: C.CDLL) -> None:
     L.bao_create.restype = C.c_void_p
     L.bao_create.argtypes = [C.c_int]
@@ -115,6 +131,7 @@ def _declare(L: C.CDLL) -> None:
     L.mto_match.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.mto_radius_match.restype = C.c_int
     L.mto_radius_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_int, C.c_void_p, _u8p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.orbo_undistort_keypoints.argtypes = [C.c_void_p, C.c_int, C.POINTER(UndistortParams)]
     L.mto_indexed_match.restype = C.c_int
     L.mto_indexed_match.argtypes = [_u8p, C.c_int, C.c_void_p, _i32p, _i32p, _u8p, C.c_int, C.c_void_p, _i32p, _i32p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.bao_test_se3_exp.argtypes = [_f64p, _f64p]
@@ -317,3 +334,11 @@ def indexed_match(A, cand_b_off, cand_b, B, cand_a_off, cand_a, max_dist=30, min
                             np.ascontiguousarray(cand_a_off, np.int32), np.ascontiguousarray(cand_a, np.int32) if len(cand_a) else np.zeros(1, np.int32),
                             int(max_dist), int(min_diff), out.ctypes.data_as(C.c_void_p), len(out))
     return out[:n]
+
+
+def undistort_keypoints(kps: np.ndarray, params: "UndistortParams") -> np.ndarray:
+    """oracle/orb_oracle.c orbo_undistort_keypoints on a copy of a KEYPOINT_DTYPE array."""
+    out = np.ascontiguousarray(kps, KEYPOINT_DTYPE).copy()
+    if len(out):
+        lib().orbo_undistort_keypoints(out.ctypes.data_as(C.c_void_p), len(out), C.byref(params))
+    return out

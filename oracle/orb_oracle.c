@@ -427,3 +427,42 @@ ORBO_API int orbo_detect(const orbo_params* P, const uint8_t* img, int w, int h,
     free(pat); free(blur); free(kp);
     return ORBO_OK;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * OrbFeatureDetector::UndistortKeypoints (Image/OrbFeatureDetector.cpp:30-62):
+ *     cv::undistortPoints(points, K_distorted, distCoeffs, noArray(), K_undistorted)
+ * i.e. cvUndistortPoints of OpenCV 3.4.0 (modules/imgproc/src/undistort.cpp; OpenCV is not vendored, README pins 3.4.0):
+ * normalise with K, FIVE fixed-point iterations of the inverse distortion model in double, re-project with P = K_undistorted
+ * (R = identity), round to float.  Coefficients in OpenCV order k1 k2 p1 p2 k3 [k4 k5 k6]; the reference passes 5
+ * (Poly3k) or 8 (Rational6k) of them (Device/CameraCalibration.cpp:110-125), as float.  PARITY UNPINNED: no OpenCV here.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { float K[9]; float dist[8]; int n_dist; float P[9]; } orbo_undistort;
+ORBO_API void orbo_undistort_keypoints(orbo_keypoint* kp, int n, const orbo_undistort* U)
+{
+    double k[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int i = 0; i < U->n_dist && i < 8; ++i) k[i] = (double)U->dist[i];
+    const double fx = (double)U->K[0], fy = (double)U->K[4], cx = (double)U->K[2], cy = (double)U->K[5];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    double RR[9];
+    for (int i = 0; i < 9; ++i) RR[i] = (double)U->P[i];                   /* P * I */
+    for (int i = 0; i < n; ++i) {
+        double x = (double)kp[i].x, y = (double)kp[i].y, x0, y0;
+        x = (x - cx) * ifx;
+        y = (y - cy) * ify;
+        x0 = x; y0 = y;
+        for (int j = 0; j < 5; ++j) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        const double xx = RR[0] * x + RR[1] * y + RR[2];
+        const double yy = RR[3] * x + RR[4] * y + RR[5];
+        const double ww = 1. / (RR[6] * x + RR[7] * y + RR[8]);
+        kp[i].x = (float)(xx * ww);
+        kp[i].y = (float)(yy * ww);
+    }
+}

@@ -201,3 +201,46 @@ def test_indexed_match_golden_and_oracle(gold):
     bad = ix["cand_b"].copy(); bad[3] = len(db)
     with pytest.raises(MageError):
         mt.IndexedMatch(da, ix["cand_b_off"], bad, db, ix["cand_a_off"], ix["cand_a"], 30, 1)
+
+
+def test_undistort_keypoints_golden_oracle_and_device_path(gold):
+    """"next" row ORB-10: UndistortKeypoints.  Bit-exact against the fixture and the oracle; the device-resident form applied to
+    the extractor's batch output equals the host form applied to the same keypoints; argument checks."""
+    import os
+    from mageslam_amd._lib import MageError
+    from mageslam_amd.orb import UndistortParams
+    u = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_undistort.npz"))
+    det = OrbDetector()
+    k = np.zeros(len(u["xy"]), O.KEYPOINT_DTYPE)
+    k["x"], k["y"], k["size"], k["response"], k["class_id"] = u["xy"][:, 0], u["xy"][:, 1], 15, 40, -1
+    for model in ("poly3k", "rational6k"):
+        par = UndistortParams.make(u["K"], u["dist_" + model], u["P"])
+        g = det.UndistortKeypoints(k, par)
+        assert np.array_equal(np.stack([g["x"], g["y"]], 1), u["exp_" + model])
+        assert np.array_equal(g, O.undistort_keypoints(k, O.UndistortParams.make(u["K"], u["dist_" + model], u["P"])))
+    assert len(det.UndistortKeypoints(k[:0], par)) == 0
+    with pytest.raises(MageError):
+        det.UndistortKeypoints(k, UndistortParams.make(u["K"], np.zeros(12), u["P"]))        # thin-prism terms: not in the reference's models
+    with pytest.raises(MageError):
+        det.UndistortKeypoints(k, UndistortParams.make(np.zeros(9), u["dist_poly3k"], u["P"]))
+    # device-resident chain: detect a batch, undistort it in HBM, read the buffer back (plain HIP runtime calls through ctypes)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    cap = int(det.params.nfeatures)
+    imgs = np.ascontiguousarray(np.stack([gold["orb_640x480_a_img"], gold["orb_640x480_b_img"]]))
+    kp_host, _, cnt = det.DetectAndComputeBatch(imgs)
+    exp = [det.UndistortKeypoints(kp_host[f, : cnt[f]], par) for f in range(2)]
+    d_img = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d_img), imgs.nbytes) == 0
+    assert hip.hipMemcpy(d_img, imgs.ctypes.data_as(ctypes.c_void_p), imgs.nbytes, 1) == 0                      # 1 = hipMemcpyHostToDevice
+    kp_ptr, _, cn_ptr = det.detect_batch_device(d_img.value, 2, 640, 480)
+    det.undistort_device(kp_ptr, cn_ptr, 2, cap, par)
+    assert hip.hipDeviceSynchronize() == 0
+    got = np.zeros((2, cap), O.KEYPOINT_DTYPE)
+    assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(kp_ptr), got.nbytes, 2) == 0      # 2 = hipMemcpyDeviceToHost
+    hip.hipFree(d_img)
+    for f in range(2):
+        assert np.array_equal(got[f, : cnt[f]], exp[f])

@@ -208,3 +208,41 @@ def test_indexed_match_semantics():
     assert len(one([0, 1, 2], ([], [0], [0]), max_dist=30, min_diff=1)) == 0       # reverse list of B[0] empty: no mutual choice
     assert len(one([0, 1, 2], back, max_dist=30, min_diff=1, maskB=[0, 1, 1])[0:1]) == 1 and one([0, 1, 2], back, max_dist=30, min_diff=1, maskB=[0, 1, 1])[0]["trainIdx"] == 1
     assert len(one([0, 1, 2], back, max_dist=30, min_diff=1, maskA=[0])) == 0 and len(one([0, 1, 2], back, max_dist=30, min_diff=1, maskB=[0, 0, 0])) == 0
+
+
+UNDISTORT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_undistort.npz")
+
+
+@pytest.mark.parametrize("model", ["poly3k", "rational6k"])
+def test_undistort_keypoints_oracle_matches_golden(model):
+    """UndistortKeypoints ("next" row ORB-10): cv::undistortPoints restated; fixture from the independent numpy version.
+    float32 results must be identical (both sides compute in float64 and round once)."""
+    u = np.load(UNDISTORT)
+    k = np.zeros(len(u["xy"]), O.KEYPOINT_DTYPE)
+    k["x"], k["y"], k["size"], k["response"], k["octave"], k["class_id"] = u["xy"][:, 0], u["xy"][:, 1], 15, 33, 0, -1
+    o = O.undistort_keypoints(k, O.UndistortParams.make(u["K"], u["dist_" + model], u["P"]))
+    assert np.array_equal(np.stack([o["x"], o["y"]], 1), u["exp_" + model])
+    for f in ("size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(o[f], k[f])                      # only the coordinates change
+
+
+def test_undistort_known_answers():
+    """Zero distortion = the affine map P K^-1; the principal point maps to the new principal point whatever the coefficients;
+    undistorting a point distorted with the forward model returns it (5 iterations converge for mild distortion)."""
+    K = np.array([[500, 0, 320], [0, 500, 240], [0, 0, 1]], np.float32); P = np.array([[400, 0, 300], [0, 400, 250], [0, 0, 1]], np.float32)
+    k = np.zeros(3, O.KEYPOINT_DTYPE)
+    k["x"], k["y"] = [320, 420, 70], [240, 140, 400]
+    o = O.undistort_keypoints(k, O.UndistortParams.make(K, [0, 0, 0, 0, 0], P))
+    np.testing.assert_allclose(o["x"], (k["x"] - 320) * 0.8 + 300, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(o["y"], (k["y"] - 240) * 0.8 + 250, rtol=0, atol=1e-4)
+    o = O.undistort_keypoints(k[:1], O.UndistortParams.make(K, [-0.3, 0.1, 1e-3, -1e-3, 0.02, 0.1, 0.0, 0.0], P))
+    assert (o["x"][0], o["y"][0]) == (300.0, 250.0)
+    dist = np.array([-0.12, 0.03, 5e-4, -3e-4, 0.0])
+    xn = np.array([[0.31, -0.22], [-0.4, 0.18], [0.05, 0.45]])                       # ideal normalised points
+    r2 = (xn ** 2).sum(1)
+    rad = 1 + dist[0] * r2 + dist[1] * r2 ** 2 + dist[4] * r2 ** 3
+    xd = xn[:, 0] * rad + 2 * dist[2] * xn[:, 0] * xn[:, 1] + dist[3] * (r2 + 2 * xn[:, 0] ** 2)
+    yd = xn[:, 1] * rad + dist[2] * (r2 + 2 * xn[:, 1] ** 2) + 2 * dist[3] * xn[:, 0] * xn[:, 1]
+    k["x"], k["y"] = xd * 500 + 320, yd * 500 + 240
+    o = O.undistort_keypoints(k, O.UndistortParams.make(K, dist, P))
+    np.testing.assert_allclose(np.stack([o["x"], o["y"]], 1), xn * 400 + [300, 250], atol=2e-2)
