@@ -493,10 +493,18 @@ mage_status initialize_optimization(mage_ba* h)
     return MAGE_OK;
 }
 
+// The LM control flow needs three scalars on the host per trial; the GPU idles while they travel.  A blocking
+// hipStreamSynchronize parks the thread and costs 20-30 us of wake-up latency per read, so the host polls the event instead
+// (the step is a few milliseconds: spinning that long is the cheaper side of the trade).
 mage_status read_scalars(mage_ba* h)
 {
     MAGE_HIP(hipMemcpyAsync(h->h_scal, h->d_scal.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    MAGE_HIP(hipStreamSynchronize(h->stream));
+    MAGE_HIP(hipEventRecord(h->ev[3], h->stream));
+    for (;;) {
+        const hipError_t e = hipEventQuery(h->ev[3]);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) MAGE_HIP(e);
+    }
     return MAGE_OK;
 }
 

@@ -214,3 +214,24 @@ def test_global_size_properties_and_one_iteration_vs_oracle():
     for _ in range(6):
         g2.StepBundleAdjustment([1.8], 1e30, out)
     assert np.array_equal(g1.poses_f64(), g2.poses_f64()) and np.array_equal(g1.points_f64(), g2.points_f64())
+
+
+def test_cpp_shim_compiles_links_and_runs(tmp_path):
+    """include/BundlerLib.h (the reference's class name and methods over the C ABI): tools/shim_example.cpp builds with the
+    host compiler alone, links the shared library and optimises a toy stereo problem with two tethers."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        pytest.skip("no host C++ compiler")
+    exe = str(tmp_path / "shim_example")
+    lib_dir = os.path.join(root, "mageslam_amd")
+    subprocess.run([cxx, "-std=c++17", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "shim_example.cpp"),
+                    "-L" + lib_dir, "-lmageslam_hip", "-Wl,-rpath," + lib_dir, "-o", exe], check=True, capture_output=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("mse ") and "outliers" in r.stdout
+    mse = float(r.stdout.split()[1])
+    assert 0.0 <= mse < 1.0                      # three views of four points, 0.3 px of synthetic offset
