@@ -449,17 +449,31 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ img, i
 #pragma unroll
     for (int t = 0; t < 2 * MAXR + 1; ++t) tp[t] = t <= 2 * r ? taps.t[t] : 0;
     // horizontal pass for every staged row
-    for (int e = threadIdx.x; e < sh * BT_W; e += 256) {
-        const int ty = e / BT_W, tx = e % BT_W;
-        const uint8_t* sp = &src[ty * SP + 8 - r + tx];
-        int acc = 0;
-        if (r == 3) {
-#pragma unroll
-            for (int t = 0; t < 7; ++t) acc = (__mul24(tp[t], (int)sp[t]) + acc);
-        } else {
-            for (int t = 0; t <= 2 * r; ++t) acc = (__mul24(taps.t[t], (int)sp[t]) + acc);
+    if (r == 3 && taps.t[3] < 256) {
+        // 7 taps (all <= 255): four outputs per thread from three aligned 32-bit LDS reads; each output is two 4-way byte dot
+        // products (v_dot4_u32_u8) over windows cut out of the 12 bytes with v_alignbyte -- 17 operations for 4 pixels
+        // where the byte-at-a-time form issued 28 LDS reads and 56 multiply-adds.
+        const uint32_t T0 = (uint32_t)tp[0] | ((uint32_t)tp[1] << 8) | ((uint32_t)tp[2] << 16) | ((uint32_t)tp[3] << 24);
+        const uint32_t T1 = (uint32_t)tp[4] | ((uint32_t)tp[5] << 8) | ((uint32_t)tp[6] << 16);
+        for (int e = threadIdx.x; e < sh * (BT_W / 4); e += 256) {
+            const int ty = e / (BT_W / 4), tq = e % (BT_W / 4);
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(&src[ty * SP + 4 + 4 * tq]);      // bytes o .. o+11, o = 4 + 4 tq; output j starts at o + 1 + j
+            const uint32_t A = sp[0], B = sp[1], C = sp[2];
+            int4 o;
+            o.x = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 1), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 1), T0, 0u, false), false);
+            o.y = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 2), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 2), T0, 0u, false), false);
+            o.z = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 3), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 3), T0, 0u, false), false);
+            o.w = (int)__builtin_amdgcn_udot4(C, T1, __builtin_amdgcn_udot4(B, T0, 0u, false), false);
+            *reinterpret_cast<int4*>(&hrow[ty * BT_W + 4 * tq]) = o;
         }
-        hrow[ty * BT_W + tx] = acc;
+    } else {
+        for (int e = threadIdx.x; e < sh * BT_W; e += 256) {
+            const int ty = e / BT_W, tx = e % BT_W;
+            const uint8_t* sp = &src[ty * SP + 8 - r + tx];
+            int acc = 0;
+            for (int t = 0; t <= 2 * r; ++t) acc = (__mul24(taps.t[t], (int)sp[t]) + acc);
+            hrow[ty * BT_W + tx] = acc;
+        }
     }
     __syncthreads();
     // vertical pass, 4 pixels per thread, one 32-bit store
