@@ -96,28 +96,79 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
 {
     constexpr int TW = FT_W + 8, TH = FT_H + 2 * HALO, TP = TW;      // window starts 4 pixels left of the tile (aligned), halo 3 used
     __shared__ __attribute__((aligned(4))) uint8_t tile[TH * TP];
+    __shared__ __attribute__((aligned(4))) uint8_t sc[FT_W * FT_H];  // scores of the tile
+    __shared__ uint16_t cand[FT_W * FT_H];                           // pixels that survive the compass test
+    __shared__ int n_cand;
     const int f = blockIdx.z;
     const uint8_t* I = img + (size_t)f * frame_stride;
     uint8_t* Sc = score + (size_t)f * wp * h;
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    if (threadIdx.x == 0) n_cand = 0;
     stage_window<TW, TH, TP, false>(tile, I, w, h, stride, x0 - 4, y0 - HALO, TW, TH);
     __syncthreads();
+    // Phase 1, every pixel: the compass test.  Any arc of 9 contiguous ring pixels contains two NEIGHBOURING compass points
+    // (ring positions 0, 4, 8, 12), so a corner needs two neighbouring compass pixels both darker or both brighter than the
+    // centre by more than the threshold -- a necessary condition costing 4 ring pixels.  Survivors (a few per cent to ~20 %)
+    // are appended to an LDS list; the full 16-pixel score is then computed on the compacted list, where every lane of a
+    // wavefront has real work (evaluated in place, one passing lane made all 64 pay for the expensive part).
     // thread -> quads of 4 horizontally adjacent pixels: 16 quads per tile row, 32 rows = 512 quads, 2 per thread
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int qi = threadIdx.x + 256 * i;
+        const int ly = qi / (FT_W / 4), lq = qi % (FT_W / 4);
+        const int y = y0 + ly, xq = x0 + 4 * lq;
+        *reinterpret_cast<uint32_t*>(&sc[ly * FT_W + 4 * lq]) = 0u;
+        const bool row_ok = y >= 3 && y < h - 3 && xq < wp;
+        uint32_t up = 0, dn = 0, m0 = 0, m1 = 0, m2 = 0;
+        if (row_ok) {
+            up = *reinterpret_cast<const uint32_t*>(&tile[(ly + HALO + 3) * TP + 4 + 4 * lq]);        // row y + 3, columns xq .. xq+3  (ring 0)
+            dn = *reinterpret_cast<const uint32_t*>(&tile[(ly + HALO - 3) * TP + 4 + 4 * lq]);        // row y - 3                      (ring 8)
+            const uint32_t* mp = reinterpret_cast<const uint32_t*>(&tile[(ly + HALO) * TP + 4 * lq]); // row y, columns xq-4 .. xq+7
+            m0 = mp[0]; m1 = mp[1]; m2 = mp[2];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            bool pass = false;
+            const int x = xq + b;
+            if (row_ok && x >= 3 && x < w - 3) {
+                auto byte_of = [&](int idx) -> int { const uint32_t r = idx < 4 ? m0 : (idx < 8 ? m1 : m2); return (int)((r >> (8 * (idx & 3))) & 0xffu); };
+                const int v = byte_of(4 + b);
+                const int d0 = v - (int)((up >> (8 * b)) & 0xffu);      // (0, +3)
+                const int d4 = v - byte_of(4 + b + 3);                  // (+3, 0)
+                const int d8 = v - (int)((dn >> (8 * b)) & 0xffu);      // (0, -3)
+                const int d12 = v - byte_of(4 + b - 3);                 // (-3, 0)
+                const int t = threshold;
+                const bool k0 = d0 > t, k4 = d4 > t, k8 = d8 > t, k12 = d12 > t;
+                const bool b0 = d0 < -t, b4 = d4 < -t, b8 = d8 < -t, b12 = d12 < -t;
+                pass = (k0 && k4) || (k4 && k8) || (k8 && k12) || (k12 && k0) || (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0);
+            }
+            const unsigned long long bal = __ballot(pass);
+            if (bal) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&n_cand, __popcll(bal));
+                base = __shfl(base, 0, 64);
+                if (pass) cand[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(ly * FT_W + 4 * lq + b);
+            }
+        }
+    }
+    __syncthreads();
+    // Phase 2: exact score of the survivors
+    const int nc = n_cand;
+    for (int c = threadIdx.x; c < nc; c += 256) {
+        const int p = cand[c];
+        const int ly = p / FT_W, lx = p % FT_W;
+        sc[p] = (uint8_t)fast_score_at(&tile[(ly + HALO) * TP + 4 + lx], TP, threshold);
+    }
+    __syncthreads();
+    // Phase 3: one 32-bit store per quad
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int qi = threadIdx.x + 256 * i;
         const int ly = qi / (FT_W / 4), lq = qi % (FT_W / 4);
         const int y = y0 + ly, xq = x0 + 4 * lq;
         if (y >= h || xq >= wp) continue;
-        uint32_t packed = 0;
-        if (y >= 3 && y < h - 3) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int x = xq + b;
-                if (x >= 3 && x < w - 3) packed |= (uint32_t)fast_score_at(&tile[(ly + HALO) * TP + 4 + 4 * lq + b], TP, threshold) << (8 * b);
-            }
-        }
-        *reinterpret_cast<uint32_t*>(Sc + (size_t)y * wp + xq) = packed;
+        *reinterpret_cast<uint32_t*>(Sc + (size_t)y * wp + xq) = *reinterpret_cast<const uint32_t*>(&sc[ly * FT_W + 4 * lq]);
     }
 }
 
