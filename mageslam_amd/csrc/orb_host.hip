@@ -132,7 +132,7 @@ MAGE_EXPORT void mage_orb_destroy(mage_orb* h) { delete h; }
 
 namespace {
 
-constexpr int NMS_ROWS = 8;
+constexpr int NMS_ROWS = 32;
 
 // runs the five stages on n_frames images that are already in HBM; leaves keypoints / descriptors / counts in HBM
 mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w, int h_img, int stride, size_t frame_stride, int capacity)

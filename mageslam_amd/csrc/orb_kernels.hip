@@ -221,11 +221,23 @@ __global__ __launch_bounds__(256) void k_nms_count(const uint8_t* __restrict__ s
     const int y1 = min(y0 + rows_per_wg, h);
     const int qpr = wp / 4;
     int c = 0;
-    for (int q = y0 * qpr + tid; q < y1 * qpr; q += 256) {
-        int resp[4];
-        const int m = nms_quad(Sc, w, h, wp, 4 * (q % qpr), q / qpr, border, resp);
+    // four consecutive quads (16 score bytes, one 128-bit load) per thread and iteration: the map is almost everywhere zero,
+    // so the pass is one wide coalesced read plus rare neighbourhood tests
+    const int q_end = y1 * qpr;
+    for (int q0 = y0 * qpr + 4 * tid; q0 < q_end; q0 += 1024) {
+        uint32_t c4[4] = { 0, 0, 0, 0 };
+        if (q0 + 3 < q_end) { const uint4 v = *reinterpret_cast<const uint4*>(Sc + (size_t)q0 * 4); c4[0] = v.x; c4[1] = v.y; c4[2] = v.z; c4[3] = v.w; }
+        else for (int j = 0; j < 4; ++j) if (q0 + j < q_end) c4[j] = *reinterpret_cast<const uint32_t*>(Sc + (size_t)(q0 + j) * 4);
+        if ((c4[0] | c4[1] | c4[2] | c4[3]) == 0u) continue;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) if (m & (1 << b)) { ++c; atomicAdd(&lh[resp[b]], 1); }
+        for (int j = 0; j < 4; ++j) {
+            if (c4[j] == 0u) continue;
+            const int q = q0 + j;
+            int resp[4];
+            const int m = nms_quad(Sc, w, h, wp, 4 * (q % qpr), q / qpr, border, resp);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) if (m & (1 << b)) { ++c; atomicAdd(&lh[resp[b]], 1); }
+        }
     }
     atomicAdd(&cnt, c);
     __syncthreads();
@@ -263,12 +275,24 @@ __global__ __launch_bounds__(256) void k_nms_emit(const uint8_t* __restrict__ sc
     const int y0 = blockIdx.x * rows_per_wg;
     const int y1 = min(y0 + rows_per_wg, h);
     const int qpr = wp / 4;
-    for (int q0 = y0 * qpr; q0 < y1 * qpr; q0 += 256) {
-        const int q = q0 + tid;
-        int m = 0, resp[4] = { 0, 0, 0, 0 }, xq = 0, y = 0;
-        if (q < y1 * qpr) { xq = 4 * (q % qpr); y = q / qpr; m = nms_quad(Sc, w, h, wp, xq, y, border, resp); }
-        const int mine = __popc(m);
-        // exclusive prefix of `mine` over the wavefront (thread order = raster order of the quads)
+    const int q_end = y1 * qpr;
+    for (int qb = y0 * qpr; qb < q_end; qb += 1024) {
+        const int q0 = qb + 4 * tid;                 // this thread's four consecutive quads (thread order = raster order)
+        uint32_t c4[4] = { 0, 0, 0, 0 };
+        if (q0 + 3 < q_end) { const uint4 v = *reinterpret_cast<const uint4*>(Sc + (size_t)q0 * 4); c4[0] = v.x; c4[1] = v.y; c4[2] = v.z; c4[3] = v.w; }
+        else for (int j = 0; j < 4; ++j) if (q0 + j < q_end) c4[j] = *reinterpret_cast<const uint32_t*>(Sc + (size_t)(q0 + j) * 4);
+        int m[4] = { 0, 0, 0, 0 }, resp[4][4];
+        int mine = 0;
+        if ((c4[0] | c4[1] | c4[2] | c4[3]) != 0u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (c4[j] == 0u) continue;
+                const int q = q0 + j;
+                m[j] = nms_quad(Sc, w, h, wp, 4 * (q % qpr), q / qpr, border, resp[j]);
+                mine += __popc(m[j]);
+            }
+        }
+        // exclusive prefix of `mine` over the wavefront
         int incl = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -276,8 +300,15 @@ __global__ __launch_bounds__(256) void k_nms_emit(const uint8_t* __restrict__ sc
         __syncthreads();
         int off = base_s + incl - mine;
         for (int w2 = 0; w2 < wave; ++w2) off += wave_cnt[w2];
+        if (mine) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) if (m & (1 << b)) out[off++] = make_int2((xq + b) | (y << 16), resp[b]);
+            for (int j = 0; j < 4; ++j) {
+                if (!m[j]) continue;
+                const int q = q0 + j, xq = 4 * (q % qpr), y = q / qpr;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) if (m[j] & (1 << b)) out[off++] = make_int2((xq + b) | (y << 16), resp[j][b]);
+            }
+        }
         __syncthreads();
         if (tid == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         __syncthreads();
