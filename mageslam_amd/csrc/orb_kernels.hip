@@ -341,6 +341,12 @@ __global__ __launch_bounds__(1024) void k_select(OrbSelectArgs a)
     __shared__ int s_cut;
     __shared__ int s_minX, s_maxX, s_minY, s_maxY, s_minS;
     const int f = blockIdx.x, tid = threadIdx.x;
+    // Working set of the suppression (candidates, cell index, radii): in LDS whenever it fits -- the ring search chases
+    // cell -> member -> candidate, three dependent reads per visited point, and is pure latency when they go to L2.
+    constexpr int SEL_CAP = 2048, SEL_CELLS = 1024;
+    __shared__ int2 l_cand[SEL_CAP];
+    __shared__ int l_cellcnt[SEL_CELLS + 1], l_cellfill[SEL_CELLS + 1], l_cellmem[SEL_CAP], l_rad[SEL_CAP];
+    __shared__ int s_M;
     const int2* raw = a.raw + (size_t)f * a.raw_cap;
     int2* cand = a.cand + (size_t)f * a.raw_cap;
     int* cellcnt = a.cell_start + (size_t)f * (a.ncells + 1);
@@ -360,23 +366,34 @@ __global__ __launch_bounds__(1024) void k_select(OrbSelectArgs a)
         if (tid == 0) a.out_count[f] = n;
         return;
     }
-    // ---- RetainBestFeatures: whole histogram bins from 255 downwards
+    // ---- RetainBestFeatures: whole histogram bins from 255 downwards.  suffix[i] = number of responses >= i, by a parallel
+    // scan (a single thread walking the 256 bins three times cost ~45 us of dependent LDS reads per frame); the two
+    // thresholds of OpenCVModified.cpp:571-617 are then "largest bin whose suffix count reaches the quota".
+    __shared__ int s_mnt;
     if (tid < 256) lhist[tid] = a.hist[f * 256 + tid];
+    if (tid == 0) { s_mnt = -1; s_cut = -1; s_minX = 1 << 30; s_maxX = -1; s_minY = 1 << 30; s_maxY = -1; s_minS = 1 << 30; }
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {                      // Hillis-Steele suffix sum over 256 bins
+        int v = 0;
+        if (tid < 256) v = lhist[tid] + (tid + o < 256 ? lhist[tid + o] : 0);
+        __syncthreads();
+        if (tid < 256) lhist[tid] = v;
+        __syncthreads();
+    }
+    const int min_thr = a.fast_threshold;
+    if (tid < 256 && tid >= min_thr && lhist[tid] >= a.nfeatures) atomicMax(&s_mnt, tid);
+    __syncthreads();
+    const int mnt = s_mnt >= 0 ? s_mnt : min_thr;
+    const int lower = max((int)__fmul_rn((float)mnt, a.feature_strength), min_thr);
+    if (tid < 256 && tid >= lower && lhist[tid] >= a.max_num) atomicMax(&s_cut, tid);
     __syncthreads();
     if (tid == 0) {
-        const int* hist = lhist;
-        const int min_thr = a.fast_threshold;
-        int mnt = min_thr, num = 0;
-        for (int i = 255; i >= min_thr; --i) { num += hist[i]; if (num >= a.nfeatures) { mnt = i; break; } }
-        const int lower = max((int)__fmul_rn((float)mnt, a.feature_strength), min_thr);
-        int cut = lower;
-        num = 0;
-        for (int i = 255; i >= lower; --i) { num += hist[i]; if (num >= a.max_num) { cut = i; break; } }
-        s_cut = cut;
-        s_minX = 1 << 30; s_maxX = -1; s_minY = 1 << 30; s_maxY = -1; s_minS = 1 << 30;
+        if (s_cut < 0) s_cut = lower;
+        s_M = s_cut < 256 ? lhist[s_cut] : 0;                // how many candidates the compaction below will keep
     }
     __syncthreads();
     const int cut = s_cut;
+    if (s_M <= SEL_CAP && a.ncells <= SEL_CELLS) { cand = l_cand; cellcnt = l_cellcnt; cellfill = l_cellfill; cellmem = l_cellmem; rad = l_rad; }
     int mbase = 0;
     for (int i0 = 0; i0 < n_raw; i0 += 1024) {          // ordered compaction (raster order is kept: choice C1)
         const int i = i0 + tid;
@@ -385,11 +402,18 @@ __global__ __launch_bounds__(1024) void k_select(OrbSelectArgs a)
         const int keep = (i < n_raw && r.y >= cut) ? 1 : 0;
         int tot;
         const int off = block_scan_excl(keep, sh, tot);
-        if (keep) {
-            cand[mbase + off] = r;
-            atomicMin(&s_minX, r.x & 0xffff); atomicMax(&s_maxX, r.x & 0xffff);
-            atomicMin(&s_minY, r.x >> 16); atomicMax(&s_maxY, r.x >> 16);
-            atomicMin(&s_minS, r.y);
+        if (keep) cand[mbase + off] = r;
+        {   // bounding box and weakest response: reduce inside the wavefront first, one LDS atomic per wavefront and quantity
+            int mnx = keep ? (r.x & 0xffff) : (1 << 30), mxx = keep ? (r.x & 0xffff) : -1;
+            int mny = keep ? (r.x >> 16) : (1 << 30), mxy = keep ? (r.x >> 16) : -1, mns = keep ? r.y : (1 << 30);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                mnx = min(mnx, __shfl_xor(mnx, o, 64)); mxx = max(mxx, __shfl_xor(mxx, o, 64));
+                mny = min(mny, __shfl_xor(mny, o, 64)); mxy = max(mxy, __shfl_xor(mxy, o, 64)); mns = min(mns, __shfl_xor(mns, o, 64));
+            }
+            if ((tid & 63) == 0 && mxx >= 0) {
+                atomicMin(&s_minX, mnx); atomicMax(&s_maxX, mxx); atomicMin(&s_minY, mny); atomicMax(&s_maxY, mxy); atomicMin(&s_minS, mns);
+            }
         }
         mbase += tot;
         __syncthreads();
@@ -408,95 +432,121 @@ __global__ __launch_bounds__(1024) void k_select(OrbSelectArgs a)
         if (tid == 0) a.out_count[f] = n;
         return;
     }
-    // ---- AdaptiveNonMaximalSuppresion
-    const int minX = s_minX, maxX = s_maxX, minY = s_minY, maxY = s_maxY;
-    const int numX = a.cells_x, numY = a.cells_y, thr = a.fast_threshold;
-    float rf;
-    {
-        const float hi = __fsub_rn((float)a.strong_response, (float)thr);
-        float val = __fsub_rn((float)s_minS, (float)thr);
-        val = val < 0.0f ? 0.0f : (val > hi ? hi : val);
-        float range = __fsub_rn(a.max_robust, a.min_robust);
-        if (range < 0.0f) range = 0.0f;
-        rf = __fsub_rn(a.max_robust, __fmul_rn(__fdiv_rn(val, (float)(a.strong_response - thr)), range));
-    }
-    for (int c = tid; c <= a.ncells; c += 1024) { cellcnt[c] = 0; cellfill[c] = 0; }
-    __syncthreads();
-    for (int i = tid; i < M; i += 1024) {
-        const int2 r = cand[i];
-        const int cx = ((r.x & 0xffff) - minX) * numX / (maxX + 1 - minX), cy = ((r.x >> 16) - minY) * numY / (maxY + 1 - minY);
-        atomicAdd(&cellcnt[cy * numX + cx + 1], 1);
-    }
-    __syncthreads();
-    {   // cell_start = inclusive scan of the counts, in place: thread t owns cells [t*per, (t+1)*per)
-        const int per = (a.ncells + 1023) / 1024;
-        const int c0 = tid * per, c1 = min(c0 + per, a.ncells);
-        int local = 0;
-        for (int c = c0; c < c1; ++c) local += cellcnt[c + 1];
-        int tot;
-        int run = block_scan_excl(local, sh, tot);
-        for (int c = c0; c < c1; ++c) { run += cellcnt[c + 1]; cellcnt[c + 1] = run; }
-    }
-    __threadfence_block();
-    __syncthreads();
-    for (int i = tid; i < M; i += 1024) {
-        const int2 r = cand[i];
-        const int cx = ((r.x & 0xffff) - minX) * numX / (maxX + 1 - minX), cy = ((r.x >> 16) - minY) * numY / (maxY + 1 - minY);
-        const int c = cy * numX + cx;
-        cellmem[cellcnt[c] + atomicAdd(&cellfill[c], 1)] = i;     // member order inside a cell does not affect a minimum
-    }
-    __threadfence_block();
-    __syncthreads();
-    const int globalMaxR2 = (int)(((double)(maxX - minX)) * ((double)(maxY - minY)) / (double)N);
-    int minCellDelta2;
-    {
-        const int dx = max((maxX - minX) / numX, 1), dy = max((maxY - minY) / numY, 1);
-        const int m = min(dx, dy);
-        minCellDelta2 = m * m;
-    }
-    for (int i = tid; i < M; i += 1024) {
-        const int2 r = cand[i];
-        const int x = r.x & 0xffff, y = r.x >> 16;
-        const int cx = (x - minX) * numX / (maxX + 1 - minX), cy = (y - minY) * numY / (maxY + 1 - minY);
-        const float strength = (float)r.y;
-        const float s = __fadd_rn(__fmul_rn(strength, rf), 0.002f);          // strength >= 0 always (FAST score)
-        int minR2 = globalMaxR2;
-        for (int d = 0; max(0, d - 1) * max(0, d - 1) * minCellDelta2 < minR2; ++d)
-            for (int yy = -d; yy <= d; ++yy) {
-                const int cYY = yy + cy;
-                if (cYY < 0 || cYY >= numY) continue;
-                for (int xx = -d; xx <= d; ++xx) {
-                    const int cXX = xx + cx;
-                    if (cXX < 0 || cXX >= numX || max(abs(xx), abs(yy)) != d) continue;
-                    const int c = cYY * numX + cXX;
-                    for (int q = cellcnt[c]; q < cellcnt[c + 1]; ++q) {
-                        const int2 o = cand[cellmem[q]];
-                        if ((float)o.y > s) {
-                            const int ddx = x - (o.x & 0xffff), ddy = y - (o.x >> 16);
-                            const int rr = ddx * ddx + ddy * ddy;
-                            if (rr < minR2) minR2 = rr;
+    // The rest runs twice in the source: once on the LDS arrays (address space known to the compiler: ds_read / ds_write) and
+    // once, for oversized inputs, on the global scratch.
+    const bool in_lds = cand == l_cand;
+    auto suppress_and_rank = [&](int2* cand, int* cellcnt, int* cellfill, int* cellmem, int* rad) {
+        // ---- AdaptiveNonMaximalSuppresion
+        const int minX = s_minX, maxX = s_maxX, minY = s_minY, maxY = s_maxY;
+        const int numX = a.cells_x, numY = a.cells_y, thr = a.fast_threshold;
+        float rf;
+        {
+            const float hi = __fsub_rn((float)a.strong_response, (float)thr);
+            float val = __fsub_rn((float)s_minS, (float)thr);
+            val = val < 0.0f ? 0.0f : (val > hi ? hi : val);
+            float range = __fsub_rn(a.max_robust, a.min_robust);
+            if (range < 0.0f) range = 0.0f;
+            rf = __fsub_rn(a.max_robust, __fmul_rn(__fdiv_rn(val, (float)(a.strong_response - thr)), range));
+        }
+        for (int c = tid; c <= a.ncells; c += 1024) { cellcnt[c] = 0; cellfill[c] = 0; }
+        __syncthreads();
+        for (int i = tid; i < M; i += 1024) {
+            const int2 r = cand[i];
+            const int cx = ((r.x & 0xffff) - minX) * numX / (maxX + 1 - minX), cy = ((r.x >> 16) - minY) * numY / (maxY + 1 - minY);
+            atomicAdd(&cellcnt[cy * numX + cx + 1], 1);
+        }
+        __syncthreads();
+        {   // cell_start = inclusive scan of the counts, in place: thread t owns cells [t*per, (t+1)*per)
+            const int per = (a.ncells + 1023) / 1024;
+            const int c0 = tid * per, c1 = min(c0 + per, a.ncells);
+            int local = 0;
+            for (int c = c0; c < c1; ++c) local += cellcnt[c + 1];
+            int tot;
+            int run = block_scan_excl(local, sh, tot);
+            for (int c = c0; c < c1; ++c) { run += cellcnt[c + 1]; cellcnt[c + 1] = run; }
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int i = tid; i < M; i += 1024) {
+            const int2 r = cand[i];
+            const int cx = ((r.x & 0xffff) - minX) * numX / (maxX + 1 - minX), cy = ((r.x >> 16) - minY) * numY / (maxY + 1 - minY);
+            const int c = cy * numX + cx;
+            cellmem[cellcnt[c] + atomicAdd(&cellfill[c], 1)] = i;     // member order inside a cell does not affect a minimum
+        }
+        __threadfence_block();
+        __syncthreads();
+        const int globalMaxR2 = (int)(((double)(maxX - minX)) * ((double)(maxY - minY)) / (double)N);
+        int minCellDelta2;
+        {
+            const int dx = max((maxX - minX) / numX, 1), dy = max((maxY - minY) / numY, 1);
+            const int m = min(dx, dy);
+            minCellDelta2 = m * m;
+        }
+        for (int i = tid; i < M; i += 1024) {
+            const int2 r = cand[i];
+            const int x = r.x & 0xffff, y = r.x >> 16;
+            const int cx = (x - minX) * numX / (maxX + 1 - minX), cy = (y - minY) * numY / (maxY + 1 - minY);
+            const float strength = (float)r.y;
+            const float s = __fadd_rn(__fmul_rn(strength, rf), 0.002f);          // strength >= 0 always (FAST score)
+            int minR2 = globalMaxR2;
+            for (int d = 0; max(0, d - 1) * max(0, d - 1) * minCellDelta2 < minR2; ++d)
+                for (int yy = -d; yy <= d; ++yy) {
+                    const int cYY = yy + cy;
+                    if (cYY < 0 || cYY >= numY) continue;
+                    for (int xx = -d; xx <= d; ++xx) {
+                        const int cXX = xx + cx;
+                        if (cXX < 0 || cXX >= numX || max(abs(xx), abs(yy)) != d) continue;
+                        const int c = cYY * numX + cXX;
+                        for (int q = cellcnt[c]; q < cellcnt[c + 1]; ++q) {
+                            const int2 o = cand[cellmem[q]];
+                            if ((float)o.y > s) {
+                                const int ddx = x - (o.x & 0xffff), ddy = y - (o.x >> 16);
+                                const int rr = ddx * ddx + ddy * ddy;
+                                if (rr < minR2) minR2 = rr;
+                            }
                         }
                     }
                 }
+            rad[i] = minR2;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // ---- keep the N first in the total order (radius desc, strength desc, index asc); rank = output position (choice C2)
+        // The comparator is a lexicographic order on (radius desc, strength desc, index asc): pack it into one 64-bit key per
+        // candidate (LDS path) so that the O(M^2) rank is one wide LDS read and one compare per pair, 8 pairs in flight.
+        __shared__ unsigned long long l_key[SEL_CAP];
+        if (in_lds) {
+            for (int i = tid; i < M; i += 1024)
+                l_key[i] = ((unsigned long long)(unsigned)rad[i] << 32) | ((unsigned long long)(unsigned)l_cand[i].y << 16) | (unsigned long long)(0xFFFF - i);
+            __syncthreads();
+        }
+        for (int i = tid; i < M; i += 1024) {
+            int rank = 0;
+            if (in_lds) {
+                const unsigned long long ki = l_key[i];
+                int j = 0;
+                for (; j + 8 <= M; j += 8) {
+    #pragma unroll
+                    for (int u = 0; u < 8; ++u) rank += l_key[j + u] > ki;
+                }
+                for (; j < M; ++j) rank += l_key[j] > ki;
+            } else {
+                const int ri = rad[i], si = cand[i].y;
+                for (int j = 0; j < M; ++j) {
+                    const int rj = rad[j], sj = cand[j].y;
+                    rank += (rj > ri) || (rj == ri && (sj > si || (sj == si && j < i)));
+                }
             }
-        rad[i] = minR2;
-    }
-    __threadfence_block();
-    __syncthreads();
-    // ---- keep the N first in the total order (radius desc, strength desc, index asc); rank = output position (choice C2)
-    for (int i = tid; i < M; i += 1024) {
-        const int ri = rad[i], si = cand[i].y;
-        int rank = 0;
-        for (int j = 0; j < M; ++j) {
-            const int rj = rad[j], sj = cand[j].y;
-            rank += (rj > ri) || (rj == ri && (sj > si || (sj == si && j < i)));
+            if (rank < N && rank < a.capacity) {
+                const int2 r = cand[i];
+                mage_keypoint k = { (float)(r.x & 0xffff), (float)(r.x >> 16), size_f, 0.0f, (float)r.y, 0, -1 };
+                okp[rank] = k;
+            }
         }
-        if (rank < N && rank < a.capacity) {
-            const int2 r = cand[i];
-            mage_keypoint k = { (float)(r.x & 0xffff), (float)(r.x >> 16), size_f, 0.0f, (float)r.y, 0, -1 };
-            okp[rank] = k;
-        }
-    }
+
+    };
+    if (in_lds) suppress_and_rank(l_cand, l_cellcnt, l_cellfill, l_cellmem, l_rad);
+    else suppress_and_rank(cand, cellcnt, cellfill, cellmem, rad);
     if (tid == 0) a.out_count[f] = min(N, a.capacity);
 }
 
