@@ -92,6 +92,7 @@ __global__ __launch_bounds__(MT) void k_radius_match(const mage_keypoint* __rest
                                                      int* __restrict__ scratch /* nq x 2 + nt x 2 ints */, mage_dmatch* __restrict__ out, int cap,
                                                      int* __restrict__ count)
 {
+#pragma clang fp contract(off)          // box bounds are compared with keypoint coordinates: plain IEEE operations, never an FMA
     __shared__ int wave_cnt[MT / 64];
     __shared__ int base_s, n_almost;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -110,12 +111,12 @@ __global__ __launch_bounds__(MT) void k_radius_match(const mage_keypoint* __rest
         if (!qmask || qmask[q]) {
             const mage_keypoint k = qk[q];
             const float px = qpos ? qpos[q].x : k.x, py = qpos ? qpos[q].y : k.y;
-            const float x0 = __fsub_rn(px, radius), x1 = __fadd_rn(px, radius), y0 = __fsub_rn(py, radius), y1 = __fadd_rn(py, radius);
-            const float z0 = __fsub_rn(__fmul_rn((float)k.octave, 100.0f), 1.0f), z1 = __fadd_rn(__fmul_rn((float)k.octave, 100.0f), 1.0f);
+            const float x0 = px - radius, x1 = px + radius, y0 = py - radius, y1 = py + radius;
+            const float z0 = (float)k.octave * 100.0f - 1.0f, z1 = (float)k.octave * 100.0f + 1.0f;
             const ulonglong4 qd = Q[q];
             for (int t = 0; t < nt; ++t) {
                 const mage_keypoint c = tk[t];
-                const float tz = __fmul_rn((float)c.octave, 100.0f);
+                const float tz = (float)c.octave * 100.0f;
                 if (!(c.x >= x0 && c.x <= x1 && c.y >= y0 && c.y <= y1 && tz >= z0 && tz <= z1)) continue;
                 if (tmask && !tmask[t]) continue;
                 const ulonglong4 v = T[t];

@@ -105,7 +105,6 @@ MAGE_EXPORT mage_status mage_orb_create(const mage_orb_params* params, mage_orb*
         *out = nullptr;
         const mage_orb_params& p = *params;
         if (p.nlevels != 1) return fail(MAGE_ERR_UNSUPPORTED, "NumLevels = %u: the cv::resize pyramid is not built yet (SURVEY.md 8f rank 4)", p.nlevels);
-        if (p.use_orientation) return fail(MAGE_ERR_UNSUPPORTED, "UseOrientation: ICAngles/fastAtan2 are not built yet (SURVEY.md 8f rank 4)");
         if (p.patch_size != 15 && p.patch_size != 31) return fail(MAGE_ERR_UNSUPPORTED, "patch size %u: only the pre-rotated 15 / 31 tables are built", p.patch_size);
         if (p.gaussian_kernel_size > 15 || (p.gaussian_kernel_size > 1 && p.gaussian_kernel_size % 2 == 0))
             return fail(MAGE_ERR_INVALID_ARGUMENT, "Gaussian kernel size must be odd and <= 15");
@@ -170,7 +169,10 @@ mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     MAGE_HIP(hipEventRecord(h->ev[0], st));
     orb_launch_fast(d_images, w, h_img, stride, frame_stride, n_frames, (int)std::min(P.fast_threshold, 255u), h->d_score.p, wp, st);
     MAGE_HIP(hipEventRecord(h->ev[1], st));
-    orb_launch_collect(h->d_score.p, w, h_img, wp, n_frames, (int)P.patch_size / 2, NMS_ROWS, n_wg, h->d_wg_count.p, h->d_wg_off.p, h->d_hist.p,
+    // RunByImageBorder: half the patch, or its hypotenuse when the patch gets rotated (OpenCVModified.cpp:709-712)
+    const int half_patch = (int)P.patch_size / 2;
+    const int border = P.use_orientation ? (int)std::ceil((float)half_patch * std::sqrt(2.0f)) : half_patch;
+    orb_launch_collect(h->d_score.p, w, h_img, wp, n_frames, border, NMS_ROWS, n_wg, h->d_wg_count.p, h->d_wg_off.p, h->d_hist.p,
                        h->d_n_raw.p, h->d_raw.p, raw_cap, st);
     OrbSelectArgs a{};
     a.raw = h->d_raw.p; a.n_raw = h->d_n_raw.p; a.hist = h->d_hist.p;
@@ -181,6 +183,14 @@ mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     a.fast_threshold = (int)P.fast_threshold; a.strong_response = P.strong_response_anms; a.capacity = capacity; a.patch_size = (int)P.patch_size;
     a.feature_strength = P.feature_strength_anms; a.min_robust = P.min_robust_factor; a.max_robust = P.max_robust_factor;
     orb_launch_select(a, n_frames, st);
+    if (P.use_orientation && capacity > 0) {             // ICAngles on the unblurred image (:745-748)
+        OrbUmax um{};
+        um.half = half_patch;
+        const int vmax = (int)std::floor((float)half_patch * std::sqrt(2.f) / 2 + 1), vmin = (int)std::ceil((float)half_patch * std::sqrt(2.f) / 2);
+        for (int v = 0; v <= vmax; ++v) um.umax[v] = (int)std::nearbyint(std::sqrt((double)half_patch * half_patch - (double)v * v));
+        for (int v = half_patch, v0 = 0; v >= vmin; --v) { while (um.umax[v0] == um.umax[v0 + 1]) ++v0; um.umax[v] = v0; ++v0; }
+        orb_launch_angles(d_images, stride, frame_stride, n_frames, h->d_kp.p, h->d_count.p, capacity, um, st);
+    }
     MAGE_HIP(hipEventRecord(h->ev[2], st));
     orb_launch_blur(d_images, w, h_img, stride, frame_stride, n_frames, h->taps, h->d_blur.p, wp, st);
     MAGE_HIP(hipEventRecord(h->ev[3], st));

@@ -26,6 +26,9 @@ void orb_launch_collect(const uint8_t* score, int w, int h, int wp, int n_frames
                         int* hist, int* n_raw, int2* raw, size_t raw_cap, hipStream_t st);
 void orb_launch_select(const OrbSelectArgs& a, int n_frames, hipStream_t st);
 void orb_launch_blur(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, const OrbTaps& taps, uint8_t* out, int wp, hipStream_t st);
+struct OrbUmax { int half; int umax[18]; };         // row extents of the orientation disc, half <= 15 (OpenCVModified.cpp:672-688)
+void orb_launch_angles(const uint8_t* img, int stride, size_t frame_stride, int n_frames, mage_keypoint* kps, const int* counts, int capacity,
+                       const OrbUmax& um, hipStream_t st);
 void orb_launch_brief(const uint8_t* blurred, int wp, int h, int n_frames, const mage_keypoint* kps, const int* counts, int capacity,
                       const signed char* pattern, uint8_t* desc, hipStream_t st);
 

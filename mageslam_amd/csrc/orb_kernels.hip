@@ -8,7 +8,8 @@
 //   k_brief          ComputeOrbDescriptorsPrerotated                      :502-549
 // Frames are independent: every kernel takes the frame index from blockIdx.y (batched over frames).
 // All outputs are integers and must equal the CPU oracle bit for bit; float arithmetic that feeds comparisons
-// (ANMS robustness factor) uses explicitly rounded operations so that no FMA contraction can change a result.
+// (ANMS robustness factor, cv::fastAtan2) is written with plain operators under `#pragma clang fp contract(off)`: the
+// __f*_rn helpers of this toolchain are ordinary operators inside header functions and do get fused into FMAs.
 #include "orb_kernels.h"
 
 namespace mage {
@@ -336,6 +337,7 @@ __device__ __forceinline__ int block_scan_excl(int v, int* sh /* 17 ints */, int
 
 __global__ __launch_bounds__(1024) void k_select(OrbSelectArgs a)
 {
+#pragma clang fp contract(off)          // float results feed comparisons that must match the CPU restatement: plain IEEE operations, never an FMA
     __shared__ int sh[32];
     __shared__ int lhist[256];
     __shared__ int s_cut;
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(1024) void k_select(OrbSelectArgs a)
     if (tid < 256 && tid >= min_thr && lhist[tid] >= a.nfeatures) atomicMax(&s_mnt, tid);
     __syncthreads();
     const int mnt = s_mnt >= 0 ? s_mnt : min_thr;
-    const int lower = max((int)__fmul_rn((float)mnt, a.feature_strength), min_thr);
+    const int lower = max((int)((float)mnt * a.feature_strength), min_thr);
     if (tid < 256 && tid >= lower && lhist[tid] >= a.max_num) atomicMax(&s_cut, tid);
     __syncthreads();
     if (tid == 0) {
@@ -441,12 +443,12 @@ __global__ __launch_bounds__(1024) void k_select(OrbSelectArgs a)
         const int numX = a.cells_x, numY = a.cells_y, thr = a.fast_threshold;
         float rf;
         {
-            const float hi = __fsub_rn((float)a.strong_response, (float)thr);
-            float val = __fsub_rn((float)s_minS, (float)thr);
+            const float hi = (float)a.strong_response - (float)thr;
+            float val = (float)s_minS - (float)thr;
             val = val < 0.0f ? 0.0f : (val > hi ? hi : val);
-            float range = __fsub_rn(a.max_robust, a.min_robust);
+            float range = a.max_robust - a.min_robust;
             if (range < 0.0f) range = 0.0f;
-            rf = __fsub_rn(a.max_robust, __fmul_rn(__fdiv_rn(val, (float)(a.strong_response - thr)), range));
+            rf = a.max_robust - (val / (float)(a.strong_response - thr)) * range;
         }
         for (int c = tid; c <= a.ncells; c += 1024) { cellcnt[c] = 0; cellfill[c] = 0; }
         __syncthreads();
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(1024) void k_select(OrbSelectArgs a)
             const int x = r.x & 0xffff, y = r.x >> 16;
             const int cx = (x - minX) * numX / (maxX + 1 - minX), cy = (y - minY) * numY / (maxY + 1 - minY);
             const float strength = (float)r.y;
-            const float s = __fadd_rn(__fmul_rn(strength, rf), 0.002f);          // strength >= 0 always (FAST score)
+            const float s = strength * rf + 0.002f;                              // strength >= 0 always (FAST score); no FMA: contraction is off in this kernel
             int minR2 = globalMaxR2;
             for (int d = 0; max(0, d - 1) * max(0, d - 1) * minCellDelta2 < minR2; ++d)
                 for (int yy = -d; yy <= d; ++yy) {
@@ -650,6 +652,49 @@ __global__ void k_copy_image(const uint8_t* __restrict__ img, int w, int h, int 
 }
 
 // ---------------------------------------------------------------------------------------------
+// ICAngles (OpenCVModified.cpp:399-437), only with UseOrientation: first moments of the UNBLURRED image over the discretised
+// disc of radius half (row v spans |u| <= umax[v]); one wavefront per keypoint, lanes over the (2 half + 1)^2 window, exact
+// integer sums (order-free), then cv::fastAtan2 in float32 with contraction off.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+#pragma clang fp contract(off)          // plain IEEE operations in source order: bit-identical to the CPU restatement (tools/atan_check.hip)
+    const float scale = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale, p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float eps = (float)2.2204460492503131e-16;
+    float a, c, c2;
+    if (ax >= ay) { c = ay / (ax + eps); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else { c = ax / (ay + eps); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_ic_angles(const uint8_t* __restrict__ img, int stride, size_t frame_stride, mage_keypoint* __restrict__ kps,
+                                                   const int* __restrict__ counts, int capacity, OrbUmax um)
+{
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= counts[f]) return;
+    mage_keypoint* kp = kps + (size_t)f * capacity + k;
+    const int cx = (int)rintf(kp->x), cy = (int)rintf(kp->y);
+    const uint8_t* c = img + (size_t)f * frame_stride + (size_t)cy * stride + cx;
+    const int half = um.half, side = 2 * half + 1;
+    int m01 = 0, m10 = 0;
+    for (int e = lane; e < side * side; e += 64) {
+        const int v = e / side - half, u = e % side - half;
+        if (abs(u) <= um.umax[abs(v)]) {
+            const int val = c[v * stride + u];
+            m10 += u * val; m01 += v * val;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { m01 += __shfl_xor(m01, o, 64); m10 += __shfl_xor(m10, o, 64); }
+    if (lane == 0) kp->angle = fast_atan2_deg((float)m01, (float)m10);
+}
+
+// ---------------------------------------------------------------------------------------------
 // BRIEF-256: one wavefront per keypoint; lane l evaluates pairs 4l..4l+3, two lanes make a byte.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blurred, int wp, int h, const mage_keypoint* __restrict__ kps,
@@ -660,10 +705,12 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blurr
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (k >= counts[f]) return;
     const mage_keypoint kp = kps[(size_t)f * capacity + k];
-    // cvRound of an integer-valued float; angle 0 -> rotation row 0
+    // cvRound of an integer-valued float; angleIncrement = cvRound(angle / 12) % 30 picks the pre-rotated table row
+    // (OpenCVModified.cpp:523-532; angle is 0 unless UseOrientation)
     const int cx = (int)rintf(kp.x), cy = (int)rintf(kp.y);
     const uint8_t* c = blurred + (size_t)f * wp * h + (size_t)cy * wp + cx;
-    const signed char* p = pattern + lane * 16;
+    const int inc = (int)rintf(kp.angle / 12.0f) % 30;
+    const signed char* p = pattern + inc * 1024 + lane * 16;
     int nib = 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -702,6 +749,12 @@ void orb_launch_blur(const uint8_t* img, int w, int h, int stride, size_t frame_
 {
     if (taps.radius == 0) hipLaunchKernelGGL(k_copy_image, dim3(cdiv(wp * h, 256 * 8), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, out, wp);
     else hipLaunchKernelGGL(k_blur, dim3(cdiv(wp, BT_W), cdiv(h, BT_H), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, taps, out, wp);
+}
+
+void orb_launch_angles(const uint8_t* img, int stride, size_t frame_stride, int n_frames, mage_keypoint* kps, const int* counts, int capacity,
+                       const OrbUmax& um, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ic_angles, dim3(cdiv(capacity, 4), n_frames), dim3(256), 0, st, img, stride, frame_stride, kps, counts, capacity, um);
 }
 
 void orb_launch_brief(const uint8_t* blurred, int wp, int h, int n_frames, const mage_keypoint* kps, const int* counts, int capacity,

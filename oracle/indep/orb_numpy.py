@@ -130,11 +130,55 @@ def expand_pattern(base: np.ndarray) -> np.ndarray:
     return out
 
 
+def fast_atan2_deg(y, x):
+    """cv::fastAtan2 (OpenCV 3.4.0): 7th-order odd polynomial of min/max ratio, float32 throughout, degrees in [0, 360]."""
+    f = np.float32
+    y = np.asarray(y, f); x = np.asarray(x, f)
+    scale = f(180 / 3.1415926535897932384626433832795)
+    p1, p3, p5, p7 = f(0.9997878412794807) * scale, f(-0.3258083974640975) * scale, f(0.1555786518463281) * scale, f(-0.04432655554792128) * scale
+    ax, ay = np.abs(x), np.abs(y)
+    eps = f(np.finfo(np.float64).eps)
+    swap = ax < ay
+    num = np.where(swap, ax, ay); den = np.where(swap, ay, ax) + eps
+    c = (num / den).astype(f); c2 = (c * c).astype(f)
+    a = ((((p7 * c2 + p5).astype(f) * c2 + p3).astype(f) * c2 + p1).astype(f) * c).astype(f)
+    a = np.where(swap, f(90) - a, a).astype(f)
+    a = np.where(x < 0, f(180) - a, a).astype(f)
+    a = np.where(y < 0, f(360) - a, a).astype(f)
+    return a
+
+
+def ic_angles(img: np.ndarray, k: np.ndarray, half: int) -> np.ndarray:
+    """Intensity-centroid orientation (OpenCVModified.cpp:399-437): first moments over the discretised disc of radius `half`
+    (row v spans |u| <= umax[v], the table of :672-688), angle = fastAtan2(m01, m10)."""
+    vmax = int(np.floor(half * np.sqrt(np.float32(2)) / 2 + 1)); vmin = int(np.ceil(half * np.sqrt(np.float32(2)) / 2))
+    umax = np.zeros(half + 2, np.int64)
+    for v in range(vmax + 1):
+        umax[v] = int(np.rint(np.sqrt(float(half * half - v * v))))
+    v0 = 0
+    for v in range(half, vmin - 1, -1):
+        while umax[v0] == umax[v0 + 1]:
+            v0 += 1
+        umax[v] = v0
+        v0 += 1
+    vv, uu = np.mgrid[-half:half + 1, -half:half + 1]
+    disc = np.abs(uu) <= umax[np.abs(vv)]
+    I = img.astype(np.int64)
+    out = np.zeros(len(k), np.float32)
+    for i, (x, y) in enumerate(k[:, :2]):
+        patch = I[y - half:y + half + 1, x - half:x + half + 1] * disc
+        out[i] = fast_atan2_deg(np.float32((patch * vv).sum()), np.float32((patch * uu).sum()))
+    return out
+
+
 def detect(img: np.ndarray, base_pattern: np.ndarray, **kw):
+    """Returns (keypoints x y response, descriptors, blurred[, angles when use_orientation])."""
     P = dict(DEFAULTS); P.update(kw)
     h, w = img.shape
     k = fast_keypoints(img, P["fast_threshold"])
     b = P["patch_size"] // 2
+    if P.get("use_orientation"):
+        b = int(np.ceil(np.float32(b) * np.sqrt(np.float32(2))))
     if h <= 2 * b or w <= 2 * b:
         k = k[:0]
     else:
@@ -143,13 +187,20 @@ def detect(img: np.ndarray, base_pattern: np.ndarray, **kw):
         k = retain_best(k, P["fast_threshold"], int(np.float32(P["nfeatures"]) * np.float32(P["feature_factor"])), P["nfeatures"], P["feature_strength"])
         k = anms(k, P["nfeatures"], P["fast_threshold"], P)
     bl = blur(img, P["gaussian_kernel_size"]) if P["gaussian_kernel_size"] > 1 else img
-    pat = expand_pattern(base_pattern)[0].reshape(256, 4)
+    table = expand_pattern(base_pattern).reshape(30, 256, 4)
+    if P.get("use_orientation"):
+        ang = ic_angles(img, k, P["patch_size"] // 2)
+        inc = np.rint(ang / np.float32(12)).astype(np.int64) % 30          # cvRound: half to even, like np.rint
+    else:
+        ang = None
+        inc = np.zeros(len(k), np.int64)
+    pat = table[inc]                                                          # (n, 256, 4)
     xs, ys = k[:, 0][:, None], k[:, 1][:, None]
-    t0 = bl[ys + pat[None, :, 1], xs + pat[None, :, 0]]
-    t1 = bl[ys + pat[None, :, 3], xs + pat[None, :, 2]]
+    t0 = bl[ys + pat[:, :, 1], xs + pat[:, :, 0]]
+    t1 = bl[ys + pat[:, :, 3], xs + pat[:, :, 2]]
     bits = (t0 < t1).astype(np.uint8).reshape(len(k), 32, 8)
     desc = np.packbits(bits, axis=2, bitorder="little").reshape(len(k), 32)
-    return k, desc, bl
+    return (k, desc, bl) if ang is None else (k, desc, bl, ang)
 
 
 def hamming_matrix(A: np.ndarray, B: np.ndarray) -> np.ndarray:

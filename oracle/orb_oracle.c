@@ -31,6 +31,7 @@
  * known-answer properties (tests/test_orb_oracle.py).
  */
 #define _GNU_SOURCE
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -369,14 +370,78 @@ ORBO_API void orbo_blur(const uint8_t* src, int w, int h, int stride, int ksize,
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* ICAngles (OpenCVModified.cpp:399-437) + the u_max table (:672-688) + cv::fastAtan2 (OpenCV  */
+/* 3.4.0 core, mathfuncs: 7th-order odd polynomial in float, degrees; not vendored: restated)  */
+/* ------------------------------------------------------------------------------------------ */
+static float fast_atan2f(float y, float x)
+{
+    const float scale = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale, p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+ORBO_API void orbo_umax(int half, int* umax /* half + 2 */)
+{
+    int v, v0;
+    const int vmax = (int)floor(half * sqrtf(2.f) / 2 + 1);
+    const int vmin = (int)ceil(half * sqrtf(2.f) / 2);
+    for (v = 0; v <= half + 1; ++v) umax[v] = 0;
+    for (v = 0; v <= vmax; ++v) umax[v] = cv_round(sqrt((double)half * half - (double)v * v));
+    for (v = half, v0 = 0; v >= vmin; --v) {          /* make sure we are symmetric */
+        while (umax[v0] == umax[v0 + 1]) ++v0;
+        umax[v] = v0;
+        ++v0;
+    }
+}
+
+ORBO_API void orbo_ic_angles(const uint8_t* img, int stride, orbo_keypoint* kps, int n, int half)
+{
+    int umax[64];
+    orbo_umax(half, umax);
+    for (int i = 0; i < n; ++i) {
+        const uint8_t* center = img + (size_t)cv_round(kps[i].y) * stride + cv_round(kps[i].x);
+        int m_01 = 0, m_10 = 0;
+        for (int u = -half; u <= half; ++u) m_10 += u * center[u];
+        for (int v = 1; v <= half; ++v) {
+            int v_sum = 0;
+            const int d = umax[v];
+            for (int u = -d; u <= d; ++u) {
+                const int val_plus = center[u + v * stride], val_minus = center[u - v * stride];
+                v_sum += (val_plus - val_minus);
+                m_10 += u * (val_plus + val_minus);
+            }
+            m_01 += v * v_sum;
+        }
+        kps[i].angle = fast_atan2f((float)m_01, (float)m_10);
+    }
+}
+
+ORBO_API float orbo_fast_atan2(float y, float x) { return fast_atan2f(y, x); }
+
+/* ------------------------------------------------------------------------------------------ */
 /* DetectAndCompute                                                                           */
 /* ------------------------------------------------------------------------------------------ */
 ORBO_API int orbo_detect(const orbo_params* P, const uint8_t* img, int w, int h, int stride,
                          orbo_keypoint* kps, uint8_t* desc32, int cap, int* n_out, uint8_t* blurred_out /* optional w*h */)
 {
     *n_out = 0;
-    if (P->nlevels != 1 || P->use_orientation || (P->patch_size != 15 && P->patch_size != 31)) return ORBO_UNSUPPORTED;
-    const int half = (int)P->patch_size / 2;
+    if (P->nlevels != 1 || (P->patch_size != 15 && P->patch_size != 31)) return ORBO_UNSUPPORTED;
+    const int half_patch = (int)P->patch_size / 2;
+    /* with orientation the patch is rotated: the hypotenuse of half the patch (OpenCVModified.cpp:709-712) */
+    const int half = P->use_orientation ? (int)ceil(half_patch * sqrtf(2.0f)) : half_patch;
     uint8_t* score = (uint8_t*)malloc((size_t)w * h + 1);
     size_t raw_cap = (size_t)w * h / 4 + 16;
     raw_kp* kp = (raw_kp*)malloc(sizeof(raw_kp) * raw_cap);
@@ -405,6 +470,7 @@ ORBO_API int orbo_detect(const orbo_params* P, const uint8_t* img, int w, int h,
     }
     *n_out = (int)n;
     if (n == 0) { free(kp); return ORBO_OK; }
+    if (P->use_orientation) orbo_ic_angles(img, stride, kps, (int)n, half_patch);      /* on the unblurred level (:745-748) */
     uint8_t* blur = (uint8_t*)malloc((size_t)w * h);
     if (P->gaussian_kernel_size > 1) orbo_blur(img, w, h, stride, (int)P->gaussian_kernel_size, blur);
     else for (int y = 0; y < h; ++y) memcpy(blur + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
@@ -413,7 +479,7 @@ ORBO_API int orbo_detect(const orbo_params* P, const uint8_t* img, int w, int h,
     orbo_pattern_expand((int)P->patch_size, pat);
     for (size_t j = 0; j < n; ++j) {
         const uint8_t* center = blur + (size_t)cv_round(kps[j].y) * w + cv_round(kps[j].x);
-        const signed char* p = pat;      /* angleIncrement = cvRound(0 / 12) % 30 = 0 */
+        const signed char* p = pat + (cv_round(kps[j].angle / 12.0f) % 30) * 1024;       /* angleIncrement (:523-532); 0 without orientation */
         for (int i = 0; i < 32; ++i, p += 32) {
             int val = 0;
             for (int bit = 0; bit < 8; ++bit) {

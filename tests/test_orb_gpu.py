@@ -86,7 +86,7 @@ def test_edge_cases_match_oracle():
 
 def test_unsupported_settings_are_refused():
     from mageslam_amd._lib import MageError
-    for kw in (dict(nlevels=2), dict(use_orientation=1), dict(patch_size=21)):
+    for kw in (dict(nlevels=2), dict(patch_size=21)):
         with pytest.raises(MageError):
             OrbDetector(**kw)
 
@@ -244,3 +244,20 @@ def test_undistort_keypoints_golden_oracle_and_device_path(gold):
     hip.hipFree(d_img)
     for f in range(2):
         assert np.array_equal(got[f, : cnt[f]], exp[f])
+
+
+@pytest.mark.parametrize("name,patch", [("orb_160x120", 15), ("orb_640x480_a", 15), ("orb_160x120", 31)])
+def test_oriented_detection_golden_and_oracle(gold, name, patch):
+    """"next" row ORB-6: UseOrientation on the device -- keypoints, float32 angles and rotated-BRIEF descriptors bit-exact against
+    the fixture (independent numpy) and the C oracle."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_oriented.npz"))
+    img = gold[name + "_img"]
+    det = OrbDetector(default_params(use_orientation=1, patch_size=patch))
+    k, d = det.DetectAndCompute(img)
+    key = f"{name}_p{patch}"
+    assert np.array_equal(np.stack([k["x"], k["y"], k["response"]], 1).astype(np.int64), g[key + "_kp"])
+    assert np.array_equal(k["angle"], g[key + "_angle"])
+    assert np.array_equal(d, g[key + "_desc"])
+    ko, do = O.orb_detect(img, O.OrbParams.defaults(use_orientation=1, patch_size=patch))
+    assert np.array_equal(k, ko) and np.array_equal(d, do)

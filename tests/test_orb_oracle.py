@@ -118,7 +118,7 @@ def test_edge_cases():
 
 def test_unsupported_settings_are_refused():
     a = np.zeros((64, 64), np.uint8)
-    for kw in (dict(nlevels=2), dict(use_orientation=1), dict(patch_size=21)):
+    for kw in (dict(nlevels=2), dict(patch_size=21)):
         with pytest.raises(NotImplementedError):
             O.orb_detect(a, O.OrbParams.defaults(**kw))
 
@@ -246,3 +246,34 @@ def test_undistort_known_answers():
     k["x"], k["y"] = xd * 500 + 320, yd * 500 + 240
     o = O.undistort_keypoints(k, O.UndistortParams.make(K, dist, P))
     np.testing.assert_allclose(np.stack([o["x"], o["y"]], 1), xn * 400 + [300, 250], atol=2e-2)
+
+
+ORIENTED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_oriented.npz")
+ORIENTED_CASES = [("orb_160x120", 15), ("orb_640x480_a", 15), ("orb_160x120", 31)]
+
+
+@pytest.mark.parametrize("name,patch", ORIENTED_CASES)
+def test_oriented_detection_oracle_matches_golden(gold, name, patch):
+    """UseOrientation ("next" row ORB-6): border = ceil(half sqrt 2), ICAngles + fastAtan2, rotated-BRIEF row.  Fixture from the
+    independent numpy implementation; angles are float32 and must be identical."""
+    g = np.load(ORIENTED)
+    k, d = O.orb_detect(gold[name + "_img"], O.OrbParams.defaults(use_orientation=1, patch_size=patch))
+    key = f"{name}_p{patch}"
+    assert np.array_equal(kp_xyr(k), g[key + "_kp"])
+    assert np.array_equal(k["angle"], g[key + "_angle"])
+    assert np.array_equal(d, g[key + "_desc"])
+    assert np.all(k["size"] == patch) and np.all(k["octave"] == 0)
+
+
+def test_fast_atan2_polynomial():
+    """cv::fastAtan2: degrees in [0, 360], ~0.3 degree accurate, exact at the axes."""
+    L = O.lib()
+    L.orbo_fast_atan2.restype = __import__("ctypes").c_float
+    L.orbo_fast_atan2.argtypes = [__import__("ctypes").c_float] * 2
+    rng = np.random.default_rng(4)
+    for y, x in rng.normal(size=(200, 2)) * 1000:
+        a = L.orbo_fast_atan2(float(np.float32(y)), float(np.float32(x)))
+        ref = np.degrees(np.arctan2(np.float32(y), np.float32(x))) % 360
+        assert min(abs(a - ref), 360 - abs(a - ref)) < 0.35
+    assert L.orbo_fast_atan2(0.0, 5.0) == 0.0 and L.orbo_fast_atan2(0.0, -5.0) == 180.0
+    assert abs(L.orbo_fast_atan2(3.0, 0.0) - 90.0) < 1e-4 and abs(L.orbo_fast_atan2(-3.0, 0.0) - 270.0) < 1e-4
