@@ -44,7 +44,7 @@ typedef struct mage_orb_params {
     unsigned nlevels;                /* 1; > 1 -> MAGE_ERR_UNSUPPORTED (cv::resize pyramid) */
     unsigned patch_size;             /* 15 or 31 (pre-rotated tables); others -> MAGE_ERR_UNSUPPORTED */
     unsigned fast_threshold;         /* 4 */
-    int      use_orientation;        /* 0; 1 -> MAGE_ERR_UNSUPPORTED (ICAngles / fastAtan2) */
+    int      use_orientation;        /* 0 (default) or 1: ICAngles orientation + rotated BRIEF rows (OpenCVModified.cpp:399-437, 523-532) */
     float    feature_factor_anms;    /* 1.5 */
     float    feature_strength_anms;  /* 0.9 */
     int      strong_response_anms;   /* 20 */
