@@ -358,16 +358,20 @@ __global__ __launch_bounds__(256) void k_schur_block(BaDeviceView v, double lamb
     for (int k = 0; k < 36; ++k) acc[k] = 0;
     for (int c = v.blk_ptr[b] + lane; c < v.blk_ptr[b + 1]; c += WAVE) {
         const int2 sab = v.con[c];
-        const double* Wa = v.W + (size_t)sab.x * 18;
-        const double* Wb = v.W + (size_t)sab.y * 18;
-        const double* D = v.Dinv + (size_t)v.w_lm[sab.x] * 6;
-        const double d00 = D[0], d01 = D[1], d02 = D[2], d11 = D[3], d12 = D[4], d22 = D[5];
-        double wb[18];
+        // 144-byte W blocks and 48-byte D^-1 records are 16-byte aligned: 128-bit loads (21 per contribution instead of 42)
+        const double2* Wa2 = reinterpret_cast<const double2*>(v.W + (size_t)sab.x * 18);
+        const double2* Wb2 = reinterpret_cast<const double2*>(v.W + (size_t)sab.y * 18);
+        const double2* D2 = reinterpret_cast<const double2*>(v.Dinv + (size_t)v.w_lm[sab.x] * 6);
+        const double2 da = D2[0], db = D2[1], dc = D2[2];
+        const double d00 = da.x, d01 = da.y, d02 = db.x, d11 = db.y, d12 = dc.x, d22 = dc.y;
+        double wa[18], wb[18];
 #pragma unroll
-        for (int k = 0; k < 18; ++k) wb[k] = Wb[k];
+        for (int k = 0; k < 9; ++k) { const double2 t = Wa2[k]; wa[2 * k] = t.x; wa[2 * k + 1] = t.y; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { const double2 t = Wb2[k]; wb[2 * k] = t.x; wb[2 * k + 1] = t.y; }
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-            const double a0 = Wa[r * 3], a1 = Wa[r * 3 + 1], a2 = Wa[r * 3 + 2];
+            const double a0 = wa[r * 3], a1 = wa[r * 3 + 1], a2 = wa[r * 3 + 2];
             const double t0 = a0 * d00 + a1 * d01 + a2 * d02;
             const double t1 = a0 * d01 + a1 * d11 + a2 * d12;
             const double t2 = a0 * d02 + a1 * d12 + a2 * d22;
