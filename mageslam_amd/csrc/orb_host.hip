@@ -74,7 +74,7 @@ struct mage_orb {
     mage_orb_params P{};
     OrbTaps taps{};
     DevBuf<signed char> d_pattern;
-    DevBuf<uint8_t> d_img, d_score, d_blur, d_desc;
+    DevBuf<uint8_t> d_img, d_score, d_rawscore, d_blur, d_desc;     // d_score: kept map (NMS survivors); d_rawscore: FAST scores of frame 0 (parity tests)
     DevBuf<int> d_wg_count, d_wg_off, d_hist, d_n_raw, d_cell_start, d_cell_fill, d_cell_members, d_radius, d_count;
     DevBuf<int2> d_raw, d_cand;
     DevBuf<mage_keypoint> d_kp, d_undist;
@@ -131,7 +131,7 @@ MAGE_EXPORT void mage_orb_destroy(mage_orb* h) { delete h; }
 
 namespace {
 
-constexpr int NMS_ROWS = 32;
+constexpr int NMS_ROWS = ORB_BAND_ROWS;
 
 // runs the five stages on n_frames images that are already in HBM; leaves keypoints / descriptors / counts in HBM
 mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w, int h_img, int stride, size_t frame_stride, int capacity)
@@ -147,6 +147,7 @@ mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     const int ncells = P.num_cells_x * P.num_cells_y;
     const size_t nf = (size_t)std::max(n_frames, 1), cap = (size_t)std::max(capacity, 1);
     MAGE_TRY(h->d_score.reserve(nf * npx));
+    MAGE_TRY(h->d_rawscore.reserve(npx));
     MAGE_TRY(h->d_blur.reserve(nf * npx));
     MAGE_TRY(h->d_wg_count.reserve(nf * n_wg));
     MAGE_TRY(h->d_wg_off.reserve(nf * n_wg));
@@ -167,13 +168,13 @@ mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     if (n_frames == 0) return MAGE_OK;
 
     MAGE_HIP(hipEventRecord(h->ev[0], st));
-    orb_launch_fast(d_images, w, h_img, stride, frame_stride, n_frames, (int)std::min(P.fast_threshold, 255u), h->d_score.p, wp, st);
-    MAGE_HIP(hipEventRecord(h->ev[1], st));
     // RunByImageBorder: half the patch, or its hypotenuse when the patch gets rotated (OpenCVModified.cpp:709-712)
     const int half_patch = (int)P.patch_size / 2;
     const int border = P.use_orientation ? (int)std::ceil((float)half_patch * std::sqrt(2.0f)) : half_patch;
-    orb_launch_collect(h->d_score.p, w, h_img, wp, n_frames, border, NMS_ROWS, n_wg, h->d_wg_count.p, h->d_wg_off.p, h->d_hist.p,
-                       h->d_n_raw.p, h->d_raw.p, raw_cap, st);
+    orb_launch_fast(d_images, w, h_img, stride, frame_stride, n_frames, (int)std::min(P.fast_threshold, 255u), border, h->d_score.p, h->d_rawscore.p, wp,
+                    h->d_hist.p, h->d_wg_count.p, n_wg, st);
+    MAGE_HIP(hipEventRecord(h->ev[1], st));
+    orb_launch_collect(h->d_score.p, w, h_img, wp, n_frames, border, NMS_ROWS, n_wg, h->d_wg_count.p, h->d_wg_off.p, h->d_n_raw.p, h->d_raw.p, raw_cap, st);
     OrbSelectArgs a{};
     a.raw = h->d_raw.p; a.n_raw = h->d_n_raw.p; a.hist = h->d_hist.p;
     a.cand = h->d_cand.p; a.cell_start = h->d_cell_start.p; a.cell_fill = h->d_cell_fill.p; a.cell_members = h->d_cell_members.p; a.radius = h->d_radius.p;
@@ -269,7 +270,7 @@ MAGE_EXPORT mage_status mage_orb_debug_read(mage_orb* h, uint8_t* score_map, uin
         const size_t w = (size_t)h->last_w, rows = (size_t)h->last_h, wp = (w + 3) & ~(size_t)3;
         if (w * rows == 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "no frame has been processed yet");
         MAGE_HIP(hipSetDevice(h->device));
-        if (score_map) MAGE_HIP(hipMemcpy2D(score_map, w, h->d_score.p, wp, w, rows, hipMemcpyDeviceToHost));
+        if (score_map) MAGE_HIP(hipMemcpy2D(score_map, w, h->d_rawscore.p, wp, w, rows, hipMemcpyDeviceToHost));
         if (blurred) MAGE_HIP(hipMemcpy2D(blurred, w, h->d_blur.p, wp, w, rows, hipMemcpyDeviceToHost));
         return MAGE_OK;
     });

@@ -21,9 +21,12 @@ struct OrbSelectArgs {
 };
 
 // wp = internal row pitch of the score map / blurred image (w rounded up to 4)
-void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, uint8_t* score, int wp, hipStream_t st);
-void orb_launch_collect(const uint8_t* score, int w, int h, int wp, int n_frames, int border, int rows_per_wg, int n_wg, int* wg_count, int* wg_off,
-                        int* hist, int* n_raw, int2* raw, size_t raw_cap, hipStream_t st);
+constexpr int ORB_BAND_ROWS = 32;    // image rows per tile row of k_fast_nms = per band of the raster-order emit pass
+// FAST + NMS + border cull: kept map (score where a keypoint survives), raw scores of frame 0 (optional), histogram, per-band counts
+void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, int border, uint8_t* kept,
+                     uint8_t* raw_frame0, int wp, int* hist, int* band_count, int n_bands, hipStream_t st);
+void orb_launch_collect(const uint8_t* kept, int w, int h, int wp, int n_frames, int border, int rows_per_wg, int n_wg, int* wg_count, int* wg_off,
+                        int* n_raw, int2* raw, size_t raw_cap, hipStream_t st);
 void orb_launch_select(const OrbSelectArgs& a, int n_frames, hipStream_t st);
 void orb_launch_blur(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, const OrbTaps& taps, uint8_t* out, int wp, hipStream_t st);
 struct OrbUmax { int half; int umax[18]; };         // row extents of the orientation disc, half <= 15 (OpenCVModified.cpp:672-688)

@@ -21,7 +21,7 @@ namespace {
 // brighter rings; a pixel is a corner iff that maximum exceeds the threshold, and its score is maximum - 1
 // (identical to the reference's threshold-table pre-test + min/max ladder, which computes the same quantity).
 // ---------------------------------------------------------------------------------------------
-constexpr int FT_W = 64, FT_H = 32, HALO = 3;   // 2048 pixels per workgroup, 8 per thread (few, fat workgroups: dispatch is not free)
+constexpr int FT_W = 64, FT_H = ORB_BAND_ROWS, HALO = 3;   // 2048 pixels per workgroup, 8 per thread (few, fat workgroups: dispatch is not free)
 
 __device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ c, int TP, int t)
 {
@@ -92,85 +92,113 @@ __device__ __forceinline__ void stage_window(uint8_t* __restrict__ tile, const u
 
 // Internal images (score map, blurred image) use a row pitch wp = w rounded up to 4 so every kernel below moves 4 pixels
 // per 32-bit access; pixels in [w, wp) are written as 0.
-__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride,
-                                                    int threshold, uint8_t* __restrict__ score, int wp)
+// FAST score + 3x3 non-maximum suppression + border cull + response histogram, one 64x32 tile per workgroup.
+// Scores are computed for the tile and a one-pixel ring around it (66x34), so the suppression of every tile pixel is decided
+// here from LDS and the full-image count pass is gone; what reaches HBM is the KEPT map (score where the pixel survives, else
+// 0), the per-frame histogram and the per-band (32 image rows = one tile row) keypoint counts for the raster-order emit pass.
+constexpr int FH = 4;                                   // image halo of the staged window: 3 (ring) + 1 (score ring)
+constexpr int SCW = FT_W + 2, SCH = FT_H + 2, SCP = 68; // score region and its LDS pitch
+
+__global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride,
+                                                  int threshold, int border, uint8_t* __restrict__ kept, uint8_t* __restrict__ raw_frame0, int wp,
+                                                  int* __restrict__ hist, int* __restrict__ band_count)
 {
-    constexpr int TW = FT_W + 8, TH = FT_H + 2 * HALO, TP = TW;      // window starts 4 pixels left of the tile (aligned), halo 3 used
-    __shared__ __attribute__((aligned(4))) uint8_t tile[TH * TP];
-    __shared__ __attribute__((aligned(4))) uint8_t sc[FT_W * FT_H];  // scores of the tile
-    __shared__ uint16_t cand[FT_W * FT_H];                           // pixels that survive the compass test
-    __shared__ int n_cand;
-    const int f = blockIdx.z;
+    constexpr int TW = FT_W + 8, TH = FT_H + 2 * FH, TP = TW;        // window starts 4 pixels left of the tile (aligned)
+    __shared__ __attribute__((aligned(4))) uint8_t tile[TH * TP + 8];
+    __shared__ __attribute__((aligned(4))) uint8_t sc[SCH * SCP];     // scores of the tile and its ring
+    __shared__ uint16_t cand[SCH * SCP];                              // pixels that survive the compass test
+    __shared__ int lh[256];
+    __shared__ int n_cand, n_kept;
+    const int f = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const uint8_t* I = img + (size_t)f * frame_stride;
-    uint8_t* Sc = score + (size_t)f * wp * h;
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
-    if (threadIdx.x == 0) n_cand = 0;
-    stage_window<TW, TH, TP, false>(tile, I, w, h, stride, x0 - 4, y0 - HALO, TW, TH);
+    if (tid == 0) { n_cand = 0; n_kept = 0; }
+    lh[tid] = 0;
+    for (int e = tid; e < SCH * SCP / 4; e += 256) reinterpret_cast<uint32_t*>(sc)[e] = 0u;
+    stage_window<TW, TH, TP, false>(tile, I, w, h, stride, x0 - 4, y0 - FH, TW, TH);
     __syncthreads();
-    // Phase 1, every pixel: the compass test.  Any arc of 9 contiguous ring pixels contains two NEIGHBOURING compass points
-    // (ring positions 0, 4, 8, 12), so a corner needs two neighbouring compass pixels both darker or both brighter than the
-    // centre by more than the threshold -- a necessary condition costing 4 ring pixels.  Survivors (a few per cent to ~20 %)
-    // are appended to an LDS list; the full 16-pixel score is then computed on the compacted list, where every lane of a
-    // wavefront has real work (evaluated in place, one passing lane made all 64 pay for the expensive part).
-    // thread -> quads of 4 horizontally adjacent pixels: 16 quads per tile row, 32 rows = 512 quads, 2 per thread
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int qi = threadIdx.x + 256 * i;
-        const int ly = qi / (FT_W / 4), lq = qi % (FT_W / 4);
-        const int y = y0 + ly, xq = x0 + 4 * lq;
-        *reinterpret_cast<uint32_t*>(&sc[ly * FT_W + 4 * lq]) = 0u;
-        const bool row_ok = y >= 3 && y < h - 3 && xq < wp;
-        uint32_t up = 0, dn = 0, m0 = 0, m1 = 0, m2 = 0;
+    // Phase 1, every pixel of the 66x34 region: the compass test.  Any arc of 9 contiguous ring pixels contains two
+    // NEIGHBOURING compass points (ring positions 0, 4, 8, 12), so a corner needs two neighbouring compass pixels both darker
+    // or both brighter than the centre by more than the threshold -- a necessary condition costing 4 ring pixels.  Survivors
+    // (a few per cent to ~20 %) are appended to an LDS list; the full 16-pixel score is then computed on the compacted list,
+    // where every lane of a wavefront has real work.  Region pixel (rx, ry) = image (x0 - 1 + rx, y0 - 1 + ry) = tile byte
+    // (rx + 3, ry + 3); a thread takes four consecutive rx (17 groups per row, the last one half empty).
+    for (int qi = tid; qi < 17 * SCH; qi += 256) {
+        const int ry = qi / 17, q = qi % 17;
+        const int y = y0 - 1 + ry;
+        const bool row_ok = y >= 3 && y < h - 3;
+        uint32_t m0 = 0, m1 = 0, m2 = 0, u0 = 0, u1 = 0, d0_ = 0, d1_ = 0;
         if (row_ok) {
-            up = *reinterpret_cast<const uint32_t*>(&tile[(ly + HALO + 3) * TP + 4 + 4 * lq]);        // row y + 3, columns xq .. xq+3  (ring 0)
-            dn = *reinterpret_cast<const uint32_t*>(&tile[(ly + HALO - 3) * TP + 4 + 4 * lq]);        // row y - 3                      (ring 8)
-            const uint32_t* mp = reinterpret_cast<const uint32_t*>(&tile[(ly + HALO) * TP + 4 * lq]); // row y, columns xq-4 .. xq+7
+            const uint32_t* mp = reinterpret_cast<const uint32_t*>(&tile[(ry + 3) * TP + 4 * q]);
             m0 = mp[0]; m1 = mp[1]; m2 = mp[2];
+            const uint32_t* up = reinterpret_cast<const uint32_t*>(&tile[(ry + 6) * TP + 4 * q]);   // row y + 3 (ring 0)
+            const uint32_t* dn = reinterpret_cast<const uint32_t*>(&tile[(ry + 0) * TP + 4 * q]);   // row y - 3 (ring 8)
+            u0 = up[0]; u1 = up[1]; d0_ = dn[0]; d1_ = dn[1];
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             bool pass = false;
-            const int x = xq + b;
-            if (row_ok && x >= 3 && x < w - 3) {
-                auto byte_of = [&](int idx) -> int { const uint32_t r = idx < 4 ? m0 : (idx < 8 ? m1 : m2); return (int)((r >> (8 * (idx & 3))) & 0xffu); };
-                const int v = byte_of(4 + b);
-                const int d0 = v - (int)((up >> (8 * b)) & 0xffu);      // (0, +3)
-                const int d4 = v - byte_of(4 + b + 3);                  // (+3, 0)
-                const int d8 = v - (int)((dn >> (8 * b)) & 0xffu);      // (0, -3)
-                const int d12 = v - byte_of(4 + b - 3);                 // (-3, 0)
+            const int rx = 4 * q + b, x = x0 - 1 + rx;
+            if (row_ok && rx < SCW && x >= 3 && x < w - 3) {
+                auto b12 = [&](int idx) -> int { const uint32_t r = idx < 4 ? m0 : (idx < 8 ? m1 : m2); return (int)((r >> (8 * (idx & 3))) & 0xffu); };
+                auto b8 = [&](uint32_t lo, uint32_t hi, int idx) -> int { const uint32_t r = idx < 4 ? lo : hi; return (int)((r >> (8 * (idx & 3))) & 0xffu); };
+                const int v = b12(3 + b);
+                const int dN = v - b8(u0, u1, 3 + b);      // (0, +3)
+                const int dE = v - b12(6 + b);             // (+3, 0)
+                const int dS = v - b8(d0_, d1_, 3 + b);    // (0, -3)
+                const int dW = v - b12(b);                 // (-3, 0)
                 const int t = threshold;
-                const bool k0 = d0 > t, k4 = d4 > t, k8 = d8 > t, k12 = d12 > t;
-                const bool b0 = d0 < -t, b4 = d4 < -t, b8 = d8 < -t, b12 = d12 < -t;
-                pass = (k0 && k4) || (k4 && k8) || (k8 && k12) || (k12 && k0) || (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0);
+                const bool k0 = dN > t, k4 = dE > t, k8 = dS > t, k12 = dW > t;
+                const bool g0 = dN < -t, g4 = dE < -t, g8 = dS < -t, g12 = dW < -t;
+                pass = (k0 && k4) || (k4 && k8) || (k8 && k12) || (k12 && k0) || (g0 && g4) || (g4 && g8) || (g8 && g12) || (g12 && g0);
             }
             const unsigned long long bal = __ballot(pass);
             if (bal) {
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&n_cand, __popcll(bal));
                 base = __shfl(base, 0, 64);
-                if (pass) cand[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(ly * FT_W + 4 * lq + b);
+                if (pass) cand[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(ry * SCP + rx);
             }
         }
     }
     __syncthreads();
     // Phase 2: exact score of the survivors
     const int nc = n_cand;
-    for (int c = threadIdx.x; c < nc; c += 256) {
+    for (int c = tid; c < nc; c += 256) {
         const int p = cand[c];
-        const int ly = p / FT_W, lx = p % FT_W;
-        sc[p] = (uint8_t)fast_score_at(&tile[(ly + HALO) * TP + 4 + lx], TP, threshold);
+        const int ry = p / SCP, rx = p % SCP;
+        sc[p] = (uint8_t)fast_score_at(&tile[(ry + 3) * TP + rx + 3], TP, threshold);
     }
     __syncthreads();
-    // Phase 3: one 32-bit store per quad
+    // Phase 3: strict 3x3 maximum among the raw scores + RunByImageBorder; one 32-bit store per quad of the kept map
+    const int lo = border > 3 ? border : 3;
+    uint8_t* K = kept + (size_t)f * wp * h;
+    int mine = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int qi = threadIdx.x + 256 * i;
+        const int qi = tid + 256 * i;
         const int ly = qi / (FT_W / 4), lq = qi % (FT_W / 4);
         const int y = y0 + ly, xq = x0 + 4 * lq;
         if (y >= h || xq >= wp) continue;
-        *reinterpret_cast<uint32_t*>(Sc + (size_t)y * wp + xq) = *reinterpret_cast<const uint32_t*>(&sc[ly * FT_W + 4 * lq]);
+        const uint8_t* c0 = &sc[(ly + 1) * SCP + 4 * lq + 1];
+        uint32_t raw4 = 0, kept4 = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int s = c0[b];
+            raw4 |= (uint32_t)s << (8 * b);
+            const int x = xq + b;
+            if (s == 0 || x < lo || x >= w - lo || y < lo || y >= h - lo) continue;
+            const uint8_t* p = c0 + b;
+            const bool keep = s > p[-1] && s > p[1] && s > p[-SCP - 1] && s > p[-SCP] && s > p[-SCP + 1] && s > p[SCP - 1] && s > p[SCP] && s > p[SCP + 1];
+            if (keep) { kept4 |= (uint32_t)s << (8 * b); ++mine; atomicAdd(&lh[s], 1); }
+        }
+        *reinterpret_cast<uint32_t*>(K + (size_t)y * wp + xq) = kept4;
+        if (f == 0 && raw_frame0) *reinterpret_cast<uint32_t*>(raw_frame0 + (size_t)y * wp + xq) = raw4;
     }
+    if (mine) atomicAdd(&n_kept, mine);
+    __syncthreads();
+    if (lh[tid]) atomicAdd(&hist[f * 256 + tid], lh[tid]);
+    if (tid == 0 && n_kept) atomicAdd(&band_count[f * gridDim.y + blockIdx.y], n_kept);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -178,74 +206,6 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
 // raster segment); pass 1 counts (and builds the response histogram), pass 2 writes at the scanned offsets.
 // A thread examines 4 adjacent pixels from nine 32-bit loads.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int nms_quad(const uint8_t* __restrict__ Sc, int w, int h, int wp, int xq, int y, int border, int resp[4])
-{
-    // returns the 4-bit mask of kept keypoints among pixels xq..xq+3 of row y; resp[b] = their responses
-    const int lo = border > 3 ? border : 3;
-    resp[0] = resp[1] = resp[2] = resp[3] = 0;
-    if (y < lo || y >= h - lo) return 0;
-    const uint8_t* row = Sc + (size_t)y * wp + xq;
-    const uint32_t c = *reinterpret_cast<const uint32_t*>(row);
-    if (c == 0) return 0;
-    const uint32_t l = xq > 0 ? *reinterpret_cast<const uint32_t*>(row - 4) : 0u;
-    const uint32_t r = xq + 4 < wp ? *reinterpret_cast<const uint32_t*>(row + 4) : 0u;
-    const uint32_t cu = *reinterpret_cast<const uint32_t*>(row - wp), cd = *reinterpret_cast<const uint32_t*>(row + wp);
-    const uint32_t lu = xq > 0 ? *reinterpret_cast<const uint32_t*>(row - wp - 4) : 0u, ld_ = xq > 0 ? *reinterpret_cast<const uint32_t*>(row + wp - 4) : 0u;
-    const uint32_t ru = xq + 4 < wp ? *reinterpret_cast<const uint32_t*>(row - wp + 4) : 0u, rd = xq + 4 < wp ? *reinterpret_cast<const uint32_t*>(row + wp + 4) : 0u;
-    // 6 pixels per row: [l.b3, c.b0..b3, r.b0]
-    auto px = [](uint32_t lw, uint32_t cw, uint32_t rw, int i) -> int { return i == 0 ? (int)(lw >> 24) : i == 5 ? (int)(rw & 0xff) : (int)((cw >> (8 * (i - 1))) & 0xff); };
-    int mask = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int x = xq + b;
-        const int s = (int)((c >> (8 * b)) & 0xff);
-        if (s == 0 || x < lo || x >= w - lo) continue;
-        bool keep = s > px(l, c, r, b) && s > px(l, c, r, b + 2);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) keep = keep && s > px(lu, cu, ru, b + i) && s > px(ld_, cd, rd, b + i);
-        if (keep) { mask |= 1 << b; resp[b] = s; }
-    }
-    return mask;
-}
-
-__global__ __launch_bounds__(256) void k_nms_count(const uint8_t* __restrict__ score, int w, int h, int wp, int border, int rows_per_wg,
-                                                   int* __restrict__ wg_count, int* __restrict__ hist)
-{
-    __shared__ int lh[256];
-    __shared__ int cnt;
-    const int f = blockIdx.y, tid = threadIdx.x;
-    const uint8_t* Sc = score + (size_t)f * wp * h;
-    lh[tid] = 0;
-    if (tid == 0) cnt = 0;
-    __syncthreads();
-    const int y0 = blockIdx.x * rows_per_wg;
-    const int y1 = min(y0 + rows_per_wg, h);
-    const int qpr = wp / 4;
-    int c = 0;
-    // four consecutive quads (16 score bytes, one 128-bit load) per thread and iteration: the map is almost everywhere zero,
-    // so the pass is one wide coalesced read plus rare neighbourhood tests
-    const int q_end = y1 * qpr;
-    for (int q0 = y0 * qpr + 4 * tid; q0 < q_end; q0 += 1024) {
-        uint32_t c4[4] = { 0, 0, 0, 0 };
-        if (q0 + 3 < q_end) { const uint4 v = *reinterpret_cast<const uint4*>(Sc + (size_t)q0 * 4); c4[0] = v.x; c4[1] = v.y; c4[2] = v.z; c4[3] = v.w; }
-        else for (int j = 0; j < 4; ++j) if (q0 + j < q_end) c4[j] = *reinterpret_cast<const uint32_t*>(Sc + (size_t)(q0 + j) * 4);
-        if ((c4[0] | c4[1] | c4[2] | c4[3]) == 0u) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (c4[j] == 0u) continue;
-            const int q = q0 + j;
-            int resp[4];
-            const int m = nms_quad(Sc, w, h, wp, 4 * (q % qpr), q / qpr, border, resp);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) if (m & (1 << b)) { ++c; atomicAdd(&lh[resp[b]], 1); }
-        }
-    }
-    atomicAdd(&cnt, c);
-    __syncthreads();
-    if (lh[tid]) atomicAdd(&hist[f * 256 + tid], lh[tid]);
-    if (tid == 0) wg_count[f * gridDim.x + blockIdx.x] = cnt;
-}
-
 // exclusive scan of the per-workgroup counts of one frame (single wavefront per frame; n_wg is small)
 __global__ __launch_bounds__(64) void k_scan_counts(const int* __restrict__ wg_count, int n_wg, int* __restrict__ wg_off, int* __restrict__ n_raw)
 {
@@ -264,7 +224,7 @@ __global__ __launch_bounds__(64) void k_scan_counts(const int* __restrict__ wg_c
 }
 
 __global__ __launch_bounds__(256) void k_nms_emit(const uint8_t* __restrict__ score, int w, int h, int wp, int border, int rows_per_wg,
-                                                  const int* __restrict__ wg_off, int2* __restrict__ raw, size_t raw_cap)
+                                                  const int* __restrict__ wg_off, int2* __restrict__ raw, size_t raw_cap)   // score = the KEPT map of k_fast_nms
 {
     __shared__ int wave_cnt[4];
     __shared__ int base_s;
@@ -288,8 +248,9 @@ __global__ __launch_bounds__(256) void k_nms_emit(const uint8_t* __restrict__ sc
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (c4[j] == 0u) continue;
-                const int q = q0 + j;
-                m[j] = nms_quad(Sc, w, h, wp, 4 * (q % qpr), q / qpr, border, resp[j]);
+                // every non-zero byte of the kept map is a keypoint; its value is the response
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { resp[j][b] = (int)((c4[j] >> (8 * b)) & 0xffu); if (resp[j][b]) m[j] |= 1 << b; }
                 mine += __popc(m[j]);
             }
         }
@@ -726,18 +687,21 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
 
-void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, uint8_t* score, int wp, hipStream_t st)
+void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, int border, uint8_t* kept,
+                     uint8_t* raw_frame0, int wp, int* hist, int* band_count, int n_bands, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_fast_score, dim3(cdiv(wp, FT_W), cdiv(h, FT_H), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, threshold, score, wp);
+    // one tile row of k_fast_nms = one band of the emit pass: FT_H rows (orb_host.hip sizes n_bands with the same constant)
+    (void)hipMemsetAsync(hist, 0, sizeof(int) * 256 * (size_t)n_frames, st);
+    (void)hipMemsetAsync(band_count, 0, sizeof(int) * (size_t)n_bands * (size_t)n_frames, st);
+    hipLaunchKernelGGL(k_fast_nms, dim3(cdiv(wp, FT_W), cdiv(h, FT_H), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, threshold, border,
+                       kept, raw_frame0, wp, hist, band_count);
 }
 
-void orb_launch_collect(const uint8_t* score, int w, int h, int wp, int n_frames, int border, int rows_per_wg, int n_wg, int* wg_count, int* wg_off,
-                        int* hist, int* n_raw, int2* raw, size_t raw_cap, hipStream_t st)
+void orb_launch_collect(const uint8_t* kept, int w, int h, int wp, int n_frames, int border, int rows_per_wg, int n_wg, int* wg_count, int* wg_off,
+                        int* n_raw, int2* raw, size_t raw_cap, hipStream_t st)
 {
-    (void)hipMemsetAsync(hist, 0, sizeof(int) * 256 * (size_t)n_frames, st);
-    hipLaunchKernelGGL(k_nms_count, dim3(n_wg, n_frames), dim3(256), 0, st, score, w, h, wp, border, rows_per_wg, wg_count, hist);
     hipLaunchKernelGGL(k_scan_counts, dim3(n_frames), dim3(64), 0, st, wg_count, n_wg, wg_off, n_raw);
-    hipLaunchKernelGGL(k_nms_emit, dim3(n_wg, n_frames), dim3(256), 0, st, score, w, h, wp, border, rows_per_wg, wg_off, raw, raw_cap);
+    hipLaunchKernelGGL(k_nms_emit, dim3(n_wg, n_frames), dim3(256), 0, st, kept, w, h, wp, border, rows_per_wg, wg_off, raw, raw_cap);
 }
 
 void orb_launch_select(const OrbSelectArgs& a, int n_frames, hipStream_t st)
