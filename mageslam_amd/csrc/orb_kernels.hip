@@ -1,8 +1,8 @@
 // orb_kernels.hip -- HIP kernels (gfx950) of the ORB front-end; byte/integer HBM-bound work, no MFMA.
 //
 // Reference code replaced (Core/MAGESLAM/Source/Image/OpenCVModified.cpp):
-//   k_fast_score     FAST_t<16> segment test + cornerScore<16>            :926-1071, :1224-1486
-//   k_nms_count/emit 3x3 strict NMS in raster order + RunByImageBorder    :1488-1510, :619-639
+//   k_fast_nms       FAST_t<16> segment test + cornerScore<16> + 3x3 NMS  :926-1071, :1224-1510; RunByImageBorder :619-639
+//   k_nms_emit       raster-order keypoint list from the kept map         :1499-1510
 //   k_select         RetainBestFeatures + AdaptiveNonMaximalSuppresion    :571-617, :144-360
 //   k_blur           cv::GaussianBlur(k x k, sigma 2, REFLECT_101) on u8  :853-865 (OpenCV 3.4.0 fixed-point path)
 //   k_brief          ComputeOrbDescriptorsPrerotated                      :502-549
