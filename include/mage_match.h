@@ -77,7 +77,7 @@ mage_status mage_match_radius(mage_matcher* h, const mage_keypoint* query_keypoi
 
 /* IndexedMatch (Tracking/FeatureMatcher.cpp:192-292; TrackMatch :28-54): the two-way best / second-best test of Match, but every
  * descriptor is compared only with the candidates a vocabulary index returned for it (BaseBow::QueryFeatures(descriptor, keyframe) or
- * BaseFeatureMatcher::QueryFeatures(descriptor), BoW/*.h -- out of scope: the caller passes the lists).
+ * BaseFeatureMatcher::QueryFeatures(descriptor), in the BoW directory -- out of scope: the caller passes the lists).
  *   cand_b_offsets[nA + 1], cand_b[]  CSR: candidates (indices into B) of each A descriptor, in the order QueryFeatures returned them
  *   cand_a_offsets[nB + 1], cand_a[]  CSR: candidates (indices into A) of each B descriptor, used for the reverse check
  * Forward: an unmasked A descriptor keeps its best unmasked candidate when best < max_hamming_dist + 1 and either no second

@@ -21,7 +21,7 @@ namespace {
 // brighter rings; a pixel is a corner iff that maximum exceeds the threshold, and its score is maximum - 1
 // (identical to the reference's threshold-table pre-test + min/max ladder, which computes the same quantity).
 // ---------------------------------------------------------------------------------------------
-constexpr int FT_W = 64, FT_H = ORB_BAND_ROWS, HALO = 3;   // 2048 pixels per workgroup, 8 per thread (few, fat workgroups: dispatch is not free)
+constexpr int FT_W = 64, FT_H = ORB_BAND_ROWS;   // 2048 pixels per workgroup, 8 per thread (few, fat workgroups: dispatch is not free)
 
 __device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ c, int TP, int t)
 {
