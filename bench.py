@@ -133,7 +133,7 @@ def main() -> int:
                                    f"Huber {HUBER}, poses 0,1 fixed, one independent sub-map per GPU",
                        "parallelism": f"replica x{world} (independent sub-maps)"},
             "roofline": {
-                "kernel": "dense reduced-camera Cholesky (k_potrf_diag + k_trsm_panel + k_syrk_update[f64 MFMA] + k_bsolve_step), "
+                "kernel": "dense reduced-camera Cholesky (k_potrf_diag + k_trsm_panel + k_syrk_update[f64 MFMA] + k_bsolve_persist), "
                           "HIP-event span per factorisation on the solver stream",
                 "bound": "mfma", "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": traffic,
