@@ -518,14 +518,17 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
     mage_ba_iter_stats tr{};
     ba_launch_error(v, false, huber, st);
     ba_launch_linearize(v, huber, st);
-    if (h->iteration == 0) ba_launch_maxdiag(v, st);
-    MAGE_TRY(read_scalars(h));
-    double currentChi = h->h_scal[SC_CHI];
-    tr.chi2_before = currentChi;
+    // The chi2 of the current estimate is only needed on the host together with the first trial's (rho); it has its own
+    // scalar slot, so after the first iteration of a run no host round trip separates linearisation from the solve.
+    // Iteration 0 needs max |diag| on the host to seed lambda.
     if (h->iteration == 0) {
+        ba_launch_maxdiag(v, st);
+        MAGE_TRY(read_scalars(h));
         h->lambda = h->user_lambda > 0 ? h->user_lambda : 1e-5 * h->h_scal[SC_MAXDIAG];
         h->ni = 2;
     }
+    double currentChi = 0;
+    bool have_chi = false;
     double rho = 0;
     int qmax = 0;
     CholWorkspace ws{ h->d_Linv.p, h->d_queue.p };
@@ -547,7 +550,8 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
             h->prof.factor_ms_total += ms; h->prof.n_factorizations++;
         }
         const bool ok2 = h->h_scal[SC_CHOL_OK] != 0.0;
-        double tempChi = h->h_scal[SC_CHI];
+        if (!have_chi) { currentChi = h->h_scal[SC_CHI]; tr.chi2_before = currentChi; have_chi = true; }
+        double tempChi = h->h_scal[SC_CHI_TRIAL];
         if (!ok2) { tempChi = DBL_MAX; rho = -1.0; }       // the reference's failed-solve branch: always rejected
         else {
             const double scale = h->h_scal[SC_SCALE] + 1e-3;

@@ -71,10 +71,11 @@ struct BaDeviceView {
 enum TetherKind { TETHER_DISTANCE = 0, TETHER_ROTATION = 1, TETHER_TRANSFORM = 2 };
 constexpr int TETHER_OUT_STRIDE = 120;
 
-enum Scal { SC_CHI = 0, SC_SCALE = 1, SC_MAXDIAG = 2, SC_CHOL_OK = 3, SC_ERRSUM = 4, SC_ERRCNT = 5, SC_NOUT = 6, SC_COUNT = 8 };
+// SC_CHI: robust chi2 of the current estimate; SC_CHI_TRIAL: of the LM candidate (separate slots: one host read fetches both)
+enum Scal { SC_CHI = 0, SC_SCALE = 1, SC_MAXDIAG = 2, SC_CHOL_OK = 3, SC_ERRSUM = 4, SC_ERRCNT = 5, SC_NOUT = 6, SC_CHI_TRIAL = 7, SC_COUNT = 8 };
 
 // All launchers enqueue on `st` and return immediately.
-void ba_launch_error(const BaDeviceView& v, bool trial, double huber_delta, hipStream_t st);         // -> scal[SC_CHI]
+void ba_launch_error(const BaDeviceView& v, bool trial, double huber_delta, hipStream_t st);         // -> scal[SC_CHI] / scal[SC_CHI_TRIAL]
 void ba_launch_linearize(const BaDeviceView& v, double huber_delta, hipStream_t st);                 // U,bc,V,bp,W
 void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st);                                       // -> scal[SC_MAXDIAG]
 void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st);                          // Dinv,db,S,y
@@ -82,7 +83,7 @@ void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st);    
 void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flag_by_edge, hipStream_t st); // scal[SC_ERRSUM..SC_NOUT]
 
 // tether_kernels.hip (called by the launchers above when the problem carries tethers)
-void tether_launch_error(const BaDeviceView& v, bool trial, hipStream_t st);      // scal[SC_CHI] += tether chi2
+void tether_launch_error(const BaDeviceView& v, bool trial, hipStream_t st);      // same slot += tether chi2
 void tether_launch_linearize(const BaDeviceView& v, hipStream_t st);              // U, bc += tether blocks
 void tether_launch_schur(const BaDeviceView& v, hipStream_t st);                  // S += pose-pose blocks
 

@@ -589,7 +589,7 @@ void ba_launch_error(const BaDeviceView& v, bool trial, double delta, hipStream_
 {
     int nb = v.n_L > 0 ? (cdiv(v.n_L, 256) < RED_BLOCKS ? cdiv(v.n_L, 256) : RED_BLOCKS) : 1;
     hipLaunchKernelGGL(k_error, dim3(nb), dim3(256), 0, st, v, trial ? 1 : 0, delta, nb);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_CHI, 1);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb, 1, v.scal + (trial ? SC_CHI_TRIAL : SC_CHI), 1);
     tether_launch_error(v, trial, st);
 }
 

@@ -228,7 +228,7 @@ __device__ __forceinline__ double t_block_sum(double v, double* sm)
     return r;
 }
 
-// chi2 of the active tethers, added to scal[SC_CHI] (which k_reduce_sum has just written on the same stream)
+// chi2 of the active tethers, added to the chi2 slot k_reduce_sum has just written on the same stream
 __global__ __launch_bounds__(256) void k_tether_error(BaDeviceView v, int trial)
 {
     __shared__ double sm[4];
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void k_tether_error(BaDeviceView v, int trial)
         acc += t_chi2(m, err);
     }
     const double r = t_block_sum<4>(acc, sm);
-    if (threadIdx.x == 0) v.scal[SC_CHI] += r;
+    if (threadIdx.x == 0) v.scal[trial ? SC_CHI_TRIAL : SC_CHI] += r;
 }
 
 // linearizeOplus + constructQuadraticForm of one tether per thread -> T_out[t] = H00 | H11 | H01 | b0 | b1
