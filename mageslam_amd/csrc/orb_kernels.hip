@@ -23,36 +23,63 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 constexpr int FT_W = 64, FT_H = ORB_BAND_ROWS;   // 2048 pixels per workgroup, 8 per thread (few, fat workgroups: dispatch is not free)
 
+// The ring differences fit 16 bits, so the score runs on PACKED pairs: register k holds (d[k], d[k + 8]) -- a ring pixel and its
+// opposite.  A rotation of the ring by one position is "next register", and crossing position 7 -> 8 is a swap of the halves,
+// so every windowed minimum / maximum (v_pk_min_i16 / v_pk_max_i16) serves two ring positions at once: ~100 operations where
+// the 32-bit form needs ~180.
+typedef short short2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ short2_t swap16(short2_t v) { return __builtin_shufflevector(v, v, 1, 0); }
+__device__ __forceinline__ short2_t pmin(short2_t a, short2_t b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ short2_t pmax(short2_t a, short2_t b) { return __builtin_elementwise_max(a, b); }
+
 __device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ c, int TP, int t)
 {
     const int v = c[0];
     const int ox[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
     const int oy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
-    int d[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) d[k] = v - (int)c[oy[k] * TP + ox[k]];
-    // high-speed pre-test (a 9-arc always contains one pixel of every opposite pair)
-    bool dark = true, bright = true;
+    short2_t P[8], Q[8];                                  // P[k] = (d[k], d[k+8]),  Q[k] = swapped = (d[k+8], d[k])
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        dark = dark && (d[k] > t || d[k + 8] > t);
-        bright = bright && (d[k] < -t || d[k + 8] < -t);
+        const int lo = v - (int)c[oy[k] * TP + ox[k]], hi = v - (int)c[oy[k + 8] * TP + ox[k + 8]];
+        P[k] = (short2_t){ (short)lo, (short)hi };
+        Q[k] = (short2_t){ (short)hi, (short)lo };
     }
-    if (!(dark || bright)) return 0;
-    int m = -1000;
-    // windowed minima / maxima by doubling: 2, 4, 8, then 9
-    int a2[16], a4[16], a8[16], b2[16], b4[16], b8[16];
+    // high-speed pre-test (a 9-arc always contains one pixel of every opposite pair): every pair needs a member > t (darker
+    // ring) or every pair a member < -t (brighter ring)
+    short2_t mx = pmax(P[0], Q[0]), mn = pmin(P[0], Q[0]);          // both halves equal: max / min of the pair
+    short2_t all_dark = mx, all_bright = mn;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { a2[k] = min(d[k], d[(k + 1) & 15]); b2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { a4[k] = min(a2[k], a2[(k + 2) & 15]); b4[k] = max(b2[k], b2[(k + 2) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { a8[k] = min(a4[k], a4[(k + 4) & 15]); b8[k] = max(b4[k], b4[(k + 4) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        m = max(m, min(a8[k], d[(k + 8) & 15]));        // darker ring: min of (v - ring) over the arc
-        m = max(m, -max(b8[k], d[(k + 8) & 15]));       // brighter ring: min of (ring - v) over the arc
+    for (int k = 1; k < 8; ++k) {
+        all_dark = pmin(all_dark, pmax(P[k], Q[k]));                 // smallest pair-maximum
+        all_bright = pmax(all_bright, pmin(P[k], Q[k]));             // largest pair-minimum
     }
+    if (!((int)all_dark.x > t || (int)all_bright.x < -t)) return 0;
+    // windowed minima / maxima by doubling: windows of 2, 4, 8 ring positions, then 9
+    short2_t A2[8], B2[8], A4[8], B4[8], A8[8], B8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const short2_t nx = k < 7 ? P[k + 1] : Q[0];                 // positions k+1 and k+9
+        A2[k] = pmin(P[k], nx); B2[k] = pmax(P[k], nx);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const short2_t na = k < 6 ? A2[k + 2] : swap16(A2[k - 6]), nb = k < 6 ? B2[k + 2] : swap16(B2[k - 6]);
+        A4[k] = pmin(A2[k], na); B4[k] = pmax(B2[k], nb);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const short2_t na = k < 4 ? A4[k + 4] : swap16(A4[k - 4]), nb = k < 4 ? B4[k + 4] : swap16(B4[k - 4]);
+        A8[k] = pmin(A4[k], na); B8[k] = pmax(B4[k], nb);
+    }
+    // arcs of 9: window of 8 starting at k plus position k + 8 (the opposite pixel = the swapped pair)
+    short2_t dark = pmin(A8[0], Q[0]), bright = pmax(B8[0], Q[0]);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        dark = pmax(dark, pmin(A8[k], Q[k]));          // darker ring: largest arc minimum of (v - ring)
+        bright = pmin(bright, pmax(B8[k], Q[k]));      // brighter ring: smallest arc maximum of (v - ring)
+    }
+    const int m = max(max((int)dark.x, (int)dark.y), -min((int)bright.x, (int)bright.y));
     return m > t ? m - 1 : 0;
 }
 
