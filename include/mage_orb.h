@@ -41,7 +41,9 @@ typedef struct mage_orb_params {
     unsigned gaussian_kernel_size;   /* 7 */
     unsigned nfeatures;              /* 440 */
     float    scale_factor;           /* 1.5 (unused with one level) */
-    unsigned nlevels;                /* 1; > 1 -> MAGE_ERR_UNSUPPORTED (cv::resize pyramid) */
+    unsigned nlevels;                /* 1 (default) .. 16: cv::resize(INTER_LINEAR) pyramid with per-level quotas (OpenCVModified.cpp:659-669, 793-841);
+                                        every level is blurred as an ISOLATED image -- the reference's in-place ROI blur reads the neighbouring level or
+                                        uninitialised memory at the borders, which cannot be restated (pinned deviation) */
     unsigned patch_size;             /* 15 or 31 (pre-rotated tables); others -> MAGE_ERR_UNSUPPORTED */
     unsigned fast_threshold;         /* 4 */
     int      use_orientation;        /* 0 (default) or 1: ICAngles orientation + rotated BRIEF rows (OpenCVModified.cpp:399-437, 523-532) */

@@ -77,7 +77,9 @@ struct mage_orb {
     DevBuf<uint8_t> d_img, d_score, d_rawscore, d_blur, d_desc;     // d_score: kept map (NMS survivors); d_rawscore: FAST scores of frame 0 (parity tests)
     DevBuf<int> d_wg_count, d_wg_off, d_hist, d_n_raw, d_cell_start, d_cell_fill, d_cell_members, d_radius, d_count;
     DevBuf<int2> d_raw, d_cand;
-    DevBuf<mage_keypoint> d_kp, d_undist;
+    DevBuf<mage_keypoint> d_kp, d_undist, d_kp_lvl;
+    DevBuf<uint8_t> d_pyr[2], d_blur_lvl, d_desc_lvl;      // pyramid levels >= 1 (ping-pong), their blurred image and per-level outputs
+    DevBuf<int> d_count_lvl;
     hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     mage_orb_profile prof{};
     int last_w = 0, last_h = 0;
@@ -104,7 +106,8 @@ MAGE_EXPORT mage_status mage_orb_create(const mage_orb_params* params, mage_orb*
         if (!out || !params) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
         *out = nullptr;
         const mage_orb_params& p = *params;
-        if (p.nlevels != 1) return fail(MAGE_ERR_UNSUPPORTED, "NumLevels = %u: the cv::resize pyramid is not built yet (SURVEY.md 8f rank 4)", p.nlevels);
+        if (p.nlevels < 1 || p.nlevels > ORB_MAX_LEVELS) return fail(MAGE_ERR_INVALID_ARGUMENT, "NumLevels = %u: 1 .. %d supported", p.nlevels, ORB_MAX_LEVELS);
+        if (p.nlevels > 1 && !(p.scale_factor > 1.0f)) return fail(MAGE_ERR_INVALID_ARGUMENT, "a pyramid needs ScaleFactor > 1");
         if (p.patch_size != 15 && p.patch_size != 31) return fail(MAGE_ERR_UNSUPPORTED, "patch size %u: only the pre-rotated 15 / 31 tables are built", p.patch_size);
         if (p.gaussian_kernel_size > 15 || (p.gaussian_kernel_size > 1 && p.gaussian_kernel_size % 2 == 0))
             return fail(MAGE_ERR_INVALID_ARGUMENT, "Gaussian kernel size must be odd and <= 15");
@@ -133,22 +136,28 @@ namespace {
 
 constexpr int NMS_ROWS = ORB_BAND_ROWS;
 
-// runs the five stages on n_frames images that are already in HBM; leaves keypoints / descriptors / counts in HBM
-mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w, int h_img, int stride, size_t frame_stride, int capacity)
+// Where one level's stages leave their results and with which quota.
+struct LevelIO {
+    int nfeatures;            // quota of the level (ComputeKeyPoints: nfeaturesPerLevel)
+    int capacity;             // records per frame in kp / desc
+    mage_keypoint* kp; uint8_t* desc; int* count;
+    uint8_t* blur;            // blurred level image (pitch wp)
+    uint8_t* raw_frame0;      // FAST scores of frame 0 (level 0 only; parity tests) or null
+    bool record_events;
+};
+
+// runs the five stages on n_frames images of one pyramid level that are already in HBM
+mage_status run_level(mage_orb* h, const uint8_t* d_images, int n_frames, int w, int h_img, int stride, size_t frame_stride, const LevelIO& io)
 {
     const mage_orb_params& P = h->P;
-    if (w < 1 || h_img < 1 || w > 65535 || h_img > 32767) return fail(MAGE_ERR_INVALID_ARGUMENT, "image size %dx%d out of range", w, h_img);
-    if (capacity < 0 || n_frames < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative capacity / frame count");
     hipStream_t st = h->stream;
     const int wp = (w + 3) & ~3;                     // internal row pitch (score map, blurred image)
     const size_t npx = (size_t)wp * h_img;
     const size_t raw_cap = (size_t)w * h_img / 4 + 16;
     const int n_wg = (h_img + NMS_ROWS - 1) / NMS_ROWS;
     const int ncells = P.num_cells_x * P.num_cells_y;
-    const size_t nf = (size_t)std::max(n_frames, 1), cap = (size_t)std::max(capacity, 1);
+    const size_t nf = (size_t)std::max(n_frames, 1);
     MAGE_TRY(h->d_score.reserve(nf * npx));
-    MAGE_TRY(h->d_rawscore.reserve(npx));
-    MAGE_TRY(h->d_blur.reserve(nf * npx));
     MAGE_TRY(h->d_wg_count.reserve(nf * n_wg));
     MAGE_TRY(h->d_wg_off.reserve(nf * n_wg));
     MAGE_TRY(h->d_hist.reserve(nf * 256));
@@ -159,6 +168,54 @@ mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     MAGE_TRY(h->d_cell_fill.reserve(nf * (ncells + 1)));
     MAGE_TRY(h->d_cell_members.reserve(nf * raw_cap));
     MAGE_TRY(h->d_radius.reserve(nf * raw_cap));
+
+    if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[0], st));
+    // RunByImageBorder: half the patch, or its hypotenuse when the patch gets rotated (OpenCVModified.cpp:709-712)
+    const int half_patch = (int)P.patch_size / 2;
+    const int border = P.use_orientation ? (int)std::ceil((float)half_patch * std::sqrt(2.0f)) : half_patch;
+    orb_launch_fast(d_images, w, h_img, stride, frame_stride, n_frames, (int)std::min(P.fast_threshold, 255u), border, h->d_score.p, io.raw_frame0, wp,
+                    h->d_hist.p, h->d_wg_count.p, n_wg, st);
+    if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[1], st));
+    orb_launch_collect(h->d_score.p, w, h_img, wp, n_frames, border, NMS_ROWS, n_wg, h->d_wg_count.p, h->d_wg_off.p, h->d_n_raw.p, h->d_raw.p, raw_cap, st);
+    OrbSelectArgs a{};
+    a.raw = h->d_raw.p; a.n_raw = h->d_n_raw.p; a.hist = h->d_hist.p;
+    a.cand = h->d_cand.p; a.cell_start = h->d_cell_start.p; a.cell_fill = h->d_cell_fill.p; a.cell_members = h->d_cell_members.p; a.radius = h->d_radius.p;
+    a.out_kp = io.kp; a.out_count = io.count;
+    a.raw_cap = raw_cap; a.ncells = ncells; a.cells_x = P.num_cells_x; a.cells_y = P.num_cells_y;
+    a.nfeatures = io.nfeatures; a.max_num = (int)((float)io.nfeatures * P.feature_factor_anms);
+    a.fast_threshold = (int)P.fast_threshold; a.strong_response = P.strong_response_anms; a.capacity = io.capacity; a.patch_size = (int)P.patch_size;
+    a.feature_strength = P.feature_strength_anms; a.min_robust = P.min_robust_factor; a.max_robust = P.max_robust_factor;
+    orb_launch_select(a, n_frames, st);
+    if (P.use_orientation && io.capacity > 0) {          // ICAngles on the unblurred image (:745-748)
+        OrbUmax um{};
+        um.half = half_patch;
+        const int vmax = (int)std::floor((float)half_patch * std::sqrt(2.f) / 2 + 1), vmin = (int)std::ceil((float)half_patch * std::sqrt(2.f) / 2);
+        for (int v = 0; v <= vmax; ++v) um.umax[v] = (int)std::nearbyint(std::sqrt((double)half_patch * half_patch - (double)v * v));
+        for (int v = half_patch, v0 = 0; v >= vmin; --v) { while (um.umax[v0] == um.umax[v0 + 1]) ++v0; um.umax[v] = v0; ++v0; }
+        orb_launch_angles(d_images, stride, frame_stride, n_frames, io.kp, io.count, io.capacity, um, st);
+    }
+    if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[2], st));
+    orb_launch_blur(d_images, w, h_img, stride, frame_stride, n_frames, h->taps, io.blur, wp, st);
+    if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[3], st));
+    if (io.capacity > 0) orb_launch_brief(io.blur, wp, h_img, n_frames, io.kp, io.count, io.capacity, h->d_pattern.p, io.desc, st);
+    if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[4], st));
+    return MAGE_OK;
+}
+
+// DetectAndCompute on n_frames images that are already in HBM; leaves keypoints / descriptors / counts in HBM.
+// One level: the stages write the final buffers directly.  A pyramid (OpenCVModified.cpp:793-841): level l is cv::resize of level
+// l - 1, every level runs the same stages with its own quota into level buffers, and k_append_level concatenates the levels per
+// frame (ImageData::Insert), scaling the coordinates by the level's scale (:756-760).
+mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w, int h_img, int stride, size_t frame_stride, int capacity)
+{
+    const mage_orb_params& P = h->P;
+    if (w < 1 || h_img < 1 || w > 65535 || h_img > 32767) return fail(MAGE_ERR_INVALID_ARGUMENT, "image size %dx%d out of range", w, h_img);
+    if (capacity < 0 || n_frames < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative capacity / frame count");
+    hipStream_t st = h->stream;
+    const size_t nf = (size_t)std::max(n_frames, 1), cap = (size_t)std::max(capacity, 1);
+    const int wp0 = (w + 3) & ~3;
+    MAGE_TRY(h->d_blur.reserve(nf * (size_t)wp0 * h_img));
+    MAGE_TRY(h->d_rawscore.reserve((size_t)wp0 * h_img));
     MAGE_TRY(h->d_kp.reserve(nf * cap));
     MAGE_TRY(h->d_desc.reserve(nf * cap * 32));
     MAGE_TRY(h->d_count.reserve(nf));
@@ -166,37 +223,54 @@ mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     h->prof = mage_orb_profile{};
     h->prof.n_frames = n_frames;
     if (n_frames == 0) return MAGE_OK;
-
-    MAGE_HIP(hipEventRecord(h->ev[0], st));
-    // RunByImageBorder: half the patch, or its hypotenuse when the patch gets rotated (OpenCVModified.cpp:709-712)
-    const int half_patch = (int)P.patch_size / 2;
-    const int border = P.use_orientation ? (int)std::ceil((float)half_patch * std::sqrt(2.0f)) : half_patch;
-    orb_launch_fast(d_images, w, h_img, stride, frame_stride, n_frames, (int)std::min(P.fast_threshold, 255u), border, h->d_score.p, h->d_rawscore.p, wp,
-                    h->d_hist.p, h->d_wg_count.p, n_wg, st);
-    MAGE_HIP(hipEventRecord(h->ev[1], st));
-    orb_launch_collect(h->d_score.p, w, h_img, wp, n_frames, border, NMS_ROWS, n_wg, h->d_wg_count.p, h->d_wg_off.p, h->d_n_raw.p, h->d_raw.p, raw_cap, st);
-    OrbSelectArgs a{};
-    a.raw = h->d_raw.p; a.n_raw = h->d_n_raw.p; a.hist = h->d_hist.p;
-    a.cand = h->d_cand.p; a.cell_start = h->d_cell_start.p; a.cell_fill = h->d_cell_fill.p; a.cell_members = h->d_cell_members.p; a.radius = h->d_radius.p;
-    a.out_kp = h->d_kp.p; a.out_count = h->d_count.p;
-    a.raw_cap = raw_cap; a.ncells = ncells; a.cells_x = P.num_cells_x; a.cells_y = P.num_cells_y;
-    a.nfeatures = (int)P.nfeatures; a.max_num = (int)((float)P.nfeatures * P.feature_factor_anms);
-    a.fast_threshold = (int)P.fast_threshold; a.strong_response = P.strong_response_anms; a.capacity = capacity; a.patch_size = (int)P.patch_size;
-    a.feature_strength = P.feature_strength_anms; a.min_robust = P.min_robust_factor; a.max_robust = P.max_robust_factor;
-    orb_launch_select(a, n_frames, st);
-    if (P.use_orientation && capacity > 0) {             // ICAngles on the unblurred image (:745-748)
-        OrbUmax um{};
-        um.half = half_patch;
-        const int vmax = (int)std::floor((float)half_patch * std::sqrt(2.f) / 2 + 1), vmin = (int)std::ceil((float)half_patch * std::sqrt(2.f) / 2);
-        for (int v = 0; v <= vmax; ++v) um.umax[v] = (int)std::nearbyint(std::sqrt((double)half_patch * half_patch - (double)v * v));
-        for (int v = half_patch, v0 = 0; v >= vmin; --v) { while (um.umax[v0] == um.umax[v0 + 1]) ++v0; um.umax[v] = v0; ++v0; }
-        orb_launch_angles(d_images, stride, frame_stride, n_frames, h->d_kp.p, h->d_count.p, capacity, um, st);
+    const int L = (int)P.nlevels;
+    if (L == 1) {
+        LevelIO io{ (int)P.nfeatures, capacity, h->d_kp.p, h->d_desc.p, h->d_count.p, h->d_blur.p, h->d_rawscore.p, true };
+        return run_level(h, d_images, n_frames, w, h_img, stride, frame_stride, io);
     }
-    MAGE_HIP(hipEventRecord(h->ev[2], st));
-    orb_launch_blur(d_images, w, h_img, stride, frame_stride, n_frames, h->taps, h->d_blur.p, wp, st);
-    MAGE_HIP(hipEventRecord(h->ev[3], st));
-    if (capacity > 0) orb_launch_brief(h->d_blur.p, wp, h_img, n_frames, h->d_kp.p, h->d_count.p, capacity, h->d_pattern.p, h->d_desc.p, st);
-    MAGE_HIP(hipEventRecord(h->ev[4], st));
+    // pyramid layout (:564-567, :797-799) and per-level quotas (:659-669), in the reference's float arithmetic
+    int lw[ORB_MAX_LEVELS], lh[ORB_MAX_LEVELS], quota[ORB_MAX_LEVELS];
+    float lscale[ORB_MAX_LEVELS];
+    for (int l = 0; l < L; ++l) {
+        lscale[l] = (float)std::pow((double)P.scale_factor, (double)l);
+        lw[l] = (int)std::nearbyint((float)w / lscale[l]); lh[l] = (int)std::nearbyint((float)h_img / lscale[l]);
+    }
+    {
+        const float factor = 1.0f / P.scale_factor;
+        float ndesired = (float)P.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)L));
+        int sum = 0;
+        for (int l = 0; l < L - 1; ++l) { quota[l] = (int)std::nearbyint(ndesired); sum += quota[l]; ndesired *= factor; }
+        quota[L - 1] = std::max((int)P.nfeatures - sum, 0);
+    }
+    MAGE_HIP(hipEventRecord(h->ev[0], st));
+    MAGE_HIP(hipMemsetAsync(h->d_count.p, 0, sizeof(int) * nf, st));
+    const uint8_t* src = d_images; int sw = w, sh = h_img, sstride = stride; size_t sfs = frame_stride;
+    for (int l = 0; l < L; ++l) {
+        const uint8_t* img_l = src; int stride_l = sstride; size_t fs_l = sfs;
+        if (l > 0) {
+            if (lw[l] < 1 || lh[l] < 1) break;
+            DevBuf<uint8_t>& dst = h->d_pyr[l & 1];
+            const int pitch = (lw[l] + 3) & ~3;
+            MAGE_TRY(dst.reserve(nf * (size_t)pitch * lh[l]));
+            orb_launch_resize(src, sw, sh, sstride, sfs, dst.p, lw[l], lh[l], pitch, (size_t)pitch * lh[l], n_frames, st);
+            img_l = dst.p; stride_l = pitch; fs_l = (size_t)pitch * lh[l];
+        }
+        if (lw[l] >= 7 && lh[l] >= 7 && quota[l] >= 1) {     // a level without quota places nothing (the reference would assert in ANMS)
+            const int cap_l = quota[l];
+            const int wp = (lw[l] + 3) & ~3;
+            MAGE_TRY(h->d_kp_lvl.reserve(nf * (size_t)cap_l));
+            MAGE_TRY(h->d_desc_lvl.reserve(nf * (size_t)cap_l * 32));
+            MAGE_TRY(h->d_count_lvl.reserve(nf));
+            uint8_t* blur = h->d_blur.p;
+            if (l > 0) { MAGE_TRY(h->d_blur_lvl.reserve(nf * (size_t)wp * lh[l])); blur = h->d_blur_lvl.p; }
+            LevelIO io{ quota[l], quota[l], h->d_kp_lvl.p, h->d_desc_lvl.p, h->d_count_lvl.p, blur, l == 0 ? h->d_rawscore.p : nullptr, false };
+            MAGE_TRY(run_level(h, img_l, n_frames, lw[l], lh[l], stride_l, fs_l, io));
+            orb_launch_append_level(h->d_kp_lvl.p, h->d_desc_lvl.p, h->d_count_lvl.p, quota[l], h->d_kp.p, h->d_desc.p, h->d_count.p, capacity, n_frames,
+                                    lscale[l], (float)P.patch_size * lscale[l], l, st);
+        }
+        src = img_l; sw = lw[l]; sh = lh[l]; sstride = stride_l; sfs = fs_l;
+    }
+    for (int e = 1; e <= 4; ++e) MAGE_HIP(hipEventRecord(h->ev[e], st));     // stage split is not recorded for pyramids: total only
     return MAGE_OK;
 }
 
@@ -208,6 +282,7 @@ mage_status collect_profile(mage_orb* h)
     MAGE_HIP(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); h->prof.blur_ms = ms;
     MAGE_HIP(hipEventElapsedTime(&ms, h->ev[3], h->ev[4])); h->prof.brief_ms = ms;
     MAGE_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[4])); h->prof.total_ms = ms;
+    if (h->P.nlevels > 1) h->prof.fast_ms = h->prof.select_ms = h->prof.blur_ms = h->prof.brief_ms = 0;     // pyramids record the total only
     return MAGE_OK;
 }
 

@@ -21,12 +21,18 @@ struct OrbSelectArgs {
 };
 
 // wp = internal row pitch of the score map / blurred image (w rounded up to 4)
+constexpr int ORB_MAX_LEVELS = 16;   // pyramid depth accepted by mage_orb_create
 constexpr int ORB_BAND_ROWS = 32;    // image rows per tile row of k_fast_nms = per band of the raster-order emit pass
 // FAST + NMS + border cull: kept map (score where a keypoint survives), raw scores of frame 0 (optional), histogram, per-band counts
 void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, int border, uint8_t* kept,
                      uint8_t* raw_frame0, int wp, int* hist, int* band_count, int n_bands, hipStream_t st);
 void orb_launch_collect(const uint8_t* kept, int w, int h, int wp, int n_frames, int border, int rows_per_wg, int n_wg, int* wg_count, int* wg_off,
                         int* n_raw, int2* raw, size_t raw_cap, hipStream_t st);
+// cv::resize(INTER_LINEAR) of n_frames u8 images (OpenCV 3.4.0 fixed-point arithmetic) and the per-frame concatenation of a level's results
+void orb_launch_resize(const uint8_t* src, int sw, int sh, int sstride, size_t sframe, uint8_t* dst, int dw, int dh, int dpitch, size_t dframe, int n_frames,
+                       hipStream_t st);
+void orb_launch_append_level(const mage_keypoint* kp_l, const uint8_t* desc_l, const int* count_l, int cap_l, mage_keypoint* kp, uint8_t* desc, int* count,
+                             int capacity, int n_frames, float scale, float size, int level, hipStream_t st);
 void orb_launch_select(const OrbSelectArgs& a, int n_frames, hipStream_t st);
 void orb_launch_blur(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, const OrbTaps& taps, uint8_t* out, int wp, hipStream_t st);
 struct OrbUmax { int half; int umax[18]; };         // row extents of the orientation disc, half <= 15 (OpenCVModified.cpp:672-688)

@@ -640,6 +640,72 @@ __global__ void k_copy_image(const uint8_t* __restrict__ img, int w, int h, int 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pyramid levels >= 1: cv::resize(prev, level, INTER_LINEAR) on CV_8UC1 as OpenCV 3.4.0 computes it (resize.cpp, HResizeLinear /
+// VResizeLinear<uchar, int, short>): source position and weights in float from a double scale, weights rounded to 11-bit fixed
+// point, horizontal pass in int, vertical pass (((b0 (S0 >> 4)) >> 16) + ((b1 (S1 >> 4)) >> 16) + 2) >> 2.  Four output pixels per
+// thread (one 32-bit store); contraction off, the position arithmetic must round like the CPU restatement.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sat_short_dev(float v)
+{
+    const int r = (int)rintf(v);
+    return r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
+}
+
+__global__ __launch_bounds__(64) void k_resize_linear(const uint8_t* __restrict__ src, int sw, int sh, int sstride, size_t sframe,
+                                                      uint8_t* __restrict__ dst, int dw, int dh, int dpitch, size_t dframe)
+{
+#pragma clang fp contract(off)
+    const int f = blockIdx.z, dy = blockIdx.y, q = blockIdx.x * 64 + threadIdx.x;
+    if (4 * q >= dpitch) return;
+    const uint8_t* S = src + (size_t)f * sframe;
+    const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    const int b0 = sat_short_dev((1.f - fy) * 2048), b1 = sat_short_dev(fy * 2048);
+    const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
+    const uint8_t* S0r = S + (size_t)r0 * sstride; const uint8_t* S1r = S + (size_t)r1 * sstride;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int dx = 4 * q + b;
+        if (dx >= dw) continue;
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= (float)sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        const int a0 = sat_short_dev((1.f - fx) * 2048), a1 = sat_short_dev(fx * 2048);
+        const int sx1 = min(sx + 1, sw - 1);
+        const int H0 = (int)S0r[sx] * a0 + (int)S0r[sx1] * a1, H1 = (int)S1r[sx] * a0 + (int)S1r[sx1] * a1;
+        const int v = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2;
+        packed |= (uint32_t)(v & 0xff) << (8 * b);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)f * dframe + (size_t)dy * dpitch + 4 * q) = packed;
+}
+
+// ImageData::Insert of one level's keypoints behind those of the coarser... finer levels (ImageData.h:65-70, OpenCVModified.cpp:731-737):
+// copy what still fits, coordinates scaled to the full-resolution frame (:756-760), octave and size stamped (:713-717).
+__global__ __launch_bounds__(256) void k_append_level(const mage_keypoint* __restrict__ kp_l, const uint8_t* __restrict__ desc_l, const int* __restrict__ count_l,
+                                                      int cap_l, mage_keypoint* __restrict__ kp, uint8_t* __restrict__ desc, int* __restrict__ count, int capacity,
+                                                      float scale, float size, int level)
+{
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int n = min(count_l[f], cap_l), base = count[f];
+    const int take = min(n, max(capacity - base, 0));
+    for (int i = tid; i < take; i += 256) {
+        mage_keypoint k = kp_l[(size_t)f * cap_l + i];
+        k.x = k.x * scale; k.y = k.y * scale; k.size = size; k.octave = level;
+        kp[(size_t)f * capacity + base + i] = k;
+    }
+    const uint32_t* dsrc = reinterpret_cast<const uint32_t*>(desc_l + (size_t)f * cap_l * 32);
+    uint32_t* ddst = reinterpret_cast<uint32_t*>(desc + ((size_t)f * capacity + base) * 32);
+    for (int i = tid; i < take * 8; i += 256) ddst[i] = dsrc[i];
+    __syncthreads();
+    if (tid == 0) count[f] = base + take;
+}
+
+// ---------------------------------------------------------------------------------------------
 // ICAngles (OpenCVModified.cpp:399-437), only with UseOrientation: first moments of the UNBLURRED image over the discretised
 // disc of radius half (row v spans |u| <= umax[v]); one wavefront per keypoint, lanes over the (2 half + 1)^2 window, exact
 // integer sums (order-free), then cv::fastAtan2 in float32 with contraction off.
@@ -740,6 +806,18 @@ void orb_launch_blur(const uint8_t* img, int w, int h, int stride, size_t frame_
 {
     if (taps.radius == 0) hipLaunchKernelGGL(k_copy_image, dim3(cdiv(wp * h, 256 * 8), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, out, wp);
     else hipLaunchKernelGGL(k_blur, dim3(cdiv(wp, BT_W), cdiv(h, BT_H), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, taps, out, wp);
+}
+
+void orb_launch_resize(const uint8_t* src, int sw, int sh, int sstride, size_t sframe, uint8_t* dst, int dw, int dh, int dpitch, size_t dframe, int n_frames,
+                       hipStream_t st)
+{
+    hipLaunchKernelGGL(k_resize_linear, dim3(cdiv(dpitch / 4, 64), dh, n_frames), dim3(64), 0, st, src, sw, sh, sstride, sframe, dst, dw, dh, dpitch, dframe);
+}
+
+void orb_launch_append_level(const mage_keypoint* kp_l, const uint8_t* desc_l, const int* count_l, int cap_l, mage_keypoint* kp, uint8_t* desc, int* count,
+                             int capacity, int n_frames, float scale, float size, int level, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_append_level, dim3(n_frames), dim3(256), 0, st, kp_l, desc_l, count_l, cap_l, kp, desc, count, capacity, scale, size, level);
 }
 
 void orb_launch_angles(const uint8_t* img, int stride, size_t frame_stride, int n_frames, mage_keypoint* kps, const int* counts, int capacity,

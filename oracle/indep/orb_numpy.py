@@ -16,7 +16,7 @@ from scipy.ndimage import correlate1d
 
 RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
 
-DEFAULTS = dict(gaussian_kernel_size=7, nfeatures=440, nlevels=1, patch_size=15, fast_threshold=4, feature_factor=1.5,
+DEFAULTS = dict(gaussian_kernel_size=7, nfeatures=440, scale_factor=1.5, nlevels=1, patch_size=15, fast_threshold=4, feature_factor=1.5,
                 feature_strength=0.9, strong_response=20, min_robust=1.1, max_robust=2.0, cells_x=32, cells_y=32)
 
 
@@ -171,36 +171,106 @@ def ic_angles(img: np.ndarray, k: np.ndarray, half: int) -> np.ndarray:
     return out
 
 
+def resize_linear(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    """cv::resize(..., INTER_LINEAR) on CV_8UC1 as OpenCV 3.4.0 computes it: 11-bit fixed-point weights (rounded half to even, as
+    saturate_cast<short>), horizontal pass in int, vertical pass ((b*(S>>4))>>16 twice, +2)>>2.  Vectorised."""
+    sh, sw = src.shape
+    f = np.float32
+    fx = ((np.arange(dw) + 0.5) * (sw / dw) - 0.5).astype(f)
+    sx = np.floor(fx).astype(np.int64); fx = (fx - sx.astype(f)).astype(f)
+    fx = np.where(sx < 0, f(0), fx); sx = np.maximum(sx, 0)
+    fx = np.where(sx >= sw - 1, f(0), fx); sx = np.minimum(sx, sw - 1)
+    a0 = np.clip(np.rint((f(1) - fx) * f(2048)), -32768, 32767).astype(np.int64); a1 = np.clip(np.rint(fx * f(2048)), -32768, 32767).astype(np.int64)
+    fy = ((np.arange(dh) + 0.5) * (sh / dh) - 0.5).astype(f)
+    sy = np.floor(fy).astype(np.int64); fy = (fy - sy.astype(f)).astype(f)
+    b0 = np.clip(np.rint((f(1) - fy) * f(2048)), -32768, 32767).astype(np.int64); b1 = np.clip(np.rint(fy * f(2048)), -32768, 32767).astype(np.int64)
+    r0 = np.clip(sy, 0, sh - 1); r1 = np.clip(sy + 1, 0, sh - 1)
+    S = src.astype(np.int64)
+    H = S[:, sx] * a0[None, :] + S[:, np.minimum(sx + 1, sw - 1)] * a1[None, :]          # (sh, dw)
+    out = (((b0[:, None] * (H[r0] >> 4)) >> 16) + ((b1[:, None] * (H[r1] >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+def level_layout(w: int, h: int, P: dict):
+    """Scales, sizes and per-level feature quotas of the pyramid (OpenCVModified.cpp:564-567, :797-799, :659-669)."""
+    f = np.float32
+    L = P["nlevels"]
+    scales = [f(np.float64(P["scale_factor"]) ** l) for l in range(L)]
+    sizes = [(int(np.rint(f(w) / s)), int(np.rint(f(h) / s))) for s in scales]
+    factor = f(1) / f(P["scale_factor"])
+    nd = f(P["nfeatures"]) * (f(1) - factor) / (f(1) - f(np.float64(factor) ** L))
+    quota, tot = [], 0
+    for _ in range(L - 1):
+        quota.append(int(np.rint(nd))); tot += quota[-1]; nd = f(nd * factor)
+    quota.append(max(P["nfeatures"] - tot, 0))
+    if L == 1:
+        quota = [P["nfeatures"]]
+    return scales, sizes, quota
+
+
 def detect(img: np.ndarray, base_pattern: np.ndarray, **kw):
-    """Returns (keypoints x y response, descriptors, blurred[, angles when use_orientation])."""
+    """Returns (keypoints x y response [level coordinates], descriptors, blurred level 0[, angles when use_orientation]); with
+    nlevels > 1 the keypoint rows carry a fourth column, the octave, and `scaled_xy` gives the float32 image coordinates."""
     P = dict(DEFAULTS); P.update(kw)
     h, w = img.shape
-    k = fast_keypoints(img, P["fast_threshold"])
+    scales, sizes, quota = level_layout(w, h, P)
     b = P["patch_size"] // 2
+    half_patch = b
     if P.get("use_orientation"):
         b = int(np.ceil(np.float32(b) * np.sqrt(np.float32(2))))
-    if h <= 2 * b or w <= 2 * b:
-        k = k[:0]
-    else:
-        k = k[(k[:, 0] >= b) & (k[:, 0] < w - b) & (k[:, 1] >= b) & (k[:, 1] < h - b)]
-    if len(k) > P["nfeatures"]:
-        k = retain_best(k, P["fast_threshold"], int(np.float32(P["nfeatures"]) * np.float32(P["feature_factor"])), P["nfeatures"], P["feature_strength"])
-        k = anms(k, P["nfeatures"], P["fast_threshold"], P)
-    bl = blur(img, P["gaussian_kernel_size"]) if P["gaussian_kernel_size"] > 1 else img
+    levels = [img]
+    for l in range(1, P["nlevels"]):
+        levels.append(resize_linear(levels[-1], sizes[l][0], sizes[l][1]))
+    ks, octs = [], []
+    for l, im in enumerate(levels):
+        hh, ww = im.shape
+        if hh < 7 or ww < 7 or quota[l] < 1:
+            continue
+        k = fast_keypoints(im, P["fast_threshold"])
+        if hh <= 2 * b or ww <= 2 * b:
+            k = k[:0]
+        else:
+            k = k[(k[:, 0] >= b) & (k[:, 0] < ww - b) & (k[:, 1] >= b) & (k[:, 1] < hh - b)]
+        if len(k) > quota[l]:
+            k = retain_best(k, P["fast_threshold"], int(np.float32(quota[l]) * np.float32(P["feature_factor"])), quota[l], P["feature_strength"])
+            k = anms(k, quota[l], P["fast_threshold"], P)
+        ks.append(k); octs.append(np.full(len(k), l, np.int64))
+    k = np.concatenate(ks) if ks else np.zeros((0, 3), np.int64)
+    octave = np.concatenate(octs) if octs else np.zeros(0, np.int64)
+    blurred = [blur(im, P["gaussian_kernel_size"]) if P["gaussian_kernel_size"] > 1 else im for im in levels]
     table = expand_pattern(base_pattern).reshape(30, 256, 4)
     if P.get("use_orientation"):
-        ang = ic_angles(img, k, P["patch_size"] // 2)
+        ang = np.zeros(len(k), np.float32)
+        for l in range(P["nlevels"]):
+            m = octave == l
+            if m.any():
+                ang[m] = ic_angles(levels[l], k[m], half_patch)
         inc = np.rint(ang / np.float32(12)).astype(np.int64) % 30          # cvRound: half to even, like np.rint
     else:
         ang = None
         inc = np.zeros(len(k), np.int64)
-    pat = table[inc]                                                          # (n, 256, 4)
-    xs, ys = k[:, 0][:, None], k[:, 1][:, None]
-    t0 = bl[ys + pat[:, :, 1], xs + pat[:, :, 0]]
-    t1 = bl[ys + pat[:, :, 3], xs + pat[:, :, 2]]
-    bits = (t0 < t1).astype(np.uint8).reshape(len(k), 32, 8)
-    desc = np.packbits(bits, axis=2, bitorder="little").reshape(len(k), 32)
-    return (k, desc, bl) if ang is None else (k, desc, bl, ang)
+    desc = np.zeros((len(k), 32), np.uint8)
+    for l in range(P["nlevels"]):
+        m = np.nonzero(octave == l)[0]
+        if not len(m):
+            continue
+        pat = table[inc[m]]                                                   # (n, 256, 4)
+        xs, ys = k[m, 0][:, None], k[m, 1][:, None]
+        bl = blurred[l]
+        t0 = bl[ys + pat[:, :, 1], xs + pat[:, :, 0]]
+        t1 = bl[ys + pat[:, :, 3], xs + pat[:, :, 2]]
+        bits = (t0 < t1).astype(np.uint8).reshape(len(m), 32, 8)
+        desc[m] = np.packbits(bits, axis=2, bitorder="little").reshape(len(m), 32)
+    if P["nlevels"] > 1:
+        k = np.concatenate([k, octave[:, None]], axis=1)
+    return (k, desc, blurred[0]) if ang is None else (k, desc, blurred[0], ang)
+
+
+def scaled_xy(k: np.ndarray, P: dict) -> np.ndarray:
+    """float32 image coordinates of multi-level keypoints: pt *= scale of the octave (OpenCVModified.cpp:756-760)."""
+    f = np.float32
+    sc = np.array([f(np.float64(P["scale_factor"]) ** int(o)) for o in k[:, 3]], f)
+    return np.stack([k[:, 0].astype(f) * sc, k[:, 1].astype(f) * sc], 1)
 
 
 def hamming_matrix(A: np.ndarray, B: np.ndarray) -> np.ndarray:

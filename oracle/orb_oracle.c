@@ -432,65 +432,166 @@ ORBO_API void orbo_ic_angles(const uint8_t* img, int stride, orbo_keypoint* kps,
 ORBO_API float orbo_fast_atan2(float y, float x) { return fast_atan2f(y, x); }
 
 /* ------------------------------------------------------------------------------------------ */
-/* DetectAndCompute                                                                           */
+/* cv::resize(src, dst, size, 0, 0, INTER_LINEAR) for CV_8UC1, OpenCV 3.4.0 (imgproc/resize.cpp: */
+/* resizeGeneric_ with HResizeLinear / VResizeLinear<uchar, int, short>, fixed point with 11      */
+/* coefficient bits; not vendored, restated).  Used only for the pyramid levels >= 1 (:822-841). */
 /* ------------------------------------------------------------------------------------------ */
+static short sat_short(float v)
+{
+    int r = cv_round((double)v);
+    return (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+}
+
+ORBO_API void orbo_resize_linear(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh /* dst pitch dw */)
+{
+    const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    int* xofs = (int*)malloc(sizeof(int) * (size_t)dw);
+    short* ialpha = (short*)malloc(sizeof(short) * 2 * (size_t)dw);
+    for (int dx = 0; dx < dw; ++dx) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        ialpha[dx * 2] = sat_short((1.f - fx) * 2048);
+        ialpha[dx * 2 + 1] = sat_short(fx * 2048);
+    }
+    for (int dy = 0; dy < dh; ++dy) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        const int sy = (int)floorf(fy);
+        fy -= sy;
+        const short b0 = sat_short((1.f - fy) * 2048), b1 = sat_short(fy * 2048);
+        const int r0 = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy), r1 = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
+        const uint8_t* S0r = src + (size_t)r0 * sstride; const uint8_t* S1r = src + (size_t)r1 * sstride;
+        for (int dx = 0; dx < dw; ++dx) {
+            const int sx = xofs[dx], sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+            const int a0 = ialpha[dx * 2], a1 = ialpha[dx * 2 + 1];
+            const int S0 = S0r[sx] * a0 + S0r[sx1] * a1, S1 = S1r[sx] * a0 + S1r[sx1] * a1;
+            dst[(size_t)dy * dw + dx] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+        }
+    }
+    free(xofs); free(ialpha);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* DetectAndCompute (OpenCVModified.cpp:771-886) + ComputeKeyPoints (:642-768)                 */
+/* Multi-level deviation, PINNED: the reference blurs every level in place as an ROI of one    */
+/* shared pyramid buffer without BORDER_ISOLATED, so border taps read the neighbouring level   */
+/* or uninitialised memory; here every level is blurred as an isolated image (REFLECT_101).    */
+/* ------------------------------------------------------------------------------------------ */
+#define ORBO_MAX_LEVELS 16
+
+ORBO_API int orbo_level_layout(const orbo_params* P, int w, int h, int* lw, int* lh, float* lscale, int* nfeat /* each ORBO_MAX_LEVELS */)
+{
+    const int L = (int)P->nlevels;
+    if (L < 1 || L > ORBO_MAX_LEVELS) return ORBO_UNSUPPORTED;
+    for (int l = 0; l < L; ++l) {
+        lscale[l] = (float)pow((double)P->scale_factor, (double)l);               /* getScale, :564-567 */
+        lw[l] = cv_round(w / lscale[l]); lh[l] = cv_round(h / lscale[l]);          /* :799 (int / float -> float) */
+    }
+    /* features per level, :659-669 */
+    const float factor = 1.0f / P->scale_factor;
+    float ndesired = (float)P->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)L));
+    int sum = 0;
+    for (int l = 0; l < L - 1; ++l) { nfeat[l] = cv_round(ndesired); sum += nfeat[l]; ndesired *= factor; }
+    nfeat[L - 1] = (int)P->nfeatures - sum > 0 ? (int)P->nfeatures - sum : 0;
+    return ORBO_OK;
+}
+
 ORBO_API int orbo_detect(const orbo_params* P, const uint8_t* img, int w, int h, int stride,
-                         orbo_keypoint* kps, uint8_t* desc32, int cap, int* n_out, uint8_t* blurred_out /* optional w*h */)
+                         orbo_keypoint* kps, uint8_t* desc32, int cap, int* n_out, uint8_t* blurred_out /* optional w*h, level 0 */)
 {
     *n_out = 0;
-    if (P->nlevels != 1 || (P->patch_size != 15 && P->patch_size != 31)) return ORBO_UNSUPPORTED;
+    if (P->patch_size != 15 && P->patch_size != 31) return ORBO_UNSUPPORTED;
+    int lw[ORBO_MAX_LEVELS], lh[ORBO_MAX_LEVELS], nfeat[ORBO_MAX_LEVELS];
+    float lscale[ORBO_MAX_LEVELS];
+    if (orbo_level_layout(P, w, h, lw, lh, lscale, nfeat) != ORBO_OK) return ORBO_UNSUPPORTED;
+    const int L = (int)P->nlevels;
+    if (L == 1) nfeat[0] = (int)P->nfeatures;
     const int half_patch = (int)P->patch_size / 2;
     /* with orientation the patch is rotated: the hypotenuse of half the patch (OpenCVModified.cpp:709-712) */
     const int half = P->use_orientation ? (int)ceil(half_patch * sqrtf(2.0f)) : half_patch;
-    uint8_t* score = (uint8_t*)malloc((size_t)w * h + 1);
-    size_t raw_cap = (size_t)w * h / 4 + 16;
-    raw_kp* kp = (raw_kp*)malloc(sizeof(raw_kp) * raw_cap);
-    orbo_fast_score_map(img, w, h, stride, (int)P->fast_threshold, score);
-    size_t n = fast_nms(img, w, h, stride, (int)P->fast_threshold, score, kp, raw_cap);
-    free(score);
-    /* RunByImageBorder */
-    if (half > 0) {
-        if (h <= half * 2 || w <= half * 2) n = 0;
-        else {
-            size_t m = 0;
-            for (size_t i = 0; i < n; ++i)
-                if (kp[i].x >= half && kp[i].x < w - half && kp[i].y >= half && kp[i].y < h - half) kp[m++] = kp[i];
-            n = m;
+    /* pyramid: level 0 = the image, level l = resize of level l - 1 */
+    const uint8_t* lev[ORBO_MAX_LEVELS]; int lstride[ORBO_MAX_LEVELS]; uint8_t* own[ORBO_MAX_LEVELS];
+    lev[0] = img; lstride[0] = stride; own[0] = NULL;
+    for (int l = 1; l < L; ++l) {
+        own[l] = (uint8_t*)malloc((size_t)(lw[l] > 0 ? lw[l] : 1) * (size_t)(lh[l] > 0 ? lh[l] : 1));
+        if (lw[l] > 0 && lh[l] > 0 && lw[l - 1] > 0 && lh[l - 1] > 0) orbo_resize_linear(lev[l - 1], lw[l - 1], lh[l - 1], lstride[l - 1], own[l], lw[l], lh[l]);
+        lev[l] = own[l]; lstride[l] = lw[l];
+    }
+    size_t total = 0;
+    for (int l = 0; l < L; ++l) {
+        const int W = lw[l], H = lh[l];
+        if (W < 7 || H < 7 || nfeat[l] < 1) continue;      /* a level without quota places nothing (the reference would assert in ANMS) */
+        uint8_t* score = (uint8_t*)malloc((size_t)W * H + 1);
+        size_t raw_cap = (size_t)W * H / 4 + 16;
+        raw_kp* kp = (raw_kp*)malloc(sizeof(raw_kp) * raw_cap);
+        orbo_fast_score_map(lev[l], W, H, lstride[l], (int)P->fast_threshold, score);
+        size_t n = fast_nms(lev[l], W, H, lstride[l], (int)P->fast_threshold, score, kp, raw_cap);
+        free(score);
+        /* RunByImageBorder */
+        if (half > 0) {
+            if (H <= half * 2 || W <= half * 2) n = 0;
+            else {
+                size_t m = 0;
+                for (size_t i = 0; i < n; ++i)
+                    if (kp[i].x >= half && kp[i].x < W - half && kp[i].y >= half && kp[i].y < H - half) kp[m++] = kp[i];
+                n = m;
+            }
         }
+        if (n > (size_t)nfeat[l]) {
+            int max_num = (int)(nfeat[l] * P->feature_factor);
+            n = retain_best(kp, n, (int)P->fast_threshold, max_num, nfeat[l], P->feature_strength);
+            n = anms(kp, n, (unsigned)nfeat[l], (int)P->fast_threshold, P);
+        }
+        /* ImageData::Insert: copy what still fits; a level that cannot place a single keypoint ends the loop (:731-737) */
+        size_t room = (size_t)cap > total ? (size_t)cap - total : 0;
+        size_t take = n < room ? n : room;
+        for (size_t i = 0; i < take; ++i) {
+            orbo_keypoint* k = &kps[total + i];
+            k->x = (float)kp[i].x; k->y = (float)kp[i].y; k->size = (float)P->patch_size * lscale[l];
+            k->angle = 0.0f; k->response = (float)kp[i].resp; k->octave = l; k->class_id = -1;
+        }
+        total += take;
+        free(kp);
+        if (n > 0 && take == 0) break;
     }
-    if (n > P->nfeatures) {
-        int max_num = (int)(P->nfeatures * P->feature_factor);
-        n = retain_best(kp, n, (int)P->fast_threshold, max_num, (int)P->nfeatures, P->feature_strength);
-        n = anms(kp, n, P->nfeatures, (int)P->fast_threshold, P);
+    *n_out = (int)total;
+    if (total == 0) { for (int l = 1; l < L; ++l) free(own[l]); return ORBO_OK; }
+    if (P->use_orientation)                                   /* ICAngles on the unblurred levels (:745-748) */
+        for (size_t i = 0; i < total; ++i) orbo_ic_angles(lev[kps[i].octave], lstride[kps[i].octave], &kps[i], 1, half_patch);
+    for (size_t i = 0; i < total; ++i) { const float sc = lscale[kps[i].octave]; kps[i].x *= sc; kps[i].y *= sc; }     /* :756-760 */
+    /* blur every level (isolated), then the descriptors on the level of each keypoint */
+    uint8_t* blur[ORBO_MAX_LEVELS];
+    for (int l = 0; l < L; ++l) {
+        const int W = lw[l] > 0 ? lw[l] : 1, H = lh[l] > 0 ? lh[l] : 1;
+        blur[l] = (uint8_t*)malloc((size_t)W * H);
+        if (lw[l] <= 0 || lh[l] <= 0) continue;
+        if (P->gaussian_kernel_size > 1) orbo_blur(lev[l], lw[l], lh[l], lstride[l], (int)P->gaussian_kernel_size, blur[l]);
+        else for (int y = 0; y < lh[l]; ++y) memcpy(blur[l] + (size_t)y * lw[l], lev[l] + (size_t)y * lstride[l], (size_t)lw[l]);
     }
-    if ((int)n > cap) n = (size_t)cap;                                   /* ImageData::Insert truncates, ImageData.h:65-70 */
-    for (size_t i = 0; i < n; ++i) {
-        kps[i].x = (float)kp[i].x; kps[i].y = (float)kp[i].y; kps[i].size = (float)P->patch_size * 1.0f;
-        kps[i].angle = 0.0f; kps[i].response = (float)kp[i].resp; kps[i].octave = 0; kps[i].class_id = -1;
-    }
-    *n_out = (int)n;
-    if (n == 0) { free(kp); return ORBO_OK; }
-    if (P->use_orientation) orbo_ic_angles(img, stride, kps, (int)n, half_patch);      /* on the unblurred level (:745-748) */
-    uint8_t* blur = (uint8_t*)malloc((size_t)w * h);
-    if (P->gaussian_kernel_size > 1) orbo_blur(img, w, h, stride, (int)P->gaussian_kernel_size, blur);
-    else for (int y = 0; y < h; ++y) memcpy(blur + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
-    if (blurred_out) memcpy(blurred_out, blur, (size_t)w * h);
+    if (blurred_out) memcpy(blurred_out, blur[0], (size_t)w * h);
     signed char* pat = (signed char*)malloc(30 * 1024);
     orbo_pattern_expand((int)P->patch_size, pat);
-    for (size_t j = 0; j < n; ++j) {
-        const uint8_t* center = blur + (size_t)cv_round(kps[j].y) * w + cv_round(kps[j].x);
+    for (size_t j = 0; j < total; ++j) {
+        const int l = kps[j].octave;
+        const float inv = 1.f / lscale[l];                                             /* :521 */
+        const uint8_t* center = blur[l] + (size_t)cv_round(kps[j].y * inv) * lw[l] + cv_round(kps[j].x * inv);
         const signed char* p = pat + (cv_round(kps[j].angle / 12.0f) % 30) * 1024;       /* angleIncrement (:523-532); 0 without orientation */
         for (int i = 0; i < 32; ++i, p += 32) {
             int val = 0;
             for (int bit = 0; bit < 8; ++bit) {
-                int t0 = center[p[4 * bit + 1] * w + p[4 * bit]];
-                int t1 = center[p[4 * bit + 3] * w + p[4 * bit + 2]];
+                int t0 = center[p[4 * bit + 1] * lw[l] + p[4 * bit]];
+                int t1 = center[p[4 * bit + 3] * lw[l] + p[4 * bit + 2]];
                 val |= (t0 < t1) << bit;
             }
             desc32[j * 32 + i] = (uint8_t)val;
         }
     }
-    free(pat); free(blur); free(kp);
+    free(pat);
+    for (int l = 0; l < L; ++l) free(blur[l]);
+    for (int l = 1; l < L; ++l) free(own[l]);
     return ORBO_OK;
 }
 

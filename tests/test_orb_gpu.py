@@ -86,7 +86,7 @@ def test_edge_cases_match_oracle():
 
 def test_unsupported_settings_are_refused():
     from mageslam_amd._lib import MageError
-    for kw in (dict(nlevels=2), dict(patch_size=21)):
+    for kw in (dict(nlevels=17), dict(nlevels=2, scale_factor=1.0), dict(patch_size=21)):
         with pytest.raises(MageError):
             OrbDetector(**kw)
 
@@ -261,3 +261,29 @@ def test_oriented_detection_golden_and_oracle(gold, name, patch):
     assert np.array_equal(d, g[key + "_desc"])
     ko, do = O.orb_detect(img, O.OrbParams.defaults(use_orientation=1, patch_size=patch))
     assert np.array_equal(k, ko) and np.array_equal(d, do)
+
+
+@pytest.mark.parametrize("key", ["l3_160x120", "l2_s12_640x480", "l2_oriented_160x120", "l4_p31_160x120"])
+def test_pyramid_detection_golden_and_oracle(gold, key):
+    """NumLevels > 1 on the device: resize pyramid, per-level stages, concatenation -- bit-exact against the numpy fixture and the
+    C oracle (float32 scaled coordinates included); a smaller capacity truncates like ImageData::Insert."""
+    import os
+    from test_orb_oracle import PYRAMID_CASES, check_pyramid_case
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_pyramid.npz"))
+    name, kw = PYRAMID_CASES[key]
+    img = gold[name + "_img"]
+    det = OrbDetector(default_params(**kw))
+    k, d = det.DetectAndCompute(img)
+    check_pyramid_case(k, d, g, key)
+    ko, do = O.orb_detect(img, O.OrbParams.defaults(**kw))
+    assert np.array_equal(k, ko) and np.array_equal(d, do)
+    cap = len(ko) - 7
+    k2, d2 = det.DetectAndCompute(img, capacity=cap)
+    ko2, do2 = O.orb_detect(img, O.OrbParams.defaults(**kw), cap=cap)
+    assert len(k2) == cap and np.array_equal(k2, ko2) and np.array_equal(d2, do2)
+    # batch of two different frames of the same size: frames are independent
+    if name == "orb_640x480_a":
+        kb, db, cb = det.DetectAndComputeBatch(np.stack([gold["orb_640x480_b_img"], img]))
+        assert cb[1] == len(ko) and np.array_equal(kb[1, : cb[1]], ko) and np.array_equal(db[1, : cb[1]], do)
+        kob, dob = O.orb_detect(gold["orb_640x480_b_img"], O.OrbParams.defaults(**kw))
+        assert cb[0] == len(kob) and np.array_equal(kb[0, : cb[0]], kob) and np.array_equal(db[0, : cb[0]], dob)

@@ -118,7 +118,7 @@ def test_edge_cases():
 
 def test_unsupported_settings_are_refused():
     a = np.zeros((64, 64), np.uint8)
-    for kw in (dict(nlevels=2), dict(patch_size=21)):
+    for kw in (dict(nlevels=17), dict(patch_size=21)):
         with pytest.raises(NotImplementedError):
             O.orb_detect(a, O.OrbParams.defaults(**kw))
 
@@ -277,3 +277,55 @@ def test_fast_atan2_polynomial():
         assert min(abs(a - ref), 360 - abs(a - ref)) < 0.35
     assert L.orbo_fast_atan2(0.0, 5.0) == 0.0 and L.orbo_fast_atan2(0.0, -5.0) == 180.0
     assert abs(L.orbo_fast_atan2(3.0, 0.0) - 90.0) < 1e-4 and abs(L.orbo_fast_atan2(-3.0, 0.0) - 270.0) < 1e-4
+
+
+PYRAMID = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_pyramid.npz")
+PYRAMID_CASES = {"l3_160x120": ("orb_160x120", dict(nlevels=3)),
+                 "l2_s12_640x480": ("orb_640x480_a", dict(nlevels=2, scale_factor=1.2)),
+                 "l2_oriented_160x120": ("orb_160x120", dict(nlevels=2, use_orientation=1)),
+                 "l4_p31_160x120": ("orb_160x120", dict(nlevels=4, patch_size=31, nfeatures=300))}
+
+
+def check_pyramid_case(k, d, g, key):
+    assert np.array_equal(np.stack([k["response"], k["octave"]], 1).astype(np.int64), g[key + "_kp"][:, 2:4])
+    assert np.array_equal(np.stack([k["x"], k["y"]], 1), g[key + "_xy"])                  # float32 pt * scale, bit for bit
+    assert np.array_equal(d, g[key + "_desc"])
+    if key + "_angle" in g.files:
+        assert np.array_equal(k["angle"], g[key + "_angle"])
+    else:
+        assert np.all(k["angle"] == 0)
+
+
+@pytest.mark.parametrize("key", sorted(PYRAMID_CASES))
+def test_pyramid_detection_oracle_matches_golden(gold, key):
+    """NumLevels > 1 (the rest of ORB-1): cv::resize pyramid, per-level quotas, concatenation, scaled coordinates."""
+    g = np.load(PYRAMID)
+    name, kw = PYRAMID_CASES[key]
+    k, d = O.orb_detect(gold[name + "_img"], O.OrbParams.defaults(**kw))
+    check_pyramid_case(k, d, g, key)
+    patch = kw.get("patch_size", 15)
+    sf = np.float32(kw.get("scale_factor", 1.5))
+    assert np.array_equal(k["size"], np.array([np.float32(patch) * np.float32(np.float64(sf) ** int(o)) for o in k["octave"]], np.float32))
+
+
+def test_resize_linear_matches_golden_and_known_answers():
+    import ctypes as C
+    g = np.load(PYRAMID)
+    L = O.lib()
+    L.orbo_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    src = np.ascontiguousarray(g["resize_src"])
+    for name, (dw, dh) in (("resize_107x80", (107, 80)), ("resize_53x91", (53, 91))):
+        dst = np.zeros((dh, dw), np.uint8)
+        L.orbo_resize_linear(src.ctypes.data, src.shape[1], src.shape[0], src.shape[1], dst.ctypes.data, dw, dh)
+        assert np.array_equal(dst, g[name])
+    # a constant image stays constant; same-size resize is the identity; 2:1 averages pixel pairs (rounded)
+    c = np.full((12, 16), 77, np.uint8); d = np.zeros((7, 9), np.uint8)
+    L.orbo_resize_linear(c.ctypes.data, 16, 12, 16, d.ctypes.data, 9, 7)
+    assert np.all(d == 77)
+    r = np.arange(48, dtype=np.uint8).reshape(6, 8) * 3; d = np.zeros((6, 8), np.uint8)
+    L.orbo_resize_linear(r.ctypes.data, 8, 6, 8, d.ctypes.data, 8, 6)
+    assert np.array_equal(d, r)
+    d = np.zeros((3, 4), np.uint8)
+    L.orbo_resize_linear(r.ctypes.data, 8, 6, 8, d.ctypes.data, 4, 3)
+    exp = (r[0::2, 0::2].astype(int) + r[0::2, 1::2] + r[1::2, 0::2] + r[1::2, 1::2] + 2) // 4
+    assert np.abs(d.astype(int) - exp).max() <= 1
