@@ -44,7 +44,8 @@ typedef struct mage_orb_params {
     unsigned nlevels;                /* 1 (default) .. 16: cv::resize(INTER_LINEAR) pyramid with per-level quotas (OpenCVModified.cpp:659-669, 793-841);
                                         every level is blurred as an ISOLATED image -- the reference's in-place ROI blur reads the neighbouring level or
                                         uninitialised memory at the borders, which cannot be restated (pinned deviation) */
-    unsigned patch_size;             /* 15 or 31 (pre-rotated tables); others -> MAGE_ERR_UNSUPPORTED */
+    unsigned patch_size;             /* 15 or 31: pre-rotated tables; 2 .. 127 otherwise: MakeRandomPattern (cv::RNG, OpenCVModified.cpp:551-560),
+                                        then only with use_orientation = 0 (its rotation would go through libm: MAGE_ERR_UNSUPPORTED) */
     unsigned fast_threshold;         /* 4 */
     int      use_orientation;        /* 0 (default) or 1: ICAngles orientation + rotated BRIEF rows (OpenCVModified.cpp:399-437, 523-532) */
     float    feature_factor_anms;    /* 1.5 */

@@ -49,8 +49,19 @@ OrbTaps gaussian_taps(unsigned ksize)
 // rotation rows of the pre-rotated sampling pattern (include/mage_brief_patterns.h explains the rule)
 void expand_pattern(unsigned patch, std::vector<signed char>& out)
 {
+    out.assign(MAGE_BRIEF_ROTATIONS * 1024, 0);
+    if (patch != 15 && patch != 31) {
+        // MakeRandomPattern (OpenCVModified.cpp:551-560): 512 points from cv::RNG(0x34985739), OpenCV's multiply-with-carry generator,
+        // uniform(-patch/2, patch/2 + 1) for x then y.  Only the unrotated row is filled: orientation is refused with this pattern.
+        uint64_t state = 0x34985739u;
+        const int a = -(int)patch / 2, b = (int)patch / 2 + 1;
+        for (int i = 0; i < 1024; ++i) {
+            state = (uint64_t)(uint32_t)state * 4164903690u + (uint32_t)(state >> 32);
+            out[i] = (signed char)(a == b ? a : (int)((uint32_t)state % (uint32_t)(b - a) + (uint32_t)a));
+        }
+        return;
+    }
     const signed char* base = patch == 31 ? MAGE_BRIEF_BASE_31 : MAGE_BRIEF_BASE_15;
-    out.resize(MAGE_BRIEF_ROTATIONS * 1024);
     const double pi = 3.14159265358979323846;
     for (int k = 0; k < MAGE_BRIEF_ROTATIONS; ++k) {
         const double a = k * 12.0 * pi / 180.0, c = std::cos(a), s = std::sin(a);
@@ -108,7 +119,12 @@ MAGE_EXPORT mage_status mage_orb_create(const mage_orb_params* params, mage_orb*
         const mage_orb_params& p = *params;
         if (p.nlevels < 1 || p.nlevels > ORB_MAX_LEVELS) return fail(MAGE_ERR_INVALID_ARGUMENT, "NumLevels = %u: 1 .. %d supported", p.nlevels, ORB_MAX_LEVELS);
         if (p.nlevels > 1 && !(p.scale_factor > 1.0f)) return fail(MAGE_ERR_INVALID_ARGUMENT, "a pyramid needs ScaleFactor > 1");
-        if (p.patch_size != 15 && p.patch_size != 31) return fail(MAGE_ERR_UNSUPPORTED, "patch size %u: only the pre-rotated 15 / 31 tables are built", p.patch_size);
+        if (p.patch_size != 15 && p.patch_size != 31) {
+            // the random pattern of ComputeOrbDescriptors (:452-492, :551-560): with angle 0 its rotation is the identity; with
+            // UseOrientation the sampling points go through libm cos / sin, which cannot be made bit-identical across hosts
+            if (p.patch_size < 2 || p.patch_size > 127) return fail(MAGE_ERR_INVALID_ARGUMENT, "patch size %u out of range 2 .. 127", p.patch_size);
+            if (p.use_orientation) return fail(MAGE_ERR_UNSUPPORTED, "UseOrientation with patch size %u (random pattern rotated through libm): only 15 and 31 have pre-rotated tables", p.patch_size);
+        }
         if (p.gaussian_kernel_size > 15 || (p.gaussian_kernel_size > 1 && p.gaussian_kernel_size % 2 == 0))
             return fail(MAGE_ERR_INVALID_ARGUMENT, "Gaussian kernel size must be odd and <= 15");
         if (p.nfeatures < 2 || p.num_cells_x < 1 || p.num_cells_y < 1 || p.fast_threshold < 1)

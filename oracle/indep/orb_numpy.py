@@ -118,6 +118,18 @@ def blur(img: np.ndarray, ksize: int) -> np.ndarray:
     return np.minimum((b + 32768) >> 16, 255).astype(np.uint8)
 
 
+def random_pattern(patch: int) -> np.ndarray:
+    """MakeRandomPattern (OpenCVModified.cpp:551-560): cv::RNG(0x34985739), uniform(-patch/2, patch/2+1) for x then y of 512 points.
+    Python integers, so the 64-bit multiply-with-carry state needs explicit masks.  Returns the 1024 coordinates."""
+    state = 0x34985739
+    lo, hi = -(patch // 2), patch // 2 + 1          # C++ -patchSize / 2 truncates towards zero: equal to -(patch // 2) for patch > 0
+    out = np.zeros(1024, np.int64)
+    for i in range(1024):
+        state = ((state & 0xFFFFFFFF) * 4164903690 + (state >> 32)) & 0xFFFFFFFFFFFFFFFF
+        out[i] = lo + (state & 0xFFFFFFFF) % (hi - lo)
+    return out
+
+
 def expand_pattern(base: np.ndarray) -> np.ndarray:
     out = np.zeros((30, 512, 2), np.int64)
     b = base.reshape(512, 2).astype(np.float64)
@@ -238,7 +250,11 @@ def detect(img: np.ndarray, base_pattern: np.ndarray, **kw):
     k = np.concatenate(ks) if ks else np.zeros((0, 3), np.int64)
     octave = np.concatenate(octs) if octs else np.zeros(0, np.int64)
     blurred = [blur(im, P["gaussian_kernel_size"]) if P["gaussian_kernel_size"] > 1 else im for im in levels]
-    table = expand_pattern(base_pattern).reshape(30, 256, 4)
+    if P["patch_size"] in (15, 31):
+        table = expand_pattern(base_pattern).reshape(30, 256, 4)
+    else:                                           # random pattern: only the unrotated row exists (orientation is refused with it)
+        assert not P.get("use_orientation")
+        table = np.zeros((30, 256, 4), np.int64); table[0] = random_pattern(P["patch_size"]).reshape(256, 4)
     if P.get("use_orientation"):
         ang = np.zeros(len(k), np.float32)
         for l in range(P["nlevels"]):

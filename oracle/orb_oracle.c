@@ -62,8 +62,26 @@ static int cv_round(double v) { return (int)nearbyint(v); }
 /* ------------------------------------------------------------------------------------------ */
 /* pattern tables                                                                             */
 /* ------------------------------------------------------------------------------------------ */
+/* MakeRandomPattern (OpenCVModified.cpp:551-560) for patch sizes without a pre-rotated table: 512 points from cv::RNG(0x34985739)
+ * (OpenCV's multiply-with-carry generator, core/operations.hpp: state = (unsigned)state * 4164903690 + (state >> 32)),
+ * uniform(a, b) = a + next() % (b - a).  Point i pairs as (2i, 2i+1), the same bit order as the pre-rotated tables. */
+ORBO_API void orbo_random_pattern(int patch, signed char* out /* 1024: x0 y0 x1 y1 per pair */)
+{
+    uint64_t state = 0x34985739u;
+    const int a = -patch / 2, b = patch / 2 + 1;
+    for (int i = 0; i < 1024; ++i) {                       /* x then y of each of the 512 points */
+        state = (uint64_t)(uint32_t)state * 4164903690u + (uint32_t)(state >> 32);
+        out[i] = (signed char)(a == b ? a : (int)((uint32_t)state % (uint32_t)(b - a) + (uint32_t)a));
+    }
+}
+
 ORBO_API void orbo_pattern_expand(int patch, signed char* out /* 30 * 1024 */)
 {
+    if (patch != 15 && patch != 31) {                      /* random pattern, angle 0 only: row 0, the other rows are never selected */
+        memset(out, 0, 30 * 1024);
+        orbo_random_pattern(patch, out);
+        return;
+    }
     const signed char* base = patch == 31 ? MAGE_BRIEF_BASE_31 : MAGE_BRIEF_BASE_15;
     for (int k = 0; k < MAGE_BRIEF_ROTATIONS; ++k) {
         double a = k * 12.0 * M_PI / 180.0, c = cos(a), s = sin(a);
@@ -503,7 +521,9 @@ ORBO_API int orbo_detect(const orbo_params* P, const uint8_t* img, int w, int h,
                          orbo_keypoint* kps, uint8_t* desc32, int cap, int* n_out, uint8_t* blurred_out /* optional w*h, level 0 */)
 {
     *n_out = 0;
-    if (P->patch_size != 15 && P->patch_size != 31) return ORBO_UNSUPPORTED;
+    /* other patch sizes take the random pattern (ComputeOrbDescriptors, :452-492); with angle 0 its rotation is the identity
+       (cos 0 = 1, sin 0 = 0 exactly), with UseOrientation it would go through libm's cos / sin: refused */
+    if (P->patch_size != 15 && P->patch_size != 31 && (P->use_orientation || P->patch_size < 2 || P->patch_size > 127)) return ORBO_UNSUPPORTED;
     int lw[ORBO_MAX_LEVELS], lh[ORBO_MAX_LEVELS], nfeat[ORBO_MAX_LEVELS];
     float lscale[ORBO_MAX_LEVELS];
     if (orbo_level_layout(P, w, h, lw, lh, lscale, nfeat) != ORBO_OK) return ORBO_UNSUPPORTED;

@@ -40,6 +40,11 @@ def main():
         if len(r) == 4:
             out[key + "_angle"] = r[3]
         print(key, len(r[0]), "per level", np.bincount(r[0][:, 3], minlength=kw["nlevels"]))
+    # ORB-9: patch sizes without a pre-rotated table take the cv::RNG random pattern (angle 0)
+    for patch in (21, 9):
+        k, d, _ = N.detect(g["orb_160x120_img"], None, patch_size=patch)
+        out[f"rand{patch}_kp"], out[f"rand{patch}_desc"], out[f"rand{patch}_pattern"] = k, d, N.random_pattern(patch)
+        print("random pattern patch", patch, len(k))
     np.savez_compressed(os.path.join(HERE, "orb_pyramid.npz"), **out)
 
 

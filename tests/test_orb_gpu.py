@@ -86,7 +86,7 @@ def test_edge_cases_match_oracle():
 
 def test_unsupported_settings_are_refused():
     from mageslam_amd._lib import MageError
-    for kw in (dict(nlevels=17), dict(nlevels=2, scale_factor=1.0), dict(patch_size=21)):
+    for kw in (dict(nlevels=17), dict(nlevels=2, scale_factor=1.0), dict(patch_size=21, use_orientation=1), dict(patch_size=200)):
         with pytest.raises(MageError):
             OrbDetector(**kw)
 
@@ -287,3 +287,16 @@ def test_pyramid_detection_golden_and_oracle(gold, key):
         assert cb[1] == len(ko) and np.array_equal(kb[1, : cb[1]], ko) and np.array_equal(db[1, : cb[1]], do)
         kob, dob = O.orb_detect(gold["orb_640x480_b_img"], O.OrbParams.defaults(**kw))
         assert cb[0] == len(kob) and np.array_equal(kb[0, : cb[0]], kob) and np.array_equal(db[0, : cb[0]], dob)
+
+
+@pytest.mark.parametrize("patch", [21, 9])
+def test_random_pattern_patch_sizes_golden_and_oracle(gold, patch):
+    """ORB-9 on the device: the cv::RNG random pattern for patch sizes without a pre-rotated table (angle 0)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_pyramid.npz"))
+    img = gold["orb_160x120_img"]
+    k, d = OrbDetector(default_params(patch_size=patch)).DetectAndCompute(img)
+    assert np.array_equal(np.stack([k["x"], k["y"], k["response"]], 1).astype(np.int64), g[f"rand{patch}_kp"])
+    assert np.array_equal(d, g[f"rand{patch}_desc"])
+    ko, do = O.orb_detect(img, O.OrbParams.defaults(patch_size=patch))
+    assert np.array_equal(k, ko) and np.array_equal(d, do)

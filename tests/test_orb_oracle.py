@@ -118,7 +118,7 @@ def test_edge_cases():
 
 def test_unsupported_settings_are_refused():
     a = np.zeros((64, 64), np.uint8)
-    for kw in (dict(nlevels=17), dict(patch_size=21)):
+    for kw in (dict(nlevels=17), dict(patch_size=21, use_orientation=1), dict(patch_size=200)):
         with pytest.raises(NotImplementedError):
             O.orb_detect(a, O.OrbParams.defaults(**kw))
 
@@ -329,3 +329,18 @@ def test_resize_linear_matches_golden_and_known_answers():
     L.orbo_resize_linear(r.ctypes.data, 8, 6, 8, d.ctypes.data, 4, 3)
     exp = (r[0::2, 0::2].astype(int) + r[0::2, 1::2] + r[1::2, 0::2] + r[1::2, 1::2] + 2) // 4
     assert np.abs(d.astype(int) - exp).max() <= 1
+
+
+@pytest.mark.parametrize("patch", [21, 9])
+def test_random_pattern_patch_sizes_match_golden(gold, patch):
+    """ORB-9: patch sizes other than 15 / 31 use MakeRandomPattern (cv::RNG multiply-with-carry, seed 0x34985739) at angle 0."""
+    import ctypes as C
+    g = np.load(PYRAMID)
+    pat = np.zeros(1024, np.int8)
+    O.lib().orbo_random_pattern.argtypes = [C.c_int, C.c_void_p]
+    O.lib().orbo_random_pattern(patch, pat.ctypes.data)
+    assert np.array_equal(pat.astype(np.int64), g[f"rand{patch}_pattern"])
+    assert pat.min() >= -(patch // 2) and pat.max() <= patch // 2
+    k, d = O.orb_detect(gold["orb_160x120_img"], O.OrbParams.defaults(patch_size=patch))
+    assert np.array_equal(kp_xyr(k), g[f"rand{patch}_kp"]) and np.array_equal(d, g[f"rand{patch}_desc"])
+    assert np.all(k["size"] == patch)
