@@ -592,7 +592,8 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
         // block 0: wait for the eight others (bounded spin; relaxed polls, one acquire), pull the tile, factor it
         if (tid == 0) {
             int spins = 0;
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NDIAG - 1 && ++spins < (1 << 26)) __builtin_amdgcn_s_sleep(1);
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NDIAG - 1 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
+            if (spins >= (1 << 24)) *ok = 0.0;           // a producer never arrived: the factorisation is reported as failed, not silently wrong
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
@@ -647,8 +648,8 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
 // CHOL_DBG=1 tools/chol_test).  Inverting L_jj in LDS beforehand (one matrix-vector product at the end) was tried: the
 // 50 us it takes do not fit in the slack of any column, and the hop stayed at 4.7 us; pinning the chain to one XCD did
 // not shorten it either.  nt <= 256 workgroups are all resident (one per CU, dispatched last column first), so a
-// consumer never waits for an unscheduled producer; polls are bounded, a time-out only yields garbage in an already
-// failed solve.
+// consumer never waits for an unscheduled producer; polls are bounded, and a time-out clears *ok so the solve is reported
+// as failed instead of returning garbage.
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned long long X_SENTINEL = 0x7FF4DEADBEEF0001ull;
 
@@ -659,7 +660,7 @@ __global__ void k_fill_u64(unsigned long long* __restrict__ p, int n, unsigned l
 }
 
 __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict__ S, const double* __restrict__ y, double* __restrict__ x,
-                                                        int ld, int nt, const double* __restrict__ Linv, long long* __restrict__ dbg)
+                                                        int ld, int nt, const double* __restrict__ Linv, double* __restrict__ ok, long long* __restrict__ dbg)
 {
     extern __shared__ double sm[];
     constexpr int LDB = TILE + 2;
@@ -690,7 +691,8 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
             const unsigned long long* src = reinterpret_cast<const unsigned long long*>(x + (size_t)k * TILE + tid);
             unsigned long long v;
             int spins = 0;
-            while ((v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == X_SENTINEL && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(1);
+            while ((v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == X_SENTINEL && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
+            if (v == X_SENTINEL) *ok = 0.0;              // the producer column never published: report the solve as failed
             xk[tid] = __longlong_as_double((long long)v);
         }
         __syncthreads();
@@ -776,7 +778,7 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
         }
     }
     // backward substitution: one persistent launch (needs every workgroup resident: nt <= 256 compute units)
-    hipLaunchKernelGGL(k_bsolve_persist, dim3(nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, ws.dbg);
+    hipLaunchKernelGGL(k_bsolve_persist, dim3(nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, ok, ws.dbg);
 }
 
 }  // namespace mage
