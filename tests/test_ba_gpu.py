@@ -97,6 +97,27 @@ def test_medium_reduced_systems_match_oracle(n_cams):
     _compare_with_oracle(s, False, [([1.8], 25.0), ([0.9], 16.0), ([0.9], 9.0)])
 
 
+def test_concurrent_handles_on_separate_threads():
+    """SURVEY 8b threading contract: every BundlerLib instance is thread-confined, several run concurrently on different
+    threads (mapping, loop closure, tracking).  Four handles, each on its own thread and HIP stream, interleaved on one
+    device, must reproduce the fixtures exactly as they do alone."""
+    import threading
+    names = ["ba_tiny_clean", "ba_tiny_outliers", "ba_small_fixedcams", "ba_tiny_outliers"]
+    errors = []
+
+    def work(name):
+        try:
+            for _ in range(3):
+                run_case(BundlerLib(False), _bulk, name)
+        except BaseException as e:        # noqa: BLE001 - reported to the main thread
+            errors.append((name, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(n,)) for n in names]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors
+
+
 def test_multi_step_calls_and_lambda_persistence():
     s = scene.make_config("tiny", seed=123)
     g, o = BundlerLib(), OracleBundler()

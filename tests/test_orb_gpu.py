@@ -49,6 +49,30 @@ def test_batch_of_frames_equals_oracle_frame_by_frame():
         assert np.array_equal(kp_xyr(K[i, : C[i]]), kp_xyr(k)) and np.array_equal(D[i, : C[i]], d)
 
 
+def test_detectors_and_matchers_on_concurrent_threads(gold):
+    """One detector per camera, one frame in flight per detector, several cameras at once: four detector +
+    matcher handles on their own threads and streams give the fixture results."""
+    import threading
+    errors = []
+
+    def work(name):
+        try:
+            det, m = OrbDetector(), Matcher()
+            for _ in range(4):
+                k, d = det.DetectAndCompute(gold[name + "_img"])
+                assert np.array_equal(kp_xyr(k), gold[name + "_kp"]) and np.array_equal(d, gold[name + "_desc"])
+                got = m.Match(gold["orb_640x480_a_desc"], gold["orb_640x480_b_desc"], None, None, 30, 1)
+                got = np.stack([got["queryIdx"], got["trainIdx"], got["distance"].astype(np.int64)], axis=1)
+                assert np.array_equal(got, gold["matches_ab"])
+        except BaseException as e:        # noqa: BLE001 - reported to the main thread
+            errors.append((name, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(n,)) for n in CASES]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors
+
+
 @pytest.mark.parametrize("kw", [dict(patch_size=31), dict(gaussian_kernel_size=1), dict(gaussian_kernel_size=5, nfeatures=100),
                                 dict(fast_threshold=20, num_cells_x=8, num_cells_y=5), dict(feature_factor_anms=1.0, max_robust_factor=2.2)])
 def test_non_default_settings_match_oracle(kw):
