@@ -39,6 +39,12 @@ typedef enum mage_status {
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* mage_last_error(void);
 
+/* Device buffers of destroyed handles (BA, ORB, matcher) are parked per device and reused by the next handle, because the
+ * reference creates and destroys a bundler per optimisation (BundleAdjust.cpp:348-351) and a fresh 0.8 GB allocation costs
+ * ~25 ms.  The parked total is bounded by MAGE_DEVICE_CACHE_MB (default 4096, 0 = no caching); this call returns all of it
+ * to the HIP runtime now. */
+void mage_release_cached_memory(void);
+
 typedef struct mage_ba mage_ba;
 
 /* mage::BundlerParameters (BundlerLib.h:15-18) + device placement. */

@@ -68,7 +68,15 @@ def _declare():
     L.mage_ba_get_iter_stats.argtypes = [vp, C.POINTER(IterStats), sz, C.POINTER(sz)]
     L.mage_ba_enable_profiling.argtypes = [vp, C.c_int]
     L.mage_ba_get_profile.argtypes = [vp, C.POINTER(Profile)]
+    L.mage_release_cached_memory.argtypes = []
+    L.mage_release_cached_memory.restype = None
     _declared = True
+
+
+def release_cached_memory() -> None:
+    """Returns the device / pinned buffers and streams parked by destroyed handles to the HIP runtime (include/mage_ba.h)."""
+    _declare()
+    lib().mage_release_cached_memory()
 
 
 class BundlerLib:

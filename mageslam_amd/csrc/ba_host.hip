@@ -10,8 +10,14 @@
 // graph structure, sequences launches, and reads back three scalars per LM trial.
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
+#include <map>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "ba_kernels.h"
@@ -24,6 +30,131 @@ std::string& last_error_ref()
 {
     thread_local std::string s;
     return s;
+}
+
+namespace {
+struct DeviceCache {
+    static constexpr int MAX_DEVICES = 64;
+    std::mutex m;
+    std::multimap<size_t, void*> parked[MAX_DEVICES];
+    std::vector<hipStream_t> streams[MAX_DEVICES];
+    std::multimap<size_t, void*> pinned;
+    size_t pinned_held = 0;
+    size_t held[MAX_DEVICES] = {};
+    size_t limit;
+    DeviceCache()
+    {
+        const char* e = std::getenv("MAGE_DEVICE_CACHE_MB");
+        limit = (size_t)(e ? std::max(0L, std::atol(e)) : 4096L) << 20;
+    }
+};
+DeviceCache& device_cache()
+{
+    static DeviceCache* c = new DeviceCache();      // never destroyed: the HIP runtime may be gone by static-destructor time
+    return *c;
+}
+size_t cache_round(size_t bytes)
+{
+    const size_t g = bytes < ((size_t)1 << 20) ? 4096 : ((size_t)1 << 20);
+    return (std::max<size_t>(bytes, 1) + g - 1) / g * g;
+}
+}  // namespace
+
+mage_status cached_device_alloc(void** p, size_t bytes, int* device, size_t* granted)
+{
+    int dev = 0;
+    MAGE_HIP(hipGetDevice(&dev));
+    const size_t want = cache_round(bytes);
+    *device = dev; *granted = want; *p = nullptr;
+    DeviceCache& c = device_cache();
+    if (dev >= 0 && dev < DeviceCache::MAX_DEVICES) {
+        std::lock_guard<std::mutex> lock(c.m);
+        auto it = c.parked[dev].lower_bound(want);
+        if (it != c.parked[dev].end() && it->first <= want + want / 4) {       // a parked block no more than 25 % larger
+            *p = it->second; *granted = it->first;
+            c.held[dev] -= it->first;
+            c.parked[dev].erase(it);
+            return MAGE_OK;
+        }
+    }
+    hipError_t e = hipMalloc(p, want);
+    if (e == hipErrorOutOfMemory) {                 // give the parked memory back before reporting failure
+        mage_release_cached_memory();
+        e = hipMalloc(p, want);
+    }
+    MAGE_HIP(e);
+    return MAGE_OK;
+}
+
+mage_status cached_pinned_alloc(void** p, size_t bytes, size_t* granted)
+{
+    const size_t want = cache_round(bytes);
+    *granted = want; *p = nullptr;
+    DeviceCache& c = device_cache();
+    {
+        std::lock_guard<std::mutex> lock(c.m);
+        auto it = c.pinned.lower_bound(want);
+        if (it != c.pinned.end() && it->first <= 2 * want) {
+            *p = it->second; *granted = it->first;
+            c.pinned_held -= it->first;
+            c.pinned.erase(it);
+            return MAGE_OK;
+        }
+    }
+    MAGE_HIP(hipHostMalloc(p, want, hipHostMallocDefault));
+    return MAGE_OK;
+}
+
+void cached_pinned_release(void* p, size_t bytes)
+{
+    if (!p) return;
+    DeviceCache& c = device_cache();
+    {
+        std::lock_guard<std::mutex> lock(c.m);
+        if (c.pinned_held + bytes <= c.limit / 4) {          // pinned host memory: a quarter of the device budget
+            c.pinned.emplace(bytes, p);
+            c.pinned_held += bytes;
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+
+mage_status cached_stream_acquire(int device, hipStream_t* out)
+{
+    DeviceCache& c = device_cache();
+    if (device >= 0 && device < DeviceCache::MAX_DEVICES) {
+        std::lock_guard<std::mutex> lock(c.m);
+        if (!c.streams[device].empty()) { *out = c.streams[device].back(); c.streams[device].pop_back(); return MAGE_OK; }
+    }
+    MAGE_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return MAGE_OK;
+}
+
+void cached_stream_release(int device, hipStream_t st)
+{
+    if (!st) return;
+    DeviceCache& c = device_cache();
+    if (c.limit > 0 && device >= 0 && device < DeviceCache::MAX_DEVICES) {
+        std::lock_guard<std::mutex> lock(c.m);
+        if (c.streams[device].size() < 16) { c.streams[device].push_back(st); return; }
+    }
+    (void)hipStreamDestroy(st);
+}
+
+void cached_device_release(void* p, size_t bytes, int device)
+{
+    if (!p) return;
+    DeviceCache& c = device_cache();
+    if (device >= 0 && device < DeviceCache::MAX_DEVICES) {
+        std::lock_guard<std::mutex> lock(c.m);
+        if (c.held[device] + bytes <= c.limit) {
+            c.parked[device].emplace(bytes, p);
+            c.held[device] += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
 }
 
 mage_status select_device(int requested, int* chosen)
@@ -152,7 +283,7 @@ struct mage_ba {
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (h_scal) (void)hipHostFree(h_scal);
-        if (stream) (void)hipStreamDestroy(stream);
+        cached_stream_release(device, stream);
     }
 };
 
@@ -218,11 +349,52 @@ void refresh_view_state(mage_ba* h)
     h->view.pt_cur = h->d_pt[h->cur].p; h->view.pt_trial = h->d_pt[h->cur ^ 1].p;
 }
 
-struct Contrib { int i, j, sa, sb; };
-
 // SparseOptimizer::initializeOptimization + BlockSolver::buildStructure, re-expressed as flat CSR arrays.
+// MAGE_BA_TIMING=1 prints the host phases of the structure build to stderr (diagnostics only).
+// The structure build is host work between two GPU phases; its independent loops run on a few short-lived threads
+// (MAGE_HOST_THREADS, default min(8, hardware threads); 1 = the calling thread only).
+int host_threads()
+{
+    static const int n = [] {
+        const char* e = std::getenv("MAGE_HOST_THREADS");
+        int t = e ? std::atoi(e) : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+        return std::max(1, std::min(t, 64));
+    }();
+    return n;
+}
+
+// fn(begin, end, part) over [0, n) split into equal contiguous parts; part boundaries are a function of (n, parts) only.
+// Small problems (the tracking thread's pose-only solves, local BA) stay on the calling thread.
+inline int parts_for(int n, int grain) { return std::max(1, std::min(host_threads(), n / std::max(grain, 1))); }
+
+template <typename F>
+void parallel_ranges(int n, int parts, F&& fn)
+{
+    parts = std::max(1, std::min(parts, n));
+    if (parts == 1) { fn(0, n, 0); return; }
+    std::vector<std::thread> th;
+    th.reserve(parts - 1);
+    for (int p = 1; p < parts; ++p)
+        th.emplace_back([&, p] { fn((int)((int64_t)n * p / parts), (int)((int64_t)n * (p + 1) / parts), p); });
+    fn(0, (int)((int64_t)n / parts), 0);
+    for (auto& t : th) t.join();
+}
+
+struct PhaseTimer {
+    bool on; std::chrono::steady_clock::time_point t0;
+    PhaseTimer() : on(std::getenv("MAGE_BA_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mage_ba structure] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 mage_status initialize_optimization(mage_ba* h)
 {
+    PhaseTimer tm;
     MAGE_HIP(hipSetDevice(h->device));
     const int nc = (int)h->cams.size(), np = (int)h->pt_set.size();
     if (!h->state_on_device) MAGE_TRY(upload_state(h));
@@ -233,6 +405,7 @@ mage_status initialize_optimization(mage_ba* h)
         if (nc) MAGE_HIP(hipMemcpyAsync(h->d_pose[h->cur ^ 1].p, h->d_pose[h->cur].p, (size_t)nc * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         if (np) MAGE_HIP(hipMemcpyAsync(h->d_pt[h->cur ^ 1].p, h->d_pt[h->cur].p, (size_t)np * 4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     }
+    tm.mark("state upload");
     const size_t no = h->obs.size();
 
     // active observations: set, not removed, not (camera fixed and points fixed)
@@ -275,6 +448,25 @@ mage_status initialize_optimization(mage_ba* h)
     const bool points_free = !h->points_fixed;
     h->useless = (nfc + (points_free ? nlm : 0)) == 0;
 
+    tm.mark("active sets");
+    // Lists that go to the device are built in pinned memory and copied as soon as they are complete, so the DMA overlaps
+    // the rest of the build; small ones are staged through the same arena.
+    PinnedArena arena;
+    hipStream_t st = h->stream;
+    auto push = [&](auto& dbuf, const auto* src, size_t count) -> mage_status {
+        MAGE_TRY(dbuf.reserve(count));
+        if (count) MAGE_HIP(hipMemcpyAsync(dbuf.p, src, count * sizeof(*src), hipMemcpyHostToDevice, st));
+        return MAGE_OK;
+    };
+    auto push_vec = [&](auto& dbuf, const auto& vec) -> mage_status {
+        typename std::remove_reference<decltype(vec)>::type::value_type* q = nullptr;
+        MAGE_TRY(arena.take(vec.size(), &q));
+        if (!vec.empty()) std::memcpy(q, vec.data(), vec.size() * sizeof(*q));
+        return push(dbuf, q, vec.size());
+    };
+    MAGE_TRY(push_vec(h->d_cam2hc, cam2hc));
+    MAGE_TRY(push_vec(h->d_hc2cam, hc2cam));
+
     // landmark-ordered observation list
     std::vector<int> lm_ptr(nlm + 1, 0);
     for (int a = 0; a < nL; ++a) lm_ptr[pt2lm[h->obs[active[a]].pt] + 1]++;
@@ -289,90 +481,151 @@ mage_status initialize_optimization(mage_ba* h)
         int hcv = cam2hc[h->obs[e].cam];
         return ((uint64_t)(hcv < 0 ? 0x7fffffff : hcv) << 32) | e;
     };
-    for (int l = 0; l < nlm; ++l) {
-        auto b = L_edge.begin() + lm_ptr[l], en = L_edge.begin() + lm_ptr[l + 1];
-        std::sort(b, en, [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
-    }
-    std::vector<float2> L_uv(nL); std::vector<float> L_info(nL); std::vector<uint32_t> L_cam(nL), L_pt(nL); std::vector<int> L_slot(nL, -1);
-    std::vector<int> lm_wptr(nlm + 1, 0), w_hc, w_lm;
-    for (int l = 0; l < nlm; ++l) {
-        int prev = -1;
-        for (int i = lm_ptr[l]; i < lm_ptr[l + 1]; ++i) {
-            const HostObs& o = h->obs[L_edge[i]];
-            L_uv[i] = make_float2(o.u, o.v); L_info[i] = o.info; L_cam[i] = o.cam; L_pt[i] = o.pt;
-            const int hcv = cam2hc[o.cam];
-            if (points_free && hcv >= 0) {
-                if (hcv != prev) { w_hc.push_back(hcv); w_lm.push_back(l); prev = hcv; }
-                L_slot[i] = (int)w_hc.size() - 1;
+    float2* L_uv = nullptr; float* L_info = nullptr; uint32_t *L_cam = nullptr, *L_pt = nullptr; int *L_slot = nullptr, *w_hc = nullptr, *w_lm = nullptr;
+    MAGE_TRY(arena.take(nL, &L_uv)); MAGE_TRY(arena.take(nL, &L_info)); MAGE_TRY(arena.take(nL, &L_cam)); MAGE_TRY(arena.take(nL, &L_pt));
+    MAGE_TRY(arena.take(nL, &L_slot)); MAGE_TRY(arena.take(nL, &w_hc)); MAGE_TRY(arena.take(nL, &w_lm));        // slots <= observations
+    std::vector<int> lm_wptr(nlm + 1, 0);
+    const int lm_parts = parts_for(nlm, 8192);
+    // order inside each landmark, and its number of slots (distinct free cameras)
+    parallel_ranges(nlm, lm_parts, [&](int l0, int l1, int) {
+        std::vector<uint64_t> keys;
+        for (int l = l0; l < l1; ++l) {
+            const int b = lm_ptr[l], k = lm_ptr[l + 1] - b;
+            bool sorted = true;
+            keys.resize(k);
+            for (int i = 0; i < k; ++i) { keys[i] = key(L_edge[b + i]); if (i && keys[i] < keys[i - 1]) sorted = false; }
+            if (!sorted) {
+                std::sort(keys.begin(), keys.end());
+                for (int i = 0; i < k; ++i) L_edge[b + i] = (uint32_t)(keys[i] & 0xffffffffu);
+            }
+            int slots = 0;
+            if (points_free) {
+                uint32_t prev = 0xffffffffu;
+                for (int i = 0; i < k; ++i) {
+                    const uint32_t hcv = (uint32_t)(keys[i] >> 32);
+                    if (hcv != 0x7fffffffu && hcv != prev) { ++slots; prev = hcv; }
+                }
+            }
+            lm_wptr[l + 1] = slots;
+        }
+    });
+    for (int l = 0; l < nlm; ++l) lm_wptr[l + 1] += lm_wptr[l];
+    const int nw = lm_wptr[nlm];
+    parallel_ranges(nlm, lm_parts, [&](int l0, int l1, int) {
+        for (int l = l0; l < l1; ++l) {
+            int prev = -1, w = lm_wptr[l];
+            for (int i = lm_ptr[l]; i < lm_ptr[l + 1]; ++i) {
+                const HostObs& o = h->obs[L_edge[i]];
+                L_uv[i] = make_float2(o.u, o.v); L_info[i] = o.info; L_cam[i] = o.cam; L_pt[i] = o.pt;
+                const int hcv = cam2hc[o.cam];
+                int slot = -1;
+                if (points_free && hcv >= 0) {
+                    if (hcv != prev) { w_hc[w] = hcv; w_lm[w] = l; ++w; prev = hcv; }
+                    slot = w - 1;
+                }
+                L_slot[i] = slot;
             }
         }
-        lm_wptr[l + 1] = (int)w_hc.size();
-    }
-    const int nw = (int)w_hc.size();
+    });
+    MAGE_TRY(push(h->d_L_uv, L_uv, nL)); MAGE_TRY(push(h->d_L_info, L_info, nL)); MAGE_TRY(push(h->d_L_cam, L_cam, nL));
+    MAGE_TRY(push(h->d_L_pt, L_pt, nL)); MAGE_TRY(push(h->d_L_slot, L_slot, nL));
+    MAGE_TRY(push(h->d_w_hc, w_hc, nw)); MAGE_TRY(push(h->d_w_lm, w_lm, nw));
+    MAGE_TRY(push_vec(h->d_L_edge, L_edge));
+    MAGE_TRY(push_vec(h->d_lm_ptr, lm_ptr)); MAGE_TRY(push_vec(h->d_lm_pt, lm_pt)); MAGE_TRY(push_vec(h->d_lm_wptr, lm_wptr));
 
+    tm.mark("landmark lists");
     // per-camera lists
+    // Both are counting sorts by camera that keep the input order (observation index for camE, slot index for camS); each
+    // thread counts a contiguous range of the input, the offsets are the camera's base plus the counts of the ranges before it.
     std::vector<int> camE_ptr(nfc + 1, 0), camS_ptr(nfc + 1, 0);
-    std::vector<int> pos_of(nL);
+    int *camE = nullptr, *camS = nullptr;
     {
-        // positions in ascending observation index: sort (edge, pos) pairs by edge
-        std::vector<std::pair<uint32_t, int>> ep(nL);
-        for (int i = 0; i < nL; ++i) ep[i] = { L_edge[i], i };
-        std::sort(ep.begin(), ep.end());
-        for (int i = 0; i < nL; ++i) pos_of[i] = ep[i].second;
+        const int parts = parts_for(nL, 65536);
+        std::vector<int> where(no, -1);                 // observation index -> landmark-order position
+        parallel_ranges(nL, parts, [&](int i0, int i1, int) { for (int i = i0; i < i1; ++i) where[L_edge[i]] = i; });
+        auto stable_by_camera = [&](int count, auto&& camera_of, auto&& item_of, std::vector<int>& ptr, int** out) -> mage_status {
+            const int np_ = std::max(1, std::min(parts, count));
+            std::vector<std::vector<int>> cnt(np_, std::vector<int>(nfc, 0));
+            parallel_ranges(count, np_, [&](int a0, int a1, int part) {
+                for (int a = a0; a < a1; ++a) { const int c = camera_of(a); if (c >= 0) cnt[part][c]++; }
+            });
+            for (int c = 0; c < nfc; ++c) {
+                int base = ptr[c];
+                for (int part = 0; part < np_; ++part) { const int k = cnt[part][c]; cnt[part][c] = base; base += k; }
+                ptr[c + 1] = base;
+            }
+            MAGE_TRY(arena.take((size_t)ptr[nfc], out));
+            int* dst = *out;
+            parallel_ranges(count, np_, [&](int a0, int a1, int part) {
+                for (int a = a0; a < a1; ++a) { const int c = camera_of(a); if (c >= 0) dst[cnt[part][c]++] = item_of(a); }
+            });
+            return MAGE_OK;
+        };
+        // a camera's observations in ascending observation index: `active` is ascending and L_edge is a permutation of it
+        MAGE_TRY(stable_by_camera(nL, [&](int a) { return cam2hc[L_cam[where[active[a]]]]; }, [&](int a) { return where[active[a]]; }, camE_ptr, &camE));
+        MAGE_TRY(stable_by_camera(nw, [&](int s2) { return w_hc[s2]; }, [&](int s2) { return s2; }, camS_ptr, &camS));
     }
-    for (int i = 0; i < nL; ++i) { int hcv = cam2hc[L_cam[i]]; if (hcv >= 0) camE_ptr[hcv + 1]++; }
-    for (int c = 0; c < nfc; ++c) camE_ptr[c + 1] += camE_ptr[c];
-    std::vector<int> camE(camE_ptr[nfc]);
-    {
-        std::vector<int> fill(camE_ptr.begin(), camE_ptr.end() - 1);
-        for (int a = 0; a < nL; ++a) { int i = pos_of[a]; int hcv = cam2hc[L_cam[i]]; if (hcv >= 0) camE[fill[hcv]++] = i; }
-    }
-    for (int s = 0; s < nw; ++s) camS_ptr[w_hc[s] + 1]++;
-    for (int c = 0; c < nfc; ++c) camS_ptr[c + 1] += camS_ptr[c];
-    std::vector<int> camS(nw);
-    {
-        std::vector<int> fill(camS_ptr.begin(), camS_ptr.end() - 1);
-        for (int s = 0; s < nw; ++s) camS[fill[w_hc[s]]++] = s;
-    }
+    MAGE_TRY(push(h->d_camE, camE, (size_t)camE_ptr[nfc])); MAGE_TRY(push(h->d_camS, camS, (size_t)nw));
+    MAGE_TRY(push_vec(h->d_camE_ptr, camE_ptr)); MAGE_TRY(push_vec(h->d_camS_ptr, camS_ptr));
 
+    tm.mark("camera lists");
     // reduced-camera-matrix blocks: contributions (slot_a, slot_b), a <= b inside a landmark, ordered by
-    // (i, j) with landmark order preserved inside a block (two stable counting sorts).
+    // (i, j) with landmark order preserved inside a block.
     size_t ncon = 0;
     for (int l = 0; l < nlm; ++l) { size_t k = (size_t)(lm_wptr[l + 1] - lm_wptr[l]); ncon += k * (k + 1) / 2; }
-    std::vector<Contrib> E(ncon), E2(ncon);
+    // Row i of the block structure is built from the slots of camera i (camS: ascending slot = ascending landmark): every
+    // later slot b >= a of the same landmark is a camera j >= i.  A counting sort over j inside the row (two passes over a
+    // few thousand contributions, cache resident) replaces a global sort of all contributions.
+    std::vector<int> blk_ptr; std::vector<int2> blk_ij;
+    int2* con = nullptr;
+    MAGE_TRY(arena.take(ncon, &con));
     {
-        size_t p = 0;
-        for (int l = 0; l < nlm; ++l)
-            for (int a = lm_wptr[l]; a < lm_wptr[l + 1]; ++a)
-                for (int b = a; b < lm_wptr[l + 1]; ++b) E[p++] = { w_hc[a], w_hc[b], a, b };
-        std::vector<size_t> cnt((size_t)nfc + 1, 0);
-        for (size_t q = 0; q < ncon; ++q) cnt[E[q].j + 1]++;
-        for (int c = 0; c < nfc; ++c) cnt[c + 1] += cnt[c];
-        for (size_t q = 0; q < ncon; ++q) E2[cnt[E[q].j]++] = E[q];
-        std::fill(cnt.begin(), cnt.end(), 0);
-        for (size_t q = 0; q < ncon; ++q) cnt[E2[q].i + 1]++;
-        for (int c = 0; c < nfc; ++c) cnt[c + 1] += cnt[c];
-        for (size_t q = 0; q < ncon; ++q) E[cnt[E2[q].i]++] = E2[q];
-    }
-    E2.clear(); E2.shrink_to_fit();
-    std::vector<int> blk_ptr; std::vector<int2> blk_ij; std::vector<int2> con(ncon);
-    blk_ptr.reserve(ncon / 8 + nfc + 2);
-    {
+        // pass 1 (parallel over rows): the blocks of each row and their sizes
+        const int parts = ncon >= 262144 ? parts_for(nfc, 8) : 1;
+        std::vector<std::vector<int2>> row_blocks(nfc);                 // (j, count) ascending j
+        parallel_ranges(nfc, parts, [&](int r0, int r1, int) {
+            std::vector<int> cnt(nfc, 0), touched;
+            for (int i = r0; i < r1; ++i) {
+                touched.clear();
+                touched.push_back(i);    // the diagonal block of every free camera exists even with no landmark contribution
+                for (int k = camS_ptr[i]; k < camS_ptr[i + 1]; ++k) {
+                    const int a = camS[k], end = lm_wptr[w_lm[a] + 1];
+                    for (int b = a; b < end; ++b) { const int j = w_hc[b]; if (cnt[j]++ == 0 && j != i) touched.push_back(j); }
+                }
+                std::sort(touched.begin(), touched.end());
+                row_blocks[i].reserve(touched.size());
+                for (int j : touched) { row_blocks[i].push_back(make_int2(j, cnt[j])); cnt[j] = 0; }
+            }
+        });
+        // block offsets (serial prefix sum)
+        size_t nb = 0;
+        for (int i = 0; i < nfc; ++i) nb += row_blocks[i].size();
+        blk_ptr.reserve(nb + 1); blk_ij.reserve(nb);
+        std::vector<size_t> row_first(nfc + 1, 0);
         size_t q = 0;
         for (int i = 0; i < nfc; ++i) {
-            // the diagonal block of every free camera exists even with no landmark contribution
-            if (!(q < ncon && E[q].i == i && E[q].j == i)) { blk_ptr.push_back((int)q); blk_ij.push_back(make_int2(i, i)); }
-            while (q < ncon && E[q].i == i) {
-                const int j = E[q].j;
-                blk_ptr.push_back((int)q); blk_ij.push_back(make_int2(i, j));
-                while (q < ncon && E[q].i == i && E[q].j == j) { con[q] = make_int2(E[q].sa, E[q].sb); ++q; }
-            }
+            row_first[i] = blk_ptr.size();
+            for (const int2& jc : row_blocks[i]) { blk_ptr.push_back((int)q); blk_ij.push_back(make_int2(i, jc.x)); q += (size_t)jc.y; }
         }
+        row_first[nfc] = blk_ptr.size();
         blk_ptr.push_back((int)ncon);
+        // pass 2 (parallel over rows): scatter the contributions of a row into its blocks
+        parallel_ranges(nfc, parts, [&](int r0, int r1, int) {
+            std::vector<size_t> start(nfc, 0);
+            for (int i = r0; i < r1; ++i) {
+                for (size_t k = row_first[i]; k < row_first[i + 1]; ++k) start[blk_ij[k].y] = (size_t)blk_ptr[k];
+                for (int k = camS_ptr[i]; k < camS_ptr[i + 1]; ++k) {
+                    const int a = camS[k], end = lm_wptr[w_lm[a] + 1];
+                    for (int b = a; b < end; ++b) con[start[w_hc[b]]++] = make_int2(a, b);
+                }
+            }
+        });
     }
     const int nblk = (int)blk_ij.size();
-    E.clear(); E.shrink_to_fit();
+    MAGE_TRY(push(h->d_con, con, ncon));
+    MAGE_TRY(push_vec(h->d_blk_ptr, blk_ptr)); MAGE_TRY(push_vec(h->d_blk_ij, blk_ij));
 
+    tm.mark("schur contributions");
     // tether gather lists: per camera (tether, side) and per free-camera pair i < j (tether, transposed), tether order kept
     std::vector<int> tc_hc, tc_ptr{ 0 }, tc_item, tp_ptr{ 0 }, tp_item; std::vector<int2> tp_ij;
     if (nT > 0) {
@@ -407,40 +660,21 @@ mage_status initialize_optimization(mage_ba* h)
     const int n = nfc * 6;
     const int n_pad = std::max(CHOL_TILE, ((n + CHOL_TILE - 1) / CHOL_TILE) * CHOL_TILE);
 
-    hipStream_t st = h->stream;
-    MAGE_TRY(h->d_cam2hc.upload(cam2hc.data(), cam2hc.size(), st));
-    MAGE_TRY(h->d_hc2cam.upload(hc2cam.data(), hc2cam.size(), st));
-    MAGE_TRY(h->d_L_uv.upload(L_uv.data(), L_uv.size(), st));
-    MAGE_TRY(h->d_L_info.upload(L_info.data(), L_info.size(), st));
-    MAGE_TRY(h->d_L_cam.upload(L_cam.data(), L_cam.size(), st));
-    MAGE_TRY(h->d_L_pt.upload(L_pt.data(), L_pt.size(), st));
-    MAGE_TRY(h->d_L_slot.upload(L_slot.data(), L_slot.size(), st));
-    MAGE_TRY(h->d_L_edge.upload(L_edge.data(), L_edge.size(), st));
-    MAGE_TRY(h->d_lm_ptr.upload(lm_ptr.data(), lm_ptr.size(), st));
-    MAGE_TRY(h->d_lm_pt.upload(lm_pt.data(), lm_pt.size(), st));
-    MAGE_TRY(h->d_lm_wptr.upload(lm_wptr.data(), lm_wptr.size(), st));
-    MAGE_TRY(h->d_w_hc.upload(w_hc.data(), w_hc.size(), st));
-    MAGE_TRY(h->d_w_lm.upload(w_lm.data(), w_lm.size(), st));
-    MAGE_TRY(h->d_camE_ptr.upload(camE_ptr.data(), camE_ptr.size(), st));
-    MAGE_TRY(h->d_camE.upload(camE.data(), camE.size(), st));
-    MAGE_TRY(h->d_camS_ptr.upload(camS_ptr.data(), camS_ptr.size(), st));
-    MAGE_TRY(h->d_camS.upload(camS.data(), camS.size(), st));
-    MAGE_TRY(h->d_blk_ptr.upload(blk_ptr.data(), blk_ptr.size(), st));
-    MAGE_TRY(h->d_blk_ij.upload(blk_ij.data(), blk_ij.size(), st));
-    MAGE_TRY(h->d_con.upload(con.data(), con.size(), st));
-    MAGE_TRY(h->d_T_kind.upload(T_kind.data(), T_kind.size(), st));
-    MAGE_TRY(h->d_T_cam.upload(T_cam.data(), T_cam.size(), st));
-    MAGE_TRY(h->d_T_fixed.upload(T_fixed.data(), T_fixed.size(), st));
-    MAGE_TRY(h->d_T_meas.upload(T_meas.data(), T_meas.size(), st));
-    MAGE_TRY(h->d_T_w.upload(T_w.data(), T_w.size(), st));
-    MAGE_TRY(h->d_tc_hc.upload(tc_hc.data(), tc_hc.size(), st));
-    MAGE_TRY(h->d_tc_ptr.upload(tc_ptr.data(), tc_ptr.size(), st));
-    MAGE_TRY(h->d_tc_item.upload(tc_item.data(), tc_item.size(), st));
-    MAGE_TRY(h->d_tp_ij.upload(tp_ij.data(), tp_ij.size(), st));
-    MAGE_TRY(h->d_tp_ptr.upload(tp_ptr.data(), tp_ptr.size(), st));
-    MAGE_TRY(h->d_tp_item.upload(tp_item.data(), tp_item.size(), st));
+    tm.mark("tethers");
+    MAGE_TRY(push_vec(h->d_T_kind, T_kind));
+    MAGE_TRY(push_vec(h->d_T_cam, T_cam));
+    MAGE_TRY(push_vec(h->d_T_fixed, T_fixed));
+    MAGE_TRY(push_vec(h->d_T_meas, T_meas));
+    MAGE_TRY(push_vec(h->d_T_w, T_w));
+    MAGE_TRY(push_vec(h->d_tc_hc, tc_hc));
+    MAGE_TRY(push_vec(h->d_tc_ptr, tc_ptr));
+    MAGE_TRY(push_vec(h->d_tc_item, tc_item));
+    MAGE_TRY(push_vec(h->d_tp_ij, tp_ij));
+    MAGE_TRY(push_vec(h->d_tp_ptr, tp_ptr));
+    MAGE_TRY(push_vec(h->d_tp_item, tp_item));
     MAGE_TRY(h->d_T_out.reserve((size_t)nT * TETHER_OUT_STRIDE + 1));
 
+    tm.mark("uploads queued");
     const int nb_l = (nlm + 255) / 256, nb_c = (nfc + 255) / 256;
     MAGE_TRY(h->d_errL.reserve((size_t)nL * 2 + 2));
     MAGE_TRY(h->d_U.reserve((size_t)nfc * 36 + 1));
@@ -464,8 +698,9 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_HIP(hipMemsetAsync(h->d_L_active.p, 1, (size_t)nL + 1, st));
     if (!h->h_scal) MAGE_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), SC_COUNT * sizeof(double)));
     MAGE_HIP(hipMemsetAsync(h->d_errL.p, 0, ((size_t)nL * 2 + 2) * sizeof(double), st));
-    MAGE_HIP(hipStreamSynchronize(st));   // the host vectors above go out of scope
+    MAGE_HIP(hipStreamSynchronize(st));   // the pinned arena goes back to the cache
 
+    tm.mark("reserve + sync");
     BaDeviceView& v = h->view;
     v.n_cams = nc; v.n_pts = np; v.n_L = nL; v.n_lm = nlm; v.n_fc = nfc; v.n_w = nw; v.n_blk = nblk;
     v.points_free = points_free ? 1 : 0; v.n_pad = n_pad;
@@ -595,7 +830,10 @@ mage_status step_optimizer(mage_ba* h, double huber, bool* cont)
     }
     if (h->useless) { *cont = false; return MAGE_OK; }
     int r = LM_OK;
+    PhaseTimer tm;
+    const bool first = h->iteration == 0;
     MAGE_TRY(lm_solve(h, huber, &r));
+    if (first) tm.mark("first LM iteration");
     h->iteration++;
     *cont = (r == LM_OK);
     return MAGE_OK;
@@ -617,6 +855,27 @@ mage_status guarded(F&& f)
 // ================================================================================================
 MAGE_EXPORT const char* mage_last_error(void) { return last_error_ref().c_str(); }
 
+MAGE_EXPORT void mage_release_cached_memory(void)
+{
+    DeviceCache& c = device_cache();
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    std::lock_guard<std::mutex> lock(c.m);
+    for (int d = 0; d < DeviceCache::MAX_DEVICES; ++d) {
+        if (c.parked[d].empty() && c.streams[d].empty()) continue;
+        (void)hipSetDevice(d);
+        for (auto& kv : c.parked[d]) (void)hipFree(kv.second);
+        c.parked[d].clear();
+        c.held[d] = 0;
+        for (hipStream_t st : c.streams[d]) (void)hipStreamDestroy(st);
+        c.streams[d].clear();
+    }
+    for (auto& kv : c.pinned) (void)hipHostFree(kv.second);
+    c.pinned.clear();
+    c.pinned_held = 0;
+    if (have_cur) (void)hipSetDevice(cur);
+}
+
 MAGE_EXPORT mage_status mage_ba_create(const mage_ba_params* params, mage_ba** out)
 {
     return guarded([&]() -> mage_status {
@@ -628,7 +887,7 @@ MAGE_EXPORT mage_status mage_ba_create(const mage_ba_params* params, mage_ba** o
         h->device = dev;
         h->points_fixed = params ? params->are_points_fixed != 0 : false;
         MAGE_HIP(hipSetDevice(dev));
-        MAGE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        MAGE_TRY(cached_stream_acquire(dev, &h->stream));
         for (auto& e : h->ev) MAGE_HIP(hipEventCreate(&e));
         chol_init_device();
         *out = h.release();

@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <string>
+#include <vector>
 
 #include "../../include/mage_ba.h"
 
@@ -44,22 +46,72 @@ inline mage_status fail(mage_status s, const char* fmt, ...)
 // Checks that a usable gfx950 device exists; the HIP path never falls back to a CPU.
 mage_status select_device(int requested, int* chosen);
 
+// Device-memory cache.  The reference builds a bundler per optimisation and destroys it afterwards (BundleAdjust.cpp:348-351);
+// a 1k-pose problem holds ~0.8 GB, and a fresh hipMalloc of that size costs ~25 ms per handle (allocation, first use, hipFree).
+// Buffers of a destroyed handle are therefore parked here (per device, bounded, MAGE_DEVICE_CACHE_MB, default 4096; 0 turns
+// the cache off) and handed to the next handle.  Contents are undefined, as with hipMalloc.
+mage_status cached_device_alloc(void** p, size_t bytes, int* device, size_t* granted);
+void cached_device_release(void* p, size_t bytes, int device);     // caller guarantees no work in flight touches p
+
+// Streams are parked the same way: the first kernel on a new stream pays for its hardware queue and scratch (~16 ms).
+mage_status cached_stream_acquire(int device, hipStream_t* out);
+void cached_stream_release(int device, hipStream_t st);             // caller has synchronised st
+
+// Pinned host memory, parked like the device buffers.  hipMemcpyAsync from pageable memory makes the runtime pin and
+// unpin the source around every copy (several ms per 100 MB, paid at the next synchronisation); lists that are built for
+// upload are therefore built directly in pinned blocks, so the copy is one asynchronous DMA that overlaps the host work after it.
+mage_status cached_pinned_alloc(void** p, size_t bytes, size_t* granted);
+void cached_pinned_release(void* p, size_t bytes);                   // caller guarantees no copy in flight reads p
+
+// Bump allocator over pinned blocks; everything taken from it lives until release().
+struct PinnedArena {
+    struct Block { char* p; size_t cap, used; };
+    std::vector<Block> blocks;
+    PinnedArena() = default;
+    PinnedArena(const PinnedArena&) = delete;
+    PinnedArena& operator=(const PinnedArena&) = delete;
+    ~PinnedArena() { release(); }
+    void release()
+    {
+        for (Block& b : blocks) cached_pinned_release(b.p, b.cap);
+        blocks.clear();
+    }
+    template <typename T>
+    mage_status take(size_t n, T** out)
+    {
+        const size_t need = (n * sizeof(T) + 255) & ~(size_t)255;
+        if (blocks.empty() || blocks.back().used + need > blocks.back().cap) {
+            void* q = nullptr; size_t got = 0;
+            MAGE_TRY(cached_pinned_alloc(&q, std::max<size_t>(need, (size_t)32 << 20), &got));
+            blocks.push_back({ static_cast<char*>(q), got, 0 });
+        }
+        Block& b = blocks.back();
+        *out = reinterpret_cast<T*>(b.p + b.used);
+        b.used += need;
+        return MAGE_OK;
+    }
+};
+
 // Grow-only device buffer.
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;
+    size_t bytes = 0;
+    int device = 0;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p) cached_device_release(p, bytes, device); }       // handle destructors synchronise their stream first
     mage_status reserve(size_t n)
     {
         if (n <= cap) return MAGE_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = n + n / 8 + 16;
-        MAGE_HIP(hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T)));
-        cap = want;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }                // growth inside a live handle: hipFree synchronises
+        const size_t want = n + n / 8 + 16;
+        void* q = nullptr;
+        MAGE_TRY(cached_device_alloc(&q, want * sizeof(T), &device, &bytes));
+        p = static_cast<T*>(q);
+        cap = bytes / sizeof(T);
         return MAGE_OK;
     }
     mage_status upload(const T* src, size_t n, hipStream_t st)

@@ -99,7 +99,7 @@ struct mage_orb {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-        if (stream) (void)hipStreamDestroy(stream);
+        cached_stream_release(device, stream);
     }
 };
 
@@ -135,7 +135,7 @@ MAGE_EXPORT mage_status mage_orb_create(const mage_orb_params* params, mage_orb*
         h->device = dev; h->P = p;
         h->taps = gaussian_taps(p.gaussian_kernel_size);
         MAGE_HIP(hipSetDevice(dev));
-        MAGE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        MAGE_TRY(cached_stream_acquire(dev, &h->stream));
         for (auto& e : h->ev) MAGE_HIP(hipEventCreate(&e));
         std::vector<signed char> pat;
         expand_pattern(p.patch_size, pat);
@@ -443,7 +443,7 @@ struct mage_matcher {
         if (stream) (void)hipStreamSynchronize(stream);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
-        if (stream) (void)hipStreamDestroy(stream);
+        cached_stream_release(device, stream);
     }
 };
 
@@ -472,7 +472,7 @@ MAGE_EXPORT mage_status mage_matcher_create(int device, mage_matcher** out)
         std::unique_ptr<mage_matcher> h(new mage_matcher());
         h->device = dev;
         MAGE_HIP(hipSetDevice(dev));
-        MAGE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        MAGE_TRY(cached_stream_acquire(dev, &h->stream));
         MAGE_HIP(hipEventCreate(&h->e0)); MAGE_HIP(hipEventCreate(&h->e1));
         match_init_device();
         *out = h.release();

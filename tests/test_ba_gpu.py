@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from mageslam_amd import scene
-from mageslam_amd.bundler import BundlerLib, load_scene
+from mageslam_amd.bundler import BundlerLib, load_scene, release_cached_memory
 from oracle.oracle import OracleBundler, load_scene_bulk
 
 from ba_cases import BA_CASES, BA_TETHER_CASES, load_case, run_case
@@ -116,6 +116,18 @@ def test_concurrent_handles_on_separate_threads():
     for t in threads: t.start()
     for t in threads: t.join()
     assert not errors, errors
+
+
+def test_handles_reuse_parked_buffers_and_release_them():
+    """The reference builds and destroys a bundler per optimisation (BundleAdjust.cpp:348-351); destroyed handles park their
+    device / pinned buffers and stream for the next one.  Recycled (dirty) memory must not change any result, and
+    mage_release_cached_memory() must leave the library usable."""
+    for name in ("ba_small_fixedcams", "ba_tiny_outliers", "ba_small_fixedcams", "ba_tiny_clean"):
+        b = run_case(BundlerLib(False), _bulk, name)
+        del b
+    release_cached_memory()
+    release_cached_memory()          # idempotent
+    run_case(BundlerLib(False), _bulk, "ba_small_fixedcams")
 
 
 def test_multi_step_calls_and_lambda_persistence():
