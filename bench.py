@@ -84,7 +84,7 @@ def main() -> int:
     device = local_rank % max(n_dev, 1)             # one GPU per rank on the node; the modulo only matters for the single-GPU plumbing test
     torch.cuda.set_device(device)
     # "nccl" is RCCL on ROCm.  MAGE_DIST_BACKEND=gloo lets the N > 1 plumbing be exercised on a box with fewer GPUs than ranks.
-    dist = D.init(os.environ.get("MAGE_DIST_BACKEND", "nccl"), info)
+    dist = D.init(os.environ.get("MAGE_DIST_BACKEND", "nccl"), info, device_index=device)
 
     from mageslam_amd import scene
     from mageslam_amd.bundler import BundlerLib, load_scene
@@ -115,7 +115,7 @@ def main() -> int:
         trials += sum(t["trials"] for t in b.trace())
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed, total_steps, worst_rmse = D.reduce_stats(dist, elapsed, args.steps, float(np.sqrt(mse)), device="cuda")
+    elapsed, total_steps, worst_rmse = D.reduce_stats(dist, elapsed, args.steps, float(np.sqrt(mse)), device=D.stats_device(device))
     prof = b.profile()
 
     if rank == 0:
@@ -141,7 +141,8 @@ def main() -> int:
             "config": {"workload": f"{args.workload}: {kw['n_cams']} poses / {kw['n_pts']} points / {kw['n_obs']} observations, "
                                    f"Huber {HUBER}, poses 0,1 fixed, lambda seed {LAMBDA_SEED.get(args.workload, 'g2o default')}, "
                                    f"one independent sub-map per GPU",
-                       "parallelism": f"replica x{world} (independent sub-maps)"},
+                       "parallelism": f"replica x{world} (independent sub-maps)",
+                       "control_plane": (D.init.backend or "none") + (" (RCCL)" if D.init.backend == "nccl" else "")},
             "roofline": {
                 "kernel": "dense reduced-camera Cholesky (k_potrf_diag + k_trsm_panel + k_syrk_update[f64 MFMA] + k_bsolve_persist), "
                           "HIP-event span per factorisation on the solver stream",

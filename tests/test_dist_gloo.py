@@ -43,3 +43,35 @@ def test_two_rank_gloo_roundtrip(tmp_path):
     assert outs[0]["seed"] != outs[1]["seed"] and outs[0]["first_uv"] != outs[1]["first_uv"]     # distinct sub-maps
     for d in outs:                                                                               # every rank sees the same reduced stats
         assert d["el"] == 2.0 and d["n"] == 30 and d["rmse"] == 1.5
+
+
+FALLBACK_WORKER = textwrap.dedent("""
+    import sys, json
+    sys.path.insert(0, %r)
+    from mageslam_amd import dist as D
+    info = D.rank_info()
+    dist = D.init("nccl", info, device_index=0, timeout_s=60)        # no GPU here: RCCL cannot come up
+    assert dist is not None and D.init.backend == "gloo" and D.stats_device(0) == "cpu"
+    dist.barrier()
+    el, n, rmse = D.reduce_stats(dist, 1.0 + info.rank, 7, 0.25 * (info.rank + 1), device=D.stats_device(0))
+    print(json.dumps(dict(rank=info.rank, el=el, n=n, rmse=rmse)))
+    dist.barrier(); dist.destroy_process_group()
+""") % ROOT
+
+
+def test_rccl_bring_up_failure_falls_back_to_gloo_under_torchrun(tmp_path):
+    """bench.py's control plane must survive a node whose RCCL does not initialise: launched exactly as the driver does
+    (python -m torch.distributed.run, agent-hosted store), a failed "nccl" bring-up ends on gloo over the same store."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without GPUs so that RCCL bring-up fails")
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    script = tmp_path / "worker.py"
+    script.write_text(FALLBACK_WORKER)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    outs = [__import__("json").loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(outs) == 2 and all(d["el"] == 2.0 and d["n"] == 14 and d["rmse"] == 0.5 for d in outs)
+    assert "falling back to gloo" in p.stderr
