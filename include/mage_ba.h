@@ -143,7 +143,7 @@ mage_status mage_ba_get_iter_stats(const mage_ba* h, mage_ba_iter_stats* out, si
 typedef struct mage_ba_profile {
     uint64_t n_factorizations;
     double   factor_ms_total;      /* sum of event-timed factorisation spans */
-    double   factor_flops_each;    /* n^3/3 for the padded order n */
+    double   factor_flops_each;    /* n^3/3 for the system order n = 6 * free cameras (padding not counted) */
     uint64_t schur_launches;
     double   schur_ms_total;
     int      system_order;         /* 6 * free cameras */

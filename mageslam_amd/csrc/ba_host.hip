@@ -720,7 +720,7 @@ mage_status initialize_optimization(mage_ba* h)
     refresh_view_state(h);
     h->L_edge_host.swap(L_edge);
     h->prof.system_order = n; h->prof.padded_order = n_pad;
-    h->prof.factor_flops_each = (double)n_pad * n_pad * n_pad / 3.0;
+    h->prof.factor_flops_each = (double)n * n * n / 3.0;      // algorithmic: the system's order, not the padded one
     h->iteration = 0;
     h->dirty = false;
     h->soft_dirty = false;
