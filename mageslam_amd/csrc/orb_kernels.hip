@@ -751,29 +751,50 @@ __global__ __launch_bounds__(256) void k_ic_angles(const uint8_t* __restrict__ i
 // ---------------------------------------------------------------------------------------------
 // BRIEF-256: one wavefront per keypoint; lane l evaluates pairs 4l..4l+3, two lanes make a byte.
 // ---------------------------------------------------------------------------------------------
+constexpr int BRIEF_KPW = 4;      // keypoints per wavefront: their 32 pixel loads are in flight together, the pattern row is fetched once
 __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blurred, int wp, int h, const mage_keypoint* __restrict__ kps,
                                                const int* __restrict__ counts, int capacity, const signed char* __restrict__ pattern,
                                                uint8_t* __restrict__ desc)
 {
     const int f = blockIdx.y;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (k >= counts[f]) return;
-    const mage_keypoint kp = kps[(size_t)f * capacity + k];
+    const int k0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * BRIEF_KPW, lane = threadIdx.x & 63;
+    const int n = counts[f];
+    if (k0 >= n) return;
+    const uint8_t* frame = blurred + (size_t)f * wp * h;
     // cvRound of an integer-valued float; angleIncrement = cvRound(angle / 12) % 30 picks the pre-rotated table row
     // (OpenCVModified.cpp:523-532; angle is 0 unless UseOrientation)
-    const int cx = (int)rintf(kp.x), cy = (int)rintf(kp.y);
-    const uint8_t* c = blurred + (size_t)f * wp * h + (size_t)cy * wp + cx;
-    const int inc = (int)rintf(kp.angle / 12.0f) % 30;
-    const signed char* p = pattern + inc * 1024 + lane * 16;
-    int nib = 0;
+    const uint8_t* c[BRIEF_KPW];
+    int inc[BRIEF_KPW];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int t0 = c[p[4 * b + 1] * wp + p[4 * b]];
-        const int t1 = c[p[4 * b + 3] * wp + p[4 * b + 2]];
-        nib |= (t0 < t1) << b;
+    for (int q = 0; q < BRIEF_KPW; ++q) {
+        const int k = min(k0 + q, n - 1);
+        const mage_keypoint kp = kps[(size_t)f * capacity + k];
+        c[q] = frame + (size_t)((int)rintf(kp.y)) * wp + (int)rintf(kp.x);
+        inc[q] = (int)rintf(kp.angle / 12.0f) % 30;
     }
-    const int hi = __shfl_down(nib, 1, 64);
-    if ((lane & 1) == 0) desc[((size_t)f * capacity + k) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+    // this lane's four pairs of the table row: 16 signed bytes, one 128-bit load (rows are 1024 bytes, lane * 16 is aligned)
+    int4 pr = *reinterpret_cast<const int4*>(pattern + inc[0] * 1024 + lane * 16);
+    int t[BRIEF_KPW][8];
+#pragma unroll
+    for (int q = 0; q < BRIEF_KPW; ++q) {
+        if (q > 0 && inc[q] != inc[q - 1]) pr = *reinterpret_cast<const int4*>(pattern + inc[q] * 1024 + lane * 16);
+        const int w4[4] = { pr.x, pr.y, pr.z, pr.w };
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int x0 = (int)(signed char)(w4[b] & 0xff), y0 = (int)(signed char)((w4[b] >> 8) & 0xff);
+            const int x1 = (int)(signed char)((w4[b] >> 16) & 0xff), y1 = (int)(signed char)((w4[b] >> 24) & 0xff);
+            t[q][2 * b] = c[q][y0 * wp + x0];
+            t[q][2 * b + 1] = c[q][y1 * wp + x1];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < BRIEF_KPW; ++q) {
+        int nib = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) nib |= (t[q][2 * b] < t[q][2 * b + 1]) << b;
+        const int hi = __shfl_down(nib, 1, 64);
+        if ((lane & 1) == 0 && k0 + q < n) desc[((size_t)f * capacity + k0 + q) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+    }
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -829,7 +850,7 @@ void orb_launch_angles(const uint8_t* img, int stride, size_t frame_stride, int 
 void orb_launch_brief(const uint8_t* blurred, int wp, int h, int n_frames, const mage_keypoint* kps, const int* counts, int capacity,
                       const signed char* pattern, uint8_t* desc, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_brief, dim3(cdiv(capacity, 4), n_frames), dim3(256), 0, st, blurred, wp, h, kps, counts, capacity, pattern, desc);
+    hipLaunchKernelGGL(k_brief, dim3(cdiv(capacity, 4 * BRIEF_KPW), n_frames), dim3(256), 0, st, blurred, wp, h, kps, counts, capacity, pattern, desc);
 }
 
 }  // namespace mage

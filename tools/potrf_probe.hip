@@ -1,6 +1,11 @@
 // Cycle probe for the diagonal-tile factorisation pieces (development tool).
 #include "../mageslam_amd/csrc/chol_kernels.hip"
+#ifndef FACTOR_BLOCK
+#define FACTOR_BLOCK factor_block16
+#endif
 #include <cstdio>
+#include <cmath>
+#include <algorithm>
 #include <vector>
 using namespace mage;
 namespace mage { namespace {
@@ -13,7 +18,7 @@ __global__ __launch_bounds__(256) void k_probe(const double* __restrict__ S, int
     __syncthreads();
     long long t0 = clock64();
     bool f = false;
-    if (wave == 0) f = factor_block16(A, 0, lane, Li, Linv);
+    if (wave == 0) f = FACTOR_BLOCK(A, 0, lane, Li, Linv);
     long long t1 = clock64();
     __syncthreads();
     long long t2 = clock64();
@@ -22,6 +27,8 @@ __global__ __launch_bounds__(256) void k_probe(const double* __restrict__ S, int
     long long t3 = clock64();
     f |= potrf_tile_lds(A, Li, Linv, tid);
     long long t4 = clock64();
+    __syncthreads();
+    store_tile_lower(const_cast<double*>(S) + (size_t)ld * ld, A, ld, tid);      // second ld x ld matrix of the buffer receives L
     if (tid == 0) { out[0] = t1 - t0; out[1] = t2 - t1; out[2] = t4 - t3; out[3] = f; }
     if (tid == 64) { out[4] = t1 - t0; }
 }
@@ -34,7 +41,7 @@ int main()
     for (int j = 0; j < n; ++j) for (int i = j; i < n; ++i) { double v = (double)rand() / RAND_MAX - 0.5; A[(size_t)j * n + i] = v; A[(size_t)i * n + j] = v; }
     for (int i = 0; i < n; ++i) A[(size_t)i * n + i] = 70.0;
     double *dS, *dL; long long* dout;
-    hipMalloc(&dS, sizeof(double) * n * n); hipMalloc(&dL, sizeof(double) * 8 * 256); hipMalloc(&dout, 64);
+    hipMalloc(&dS, sizeof(double) * n * n * 2); hipMalloc(&dL, sizeof(double) * 8 * 256); hipMalloc(&dout, 64);
     hipMemcpy(dS, A.data(), sizeof(double) * n * n, hipMemcpyHostToDevice);
     const size_t lds = ((size_t)TILE * LDC + 2 * NB * NB) * sizeof(double);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -43,6 +50,28 @@ int main()
         hipDeviceSynchronize();
         long long o[5]; hipMemcpy(o, dout, 40, hipMemcpyDeviceToHost);
         printf("factor chol %lld cycles (inverse wave %lld), barrier %lld, potrf_tile_lds %lld cycles, failed %lld\n", o[0], o[4], o[1], o[2], o[3]);
+    }
+    {   // residuals: || A - L L^T || / || A || over the lower triangle, and || Linv_b L_bb - I || for the eight diagonal blocks
+        std::vector<double> L((size_t)n * n), Li(8 * 256);
+        hipMemcpy(L.data(), dS + (size_t)n * n, sizeof(double) * n * n, hipMemcpyDeviceToHost);
+        hipMemcpy(Li.data(), dL, sizeof(double) * 8 * 256, hipMemcpyDeviceToHost);
+        double num = 0, den = 0;
+        for (int j = 0; j < n; ++j) for (int i = j; i < n; ++i) {
+            double acc = 0;
+            for (int k = 0; k <= j; ++k) acc += L[(size_t)k * n + i] * L[(size_t)k * n + j];
+            const double d = acc - A[(size_t)j * n + i];
+            num += d * d; den += A[(size_t)j * n + i] * A[(size_t)j * n + i];
+        }
+        double worst = 0;
+        for (int b = 0; b < 8; ++b) for (int r = 0; r < 16; ++r) for (int c = 0; c < 16; ++c) {
+            double acc = 0;       // (Linv L)[r][c], Linv stored as Li[b][row * 16 + col]
+            for (int k = 0; k < 16; ++k) {
+                const double lkc = (k >= c) ? L[(size_t)(b * 16 + c) * n + b * 16 + k] : 0.0;
+                acc += Li[b * 256 + r * 16 + k] * lkc;
+            }
+            worst = std::max(worst, std::abs(acc - (r == c ? 1.0 : 0.0)));
+        }
+        printf("residual ||A - L L^T|| / ||A|| = %.3e   max |Linv L - I| = %.3e\n", std::sqrt(num / den), worst);
     }
     printf("%s\n", hipGetErrorString(hipGetLastError()));
     return 0;
