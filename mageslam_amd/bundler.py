@@ -53,6 +53,7 @@ def _declare():
     L.mage_ba_set_observation.argtypes = [vp, sz, _f32, C.c_uint64, C.c_uint64, C.c_float]
     L.mage_ba_set_cameras_bulk.argtypes = [vp, sz, _f32, _f32, _f32, _u8]
     L.mage_ba_set_points_bulk.argtypes = [vp, sz, _f32]
+    L.mage_ba_update_camera_poses.argtypes = [vp, sz, _u32, _f32, _f32]
     L.mage_ba_set_observations_bulk.argtypes = [vp, sz, _f32, _u32, _u32, _f32]
     L.mage_ba_set_fixed_distance_constraint.argtypes = [vp, sz, sz, sz, C.c_float, C.c_float]
     L.mage_ba_set_relative_rotation_constraint.argtypes = [vp, sz, sz, sz, _f32, C.c_float]
@@ -107,6 +108,13 @@ class BundlerLib:
                                          np.ascontiguousarray(intrinsics, np.float32), int(is_fixed)))
 
     def FixCameraPose(self, idx, value): check(self._L.mage_ba_fix_camera(self._h, idx, int(value)))
+
+    def UpdateCameraPoses(self, indices, positions, orientations_colmajor):
+        """Extension (include/mage_ba.h): pose-only re-seed of cameras already in the graph; no structure rebuild."""
+        idx = np.ascontiguousarray(indices, np.uint32)
+        check(self._L.mage_ba_update_camera_poses(self._h, len(idx), idx, np.ascontiguousarray(positions, np.float32).reshape(-1),
+                                                  np.ascontiguousarray(orientations_colmajor, np.float32).reshape(-1)))
+
     def AllocateMapPoints(self, count): check(self._L.mage_ba_alloc_points(self._h, count)); self.n_pts = count
     def SetMapPoint(self, idx, point): check(self._L.mage_ba_set_point(self._h, idx, np.ascontiguousarray(point, np.float32)))
     def AllocateObservations(self, count): check(self._L.mage_ba_alloc_observations(self._h, count)); self.n_obs = count

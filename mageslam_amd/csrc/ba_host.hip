@@ -951,6 +951,38 @@ MAGE_EXPORT mage_status mage_ba_fix_camera(mage_ba* h, size_t idx, int is_fixed)
     });
 }
 
+MAGE_EXPORT mage_status mage_ba_update_camera_poses(mage_ba* h, size_t count, const uint32_t* indices, const float* positions3,
+                                                    const float* R_colmajor9)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || (count && (!indices || !positions3 || !R_colmajor9))) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        for (size_t k = 0; k < count; ++k) {
+            if (indices[k] >= h->cams.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "camera index %u out of range (%zu)", indices[k], h->cams.size());
+            if (!h->cams[indices[k]].set) return fail(MAGE_ERR_INVALID_ARGUMENT, "camera %u was never set: use mage_ba_set_camera first", indices[k]);
+        }
+        if (count == 0) return MAGE_OK;
+        // The estimate may live on the device (stepping has started): the host copy of every other entity stays as stale or
+        // as fresh as it was; the edited cameras are written to both places, and to BOTH device state buffers (a fixed camera
+        // is never written by a trial, so the buffer that becomes current after an accepted trial must hold it too).
+        if (h->state_on_device) {
+            MAGE_HIP(hipSetDevice(h->device));
+            MAGE_HIP(hipStreamSynchronize(h->stream));
+        }
+        for (size_t k = 0; k < count; ++k) {
+            HostCam& c = h->cams[indices[k]];
+            pose_from_f32(R_colmajor9 + 9 * k, positions3 + 3 * k, c);
+            if (h->state_on_device) {
+                const double rec[8] = { c.q[0], c.q[1], c.q[2], c.q[3], c.t[0], c.t[1], c.t[2], 0.0 };
+                for (int b = 0; b < 2; ++b)
+                    MAGE_HIP(hipMemcpyAsync(h->d_pose[b].p + (size_t)indices[k] * 8, rec, sizeof(rec), hipMemcpyHostToDevice, h->stream));
+                MAGE_HIP(hipStreamSynchronize(h->stream));      // rec is a stack buffer
+            }
+        }
+        h->iteration = 0;          // a different linear system: the optimiser starts over (lambda re-seeded), the graph is unchanged
+        return MAGE_OK;
+    });
+}
+
 MAGE_EXPORT mage_status mage_ba_alloc_points(mage_ba* h, size_t count)
 {
     return guarded([&]() -> mage_status {

@@ -414,6 +414,23 @@ BAO_API void bao_set_camera(ba_oracle* b, size_t idx, const float t[3], const fl
     b->dirty = 1;
 }
 
+/* Counterpart of the product's extension mage_ba_update_camera_poses (include/mage_ba.h): pose-only re-seed of cameras that are
+   already in the graph; the graph is untouched, the optimiser starts over (iteration 0) as after SetCurrentLambda. */
+BAO_API void bao_update_camera_poses(ba_oracle* b, size_t n, const uint32_t* idx, const float* t3, const float* R9)
+{
+    for (size_t k = 0; k < n; ++k) {
+        cam_t* c = &b->cams[idx[k]];
+        const float* Rcm = R9 + 9 * k;
+        float Rrm[9], qf[4];
+        for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) Rrm[r * 3 + cc] = Rcm[cc * 3 + r];
+        R_to_q_f32(Rrm, qf);
+        c->est.r.x = qf[0]; c->est.r.y = qf[1]; c->est.r.z = qf[2]; c->est.r.w = qf[3];
+        c->est.t[0] = t3[3 * k]; c->est.t[1] = t3[3 * k + 1]; c->est.t[2] = t3[3 * k + 2];
+        se3_normalize(&c->est);
+    }
+    b->iteration = 0;
+}
+
 BAO_API void bao_fix_camera(ba_oracle* b, size_t idx, int fixed) { b->cams[idx].fixed = fixed; /* BundlerLib.cpp:278-281: does not dirty */ }
 
 /* BundlerLib.cpp:283-292 */

@@ -89,6 +89,7 @@ def _declare(L: C.CDLL) -> None:
         getattr(L, n).argtypes = [C.c_void_p, C.c_size_t]
     L.bao_set_camera.argtypes = [C.c_void_p, C.c_size_t, _f32p, _f32p, _f32p, C.c_int]
     L.bao_fix_camera.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    L.bao_update_camera_poses.argtypes = [C.c_void_p, C.c_size_t, np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), _f32p, _f32p]
     L.bao_set_point.argtypes = [C.c_void_p, C.c_size_t, _f32p]
     L.bao_set_observation.argtypes = [C.c_void_p, C.c_size_t, _f32p, C.c_size_t, C.c_size_t, C.c_float]
     L.bao_alloc_tethers.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
@@ -165,6 +166,18 @@ class OracleBundler:
                                np.ascontiguousarray(intrinsics, np.float32), int(is_fixed))
 
     def FixCameraPose(self, idx, value): self._L.bao_fix_camera(self._h, idx, int(value))
+
+    def UpdateCameraPoses(self, indices, positions, orientations_colmajor):
+        idx = np.ascontiguousarray(indices, np.uint32)
+        self._L.bao_update_camera_poses(self._h, len(idx), idx, np.ascontiguousarray(positions, np.float32).reshape(-1),
+                                        np.ascontiguousarray(orientations_colmajor, np.float32).reshape(-1))
+
+    def GetPosesBulk(self):
+        t = np.zeros((self.n_cams, 3), np.float32); R = np.zeros((self.n_cams, 9), np.float32)
+        for i in range(self.n_cams):
+            self._L.bao_get_pose(self._h, i, t[i], R[i])
+        return t, R
+
     def SetMapPoint(self, idx, p): self._L.bao_set_point(self._h, idx, np.ascontiguousarray(p, np.float32))
 
     def SetObservation(self, idx, uv, cam, pt, info):

@@ -1,0 +1,100 @@
+"""CPU tests of the window-sharded map driver (mageslam_amd/windowed.py): the cutting of windows and halos, the block-Jacobi
+outer loop against the monolithic solve, and the N > 1 exchange over gloo (world_size 2) -- with the CPU oracle standing in for
+the HIP back-end, which is exactly what pins the driver's logic (the oracle is test infrastructure; the GPU tests run the same
+driver on the product path)."""
+import hashlib
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from mageslam_amd import scene
+from mageslam_amd.windowed import WindowedMap, cut_windows, owned_windows
+from oracle.oracle import OracleBundler, load_scene_bulk
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCENE = dict(n_cams=36, n_pts=540, n_obs=3240, seed=0x5EED0A00)
+
+
+def test_windows_partition_keyframes_and_carry_complete_landmarks():
+    s = scene.make_scene(**SCENE)
+    wins = cut_windows(s, 4)
+    own = np.concatenate([w.own for w in wins])
+    assert np.array_equal(np.sort(own), np.arange(s.n_cams))                      # every keyframe is free in exactly one window
+    n_obs_of_pt = np.bincount(s.obs_pt, minlength=s.n_pts)
+    for w in wins:
+        sub = w.scene
+        k = len(w.own)
+        assert np.array_equal(sub.cam_fixed[:k], s.cam_fixed[w.own]) and sub.cam_fixed[k:].all()     # halo = fixed
+        assert np.array_equal(np.bincount(sub.obs_pt, minlength=sub.n_pts), n_obs_of_pt[w.pts])     # all observations of its points
+        assert np.array_equal(w.cams[sub.obs_cam], s.obs_cam[w.obs]) and np.array_equal(w.pts[sub.obs_pt], s.obs_pt[w.obs])
+        seen_by_own = np.zeros(s.n_pts, bool); seen_by_own[s.obs_pt[np.isin(s.obs_cam, w.own)]] = True
+        assert np.array_equal(np.nonzero(seen_by_own)[0], w.pts)
+    assert owned_windows(8, 0, 2) == [0, 1, 2, 3] and owned_windows(8, 1, 2) == [4, 5, 6, 7]
+    for nw, world in ((3, 8), (8, 8), (5, 2), (1, 4)):                             # every window has exactly one owner
+        assert sorted(w for r in range(world) for w in owned_windows(nw, r, world)) == list(range(nw))
+
+
+def _run(n_windows, iters, rank=0, world=1, dist=None, overlap=0):
+    s = scene.make_scene(**SCENE)
+    m = WindowedMap(s, n_windows, lambda: OracleBundler(False), load_scene_bulk, rank=rank, world=world, dist=dist, overlap=overlap)
+    mse = [m.outer_iteration(1.8) for _ in range(iters)]
+    return s, m, mse
+
+
+def test_windowed_outer_loop_approaches_the_monolithic_minimum():
+    """Block-Jacobi over windows (2 overlap keyframes either side) against one BundlerLib over the whole map: the error falls
+    monotonically after the first exchange and ends within a few per cent of the monolithic minimum; overlap speeds it up."""
+    s, m, mse = _run(3, 25, overlap=2)
+    mono = OracleBundler(False); load_scene_bulk(mono, s)
+    out: list = []
+    ref = [mono.StepBundleAdjustment([1.8], 1e30, out) for _ in range(25)][-1]
+    assert all(b <= a * (1 + 1e-3) for a, b in zip(mse[1:], mse[2:]))
+    # the windows duplicate shared points, so the two means run over different multisets of observations
+    assert abs(np.sqrt(mse[-1]) - np.sqrt(ref)) < 0.02 * np.sqrt(ref)
+    t, R = m.poses()
+    tm, Rm = mono.GetPosesBulk()
+    assert np.abs(t - tm).max() < 0.1 and np.abs(R - Rm).max() < 5e-3
+    _, m0, mse0 = _run(3, 25, overlap=0)
+    t0, _ = m0.poses()
+    assert np.abs(t - tm).max() < np.abs(t0 - tm).max()                              # overlap converges faster
+
+
+WORKER = textwrap.dedent("""
+    import sys, json, hashlib
+    sys.path.insert(0, %r); sys.path.insert(0, %r)
+    from mageslam_amd import dist as D
+    from test_windowed import _run
+    info = D.rank_info()
+    dist = D.init("gloo", info)
+    s, m, mse = _run(4, 6, rank=info.rank, world=info.world, dist=dist, overlap=2)
+    t, R = m.poses()
+    print(json.dumps(dict(rank=info.rank, sha=hashlib.sha256(t.tobytes() + R.tobytes()).hexdigest(), mine=m.mine, bytes=m.exchanged_bytes)))
+    dist.barrier(); dist.destroy_process_group()
+""") % (ROOT, os.path.join(ROOT, "tests"))
+
+
+def test_two_ranks_over_gloo_equal_one_rank_bit_for_bit(tmp_path):
+    _, m, _ = _run(4, 6, overlap=2)
+    t, R = m.poses()
+    want = hashlib.sha256(t.tobytes() + R.tobytes()).hexdigest()
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    outs.sort(key=lambda d: d["rank"])
+    assert outs[0]["mine"] == [0, 1] and outs[1]["mine"] == [2, 3]
+    assert outs[0]["sha"] == want and outs[1]["sha"] == want
+    assert outs[0]["bytes"] == 6 * SCENE["n_cams"] * 12 * 4                        # one 12-float pose block per outer iteration
