@@ -56,6 +56,13 @@ namespace mage
 
         void FixCameraPose(size_t idx, bool value) { Check(mage_ba_fix_camera(m_impl.get(), idx, value ? 1 : 0)); }
 
+        // EXTENSION (not in the reference class): new poses for cameras already in the graph, no structure rebuild -- what a
+        // window of a keyframe-sharded map does to its halo once per outer iteration (mage_ba.h, mageslam_amd/windowed.py).
+        void UpdateCameraPoses(size_t count, const uint32_t* indices, const float* positions3, const float* orientations_colmajor9)
+        {
+            Check(mage_ba_update_camera_poses(m_impl.get(), count, indices, positions3, orientations_colmajor9));
+        }
+
         void AllocateMapPoints(size_t count) { Check(mage_ba_alloc_points(m_impl.get(), count)); }
         template <typename V3>
         void SetMapPoint(size_t idx, const V3& point) { Check(mage_ba_set_point(m_impl.get(), idx, point.data())); }
