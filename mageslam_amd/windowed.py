@@ -78,9 +78,10 @@ class WindowedMap:
     production; tests also pass the CPU oracle to pin the driver's logic); `dist` is torch.distributed or None."""
 
     def __init__(self, scene: Scene, n_windows: int, make_bundler, load, *, rank: int = 0, world: int = 1, dist=None,
-                 exchange_device: str = "cpu", overlap: int = 0):
+                 exchange_device: str = "cpu", overlap: int = 0, threads: int = 1):
         self.scene, self.dist, self.rank, self.world = scene, dist, rank, world
         self.exchange_device = exchange_device
+        self.threads = threads
         self.windows = cut_windows(scene, n_windows, overlap)
         self.mine = owned_windows(n_windows, rank, world)
         self.bundlers = {}
@@ -96,13 +97,23 @@ class WindowedMap:
     def outer_iteration(self, huber: float, max_err_sq: float = 1e30, inner: int = 1) -> float:
         """Every owned window takes `inner` LM iterations against the frozen halo, then poses are exchanged and the halos
         re-seeded.  Returns the observation-weighted mean square error over the owned windows (before the exchange)."""
-        err_sum, n_sum = 0.0, 0
-        for w in self.mine:
+        def step(w):
             out: list = []
             mse = self.bundlers[w].StepBundleAdjustment([huber] * inner, max_err_sq, out)
-            n = self.windows[w].scene.n_obs - len(out)
+            return float(mse), self.windows[w].scene.n_obs - len(out)
+
+        # The windows of a rank are independent between exchanges: stepped from concurrent host threads, each handle on its
+        # own stream, the chain-bound tail of one factorisation overlaps the matrix-core bulk of another (DESIGN.md 10).
+        if self.threads > 1 and len(self.mine) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(self.threads, len(self.mine))) as ex:
+                results = list(ex.map(step, self.mine))
+        else:
+            results = [step(w) for w in self.mine]
+        err_sum, n_sum = 0.0, 0
+        for mse, n in results:
             if n > 0 and np.isfinite(mse):
-                err_sum += float(mse) * n; n_sum += n
+                err_sum += mse * n; n_sum += n
         self.exchange()
         return err_sum / n_sum if n_sum else float("nan")
 

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--overlap", type=int, default=10)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--threads", type=int, default=4, help="windows of a rank stepped concurrently")
     a = ap.parse_args()
     import torch
     from mageslam_amd import dist as D, scene
@@ -38,7 +39,7 @@ def main():
     s = scene.make_scene(n_cams=a.poses, n_pts=100 * a.poses, n_obs=1000 * a.poses, seed=0x5EED0008)
     t1 = time.perf_counter()
     m = WindowedMap(s, a.windows, lambda: BundlerLib(False, device=device), lambda b, sc: load_scene(b, sc, bulk=True),
-                    rank=info.rank, world=info.world, dist=dist, overlap=a.overlap, exchange_device=D.stats_device(device))
+                    rank=info.rank, world=info.world, dist=dist, overlap=a.overlap, exchange_device=D.stats_device(device), threads=a.threads)
     t2 = time.perf_counter()
     errs = [m.outer_iteration(1.8) for _ in range(a.warmup)]
     if dist is not None:
@@ -54,7 +55,7 @@ def main():
         sizes = [(len(m.windows[w].own), m.windows[w].scene.n_cams, m.windows[w].scene.n_obs) for w in m.mine]
         print(json.dumps({
             "workload": f"one map of {a.poses} poses / {100 * a.poses} points / {1000 * a.poses} observations in {a.windows} windows, overlap {a.overlap}",
-            "n_gpus": info.world, "scaling": "strong", "control_plane": D.init.backend or "none",
+            "n_gpus": info.world, "scaling": "strong", "threads_per_rank": a.threads, "control_plane": D.init.backend or "none",
             "outer_iterations_per_s": a.iters / (t4 - t3), "ms_per_outer_iteration": 1e3 * (t4 - t3) / a.iters,
             "lm_window_iterations_per_s": a.iters * a.windows / (t4 - t3),
             "mse_rank0_windows": [round(float(e), 5) for e in errs],
