@@ -57,7 +57,7 @@ def cpu_baseline(workload: str, max_seconds: float = 60.0) -> dict:
         el = time.perf_counter() - t0
         if el > 10.0 or n >= 50 or el + el / n > max_seconds:
             break
-    return {"value": n / el, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+    return {"value": n / el, "unit": "LM iterations/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"{n} LM iteration(s) of the same {workload} scene from the same initial state, {el:.1f} s, "
                       f"oracle/ba_oracle.c (gcc -O3), 1 thread"}
 
