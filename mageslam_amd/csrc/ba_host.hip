@@ -259,6 +259,7 @@ struct mage_ba {
     DevBuf<float2> d_L_uv; DevBuf<float> d_L_info; DevBuf<uint32_t> d_L_cam, d_L_pt, d_L_edge; DevBuf<int> d_L_slot;
     DevBuf<int> d_lm_ptr, d_lm_pt, d_lm_wptr, d_w_hc, d_w_lm, d_camE_ptr, d_camE, d_camS_ptr, d_camS, d_blk_ptr;
     DevBuf<int2> d_blk_ij, d_con;
+    DevBuf<int> d_blk_order;
     DevBuf<double> d_errL, d_U, d_bc, d_V, d_bp, d_W, d_Dinv, d_db, d_S, d_y, d_xc, d_xl, d_partial, d_scal, d_Linv;
     DevBuf<uint8_t> d_flagL, d_L_active;
     DevBuf<int> d_T_kind, d_tc_hc, d_tc_ptr, d_tc_item, d_tp_ptr, d_tp_item;
@@ -624,6 +625,27 @@ mage_status initialize_optimization(mage_ba* h)
     const int nblk = (int)blk_ij.size();
     MAGE_TRY(push(h->d_con, con, ncon));
     MAGE_TRY(push_vec(h->d_blk_ptr, blk_ptr)); MAGE_TRY(push_vec(h->d_blk_ij, blk_ij));
+    // slot -> block table of k_schur_block: workgroup w (SCHUR_WAVES wavefront slots) lands on XCD w % 8 and takes the next blocks of that XCD's run
+    std::vector<int> blk_order;
+    {
+        constexpr int XCD = 8;
+        std::vector<std::vector<int>> per(XCD);
+        // contiguous runs of rows per XCD, cut at equal shares of the contributions: blocks whose cameras are close see the
+        // same landmarks, so their W blocks meet in one L2
+        for (int b2 = 0; b2 < nblk; ++b2) {
+            const size_t mid = ((size_t)blk_ptr[b2] + (size_t)blk_ptr[b2 + 1]) / 2;
+            const int x = ncon ? (int)std::min<size_t>(XCD - 1, mid * XCD / ncon) : 0;
+            per[x].push_back(b2);
+        }
+        size_t longest = 0;
+        for (auto& v2 : per) longest = std::max(longest, v2.size());
+        constexpr size_t G = SCHUR_WAVES;
+        const size_t groups = (longest + G - 1) / G;
+        blk_order.assign(groups * XCD * G, -1);
+        for (int x = 0; x < XCD; ++x)
+            for (size_t q2 = 0; q2 < per[x].size(); ++q2) blk_order[((q2 / G) * XCD + x) * G + (q2 % G)] = per[x][q2];
+    }
+    MAGE_TRY(push_vec(h->d_blk_order, blk_order));
 
     tm.mark("schur contributions");
     // tether gather lists: per camera (tether, side) and per free-camera pair i < j (tether, transposed), tether order kept
@@ -709,6 +731,7 @@ mage_status initialize_optimization(mage_ba* h)
     v.lm_ptr = h->d_lm_ptr.p; v.lm_pt = h->d_lm_pt.p; v.lm_wptr = h->d_lm_wptr.p; v.w_hc = h->d_w_hc.p; v.w_lm = h->d_w_lm.p;
     v.camE_ptr = h->d_camE_ptr.p; v.camE = h->d_camE.p; v.camS_ptr = h->d_camS_ptr.p; v.camS = h->d_camS.p;
     v.blk_ptr = h->d_blk_ptr.p; v.blk_ij = h->d_blk_ij.p; v.con = h->d_con.p;
+    v.blk_order = h->d_blk_order.p; v.n_blk_slots = (int)blk_order.size();
     v.n_T = nT; v.n_tc = (int)tc_hc.size(); v.n_tp = (int)tp_ij.size();
     v.T_kind = h->d_T_kind.p; v.T_cam = h->d_T_cam.p; v.T_fixed = h->d_T_fixed.p; v.T_meas = h->d_T_meas.p; v.T_w = h->d_T_w.p; v.T_out = h->d_T_out.p;
     v.tc_hc = h->d_tc_hc.p; v.tc_ptr = h->d_tc_ptr.p; v.tc_item = h->d_tc_item.p;

@@ -11,6 +11,8 @@
 
 namespace mage {
 
+constexpr int SCHUR_WAVES = 1;     // wavefronts (= blocks of S) per workgroup of k_schur_block; the slot table is built for it
+
 struct BaDeviceView {
     // ---- sizes
     int n_cams, n_pts;        // allocated cameras / points
@@ -43,6 +45,7 @@ struct BaDeviceView {
     const int* camS_ptr; const int* camS;      // per free camera: its W slots
     // ---- reduced-camera-matrix structure
     const int* blk_ptr; const int2* blk_ij; const int2* con;   // contributions (slot_a, slot_b) per block
+    const int* blk_order; int n_blk_slots;                     // wavefront slot -> block (-1: none): rows of S are pinned to XCDs (ba_host.hip)
 
     // ---- tether edges (pose-pose constraints; active ones only, all three kinds in one list)
     int n_T, n_tc, n_tp;                       // tethers / cameras carrying tethers / free-camera pairs joined by tethers

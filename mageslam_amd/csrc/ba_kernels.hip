@@ -344,15 +344,21 @@ __global__ void k_pad_diag(double* S, int n, int n_pad)
     if (i < n_pad) S[(size_t)i * n_pad + i] = 1.0;
 }
 
-// One wavefront per non-empty upper block (i <= j).  Each lane owns a strided subset of the block's
+// One wavefront per non-empty upper block (i <= j).  Workgroups go to the eight XCDs round-robin and every XCD has its own
+// L2, so the slot -> block table (blk_order) hands workgroup w the blocks of rows i with i % 8 == w % 8: camera i's W blocks
+// are then fetched into ONE L2 instead of eight, and consecutive rows of an XCD share most of their column cameras (measured:
+// L2 misses per launch 15.4 M -> see DESIGN.md 5).  Placement only: any table is correct.  Each lane owns a strided subset of the block's
 // landmark contributions, forms (W_a D^-1) W_b^T in registers, then the 36 partial sums are combined
 // with a butterfly.  The block is written to the lower triangle of S (column-major), i.e. as the
 // transposed (j, i) block, plus the full diagonal block.
-__global__ __launch_bounds__(256) void k_schur_block(BaDeviceView v, double lambda)
+__global__ __launch_bounds__(64 * SCHUR_WAVES) void k_schur_block(BaDeviceView v, double lambda)
 {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (b >= v.n_blk) return;
+    __shared__ double red[SCHUR_WAVES][64 * 37];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * SCHUR_WAVES + wave;
+    if (slot >= v.n_blk_slots) return;
+    const int b = v.blk_order[slot];
+    if (b < 0) return;
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0;
@@ -379,13 +385,25 @@ __global__ __launch_bounds__(256) void k_schur_block(BaDeviceView v, double lamb
             for (int cc = 0; cc < 6; ++cc) acc[r * 6 + cc] += t0 * wb[cc * 3] + t1 * wb[cc * 3 + 1] + t2 * wb[cc * 3 + 2];
         }
     }
+    // 36 sums over 64 lanes: a butterfly costs 36 x 6 cross-lane exchanges; instead every lane parks its 36 partials in LDS
+    // (lane-major, odd pitch: conflict-free both ways) and lane k < 36 adds the 64 partials of entry k in lane order.
+    double* R = red[wave];
 #pragma unroll
-    for (int k = 0; k < 36; ++k) acc[k] = wave_sum(acc[k]);
+    for (int k = 0; k < 36; ++k) R[lane * 37 + k] = acc[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int2 ij = v.blk_ij[b];
     // lane k < 36 writes entry (r, c) of the block
     double val = 0;
+    if (lane < 36) {
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
-    for (int k = 0; k < 36; ++k) if (lane == k) val = acc[k];
+        for (int j = 0; j < 64; j += 4) {
+            s0 += R[(j + 0) * 37 + lane]; s1 += R[(j + 1) * 37 + lane]; s2 += R[(j + 2) * 37 + lane]; s3 += R[(j + 3) * 37 + lane];
+        }
+        val = (s0 + s1) + (s2 + s3);
+    }
     if (lane < 36) {
         const int r = lane / 6, c = lane % 6;
         if (ij.x == ij.y) {
@@ -612,7 +630,7 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st)
     (void)hipMemsetAsync(v.y, 0, (size_t)v.n_pad * sizeof(double), st);
     if (v.n_pad > n) hipLaunchKernelGGL(k_pad_diag, dim3(cdiv(v.n_pad - n, 128)), dim3(128), 0, st, v.S, n, v.n_pad);
     if (v.points_free && v.n_lm > 0) hipLaunchKernelGGL(k_lm_invert, dim3(cdiv(v.n_lm, 256)), dim3(256), 0, st, v, lambda);
-    if (v.n_blk > 0) hipLaunchKernelGGL(k_schur_block, dim3(cdiv(v.n_blk, 4)), dim3(256), 0, st, v, lambda);
+    if (v.n_blk > 0) hipLaunchKernelGGL(k_schur_block, dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda);
     tether_launch_schur(v, st);
     if (v.n_fc > 0) hipLaunchKernelGGL(k_schur_rhs, dim3(cdiv(v.n_fc, 4)), dim3(256), 0, st, v);
 }
