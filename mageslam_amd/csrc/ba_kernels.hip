@@ -53,6 +53,18 @@ __device__ __forceinline__ double block_sum(double v, double* sm /* NW doubles *
     return r;
 }
 
+// Camera handled by wavefront `wave` of workgroup `bid` when workgroups of 4 wavefronts cover n cameras: workgroups go to the
+// eight XCDs round-robin, so XCD x = bid % 8 gets the contiguous run of cameras [x * run, (x + 1) * run) -- neighbouring
+// cameras observe the same landmarks and then meet in one L2.  Returns n (= nothing to do) past the end of a run.
+__device__ __forceinline__ int xcd_camera(int bid, int wave, int n)
+{
+    const int run = ((n + 7) / 8 + 3) / 4 * 4;                 // cameras per XCD, a multiple of the 4 per workgroup
+    const int within = (bid / 8) * 4 + wave;
+    const int hc = (bid % 8) * run + within;
+    return within < run && hc < n ? hc : n;
+}
+__host__ inline int xcd_camera_grid(int n) { return (((n + 7) / 8 + 3) / 4) * 8; }
+
 struct PoseD { double qx, qy, qz, qw, tx, ty, tz; };
 
 __device__ __forceinline__ PoseD load_pose(const double* __restrict__ p, int cam)
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(256) void k_linearize_lm(BaDeviceView v, double del
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_linearize_cam(BaDeviceView v, double delta)
 {
-    const int hc = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int hc = xcd_camera((int)blockIdx.x, (int)(threadIdx.x >> 6), v.n_fc);
     const int lane = threadIdx.x & 63;
     if (hc >= v.n_fc) return;
     const int cam = v.hc2cam[hc];
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(64 * SCHUR_WAVES) void k_schur_block(BaDeviceView v
 
 __global__ __launch_bounds__(256) void k_schur_rhs(BaDeviceView v)
 {
-    const int hc = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int hc = xcd_camera((int)blockIdx.x, (int)(threadIdx.x >> 6), v.n_fc);
     const int lane = threadIdx.x & 63;
     if (hc >= v.n_fc) return;
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
@@ -614,7 +626,7 @@ void ba_launch_error(const BaDeviceView& v, bool trial, double delta, hipStream_
 void ba_launch_linearize(const BaDeviceView& v, double delta, hipStream_t st)
 {
     if (v.points_free && v.n_lm > 0) hipLaunchKernelGGL(k_linearize_lm, dim3(cdiv(v.n_lm, 256)), dim3(256), 0, st, v, delta);
-    if (v.n_fc > 0) hipLaunchKernelGGL(k_linearize_cam, dim3(cdiv(v.n_fc, 4)), dim3(256), 0, st, v, delta);
+    if (v.n_fc > 0) hipLaunchKernelGGL(k_linearize_cam, dim3(xcd_camera_grid(v.n_fc)), dim3(256), 0, st, v, delta);
     tether_launch_linearize(v, st);
 }
 
@@ -632,7 +644,7 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st)
     if (v.points_free && v.n_lm > 0) hipLaunchKernelGGL(k_lm_invert, dim3(cdiv(v.n_lm, 256)), dim3(256), 0, st, v, lambda);
     if (v.n_blk > 0) hipLaunchKernelGGL(k_schur_block, dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda);
     tether_launch_schur(v, st);
-    if (v.n_fc > 0) hipLaunchKernelGGL(k_schur_rhs, dim3(cdiv(v.n_fc, 4)), dim3(256), 0, st, v);
+    if (v.n_fc > 0) hipLaunchKernelGGL(k_schur_rhs, dim3(xcd_camera_grid(v.n_fc)), dim3(256), 0, st, v);
 }
 
 void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st)
