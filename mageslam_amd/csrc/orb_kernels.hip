@@ -598,6 +598,38 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ img, i
         }
     }
     __syncthreads();
+    if (r == 3) {
+        // vertical pass, 7 taps: a thread owns four pixel columns and four consecutive rows, reads the ten row sums they need once
+        // (10 LDS reads for 4 outputs where the row-at-a-time form below issues 28) and packs one 32-bit store per row
+        static_assert(BT_H * (BT_W / 4) == 4 * 256, "one 4 x 4 pixel patch per thread");
+        const int tq = threadIdx.x % (BT_W / 4), strip = threadIdx.x / (BT_W / 4);
+        const int xq = x0 + 4 * tq;
+        if (xq < wp) {
+            int4 hv[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) hv[i] = *reinterpret_cast<const int4*>(&hrow[(strip * 4 + i) * BT_W + 4 * tq]);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int y = y0 + strip * 4 + o;
+                if (y >= h) break;
+                int acc4[4] = { 0, 0, 0, 0 };
+#pragma unroll
+                for (int t = 0; t < 7; ++t) {
+                    acc4[0] = (__mul24(tp[t], hv[o + t].x) + acc4[0]); acc4[1] = (__mul24(tp[t], hv[o + t].y) + acc4[1]);
+                    acc4[2] = (__mul24(tp[t], hv[o + t].z) + acc4[2]); acc4[3] = (__mul24(tp[t], hv[o + t].w) + acc4[3]);
+                }
+                uint32_t packed = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (xq + b >= w) continue;
+                    const int v = (acc4[b] + (1 << 15)) >> 16;
+                    packed |= (uint32_t)(v > 255 ? 255 : v) << (8 * b);
+                }
+                *reinterpret_cast<uint32_t*>(O + (size_t)y * wp + xq) = packed;
+            }
+        }
+        return;
+    }
     // vertical pass, 4 pixels per thread, one 32-bit store
     for (int e = threadIdx.x; e < BT_H * (BT_W / 4); e += 256) {
         const int ty = e / (BT_W / 4), tq = e % (BT_W / 4);
