@@ -24,6 +24,8 @@ namespace mage {
 namespace {
 
 constexpr int WAVE = 64;
+constexpr int SPLIT_BLOCKS_BELOW = 2048;       // Schur blocks: at most this many -> four wavefronts per block
+constexpr int SPLIT_CAMERAS_BELOW = 256;      // per-camera kernels: at most this many free cameras -> a workgroup per camera
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -252,11 +254,18 @@ __global__ __launch_bounds__(256) void k_linearize_lm(BaDeviceView v, double del
 // ---------------------------------------------------------------------------------------------
 // camera side: one wavefront per free camera, lanes stride over its observations
 // ---------------------------------------------------------------------------------------------
+// SPLIT = false: one wavefront per camera (four cameras per workgroup, XCD runs).  SPLIT = true: the four wavefronts of a
+// workgroup share ONE camera (observations dealt out 64 at a time), partial sums combined in wavefront order through LDS --
+// for problems with few cameras (local BA: ~15 free keyframes x 2 500 observations) where one wavefront per camera leaves
+// the GPU empty and walks 40 dependent gathers.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_linearize_cam(BaDeviceView v, double delta)
 {
-    const int hc = xcd_camera((int)blockIdx.x, (int)(threadIdx.x >> 6), v.n_fc);
+    const int wave = threadIdx.x >> 6;
+    const int hc = SPLIT ? (int)blockIdx.x : xcd_camera((int)blockIdx.x, wave, v.n_fc);
     const int lane = threadIdx.x & 63;
     if (hc >= v.n_fc) return;
+    const int first = SPLIT ? wave * WAVE + lane : lane, stride = SPLIT ? 4 * WAVE : WAVE;
     const int cam = v.hc2cam[hc];
     PoseD P = load_pose(v.pose_cur, cam);
     const double f = v.camK[cam * 4];
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(256) void k_linearize_cam(BaDeviceView v, double de
     for (int k = 0; k < 21; ++k) A[k] = 0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) b[k] = 0;
-    for (int idx = v.camE_ptr[hc] + lane; idx < v.camE_ptr[hc + 1]; idx += WAVE) {
+    for (int idx = v.camE_ptr[hc] + first; idx < v.camE_ptr[hc + 1]; idx += stride) {
         const int i = v.camE[idx];
         if (!v.L_active[i]) continue;
         const int pt = v.L_pt[i];
@@ -291,6 +300,21 @@ __global__ __launch_bounds__(256) void k_linearize_cam(BaDeviceView v, double de
     for (int k = 0; k < 21; ++k) A[k] = wave_sum(A[k]);
 #pragma unroll
     for (int k = 0; k < 6; ++k) b[k] = wave_sum(b[k]);
+    if (SPLIT) {
+        __shared__ double part[4][28];
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 21; ++k) part[wave][k] = A[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) part[wave][21 + k] = b[k];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) A[k] = ((part[0][k] + part[1][k]) + part[2][k]) + part[3][k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) b[k] = ((part[0][21 + k] + part[1][21 + k]) + part[2][21 + k]) + part[3][21 + k];
+    }
     if (lane == 0) {
         int k = 0;
 #pragma unroll
@@ -363,18 +387,30 @@ __global__ void k_pad_diag(double* S, int n, int n_pad)
 // landmark contributions, forms (W_a D^-1) W_b^T in registers, then the 36 partial sums are combined
 // with a butterfly.  The block is written to the lower triangle of S (column-major), i.e. as the
 // transposed (j, i) block, plus the full diagonal block.
-__global__ __launch_bounds__(64 * SCHUR_WAVES) void k_schur_block(BaDeviceView v, double lambda)
+// SPLIT = false: one wavefront (= one workgroup) per block.  SPLIT = true (few blocks, each with thousands of contributions:
+// local BA): four wavefronts share a block, contributions dealt out 64 at a time, the four partial blocks added in wavefront order.
+template <bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block(BaDeviceView v, double lambda)
 {
-    __shared__ double red[SCHUR_WAVES][64 * 37];
+    constexpr int NW = SPLIT ? 4 : SCHUR_WAVES;
+    __shared__ double red[NW][64 * 37];
+    __shared__ double part[SPLIT ? 4 : 1][36];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * SCHUR_WAVES + wave;
-    if (slot >= v.n_blk_slots) return;
-    const int b = v.blk_order[slot];
-    if (b < 0) return;
+    int b;
+    if (SPLIT) {
+        b = (int)blockIdx.x;
+        if (b >= v.n_blk) return;
+    } else {
+        const int slot = blockIdx.x * SCHUR_WAVES + wave;
+        if (slot >= v.n_blk_slots) return;
+        b = v.blk_order[slot];
+        if (b < 0) return;
+    }
+    const int first = SPLIT ? wave * WAVE + lane : lane, stride = SPLIT ? 4 * WAVE : WAVE;
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0;
-    for (int c = v.blk_ptr[b] + lane; c < v.blk_ptr[b + 1]; c += WAVE) {
+    for (int c = v.blk_ptr[b] + first; c < v.blk_ptr[b + 1]; c += stride) {
         const int2 sab = v.con[c];
         // 144-byte W blocks and 48-byte D^-1 records are 16-byte aligned: 128-bit loads (21 per contribution instead of 42)
         const double2* Wa2 = reinterpret_cast<const double2*>(v.W + (size_t)sab.x * 18);
@@ -416,6 +452,12 @@ __global__ __launch_bounds__(64 * SCHUR_WAVES) void k_schur_block(BaDeviceView v
         }
         val = (s0 + s1) + (s2 + s3);
     }
+    if (SPLIT) {
+        if (lane < 36) part[wave][lane] = val;
+        __syncthreads();
+        if (wave != 0) return;
+        if (lane < 36) val = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    }
     if (lane < 36) {
         const int r = lane / 6, c = lane % 6;
         if (ij.x == ij.y) {
@@ -428,13 +470,16 @@ __global__ __launch_bounds__(64 * SCHUR_WAVES) void k_schur_block(BaDeviceView v
     }
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_schur_rhs(BaDeviceView v)
 {
-    const int hc = xcd_camera((int)blockIdx.x, (int)(threadIdx.x >> 6), v.n_fc);
+    const int wave = threadIdx.x >> 6;
+    const int hc = SPLIT ? (int)blockIdx.x : xcd_camera((int)blockIdx.x, wave, v.n_fc);
     const int lane = threadIdx.x & 63;
     if (hc >= v.n_fc) return;
+    const int first = SPLIT ? wave * WAVE + lane : lane, stride = SPLIT ? 4 * WAVE : WAVE;
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
-    for (int idx = v.camS_ptr[hc] + lane; idx < v.camS_ptr[hc + 1]; idx += WAVE) {
+    for (int idx = v.camS_ptr[hc] + first; idx < v.camS_ptr[hc + 1]; idx += stride) {
         const int s = v.camS[idx];
         const double* W = v.W + (size_t)s * 18;
         const double* db = v.db + (size_t)v.w_lm[s] * 4;
@@ -444,6 +489,17 @@ __global__ __launch_bounds__(256) void k_schur_rhs(BaDeviceView v)
     }
 #pragma unroll
     for (int r = 0; r < 6; ++r) acc[r] = wave_sum(acc[r]);
+    if (SPLIT) {
+        __shared__ double part[4][6];
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) part[wave][r] = acc[r];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[r] = ((part[0][r] + part[1][r]) + part[2][r]) + part[3][r];
+    }
     if (lane < 6) {
         double a = 0;
 #pragma unroll
@@ -626,7 +682,10 @@ void ba_launch_error(const BaDeviceView& v, bool trial, double delta, hipStream_
 void ba_launch_linearize(const BaDeviceView& v, double delta, hipStream_t st)
 {
     if (v.points_free && v.n_lm > 0) hipLaunchKernelGGL(k_linearize_lm, dim3(cdiv(v.n_lm, 256)), dim3(256), 0, st, v, delta);
-    if (v.n_fc > 0) hipLaunchKernelGGL(k_linearize_cam, dim3(xcd_camera_grid(v.n_fc)), dim3(256), 0, st, v, delta);
+    if (v.n_fc > 0) {
+        if (v.n_fc <= SPLIT_CAMERAS_BELOW) hipLaunchKernelGGL(k_linearize_cam<true>, dim3(v.n_fc), dim3(256), 0, st, v, delta);
+        else hipLaunchKernelGGL(k_linearize_cam<false>, dim3(xcd_camera_grid(v.n_fc)), dim3(256), 0, st, v, delta);
+    }
     tether_launch_linearize(v, st);
 }
 
@@ -642,9 +701,15 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st)
     (void)hipMemsetAsync(v.y, 0, (size_t)v.n_pad * sizeof(double), st);
     if (v.n_pad > n) hipLaunchKernelGGL(k_pad_diag, dim3(cdiv(v.n_pad - n, 128)), dim3(128), 0, st, v.S, n, v.n_pad);
     if (v.points_free && v.n_lm > 0) hipLaunchKernelGGL(k_lm_invert, dim3(cdiv(v.n_lm, 256)), dim3(256), 0, st, v, lambda);
-    if (v.n_blk > 0) hipLaunchKernelGGL(k_schur_block, dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda);
+    if (v.n_blk > 0) {
+        if (v.n_blk <= SPLIT_BLOCKS_BELOW) hipLaunchKernelGGL(k_schur_block<true>, dim3(v.n_blk), dim3(256), 0, st, v, lambda);
+        else hipLaunchKernelGGL(k_schur_block<false>, dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda);
+    }
     tether_launch_schur(v, st);
-    if (v.n_fc > 0) hipLaunchKernelGGL(k_schur_rhs, dim3(xcd_camera_grid(v.n_fc)), dim3(256), 0, st, v);
+    if (v.n_fc > 0) {
+        if (v.n_fc <= SPLIT_CAMERAS_BELOW) hipLaunchKernelGGL(k_schur_rhs<true>, dim3(v.n_fc), dim3(256), 0, st, v);
+        else hipLaunchKernelGGL(k_schur_rhs<false>, dim3(xcd_camera_grid(v.n_fc)), dim3(256), 0, st, v);
+    }
 }
 
 void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st)
