@@ -84,6 +84,33 @@ def test_non_default_settings_match_oracle(kw):
     assert np.array_equal(kp_xyr(k), kp_xyr(ko)) and np.array_equal(d, do)
 
 
+@pytest.mark.parametrize("case", range(24))
+def test_randomised_settings_and_frames_match_oracle(case):
+    """Differential test over the detector's whole parameter surface: random frame size and content, feature budget, FAST
+    threshold, cell grid, ANMS factors, blur kernel, patch 15 / 31, pyramid depth and scale, orientation.  Keypoints (x, y,
+    response, octave, size, angle) and descriptors must equal the oracle's bit for bit."""
+    rng = np.random.default_rng(0x0B5E + case)
+    w, h = int(rng.integers(40, 360)), int(rng.integers(40, 280))
+    img = frames.make_frame(900 + case, w, h, n_rect=int(rng.integers(5, 80)), n_disc=int(rng.integers(5, 120)))
+    if case % 5 == 4:
+        img = (rng.integers(0, 256, (h, w))).astype(np.uint8)                      # pure noise: thousands of raw corners
+    nlevels = int(rng.integers(1, 5)) if case % 2 else 1
+    kw = dict(nfeatures=int(rng.integers(8, 700)), fast_threshold=int(rng.integers(1, 40)), num_cells_x=int(rng.integers(1, 40)),
+              num_cells_y=int(rng.integers(1, 40)), gaussian_kernel_size=int(rng.choice([1, 3, 5, 7, 9])),
+              patch_size=int(rng.choice([15, 31])), nlevels=nlevels, scale_factor=float(rng.choice([1.2, 1.5, 2.0])),
+              use_orientation=int(case % 3 == 0), feature_factor_anms=float(rng.choice([1.0, 1.5, 2.5])),
+              feature_strength_anms=float(rng.choice([0.5, 0.9, 1.0])), strong_response_anms=int(rng.integers(5, 60)),
+              min_robust_factor=float(rng.choice([1.0, 1.1])), max_robust_factor=float(rng.choice([2.0, 2.2, 3.0])))
+    okw = {"feature_factor_anms": "feature_factor", "feature_strength_anms": "feature_strength", "strong_response_anms": "strong_response",
+           "min_robust_factor": "min_robust", "max_robust_factor": "max_robust", "num_cells_x": "cells_x", "num_cells_y": "cells_y"}
+    k, d = OrbDetector(**kw).DetectAndCompute(img)
+    ko, do = O.orb_detect(img, O.OrbParams.defaults(**{okw.get(a, a): b for a, b in kw.items()}))
+    assert len(k) == len(ko), (kw, w, h)
+    for f in ("x", "y", "response", "octave", "size", "angle", "class_id"):
+        assert np.array_equal(k[f], ko[f]), (f, kw, w, h)
+    assert np.array_equal(d, do), (kw, w, h)
+
+
 def test_edge_cases_match_oracle():
     det = OrbDetector()
     for shape in ((5, 5), (14, 40), (40, 14), (1, 1), (15, 15), (16, 33)):
@@ -152,6 +179,39 @@ def test_match_batch_ragged_pairs():
     for p in range(npairs):
         mo = O.match(A[p, : cA[p]], B[p, : cB[p]], 60, 1)
         assert cnt[p] == len(mo) and np.array_equal(out[p, : cnt[p]], mo)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_randomised_descriptor_sets_match_oracle(case):
+    """Brute-force matcher on adversarial sets: clusters of near-identical descriptors (ties between best and second best,
+    between queries claiming the same train descriptor), exact duplicates, empty and one-element sides, random masks and
+    thresholds including 0 and 256.  The match list must equal the oracle's record for record."""
+    rng = np.random.default_rng(0x3A7C + case)
+    nA, nB = int(rng.integers(0, 300)), int(rng.integers(0, 300))
+    if case == 0: nA = 0
+    if case == 1: nB = 1
+    centres = rng.integers(0, 256, (max(1, int(rng.integers(1, 12))), 32)).astype(np.uint8)
+
+    def draw(n):
+        d = centres[rng.integers(0, len(centres), n)].copy()
+        noise = (rng.random((n, 32, 8)) < rng.choice([0.0, 0.01, 0.05])).astype(np.uint8)
+        d ^= np.packbits(noise, axis=2).reshape(n, 32)
+        fresh = rng.random(n) < 0.3
+        d[fresh] = rng.integers(0, 256, (int(fresh.sum()), 32)).astype(np.uint8)
+        return d
+
+    A, B = draw(nA), draw(nB)
+    md, mdiff = int(rng.choice([0, 10, 30, 64, 256])), int(rng.choice([0, 1, 2, 5]))
+    ma = rng.random(nA) < 0.8 if case % 2 else None
+    mb = rng.random(nB) < 0.8 if case % 3 == 0 else None
+    m = Matcher().Match(A, B, ma, mb, md, mdiff)
+    ia = np.arange(nA) if ma is None else np.nonzero(ma)[0]
+    ib = np.arange(nB) if mb is None else np.nonzero(mb)[0]
+    mo = O.match(A[ia], B[ib], md, mdiff)
+    assert len(m) == len(mo)
+    if len(mo):
+        assert np.array_equal(m["queryIdx"], ia[mo["queryIdx"]]) and np.array_equal(m["trainIdx"], ib[mo["trainIdx"]])
+        assert np.array_equal(m["distance"], mo["distance"])
 
 
 def test_hamming_distance_helper():
