@@ -39,6 +39,11 @@ typedef enum mage_status {
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* mage_last_error(void);
 
+/* DIAGNOSTIC (tests only): the dense solver of the reduced camera system on its own.  Solves A x = b for a symmetric positive
+ * definite A (column-major, lower triangle read, host memory) with the same tiled Cholesky + substitutions the bundle adjustment
+ * runs; *ok = 0 when a pivot is not positive.  Lets the factorisation be checked against LAPACK / rocSOLVER. */
+mage_status mage_debug_dense_solve(int device, int n, const double* A_colmajor, const double* b, double* x, int* ok);
+
 /* Device buffers of destroyed handles (BA, ORB, matcher) are parked per device and reused by the next handle, because the
  * reference creates and destroys a bundler per optimisation (BundleAdjust.cpp:348-351) and a fresh 0.8 GB allocation costs
  * ~25 ms.  The parked total is bounded by MAGE_DEVICE_CACHE_MB (default 4096, 0 = no caching); this call returns all of it

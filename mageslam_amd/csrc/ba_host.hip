@@ -899,6 +899,46 @@ MAGE_EXPORT void mage_release_cached_memory(void)
     if (have_cur) (void)hipSetDevice(cur);
 }
 
+MAGE_EXPORT mage_status mage_debug_dense_solve(int device, int n, const double* A_colmajor, const double* b, double* x, int* ok)
+{
+    return guarded([&]() -> mage_status {
+        if (n <= 0 || !A_colmajor || !b || !x || !ok) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument or n <= 0");
+        int dev = 0;
+        MAGE_TRY(select_device(device, &dev));
+        MAGE_HIP(hipSetDevice(dev));
+        chol_init_device();
+        const int n_pad = std::max(CHOL_TILE, ((n + CHOL_TILE - 1) / CHOL_TILE) * CHOL_TILE);
+        if (n_pad > CHOL_MAX_ORDER) return fail(MAGE_ERR_UNSUPPORTED, "order %d exceeds %d", n_pad, CHOL_MAX_ORDER);
+        // the lower triangle, padded with an identity block exactly as the bundle adjustment pads its reduced camera system
+        std::vector<double> S((size_t)n_pad * n_pad, 0.0), y(n_pad, 0.0);
+        for (int c = 0; c < n; ++c)
+            for (int r = c; r < n; ++r) S[(size_t)c * n_pad + r] = A_colmajor[(size_t)c * n + r];
+        for (int i = n; i < n_pad; ++i) S[(size_t)i * n_pad + i] = 1.0;
+        for (int i = 0; i < n; ++i) y[i] = b[i];
+        DevBuf<double> dS, dy, dx, dLinv, dok; DevBuf<int> dsync;
+        hipStream_t st = nullptr;
+        MAGE_TRY(cached_stream_acquire(dev, &st));
+        mage_status rc = [&]() -> mage_status {
+            MAGE_TRY(dS.upload(S.data(), S.size(), st)); MAGE_TRY(dy.upload(y.data(), y.size(), st));
+            MAGE_TRY(dx.reserve(n_pad)); MAGE_TRY(dLinv.reserve(chol_workspace_doubles(n_pad))); MAGE_TRY(dok.reserve(1));
+            MAGE_TRY(dsync.reserve(chol_sync_ints(n_pad)));
+            CholWorkspace ws{ dLinv.p, dsync.p };
+            chol_factor_solve(dS.p, dy.p, dx.p, n_pad, ws, dok.p, st);
+            std::vector<double> xs(n_pad);
+            double okv = 0;
+            MAGE_HIP(hipMemcpyAsync(xs.data(), dx.p, n_pad * sizeof(double), hipMemcpyDeviceToHost, st));
+            MAGE_HIP(hipMemcpyAsync(&okv, dok.p, sizeof(double), hipMemcpyDeviceToHost, st));
+            MAGE_HIP(hipStreamSynchronize(st));
+            for (int i = 0; i < n; ++i) x[i] = xs[i];
+            *ok = okv != 0.0 ? 1 : 0;
+            return MAGE_OK;
+        }();
+        (void)hipStreamSynchronize(st);
+        cached_stream_release(dev, st);
+        return rc;
+    });
+}
+
 MAGE_EXPORT mage_status mage_ba_create(const mage_ba_params* params, mage_ba** out)
 {
     return guarded([&]() -> mage_status {

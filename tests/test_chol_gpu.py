@@ -1,0 +1,76 @@
+"""GPU tests (-m gpu) of the dense solver alone (mage_debug_dense_solve): the hand-written tiled Cholesky against LAPACK on
+the host (scipy) and, where torch's ROCm build offers it, rocSOLVER through torch.linalg on the same GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mageslam_amd.bundler import check, lib
+
+pytestmark = pytest.mark.gpu
+
+
+def dense_solve(A, b):
+    L = lib()
+    L.mage_debug_dense_solve.argtypes = [C.c_int, C.c_int, np.ctypeslib.ndpointer(np.float64, flags="F_CONTIGUOUS"),
+                                         np.ctypeslib.ndpointer(np.float64), np.ctypeslib.ndpointer(np.float64), C.POINTER(C.c_int)]
+    n = len(b)
+    x = np.zeros(n); ok = C.c_int(-1)
+    check(L.mage_debug_dense_solve(-1, n, np.asfortranarray(A), np.ascontiguousarray(b), x, C.byref(ok)))
+    return x, ok.value
+
+
+def spd(n, seed, cond_shift=1.0):
+    rng = np.random.default_rng(seed)
+    M = rng.standard_normal((n, n + 8))
+    return M @ M.T / n + cond_shift * np.eye(n), rng.standard_normal(n)
+
+
+@pytest.mark.parametrize("n", [1, 6, 17, 127, 128, 129, 500, 1408, 2999])
+def test_solution_matches_lapack(n):
+    """Orders around the tile size (one tile, exactly one, one row more), a few tiles (split diagonal update, quartered
+    rounds), and a size that needs every role of the update kernel."""
+    import scipy.linalg
+    A, b = spd(n, 100 + n)
+    x, ok = dense_solve(A, b)
+    assert ok == 1
+    ref = scipy.linalg.cho_solve(scipy.linalg.cho_factor(A, lower=True), b)
+    assert np.linalg.norm(x - ref) <= 1e-11 * np.linalg.norm(ref)
+    assert np.linalg.norm(A @ x - b) <= 1e-12 * (np.linalg.norm(A) * np.linalg.norm(x) + np.linalg.norm(b))
+
+
+def test_ill_conditioned_system_has_a_backward_stable_residual():
+    A, b = spd(900, 7, cond_shift=1e-9)                                  # condition number ~1e10
+    x, ok = dense_solve(A, b)
+    assert ok == 1
+    assert np.linalg.norm(A @ x - b) <= 1e-11 * (np.linalg.norm(A) * np.linalg.norm(x) + np.linalg.norm(b))
+
+
+def test_indefinite_and_semidefinite_matrices_are_reported():
+    A, b = spd(300, 3)
+    A[150, 150] = -1.0                                                   # a negative pivot appears in the second tile
+    assert dense_solve(A, b)[1] == 0
+    Z = np.zeros((140, 140)); Z[:139, :139] = spd(139, 4)[0]             # exact zero pivot in the last position
+    assert dense_solve(Z, np.ones(140))[1] == 0
+
+
+def test_solution_matches_rocsolver_via_torch(tmp_path):
+    """torch.linalg on the GPU is rocSOLVER / hipSOLVER.  torch must initialise HIP itself, so the reference solve runs in its
+    own process and hands the solution back through a file."""
+    import subprocess
+    import sys
+    A, b = spd(1408, 21)
+    x, ok = dense_solve(A, b)
+    assert ok == 1
+    np.savez(tmp_path / "sys.npz", A=A, b=b)
+    code = ("import numpy as np, torch, sys\n"
+            "if not torch.cuda.is_available(): sys.exit(3)\n"
+            "z = np.load(sys.argv[1]); A = torch.from_numpy(z['A']).cuda(); b = torch.from_numpy(z['b']).cuda()\n"
+            "x = torch.cholesky_solve(b[:, None], torch.linalg.cholesky(A))[:, 0].cpu().numpy()\n"
+            "np.save(sys.argv[2], x)\n")
+    p = subprocess.run([sys.executable, "-c", code, str(tmp_path / "sys.npz"), str(tmp_path / "x.npy")], capture_output=True, text=True, timeout=600)
+    if p.returncode == 3:
+        pytest.skip("no GPU visible to torch")
+    assert p.returncode == 0, p.stderr[-2000:]
+    ref = np.load(tmp_path / "x.npy")
+    assert np.linalg.norm(x - ref) <= 1e-11 * np.linalg.norm(ref)
