@@ -162,23 +162,42 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ im
             const uint32_t* dn = reinterpret_cast<const uint32_t*>(&tile[(ry + 0) * TP + 4 * q]);   // row y - 3 (ring 8)
             u0 = up[0]; u1 = up[1]; d0_ = dn[0]; d1_ = dn[1];
         }
+        // the four centres are bytes 3..6 of (m0, m1, m2); N / S are bytes 3..6 of the rows three above / below; E and W are the
+        // centre row three bytes on.  Two pixels at a time in packed 16-bit arithmetic: a corner needs two neighbouring compass
+        // points both darker (min of the pair of differences > t) or both brighter (max of the pair < -t).
+        unsigned passbits = 0;
+        if (row_ok) {
+            const short2_t T1 = (short2_t){ (short)(threshold + 1), (short)(threshold + 1) }, T = (short2_t){ (short)threshold, (short)threshold };
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+                // two adjacent bytes j, j + 1 (0 <= j <= 6) of the 8 bytes hi:lo, zero-extended to 16 bits each (v_perm_b32:
+                // selector 0..3 = bytes of lo, 4..7 = bytes of hi, 0x0c = zero)
+                auto pair16 = [&](uint32_t hi, uint32_t lo, int j) -> short2_t {
+                    const uint32_t sel = 0x0c000c00u | (uint32_t)j | ((uint32_t)(j + 1) << 16);
+                    const uint32_t r = __builtin_amdgcn_perm(hi, lo, sel);
+                    short2_t o; __builtin_memcpy(&o, &r, 4); return o;
+                };
+                // pixels 2 hp, 2 hp + 1 of the group: centre bytes 3 + 2 hp .., east 6 + 2 hp .., west 2 hp .. of (m0, m1, m2)
+                const short2_t V = hp == 0 ? pair16(m1, m0, 3) : pair16(m2, m1, 1);
+                const short2_t Ee = hp == 0 ? pair16(m2, m1, 2) : pair16(0u, m2, 0);
+                const short2_t Ww = hp == 0 ? pair16(m1, m0, 0) : pair16(m1, m0, 2);
+                const short2_t Nn = hp == 0 ? pair16(u1, u0, 3) : pair16(0u, u1, 1);
+                const short2_t Ss = hp == 0 ? pair16(d1_, d0_, 3) : pair16(0u, d1_, 1);
+                const short2_t dN = V - Nn, dE = V - Ee, dS = V - Ss, dW = V - Ww;
+                const short2_t dark = pmax(pmax(pmin(dN, dE), pmin(dE, dS)), pmax(pmin(dS, dW), pmin(dW, dN)));
+                const short2_t bright = pmin(pmin(pmax(dN, dE), pmax(dE, dS)), pmin(pmax(dS, dW), pmax(dW, dN)));
+                const short2_t xd = dark - T1, xb = bright + T;                       // dark > t  <=>  xd >= 0 ; bright < -t  <=>  xb < 0
+                uint32_t ud, ub;
+                __builtin_memcpy(&ud, &xd, 4); __builtin_memcpy(&ub, &xb, 4);
+                const uint32_t sg = (~ud | ub) & 0x80008000u;
+                passbits |= ((sg >> 15) & 1u) << (2 * hp);
+                passbits |= ((sg >> 31) & 1u) << (2 * hp + 1);
+            }
+        }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            bool pass = false;
             const int rx = 4 * q + b, x = x0 - 1 + rx;
-            if (row_ok && rx < SCW && x >= 3 && x < w - 3) {
-                auto b12 = [&](int idx) -> int { const uint32_t r = idx < 4 ? m0 : (idx < 8 ? m1 : m2); return (int)((r >> (8 * (idx & 3))) & 0xffu); };
-                auto b8 = [&](uint32_t lo, uint32_t hi, int idx) -> int { const uint32_t r = idx < 4 ? lo : hi; return (int)((r >> (8 * (idx & 3))) & 0xffu); };
-                const int v = b12(3 + b);
-                const int dN = v - b8(u0, u1, 3 + b);      // (0, +3)
-                const int dE = v - b12(6 + b);             // (+3, 0)
-                const int dS = v - b8(d0_, d1_, 3 + b);    // (0, -3)
-                const int dW = v - b12(b);                 // (-3, 0)
-                const int t = threshold;
-                const bool k0 = dN > t, k4 = dE > t, k8 = dS > t, k12 = dW > t;
-                const bool g0 = dN < -t, g4 = dE < -t, g8 = dS < -t, g12 = dW < -t;
-                pass = (k0 && k4) || (k4 && k8) || (k8 && k12) || (k12 && k0) || (g0 && g4) || (g4 && g8) || (g8 && g12) || (g12 && g0);
-            }
+            const bool pass = ((passbits >> b) & 1u) && rx < SCW && x >= 3 && x < w - 3;
             const unsigned long long bal = __ballot(pass);
             if (bal) {
                 int base = 0;
