@@ -22,7 +22,7 @@ struct OrbSelectArgs {
 
 // wp = internal row pitch of the score map / blurred image (w rounded up to 4)
 constexpr int ORB_MAX_LEVELS = 16;   // pyramid depth accepted by mage_orb_create
-constexpr int ORB_BAND_ROWS = 32;    // image rows per tile row of k_fast_nms = per band of the raster-order emit pass
+constexpr int ORB_BAND_ROWS = 48;    // image rows per tile row of k_fast_nms = per band of the raster-order emit pass
 // FAST + NMS + border cull: kept map (score where a keypoint survives), raw scores of frame 0 (optional), histogram, per-band counts
 void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, int border, uint8_t* kept,
                      uint8_t* raw_frame0, int wp, int* hist, int* band_count, int n_bands, hipStream_t st);

@@ -21,7 +21,7 @@ namespace {
 // brighter rings; a pixel is a corner iff that maximum exceeds the threshold, and its score is maximum - 1
 // (identical to the reference's threshold-table pre-test + min/max ladder, which computes the same quantity).
 // ---------------------------------------------------------------------------------------------
-constexpr int FT_W = 64, FT_H = ORB_BAND_ROWS;   // 2048 pixels per workgroup, 8 per thread (few, fat workgroups: dispatch is not free)
+constexpr int FT_W = 64, FT_H = ORB_BAND_ROWS;   // 3072 pixels per workgroup, 12 per thread: fat workgroups amortise the halo, the LDS clears and five barriers (480 rows = 10 bands)
 
 // The ring differences fit 16 bits, so the score runs on PACKED pairs: register k holds (d[k], d[k + 8]) -- a ring pixel and its
 // opposite.  A rotation of the ring by one position is "next register", and crossing position 7 -> 8 is a swap of the halves,
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ im
     uint8_t* K = kept + (size_t)f * wp * h;
     int mine = 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < FT_W * FT_H / 4 / 256; ++i) {
         const int qi = tid + 256 * i;
         const int ly = qi / (FT_W / 4), lq = qi % (FT_W / 4);
         const int y = y0 + ly, xq = x0 + 4 * lq;
