@@ -124,7 +124,8 @@ __device__ __forceinline__ void stage_window(uint8_t* __restrict__ tile, const u
 // here from LDS and the full-image count pass is gone; what reaches HBM is the KEPT map (score where the pixel survives, else
 // 0), the per-frame histogram and the per-band (32 image rows = one tile row) keypoint counts for the raster-order emit pass.
 constexpr int FH = 4;                                   // image halo of the staged window: 3 (ring) + 1 (score ring)
-constexpr int SCW = FT_W + 2, SCH = FT_H + 2, SCP = 68; // score region and its LDS pitch
+constexpr int SCW = FT_W + 2, SCH = FT_H + 2, SCP = 72; // score region and its LDS pitch
+constexpr int SC_OFF = 3;                               // region pixel rx sits at byte rx + 3 of its row: the tile's quads are dword-aligned
 
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride,
                                                   int threshold, int border, uint8_t* __restrict__ kept, uint8_t* __restrict__ raw_frame0, int wp,
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ im
     for (int c = tid; c < nc; c += 256) {
         const int p = cand[c];
         const int ry = p / SCP, rx = p % SCP;
-        sc[p] = (uint8_t)fast_score_at(&tile[(ry + 3) * TP + rx + 3], TP, threshold);
+        sc[p + SC_OFF] = (uint8_t)fast_score_at(&tile[(ry + 3) * TP + rx + 3], TP, threshold);
     }
     __syncthreads();
     // Phase 3: strict 3x3 maximum among the raw scores + RunByImageBorder; one 32-bit store per quad of the kept map
@@ -226,17 +227,19 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ im
         const int ly = qi / (FT_W / 4), lq = qi % (FT_W / 4);
         const int y = y0 + ly, xq = x0 + 4 * lq;
         if (y >= h || xq >= wp) continue;
-        const uint8_t* c0 = &sc[(ly + 1) * SCP + 4 * lq + 1];
-        uint32_t raw4 = 0, kept4 = 0;
+        const uint8_t* c0 = &sc[(ly + 1) * SCP + 4 * lq + 1 + SC_OFF];           // dword-aligned: the four scores in one LDS read
+        const uint32_t raw4 = *reinterpret_cast<const uint32_t*>(c0);
+        uint32_t kept4 = 0;
+        if (raw4 != 0u && y >= lo && y < h - lo) {                              // most quads hold no corner at all
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int s = c0[b];
-            raw4 |= (uint32_t)s << (8 * b);
-            const int x = xq + b;
-            if (s == 0 || x < lo || x >= w - lo || y < lo || y >= h - lo) continue;
-            const uint8_t* p = c0 + b;
-            const bool keep = s > p[-1] && s > p[1] && s > p[-SCP - 1] && s > p[-SCP] && s > p[-SCP + 1] && s > p[SCP - 1] && s > p[SCP] && s > p[SCP + 1];
-            if (keep) { kept4 |= (uint32_t)s << (8 * b); ++mine; atomicAdd(&lh[s], 1); }
+            for (int b = 0; b < 4; ++b) {
+                const int s = (int)((raw4 >> (8 * b)) & 0xffu);
+                const int x = xq + b;
+                if (s == 0 || x < lo || x >= w - lo) continue;
+                const uint8_t* p = c0 + b;
+                const bool keep = s > p[-1] && s > p[1] && s > p[-SCP - 1] && s > p[-SCP] && s > p[-SCP + 1] && s > p[SCP - 1] && s > p[SCP] && s > p[SCP + 1];
+                if (keep) { kept4 |= (uint32_t)s << (8 * b); ++mine; atomicAdd(&lh[s], 1); }
+            }
         }
         *reinterpret_cast<uint32_t*>(K + (size_t)y * wp + xq) = kept4;
         if (f == 0 && raw_frame0) *reinterpret_cast<uint32_t*>(raw_frame0 + (size_t)y * wp + xq) = raw4;
