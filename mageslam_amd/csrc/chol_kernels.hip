@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
         const int row0 = (j0 + rt) * TILE + ((q >> 0) & 1) * 64 + (wave & 1) * 32;
         const int col0 = (j0 + ct) * TILE + ((q >> 1) & 1) * 64 + (wave >> 1) * 32;
         double4_t out[2][2];
-        update_block<2, 32>(S, ld, k, row0, col0, lane, out);
+        update_block<2, 8>(S, ld, k, row0, col0, lane, out);
         double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
