@@ -12,6 +12,7 @@
 #pragma once
 
 #include <cstddef>
+#include <cstdint>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -120,19 +121,22 @@ namespace mage
         }
         float StepBundleAdjustment(const float* huberWidths, size_t count, float maxErrorSquare, std::vector<unsigned int>& outliers)
         {
-            // the reference appends to `outliers`; the number of new entries is only known after the call
+            // The reference appends to `outliers` (BundlerLib.cpp:427-446) and the number of new entries is only known after the
+            // call: the step keeps its complete list in the handle, and it is appended from there -- no capacity to guess.
+            static_assert(sizeof(unsigned int) == sizeof(uint32_t), "outlier indices are 32-bit");
             size_t n = 0;
             float mse = 0;
-            const size_t old = outliers.size();
-            std::vector<uint32_t> buf(m_scratch < 64 ? 64 : m_scratch);
-            Check(mage_ba_step(m_impl.get(), huberWidths, count, maxErrorSquare, buf.data(), buf.size(), &n, &mse));
-            if (n > buf.size()) throw std::runtime_error("BundlerLib: outlier buffer too small; call ReserveOutliers(n_observations) first");
-            outliers.resize(old + n);
-            for (size_t i = 0; i < n; ++i) outliers[old + i] = buf[i];
+            Check(mage_ba_step(m_impl.get(), huberWidths, count, maxErrorSquare, nullptr, 0, &n, &mse));
+            if (n > 0) {
+                const size_t old = outliers.size();
+                outliers.resize(old + n);
+                size_t got = 0;
+                Check(mage_ba_get_outliers(m_impl.get(), reinterpret_cast<uint32_t*>(outliers.data() + old), n, &got));
+            }
             return mse;
         }
-        // capacity hint for the outlier list of one StepBundleAdjustment call (= the observation count is always enough)
-        void ReserveOutliers(size_t count) { m_scratch = count; }
+        // kept for source compatibility with round-1 integrations; no capacity is needed any more
+        void ReserveOutliers(size_t) {}
 
         template <typename V3, typename M3>
         void GetPose(size_t idx, V3&& position, M3&& orientation) const { Check(mage_ba_get_pose(m_impl.get(), idx, position.data(), orientation.data())); }
@@ -151,6 +155,5 @@ namespace mage
         struct Deleter { void operator()(mage_ba* h) const { mage_ba_destroy(h); } };
         std::unique_ptr<mage_ba, Deleter> m_impl;
         BundlerParameters m_bundlerParameters;
-        size_t m_scratch{ 0 };
     };
 }

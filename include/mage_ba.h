@@ -91,6 +91,26 @@ mage_status mage_ba_set_points_bulk(mage_ba* h, size_t count, const float* xyz3)
 mage_status mage_ba_update_camera_poses(mage_ba* h, size_t count, const uint32_t* indices, const float* positions3,
                                         const float* R_colmajor9);
 
+/* EXTENSION -- device-resident pose exchange for a map sharded by keyframe window (north star: "RCCL all-reduce of the
+ * pose block over xGMI").  A POSE BLOCK is device memory of rows x 8 float64, one row per keyframe of the whole map in the
+ * solver's own state format: qx qy qz qw tx ty tz 0 (world -> camera).  Nothing is staged through the host and nothing
+ * synchronises: export / import run on the handle's stream but are ordered AS IF ENQUEUED ON `stream` (a hipStream_t of the
+ * caller, NULL = no ordering: use mage_ba_synchronize) -- they wait for what `stream` holds and `stream` waits for them.
+ *   bind    the handle's cameras that are published (export_cameras[k] -> block row export_rows[k]) and the ones that are
+ *           re-seeded from the block (import_cameras[k] <- row import_rows[k]); host arrays, copied once.
+ *   export  block[row] = current estimate (+0.0, so a row is bit-identical whether or not it went through a SUM with other
+ *           ranks' zero rows).
+ *   import  both device state buffers of the bound cameras <- block rows.  Same effect as mage_ba_update_camera_poses: the graph is kept, the optimiser
+ *           restarts (iteration 0; re-seed lambda with mage_ba_set_lambda to carry the damping over).
+ * The caller zero-fills the rows nobody exports, runs its collective (ncclAllReduce SUM of rows x 8 doubles: rows are disjoint
+ * between ranks, so the sum is exact) on its own stream, and imports.  tools/windowed_rccl.cpp / mage_window.h do exactly this. */
+mage_status mage_ba_bind_pose_exchange(mage_ba* h, size_t n_export, const uint32_t* export_cameras, const uint32_t* export_rows,
+                                       size_t n_import, const uint32_t* import_cameras, const uint32_t* import_rows);
+mage_status mage_ba_export_poses_device(mage_ba* h, double* block_device, void* stream);
+mage_status mage_ba_import_poses_device(mage_ba* h, const double* block_device, void* stream);
+/* Blocks until everything enqueued on the handle's stream has finished (the handle's stream is private). */
+mage_status mage_ba_synchronize(mage_ba* h);
+
 mage_status mage_ba_set_observations_bulk(mage_ba* h, size_t count, const float* uv2, const uint32_t* camera_index,
                                           const uint32_t* point_index, const float* information_scalar);
 
@@ -123,11 +143,18 @@ mage_status mage_ba_get_lambda(const mage_ba* h, float* lambda_out);
  * then classification of every active observation (behind the camera, or squared reprojection error
  * above max_error_square -> removed and reported).  Outlier observation indices are written in
  * ascending order to outliers[0..min(*n_outliers, capacity)); *n_outliers is the full count
- * (the reference appends to a std::vector).  *mean_square_error is the reference's return value
+ * (the reference appends to a std::vector); the full list stays readable through mage_ba_get_outliers
+ * until the next step, so a short buffer never loses removed observations.  *mean_square_error is the reference's return value
  * (NaN when no inlier remains). */
 mage_status mage_ba_step(mage_ba* h, const float* huber_width_per_iteration, size_t n_iterations,
                          float max_error_square, uint32_t* outliers, size_t capacity, size_t* n_outliers,
                          float* mean_square_error);
+
+/* The complete outlier list of the most recent mage_ba_step, ascending (the same entries the step wrote, without its capacity
+ * limit): *count is the full length, outliers[0..min(*count, capacity)) is filled (outliers may be NULL to query the length).
+ * A caller that cannot bound the list up front -- the reference's callers pass a growing std::vector, BundleAdjust.cpp:316-320 --
+ * steps with capacity 0 and reads the list here; nothing is ever dropped. */
+mage_status mage_ba_get_outliers(const mage_ba* h, uint32_t* outliers, size_t capacity, size_t* count);
 
 /* GetPose / GetPoint  (BundlerLib.cpp:457-471) */
 mage_status mage_ba_get_pose(const mage_ba* h, size_t idx, float position[3], float R_colmajor[9]);

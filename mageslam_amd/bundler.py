@@ -61,6 +61,11 @@ def _declare():
     L.mage_ba_set_lambda.argtypes = [vp, C.c_float]
     L.mage_ba_get_lambda.argtypes = [vp, C.POINTER(C.c_float)]
     L.mage_ba_step.argtypes = [vp, _f32, sz, C.c_float, _u32, sz, C.POINTER(sz), C.POINTER(C.c_float)]
+    L.mage_ba_get_outliers.argtypes = [vp, C.c_void_p, sz, C.POINTER(sz)]
+    L.mage_ba_bind_pose_exchange.argtypes = [vp, sz, _u32, _u32, sz, _u32, _u32]
+    L.mage_ba_export_poses_device.argtypes = [vp, vp, vp]
+    L.mage_ba_import_poses_device.argtypes = [vp, vp, vp]
+    L.mage_ba_synchronize.argtypes = [vp]
     L.mage_ba_get_pose.argtypes = [vp, sz, _f32, _f32]
     L.mage_ba_get_point.argtypes = [vp, sz, _f32]
     L.mage_ba_get_poses_bulk.argtypes = [vp, sz, _f32, _f32]
@@ -171,6 +176,28 @@ class BundlerLib:
         check(self._L.mage_ba_step(self._h, hw, hw.size, float(max_error_square), buf, buf.size, C.byref(n), C.byref(mse)))
         outliers.extend(int(x) for x in buf[: min(n.value, buf.size)])
         return float(mse.value)
+
+    def GetOutliers(self) -> list:
+        """mage_ba_get_outliers: the complete outlier list of the most recent step."""
+        n = C.c_size_t(0)
+        check(self._L.mage_ba_get_outliers(self._h, None, 0, C.byref(n)))
+        buf = np.zeros(max(n.value, 1), np.uint32)
+        check(self._L.mage_ba_get_outliers(self._h, buf.ctypes.data, buf.size, C.byref(n)))
+        return [int(x) for x in buf[: n.value]]
+
+    # --- device-resident pose exchange (mage_ba.h): block_ptr / stream are raw device pointer / hipStream_t values
+    def BindPoseExchange(self, export_cameras, export_rows, import_cameras, import_rows):
+        ec, er = np.ascontiguousarray(export_cameras, np.uint32), np.ascontiguousarray(export_rows, np.uint32)
+        ic, ir = np.ascontiguousarray(import_cameras, np.uint32), np.ascontiguousarray(import_rows, np.uint32)
+        check(self._L.mage_ba_bind_pose_exchange(self._h, len(ec), ec, er, len(ic), ic, ir))
+
+    def ExportPosesDevice(self, block_ptr: int, consumer_stream: int = 0):
+        check(self._L.mage_ba_export_poses_device(self._h, C.c_void_p(block_ptr), C.c_void_p(consumer_stream or None)))
+
+    def ImportPosesDevice(self, block_ptr: int, producer_stream: int = 0):
+        check(self._L.mage_ba_import_poses_device(self._h, C.c_void_p(block_ptr), C.c_void_p(producer_stream or None)))
+
+    def Synchronize(self): check(self._L.mage_ba_synchronize(self._h))
 
     def GetPose(self, idx):
         t = np.zeros(3, np.float32); R = np.zeros(9, np.float32)

@@ -271,6 +271,12 @@ struct mage_ba {
     BaDeviceView view{};
     std::vector<uint32_t> L_edge_host;  // landmark-order position -> observation index
     std::vector<uint8_t> flag_host;
+    std::vector<uint32_t> last_outliers;   // full outlier list of the most recent mage_ba_step (mage_ba_get_outliers)
+
+    // ---- device-resident pose exchange (mage_ba_bind_pose_exchange): camera index / block row lists, bound once
+    DevBuf<uint32_t> d_x_exp_cam, d_x_exp_row, d_x_imp_cam, d_x_imp_row;
+    size_t n_x_exp = 0, n_x_imp = 0;
+    hipEvent_t ev_x[2] = { nullptr, nullptr };
 
     // ---- diagnostics
     std::vector<mage_ba_iter_stats> stats;
@@ -280,9 +286,10 @@ struct mage_ba {
 
     ~mage_ba()
     {
-        (void)hipSetDevice(device);
+        DeviceScope scope(device);
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto& e : ev_x) if (e) (void)hipEventDestroy(e);
         if (h_scal) (void)hipHostFree(h_scal);
         cached_stream_release(device, stream);
     }
@@ -294,7 +301,7 @@ mage_status download_state(const mage_ba* hc)
 {
     mage_ba* h = const_cast<mage_ba*>(hc);
     if (!h->state_on_device || h->host_state_fresh) return MAGE_OK;
-    MAGE_HIP(hipSetDevice(h->device));
+    MAGE_DEVICE_SCOPE(h->device);
     std::vector<double> pose(h->cams.size() * 8), pts(h->pt_set.size() * 4);
     if (!pose.empty()) MAGE_HIP(hipMemcpyAsync(pose.data(), h->d_pose[h->cur].p, pose.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (!pts.empty()) MAGE_HIP(hipMemcpyAsync(pts.data(), h->d_pt[h->cur].p, pts.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -396,7 +403,7 @@ struct PhaseTimer {
 mage_status initialize_optimization(mage_ba* h)
 {
     PhaseTimer tm;
-    MAGE_HIP(hipSetDevice(h->device));
+    MAGE_DEVICE_SCOPE(h->device);
     const int nc = (int)h->cams.size(), np = (int)h->pt_set.size();
     if (!h->state_on_device) MAGE_TRY(upload_state(h));
     else {
@@ -574,6 +581,8 @@ mage_status initialize_optimization(mage_ba* h)
     // (i, j) with landmark order preserved inside a block.
     size_t ncon = 0;
     for (int l = 0; l < nlm; ++l) { size_t k = (size_t)(lm_wptr[l + 1] - lm_wptr[l]); ncon += k * (k + 1) / 2; }
+    if (ncon > (size_t)0x7fffffff)      // block offsets and contribution indices are 32-bit on the device
+        return fail(MAGE_ERR_UNSUPPORTED, "%zu Schur contributions exceed the 32-bit index range of the block lists (tracks too long)", ncon);
     // Row i of the block structure is built from the slots of camera i (camS: ascending slot = ascending landmark): every
     // later slot b >= a of the same landmark is a camera j >= i.  A counting sort over j inside the row (two passes over a
     // few thousand contributions, cache resident) replaces a global sort of all contributions.
@@ -697,6 +706,7 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(h->d_T_out.reserve((size_t)nT * TETHER_OUT_STRIDE + 1));
 
     tm.mark("uploads queued");
+    if (n_pad > CHOL_MAX_ORDER) return fail(MAGE_ERR_UNSUPPORTED, "reduced camera system of order %d exceeds %d (one resident workgroup per tile column)", n_pad, CHOL_MAX_ORDER);
     const int nb_l = (nlm + 255) / 256, nb_c = (nfc + 255) / 256;
     MAGE_TRY(h->d_errL.reserve((size_t)nL * 2 + 2));
     MAGE_TRY(h->d_U.reserve((size_t)nfc * 36 + 1));
@@ -713,7 +723,6 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(h->d_partial.reserve(std::max<size_t>(3 * 1024, (size_t)nb_l + nb_c) + 16));
     MAGE_TRY(h->d_scal.reserve(SC_COUNT));
     MAGE_TRY(h->d_Linv.reserve(chol_workspace_doubles(n_pad)));
-    if (n_pad > CHOL_MAX_ORDER) return fail(MAGE_ERR_UNSUPPORTED, "reduced camera system of order %d exceeds %d (one resident workgroup per tile column)", n_pad, CHOL_MAX_ORDER);
     MAGE_TRY(h->d_queue.reserve(chol_sync_ints(n_pad)));
     MAGE_TRY(h->d_flagL.reserve((size_t)nL + 1));
     MAGE_TRY(h->d_L_active.reserve((size_t)nL + 1));
@@ -789,7 +798,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
     bool have_chi = false;
     double rho = 0;
     int qmax = 0;
-    CholWorkspace ws{ h->d_Linv.p, h->d_queue.p };
+    CholWorkspace ws{ h->d_Linv.p, h->d_queue.p, nullptr, v.scal + SC_CHOL_STALL };
     do {
         const double lambda = h->lambda;
         if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[0], st));
@@ -807,6 +816,8 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
             MAGE_HIP(hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
             h->prof.factor_ms_total += ms; h->prof.n_factorizations++;
         }
+        if (h->h_scal[SC_CHOL_STALL] != 0.0)
+            return fail(MAGE_ERR_DEVICE, "dense solve: a cross-workgroup hand-off timed out (device stalled or oversubscribed); the trial was not evaluated");
         const bool ok2 = h->h_scal[SC_CHOL_OK] != 0.0;
         if (!have_chi) { currentChi = h->h_scal[SC_CHI]; tr.chi2_before = currentChi; have_chi = true; }
         double tempChi = h->h_scal[SC_CHI_TRIAL];
@@ -905,7 +916,7 @@ MAGE_EXPORT mage_status mage_debug_dense_solve(int device, int n, const double* 
         if (n <= 0 || !A_colmajor || !b || !x || !ok) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument or n <= 0");
         int dev = 0;
         MAGE_TRY(select_device(device, &dev));
-        MAGE_HIP(hipSetDevice(dev));
+        MAGE_DEVICE_SCOPE(dev);
         chol_init_device();
         const int n_pad = std::max(CHOL_TILE, ((n + CHOL_TILE - 1) / CHOL_TILE) * CHOL_TILE);
         if (n_pad > CHOL_MAX_ORDER) return fail(MAGE_ERR_UNSUPPORTED, "order %d exceeds %d", n_pad, CHOL_MAX_ORDER);
@@ -920,17 +931,18 @@ MAGE_EXPORT mage_status mage_debug_dense_solve(int device, int n, const double* 
         MAGE_TRY(cached_stream_acquire(dev, &st));
         mage_status rc = [&]() -> mage_status {
             MAGE_TRY(dS.upload(S.data(), S.size(), st)); MAGE_TRY(dy.upload(y.data(), y.size(), st));
-            MAGE_TRY(dx.reserve(n_pad)); MAGE_TRY(dLinv.reserve(chol_workspace_doubles(n_pad))); MAGE_TRY(dok.reserve(1));
+            MAGE_TRY(dx.reserve(n_pad)); MAGE_TRY(dLinv.reserve(chol_workspace_doubles(n_pad))); MAGE_TRY(dok.reserve(2));
             MAGE_TRY(dsync.reserve(chol_sync_ints(n_pad)));
             CholWorkspace ws{ dLinv.p, dsync.p };
             chol_factor_solve(dS.p, dy.p, dx.p, n_pad, ws, dok.p, st);
             std::vector<double> xs(n_pad);
-            double okv = 0;
+            double okv[2] = { 0, 0 };
             MAGE_HIP(hipMemcpyAsync(xs.data(), dx.p, n_pad * sizeof(double), hipMemcpyDeviceToHost, st));
-            MAGE_HIP(hipMemcpyAsync(&okv, dok.p, sizeof(double), hipMemcpyDeviceToHost, st));
+            MAGE_HIP(hipMemcpyAsync(okv, dok.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
             MAGE_HIP(hipStreamSynchronize(st));
+            if (okv[1] != 0.0) return fail(MAGE_ERR_DEVICE, "dense solve: a cross-workgroup hand-off timed out");
             for (int i = 0; i < n; ++i) x[i] = xs[i];
-            *ok = okv != 0.0 ? 1 : 0;
+            *ok = okv[0] != 0.0 ? 1 : 0;
             return MAGE_OK;
         }();
         (void)hipStreamSynchronize(st);
@@ -949,9 +961,10 @@ MAGE_EXPORT mage_status mage_ba_create(const mage_ba_params* params, mage_ba** o
         std::unique_ptr<mage_ba> h(new mage_ba());
         h->device = dev;
         h->points_fixed = params ? params->are_points_fixed != 0 : false;
-        MAGE_HIP(hipSetDevice(dev));
+        MAGE_DEVICE_SCOPE(dev);
         MAGE_TRY(cached_stream_acquire(dev, &h->stream));
         for (auto& e : h->ev) MAGE_HIP(hipEventCreate(&e));
+        for (auto& e : h->ev_x) MAGE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         chol_init_device();
         *out = h.release();
         return MAGE_OK;
@@ -1027,19 +1040,23 @@ MAGE_EXPORT mage_status mage_ba_update_camera_poses(mage_ba* h, size_t count, co
         // The estimate may live on the device (stepping has started): the host copy of every other entity stays as stale or
         // as fresh as it was; the edited cameras are written to both places, and to BOTH device state buffers (a fixed camera
         // is never written by a trial, so the buffer that becomes current after an accepted trial must hold it too).
-        if (h->state_on_device) {
-            MAGE_HIP(hipSetDevice(h->device));
-            MAGE_HIP(hipStreamSynchronize(h->stream));
-        }
+        MAGE_DEVICE_SCOPE(h->device);
+        std::vector<double> recs;
         for (size_t k = 0; k < count; ++k) {
             HostCam& c = h->cams[indices[k]];
             pose_from_f32(R_colmajor9 + 9 * k, positions3 + 3 * k, c);
             if (h->state_on_device) {
                 const double rec[8] = { c.q[0], c.q[1], c.q[2], c.q[3], c.t[0], c.t[1], c.t[2], 0.0 };
-                for (int b = 0; b < 2; ++b)
-                    MAGE_HIP(hipMemcpyAsync(h->d_pose[b].p + (size_t)indices[k] * 8, rec, sizeof(rec), hipMemcpyHostToDevice, h->stream));
-                MAGE_HIP(hipStreamSynchronize(h->stream));      // rec is a stack buffer
+                recs.insert(recs.end(), rec, rec + 8);
             }
+        }
+        if (h->state_on_device) {
+            // one staging copy, then a scatter on the device into both state buffers (instead of a synchronised copy per camera)
+            DevBuf<double> stage; DevBuf<uint32_t> idx;
+            MAGE_TRY(stage.upload(recs.data(), recs.size(), h->stream));
+            MAGE_TRY(idx.upload(indices, count, h->stream));
+            ba_launch_import_poses(h->d_pose[0].p, h->d_pose[1].p, idx.p, nullptr, count, stage.p, h->stream);
+            MAGE_HIP(hipStreamSynchronize(h->stream));      // the staging buffers go back to the cache
         }
         h->iteration = 0;          // a different linear system: the optimiser starts over (lambda re-seeded), the graph is unchanged
         return MAGE_OK;
@@ -1215,8 +1232,9 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
         if (!h || (n_iter && !huber)) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
         if (n_outliers) *n_outliers = 0;
         if (mean_sq_err) *mean_sq_err = NAN;
-        MAGE_HIP(hipSetDevice(h->device));
+        MAGE_DEVICE_SCOPE(h->device);
         h->stats.clear();
+        h->last_outliers.clear();
         for (size_t it = 0; it < n_iter; ++it) {
             if (huber[it] < 0.f) return fail(MAGE_ERR_INVALID_ARGUMENT, "Huber widths must be nonnegative");
             bool cont = true;
@@ -1235,7 +1253,9 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
             h->flag_host.resize(v.n_L);
             MAGE_HIP(hipMemcpyAsync(h->flag_host.data(), h->d_flagL.p, (size_t)v.n_L, hipMemcpyDeviceToHost, h->stream));
             MAGE_HIP(hipStreamSynchronize(h->stream));
-            std::vector<uint32_t> ids;
+            // The whole list stays in the handle (mage_ba_get_outliers): a caller whose buffer was too small loses nothing --
+            // the reference appends to a std::vector and its callers drop these associations from the map (BundleAdjust.cpp:316-320).
+            std::vector<uint32_t>& ids = h->last_outliers;
             ids.reserve(nout);
             for (int i = 0; i < v.n_L; ++i) if (h->flag_host[i]) ids.push_back(h->L_edge_host[i]);
             std::sort(ids.begin(), ids.end());
@@ -1247,6 +1267,93 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
             h->n_active_remaining -= (long long)ids.size();
         }
         if (n_outliers) *n_outliers = nout;
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_get_outliers(const mage_ba* h, uint32_t* outliers, size_t capacity, size_t* count)
+{
+    if (!h || !count) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+    *count = h->last_outliers.size();
+    for (size_t i = 0; outliers && i < h->last_outliers.size() && i < capacity; ++i) outliers[i] = h->last_outliers[i];
+    return MAGE_OK;
+}
+
+// ---- device-resident pose exchange (window-sharded maps; include/mage_ba.h)
+MAGE_EXPORT mage_status mage_ba_bind_pose_exchange(mage_ba* h, size_t n_export, const uint32_t* export_cameras, const uint32_t* export_rows,
+                                                   size_t n_import, const uint32_t* import_cameras, const uint32_t* import_rows)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || (n_export && (!export_cameras || !export_rows)) || (n_import && (!import_cameras || !import_rows)))
+            return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        for (size_t k = 0; k < n_export; ++k)
+            if (export_cameras[k] >= h->cams.size() || !h->cams[export_cameras[k]].set) return fail(MAGE_ERR_INVALID_ARGUMENT, "export camera %u is not a set camera", export_cameras[k]);
+        for (size_t k = 0; k < n_import; ++k)
+            if (import_cameras[k] >= h->cams.size() || !h->cams[import_cameras[k]].set) return fail(MAGE_ERR_INVALID_ARGUMENT, "import camera %u is not a set camera", import_cameras[k]);
+        MAGE_DEVICE_SCOPE(h->device);
+        MAGE_HIP(hipStreamSynchronize(h->stream));          // a previous export / import may still read the old lists
+        MAGE_TRY(h->d_x_exp_cam.upload(export_cameras, n_export, h->stream)); MAGE_TRY(h->d_x_exp_row.upload(export_rows, n_export, h->stream));
+        MAGE_TRY(h->d_x_imp_cam.upload(import_cameras, n_import, h->stream)); MAGE_TRY(h->d_x_imp_row.upload(import_rows, n_import, h->stream));
+        MAGE_HIP(hipStreamSynchronize(h->stream));          // the sources are the caller's pageable arrays
+        h->n_x_exp = n_export; h->n_x_imp = n_import;
+        return MAGE_OK;
+    });
+}
+
+// Both calls are ordered AS IF ENQUEUED ON `stream`: the handle's stream first waits for what `stream` holds (the caller's
+// zero-fill before an export, its all-reduce before an import), and `stream` then waits for the kernel (so the caller's next
+// zero-fill cannot overtake an import that still reads the block).  Two events, no host synchronisation.
+static mage_status join_before(mage_ba* h, void* stream)
+{
+    if (stream && stream != (void*)h->stream) {
+        MAGE_HIP(hipEventRecord(h->ev_x[0], static_cast<hipStream_t>(stream)));
+        MAGE_HIP(hipStreamWaitEvent(h->stream, h->ev_x[0], 0));
+    }
+    return MAGE_OK;
+}
+static mage_status join_after(mage_ba* h, void* stream)
+{
+    if (stream && stream != (void*)h->stream) {
+        MAGE_HIP(hipEventRecord(h->ev_x[1], h->stream));
+        MAGE_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->ev_x[1], 0));
+    }
+    return MAGE_OK;
+}
+
+MAGE_EXPORT mage_status mage_ba_export_poses_device(mage_ba* h, double* block, void* stream)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !block) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        MAGE_DEVICE_SCOPE(h->device);
+        if (!h->state_on_device) MAGE_TRY(upload_state(h));
+        MAGE_TRY(join_before(h, stream));
+        if (h->n_x_exp) ba_launch_export_poses(h->d_pose[h->cur].p, h->d_x_exp_cam.p, h->d_x_exp_row.p, h->n_x_exp, block, h->stream);
+        return join_after(h, stream);
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_import_poses_device(mage_ba* h, const double* block, void* stream)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !block) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        MAGE_DEVICE_SCOPE(h->device);
+        if (!h->state_on_device) MAGE_TRY(upload_state(h));
+        MAGE_TRY(join_before(h, stream));
+        if (h->n_x_imp) {
+            ba_launch_import_poses(h->d_pose[0].p, h->d_pose[1].p, h->d_x_imp_cam.p, h->d_x_imp_row.p, h->n_x_imp, block, h->stream);
+            h->host_state_fresh = false;
+            h->iteration = 0;          // a different linear system: the optimiser starts over, the graph is unchanged
+        }
+        return join_after(h, stream);
+    });
+}
+
+MAGE_EXPORT mage_status mage_ba_synchronize(mage_ba* h)
+{
+    return guarded([&]() -> mage_status {
+        if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+        MAGE_DEVICE_SCOPE(h->device);
+        MAGE_HIP(hipStreamSynchronize(h->stream));
         return MAGE_OK;
     });
 }

@@ -75,7 +75,7 @@ enum TetherKind { TETHER_DISTANCE = 0, TETHER_ROTATION = 1, TETHER_TRANSFORM = 2
 constexpr int TETHER_OUT_STRIDE = 120;
 
 // SC_CHI: robust chi2 of the current estimate; SC_CHI_TRIAL: of the LM candidate (separate slots: one host read fetches both)
-enum Scal { SC_CHI = 0, SC_SCALE = 1, SC_MAXDIAG = 2, SC_CHOL_OK = 3, SC_ERRSUM = 4, SC_ERRCNT = 5, SC_NOUT = 6, SC_CHI_TRIAL = 7, SC_COUNT = 8 };
+enum Scal { SC_CHI = 0, SC_SCALE = 1, SC_MAXDIAG = 2, SC_CHOL_OK = 3, SC_ERRSUM = 4, SC_ERRCNT = 5, SC_NOUT = 6, SC_CHI_TRIAL = 7, SC_CHOL_STALL = 8, SC_COUNT = 9 };
 
 // All launchers enqueue on `st` and return immediately.
 void ba_launch_error(const BaDeviceView& v, bool trial, double huber_delta, hipStream_t st);         // -> scal[SC_CHI] / scal[SC_CHI_TRIAL]
@@ -84,6 +84,12 @@ void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st);                  
 void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st);                          // Dinv,db,S,y
 void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st);                         // xl, trial state, scal[SC_SCALE]
 void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flag_by_edge, hipStream_t st); // scal[SC_ERRSUM..SC_NOUT]
+
+// Pose exchange of a window-sharded map (mage_ba_export_poses_device / mage_ba_import_poses_device).  A block row is 8 doubles
+// (qx qy qz qw tx ty tz 0).  export: block[row[k]] = pose[cam[k]] (+0.0, so that -0.0 leaves as +0.0 -- what a SUM with the
+// zero rows of the other ranks would make of it anyway); import: pose0[cam[k]] = pose1[cam[k]] = block[row ? row[k] : k].
+void ba_launch_export_poses(const double* pose, const uint32_t* cam, const uint32_t* row, size_t n, double* block, hipStream_t st);
+void ba_launch_import_poses(double* pose0, double* pose1, const uint32_t* cam, const uint32_t* row, size_t n, const double* block, hipStream_t st);
 
 // tether_kernels.hip (called by the launchers above when the problem carries tethers)
 void tether_launch_error(const BaDeviceView& v, bool trial, hipStream_t st);      // same slot += tether chi2

@@ -666,6 +666,28 @@ __global__ __launch_bounds__(256) void k_classify(BaDeviceView v, double max_err
     if (threadIdx.x == 0) { v.partial[blockIdx.x] = r0; v.partial[nb + blockIdx.x] = r1; v.partial[2 * nb + blockIdx.x] = r2; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// pose exchange of a window-sharded map: 8 doubles per pose, one thread per double
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_export_poses(const double* __restrict__ pose, const uint32_t* __restrict__ cam,
+                                                      const uint32_t* __restrict__ row, size_t n, double* __restrict__ block)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 8) return;
+    const size_t k = i >> 3, a = i & 7;
+    block[(size_t)row[k] * 8 + a] = pose[(size_t)cam[k] * 8 + a] + 0.0;      // -0.0 -> +0.0
+}
+__global__ __launch_bounds__(256) void k_import_poses(double* __restrict__ pose0, double* __restrict__ pose1, const uint32_t* __restrict__ cam,
+                                                      const uint32_t* __restrict__ row, size_t n, const double* __restrict__ block)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 8) return;
+    const size_t k = i >> 3, a = i & 7;
+    const double val = block[(row ? (size_t)row[k] : k) * 8 + a];
+    pose0[(size_t)cam[k] * 8 + a] = val;
+    pose1[(size_t)cam[k] * 8 + a] = val;
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int RED_BLOCKS = 1024;   // grid-stride blocks for the streaming reductions (<= partial capacity / 3)
 
@@ -725,6 +747,15 @@ void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st)
         hipLaunchKernelGGL(k_pose_update, dim3(nb_c), dim3(256), 0, st, v, lambda, nb_l);
     }
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb_l + nb_c, 1, v.scal + SC_SCALE, 1);
+}
+
+void ba_launch_export_poses(const double* pose, const uint32_t* cam, const uint32_t* row, size_t n, double* block, hipStream_t st)
+{
+    if (n) hipLaunchKernelGGL(k_export_poses, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, st, pose, cam, row, n, block);
+}
+void ba_launch_import_poses(double* pose0, double* pose1, const uint32_t* cam, const uint32_t* row, size_t n, const double* block, hipStream_t st)
+{
+    if (n) hipLaunchKernelGGL(k_import_poses, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, st, pose0, pose1, cam, row, n, block);
 }
 
 void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flagL, hipStream_t st)

@@ -10,6 +10,7 @@ struct CholWorkspace {
     double* Linv;      // chol_workspace_doubles(n_pad): inverses of the 16x16 diagonal blocks of L, per tile
     int* sync;         // chol_sync_ints(n_pad) ints: [0] arrival counter of the split diagonal tile
     long long* dbg = nullptr;   // development only: 4 x nt time stamps of the backward solve (tools/chol_test.hip)
+    double* stall = nullptr;    // device double: set to 1.0 when a bounded cross-workgroup wait timed out (a device fault, not a property of S)
 };
 size_t chol_workspace_doubles(int n_pad);
 inline size_t chol_sync_ints(int n_pad) { return (size_t)(n_pad / CHOL_TILE) + 2; }
@@ -18,7 +19,8 @@ void chol_init_device();   // once per device (after hipSetDevice): opt the LDS-
 
 // Factor S = L L^T in place (lower triangle, column-major, n_pad multiple of CHOL_TILE) and solve
 // S x = y.  y is overwritten by the forward-substituted rhs, x receives the solution.  *ok (device
-// double) is set to 1.0 first and to 0.0 when a pivot is not positive.
+// double) is set to 1.0 first and to 0.0 when a pivot is not positive; *ws.stall (ok[1] when ws.stall is null) is set to 0.0
+// first and to 1.0 when a cross-workgroup hand-off timed out.
 void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWorkspace& ws, double* ok, hipStream_t st);
 
 }  // namespace mage

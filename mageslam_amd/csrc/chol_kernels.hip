@@ -545,7 +545,7 @@ __device__ __forceinline__ void tile_of_index(int t, int& rt, int& ct)
 }
 
 __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
-                                                     double* __restrict__ Linv_next, double* __restrict__ ok, int* __restrict__ flag, int n_q4)
+                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int n_q4)
 {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
         if (tid == 0) {
             int spins = 0;
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NDIAG - 1 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
-            if (spins >= (1 << 24)) *ok = 0.0;           // a producer never arrived: the factorisation is reported as failed, not silently wrong
+            if (spins >= (1 << 24)) *stall = 1.0;        // a producer never arrived: reported as a device error (never folded into "not positive definite")
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
@@ -647,9 +647,11 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
 // consumers poll the VALUES (one L2 round trip per hop instead of flag + data: 6.1 -> 4.8 us per hop, measured with
 // CHOL_DBG=1 tools/chol_test).  Inverting L_jj in LDS beforehand (one matrix-vector product at the end) was tried: the
 // 50 us it takes do not fit in the slack of any column, and the hop stayed at 4.7 us; pinning the chain to one XCD did
-// not shorten it either.  nt <= 256 workgroups are all resident (one per CU, dispatched last column first), so a
-// consumer never waits for an unscheduled producer; polls are bounded, and a time-out clears *ok so the solve is reported
-// as failed instead of returning garbage.
+// not shorten it either.  Progress relies on IN-ORDER WORKGROUP DISPATCH: a consumer (column j) is dispatched after every
+// producer it waits for (columns > j come first in the grid), so a waiting workgroup never occupies a slot its producer
+// needs -- with one handle all nt <= 256 workgroups are resident at once, with several handles on one GPU they may not be,
+// and the dispatch order is then what guarantees progress.  Polls are bounded; a time-out sets *stall, which the host turns
+// into MAGE_ERR_DEVICE (it is never folded into the "matrix not positive definite" outcome, which steers the LM loop).
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned long long X_SENTINEL = 0x7FF4DEADBEEF0001ull;
 
@@ -660,7 +662,7 @@ __global__ void k_fill_u64(unsigned long long* __restrict__ p, int n, unsigned l
 }
 
 __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict__ S, const double* __restrict__ y, double* __restrict__ x,
-                                                        int ld, int nt, const double* __restrict__ Linv, double* __restrict__ ok, long long* __restrict__ dbg)
+                                                        int ld, int nt, const double* __restrict__ Linv, double* __restrict__ stall, long long* __restrict__ dbg)
 {
     extern __shared__ double sm[];
     constexpr int LDB = TILE + 2;
@@ -692,7 +694,7 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
             unsigned long long v;
             int spins = 0;
             while ((v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == X_SENTINEL && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
-            if (v == X_SENTINEL) *ok = 0.0;              // the producer column never published: report the solve as failed
+            if (v == X_SENTINEL) *stall = 1.0;           // the producer column never published: reported as a device error
             xk[tid] = __longlong_as_double((long long)v);
         }
         __syncthreads();
@@ -764,7 +766,9 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
     const size_t lds_diag = ((size_t)TILE * LDC + 2 * NB * NB) * sizeof(double);
     const size_t lds_panel = (size_t)TILE * (TILE + 2) * sizeof(double);
     const size_t linv_stride = (size_t)NBLK * NB * NB;
+    double* stall = ws.stall ? ws.stall : ok + 1;     // callers without a slot of their own pass a two-element ok
     hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, st, ok, 1.0);
+    hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, st, stall, 0.0);
     hipLaunchKernelGGL(k_fill_u64, dim3((n_pad + 255) / 256), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(x), n_pad, X_SENTINEL);
     hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), lds_diag, st, S, n_pad, 0, ws.Linv, ok);
     for (int k = 0; k < nt; ++k) {
@@ -774,11 +778,11 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
             const int n_tiles = m * (m + 1) / 2;
             const int n_q4 = syrk_quartered_tiles(n_tiles, g_n_cu);
             hipLaunchKernelGGL(k_syrk_update, dim3(NDIAG + (n_tiles - 1 - n_q4) + 4 * n_q4 + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
-                               ws.Linv + (size_t)(k + 1) * linv_stride, ok, ws.sync, n_q4);
+                               ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, n_q4);
         }
     }
     // backward substitution: one persistent launch (needs every workgroup resident: nt <= 256 compute units)
-    hipLaunchKernelGGL(k_bsolve_persist, dim3(nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, ok, ws.dbg);
+    hipLaunchKernelGGL(k_bsolve_persist, dim3(nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, stall, ws.dbg);
 }
 
 }  // namespace mage

@@ -43,6 +43,29 @@ inline mage_status fail(mage_status s, const char* fmt, ...)
         if (_s != MAGE_OK) return _s;                   \
     } while (0)
 
+// Makes `device` the calling thread's current HIP device for the lifetime of the object and puts the caller's device back
+// afterwards: a host process that drives several GPUs from one thread (or keeps its own HIP work on another device) must not
+// find its current device changed by a library call or by a handle's destructor.
+struct DeviceScope {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int device)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            changed = (err == hipSuccess);
+        }
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+    ~DeviceScope() { if (changed) (void)hipSetDevice(prev); }
+};
+#define MAGE_DEVICE_SCOPE(dev)            \
+    ::mage::DeviceScope _mage_scope(dev); \
+    MAGE_HIP(_mage_scope.err)
+
 // Checks that a usable gfx950 device exists; the HIP path never falls back to a CPU.
 mage_status select_device(int requested, int* chosen);
 

@@ -96,7 +96,7 @@ struct mage_orb {
     int last_w = 0, last_h = 0;
     ~mage_orb()
     {
-        (void)hipSetDevice(device);
+        DeviceScope scope(device);
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         cached_stream_release(device, stream);
@@ -134,7 +134,7 @@ MAGE_EXPORT mage_status mage_orb_create(const mage_orb_params* params, mage_orb*
         std::unique_ptr<mage_orb> h(new mage_orb());
         h->device = dev; h->P = p;
         h->taps = gaussian_taps(p.gaussian_kernel_size);
-        MAGE_HIP(hipSetDevice(dev));
+        MAGE_DEVICE_SCOPE(dev);
         MAGE_TRY(cached_stream_acquire(dev, &h->stream));
         for (auto& e : h->ev) MAGE_HIP(hipEventCreate(&e));
         std::vector<signed char> pat;
@@ -312,7 +312,7 @@ MAGE_EXPORT mage_status mage_orb_detect_batch(mage_orb* h, const uint8_t* images
         if (!h || (n_frames > 0 && (!images || !counts))) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
         if (capacity > 0 && (!keypoints || !descriptors32)) return fail(MAGE_ERR_INVALID_ARGUMENT, "null output buffer");
         if (stride < width) return fail(MAGE_ERR_INVALID_ARGUMENT, "stride < width");
-        MAGE_HIP(hipSetDevice(h->device));
+        MAGE_DEVICE_SCOPE(h->device);
         const uint8_t* dimg = images;
         if (!images_on_device && n_frames > 0) {
             const size_t bytes = (size_t)(n_frames - 1) * frame_stride + (size_t)(height - 1) * stride + width;
@@ -346,7 +346,7 @@ MAGE_EXPORT mage_status mage_orb_detect_batch_device(mage_orb* h, const uint8_t*
     return guarded([&]() -> mage_status {
         if (!h || !images_device || !keypoints_device || !descriptors_device || !counts_device) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
         if (stride < width) return fail(MAGE_ERR_INVALID_ARGUMENT, "stride < width");
-        MAGE_HIP(hipSetDevice(h->device));
+        MAGE_DEVICE_SCOPE(h->device);
         MAGE_TRY(run_batch(h, images_device, n_frames, width, height, stride, frame_stride, capacity));
         MAGE_HIP(hipStreamSynchronize(h->stream));
         *keypoints_device = h->d_kp.p; *descriptors_device = h->d_desc.p; *counts_device = h->d_count.p;
@@ -360,7 +360,7 @@ MAGE_EXPORT mage_status mage_orb_debug_read(mage_orb* h, uint8_t* score_map, uin
         if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
         const size_t w = (size_t)h->last_w, rows = (size_t)h->last_h, wp = (w + 3) & ~(size_t)3;
         if (w * rows == 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "no frame has been processed yet");
-        MAGE_HIP(hipSetDevice(h->device));
+        MAGE_DEVICE_SCOPE(h->device);
         if (score_map) MAGE_HIP(hipMemcpy2D(score_map, w, h->d_rawscore.p, wp, w, rows, hipMemcpyDeviceToHost));
         if (blurred) MAGE_HIP(hipMemcpy2D(blurred, w, h->d_blur.p, wp, w, rows, hipMemcpyDeviceToHost));
         return MAGE_OK;
@@ -391,7 +391,7 @@ MAGE_EXPORT mage_status mage_orb_undistort_keypoints(mage_orb* h, mage_keypoint*
         if (count < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative count");
         if (count == 0) return MAGE_OK;                                              // OrbFeatureDetector.cpp:39-42
         if (!keypoints) return fail(MAGE_ERR_INVALID_ARGUMENT, "null buffer");
-        MAGE_HIP(hipSetDevice(h->device));
+        MAGE_DEVICE_SCOPE(h->device);
         MAGE_TRY(h->d_undist.reserve((size_t)count));
         MAGE_HIP(hipMemcpyAsync(h->d_undist.p, keypoints, sizeof(mage_keypoint) * (size_t)count, hipMemcpyHostToDevice, h->stream));
         undistort_launch(h->d_undist.p, nullptr, 1, count, count, U, h->stream);
@@ -411,7 +411,7 @@ MAGE_EXPORT mage_status mage_orb_undistort_keypoints_device(mage_orb* h, const m
         if (n_frames < 0 || capacity < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative size");
         if (n_frames == 0 || capacity == 0) return MAGE_OK;
         if (!keypoints_device || !counts_device) return fail(MAGE_ERR_INVALID_ARGUMENT, "null buffer");
-        MAGE_HIP(hipSetDevice(h->device));
+        MAGE_DEVICE_SCOPE(h->device);
         // the buffers belong to the handle (mage_orb_detect_batch_device hands them out as const views)
         undistort_launch(const_cast<mage_keypoint*>(keypoints_device), counts_device, n_frames, capacity, 0, U, h->stream);
         MAGE_HIP(hipGetLastError());
@@ -439,7 +439,7 @@ struct mage_matcher {
     double last_ms = 0;
     ~mage_matcher()
     {
-        (void)hipSetDevice(device);
+        DeviceScope scope(device);
         if (stream) (void)hipStreamSynchronize(stream);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
@@ -471,7 +471,7 @@ MAGE_EXPORT mage_status mage_matcher_create(int device, mage_matcher** out)
         MAGE_TRY(select_device(device, &dev));
         std::unique_ptr<mage_matcher> h(new mage_matcher());
         h->device = dev;
-        MAGE_HIP(hipSetDevice(dev));
+        MAGE_DEVICE_SCOPE(dev);
         MAGE_TRY(cached_stream_acquire(dev, &h->stream));
         MAGE_HIP(hipEventCreate(&h->e0)); MAGE_HIP(hipEventCreate(&h->e1));
         match_init_device();
@@ -510,7 +510,7 @@ MAGE_EXPORT mage_status mage_match_bf_batch(mage_matcher* h, int n_pairs, const 
         if (n_pairs > 0 && ((capA > 0 && !descA) || (capB > 0 && !descB) || (cap_out > 0 && !out))) return fail(MAGE_ERR_INVALID_ARGUMENT, "null buffer");
         for (int p = 0; p < n_pairs; ++p)
             if (countsA[p] < 0 || countsA[p] > capA || countsB[p] < 0 || countsB[p] > capB) return fail(MAGE_ERR_INVALID_ARGUMENT, "pair %d: count exceeds capacity", p);
-        MAGE_HIP(hipSetDevice(h->device));
+        MAGE_DEVICE_SCOPE(h->device);
         const size_t np = (size_t)std::max(n_pairs, 1);
         MAGE_TRY(h->d_A.reserve(np * (size_t)capA * 32 + 32)); MAGE_TRY(h->d_B.reserve(np * (size_t)capB * 32 + 32));
         MAGE_TRY(h->d_cA.reserve(np)); MAGE_TRY(h->d_cB.reserve(np));
@@ -571,7 +571,7 @@ MAGE_EXPORT mage_status mage_match_bf_batch_device(mage_matcher* h, int n_pairs,
 {
     return guarded([&]() -> mage_status {
         if (!h || !descA_dev || !descB_dev || !countsA_dev || !countsB_dev || !out_dev || !counts_dev) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
-        MAGE_HIP(hipSetDevice(h->device));
+        MAGE_DEVICE_SCOPE(h->device);
         MAGE_TRY(run_match(h, n_pairs, descA_dev, countsA_dev, capA, descB_dev, countsB_dev, capB, max_dist, min_diff, cap_out));
         MAGE_HIP(hipStreamSynchronize(h->stream));
         if (n_pairs > 0) { float ms = 0; MAGE_HIP(hipEventElapsedTime(&ms, h->e0, h->e1)); h->last_ms = ms; }
@@ -590,7 +590,7 @@ MAGE_EXPORT mage_status mage_match_radius(mage_matcher* h, const mage_keypoint* 
         if (nQ < 0 || nT < 0 || capacity < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative size");
         if (nQ == 0 || nT == 0) return MAGE_OK;
         if (!qk || !qdesc || !tk || !tdesc || (capacity > 0 && !out)) return fail(MAGE_ERR_INVALID_ARGUMENT, "null buffer");
-        MAGE_HIP(hipSetDevice(h->device));
+        MAGE_DEVICE_SCOPE(h->device);
         hipStream_t st = h->stream;
         // one staging buffer: [qk | tk | qpos | qdesc | tdesc | qmask | tmask], 16-byte aligned pieces
         auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -648,7 +648,7 @@ MAGE_EXPORT mage_status mage_match_indexed(mage_matcher* h, const uint8_t* descA
         if ((ncb && !cb) || (nca && !ca)) return fail(MAGE_ERR_INVALID_ARGUMENT, "null candidate list");
         for (size_t k = 0; k < ncb; ++k) if (cb[k] < 0 || cb[k] >= nB) return fail(MAGE_ERR_INVALID_ARGUMENT, "candidate %zu of A is outside B", k);
         for (size_t k = 0; k < nca; ++k) if (ca[k] < 0 || ca[k] >= nA) return fail(MAGE_ERR_INVALID_ARGUMENT, "candidate %zu of B is outside A", k);
-        MAGE_HIP(hipSetDevice(h->device));
+        MAGE_DEVICE_SCOPE(h->device);
         hipStream_t st = h->stream;
         // one staging buffer: [descA | descB | cb_off | ca_off | cb | ca | maskA | maskB], 16-byte aligned pieces
         auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };

@@ -311,3 +311,18 @@ def make_config(name: str, **overrides) -> Scene:
     kw = dict(CONFIGS[name])
     kw.update(overrides)
     return make_scene(**kw)
+
+
+SCENE_MAGIC = b"MAGESCN1"
+
+
+def save_scene(scene: Scene, path: str) -> None:
+    """Writes the float32 problem as one flat little-endian file for the C++ drivers (tools/scene_io.h reads it):
+    magic, u32 n_cams n_pts n_obs 0, then cam_t[3n] cam_R_colmajor[9n] cam_K[4n] fixed[u32 n] points[3m] uv[2k] cam[u32 k]
+    pt[u32 k] info[k].  No tethers."""
+    with open(path, "wb") as f:
+        f.write(SCENE_MAGIC)
+        f.write(np.array([scene.n_cams, scene.n_pts, scene.n_obs, 0], "<u4").tobytes())
+        for a, dt in ((scene.cam_t, "<f4"), (scene.cam_R_colmajor(), "<f4"), (scene.cam_K, "<f4"), (scene.cam_fixed, "<u4"),
+                      (scene.points, "<f4"), (scene.obs_uv, "<f4"), (scene.obs_cam, "<u4"), (scene.obs_pt, "<u4"), (scene.obs_info, "<f4")):
+            f.write(np.ascontiguousarray(a).astype(dt).tobytes())

@@ -7,9 +7,11 @@ of consecutive keyframes; every window is a BundlerLib problem with exactly the 
 keyframe observing one of those points enters as a FIXED camera (the halo).  One outer iteration = every window takes its LM
 iterations with the halo frozen, then the windows exchange their poses -- the one real exchange step of the path:
 
-    every rank writes the poses of the windows it owns into a (n_cams x 12) float32 block (t, R column-major: the BundlerLib
-    surface's own pose format), zeros elsewhere; all-reduce(SUM) over RCCL (384 KB at 8k poses); every window re-seeds its
-    halo cameras from the result (mage_ba_update_camera_poses: no structure rebuild).
+    every rank writes the poses of the windows it owns into the POSE BLOCK, n_cams x 8 float64 (qx qy qz qw tx ty tz 0: the
+    solver's own state rows), zeros elsewhere; all-reduce(SUM) over RCCL (512 KB at 8k poses); every window re-seeds the
+    cameras it does not own from the result.  With the HIP back-end the block lives in HBM and nothing is staged through the
+    host (mage_ba_export_poses_device / mage_ba_import_poses_device, include/mage_ba.h); the C++ form of this driver is
+    include/mage_window.h (mageslam_amd/csrc/window_host.hip) -- both give the same block bit for bit (tests).
 
 This is block-Jacobi on windows: not the monolithic solve, but it has the same fixed point (every copy of a shared point sees
 all of that point's observations), and, because a window's step depends only on its own state and the exchanged block, the
@@ -75,10 +77,15 @@ def owned_windows(n_windows: int, rank: int, world: int) -> list[int]:
 
 class WindowedMap:
     """Drives the windows owned by this rank.  `make_bundler()` returns a BundlerLib-surface object (the HIP back-end in
-    production; tests also pass the CPU oracle to pin the driver's logic); `dist` is torch.distributed or None."""
+    production; tests also pass the CPU oracle to pin the driver's logic); `dist` is torch.distributed or None.
+
+    With the HIP back-end (`device` = HIP ordinal) the pose block is a float64 torch tensor in HBM: windows export / import
+    their rows with kernels ordered on torch's current stream, and the all-reduce runs on the device tensor (RCCL); only a
+    gloo control plane stages the 8 * n_cams doubles through the host.  With any other back-end (the oracle) the block is a
+    numpy array."""
 
     def __init__(self, scene: Scene, n_windows: int, make_bundler, load, *, rank: int = 0, world: int = 1, dist=None,
-                 exchange_device: str = "cpu", overlap: int = 0, threads: int = 1):
+                 exchange_device: str = "cpu", overlap: int = 0, threads: int = 1, device: int | None = None):
         self.scene, self.dist, self.rank, self.world = scene, dist, rank, world
         self.exchange_device = exchange_device
         self.threads = threads
@@ -89,9 +96,17 @@ class WindowedMap:
             b = make_bundler()
             load(b, self.windows[w].scene)
             self.bundlers[w] = b
-        # the exchanged block starts as the map's own poses (float32, BundlerLib surface format)
-        self.pose_t = scene.cam_t.astype(np.float32).copy()
-        self.pose_R = scene.cam_R_colmajor().astype(np.float32).copy()
+        self.on_device = bool(self.mine) and hasattr(self.bundlers[self.mine[0]], "ExportPosesDevice") and device is not None
+        self.block = np.zeros((scene.n_cams, 8))          # host copy of the pose block as of the last exchange
+        if self.on_device:
+            import torch
+            self._torch = torch
+            self.device = torch.device("cuda", device)
+            self.tblock = torch.zeros((scene.n_cams, 8), dtype=torch.float64, device=self.device)
+            for w in self.mine:
+                win = self.windows[w]
+                k = len(win.own)
+                self.bundlers[w].BindPoseExchange(np.arange(k), win.own, np.arange(k, len(win.cams)), win.cams[k:])
         self.exchanged_bytes = 0
 
     def outer_iteration(self, huber: float, max_err_sq: float = 1e30, inner: int = 1) -> float:
@@ -118,32 +133,68 @@ class WindowedMap:
         return err_sum / n_sum if n_sum else float("nan")
 
     def exchange(self) -> None:
-        nc = self.scene.n_cams
-        block = np.zeros((nc, 12), np.float32)
+        if self.on_device:
+            return self._exchange_device()
+        block = np.zeros((self.scene.n_cams, 8))
         for w in self.mine:
             win = self.windows[w]
-            t, R = self.bundlers[w].GetPosesBulk()
             k = len(win.own)
-            block[win.own, :3] = t[:k]; block[win.own, 3:] = R[:k]
-        block += np.float32(0.0)              # -0.0 -> +0.0, which is what a sum with the other ranks' zeros does anyway
+            block[win.own, :7] = self.bundlers[w].poses_f64()[:k]
+        block += 0.0                          # -0.0 -> +0.0, which is what a sum with the other ranks' zeros does anyway
         if self.dist is not None:
             import torch
             buf = torch.from_numpy(block).to(self.exchange_device)
             self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)          # disjoint rows + zeros: the sum is exact
             block = buf.cpu().numpy()
             self.exchanged_bytes += block.nbytes
-        self.pose_t, self.pose_R = block[:, :3].copy(), block[:, 3:].copy()
+        self.block = block
         for w in self.mine:
             win = self.windows[w]
             k = len(win.own)
-            halo = win.cams[k:]                   # everything this window does not own: overlap keyframes and the fixed halo
-            if len(halo):
+            rest = win.cams[k:]                   # everything this window does not own: overlap keyframes and the fixed halo
+            if len(rest):
                 b = self.bundlers[w]
                 lam = b.GetCurrentLambda()
-                b.UpdateCameraPoses(np.arange(k, len(win.cams), dtype=np.uint32), self.pose_t[halo], self.pose_R[halo])
+                b.SetCameraPosesF64(np.arange(k, len(win.cams), dtype=np.uint32), block[rest])
                 if lam > 0:
                     b.SetCurrentLambda(lam)       # the damping carries over, as MappingWorker carries it from one BA to the next
 
+    def _exchange_device(self) -> None:
+        torch = self._torch
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream().cuda_stream
+            self.tblock.zero_()
+            ptr = self.tblock.data_ptr()
+            for w in self.mine:
+                self.bundlers[w].ExportPosesDevice(ptr, st)
+            if self.dist is not None:
+                if self.dist.get_backend() == "nccl":
+                    self.dist.all_reduce(self.tblock, op=self.dist.ReduceOp.SUM)      # RCCL on the device block
+                else:                                                                  # gloo control plane: 8 n doubles through the host
+                    buf = self.tblock.cpu()
+                    self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)
+                    self.tblock.copy_(buf)
+                self.exchanged_bytes += self.tblock.numel() * 8
+            for w in self.mine:
+                b = self.bundlers[w]
+                lam = b.GetCurrentLambda()
+                b.ImportPosesDevice(ptr, st)
+                if lam > 0:
+                    b.SetCurrentLambda(lam)
+            self.block = None                     # fetched on demand
+
+    def pose_block(self) -> np.ndarray:
+        """(n_cams, 8) float64 rows qx qy qz qw tx ty tz 0 of the whole map as of the last exchange."""
+        if self.block is None:
+            self.block = self.tblock.cpu().numpy()
+        return self.block
+
     def poses(self):
-        """(t, R column-major) float32 of the whole map as of the last exchange."""
-        return self.pose_t, self.pose_R
+        """(t, R column-major) float32 of the whole map as of the last exchange (the BundlerLib surface's pose format)."""
+        b = self.pose_block()
+        x, y, z, w = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+        R = np.empty((len(b), 3, 3))
+        R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - z * w); R[:, 0, 2] = 2 * (x * z + y * w)
+        R[:, 1, 0] = 2 * (x * y + z * w); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - x * w)
+        R[:, 2, 0] = 2 * (x * z - y * w); R[:, 2, 1] = 2 * (y * z + x * w); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+        return b[:, 4:7].astype(np.float32), np.ascontiguousarray(R.transpose(0, 2, 1).reshape(len(b), 9)).astype(np.float32)

@@ -431,6 +431,18 @@ BAO_API void bao_update_camera_poses(ba_oracle* b, size_t n, const uint32_t* idx
     b->iteration = 0;
 }
 
+/* Counterpart of the product's device-resident pose exchange (mage_ba_import_poses_device): the float64 state rows
+   (qx qy qz qw tx ty tz pad) are taken as they are -- they are another solver's state, already normalised. */
+BAO_API void bao_set_camera_poses_f64(ba_oracle* b, size_t n, const uint32_t* idx, const double* qt8)
+{
+    for (size_t k = 0; k < n; ++k) {
+        cam_t* c = &b->cams[idx[k]];
+        c->est.r.x = qt8[8 * k]; c->est.r.y = qt8[8 * k + 1]; c->est.r.z = qt8[8 * k + 2]; c->est.r.w = qt8[8 * k + 3];
+        c->est.t[0] = qt8[8 * k + 4]; c->est.t[1] = qt8[8 * k + 5]; c->est.t[2] = qt8[8 * k + 6];
+    }
+    b->iteration = 0;
+}
+
 BAO_API void bao_fix_camera(ba_oracle* b, size_t idx, int fixed) { b->cams[idx].fixed = fixed; /* BundlerLib.cpp:278-281: does not dirty */ }
 
 /* BundlerLib.cpp:283-292 */

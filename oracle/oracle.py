@@ -90,6 +90,7 @@ def _declare(L: C.CDLL) -> None:
     L.bao_set_camera.argtypes = [C.c_void_p, C.c_size_t, _f32p, _f32p, _f32p, C.c_int]
     L.bao_fix_camera.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
     L.bao_update_camera_poses.argtypes = [C.c_void_p, C.c_size_t, np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), _f32p, _f32p]
+    L.bao_set_camera_poses_f64.argtypes = [C.c_void_p, C.c_size_t, np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), _f64p]
     L.bao_set_point.argtypes = [C.c_void_p, C.c_size_t, _f32p]
     L.bao_set_observation.argtypes = [C.c_void_p, C.c_size_t, _f32p, C.c_size_t, C.c_size_t, C.c_float]
     L.bao_alloc_tethers.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
@@ -171,6 +172,11 @@ class OracleBundler:
         idx = np.ascontiguousarray(indices, np.uint32)
         self._L.bao_update_camera_poses(self._h, len(idx), idx, np.ascontiguousarray(positions, np.float32).reshape(-1),
                                         np.ascontiguousarray(orientations_colmajor, np.float32).reshape(-1))
+
+    def SetCameraPosesF64(self, indices, rows8):
+        """Counterpart of mage_ba_import_poses_device: float64 state rows (qx qy qz qw tx ty tz pad) taken as they are."""
+        idx = np.ascontiguousarray(indices, np.uint32)
+        self._L.bao_set_camera_poses_f64(self._h, len(idx), idx, np.ascontiguousarray(rows8, np.float64).reshape(-1))
 
     def GetPosesBulk(self):
         t = np.zeros((self.n_cams, 3), np.float32); R = np.zeros((self.n_cams, 9), np.float32)

@@ -294,3 +294,67 @@ def test_cpp_shim_compiles_links_and_runs(tmp_path):
     assert r.stdout.startswith("mse ") and "outliers" in r.stdout
     mse = float(r.stdout.split()[1])
     assert 0.0 <= mse < 1.0                      # three views of four points, 0.3 px of synthetic offset
+
+
+def _build_tool(tmp_path, name):
+    import os, shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        pytest.skip("no host C++ compiler")
+    exe = str(tmp_path / name)
+    lib_dir = os.path.join(root, "mageslam_amd")
+    subprocess.run([cxx, "-std=c++17", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tools", name + ".cpp"),
+                    "-L" + lib_dir, "-lmageslam_hip", "-Wl,-rpath," + lib_dir, "-o", exe], check=True, capture_output=True, timeout=300)
+    return exe
+
+
+def test_cpp_shim_unchanged_caller_gets_every_outlier(tmp_path):
+    """The reference's caller (BundleAdjust.cpp:316-320) hands StepBundleAdjustment a growing std::vector and never states a
+    capacity.  tools/shim_local_ba.cpp is that caller, written against include/BundlerLib.h with per-element Set* calls and
+    nothing else: config 3 with 2 % gross outliers reports hundreds per step (far more than any fixed scratch buffer), and
+    the lists must equal the oracle's, step by step."""
+    import subprocess
+    s = scene.make_config("local", outlier_frac=0.02)
+    path = str(tmp_path / "local.bin")
+    scene.save_scene(s, path)
+    thrs = [7.25, 6.5, 5.9]
+    exe = _build_tool(tmp_path, "shim_local_ba")
+    r = subprocess.run([exe, path, "0.9"] + [repr(t) for t in thrs], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    o = OracleBundler(False)
+    load_scene_bulk(o, s)
+    want, counts = [], []
+    for t, line in zip(thrs, lines):
+        new = []
+        mse = o.StepBundleAdjustment([0.9], t, new)
+        _, got_mse, got_n = line.split()
+        assert int(got_n) == len(new)
+        assert abs(float(got_mse) - mse) <= 1e-6 * abs(mse)
+        want += new; counts.append(len(new))
+    assert max(counts) > 64                       # the case the 64-entry scratch buffer of round 1 lost
+    got = [int(x) for x in lines[len(thrs)].split()[1:]]
+    assert got == want
+
+
+def test_short_outlier_buffer_loses_nothing():
+    """C ABI: a step whose buffer is too small still removes the observations, reports the full count, and the complete list
+    stays readable through mage_ba_get_outliers until the next step."""
+    import ctypes as C
+    s = scene.make_config("local", outlier_frac=0.02)
+    g, o = BundlerLib(False), OracleBundler(False)
+    _bulk(g, s); load_scene_bulk(o, s)
+    want = []
+    o.StepBundleAdjustment([0.9], 7.25, want)
+    hw = np.array([0.9], np.float32)
+    buf = np.zeros(8, np.uint32)
+    n, mse = C.c_size_t(0), C.c_float(0)
+    from mageslam_amd._lib import check
+    check(g._L.mage_ba_step(g._h, hw, 1, 7.25, buf, buf.size, C.byref(n), C.byref(mse)))
+    assert n.value == len(want) > 64 and list(buf) == want[:8]
+    assert g.GetOutliers() == want
+    again = []
+    o.StepBundleAdjustment([0.9], 6.5, want2 := [])
+    g.StepBundleAdjustment([0.9], 6.5, again)
+    assert again == want2 and g.GetOutliers() == want2

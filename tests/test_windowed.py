@@ -72,16 +72,14 @@ WORKER = textwrap.dedent("""
     info = D.rank_info()
     dist = D.init("gloo", info)
     s, m, mse = _run(4, 6, rank=info.rank, world=info.world, dist=dist, overlap=2)
-    t, R = m.poses()
-    print(json.dumps(dict(rank=info.rank, sha=hashlib.sha256(t.tobytes() + R.tobytes()).hexdigest(), mine=m.mine, bytes=m.exchanged_bytes)))
+    print(json.dumps(dict(rank=info.rank, sha=hashlib.sha256(m.pose_block().tobytes()).hexdigest(), mine=m.mine, bytes=m.exchanged_bytes)))
     dist.barrier(); dist.destroy_process_group()
 """) % (ROOT, os.path.join(ROOT, "tests"))
 
 
 def test_two_ranks_over_gloo_equal_one_rank_bit_for_bit(tmp_path):
     _, m, _ = _run(4, 6, overlap=2)
-    t, R = m.poses()
-    want = hashlib.sha256(t.tobytes() + R.tobytes()).hexdigest()
+    want = hashlib.sha256(m.pose_block().tobytes()).hexdigest()
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
@@ -97,4 +95,4 @@ def test_two_ranks_over_gloo_equal_one_rank_bit_for_bit(tmp_path):
     outs.sort(key=lambda d: d["rank"])
     assert outs[0]["mine"] == [0, 1] and outs[1]["mine"] == [2, 3]
     assert outs[0]["sha"] == want and outs[1]["sha"] == want
-    assert outs[0]["bytes"] == 6 * SCENE["n_cams"] * 12 * 4                        # one 12-float pose block per outer iteration
+    assert outs[0]["bytes"] == 6 * SCENE["n_cams"] * 8 * 8                         # one (n_cams x 8) float64 pose block per outer iteration

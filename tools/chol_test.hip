@@ -26,7 +26,7 @@ int main(int argc, char** argv)
         double *dS, *dS0, *dy, *dy0, *dx, *dok, *dws;
         CK(hipMalloc(&dS, sizeof(double) * n * n)); CK(hipMalloc(&dS0, sizeof(double) * n * n));
         CK(hipMalloc(&dy, sizeof(double) * n)); CK(hipMalloc(&dy0, sizeof(double) * n)); CK(hipMalloc(&dx, sizeof(double) * n));
-        CK(hipMalloc(&dok, 8)); CK(hipMalloc(&dws, sizeof(double) * chol_workspace_doubles(n)));
+        CK(hipMalloc(&dok, 16)); CK(hipMalloc(&dws, sizeof(double) * chol_workspace_doubles(n)));
         CK(hipMemcpy(dS0, A.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
         CK(hipMemcpy(dy0, b.data(), sizeof(double) * n, hipMemcpyHostToDevice));
         hipStream_t st; CK(hipStreamCreate(&st));

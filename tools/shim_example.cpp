@@ -34,7 +34,6 @@ int main()
         bundler.SetRelativeRotationConstraint(0, 1, 2, Quat{ { 0, 0, 0, 1 } }, 10.0f);
         bundler.AllocateRelativeTransformConstraints(0);
         std::vector<unsigned int> outliers;
-        bundler.ReserveOutliers(12);
         const std::vector<float> huber(3, 1.8f);
         const float mse = bundler.StepBundleAdjustment(huber, 7.25f, outliers);
         std::array<float, 3> t; std::array<float, 9> Rout;
