@@ -24,6 +24,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E (/opt/skills/guides/MI355X_MICROARCH.md: ~8 TB/s peak, ~6.3 TB/s achievable)
 F64_MFMA_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: 32 flop/clk/SIMD * 4 SIMD * 256 CU * 2.4 GHz (AMD MI355X spec)
 HUBER = 1.8                   # BundleAdjustSettings.HuberWidth default (MageSettings.h:41-52)
 # "for throughput runs seed lambda so that >= 95 % of iterations take exactly 1 trial" (report trials/iter).  With
@@ -38,28 +39,51 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(workload: str, max_seconds: float = 60.0) -> dict:
-    """Times the CPU oracle (oracle/ba_oracle.c: same algorithm incl. the reference's unblocked pivoted LDLT,
-    one thread like the reference's single-threaded g2o path) on the same scene, for a bounded sample."""
+def _oracle_iterations(args):
+    """One replica of the CPU baseline: n LM iterations of the oracle on the workload's scene (seed offset per replica)."""
+    workload, n_iter, replica = args
+    import time as _t
     from mageslam_amd import scene
     from oracle.oracle import OracleBundler, load_scene_bulk
-    s = scene.make_scene(**WORKLOADS[workload])
+    kw = dict(WORKLOADS[workload])
+    kw["seed"] = kw["seed"] + 0x100 * replica
+    s = scene.make_scene(**kw)
     b = OracleBundler()
     load_scene_bulk(b, s)
     if workload in LAMBDA_SEED:
         b.SetCurrentLambda(LAMBDA_SEED[workload])
     out: list = []
-    n = 0
-    t0 = time.perf_counter()
-    while True:
+    t0 = _t.perf_counter()
+    for _ in range(n_iter):
         b.StepBundleAdjustment([HUBER], 1e30, out)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > 10.0 or n >= 50 or el + el / n > max_seconds:
-            break
-    return {"value": n / el, "unit": "LM iterations/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n} LM iteration(s) of the same {workload} scene from the same initial state, {el:.1f} s, "
-                      f"oracle/ba_oracle.c (gcc -O3), 1 thread"}
+    return _t.perf_counter() - t0
+
+
+def cpu_baseline(workload: str, min_iterations: int = 2, max_seconds: float = 45.0, replicas: int = 8) -> dict:
+    """Times the CPU oracle (oracle/ba_oracle.c: same algorithm incl. the reference's unblocked pivoted LDLT, one thread like the
+    reference's single-threaded g2o path) on the same scene for a bounded sample: at least `min_iterations` LM iterations on
+    one core, then `replicas` independent sub-maps side by side, one per core (the multi-GPU comparison)."""
+    el1 = _oracle_iterations((workload, 1, 0))
+    n = max(min_iterations, min(50, int(10.0 / max(el1, 1e-9))))
+    if n * el1 > max_seconds:
+        n = max(min_iterations, int(max_seconds / el1))
+    el = _oracle_iterations((workload, n, 0))
+    res = {"value": n / el, "unit": "LM iterations/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
+           "sample": f"{n} LM iteration(s) of the same {workload} scene from the same initial state, {el:.1f} s, "
+                     f"oracle/ba_oracle.c (gcc -O3), 1 thread"}
+    try:
+        import multiprocessing as mp
+        r = min(replicas, os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        with mp.get_context("spawn").Pool(r) as pool:
+            pool.map(_oracle_iterations, [(workload, 1, i) for i in range(r)])
+        wall = time.perf_counter() - t0
+        res["replicas"] = {"value": r / wall, "unit": "LM iterations/s", "cores": r,
+                           "sample": f"{r} independent sub-maps, one oracle process per core, 1 LM iteration each, {wall:.1f} s wall "
+                                     f"(scene generation included)"}
+    except Exception as e:  # noqa: a report only
+        res["replicas"] = {"value": None, "sample": f"failed: {e}"}
+    return res
 
 
 def main() -> int:
@@ -148,11 +172,33 @@ def main() -> int:
                           "HIP-event span per factorisation on the solver stream",
                 "bound": "mfma", "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                "traffic_note": "HBM bytes per factorisation, (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/chol_traffic.json)",
+                "traffic_source": "committed profile (profiles/chol_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                  "tools/_bin/chol_test at the same padded order, (2*FETCH_SIZE + WRITE_SIZE)*1024 per factorisation; regenerate with "
+                                  "tools/regen_profiles.sh) -- NOT measured in this run",
                 "flops_per_launch": flops, "ms_per_launch": fac_ms, "launches": int(prof.n_factorizations),
                 "system_order": int(prof.system_order), "padded_order": int(prof.padded_order),
                 "schur_ms_per_launch": prof.schur_ms_total / max(int(prof.schur_launches), 1),
             },
+        }
+        # the HBM-bound stages of the same iterations: linearise (once per iteration), Schur build and back-substitution + trial
+        # evaluation (once per trial); algorithmic bytes from the handle (every array a stage reads or writes counted once)
+        n_lin, n_sch, n_upd = max(int(prof.linearize_launches), 1), max(int(prof.schur_launches), 1), max(int(prof.update_launches), 1)
+        stages = {
+            "linearize": (prof.linearize_ms_total / n_lin, prof.linearize_bytes_each),
+            "schur_build": (prof.schur_ms_total / n_sch, prof.schur_bytes_each),
+            "backsubst_and_trial_error": (prof.update_ms_total / n_upd, prof.update_bytes_each),
+        }
+        tot_ms = sum(ms for ms, _ in stages.values())
+        tot_b = sum(by for _, by in stages.values())
+        line["roofline_hbm"] = {
+            "kernels": "k_error + k_linearize_lm + k_linearize_cam | S zero-fill + k_lm_invert + k_schur_block + k_schur_rhs | k_backsub + k_pose_update + k_error(trial); "
+                       "HIP-event spans on the solver stream, per LM iteration with one trial",
+            "bound": "hbm", "achieved": tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tot_ms > 0 else 0.0,
+            "algorithmic_bytes": tot_b, "ms": tot_ms,
+            "stages": {k: {"ms": ms, "algorithmic_bytes": by, "GB/s": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                           "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0} for k, (ms, by) in stages.items()},
+            "traffic": None,
         }
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0, N = 1 only
             try:

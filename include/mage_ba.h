@@ -188,6 +188,16 @@ typedef struct mage_ba_profile {
     double   schur_ms_total;
     int      system_order;         /* 6 * free cameras */
     int      padded_order;
+    /* the HBM-bound stages of an LM iteration (everything but the dense factorisation), HIP-event spans on the handle's stream,
+     * and their ALGORITHMIC bytes per launch for this problem and this data layout (every array a stage must
+     * read or write counted once, W blocks materialised) */
+    uint64_t linearize_launches;   /* k_error + k_linearize_lm + k_linearize_cam (+ tethers): once per LM iteration */
+    double   linearize_ms_total;
+    double   linearize_bytes_each;
+    double   schur_bytes_each;     /* zero-fill of S + k_lm_invert + k_schur_block + k_schur_rhs: once per LM trial */
+    uint64_t update_launches;      /* k_backsub + k_pose_update + k_error of the trial state: once per LM trial */
+    double   update_ms_total;
+    double   update_bytes_each;
 } mage_ba_profile;
 mage_status mage_ba_enable_profiling(mage_ba* h, int enable);
 mage_status mage_ba_get_profile(const mage_ba* h, mage_ba_profile* out);

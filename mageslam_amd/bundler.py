@@ -29,7 +29,9 @@ class IterStats(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("n_factorizations", C.c_uint64), ("factor_ms_total", C.c_double), ("factor_flops_each", C.c_double),
                 ("schur_launches", C.c_uint64), ("schur_ms_total", C.c_double), ("system_order", C.c_int),
-                ("padded_order", C.c_int)]
+                ("padded_order", C.c_int), ("linearize_launches", C.c_uint64), ("linearize_ms_total", C.c_double),
+                ("linearize_bytes_each", C.c_double), ("schur_bytes_each", C.c_double), ("update_launches", C.c_uint64),
+                ("update_ms_total", C.c_double), ("update_bytes_each", C.c_double)]
 
 
 _declared = False

@@ -283,12 +283,14 @@ struct mage_ba {
     bool profiling = false;
     mage_ba_profile prof{};
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t ev_p[4] = { nullptr, nullptr, nullptr, nullptr };     // profiling only: linearise begin / end, update begin / end
 
     ~mage_ba()
     {
         DeviceScope scope(device);
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto& e : ev_p) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_x) if (e) (void)hipEventDestroy(e);
         if (h_scal) (void)hipHostFree(h_scal);
         cached_stream_release(device, stream);
@@ -753,6 +755,12 @@ mage_status initialize_optimization(mage_ba* h)
     h->L_edge_host.swap(L_edge);
     h->prof.system_order = n; h->prof.padded_order = n_pad;
     h->prof.factor_flops_each = (double)n * n * n / 3.0;      // algorithmic: the system's order, not the padded one
+    {   // algorithmic bytes of the HBM-bound stages for this problem (each array counted once per stage)
+        const double dL = nL, dW = nw, dP = nlm, dC = nfc;
+        h->prof.linearize_bytes_each = dL * (3 * 24 + 16 + 4) + dW * 144 + dP * (80 + 3 * 32) + dC * 336;
+        h->prof.schur_bytes_each = dP * (160 + 48 + 32) + 2 * 144 * dW + 8.0 * (double)ncon + 288.0 * nblk + 4.0 * (double)n_pad * n_pad;
+        h->prof.update_bytes_each = 144 * dW + dP * (32 + 48 + 32 + 64 + 32) + dL * 40;
+    }
     h->iteration = 0;
     h->dirty = false;
     h->soft_dirty = false;
@@ -783,8 +791,11 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
     hipStream_t st = h->stream;
     BaDeviceView& v = h->view;
     mage_ba_iter_stats tr{};
+    if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[0], st));
     ba_launch_error(v, false, huber, st);
     ba_launch_linearize(v, huber, st);
+    if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[1], st));
+    bool lin_timed = false;
     // The chi2 of the current estimate is only needed on the host together with the first trial's (rho); it has its own
     // scalar slot, so after the first iteration of a run no host round trip separates linearisation from the solve.
     // Iteration 0 needs max |diag| on the host to seed lambda.
@@ -808,9 +819,17 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
         if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[2], st));
         ba_launch_update(v, lambda, st);
         ba_launch_error(v, true, huber, st);
+        if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[3], st));
         MAGE_TRY(read_scalars(h));
         if (h->profiling) {
             float ms = 0;
+            if (!lin_timed) {
+                MAGE_HIP(hipEventElapsedTime(&ms, h->ev_p[0], h->ev_p[1]));
+                h->prof.linearize_ms_total += ms; h->prof.linearize_launches++;
+                lin_timed = true;
+            }
+            MAGE_HIP(hipEventElapsedTime(&ms, h->ev[2], h->ev_p[3]));
+            h->prof.update_ms_total += ms; h->prof.update_launches++;
             MAGE_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
             h->prof.schur_ms_total += ms; h->prof.schur_launches++;
             MAGE_HIP(hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
@@ -964,6 +983,7 @@ MAGE_EXPORT mage_status mage_ba_create(const mage_ba_params* params, mage_ba** o
         MAGE_DEVICE_SCOPE(dev);
         MAGE_TRY(cached_stream_acquire(dev, &h->stream));
         for (auto& e : h->ev) MAGE_HIP(hipEventCreate(&e));
+        for (auto& e : h->ev_p) MAGE_HIP(hipEventCreate(&e));
         for (auto& e : h->ev_x) MAGE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         chol_init_device();
         *out = h.release();
@@ -1442,6 +1462,7 @@ MAGE_EXPORT mage_status mage_ba_enable_profiling(mage_ba* h, int enable)
     if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
     h->profiling = enable != 0;
     h->prof.n_factorizations = 0; h->prof.factor_ms_total = 0; h->prof.schur_launches = 0; h->prof.schur_ms_total = 0;
+    h->prof.linearize_launches = 0; h->prof.linearize_ms_total = 0; h->prof.update_launches = 0; h->prof.update_ms_total = 0;
     return MAGE_OK;
 }
 
