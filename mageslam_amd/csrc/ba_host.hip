@@ -725,7 +725,8 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(h->d_partial.reserve(std::max<size_t>(3 * 1024, (size_t)nb_l + nb_c) + 16));
     MAGE_TRY(h->d_scal.reserve(SC_COUNT));
     MAGE_TRY(h->d_Linv.reserve(chol_workspace_doubles(n_pad)));
-    MAGE_TRY(h->d_queue.reserve(chol_sync_ints(n_pad)));
+    MAGE_TRY(h->d_queue.reserve(chol_sync_ints(n_pad) + 1));
+    MAGE_HIP(hipMemsetAsync(h->d_queue.p, 0, (chol_sync_ints(n_pad) + 1) * sizeof(int), st));       // recycled memory arrives dirty
     MAGE_TRY(h->d_flagL.reserve((size_t)nL + 1));
     MAGE_TRY(h->d_L_active.reserve((size_t)nL + 1));
     MAGE_HIP(hipMemsetAsync(h->d_L_active.p, 1, (size_t)nL + 1, st));
@@ -791,16 +792,21 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
     hipStream_t st = h->stream;
     BaDeviceView& v = h->view;
     mage_ba_iter_stats tr{};
+    const bool small = ba_small_applies(v);
+    int* counter = h->d_queue.p + chol_sync_ints(v.n_pad);       // one int behind the factorisation's counters, zero between launches
     if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[0], st));
-    ba_launch_error(v, false, huber, st);
-    ba_launch_linearize(v, huber, st);
+    if (small) ba_small_linearize(v, huber, h->iteration == 0, counter, st);
+    else {
+        ba_launch_error(v, false, huber, st);
+        ba_launch_linearize(v, huber, st);
+    }
     if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[1], st));
     bool lin_timed = false;
     // The chi2 of the current estimate is only needed on the host together with the first trial's (rho); it has its own
     // scalar slot, so after the first iteration of a run no host round trip separates linearisation from the solve.
     // Iteration 0 needs max |diag| on the host to seed lambda.
     if (h->iteration == 0) {
-        ba_launch_maxdiag(v, st);
+        if (!small) ba_launch_maxdiag(v, st);
         MAGE_TRY(read_scalars(h));
         h->lambda = h->user_lambda > 0 ? h->user_lambda : 1e-5 * h->h_scal[SC_MAXDIAG];
         h->ni = 2;
@@ -813,12 +819,17 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
     do {
         const double lambda = h->lambda;
         if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[0], st));
-        ba_launch_schur(v, lambda, st);
-        if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[1], st));
-        chol_factor_solve(v.S, v.y, v.xc, v.n_pad, ws, v.scal + SC_CHOL_OK, st);
-        if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[2], st));
-        ba_launch_update(v, lambda, st);
-        ba_launch_error(v, true, huber, st);
+        if (small) {
+            ba_small_solve_trial(v, lambda, huber, counter, st);
+            if (h->profiling) { MAGE_HIP(hipEventRecord(h->ev[1], st)); MAGE_HIP(hipEventRecord(h->ev[2], st)); }
+        } else {
+            ba_launch_schur(v, lambda, st);
+            if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[1], st));
+            chol_factor_solve(v.S, v.y, v.xc, v.n_pad, ws, v.scal + SC_CHOL_OK, st);
+            if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[2], st));
+            ba_launch_update(v, lambda, st);
+            ba_launch_error(v, true, huber, st);
+        }
         if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[3], st));
         MAGE_TRY(read_scalars(h));
         if (h->profiling) {
@@ -986,6 +997,7 @@ MAGE_EXPORT mage_status mage_ba_create(const mage_ba_params* params, mage_ba** o
         for (auto& e : h->ev_p) MAGE_HIP(hipEventCreate(&e));
         for (auto& e : h->ev_x) MAGE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         chol_init_device();
+        ba_small_init_device();
         *out = h.release();
         return MAGE_OK;
     });
@@ -1264,7 +1276,8 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
         // post-pass over the active observations of the last initialisation
         const BaDeviceView& v = h->view;
         if (v.n_L == 0 || h->L_edge_host.empty()) return MAGE_OK;     // count == 0 -> NaN
-        ba_launch_classify(v, (double)max_err_sq, h->d_flagL.p, h->stream);
+        if (ba_small_applies(v)) ba_small_classify(v, (double)max_err_sq, h->d_flagL.p, h->d_queue.p + chol_sync_ints(v.n_pad), h->stream);
+        else ba_launch_classify(v, (double)max_err_sq, h->d_flagL.p, h->stream);
         MAGE_TRY(read_scalars(h));
         const double err_sum = h->h_scal[SC_ERRSUM], cnt = h->h_scal[SC_ERRCNT];
         const size_t nout = (size_t)h->h_scal[SC_NOUT];

@@ -85,6 +85,14 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st);     
 void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st);                         // xl, trial state, scal[SC_SCALE]
 void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flag_by_edge, hipStream_t st); // scal[SC_ERRSUM..SC_NOUT]
 
+// Small problems (reduced camera system of order <= 128, no tethers): one LM trial in five launches instead of ~22
+// (ba_kernels.hip, "SMALL PROBLEMS").  `counter` is one zero-initialised device int owned by the handle (the kernels leave it 0).
+bool ba_small_applies(const BaDeviceView& v);
+void ba_small_init_device();                                                                          // once per device: LDS opt-in
+void ba_small_linearize(const BaDeviceView& v, double huber_delta, bool want_maxdiag, int* counter, hipStream_t st);   // U,bc,V,bp,W, S/y zeroed, scal[SC_CHI] (+ SC_MAXDIAG)
+void ba_small_solve_trial(const BaDeviceView& v, double lambda, double huber_delta, int* counter, hipStream_t st);    // S, y, xc, trial state, SC_SCALE, SC_CHI_TRIAL, SC_CHOL_OK/STALL
+void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flag_by_edge, int* counter, hipStream_t st);
+
 // Pose exchange of a window-sharded map (mage_ba_export_poses_device / mage_ba_import_poses_device).  A block row is 8 doubles
 // (qx qy qz qw tx ty tz 0).  export: block[row[k]] = pose[cam[k]] (+0.0, so that -0.0 leaves as +0.0 -- what a SUM with the
 // zero rows of the other ranks would make of it anyway); import: pose0[cam[k]] = pose1[cam[k]] = block[row ? row[k] : k].

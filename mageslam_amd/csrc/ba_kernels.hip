@@ -19,6 +19,7 @@
 // the property the reference checks with mira::determinator (BundleAdjust.cpp:43-44,250,320,389).
 // HBM-bound integer/f64 streaming work: no MFMA here (the dense factorisation is in chol_kernels.hip).
 #include <algorithm>
+#include <cstdlib>
 
 #include "ba_kernels.h"
 
@@ -328,21 +329,32 @@ __global__ __launch_bounds__(256) void k_linearize_cam(BaDeviceView v, double de
     }
 }
 
-// max |diagonal| over pose and landmark blocks (computeLambdaInit, A.4)
+// max |diagonal| over pose and landmark blocks (computeLambdaInit, A.4): grid-stride partial maxima, then one block folds them
+// (a single block over 100 k landmarks took 345 us -- and lambda is re-seeded after every outlier removal)
 __global__ __launch_bounds__(256) void k_maxdiag(BaDeviceView v)
 {
     __shared__ double sm[4];
     double m = 0;
     const int nU = v.n_fc * 6, nV = v.points_free ? v.n_lm * 3 : 0;
-    for (int i = threadIdx.x; i < nU; i += 256) m = fmax(m, fabs(v.U[(size_t)(i / 6) * 36 + (i % 6) * 7]));
-    for (int i = threadIdx.x; i < nV; i += 256) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nU; i += gridDim.x * 256) m = fmax(m, fabs(v.U[(size_t)(i / 6) * 36 + (i % 6) * 7]));
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nV; i += gridDim.x * 256) {
         const int l = i / 3, d = i % 3;
         m = fmax(m, fabs(v.V[(size_t)l * 6 + (d == 0 ? 0 : d == 1 ? 3 : 5)]));
     }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) v.scal[SC_MAXDIAG] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+    if (threadIdx.x == 0) v.partial[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+__global__ __launch_bounds__(256) void k_reduce_max(const double* __restrict__ in, int n, double* __restrict__ out)
+{
+    __shared__ double sm[4];
+    double m = 0;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, in[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -592,59 +604,65 @@ __device__ __forceinline__ void R_to_q(const double m[9], double c[4])
     }
 }
 
-// pose <- exp(x) * pose for every free camera; one thread per camera; scale partials
+// pose <- exp(x) * pose for one free camera (VertexSE3Expmap::oplusImpl, appendix A.1); returns its share of the scale term
+__device__ __forceinline__ double pose_update_one(const BaDeviceView& v, double lambda, int hc)
+{
+    double sc = 0;
+    const int cam = v.hc2cam[hc];
+    const double* u = v.xc + (size_t)hc * 6;
+    const double* b = v.bc + (size_t)hc * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sc += u[k] * (lambda * u[k] + b[k]);
+    const double w0 = u[0], w1 = u[1], w2 = u[2];
+    const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+    const double Om[9] = { 0, -w2, w1, w2, 0, -w0, -w1, w0, 0 };
+    double Om2[9], R[9], Vm[9];
+    m3mul(Om, Om, Om2);
+    double a, bb, d;
+    if (theta < 0.00001) { a = 1.0; bb = 0.5; d = 1.0 / 6.0; }
+    else {
+        const double s = sin(theta), c = cos(theta);
+        a = s / theta; bb = (1 - c) / (theta * theta); d = (theta - s) / (theta * theta * theta);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const double I = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
+        R[k] = I + a * Om[k] + bb * Om2[k];
+        Vm[k] = I + bb * Om[k] + d * Om2[k];
+    }
+    double q[4];
+    R_to_q(R, q);
+    double ex = Vm[0] * u[3] + Vm[1] * u[4] + Vm[2] * u[5];
+    double ey = Vm[3] * u[3] + Vm[4] * u[4] + Vm[5] * u[5];
+    double ez = Vm[6] * u[3] + Vm[7] * u[4] + Vm[8] * u[5];
+    // SE3Quat(q, t) ctor normalises
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+    PoseD P = load_pose(v.pose_cur, cam);
+    // result = E * P : t = E.t + E.r * P.t ; r = E.r * P.r ; normalise
+    double rx, ry, rz;
+    q_rot(q[0], q[1], q[2], q[3], P.tx, P.ty, P.tz, rx, ry, rz);
+    PoseD O;
+    O.tx = ex + rx; O.ty = ey + ry; O.tz = ez + rz;
+    O.qw = q[3] * P.qw - q[0] * P.qx - q[1] * P.qy - q[2] * P.qz;
+    O.qx = q[3] * P.qx + q[0] * P.qw + q[1] * P.qz - q[2] * P.qy;
+    O.qy = q[3] * P.qy + q[1] * P.qw + q[2] * P.qx - q[0] * P.qz;
+    O.qz = q[3] * P.qz + q[2] * P.qw + q[0] * P.qy - q[1] * P.qx;
+    if (O.qw < 0) { O.qx = -O.qx; O.qy = -O.qy; O.qz = -O.qz; O.qw = -O.qw; }
+    n = sqrt(O.qx * O.qx + O.qy * O.qy + O.qz * O.qz + O.qw * O.qw);
+    O.qx /= n; O.qy /= n; O.qz /= n; O.qw /= n;
+    store_pose(v.pose_trial, cam, O);
+    return sc;
+}
+
+// every free camera; one thread per camera; scale partials
 __global__ __launch_bounds__(256) void k_pose_update(BaDeviceView v, double lambda, int part_off)
 {
     __shared__ double sm[4];
     const int hc = blockIdx.x * 256 + threadIdx.x;
     double sc = 0;
-    if (hc < v.n_fc) {
-        const int cam = v.hc2cam[hc];
-        const double* u = v.xc + (size_t)hc * 6;
-        const double* b = v.bc + (size_t)hc * 6;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) sc += u[k] * (lambda * u[k] + b[k]);
-        const double w0 = u[0], w1 = u[1], w2 = u[2];
-        const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
-        const double Om[9] = { 0, -w2, w1, w2, 0, -w0, -w1, w0, 0 };
-        double Om2[9], R[9], Vm[9];
-        m3mul(Om, Om, Om2);
-        double a, bb, d;
-        if (theta < 0.00001) { a = 1.0; bb = 0.5; d = 1.0 / 6.0; }
-        else {
-            const double s = sin(theta), c = cos(theta);
-            a = s / theta; bb = (1 - c) / (theta * theta); d = (theta - s) / (theta * theta * theta);
-        }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const double I = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
-            R[k] = I + a * Om[k] + bb * Om2[k];
-            Vm[k] = I + bb * Om[k] + d * Om2[k];
-        }
-        double q[4];
-        R_to_q(R, q);
-        double ex = Vm[0] * u[3] + Vm[1] * u[4] + Vm[2] * u[5];
-        double ey = Vm[3] * u[3] + Vm[4] * u[4] + Vm[5] * u[5];
-        double ez = Vm[6] * u[3] + Vm[7] * u[4] + Vm[8] * u[5];
-        // SE3Quat(q, t) ctor normalises
-        if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
-        double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-        q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
-        PoseD P = load_pose(v.pose_cur, cam);
-        // result = E * P : t = E.t + E.r * P.t ; r = E.r * P.r ; normalise
-        double rx, ry, rz;
-        q_rot(q[0], q[1], q[2], q[3], P.tx, P.ty, P.tz, rx, ry, rz);
-        PoseD O;
-        O.tx = ex + rx; O.ty = ey + ry; O.tz = ez + rz;
-        O.qw = q[3] * P.qw - q[0] * P.qx - q[1] * P.qy - q[2] * P.qz;
-        O.qx = q[3] * P.qx + q[0] * P.qw + q[1] * P.qz - q[2] * P.qy;
-        O.qy = q[3] * P.qy + q[1] * P.qw + q[2] * P.qx - q[0] * P.qz;
-        O.qz = q[3] * P.qz + q[2] * P.qw + q[0] * P.qy - q[1] * P.qx;
-        if (O.qw < 0) { O.qx = -O.qx; O.qy = -O.qy; O.qz = -O.qz; O.qw = -O.qw; }
-        n = sqrt(O.qx * O.qx + O.qy * O.qy + O.qz * O.qz + O.qw * O.qw);
-        O.qx /= n; O.qy /= n; O.qz /= n; O.qw /= n;
-        store_pose(v.pose_trial, cam, O);
-    }
+    if (hc < v.n_fc) sc = pose_update_one(v, lambda, hc);
     double r = block_sum<4>(sc, sm);
     if (threadIdx.x == 0) v.partial[part_off + blockIdx.x] = r;
 }
@@ -701,6 +719,456 @@ __global__ __launch_bounds__(256) void k_import_poses(double* __restrict__ pose0
     pose1[(size_t)cam[k] * 8 + a] = val;
 }
 
+// =================================================================================================
+// SMALL PROBLEMS: the reduced camera system fits one 128x128 tile (local bundle adjustment: ~15 free keyframes; map
+// initialisation; the tracker's pose-only refinement).  There the step is launch-latency, not bandwidth: the large-problem
+// path spends ~22 launches and 4-5 us each on a 78x78 system.  Here one LM trial is FIVE launches,
+//     k_small_linearize   landmark side + camera side + zero-fill of S, y (roles by block range); the LAST block to finish
+//                         adds the chi2 partials in block order and (first iteration) takes max |diag|
+//     k_small_schur       all blocks of S + the reduced rhs ((V + lambda I)^-1 formed where it is used, no D^-1 array)
+//     k_small_solve       dense Cholesky + both substitutions of the n x n system (n = its true order) in LDS, one workgroup
+//     k_small_update      back-substitution + pose update; last block adds the scale partials
+//     k_small_error       residuals of the trial state; last block adds the chi2 partials
+// plus one scalar read-back.  Same arithmetic per element as the large-problem kernels (the device functions are shared);
+// sums keep a fixed order (partials in block order), so results stay bit-reproducible run to run.
+// Callers: Tasks/MappingWorker.cpp:330-371 (local BA), Tracking/TrackLocalMap.cpp:421-501, Tracking/PoseEstimator.cpp:168-207.
+// =================================================================================================
+// Every block calls this once, after writing its partial(s): true in the block that arrives last (it then sees all partials).
+__device__ __forceinline__ bool last_block_arrives(int* __restrict__ counter, int n_blocks)
+{
+    __shared__ int is_last;
+    __threadfence();                                  // this block's partials: visible device-wide before the count
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = prev == n_blocks - 1;
+        if (is_last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+    }
+    __syncthreads();
+    if (is_last) __threadfence();
+    return is_last != 0;
+}
+// sum of partial[0..n) in a fixed order by one block; result to *out (all 256 threads call)
+__device__ __forceinline__ void fold_partials(const double* __restrict__ partial, int n, double* __restrict__ out, double* sm4)
+{
+    double acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    const double r = block_sum<4>(acc, sm4);
+    if (threadIdx.x == 0) *out = r;
+}
+
+// (V_l + lambda I)^-1 in the cofactor form of k_lm_invert (same operations, same order)
+__device__ __forceinline__ void lm_dinv(const BaDeviceView& v, int l, double lambda, double D[6])
+{
+    const double* Vl = v.V + (size_t)l * 6;
+    const double m00 = Vl[0] + lambda, m01 = Vl[1], m02 = Vl[2], m11 = Vl[3] + lambda, m12 = Vl[4], m22 = Vl[5] + lambda;
+    const double c00 = m11 * m22 - m12 * m12;
+    const double c10 = m12 * m02 - m22 * m01;
+    const double c20 = m01 * m12 - m02 * m11;
+    const double det = c00 * m00 + c10 * m01 + c20 * m02;
+    const double id = 1.0 / det;
+    D[0] = c00 * id; D[1] = c10 * id; D[2] = c20 * id;
+    D[3] = (m22 * m00 - m02 * m02) * id;
+    D[4] = (m02 * m01 - m00 * m12) * id;
+    D[5] = (m00 * m11 - m01 * m01) * id;
+}
+
+__global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double delta, int nbL, int want_maxdiag, int* __restrict__ counter)
+{
+    __shared__ double sm[4];
+    __shared__ double part[4][28];
+    const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_blocks = gridDim.x;
+    double chi = 0;                                    // this thread's share of the robust chi2 (one role per problem kind owns it)
+    if (bid < nbL) {
+        // ---- landmark role: k_linearize_lm, plus the residuals / chi2 k_error would have produced
+        const int l = bid * 256 + tid;
+        if (l < v.n_lm) {
+            const int pt = v.lm_pt[l];
+            const double X = v.pt_cur[(size_t)pt * 4], Y = v.pt_cur[(size_t)pt * 4 + 1], Z = v.pt_cur[(size_t)pt * 4 + 2];
+            double V[6] = { 0, 0, 0, 0, 0, 0 }, bp[3] = { 0, 0, 0 };
+            double Wacc[18];
+#pragma unroll
+            for (int k = 0; k < 18; ++k) Wacc[k] = 0;
+            const int beg = v.lm_ptr[l], end = v.lm_ptr[l + 1];
+            int cur_slot = -1;
+            for (int i = beg; i < end; ++i) {
+                const int slot = v.L_slot[i];
+                if (slot != cur_slot) {
+                    if (cur_slot >= 0) {
+#pragma unroll
+                        for (int k = 0; k < 18; ++k) { v.W[(size_t)cur_slot * 18 + k] = Wacc[k]; Wacc[k] = 0; }
+                    }
+                    cur_slot = slot;
+                }
+                if (!v.L_active[i]) continue;
+                const int cam = v.L_cam[i];
+                PoseD P = load_pose(v.pose_cur, cam);
+                EdgeGeom g = edge_geom(P, v.camK, cam, X, Y, Z, v.L_uv[i]);
+                *reinterpret_cast<double2*>(v.errL + (size_t)i * 2) = make_double2(g.e0, g.e1);
+                const double f = v.camK[cam * 4];
+                const double info = (double)v.L_info[i];
+                double rho0, rho1;
+                huber(info * (g.e0 * g.e0 + g.e1 * g.e1), delta, rho0, rho1);
+                chi += rho0;
+                const double w = info * rho1;
+                const double r0 = -info * g.e0 * rho1, r1 = -info * g.e1 * rho1;
+                double R[9], Jp[6];
+                q_to_R(P.qx, P.qy, P.qz, P.qw, R);
+                jac_point(g, f, R, Jp);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) bp[a] += Jp[a] * r0 + Jp[3 + a] * r1;
+                V[0] += Jp[0] * w * Jp[0] + Jp[3] * w * Jp[3];
+                V[1] += Jp[0] * w * Jp[1] + Jp[3] * w * Jp[4];
+                V[2] += Jp[0] * w * Jp[2] + Jp[3] * w * Jp[5];
+                V[3] += Jp[1] * w * Jp[1] + Jp[4] * w * Jp[4];
+                V[4] += Jp[1] * w * Jp[2] + Jp[4] * w * Jp[5];
+                V[5] += Jp[2] * w * Jp[2] + Jp[5] * w * Jp[5];
+                if (slot >= 0) {
+                    double Jc[12];
+                    jac_pose(g, f, Jc);
+#pragma unroll
+                    for (int a = 0; a < 6; ++a)
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) Wacc[a * 3 + b] += Jc[a] * w * Jp[b] + Jc[6 + a] * w * Jp[3 + b];
+                }
+            }
+            if (cur_slot >= 0) {
+#pragma unroll
+                for (int k = 0; k < 18; ++k) v.W[(size_t)cur_slot * 18 + k] = Wacc[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v.V[(size_t)l * 6 + k] = V[k];
+            v.bp[(size_t)l * 4 + 0] = bp[0]; v.bp[(size_t)l * 4 + 1] = bp[1]; v.bp[(size_t)l * 4 + 2] = bp[2]; v.bp[(size_t)l * 4 + 3] = 0;
+        }
+    } else if (bid < nbL + v.n_fc) {
+        // ---- camera role: k_linearize_cam<true> (one workgroup per camera); owns the chi2 when the points are fixed
+        const int hc = bid - nbL;
+        const int cam = v.hc2cam[hc];
+        PoseD P = load_pose(v.pose_cur, cam);
+        const double f = v.camK[cam * 4];
+        double A[21], b[6];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) A[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) b[k] = 0;
+        for (int idx = v.camE_ptr[hc] + wave * WAVE + lane; idx < v.camE_ptr[hc + 1]; idx += 4 * WAVE) {
+            const int i = v.camE[idx];
+            if (!v.L_active[i]) continue;
+            const int pt = v.L_pt[i];
+            const double2 xy = *reinterpret_cast<const double2*>(v.pt_cur + (size_t)pt * 4);
+            const double Z = v.pt_cur[(size_t)pt * 4 + 2];
+            EdgeGeom g = edge_geom(P, v.camK, cam, xy.x, xy.y, Z, v.L_uv[i]);
+            const double info = (double)v.L_info[i];
+            double rho0, rho1;
+            huber(info * (g.e0 * g.e0 + g.e1 * g.e1), delta, rho0, rho1);
+            if (!v.points_free) { chi += rho0; *reinterpret_cast<double2*>(v.errL + (size_t)i * 2) = make_double2(g.e0, g.e1); }
+            const double w = info * rho1;
+            const double r0 = -info * g.e0 * rho1, r1 = -info * g.e1 * rho1;
+            double Jc[12];
+            jac_pose(g, f, Jc);
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                b[a] += Jc[a] * r0 + Jc[6 + a] * r1;
+#pragma unroll
+                for (int c = 0; c <= a; ++c) A[k++] += Jc[a] * w * Jc[c] + Jc[6 + a] * w * Jc[6 + c];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 21; ++k) A[k] = wave_sum(A[k]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) b[k] = wave_sum(b[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 21; ++k) part[wave][k] = A[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) part[wave][21 + k] = b[k];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int c = 0; c <= a; ++c) {
+                    const double val = ((part[0][k] + part[1][k]) + part[2][k]) + part[3][k];
+                    v.U[(size_t)hc * 36 + a * 6 + c] = val; v.U[(size_t)hc * 36 + c * 6 + a] = val; ++k;
+                }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) v.bc[(size_t)hc * 6 + a] = ((part[0][21 + a] + part[1][21 + a]) + part[2][21 + a]) + part[3][21 + a];
+        }
+    } else {
+        // ---- zero role: S (n_pad x n_pad), y, identity on the padded tail of the diagonal
+        const int n = v.n_fc * 6, np = v.n_pad;
+        for (int i = tid; i < np * np; i += 256) v.S[i] = 0.0;
+        for (int i = tid; i < np; i += 256) v.y[i] = 0.0;
+        __syncthreads();
+        for (int i = n + tid; i < np; i += 256) v.S[(size_t)i * np + i] = 1.0;
+    }
+    const double r = block_sum<4>(chi, sm);
+    if (tid == 0) v.partial[bid] = r;
+    if (!last_block_arrives(counter, n_blocks)) return;
+    fold_partials(v.partial, n_blocks, v.scal + SC_CHI, sm);
+    if (want_maxdiag) {
+        double m = 0;
+        const int nU = v.n_fc * 6, nV = v.points_free ? v.n_lm * 3 : 0;
+        for (int i = tid; i < nU; i += 256) m = fmax(m, fabs(v.U[(size_t)(i / 6) * 36 + (i % 6) * 7]));
+        for (int i = tid; i < nV; i += 256) {
+            const int l = i / 3, d = i % 3;
+            m = fmax(m, fabs(v.V[(size_t)l * 6 + (d == 0 ? 0 : d == 1 ? 3 : 5)]));
+        }
+        m = wave_max(m);
+        __syncthreads();
+        if (lane == 0) sm[wave] = m;
+        __syncthreads();
+        if (tid == 0) v.scal[SC_MAXDIAG] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+    }
+}
+
+// blocks [0, n_blk): one workgroup per 6x6 block of S (k_schur_block<true> with D^-1 formed in place);
+// blocks [n_blk, n_blk + n_fc): the reduced rhs of one camera (k_schur_rhs<true>, D^-1 b_p formed in place)
+__global__ __launch_bounds__(256) void k_small_schur(BaDeviceView v, double lambda)
+{
+    __shared__ double red[4][64 * 37];
+    __shared__ double part[4][36];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int first = wave * WAVE + lane, stride = 4 * WAVE;
+    if ((int)blockIdx.x < v.n_blk) {
+        const int b = blockIdx.x;
+        double acc[36];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) acc[k] = 0;
+        for (int c = v.blk_ptr[b] + first; c < v.blk_ptr[b + 1]; c += stride) {
+            const int2 sab = v.con[c];
+            const double2* Wa2 = reinterpret_cast<const double2*>(v.W + (size_t)sab.x * 18);
+            const double2* Wb2 = reinterpret_cast<const double2*>(v.W + (size_t)sab.y * 18);
+            double D[6];
+            lm_dinv(v, v.w_lm[sab.x], lambda, D);
+            const double d00 = D[0], d01 = D[1], d02 = D[2], d11 = D[3], d12 = D[4], d22 = D[5];
+            double wa[18], wb[18];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { const double2 t = Wa2[k]; wa[2 * k] = t.x; wa[2 * k + 1] = t.y; }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { const double2 t = Wb2[k]; wb[2 * k] = t.x; wb[2 * k + 1] = t.y; }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const double a0 = wa[r * 3], a1 = wa[r * 3 + 1], a2 = wa[r * 3 + 2];
+                const double t0 = a0 * d00 + a1 * d01 + a2 * d02;
+                const double t1 = a0 * d01 + a1 * d11 + a2 * d12;
+                const double t2 = a0 * d02 + a1 * d12 + a2 * d22;
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) acc[r * 6 + cc] += t0 * wb[cc * 3] + t1 * wb[cc * 3 + 1] + t2 * wb[cc * 3 + 2];
+            }
+        }
+        double* R = red[wave];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) R[lane * 37 + k] = acc[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int2 ij = v.blk_ij[b];
+        double val = 0;
+        if (lane < 36) {
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int j = 0; j < 64; j += 4) {
+                s0 += R[(j + 0) * 37 + lane]; s1 += R[(j + 1) * 37 + lane]; s2 += R[(j + 2) * 37 + lane]; s3 += R[(j + 3) * 37 + lane];
+            }
+            val = (s0 + s1) + (s2 + s3);
+            part[wave][lane] = val;
+        }
+        __syncthreads();
+        if (wave == 0 && lane < 36) {
+            val = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+            const int r = lane / 6, c = lane % 6;
+            if (ij.x == ij.y) {
+                const double u = v.U[(size_t)ij.x * 36 + r * 6 + c] + (r == c ? lambda : 0.0);
+                v.S[(size_t)(ij.x * 6 + c) * v.n_pad + (ij.x * 6 + r)] = u - val;
+            } else {
+                v.S[(size_t)(ij.x * 6 + r) * v.n_pad + (ij.y * 6 + c)] = -val;
+            }
+        }
+        return;
+    }
+    const int hc = (int)blockIdx.x - v.n_blk;
+    if (hc >= v.n_fc) return;
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int idx = v.camS_ptr[hc] + first; idx < v.camS_ptr[hc + 1]; idx += stride) {
+        const int s = v.camS[idx];
+        const double* W = v.W + (size_t)s * 18;
+        const int l = v.w_lm[s];
+        double D[6];
+        lm_dinv(v, l, lambda, D);
+        const double b0 = v.bp[(size_t)l * 4], b1 = v.bp[(size_t)l * 4 + 1], b2 = v.bp[(size_t)l * 4 + 2];
+        const double d0 = D[0] * b0 + D[1] * b1 + D[2] * b2;
+        const double d1 = D[1] * b0 + D[3] * b1 + D[4] * b2;
+        const double d2 = D[2] * b0 + D[4] * b1 + D[5] * b2;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[r] += W[r * 3] * d0 + W[r * 3 + 1] * d1 + W[r * 3 + 2] * d2;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc[r] = wave_sum(acc[r]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) part[wave][r] = acc[r];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int r = threadIdx.x;
+        const double a = ((part[0][r] + part[1][r]) + part[2][r]) + part[3][r];
+        v.y[hc * 6 + r] = v.bc[(size_t)hc * 6 + r] - a;
+    }
+}
+
+// Dense solve of the n x n reduced camera system (n <= 128, its TRUE order: no padding), one workgroup, everything in LDS:
+// right-looking Cholesky by columns (the column's scaling and the rank-1 update of the trailing block between two barriers),
+// then the two substitutions.  Replaces g2o::LinearSolverDense (Eigen LDLT) for small systems, as chol_kernels.hip does for
+// large ones; a non-positive pivot clears *ok.
+__global__ __launch_bounds__(256) void k_small_solve(const double* __restrict__ S, const double* __restrict__ y, double* __restrict__ x, int n, int ld, double* __restrict__ ok, double* __restrict__ stall)
+{
+    extern __shared__ double smem[];
+    double* A = smem;                 // n x (n + 1), column-major with an odd pitch
+    double* rhs = smem + (size_t)n * (n + 1);
+    __shared__ int bad;
+    const int tid = threadIdx.x, P = n + 1;
+    if (tid == 0) bad = 0;
+    for (int e = tid; e < n * n; e += 256) { const int c = e / n, r = e % n; A[c * P + r] = r >= c ? S[(size_t)c * ld + r] : 0.0; }
+    for (int i = tid; i < n; i += 256) rhs[i] = y[i];
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        const double d = A[j * P + j];
+        if (!(d > 0.0)) { if (tid == 0) bad = 1; }
+        const double inv = 1.0 / sqrt(d);
+        __syncthreads();
+        // scale column j (rows j..n-1)
+        for (int r = j + tid; r < n; r += 256) A[j * P + r] *= inv;
+        __syncthreads();
+        // trailing update: A[r][c] -= L[r][j] L[c][j] for j < c <= r
+        const int m = n - j - 1;
+        for (int e = tid; e < m * m; e += 256) {
+            const int c = j + 1 + e / m, r = j + 1 + e % m;
+            if (r >= c) A[c * P + r] = __builtin_fma(-A[j * P + r], A[j * P + c], A[c * P + r]);
+        }
+        __syncthreads();
+    }
+    // forward substitution L z = rhs, then backward L^T x = z; one column per step, rows in parallel
+    for (int j = 0; j < n; ++j) {
+        if (tid == 0) rhs[j] /= A[j * P + j];
+        __syncthreads();
+        const double zj = rhs[j];
+        for (int r = j + 1 + tid; r < n; r += 256) rhs[r] = __builtin_fma(-A[j * P + r], zj, rhs[r]);
+        __syncthreads();
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        if (tid == 0) rhs[j] /= A[j * P + j];
+        __syncthreads();
+        const double xj = rhs[j];
+        for (int r = tid; r < j; r += 256) rhs[r] = __builtin_fma(-A[r * P + j], xj, rhs[r]);
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 256) x[i] = rhs[i];
+    if (tid == 0) { *ok = bad ? 0.0 : 1.0; *stall = 0.0; }
+}
+
+// blocks [0, nbL): k_backsub with D^-1 formed in place; blocks [nbL, nbL + nbC): k_pose_update; last block adds the scale partials
+__global__ __launch_bounds__(256) void k_small_update(BaDeviceView v, double lambda, int nbL, int* __restrict__ counter)
+{
+    __shared__ double sm[4];
+    const int bid = blockIdx.x;
+    double sc = 0;
+    if (bid < nbL) {
+        const int l = bid * 256 + threadIdx.x;
+        if (l < v.n_lm) {
+            const double b0 = v.bp[(size_t)l * 4], b1 = v.bp[(size_t)l * 4 + 1], b2 = v.bp[(size_t)l * 4 + 2];
+            double c0 = b0, c1 = b1, c2 = b2;
+            for (int s = v.lm_wptr[l]; s < v.lm_wptr[l + 1]; ++s) {
+                const double* W = v.W + (size_t)s * 18;
+                const double* xx = v.xc + (size_t)v.w_hc[s] * 6;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    const double mx = -xx[r];
+                    c0 += W[r * 3] * mx; c1 += W[r * 3 + 1] * mx; c2 += W[r * 3 + 2] * mx;
+                }
+            }
+            double D[6];
+            lm_dinv(v, l, lambda, D);
+            const double x0 = D[0] * c0 + D[1] * c1 + D[2] * c2;
+            const double x1 = D[1] * c0 + D[3] * c1 + D[4] * c2;
+            const double x2 = D[2] * c0 + D[4] * c1 + D[5] * c2;
+            const int pt = v.lm_pt[l];
+            const double* pc = v.pt_cur + (size_t)pt * 4;
+            double* pt_t = v.pt_trial + (size_t)pt * 4;
+            pt_t[0] = pc[0] + x0; pt_t[1] = pc[1] + x1; pt_t[2] = pc[2] + x2;
+            sc = x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
+        }
+    } else {
+        const int hc = (bid - nbL) * 256 + threadIdx.x;
+        if (hc < v.n_fc) sc = pose_update_one(v, lambda, hc);
+    }
+    const double r = block_sum<4>(sc, sm);
+    if (threadIdx.x == 0) v.partial[bid] = r;
+    if (!last_block_arrives(counter, gridDim.x)) return;
+    fold_partials(v.partial, gridDim.x, v.scal + SC_SCALE, sm);
+}
+
+// k_error with the reduction folded in: last block adds the partials
+__global__ __launch_bounds__(256) void k_small_error(BaDeviceView v, int trial, double delta, int* __restrict__ counter)
+{
+    __shared__ double sm[4];
+    const double* pose = trial ? v.pose_trial : v.pose_cur;
+    const double* pts = trial ? v.pt_trial : v.pt_cur;
+    double acc = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n_L; i += gridDim.x * 256) {
+        if (!v.L_active[i]) continue;
+        const int cam = v.L_cam[i], pt = v.L_pt[i];
+        PoseD P = load_pose(pose, cam);
+        const double2 xy = *reinterpret_cast<const double2*>(pts + (size_t)pt * 4);
+        const double Z = pts[(size_t)pt * 4 + 2];
+        EdgeGeom g = edge_geom(P, v.camK, cam, xy.x, xy.y, Z, v.L_uv[i]);
+        *reinterpret_cast<double2*>(v.errL + (size_t)i * 2) = make_double2(g.e0, g.e1);
+        double rho0, rho1;
+        huber((double)v.L_info[i] * (g.e0 * g.e0 + g.e1 * g.e1), delta, rho0, rho1);
+        acc += rho0;
+    }
+    const double r = block_sum<4>(acc, sm);
+    if (threadIdx.x == 0) v.partial[blockIdx.x] = r;
+    if (!last_block_arrives(counter, gridDim.x)) return;
+    fold_partials(v.partial, gridDim.x, v.scal + (trial ? SC_CHI_TRIAL : SC_CHI), sm);
+}
+
+// k_classify with the three reductions folded in
+__global__ __launch_bounds__(256) void k_small_classify(BaDeviceView v, double max_err_sq, uint8_t* __restrict__ flagL, int* __restrict__ counter)
+{
+    __shared__ double sm[4];
+    double es = 0, ec = 0, no = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n_L; i += gridDim.x * 256) {
+        if (!v.L_active[i]) { flagL[i] = 0; continue; }
+        const double2 e = *reinterpret_cast<const double2*>(v.errL + (size_t)i * 2);
+        const double ss = e.x * e.x + e.y * e.y;
+        const int cam = v.L_cam[i], pt = v.L_pt[i];
+        PoseD P = load_pose(v.pose_cur, cam);
+        double wx, wy, wz, fx, fy, fz;
+        q_rot(-P.qx, -P.qy, -P.qz, P.qw, -P.tx, -P.ty, -P.tz, wx, wy, wz);
+        q_rot(-P.qx, -P.qy, -P.qz, P.qw, 0.0, 0.0, 1.0, fx, fy, fz);
+        const double* X = v.pt_cur + (size_t)pt * 4;
+        const double dot = (X[0] - wx) * fx + (X[1] - wy) * fy + (X[2] - wz) * fz;
+        const bool out = (dot <= 0) || (ss > max_err_sq);
+        flagL[i] = out ? 1 : 0;
+        if (out) { no += 1.0; v.L_active[i] = 0; }
+        else { es += ss; ec += 1.0; }
+    }
+    const int nb = gridDim.x;
+    const double r0 = block_sum<4>(es, sm);
+    const double r1 = block_sum<4>(ec, sm);
+    const double r2 = block_sum<4>(no, sm);
+    if (threadIdx.x == 0) { v.partial[blockIdx.x] = r0; v.partial[nb + blockIdx.x] = r1; v.partial[2 * nb + blockIdx.x] = r2; }
+    if (!last_block_arrives(counter, nb)) return;
+    fold_partials(v.partial, nb, v.scal + SC_ERRSUM, sm);
+    fold_partials(v.partial + nb, nb, v.scal + SC_ERRCNT, sm);
+    fold_partials(v.partial + 2 * nb, nb, v.scal + SC_NOUT, sm);
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int RED_BLOCKS = 1024;   // grid-stride blocks for the streaming reductions (<= partial capacity / 3)
 
@@ -726,7 +1194,10 @@ void ba_launch_linearize(const BaDeviceView& v, double delta, hipStream_t st)
 
 void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_maxdiag, dim3(1), dim3(256), 0, st, v);
+    const int work = v.n_fc * 6 + (v.points_free ? v.n_lm * 3 : 0);
+    const int nb = std::max(1, std::min(256, (work + 1023) / 1024));
+    hipLaunchKernelGGL(k_maxdiag, dim3(nb), dim3(256), 0, st, v);
+    hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, st, v.partial, nb, v.scal + SC_MAXDIAG);
 }
 
 void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st)
@@ -761,6 +1232,36 @@ void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st)
         hipLaunchKernelGGL(k_pose_update, dim3(nb_c), dim3(256), 0, st, v, lambda, nb_l);
     }
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb_l + nb_c, 1, v.scal + SC_SCALE, 1);
+}
+
+// ---- small-problem path (ba_kernels.h: ba_small_*)
+bool ba_small_applies(const BaDeviceView& v)
+{
+    static const bool off = std::getenv("MAGE_BA_NO_SMALL_PATH") != nullptr;
+    return !off && v.n_fc > 0 && v.n_fc * 6 <= 128 && v.n_T == 0 && v.n_L <= (1 << 20);
+}
+static int small_error_blocks(const BaDeviceView& v) { return v.n_L > 0 ? std::min(cdiv(v.n_L, 256), RED_BLOCKS) : 1; }
+void ba_small_linearize(const BaDeviceView& v, double delta, bool want_maxdiag, int* counter, hipStream_t st)
+{
+    const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm, 256) : 0;
+    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + v.n_fc + 1), dim3(256), 0, st, v, delta, nbL, want_maxdiag ? 1 : 0, counter);
+}
+void ba_small_solve_trial(const BaDeviceView& v, double lambda, double delta, int* counter, hipStream_t st)
+{
+    const int n = v.n_fc * 6;
+    hipLaunchKernelGGL(k_small_schur, dim3(v.n_blk + v.n_fc), dim3(256), 0, st, v, lambda);
+    hipLaunchKernelGGL(k_small_solve, dim3(1), dim3(256), ((size_t)n * (n + 1) + n) * sizeof(double), st, v.S, v.y, v.xc, n, v.n_pad, v.scal + SC_CHOL_OK, v.scal + SC_CHOL_STALL);
+    const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm, 256) : 0;
+    hipLaunchKernelGGL(k_small_update, dim3(nbL + cdiv(v.n_fc, 256)), dim3(256), 0, st, v, lambda, nbL, counter);
+    hipLaunchKernelGGL(k_small_error, dim3(small_error_blocks(v)), dim3(256), 0, st, v, 1, delta, counter);
+}
+void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flagL, int* counter, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_small_classify, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, flagL, counter);
+}
+void ba_small_init_device()
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((128 * 129 + 128) * sizeof(double)));
 }
 
 void ba_launch_export_poses(const double* pose, const uint32_t* cam, const uint32_t* row, size_t n, double* block, hipStream_t st)
