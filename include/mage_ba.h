@@ -95,7 +95,7 @@ mage_status mage_ba_update_camera_poses(mage_ba* h, size_t count, const uint32_t
  * pose block over xGMI").  A POSE BLOCK is device memory of rows x 8 float64, one row per keyframe of the whole map in the
  * solver's own state format: qx qy qz qw tx ty tz 0 (world -> camera).  Nothing is staged through the host and nothing
  * synchronises: export / import run on the handle's stream but are ordered AS IF ENQUEUED ON `stream` (a hipStream_t of the
- * caller, NULL = no ordering: use mage_ba_synchronize) -- they wait for what `stream` holds and `stream` waits for them.
+ * caller; NULL = the device's null stream) -- they wait for what `stream` holds and `stream` waits for them.
  *   bind    the handle's cameras that are published (export_cameras[k] -> block row export_rows[k]) and the ones that are
  *           re-seeded from the block (import_cameras[k] <- row import_rows[k]); host arrays, copied once.
  *   export  block[row] = current estimate (+0.0, so a row is bit-identical whether or not it went through a SUM with other

@@ -32,6 +32,17 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -m mageslam_amd.build` (hipcc, gfx950). "
                 "mageslam_amd has no CPU fallback.")
+        # PyTorch-ROCm wheels bundle their own HIP / HSA runtime.  In a process that uses both (tests, bench.py, the Python
+        # window driver) torch's runtime has to come up FIRST: when this library's (system) runtime initialises first, torch
+        # later reports "No HIP GPUs are available".  Harness detail only -- the shared library itself never touches torch.
+        import sys
+        torch = sys.modules.get("torch")
+        if torch is not None:
+            try:
+                if torch.cuda.is_available():
+                    torch.cuda.init()
+            except Exception:            # noqa: a CPU-only torch is fine
+                pass
         _lib = C.CDLL(LIB_PATH)
         _lib.mage_last_error.restype = C.c_char_p
     return _lib

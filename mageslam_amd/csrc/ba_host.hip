@@ -268,6 +268,8 @@ struct mage_ba {
     int n_active_tethers = 0;
     DevBuf<int> d_queue;
     double* h_scal = nullptr;           // pinned mirror of d_scal
+    DevBuf<PoseLmResult> d_pose_lm;     // pose-only problems: the record the one-launch solve leaves
+    PoseLmResult* h_pose_lm = nullptr;  // pinned mirror
     BaDeviceView view{};
     std::vector<uint32_t> L_edge_host;  // landmark-order position -> observation index
     std::vector<uint8_t> flag_host;
@@ -293,6 +295,7 @@ struct mage_ba {
         for (auto& e : ev_p) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_x) if (e) (void)hipEventDestroy(e);
         if (h_scal) (void)hipHostFree(h_scal);
+        if (h_pose_lm) (void)hipHostFree(h_pose_lm);
         cached_stream_release(device, stream);
     }
 };
@@ -820,7 +823,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
         const double lambda = h->lambda;
         if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[0], st));
         if (small) {
-            ba_small_solve_trial(v, lambda, huber, counter, st);
+            ba_small_solve_trial(v, lambda, huber, h->d_Linv.p, counter, st);
             if (h->profiling) { MAGE_HIP(hipEventRecord(h->ev[1], st)); MAGE_HIP(hipEventRecord(h->ev[2], st)); }
         } else {
             ba_launch_schur(v, lambda, st);
@@ -1267,20 +1270,64 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
         MAGE_DEVICE_SCOPE(h->device);
         h->stats.clear();
         h->last_outliers.clear();
-        for (size_t it = 0; it < n_iter; ++it) {
+        for (size_t it = 0; it < n_iter; ++it)
             if (huber[it] < 0.f) return fail(MAGE_ERR_INVALID_ARGUMENT, "Huber widths must be nonnegative");
-            bool cont = true;
-            MAGE_TRY(step_optimizer(h, (double)huber[it], &cont));
-            if (!cont) break;
-        }
-        // post-pass over the active observations of the last initialisation
         const BaDeviceView& v = h->view;
-        if (v.n_L == 0 || h->L_edge_host.empty()) return MAGE_OK;     // count == 0 -> NaN
-        if (ba_small_applies(v)) ba_small_classify(v, (double)max_err_sq, h->d_flagL.p, h->d_queue.p + chol_sync_ints(v.n_pad), h->stream);
-        else ba_launch_classify(v, (double)max_err_sq, h->d_flagL.p, h->stream);
-        MAGE_TRY(read_scalars(h));
-        const double err_sum = h->h_scal[SC_ERRSUM], cnt = h->h_scal[SC_ERRCNT];
-        const size_t nout = (size_t)h->h_scal[SC_NOUT];
+        double err_sum = 0, cnt = 0;
+        size_t nout = 0;
+        bool in_one_launch = false;
+        if (n_iter > 0) {
+            // StepOptimizer's entry conditions (BundlerLib.cpp:132-149), then: a pose-only problem runs the whole call in one launch
+            if (h->dirty) MAGE_TRY(initialize_optimization(h));
+            if (!h->dirty && !h->useless && v.n_L > 0 && ba_pose_lm_applies(v, n_iter)) {
+                if (h->soft_dirty) {
+                    h->iteration = 0; h->soft_dirty = false;
+                    if (h->n_active_remaining <= 0 && h->n_active_tethers == 0) h->useless = true;
+                }
+                if (!h->useless) {
+                    PoseLmArgs a{};
+                    a.n_huber = (int)n_iter;
+                    for (size_t it = 0; it < n_iter; ++it) a.huber[it] = huber[it];
+                    a.max_err_sq = (double)max_err_sq; a.lambda = h->lambda; a.user_lambda = h->user_lambda; a.ni = h->ni; a.iteration = h->iteration;
+                    MAGE_TRY(h->d_pose_lm.reserve(1));
+                    if (!h->h_pose_lm) MAGE_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_pose_lm), sizeof(PoseLmResult)));
+                    ba_launch_pose_lm(v, a, h->d_pose_lm.p, h->d_flagL.p, h->stream);
+                    MAGE_HIP(hipMemcpyAsync(h->h_pose_lm, h->d_pose_lm.p, sizeof(PoseLmResult), hipMemcpyDeviceToHost, h->stream));
+                    MAGE_HIP(hipEventRecord(h->ev[3], h->stream));
+                    for (;;) {
+                        const hipError_t e = hipEventQuery(h->ev[3]);
+                        if (e == hipSuccess) break;
+                        if (e != hipErrorNotReady) MAGE_HIP(e);
+                    }
+                    const PoseLmResult& r = *h->h_pose_lm;
+                    h->lambda = r.lambda; h->ni = r.ni; h->iteration = r.iteration;
+                    if (r.flips & 1) { h->cur ^= 1; refresh_view_state(h); }
+                    h->host_state_fresh = false;
+                    for (int i = 0; i < r.n_stats && i < POSE_LM_MAX_ITERS; ++i) {
+                        mage_ba_iter_stats tr{};
+                        tr.code = r.stats[i].code; tr.trials = r.stats[i].trials; tr.chi2_before = r.stats[i].chi2_before;
+                        tr.chi2_after = r.stats[i].chi2_after; tr.lambda = r.stats[i].lambda;
+                        if (h->stats.size() < 64) h->stats.push_back(tr);
+                    }
+                    err_sum = r.err_sum; cnt = r.err_cnt; nout = (size_t)r.n_out;
+                    in_one_launch = true;
+                }
+            }
+        }
+        if (!in_one_launch) {
+            for (size_t it = 0; it < n_iter; ++it) {
+                bool cont = true;
+                MAGE_TRY(step_optimizer(h, (double)huber[it], &cont));
+                if (!cont) break;
+            }
+            // post-pass over the active observations of the last initialisation
+            if (v.n_L == 0 || h->L_edge_host.empty()) return MAGE_OK;     // count == 0 -> NaN
+            if (ba_small_applies(v)) ba_small_classify(v, (double)max_err_sq, h->d_flagL.p, h->d_queue.p + chol_sync_ints(v.n_pad), h->stream);
+            else ba_launch_classify(v, (double)max_err_sq, h->d_flagL.p, h->stream);
+            MAGE_TRY(read_scalars(h));
+            err_sum = h->h_scal[SC_ERRSUM]; cnt = h->h_scal[SC_ERRCNT];
+            nout = (size_t)h->h_scal[SC_NOUT];
+        }
         if (mean_sq_err) *mean_sq_err = (float)(err_sum / cnt);
         if (nout > 0) {
             h->flag_host.resize(v.n_L);
@@ -1338,7 +1385,7 @@ MAGE_EXPORT mage_status mage_ba_bind_pose_exchange(mage_ba* h, size_t n_export, 
 // zero-fill cannot overtake an import that still reads the block).  Two events, no host synchronisation.
 static mage_status join_before(mage_ba* h, void* stream)
 {
-    if (stream && stream != (void*)h->stream) {
+    if (stream != (void*)h->stream) {          // NULL is the device's null stream: the handle's stream is non-blocking, so it must be joined explicitly too
         MAGE_HIP(hipEventRecord(h->ev_x[0], static_cast<hipStream_t>(stream)));
         MAGE_HIP(hipStreamWaitEvent(h->stream, h->ev_x[0], 0));
     }
@@ -1346,7 +1393,7 @@ static mage_status join_before(mage_ba* h, void* stream)
 }
 static mage_status join_after(mage_ba* h, void* stream)
 {
-    if (stream && stream != (void*)h->stream) {
+    if (stream != (void*)h->stream) {
         MAGE_HIP(hipEventRecord(h->ev_x[1], h->stream));
         MAGE_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->ev_x[1], 0));
     }

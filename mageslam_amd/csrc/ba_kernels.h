@@ -90,8 +90,24 @@ void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flag_
 bool ba_small_applies(const BaDeviceView& v);
 void ba_small_init_device();                                                                          // once per device: LDS opt-in
 void ba_small_linearize(const BaDeviceView& v, double huber_delta, bool want_maxdiag, int* counter, hipStream_t st);   // U,bc,V,bp,W, S/y zeroed, scal[SC_CHI] (+ SC_MAXDIAG)
-void ba_small_solve_trial(const BaDeviceView& v, double lambda, double huber_delta, int* counter, hipStream_t st);    // S, y, xc, trial state, SC_SCALE, SC_CHI_TRIAL, SC_CHOL_OK/STALL
+void ba_small_solve_trial(const BaDeviceView& v, double lambda, double huber_delta, double* linv_ws, int* counter, hipStream_t st);    // S, y, xc, trial state, SC_SCALE, SC_CHI_TRIAL, SC_CHOL_OK/STALL
 void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flag_by_edge, int* counter, hipStream_t st);
+
+// Pose-only problems (points fixed): the whole StepBundleAdjustment call in ONE launch (ba_kernels.hip, "POSE-ONLY problems").
+constexpr int POSE_LM_MAX_ITERS = 16;
+struct PoseLmArgs {
+    int n_huber; float huber[POSE_LM_MAX_ITERS];      // one LM iteration per Huber width
+    double max_err_sq;                                // outlier threshold of the post-pass
+    double lambda, user_lambda, ni; int iteration;    // LM state on entry
+};
+struct PoseLmIter { int code, trials; double chi2_before, chi2_after, lambda; };
+struct PoseLmResult {
+    double lambda, ni; int iteration, n_stats, flips; // LM state on exit; flips = accepted trials (each swaps the two pose buffers)
+    double err_sum, err_cnt, n_out;                   // post-pass
+    PoseLmIter stats[POSE_LM_MAX_ITERS];
+};
+bool ba_pose_lm_applies(const BaDeviceView& v, size_t n_huber);
+void ba_launch_pose_lm(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out_device, uint8_t* flag_by_edge, hipStream_t st);
 
 // Pose exchange of a window-sharded map (mage_ba_export_poses_device / mage_ba_import_poses_device).  A block row is 8 doubles
 // (qx qy qz qw tx ty tz 0).  export: block[row[k]] = pose[cam[k]] (+0.0, so that -0.0 leaves as +0.0 -- what a SUM with the

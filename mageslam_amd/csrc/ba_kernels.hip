@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 #include "ba_kernels.h"
+#include "chol_kernels.h"
 
 namespace mage {
 namespace {
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(256) void k_import_poses(double* __restrict__ pose0
 //     k_small_linearize   landmark side + camera side + zero-fill of S, y (roles by block range); the LAST block to finish
 //                         adds the chi2 partials in block order and (first iteration) takes max |diag|
 //     k_small_schur       all blocks of S + the reduced rhs ((V + lambda I)^-1 formed where it is used, no D^-1 array)
-//     k_small_solve       dense Cholesky + both substitutions of the n x n system (n = its true order) in LDS, one workgroup
+//     k_small_solve       (chol_kernels.hip) Cholesky of the leading ceil(n/16) blocks + both substitutions in LDS, one workgroup
 //     k_small_update      back-substitution + pose update; last block adds the scale partials
 //     k_small_error       residuals of the trial state; last block adds the chi2 partials
 // plus one scalar read-back.  Same arithmetic per element as the large-problem kernels (the device functions are shared);
@@ -1021,56 +1022,6 @@ __global__ __launch_bounds__(256) void k_small_schur(BaDeviceView v, double lamb
     }
 }
 
-// Dense solve of the n x n reduced camera system (n <= 128, its TRUE order: no padding), one workgroup, everything in LDS:
-// right-looking Cholesky by columns (the column's scaling and the rank-1 update of the trailing block between two barriers),
-// then the two substitutions.  Replaces g2o::LinearSolverDense (Eigen LDLT) for small systems, as chol_kernels.hip does for
-// large ones; a non-positive pivot clears *ok.
-__global__ __launch_bounds__(256) void k_small_solve(const double* __restrict__ S, const double* __restrict__ y, double* __restrict__ x, int n, int ld, double* __restrict__ ok, double* __restrict__ stall)
-{
-    extern __shared__ double smem[];
-    double* A = smem;                 // n x (n + 1), column-major with an odd pitch
-    double* rhs = smem + (size_t)n * (n + 1);
-    __shared__ int bad;
-    const int tid = threadIdx.x, P = n + 1;
-    if (tid == 0) bad = 0;
-    for (int e = tid; e < n * n; e += 256) { const int c = e / n, r = e % n; A[c * P + r] = r >= c ? S[(size_t)c * ld + r] : 0.0; }
-    for (int i = tid; i < n; i += 256) rhs[i] = y[i];
-    __syncthreads();
-    for (int j = 0; j < n; ++j) {
-        const double d = A[j * P + j];
-        if (!(d > 0.0)) { if (tid == 0) bad = 1; }
-        const double inv = 1.0 / sqrt(d);
-        __syncthreads();
-        // scale column j (rows j..n-1)
-        for (int r = j + tid; r < n; r += 256) A[j * P + r] *= inv;
-        __syncthreads();
-        // trailing update: A[r][c] -= L[r][j] L[c][j] for j < c <= r
-        const int m = n - j - 1;
-        for (int e = tid; e < m * m; e += 256) {
-            const int c = j + 1 + e / m, r = j + 1 + e % m;
-            if (r >= c) A[c * P + r] = __builtin_fma(-A[j * P + r], A[j * P + c], A[c * P + r]);
-        }
-        __syncthreads();
-    }
-    // forward substitution L z = rhs, then backward L^T x = z; one column per step, rows in parallel
-    for (int j = 0; j < n; ++j) {
-        if (tid == 0) rhs[j] /= A[j * P + j];
-        __syncthreads();
-        const double zj = rhs[j];
-        for (int r = j + 1 + tid; r < n; r += 256) rhs[r] = __builtin_fma(-A[j * P + r], zj, rhs[r]);
-        __syncthreads();
-    }
-    for (int j = n - 1; j >= 0; --j) {
-        if (tid == 0) rhs[j] /= A[j * P + j];
-        __syncthreads();
-        const double xj = rhs[j];
-        for (int r = tid; r < j; r += 256) rhs[r] = __builtin_fma(-A[r * P + j], xj, rhs[r]);
-        __syncthreads();
-    }
-    for (int i = tid; i < n; i += 256) x[i] = rhs[i];
-    if (tid == 0) { *ok = bad ? 0.0 : 1.0; *stall = 0.0; }
-}
-
 // blocks [0, nbL): k_backsub with D^-1 formed in place; blocks [nbL, nbL + nbC): k_pose_update; last block adds the scale partials
 __global__ __launch_bounds__(256) void k_small_update(BaDeviceView v, double lambda, int nbL, int* __restrict__ counter)
 {
@@ -1169,6 +1120,234 @@ __global__ __launch_bounds__(256) void k_small_classify(BaDeviceView v, double m
     fold_partials(v.partial + 2 * nb, nb, v.scal + SC_NOUT, sm);
 }
 
+// =================================================================================================
+// POSE-ONLY problems (BundlerParameters::ArePointsFixed, a handful of free cameras, a few thousand observations): the tracker's
+// per-frame refinement (Tracking/TrackLocalMap.cpp:421-501 OptimizeCameraPose, Tracking/PoseEstimator.cpp:168-207).  With the
+// points fixed the system is one 6x6 block per camera, so the WHOLE StepBundleAdjustment call -- every LM iteration with its
+// damped trials (OptimizationAlgorithmLevenberg::solve, appendix A.4), and the outlier post-pass (BundlerLib.cpp:384-427) -- runs
+// in ONE launch of one workgroup; the host reads one record back.  Control flow and arithmetic per element are those of
+// lm_solve / the kernels above; sums keep a fixed order.
+// =================================================================================================
+__device__ __forceinline__ bool solve6_spd(const double* __restrict__ U36, double lambda, const double* __restrict__ b, double* __restrict__ x)
+{
+    double L[6][6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = U36[j * 6 + j] + lambda;
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        if (!(d > 0.0)) ok = false;
+        const double s = sqrt(d);
+        L[j][j] = s;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double a = U36[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) a -= L[i][k] * L[j][k];
+            L[i][j] = a / s;
+        }
+    }
+    double z[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double a = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) a -= L[i][k] * z[k];
+        z[i] = a / L[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double a = z[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) a -= L[k][i] * x[k];
+        x[i] = a / L[i][i];
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView v, PoseLmArgs a, PoseLmResult* __restrict__ out, uint8_t* __restrict__ flagL)
+{
+    __shared__ double sm[4];
+    __shared__ double part[4][28];
+    __shared__ double s_chi, s_scale, s_lambda, s_ni, s_rho, s_cur_chi;
+    __shared__ int s_ok, s_go, s_accept;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double lambda = a.lambda, ni = a.ni;
+    int iteration = a.iteration, n_stats = 0, flips = 0, cont = 1;
+    BaDeviceView w = v;                                 // w.pose_cur / w.pose_trial swap on every accepted trial
+
+    // robust chi2 of state `pose` over all active observations (residuals to errL): thread-strided, fixed order
+    auto chi2_of = [&](const double* pose, double delta) -> double {
+        double acc = 0;
+        for (int i = tid; i < v.n_L; i += 256) {
+            if (!v.L_active[i]) continue;
+            const int cam = v.L_cam[i], pt = v.L_pt[i];
+            PoseD P = load_pose(pose, cam);
+            const double2 xy = *reinterpret_cast<const double2*>(v.pt_cur + (size_t)pt * 4);
+            const double Z = v.pt_cur[(size_t)pt * 4 + 2];
+            EdgeGeom g = edge_geom(P, v.camK, cam, xy.x, xy.y, Z, v.L_uv[i]);
+            *reinterpret_cast<double2*>(v.errL + (size_t)i * 2) = make_double2(g.e0, g.e1);
+            double rho0, rho1;
+            huber((double)v.L_info[i] * (g.e0 * g.e0 + g.e1 * g.e1), delta, rho0, rho1);
+            acc += rho0;
+        }
+        return block_sum<4>(acc, sm);
+    };
+
+    for (int it = 0; it < a.n_huber && cont; ++it) {
+        const double delta = (double)a.huber[it];
+        // ---- linearise at the current estimate: chi2, U, b per free camera
+        const double chi_cur0 = chi2_of(w.pose_cur, delta);
+        for (int hc = 0; hc < v.n_fc; ++hc) {
+            const int cam = v.hc2cam[hc];
+            PoseD P = load_pose(w.pose_cur, cam);
+            const double f = v.camK[cam * 4];
+            double A[21], b[6];
+#pragma unroll
+            for (int k = 0; k < 21; ++k) A[k] = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) b[k] = 0;
+            for (int idx = v.camE_ptr[hc] + tid; idx < v.camE_ptr[hc + 1]; idx += 256) {
+                const int i = v.camE[idx];
+                if (!v.L_active[i]) continue;
+                const int pt = v.L_pt[i];
+                const double2 xy = *reinterpret_cast<const double2*>(v.pt_cur + (size_t)pt * 4);
+                const double Z = v.pt_cur[(size_t)pt * 4 + 2];
+                EdgeGeom g = edge_geom(P, v.camK, cam, xy.x, xy.y, Z, v.L_uv[i]);
+                const double info = (double)v.L_info[i];
+                double rho0, rho1;
+                huber(info * (g.e0 * g.e0 + g.e1 * g.e1), delta, rho0, rho1);
+                const double wgt = info * rho1;
+                const double r0 = -info * g.e0 * rho1, r1 = -info * g.e1 * rho1;
+                double Jc[12];
+                jac_pose(g, f, Jc);
+                int k = 0;
+#pragma unroll
+                for (int p = 0; p < 6; ++p) {
+                    b[p] += Jc[p] * r0 + Jc[6 + p] * r1;
+#pragma unroll
+                    for (int c = 0; c <= p; ++c) A[k++] += Jc[p] * wgt * Jc[c] + Jc[6 + p] * wgt * Jc[6 + c];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 21; ++k) A[k] = wave_sum(A[k]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) b[k] = wave_sum(b[k]);
+            __syncthreads();
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 21; ++k) part[wave][k] = A[k];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) part[wave][21 + k] = b[k];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int k = 0;
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int c = 0; c <= p; ++c) {
+                        const double val = ((part[0][k] + part[1][k]) + part[2][k]) + part[3][k];
+                        v.U[(size_t)hc * 36 + p * 6 + c] = val; v.U[(size_t)hc * 36 + c * 6 + p] = val; ++k;
+                    }
+#pragma unroll
+                for (int p = 0; p < 6; ++p) v.bc[(size_t)hc * 6 + p] = ((part[0][21 + p] + part[1][21 + p]) + part[2][21 + p]) + part[3][21 + p];
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (tid == 0) {
+            if (iteration == 0) {
+                double m = 0;
+                for (int i = 0; i < v.n_fc * 6; ++i) m = fmax(m, fabs(v.U[(size_t)(i / 6) * 36 + (i % 6) * 7]));
+                lambda = a.user_lambda > 0 ? a.user_lambda : 1e-5 * m;
+                ni = 2;
+            }
+            s_lambda = lambda; s_ni = ni; s_cur_chi = chi_cur0;
+        }
+        __syncthreads();
+        lambda = s_lambda; ni = s_ni;
+        double cur_chi = s_cur_chi, rho = 0;
+        int qmax = 0;
+        do {
+            // ---- one damped trial: x = (U + lambda I)^-1 b per camera, pose_trial = exp(x) pose_cur, scale, chi2 of the trial
+            if (tid == 0) s_ok = 1;
+            __syncthreads();
+            double sc = 0;
+            if (tid < v.n_fc) {
+                double x[6];
+                const bool ok = solve6_spd(v.U + (size_t)tid * 36, lambda, v.bc + (size_t)tid * 6, x);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) v.xc[(size_t)tid * 6 + k] = x[k];
+                if (!ok) s_ok = 0;
+                sc = pose_update_one(w, lambda, tid);
+            }
+            const double scale = block_sum<4>(sc, sm);
+            __threadfence_block();
+            __syncthreads();
+            const double chi_trial = chi2_of(w.pose_trial, delta);
+            if (tid == 0) {
+                const bool ok2 = s_ok != 0;
+                double temp = chi_trial, r;
+                if (!ok2) { temp = 1.7976931348623157e308; r = -1.0; }
+                else r = (cur_chi - temp) / (scale + 1e-3);
+                int acc = 0;
+                if (ok2 && r > 0 && isfinite(temp)) {
+                    double alpha = 1. - pow((2 * r - 1), 3);
+                    alpha = fmin(alpha, 2. / 3.);
+                    lambda *= fmax(1. / 3., alpha);
+                    ni = 2;
+                    cur_chi = temp;
+                    acc = 1;
+                } else {
+                    lambda *= ni;
+                    ni *= 2;
+                }
+                s_rho = r; s_accept = acc; s_lambda = lambda; s_ni = ni; s_cur_chi = cur_chi;
+            }
+            __syncthreads();
+            rho = s_rho; lambda = s_lambda; ni = s_ni; cur_chi = s_cur_chi;
+            if (s_accept) { double* t = w.pose_cur; w.pose_cur = w.pose_trial; w.pose_trial = t; ++flips; }
+            ++qmax;
+            __syncthreads();
+        } while (rho < 0 && qmax < 10);
+        const int code = (qmax == 10 || rho == 0) ? 1 : 0;
+        if (tid == 0 && n_stats < POSE_LM_MAX_ITERS) {
+            out->stats[n_stats].code = code; out->stats[n_stats].trials = qmax; out->stats[n_stats].chi2_before = chi_cur0;
+            out->stats[n_stats].chi2_after = cur_chi; out->stats[n_stats].lambda = lambda;
+        }
+        ++n_stats;
+        ++iteration;
+        cont = code == 0;
+    }
+    // ---- post-pass: classification with the residuals of the LAST error evaluation and the kept estimate (k_classify)
+    double es = 0, ec = 0, no = 0;
+    for (int i = tid; i < v.n_L; i += 256) {
+        if (!v.L_active[i]) { flagL[i] = 0; continue; }
+        const double2 e = *reinterpret_cast<const double2*>(v.errL + (size_t)i * 2);
+        const double ss = e.x * e.x + e.y * e.y;
+        const int cam = v.L_cam[i], pt = v.L_pt[i];
+        PoseD P = load_pose(w.pose_cur, cam);
+        double wx, wy, wz, fx, fy, fz;
+        q_rot(-P.qx, -P.qy, -P.qz, P.qw, -P.tx, -P.ty, -P.tz, wx, wy, wz);
+        q_rot(-P.qx, -P.qy, -P.qz, P.qw, 0.0, 0.0, 1.0, fx, fy, fz);
+        const double* X = v.pt_cur + (size_t)pt * 4;
+        const double dot = (X[0] - wx) * fx + (X[1] - wy) * fy + (X[2] - wz) * fz;
+        const bool o = (dot <= 0) || (ss > a.max_err_sq);
+        flagL[i] = o ? 1 : 0;
+        if (o) { no += 1.0; v.L_active[i] = 0; }
+        else { es += ss; ec += 1.0; }
+    }
+    const double r0 = block_sum<4>(es, sm);
+    const double r1 = block_sum<4>(ec, sm);
+    const double r2 = block_sum<4>(no, sm);
+    if (tid == 0) {
+        out->lambda = lambda; out->ni = ni; out->iteration = iteration; out->n_stats = n_stats; out->flips = flips;
+        out->err_sum = r0; out->err_cnt = r1; out->n_out = r2;
+    }
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int RED_BLOCKS = 1024;   // grid-stride blocks for the streaming reductions (<= partial capacity / 3)
 
@@ -1246,11 +1425,11 @@ void ba_small_linearize(const BaDeviceView& v, double delta, bool want_maxdiag, 
     const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm, 256) : 0;
     hipLaunchKernelGGL(k_small_linearize, dim3(nbL + v.n_fc + 1), dim3(256), 0, st, v, delta, nbL, want_maxdiag ? 1 : 0, counter);
 }
-void ba_small_solve_trial(const BaDeviceView& v, double lambda, double delta, int* counter, hipStream_t st)
+void ba_small_solve_trial(const BaDeviceView& v, double lambda, double delta, double* linv_ws, int* counter, hipStream_t st)
 {
     const int n = v.n_fc * 6;
     hipLaunchKernelGGL(k_small_schur, dim3(v.n_blk + v.n_fc), dim3(256), 0, st, v, lambda);
-    hipLaunchKernelGGL(k_small_solve, dim3(1), dim3(256), ((size_t)n * (n + 1) + n) * sizeof(double), st, v.S, v.y, v.xc, n, v.n_pad, v.scal + SC_CHOL_OK, v.scal + SC_CHOL_STALL);
+    chol_small_solve(v.S, v.y, v.xc, n, v.n_pad, linv_ws, v.scal + SC_CHOL_OK, v.scal + SC_CHOL_STALL, st);
     const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm, 256) : 0;
     hipLaunchKernelGGL(k_small_update, dim3(nbL + cdiv(v.n_fc, 256)), dim3(256), 0, st, v, lambda, nbL, counter);
     hipLaunchKernelGGL(k_small_error, dim3(small_error_blocks(v)), dim3(256), 0, st, v, 1, delta, counter);
@@ -1259,9 +1438,16 @@ void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flagL,
 {
     hipLaunchKernelGGL(k_small_classify, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, flagL, counter);
 }
-void ba_small_init_device()
+void ba_small_init_device() {}
+
+bool ba_pose_lm_applies(const BaDeviceView& v, size_t n_huber)
 {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((128 * 129 + 128) * sizeof(double)));
+    static const bool off = std::getenv("MAGE_BA_NO_SMALL_PATH") != nullptr;
+    return !off && !v.points_free && v.n_T == 0 && v.n_fc >= 1 && v.n_fc <= 64 && v.n_L <= 16384 && n_huber >= 1 && n_huber <= (size_t)POSE_LM_MAX_ITERS;
+}
+void ba_launch_pose_lm(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out, uint8_t* flagL, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pose_lm, dim3(1), dim3(256), 0, st, v, a, out, flagL);
 }
 
 void ba_launch_export_poses(const double* pose, const uint32_t* cam, const uint32_t* row, size_t n, double* block, hipStream_t st)

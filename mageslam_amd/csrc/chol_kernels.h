@@ -23,4 +23,8 @@ void chol_init_device();   // once per device (after hipSetDevice): opt the LDS-
 // first and to 1.0 when a cross-workgroup hand-off timed out.
 void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWorkspace& ws, double* ok, hipStream_t st);
 
+// Order n <= CHOL_TILE: the same solve as ONE launch of one workgroup (S with ld >= 16 ceil(n / 16), identity beyond n; Linv_ws >=
+// chol_workspace_doubles(CHOL_TILE) doubles).  *ok as above, *stall = 0.
+void chol_small_solve(const double* S, const double* y, double* x, int n, int ld, double* Linv_ws, double* ok, double* stall, hipStream_t st);
+
 }  // namespace mage

@@ -284,24 +284,27 @@ __device__ __forceinline__ void lds_update_tile_left(double* __restrict__ A, int
 // factors it while wavefronts 1-3 apply the rest of the trailing update (look-ahead inside the tile).
 // ---------------------------------------------------------------------------------------------
 // Factor the LDS-resident tile A (column-major, pitch LDC) in place; Li = 2 x 256 doubles of LDS scratch.
-__device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __restrict__ Li, double* __restrict__ Linv_k, int tid)
+// PARTIAL: only the leading nblk 16-column blocks are factored (the rest of the tile is the identity padding of a small system).
+template <bool PARTIAL>
+__device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __restrict__ Li, double* __restrict__ Linv_k, int tid, int nblk = NBLK)
 {
+    const int NBK = PARTIAL ? nblk : NBLK;
     const int lane = tid & 63, wave = tid >> 6;
     bool failed = false;
     if (wave == 0) failed = factor_block16(A, 0, lane, Li, Linv_k);
     __syncthreads();
-    for (int s = 0; s < NBLK; ++s) {
+    for (int s = 0; s < NBK; ++s) {
         const int p0 = s * NB;
         const double* Lc = Li + (s & 1) * NB * NB;
         if (wave == 3) {                           // block inverse s -> global workspace (read by k_trsm_panel / k_bsolve_persist)
             const double4_t v = *reinterpret_cast<const double4_t*>(Lc + lane * 4);
             *reinterpret_cast<double4_t*>(Linv_k + s * NB * NB + lane * 4) = v;
         }
-        if (s == NBLK - 1) break;
+        if (s == NBK - 1) break;
         // rows below block s:  Y = Linv * A^T per 16-row strip; Y[m][n] = X[row r0 + n][col p0 + m].
         // Wavefront 0 is the critical path: it solves only the strip it needs (the rows of the next diagonal block) and
         // updates that block before the barrier, while the other three share the remaining strips.
-        const int nstrips = NBLK - 1 - s;
+        const int nstrips = NBK - 1 - s;
         if (wave == 0) {
             // strip 0 and the next diagonal block in one go: the strip's result registers ARE both MFMA operands of
             // D -= Y^T Y (register r of a lane is element [4r + (lane >> 4)][lane & 15] of Y = operand chunk r of either side)
@@ -348,7 +351,7 @@ __device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __re
         if (wave == 0) {
             failed |= factor_block16(A, p0 + NB, lane, Li + ((s + 1) & 1) * NB * NB, Linv_k + (s + 1) * NB * NB);
         } else {
-            const int nrow = NBLK - 2 - s;                 // block rows s+2 .. 7
+            const int nrow = NBK - 2 - s;                 // block rows s+2 .. 7
             for (int t = wave - 1; t < 2 * nrow; t += 3) {
                 const int i = s + 2 + (t >> 1);
                 if ((t & 1) == 0) lds_update_tile_left(A, i * NB, p0 + NB, s + 1, lane);
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int 
     double* T = S + (size_t)(k * TILE) * ld + (size_t)k * TILE;
     load_tile<LDC>(A, T, ld, tid);
     __syncthreads();
-    const bool failed = potrf_tile_lds(A, Li, Linv_k, tid);
+    const bool failed = potrf_tile_lds<false>(A, Li, Linv_k, tid);
     store_tile_lower(T, A, ld, tid);
     if (tid == 0 && failed) *ok = 0.0;
 }
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
         double* T = S + (size_t)(j0 * TILE) * ld + (size_t)j0 * TILE;
         load_tile<LDC>(A, T, ld, tid);
         __syncthreads();
-        const bool failed = potrf_tile_lds(A, sm + TILE * LDC, Linv_next, tid);
+        const bool failed = potrf_tile_lds<false>(A, sm + TILE * LDC, Linv_next, tid);
         store_tile_lower(T, A, ld, tid);
         if (tid == 0 && failed) *ok = 0.0;
         return;
@@ -734,6 +737,68 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
     if (dbg && tid == 0) dbg[j * 4 + 3] = wall_clock64();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small systems (order n <= 128: local bundle adjustment, map initialisation, pose-only refinement): the whole dense solve in
+// ONE launch of one workgroup -- the leading ceil(n / 16) blocks of the tile factored in LDS (potrf_tile_lds<true>), then both
+// substitutions in LDS with the 16x16 block inverses.  The chain of launches of the large-system path (potrf + solve + backward
+// solve, ~40 us for any n <= 128) becomes ~3 us per 16 columns.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_small_solve(const double* __restrict__ S, const double* __restrict__ y, double* __restrict__ x, int n, int ld,
+                                                     double* __restrict__ Linv_ws, double* __restrict__ ok, double* __restrict__ stall)
+{
+    extern __shared__ double sm[];
+    double* A = sm;
+    double* Li = sm + TILE * LDC;
+    __shared__ double rhs[TILE], xc[NB];
+    const int tid = threadIdx.x;
+    const int nblk = (n + NB - 1) / NB, np = nblk * NB;          // S carries the identity beyond n (it is padded to a whole tile)
+    for (int e = tid; e < np * np; e += 256) { const int c = e / np, r = e % np; A[c * LDC + r] = S[(size_t)c * ld + r]; }
+    for (int i = tid; i < np; i += 256) rhs[i] = y[i];
+    __syncthreads();
+    const bool failed = potrf_tile_lds<true>(A, Li, Linv_ws, tid, nblk);
+    __threadfence_block();
+    __syncthreads();
+    // forward substitution L z = rhs
+    for (int cb = 0; cb < nblk; ++cb) {
+        if (tid < NB) {
+            double acc = 0;
+#pragma unroll
+            for (int q = 0; q < NB; ++q) acc = __builtin_fma(Linv_ws[cb * NB * NB + tid * NB + q], rhs[cb * NB + q], acc);
+            xc[tid] = acc;
+        }
+        __syncthreads();
+        if (tid < NB) rhs[cb * NB + tid] = xc[tid];
+        const int r = (cb + 1) * NB + tid;
+        if (r < np) {
+            double acc = rhs[r];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) acc = __builtin_fma(-A[(cb * NB + q) * LDC + r], xc[q], acc);
+            rhs[r] = acc;
+        }
+        __syncthreads();
+    }
+    // backward substitution L^T x = z
+    for (int cb = nblk - 1; cb >= 0; --cb) {
+        if (tid < NB) {
+            double acc = 0;
+#pragma unroll
+            for (int q = 0; q < NB; ++q) acc = __builtin_fma(Linv_ws[cb * NB * NB + q * NB + tid], rhs[cb * NB + q], acc);
+            xc[tid] = acc;
+        }
+        __syncthreads();
+        if (tid < NB) rhs[cb * NB + tid] = xc[tid];
+        if (tid < cb * NB) {
+            double acc = rhs[tid];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) acc = __builtin_fma(-A[tid * LDC + cb * NB + q], xc[q], acc);
+            rhs[tid] = acc;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 256) x[i] = rhs[i];
+    if (tid == 0) { *ok = failed ? 0.0 : 1.0; *stall = 0.0; }
+}
+
 __global__ void k_set_scalar(double* p, double v) { *p = v; }
 
 }  // namespace
@@ -755,6 +820,13 @@ void chol_init_device()
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bsolve_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_panel);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+}
+
+void chol_small_solve(const double* S, const double* y, double* x, int n, int ld, double* Linv_ws, double* ok, double* stall, hipStream_t st)
+{
+    const size_t lds_diag = ((size_t)TILE * LDC + 2 * NB * NB) * sizeof(double);
+    hipLaunchKernelGGL(k_small_solve, dim3(1), dim3(256), lds_diag, st, S, y, x, n, ld, Linv_ws, ok, stall);
 }
 
 // Right-looking factorisation.  Step k = one k_trsm_panel launch + one k_syrk_update launch; the diagonal

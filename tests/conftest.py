@@ -17,3 +17,14 @@ def hip_lib():
     """The product library; building it here would hide a missing artefact, so it must already exist."""
     from mageslam_amd import _lib
     return _lib.lib()
+
+
+def pytest_sessionstart(session):
+    """PyTorch-ROCm bundles its own HIP runtime, and in a process that also loads libmageslam_hip.so (system runtime) torch's
+    has to initialise first (mageslam_amd/_lib.py): some GPU tests only import torch after the first handle exists."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:       # noqa: CPU-only environments
+        pass
