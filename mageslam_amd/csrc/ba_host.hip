@@ -267,6 +267,7 @@ struct mage_ba {
     DevBuf<double> d_T_meas, d_T_w, d_T_out;
     int n_active_tethers = 0;
     DevBuf<int> d_queue;
+    void* h_pinned = nullptr; size_t h_pinned_bytes = 0;     // one pinned block (from the cache) holding the two mirrors below
     double* h_scal = nullptr;           // pinned mirror of d_scal
     DevBuf<PoseLmResult> d_pose_lm;     // pose-only problems: the record the one-launch solve leaves
     PoseLmResult* h_pose_lm = nullptr;  // pinned mirror
@@ -294,20 +295,39 @@ struct mage_ba {
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_p) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_x) if (e) (void)hipEventDestroy(e);
-        if (h_scal) (void)hipHostFree(h_scal);
-        if (h_pose_lm) (void)hipHostFree(h_pose_lm);
+        if (h_pinned) cached_pinned_release(h_pinned, h_pinned_bytes);      // parked, not freed: hipHostFree costs ~200 us
         cached_stream_release(device, stream);
     }
 };
 
 namespace {
 
+mage_status ensure_pinned_mirrors(mage_ba* h)
+{
+    if (h->h_pinned) return MAGE_OK;
+    const size_t off = (SC_COUNT * sizeof(double) + 255) & ~(size_t)255;
+    MAGE_TRY(cached_pinned_alloc(&h->h_pinned, off + sizeof(PoseLmResult), &h->h_pinned_bytes));
+    h->h_scal = static_cast<double*>(h->h_pinned);
+    h->h_pose_lm = reinterpret_cast<PoseLmResult*>(static_cast<char*>(h->h_pinned) + off);
+    return MAGE_OK;
+}
+
+// events are created when first needed: the profiling ones only under mage_ba_enable_profiling, the exchange pair on the first
+// device-resident export / import -- a bundler per frame (the tracker) must not pay for ten event create / destroy pairs
+mage_status ensure_events(hipEvent_t* ev, int n, unsigned flags)
+{
+    for (int i = 0; i < n; ++i)
+        if (!ev[i]) MAGE_HIP(hipEventCreateWithFlags(&ev[i], flags));
+    return MAGE_OK;
+}
+
 mage_status download_state(const mage_ba* hc)
 {
     mage_ba* h = const_cast<mage_ba*>(hc);
     if (!h->state_on_device || h->host_state_fresh) return MAGE_OK;
     MAGE_DEVICE_SCOPE(h->device);
-    std::vector<double> pose(h->cams.size() * 8), pts(h->pt_set.size() * 4);
+    // fixed points never change on the device: only the poses come back then (the tracker's per-frame call)
+    std::vector<double> pose(h->cams.size() * 8), pts(h->points_fixed ? 0 : h->pt_set.size() * 4);
     if (!pose.empty()) MAGE_HIP(hipMemcpyAsync(pose.data(), h->d_pose[h->cur].p, pose.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (!pts.empty()) MAGE_HIP(hipMemcpyAsync(pts.data(), h->d_pt[h->cur].p, pts.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     MAGE_HIP(hipStreamSynchronize(h->stream));
@@ -315,7 +335,7 @@ mage_status download_state(const mage_ba* hc)
         for (int a = 0; a < 4; ++a) h->cams[i].q[a] = pose[i * 8 + a];
         for (int a = 0; a < 3; ++a) h->cams[i].t[a] = pose[i * 8 + 4 + a];
     }
-    for (size_t i = 0; i < h->pt_set.size(); ++i)
+    for (size_t i = 0; i * 4 < pts.size(); ++i)
         for (int a = 0; a < 3; ++a) h->pts[i * 3 + a] = pts[i * 4 + a];
     h->host_state_fresh = true;
     return MAGE_OK;
@@ -332,24 +352,32 @@ mage_status before_host_edit(mage_ba* h)
     return MAGE_OK;
 }
 
-mage_status upload_state(mage_ba* h)
+// `arena` non-null: the staging copies live in the caller's pinned arena and the caller synchronises before releasing it (the
+// structure build does, once, for all its uploads); null: staged locally and synchronised here.
+mage_status upload_state(mage_ba* h, PinnedArena* arena = nullptr)
 {
     const size_t nc = h->cams.size(), np = h->pt_set.size();
-    std::vector<double> pose(nc * 8, 0.0), K(nc * 4, 0.0), pts(np * 4, 0.0);
+    PinnedArena local;
+    PinnedArena& A = arena ? *arena : local;
+    double *pose = nullptr, *K = nullptr, *pts = nullptr;
+    MAGE_TRY(A.take(nc * 8 + 1, &pose)); MAGE_TRY(A.take(nc * 4 + 1, &K)); MAGE_TRY(A.take(np * 4 + 1, &pts));
     for (size_t i = 0; i < nc; ++i) {
         const HostCam& c = h->cams[i];
         for (int a = 0; a < 4; ++a) pose[i * 8 + a] = c.q[a];
         for (int a = 0; a < 3; ++a) pose[i * 8 + 4 + a] = c.t[a];
-        K[i * 4] = c.f; K[i * 4 + 1] = c.cx; K[i * 4 + 2] = c.cy;
+        pose[i * 8 + 7] = 0.0;
+        K[i * 4] = c.f; K[i * 4 + 1] = c.cx; K[i * 4 + 2] = c.cy; K[i * 4 + 3] = 0.0;
     }
-    for (size_t i = 0; i < np; ++i)
+    for (size_t i = 0; i < np; ++i) {
         for (int a = 0; a < 3; ++a) pts[i * 4 + a] = h->pts[i * 3 + a];
-    for (int b = 0; b < 2; ++b) {
-        MAGE_TRY(h->d_pose[b].upload(pose.data(), pose.size(), h->stream));
-        MAGE_TRY(h->d_pt[b].upload(pts.data(), pts.size(), h->stream));
+        pts[i * 4 + 3] = 0.0;
     }
-    MAGE_TRY(h->d_camK.upload(K.data(), K.size(), h->stream));
-    MAGE_HIP(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < 2; ++b) {
+        MAGE_TRY(h->d_pose[b].upload(pose, nc * 8, h->stream));
+        MAGE_TRY(h->d_pt[b].upload(pts, np * 4, h->stream));
+    }
+    MAGE_TRY(h->d_camK.upload(K, nc * 4, h->stream));
+    if (!arena) MAGE_HIP(hipStreamSynchronize(h->stream));
     h->cur = 0;
     h->state_on_device = true;
     h->host_state_fresh = true;
@@ -410,7 +438,10 @@ mage_status initialize_optimization(mage_ba* h)
     PhaseTimer tm;
     MAGE_DEVICE_SCOPE(h->device);
     const int nc = (int)h->cams.size(), np = (int)h->pt_set.size();
-    if (!h->state_on_device) MAGE_TRY(upload_state(h));
+    // Lists that go to the device are built in pinned memory and copied as soon as they are complete, so the DMA overlaps
+    // the rest of the build; small ones are staged through the same arena.  ONE synchronisation at the end releases it.
+    PinnedArena arena;
+    if (!h->state_on_device) MAGE_TRY(upload_state(h, &arena));
     else {
         // Trials only write the entities that are in the system, and accepting a trial swaps the two
         // state buffers; an entity that just left the system (all its observations removed) must
@@ -462,9 +493,6 @@ mage_status initialize_optimization(mage_ba* h)
     h->useless = (nfc + (points_free ? nlm : 0)) == 0;
 
     tm.mark("active sets");
-    // Lists that go to the device are built in pinned memory and copied as soon as they are complete, so the DMA overlaps
-    // the rest of the build; small ones are staged through the same arena.
-    PinnedArena arena;
     hipStream_t st = h->stream;
     auto push = [&](auto& dbuf, const auto* src, size_t count) -> mage_status {
         MAGE_TRY(dbuf.reserve(count));
@@ -733,7 +761,7 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(h->d_flagL.reserve((size_t)nL + 1));
     MAGE_TRY(h->d_L_active.reserve((size_t)nL + 1));
     MAGE_HIP(hipMemsetAsync(h->d_L_active.p, 1, (size_t)nL + 1, st));
-    if (!h->h_scal) MAGE_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), SC_COUNT * sizeof(double)));
+    MAGE_TRY(ensure_pinned_mirrors(h));
     MAGE_HIP(hipMemsetAsync(h->d_errL.p, 0, ((size_t)nL * 2 + 2) * sizeof(double), st));
     MAGE_HIP(hipStreamSynchronize(st));   // the pinned arena goes back to the cache
 
@@ -996,9 +1024,7 @@ MAGE_EXPORT mage_status mage_ba_create(const mage_ba_params* params, mage_ba** o
         h->points_fixed = params ? params->are_points_fixed != 0 : false;
         MAGE_DEVICE_SCOPE(dev);
         MAGE_TRY(cached_stream_acquire(dev, &h->stream));
-        for (auto& e : h->ev) MAGE_HIP(hipEventCreate(&e));
-        for (auto& e : h->ev_p) MAGE_HIP(hipEventCreate(&e));
-        for (auto& e : h->ev_x) MAGE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        MAGE_HIP(hipEventCreateWithFlags(&h->ev[3], hipEventDisableTiming));       // the scalar read-back's event; the others: ensure_events
         chol_init_device();
         ba_small_init_device();
         *out = h.release();
@@ -1290,7 +1316,7 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
                     for (size_t it = 0; it < n_iter; ++it) a.huber[it] = huber[it];
                     a.max_err_sq = (double)max_err_sq; a.lambda = h->lambda; a.user_lambda = h->user_lambda; a.ni = h->ni; a.iteration = h->iteration;
                     MAGE_TRY(h->d_pose_lm.reserve(1));
-                    if (!h->h_pose_lm) MAGE_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_pose_lm), sizeof(PoseLmResult)));
+                    MAGE_TRY(ensure_pinned_mirrors(h));
                     ba_launch_pose_lm(v, a, h->d_pose_lm.p, h->d_flagL.p, h->stream);
                     MAGE_HIP(hipMemcpyAsync(h->h_pose_lm, h->d_pose_lm.p, sizeof(PoseLmResult), hipMemcpyDeviceToHost, h->stream));
                     MAGE_HIP(hipEventRecord(h->ev[3], h->stream));
@@ -1385,6 +1411,7 @@ MAGE_EXPORT mage_status mage_ba_bind_pose_exchange(mage_ba* h, size_t n_export, 
 // zero-fill cannot overtake an import that still reads the block).  Two events, no host synchronisation.
 static mage_status join_before(mage_ba* h, void* stream)
 {
+    MAGE_TRY(ensure_events(h->ev_x, 2, hipEventDisableTiming));
     if (stream != (void*)h->stream) {          // NULL is the device's null stream: the handle's stream is non-blocking, so it must be joined explicitly too
         MAGE_HIP(hipEventRecord(h->ev_x[0], static_cast<hipStream_t>(stream)));
         MAGE_HIP(hipStreamWaitEvent(h->stream, h->ev_x[0], 0));
@@ -1520,6 +1547,10 @@ MAGE_EXPORT mage_status mage_ba_get_iter_stats(const mage_ba* h, mage_ba_iter_st
 MAGE_EXPORT mage_status mage_ba_enable_profiling(mage_ba* h, int enable)
 {
     if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+    if (enable) {
+        DeviceScope scope(h->device);
+        if (ensure_events(h->ev, 3, hipEventDefault) != MAGE_OK || ensure_events(h->ev_p, 4, hipEventDefault) != MAGE_OK) return MAGE_ERR_DEVICE;
+    }
     h->profiling = enable != 0;
     h->prof.n_factorizations = 0; h->prof.factor_ms_total = 0; h->prof.schur_launches = 0; h->prof.schur_ms_total = 0;
     h->prof.linearize_launches = 0; h->prof.linearize_ms_total = 0; h->prof.update_launches = 0; h->prof.update_ms_total = 0;

@@ -155,7 +155,9 @@ WORKER = textwrap.dedent("""
     info = D.rank_info()
     dist = D.init("gloo", info)
     m, mse = _run("hip", 4, 5, rank=info.rank, world=info.world, dist=dist)
-    print(json.dumps(dict(rank=info.rank, sha=_sha(m.pose_block()), mine=m.mine, on_device=m.on_device)))
+    import os
+    with open(os.path.join(os.environ["MAGE_TEST_OUT"], "rank%%d.json" %% info.rank), "w") as f:      # not stdout: two ranks' lines can interleave
+        json.dump(dict(rank=info.rank, sha=_sha(m.pose_block()), mine=m.mine, on_device=m.on_device), f)
     dist.barrier(); dist.destroy_process_group()
 """) % (ROOT, os.path.join(ROOT, "tests"))
 
@@ -167,9 +169,10 @@ def test_two_ranks_sharing_the_gpu_equal_one_rank_bit_for_bit(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=600)
+                        "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, MAGE_TEST_OUT=str(tmp_path)))
     assert p.returncode == 0, p.stderr[-3000:]
-    outs = sorted((json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+    outs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
     assert [o["mine"] for o in outs] == [[0, 1], [2, 3]] and all(o["on_device"] for o in outs)
     assert outs[0]["sha"] == want and outs[1]["sha"] == want
 

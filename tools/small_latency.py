@@ -35,6 +35,16 @@ def main():
     ts = [local_ba() for _ in range(n)]
     out["local_ms_per_lm_iteration"] = 1e3 * sum(t for t, _, _ in ts) / (10 * n)
     out["local_rmse_px"] = float(np.sqrt(ts[-1][1])); out["local_outliers"] = ts[-1][2]
+    # steady state: the LM iteration alone (structure built, no outlier removed, no re-seed of lambda)
+    b = BundlerLib(False, device=0)
+    load_scene(b, scene.make_config("local"), bulk=True)
+    b.StepBundleAdjustment([0.9], 1e30, [])
+    t0 = time.perf_counter()
+    for _ in range(6):
+        b.StepBundleAdjustment([0.9], 1e30, [])
+    out["local_steady_ms_per_lm_iteration"] = 1e3 * (time.perf_counter() - t0) / 6
+    out["local_steady_trials"] = [t["trials"] for t in b.trace()]
+    b.close()
     n = 200
     # pose-only: one free camera observing 200 fixed points
     p = scene.make_scene(n_cams=1, n_pts=200, n_obs=200, seed=0x5EED0A77, fixed=())
