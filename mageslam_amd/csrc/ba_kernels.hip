@@ -211,8 +211,9 @@ __global__ __launch_bounds__(256) void k_linearize_lm(BaDeviceView v, double del
         const int slot = v.L_slot[i];
         if (slot != cur_slot) {
             if (cur_slot >= 0) {
+                double2* Wd = reinterpret_cast<double2*>(v.W + (size_t)cur_slot * 18);        // 144-byte block, 16-byte aligned: nine 128-bit stores
 #pragma unroll
-                for (int k = 0; k < 18; ++k) { v.W[(size_t)cur_slot * 18 + k] = Wacc[k]; Wacc[k] = 0; }
+                for (int k = 0; k < 9; ++k) { Wd[k] = make_double2(Wacc[2 * k], Wacc[2 * k + 1]); Wacc[2 * k] = 0; Wacc[2 * k + 1] = 0; }
             }
             cur_slot = slot;
         }
@@ -247,8 +248,9 @@ __global__ __launch_bounds__(256) void k_linearize_lm(BaDeviceView v, double del
         }
     }
     if (cur_slot >= 0) {
+        double2* Wd = reinterpret_cast<double2*>(v.W + (size_t)cur_slot * 18);
 #pragma unroll
-        for (int k = 0; k < 18; ++k) v.W[(size_t)cur_slot * 18 + k] = Wacc[k];
+        for (int k = 0; k < 9; ++k) Wd[k] = make_double2(Wacc[2 * k], Wacc[2 * k + 1]);
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) v.V[(size_t)l * 6 + k] = V[k];
@@ -507,9 +509,13 @@ __global__ __launch_bounds__(256) void k_schur_rhs(BaDeviceView v)
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
     for (int idx = v.camS_ptr[hc] + first; idx < v.camS_ptr[hc + 1]; idx += stride) {
         const int s = v.camS[idx];
-        const double* W = v.W + (size_t)s * 18;
-        const double* db = v.db + (size_t)v.w_lm[s] * 4;
-        const double d0 = db[0], d1 = db[1], d2 = db[2];
+        const double2* W2 = reinterpret_cast<const double2*>(v.W + (size_t)s * 18);
+        const double2* db2 = reinterpret_cast<const double2*>(v.db + (size_t)v.w_lm[s] * 4);
+        double W[18];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { const double2 t = W2[k]; W[2 * k] = t.x; W[2 * k + 1] = t.y; }
+        const double2 da = db2[0];
+        const double d0 = da.x, d1 = da.y, d2 = db2[1].x;
 #pragma unroll
         for (int r = 0; r < 6; ++r) acc[r] += W[r * 3] * d0 + W[r * 3 + 1] * d1 + W[r * 3 + 2] * d2;
     }
@@ -546,8 +552,13 @@ __global__ __launch_bounds__(256) void k_backsub(BaDeviceView v, double lambda)
         const double b0 = v.bp[(size_t)l * 4], b1 = v.bp[(size_t)l * 4 + 1], b2 = v.bp[(size_t)l * 4 + 2];
         double c0 = b0, c1 = b1, c2 = b2;
         for (int s = v.lm_wptr[l]; s < v.lm_wptr[l + 1]; ++s) {
-            const double* W = v.W + (size_t)s * 18;
-            const double* x = v.xc + (size_t)v.w_hc[s] * 6;
+            const double2* W2 = reinterpret_cast<const double2*>(v.W + (size_t)s * 18);
+            const double2* x2 = reinterpret_cast<const double2*>(v.xc + (size_t)v.w_hc[s] * 6);
+            double W[18], x[6];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { const double2 t = W2[k]; W[2 * k] = t.x; W[2 * k + 1] = t.y; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const double2 t = x2[k]; x[2 * k] = t.x; x[2 * k + 1] = t.y; }
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
                 const double mx = -x[r];
@@ -797,8 +808,9 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
                 const int slot = v.L_slot[i];
                 if (slot != cur_slot) {
                     if (cur_slot >= 0) {
+                        double2* Wd = reinterpret_cast<double2*>(v.W + (size_t)cur_slot * 18);        // 144-byte block, 16-byte aligned: nine 128-bit stores
 #pragma unroll
-                        for (int k = 0; k < 18; ++k) { v.W[(size_t)cur_slot * 18 + k] = Wacc[k]; Wacc[k] = 0; }
+                        for (int k = 0; k < 9; ++k) { Wd[k] = make_double2(Wacc[2 * k], Wacc[2 * k + 1]); Wacc[2 * k] = 0; Wacc[2 * k + 1] = 0; }
                     }
                     cur_slot = slot;
                 }
@@ -835,8 +847,9 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
                 }
             }
             if (cur_slot >= 0) {
+                double2* Wd = reinterpret_cast<double2*>(v.W + (size_t)cur_slot * 18);
 #pragma unroll
-                for (int k = 0; k < 18; ++k) v.W[(size_t)cur_slot * 18 + k] = Wacc[k];
+                for (int k = 0; k < 9; ++k) Wd[k] = make_double2(Wacc[2 * k], Wacc[2 * k + 1]);
             }
 #pragma unroll
             for (int k = 0; k < 6; ++k) v.V[(size_t)l * 6 + k] = V[k];
@@ -1034,8 +1047,13 @@ __global__ __launch_bounds__(256) void k_small_update(BaDeviceView v, double lam
             const double b0 = v.bp[(size_t)l * 4], b1 = v.bp[(size_t)l * 4 + 1], b2 = v.bp[(size_t)l * 4 + 2];
             double c0 = b0, c1 = b1, c2 = b2;
             for (int s = v.lm_wptr[l]; s < v.lm_wptr[l + 1]; ++s) {
-                const double* W = v.W + (size_t)s * 18;
-                const double* xx = v.xc + (size_t)v.w_hc[s] * 6;
+                const double2* W2 = reinterpret_cast<const double2*>(v.W + (size_t)s * 18);
+                const double2* x2 = reinterpret_cast<const double2*>(v.xc + (size_t)v.w_hc[s] * 6);
+                double W[18], xx[6];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { const double2 t = W2[k]; W[2 * k] = t.x; W[2 * k + 1] = t.y; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const double2 t = x2[k]; xx[2 * k] = t.x; xx[2 * k + 1] = t.y; }
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
                     const double mx = -xx[r];
