@@ -121,9 +121,8 @@ MAGE_EXPORT mage_status mage_orb_create(const mage_orb_params* params, mage_orb*
         if (p.nlevels > 1 && !(p.scale_factor > 1.0f)) return fail(MAGE_ERR_INVALID_ARGUMENT, "a pyramid needs ScaleFactor > 1");
         if (p.patch_size != 15 && p.patch_size != 31) {
             // the random pattern of ComputeOrbDescriptors (:452-492, :551-560): with angle 0 its rotation is the identity; with
-            // UseOrientation the sampling points go through libm cos / sin, which cannot be made bit-identical across hosts
+            // UseOrientation every keypoint rotates the points by its own angle (k_brief_rotated)
             if (p.patch_size < 2 || p.patch_size > 127) return fail(MAGE_ERR_INVALID_ARGUMENT, "patch size %u out of range 2 .. 127", p.patch_size);
-            if (p.use_orientation) return fail(MAGE_ERR_UNSUPPORTED, "UseOrientation with patch size %u (random pattern rotated through libm): only 15 and 31 have pre-rotated tables", p.patch_size);
         }
         if (p.gaussian_kernel_size > 15 || (p.gaussian_kernel_size > 1 && p.gaussian_kernel_size % 2 == 0))
             return fail(MAGE_ERR_INVALID_ARGUMENT, "Gaussian kernel size must be odd and <= 15");
@@ -213,7 +212,8 @@ mage_status run_level(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[2], st));
     orb_launch_blur(d_images, w, h_img, stride, frame_stride, n_frames, h->taps, io.blur, wp, st);
     if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[3], st));
-    if (io.capacity > 0) orb_launch_brief(io.blur, wp, h_img, n_frames, io.kp, io.count, io.capacity, h->d_pattern.p, io.desc, st);
+    if (io.capacity > 0) orb_launch_brief(io.blur, wp, h_img, n_frames, io.kp, io.count, io.capacity, h->d_pattern.p, io.desc,
+                                          P.use_orientation && P.patch_size != 15 && P.patch_size != 31, st);
     if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[4], st));
     return MAGE_OK;
 }

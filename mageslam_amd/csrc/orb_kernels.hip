@@ -806,6 +806,38 @@ __global__ __launch_bounds__(256) void k_ic_angles(const uint8_t* __restrict__ i
 // BRIEF-256: one wavefront per keypoint; lane l evaluates pairs 4l..4l+3, two lanes make a byte.
 // ---------------------------------------------------------------------------------------------
 constexpr int BRIEF_KPW = 4;      // keypoints per wavefront: their 32 pixel loads are in flight together, the pattern row is fetched once
+// ComputeOrbDescriptors (OpenCVModified.cpp:452-492): patch sizes without a pre-rotated table together with UseOrientation --
+// every keypoint rotates the 512 random points by its own angle: a = (float)cos(angle), b = (float)sin(angle) (taken in double and
+// rounded to float: the pinned choice of oracle/orb_oracle.c), x' = cvRound(x a - y b), y' = cvRound(x b + y a) in float, no FMA.
+// One wavefront per keypoint, four pairs per lane as in k_brief.
+__global__ __launch_bounds__(256) void k_brief_rotated(const uint8_t* __restrict__ blurred, int wp, int h, const mage_keypoint* __restrict__ kps,
+                                                       const int* __restrict__ counts, int capacity, const signed char* __restrict__ pattern,
+                                                       uint8_t* __restrict__ desc)
+{
+#pragma clang fp contract(off)
+    const int f = blockIdx.y, k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= counts[f]) return;
+    const mage_keypoint kp = kps[(size_t)f * capacity + k];
+    const uint8_t* c = blurred + (size_t)f * wp * h + (size_t)((int)rintf(kp.y)) * wp + (int)rintf(kp.x);
+    float ang = kp.angle;
+    ang = ang * (float)(3.14159265358979323846 / 180.0);
+    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+    const int4 pr = *reinterpret_cast<const int4*>(pattern + lane * 16);
+    const int w4[4] = { pr.x, pr.y, pr.z, pr.w };
+    int nib = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = (float)(int)(signed char)(w4[q] & 0xff), y0 = (float)(int)(signed char)((w4[q] >> 8) & 0xff);
+        const float x1 = (float)(int)(signed char)((w4[q] >> 16) & 0xff), y1 = (float)(int)(signed char)((w4[q] >> 24) & 0xff);
+        const float rx0 = x0 * a - y0 * b, ry0 = x0 * b + y0 * a, rx1 = x1 * a - y1 * b, ry1 = x1 * b + y1 * a;
+        const int t0 = c[(int)rintf(ry0) * wp + (int)rintf(rx0)];
+        const int t1 = c[(int)rintf(ry1) * wp + (int)rintf(rx1)];
+        nib |= (t0 < t1) << q;
+    }
+    const int hi = __shfl_down(nib, 1, 64);
+    if ((lane & 1) == 0) desc[((size_t)f * capacity + k) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+}
+
 __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blurred, int wp, int h, const mage_keypoint* __restrict__ kps,
                                                const int* __restrict__ counts, int capacity, const signed char* __restrict__ pattern,
                                                uint8_t* __restrict__ desc)
@@ -902,9 +934,10 @@ void orb_launch_angles(const uint8_t* img, int stride, size_t frame_stride, int 
 }
 
 void orb_launch_brief(const uint8_t* blurred, int wp, int h, int n_frames, const mage_keypoint* kps, const int* counts, int capacity,
-                      const signed char* pattern, uint8_t* desc, hipStream_t st)
+                      const signed char* pattern, uint8_t* desc, bool rotate_random, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_brief, dim3(cdiv(capacity, 4 * BRIEF_KPW), n_frames), dim3(256), 0, st, blurred, wp, h, kps, counts, capacity, pattern, desc);
+    if (rotate_random) hipLaunchKernelGGL(k_brief_rotated, dim3(cdiv(capacity, 4), n_frames), dim3(256), 0, st, blurred, wp, h, kps, counts, capacity, pattern, desc);
+    else hipLaunchKernelGGL(k_brief, dim3(cdiv(capacity, 4 * BRIEF_KPW), n_frames), dim3(256), 0, st, blurred, wp, h, kps, counts, capacity, pattern, desc);
 }
 
 }  // namespace mage

@@ -252,8 +252,7 @@ def detect(img: np.ndarray, base_pattern: np.ndarray, **kw):
     blurred = [blur(im, P["gaussian_kernel_size"]) if P["gaussian_kernel_size"] > 1 else im for im in levels]
     if P["patch_size"] in (15, 31):
         table = expand_pattern(base_pattern).reshape(30, 256, 4)
-    else:                                           # random pattern: only the unrotated row exists (orientation is refused with it)
-        assert not P.get("use_orientation")
+    else:                                           # random pattern: the unrotated points; with orientation every keypoint rotates them itself
         table = np.zeros((30, 256, 4), np.int64); table[0] = random_pattern(P["patch_size"]).reshape(256, 4)
     if P.get("use_orientation"):
         ang = np.zeros(len(k), np.float32)
@@ -270,7 +269,19 @@ def detect(img: np.ndarray, base_pattern: np.ndarray, **kw):
         m = np.nonzero(octave == l)[0]
         if not len(m):
             continue
-        pat = table[inc[m]]                                                   # (n, 256, 4)
+        if P.get("use_orientation") and P["patch_size"] not in (15, 31):
+            # ComputeOrbDescriptors (OpenCVModified.cpp:452-492): float angle in radians, cos / sin rounded to float, points rotated in
+            # float32 and rounded half-to-even (cvRound)
+            f = np.float32
+            rad = ang[m] * f(np.pi / 180.0)
+            a = np.cos(rad.astype(np.float64)).astype(f)[:, None]; b_ = np.sin(rad.astype(np.float64)).astype(f)[:, None]
+            base = table[0].astype(f)                                             # (256, 4): x0 y0 x1 y1
+            def rot(px, py):
+                return np.rint(px[None, :] * a - py[None, :] * b_).astype(np.int64), np.rint(px[None, :] * b_ + py[None, :] * a).astype(np.int64)
+            x0, y0 = rot(base[:, 0], base[:, 1]); x1, y1 = rot(base[:, 2], base[:, 3])
+            pat = np.stack([x0, y0, x1, y1], axis=2)                               # (n, 256, 4)
+        else:
+            pat = table[inc[m]]                                                   # (n, 256, 4)
         xs, ys = k[m, 0][:, None], k[m, 1][:, None]
         bl = blurred[l]
         t0 = bl[ys + pat[:, :, 1], xs + pat[:, :, 0]]

@@ -77,7 +77,7 @@ ORBO_API void orbo_random_pattern(int patch, signed char* out /* 1024: x0 y0 x1 
 
 ORBO_API void orbo_pattern_expand(int patch, signed char* out /* 30 * 1024 */)
 {
-    if (patch != 15 && patch != 31) {                      /* random pattern, angle 0 only: row 0, the other rows are never selected */
+    if (patch != 15 && patch != 31) {                      /* random pattern: row 0 (the unrotated points); rotation, if any, is per keypoint */
         memset(out, 0, 30 * 1024);
         orbo_random_pattern(patch, out);
         return;
@@ -522,8 +522,8 @@ ORBO_API int orbo_detect(const orbo_params* P, const uint8_t* img, int w, int h,
 {
     *n_out = 0;
     /* other patch sizes take the random pattern (ComputeOrbDescriptors, :452-492); with angle 0 its rotation is the identity
-       (cos 0 = 1, sin 0 = 0 exactly), with UseOrientation it would go through libm's cos / sin: refused */
-    if (P->patch_size != 15 && P->patch_size != 31 && (P->use_orientation || P->patch_size < 2 || P->patch_size > 127)) return ORBO_UNSUPPORTED;
+       (cos 0 = 1, sin 0 = 0 exactly); with UseOrientation every keypoint rotates the 512 points by its own angle, see below */
+    if (P->patch_size != 15 && P->patch_size != 31 && (P->patch_size < 2 || P->patch_size > 127)) return ORBO_UNSUPPORTED;
     int lw[ORBO_MAX_LEVELS], lh[ORBO_MAX_LEVELS], nfeat[ORBO_MAX_LEVELS];
     float lscale[ORBO_MAX_LEVELS];
     if (orbo_level_layout(P, w, h, lw, lh, lscale, nfeat) != ORBO_OK) return ORBO_UNSUPPORTED;
@@ -598,6 +598,29 @@ ORBO_API int orbo_detect(const orbo_params* P, const uint8_t* img, int w, int h,
         const int l = kps[j].octave;
         const float inv = 1.f / lscale[l];                                             /* :521 */
         const uint8_t* center = blur[l] + (size_t)cv_round(kps[j].y * inv) * lw[l] + cv_round(kps[j].x * inv);
+        if (P->use_orientation && P->patch_size != 15 && P->patch_size != 31) {
+            /* ComputeOrbDescriptors (:452-492): angle in radians as float, a = (float)cos(angle), b = (float)sin(angle), every point
+               (x, y) -> (cvRound(x a - y b), cvRound(x b + y a)) in float.  PINNED CHOICE: cos / sin are taken in double and rounded to
+               float (the correctly rounded float cosine for all but ~1e-8 of the arguments); the reference's own value is whatever the
+               MSVC CRT's float overload returns -- unknowable here, and one ulp of a or b only matters when x a - y b falls within
+               1e-6 of a rounding boundary. */
+            float ang = kps[j].angle;
+            ang *= (float)(M_PI / 180.0);
+            const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+            const signed char* p = pat;
+            for (int i = 0; i < 32; ++i, p += 32) {
+                int val = 0;
+                for (int bit = 0; bit < 8; ++bit) {
+                    const float x0 = (float)p[4 * bit], y0 = (float)p[4 * bit + 1], x1 = (float)p[4 * bit + 2], y1 = (float)p[4 * bit + 3];
+                    const float rx0 = x0 * a - y0 * b, ry0 = x0 * b + y0 * a, rx1 = x1 * a - y1 * b, ry1 = x1 * b + y1 * a;
+                    int t0 = center[cv_round(ry0) * lw[l] + cv_round(rx0)];
+                    int t1 = center[cv_round(ry1) * lw[l] + cv_round(rx1)];
+                    val |= (t0 < t1) << bit;
+                }
+                desc32[j * 32 + i] = (uint8_t)val;
+            }
+            continue;
+        }
         const signed char* p = pat + (cv_round(kps[j].angle / 12.0f) % 30) * 1024;       /* angleIncrement (:523-532); 0 without orientation */
         for (int i = 0; i < 32; ++i, p += 32) {
             int val = 0;

@@ -137,7 +137,7 @@ def test_edge_cases_match_oracle():
 
 def test_unsupported_settings_are_refused():
     from mageslam_amd._lib import MageError
-    for kw in (dict(nlevels=17), dict(nlevels=2, scale_factor=1.0), dict(patch_size=21, use_orientation=1), dict(patch_size=200)):
+    for kw in (dict(nlevels=17), dict(nlevels=2, scale_factor=1.0), dict(patch_size=200)):
         with pytest.raises(MageError):
             OrbDetector(**kw)
 
@@ -383,4 +383,19 @@ def test_random_pattern_patch_sizes_golden_and_oracle(gold, patch):
     assert np.array_equal(np.stack([k["x"], k["y"], k["response"]], 1).astype(np.int64), g[f"rand{patch}_kp"])
     assert np.array_equal(d, g[f"rand{patch}_desc"])
     ko, do = O.orb_detect(img, O.OrbParams.defaults(patch_size=patch))
+    assert np.array_equal(k, ko) and np.array_equal(d, do)
+
+
+@pytest.mark.parametrize("patch,name,extra", [(21, "orb_160x120", {}), (9, "orb_640x480_a", {}), (27, "orb_640x480_b", dict(nlevels=2, scale_factor=1.5)),
+                                              (21, "orb_640x480_a", dict(nfeatures=1000, gaussian_kernel_size=5))])
+def test_random_pattern_with_orientation_matches_oracle(gold, patch, name, extra):
+    """ORB-9 with UseOrientation (ComputeOrbDescriptors, OpenCVModified.cpp:452-492) on the device: k_brief_rotated rotates the 512
+    random points per keypoint (float cos / sin of the intensity-centroid angle, float rotation, cvRound).  Keypoints, float32
+    angles and descriptors bit-exact against the C oracle (which tests/test_orb_oracle.py holds against the numpy twin)."""
+    img = gold[name + "_img"]
+    kw = dict(patch_size=patch, use_orientation=1, **extra)
+    okw = {"feature_factor_anms": "feature_factor"}
+    k, d = OrbDetector(default_params(**kw)).DetectAndCompute(img)
+    ko, do = O.orb_detect(img, O.OrbParams.defaults(**{okw.get(a, a): b for a, b in kw.items()}), cap=max(440, kw.get("nfeatures", 440)))
+    assert len(k) > 100
     assert np.array_equal(k, ko) and np.array_equal(d, do)

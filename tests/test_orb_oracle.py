@@ -118,7 +118,7 @@ def test_edge_cases():
 
 def test_unsupported_settings_are_refused():
     a = np.zeros((64, 64), np.uint8)
-    for kw in (dict(nlevels=17), dict(patch_size=21, use_orientation=1), dict(patch_size=200)):
+    for kw in (dict(nlevels=17), dict(patch_size=200)):
         with pytest.raises(NotImplementedError):
             O.orb_detect(a, O.OrbParams.defaults(**kw))
 
@@ -344,3 +344,20 @@ def test_random_pattern_patch_sizes_match_golden(gold, patch):
     k, d = O.orb_detect(gold["orb_160x120_img"], O.OrbParams.defaults(patch_size=patch))
     assert np.array_equal(kp_xyr(k), g[f"rand{patch}_kp"]) and np.array_equal(d, g[f"rand{patch}_desc"])
     assert np.all(k["size"] == patch)
+
+
+@pytest.mark.parametrize("patch", [21, 9, 27])
+def test_random_pattern_with_orientation_matches_the_numpy_twin(gold, patch):
+    """ORB-9 with UseOrientation (ComputeOrbDescriptors, OpenCVModified.cpp:452-492): every keypoint rotates the 512 random points by
+    its own intensity-centroid angle -- float cos / sin (taken in double, rounded to float: the pinned choice), float rotation,
+    cvRound.  The C oracle against the independent numpy implementation (oracle/indep/orb_numpy.py), keypoints / angles / descriptors
+    bit for bit."""
+    from oracle.indep import orb_numpy as N
+    img = gold["orb_160x120_img"]
+    kn, dn, _, an = N.detect(img, None, patch_size=patch, use_orientation=1)      # no base table: the random pattern is generated
+    k, d = O.orb_detect(img, O.OrbParams.defaults(patch_size=patch, use_orientation=1))
+    assert len(k) > 50
+    assert np.array_equal(kp_xyr(k), kn[:, :3]) and np.array_equal(k["angle"], an) and np.array_equal(d, dn)
+    # and the rotation really is per keypoint: the descriptors differ from the unrotated ones wherever the angle is not ~0
+    _, d0 = O.orb_detect(img, O.OrbParams.defaults(patch_size=patch))
+    assert (d != d0[: len(d)]).any()
