@@ -1188,8 +1188,8 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView v, PoseLmArgs a, P
 {
     __shared__ double sm[4];
     __shared__ double part[4][28];
-    __shared__ double s_chi, s_scale, s_lambda, s_ni, s_rho, s_cur_chi;
-    __shared__ int s_ok, s_go, s_accept;
+    __shared__ double s_lambda, s_ni, s_rho, s_cur_chi;
+    __shared__ int s_ok, s_accept;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double lambda = a.lambda, ni = a.ni;
     int iteration = a.iteration, n_stats = 0, flips = 0, cont = 1;

@@ -85,9 +85,11 @@ struct mage_orb {
     mage_orb_params P{};
     OrbTaps taps{};
     DevBuf<signed char> d_pattern;
-    DevBuf<uint8_t> d_img, d_score, d_rawscore, d_blur, d_desc;     // d_score: kept map (NMS survivors); d_rawscore: FAST scores of frame 0 (parity tests)
-    DevBuf<int> d_wg_count, d_wg_off, d_hist, d_n_raw, d_cell_start, d_cell_fill, d_cell_members, d_radius, d_count;
-    DevBuf<int2> d_raw, d_cand;
+    DevBuf<uint8_t> d_img, d_rawscore, d_blur, d_desc;     // d_rawscore: FAST scores of frame 0 (parity tests)
+    DevBuf<int> d_n_raw, d_cell_start, d_cell_fill, d_count;   // d_n_raw: per-frame cursor of d_raw; zero between calls (k_select leaves it so)
+    size_t n_raw_zeroed = 0;                                   // entries of d_n_raw known to be zero
+    DevBuf<int2> d_raw, d_cand;                                // d_cand, d_key: scratch of k_select for frames whose working set exceeds LDS
+    DevBuf<unsigned long long> d_key;
     DevBuf<mage_keypoint> d_kp, d_undist, d_kp_lvl;
     DevBuf<uint8_t> d_pyr[2], d_blur_lvl, d_desc_lvl;      // pyramid levels >= 1 (ping-pong), their blurred image and per-level outputs
     DevBuf<int> d_count_lvl;
@@ -149,8 +151,6 @@ MAGE_EXPORT void mage_orb_destroy(mage_orb* h) { delete h; }
 
 namespace {
 
-constexpr int NMS_ROWS = ORB_BAND_ROWS;
-
 // Where one level's stages leave their results and with which quota.
 struct LevelIO {
     int nfeatures;            // quota of the level (ComputeKeyPoints: nfeaturesPerLevel)
@@ -167,34 +167,31 @@ mage_status run_level(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     const mage_orb_params& P = h->P;
     hipStream_t st = h->stream;
     const int wp = (w + 3) & ~3;                     // internal row pitch (score map, blurred image)
-    const size_t npx = (size_t)wp * h_img;
     const size_t raw_cap = (size_t)w * h_img / 4 + 16;
-    const int n_wg = (h_img + NMS_ROWS - 1) / NMS_ROWS;
     const int ncells = P.num_cells_x * P.num_cells_y;
     const size_t nf = (size_t)std::max(n_frames, 1);
-    MAGE_TRY(h->d_score.reserve(nf * npx));
-    MAGE_TRY(h->d_wg_count.reserve(nf * n_wg));
-    MAGE_TRY(h->d_wg_off.reserve(nf * n_wg));
-    MAGE_TRY(h->d_hist.reserve(nf * 256));
     MAGE_TRY(h->d_n_raw.reserve(nf));
+    if (h->n_raw_zeroed != h->d_n_raw.cap) {             // a fresh (recycled) allocation: zero every cursor once; the kernels keep them at zero
+        MAGE_HIP(hipMemsetAsync(h->d_n_raw.p, 0, sizeof(int) * h->d_n_raw.cap, st));
+        h->n_raw_zeroed = h->d_n_raw.cap;
+    }
     MAGE_TRY(h->d_raw.reserve(nf * raw_cap));
     MAGE_TRY(h->d_cand.reserve(nf * raw_cap));
+    MAGE_TRY(h->d_key.reserve(nf * raw_cap));
     MAGE_TRY(h->d_cell_start.reserve(nf * (ncells + 1)));
     MAGE_TRY(h->d_cell_fill.reserve(nf * (ncells + 1)));
-    MAGE_TRY(h->d_cell_members.reserve(nf * raw_cap));
-    MAGE_TRY(h->d_radius.reserve(nf * raw_cap));
 
     if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[0], st));
     // RunByImageBorder: half the patch, or its hypotenuse when the patch gets rotated (OpenCVModified.cpp:709-712)
     const int half_patch = (int)P.patch_size / 2;
     const int border = P.use_orientation ? (int)std::ceil((float)half_patch * std::sqrt(2.0f)) : half_patch;
-    orb_launch_fast(d_images, w, h_img, stride, frame_stride, n_frames, (int)std::min(P.fast_threshold, 255u), border, h->d_score.p, io.raw_frame0, wp,
-                    h->d_hist.p, h->d_wg_count.p, n_wg, st);
+    orb_launch_fast(d_images, w, h_img, stride, frame_stride, n_frames, (int)std::min(P.fast_threshold, 255u), border, io.raw_frame0, wp,
+                    h->d_raw.p, raw_cap, h->d_n_raw.p, st);
     if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[1], st));
-    orb_launch_collect(h->d_score.p, w, h_img, wp, n_frames, border, NMS_ROWS, n_wg, h->d_wg_count.p, h->d_wg_off.p, h->d_n_raw.p, h->d_raw.p, raw_cap, st);
     OrbSelectArgs a{};
-    a.raw = h->d_raw.p; a.n_raw = h->d_n_raw.p; a.hist = h->d_hist.p;
-    a.cand = h->d_cand.p; a.cell_start = h->d_cell_start.p; a.cell_fill = h->d_cell_fill.p; a.cell_members = h->d_cell_members.p; a.radius = h->d_radius.p;
+    a.raw = h->d_raw.p; a.n_raw = h->d_n_raw.p;
+    a.cand = h->d_cand.p; a.cand64 = reinterpret_cast<unsigned long long*>(h->d_cand.p); a.key64 = h->d_key.p;
+    a.cell_start = h->d_cell_start.p; a.cell_fill = h->d_cell_fill.p;
     a.out_kp = io.kp; a.out_count = io.count;
     a.raw_cap = raw_cap; a.ncells = ncells; a.cells_x = P.num_cells_x; a.cells_y = P.num_cells_y;
     a.nfeatures = io.nfeatures; a.max_num = (int)((float)io.nfeatures * P.feature_factor_anms);

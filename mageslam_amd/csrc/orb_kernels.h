@@ -11,8 +11,8 @@ namespace mage {
 struct OrbTaps { int radius; int t[15]; };          // 8-bit fixed-point Gaussian taps (sum ~ 256), radius <= 7
 
 struct OrbSelectArgs {
-    const int2* raw; const int* n_raw; const int* hist;      // per frame: raster-ordered (x | y << 16, response), count, 256-bin histogram
-    int2* cand; int* cell_start; int* cell_fill; int* cell_members; int* radius;   // scratch, per frame
+    const int2* raw; int* n_raw;                              // per frame: (x | y << 16, response) in no particular order, count (reset to 0 by k_select)
+    int2* cand; unsigned long long* cand64; unsigned long long* key64; int* cell_start; int* cell_fill;   // scratch in HBM for oversized frames, per frame
     mage_keypoint* out_kp; int* out_count;
     size_t raw_cap;
     int ncells, cells_x, cells_y;
@@ -20,14 +20,12 @@ struct OrbSelectArgs {
     float feature_strength, min_robust, max_robust;
 };
 
-// wp = internal row pitch of the score map / blurred image (w rounded up to 4)
+// wp = internal row pitch of the blurred image / raw score map (w rounded up to 4)
 constexpr int ORB_MAX_LEVELS = 16;   // pyramid depth accepted by mage_orb_create
-constexpr int ORB_BAND_ROWS = 48;    // image rows per tile row of k_fast_nms = per band of the raster-order emit pass
-// FAST + NMS + border cull: kept map (score where a keypoint survives), raw scores of frame 0 (optional), histogram, per-band counts
-void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, int border, uint8_t* kept,
-                     uint8_t* raw_frame0, int wp, int* hist, int* band_count, int n_bands, hipStream_t st);
-void orb_launch_collect(const uint8_t* kept, int w, int h, int wp, int n_frames, int border, int rows_per_wg, int n_wg, int* wg_count, int* wg_off,
-                        int* n_raw, int2* raw, size_t raw_cap, hipStream_t st);
+// FAST + NMS + border cull: appends the keypoints of every frame to raw[frame] (cursor n_raw[frame], which must be 0 on entry);
+// raw scores of frame 0 (optional, parity tests)
+void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, int border, uint8_t* raw_frame0, int wp,
+                     int2* raw, size_t raw_cap, int* n_raw, hipStream_t st);
 // cv::resize(INTER_LINEAR) of n_frames u8 images (OpenCV 3.4.0 fixed-point arithmetic) and the per-frame concatenation of a level's results
 void orb_launch_resize(const uint8_t* src, int sw, int sh, int sstride, size_t sframe, uint8_t* dst, int dw, int dh, int dpitch, size_t dframe, int n_frames,
                        hipStream_t st);

@@ -21,7 +21,20 @@ namespace {
 // brighter rings; a pixel is a corner iff that maximum exceeds the threshold, and its score is maximum - 1
 // (identical to the reference's threshold-table pre-test + min/max ladder, which computes the same quantity).
 // ---------------------------------------------------------------------------------------------
-constexpr int FT_W = 64, FT_H = ORB_BAND_ROWS;   // 3072 pixels per workgroup, 12 per thread: fat workgroups amortise the halo, the LDS clears and five barriers (480 rows = 10 bands)
+// Development probe (tools/orb_phase_probe.py builds a second library with -DMAGE_ORB_CLOCKS): shader-clock time per kernel
+// phase, summed over workgroups by thread 0.  Compiled out of the product library.
+#ifdef MAGE_ORB_CLOCKS
+__device__ unsigned long long g_orb_clk[32];
+// one workgroup in 64 is sampled, so the probe's own atomics do not queue up behind each other
+#define ORB_CLK_BEGIN() const bool clk_on = threadIdx.x == 0 && ((blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) & 63) == 0; \
+    unsigned long long clk_prev = clk_on ? __builtin_amdgcn_s_memtime() : 0ull; if (clk_on) atomicAdd(&g_orb_clk[31], 1ull)
+#define ORB_CLK(i) do { if (clk_on) { const unsigned long long clk_now = __builtin_amdgcn_s_memtime(); atomicAdd(&g_orb_clk[i], clk_now - clk_prev); clk_prev = clk_now; } } while (0)
+#else
+#define ORB_CLK_BEGIN() do { } while (0)
+#define ORB_CLK(i) do { } while (0)
+#endif
+
+constexpr int FT_W = 64, FT_H = 24;   // output tile of k_fast_keypoints: 640 x 480 = 10 x 20 workgroups per frame
 
 // The ring differences fit 16 bits, so the score runs on PACKED pairs: register k holds (d[k], d[k + 8]) -- a ring pixel and its
 // opposite.  A rotation of the ring by one position is "next register", and crossing position 7 -> 8 is a swap of the halves,
@@ -33,28 +46,42 @@ __device__ __forceinline__ short2_t swap16(short2_t v) { return __builtin_shuffl
 __device__ __forceinline__ short2_t pmin(short2_t a, short2_t b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ short2_t pmax(short2_t a, short2_t b) { return __builtin_elementwise_max(a, b); }
 
-__device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ c, int TP, int t)
+// the 16 ring differences v - ring[k] as packed opposite pairs: P[k] = (d[k], d[k + 8]), Q[k] = (d[k + 8], d[k])
+__device__ __forceinline__ void fast_ring(const uint8_t* __restrict__ c, int TP, short2_t (&P)[8], short2_t (&Q)[8])
 {
     const int v = c[0];
     const int ox[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
     const int oy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
-    short2_t P[8], Q[8];                                  // P[k] = (d[k], d[k+8]),  Q[k] = swapped = (d[k+8], d[k])
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int lo = v - (int)c[oy[k] * TP + ox[k]], hi = v - (int)c[oy[k + 8] * TP + ox[k + 8]];
         P[k] = (short2_t){ (short)lo, (short)hi };
         Q[k] = (short2_t){ (short)hi, (short)lo };
     }
-    // high-speed pre-test (a 9-arc always contains one pixel of every opposite pair): every pair needs a member > t (darker
-    // ring) or every pair a member < -t (brighter ring)
-    short2_t mx = pmax(P[0], Q[0]), mn = pmin(P[0], Q[0]);          // both halves equal: max / min of the pair
-    short2_t all_dark = mx, all_bright = mn;
+}
+
+// High-speed test on the whole ring: a 9-arc contains one pixel of every opposite pair, so a corner needs every pair to have a
+// member darker than the centre by more than t, or every pair a brighter one.  ~8 % of the pixels of a textured frame pass.
+__device__ __forceinline__ bool fast_pair_test(const uint8_t* __restrict__ c, int TP, int t)
+{
+    short2_t P[8], Q[8];
+    fast_ring(c, TP, P, Q);
+    short2_t all_dark = pmax(P[0], Q[0]), all_bright = pmin(P[0], Q[0]);     // both halves equal: max / min of the pair
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
         all_dark = pmin(all_dark, pmax(P[k], Q[k]));                 // smallest pair-maximum
         all_bright = pmax(all_bright, pmin(P[k], Q[k]));             // largest pair-minimum
     }
-    if (!((int)all_dark.x > t || (int)all_bright.x < -t)) return 0;
+    return (int)all_dark.x > t || (int)all_bright.x < -t;
+}
+
+// score = max over the 16 arcs of 9 contiguous ring pixels of the arc's minimum margin, for darker and for brighter rings; a
+// pixel is a corner iff that maximum exceeds the threshold, and its score is maximum - 1 (identical to the reference's
+// threshold-table pre-test + min/max ladder, which computes the same quantity).
+__device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ c, int TP, int t)
+{
+    short2_t P[8], Q[8];
+    fast_ring(c, TP, P, Q);
     // windowed minima / maxima by doubling: windows of 2, 4, 8 ring positions, then 9
     short2_t A2[8], B2[8], A4[8], B4[8], A8[8], B8[8];
 #pragma unroll
@@ -83,14 +110,20 @@ __device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ c, int 
     return m > t ? m - 1 : 0;
 }
 
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
 // Stage a (TH x TW)-byte window of the source image, top-left at (gx0, gy0) with gx0 a multiple of 4, into LDS with
-// 32-bit loads when the source allows it (row pitch and base 4-byte aligned), bytes otherwise.  `fill(gx, gy)` maps
-// out-of-image coordinates (zero padding for FAST, reflection for the blur).
+// 32-bit loads when the source allows it (row pitch and base 4-byte aligned), bytes otherwise.  Out-of-image coordinates are
+// zero (FAST) or reflected (the blur).
 template <int TW, int TH, int TP, bool REFLECT>
 __device__ __forceinline__ void stage_window(uint8_t* __restrict__ tile, const uint8_t* __restrict__ I, int w, int h, int stride, int gx0, int gy0,
                                              int tw, int th)
 {
-    auto rx = [&](int p, int n) { if (n == 1) return 0; while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p; return p; };
     const bool aligned = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(I) & 3) == 0);
     const int nq = tw / 4;                              // tw is a multiple of 4
     for (int e = threadIdx.x; e < th * nq; e += 256) {
@@ -99,7 +132,7 @@ __device__ __forceinline__ void stage_window(uint8_t* __restrict__ tile, const u
         int gy = gy0 + ty;
         uint32_t v = 0;
         const bool row_ok = REFLECT || (gy >= 0 && gy < h);
-        if (REFLECT) gy = rx(gy, h);
+        if (REFLECT) gy = reflect101(gy, h);
         if (row_ok) {
             if (aligned && gx >= 0 && gx + 3 < w) v = *reinterpret_cast<const uint32_t*>(I + (size_t)gy * stride + gx);
             else {
@@ -107,7 +140,7 @@ __device__ __forceinline__ void stage_window(uint8_t* __restrict__ tile, const u
                 for (int b = 0; b < 4; ++b) {
                     int x = gx + b;
                     uint32_t px = 0;
-                    if (REFLECT) px = I[(size_t)gy * stride + rx(x, w)];
+                    if (REFLECT) px = I[(size_t)gy * stride + reflect101(x, w)];
                     else if (x >= 0 && x < w) px = I[(size_t)gy * stride + x];
                     v |= px << (8 * b);
                 }
@@ -117,57 +150,98 @@ __device__ __forceinline__ void stage_window(uint8_t* __restrict__ tile, const u
     }
 }
 
-// Internal images (score map, blurred image) use a row pitch wp = w rounded up to 4 so every kernel below moves 4 pixels
-// per 32-bit access; pixels in [w, wp) are written as 0.
-// FAST score + 3x3 non-maximum suppression + border cull + response histogram, one 64x32 tile per workgroup.
-// Scores are computed for the tile and a one-pixel ring around it (66x34), so the suppression of every tile pixel is decided
-// here from LDS and the full-image count pass is gone; what reaches HBM is the KEPT map (score where the pixel survives, else
-// 0), the per-frame histogram and the per-band (32 image rows = one tile row) keypoint counts for the raster-order emit pass.
+// ---------------------------------------------------------------------------------------------
+// FAST-9/16 + 3x3 non-maximum suppression + border cull, one 64 x 24 pixel tile per workgroup; what reaches HBM is the list of
+// keypoints, (x | y << 16, response) per frame in NO particular order (an atomic cursor per frame): everything downstream is a
+// function of the SET (k_select ranks with the raster position inside its key), so the score map, the raster-order emit pass and
+// the per-band counts of the first version are gone.
+//   stage    the tile and a 4-pixel halo (3 ring + 1 score ring), one 128-bit load per thread
+//   phase 1  compass test on the tile and a one-pixel ring (66 x 26): any 9-arc contains two NEIGHBOURING compass points (ring
+//            positions 0, 4, 8, 12), so a corner needs two neighbouring compass pixels both darker or both brighter than the
+//            centre by more than the threshold: (N or S) and (E or W).  Survivors (~20 %) go to an LDS list.
+//   phase 2a opposite-pair test on the list (all 16 ring pixels); survivors (~8 %) go to a second list
+//   phase 2b the exact score on the second list, where every lane of a wavefront has real work
+//   phase 3  strict 3x3 maximum among the raw scores + RunByImageBorder, append
+// ---------------------------------------------------------------------------------------------
 constexpr int FH = 4;                                   // image halo of the staged window: 3 (ring) + 1 (score ring)
+constexpr int FWX = 16;                                 // the window starts 16 pixels left of the tile: 128-bit aligned rows
+constexpr int FTW = FT_W + 2 * FWX, FTH = FT_H + 2 * FH; // staged window
 constexpr int SCW = FT_W + 2, SCH = FT_H + 2, SCP = 72; // score region and its LDS pitch
 constexpr int SC_OFF = 3;                               // region pixel rx sits at byte rx + 3 of its row: the tile's quads are dword-aligned
+constexpr int FNQ = (SCW + 3) / 4;                      // quads per region row (17, the last one half empty)
+constexpr int F_MAXKP = FT_W * FT_H / 4;                // a strict 3x3 maximum leaves at most one keypoint per 2x2 block
 
-__global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride,
-                                                  int threshold, int border, uint8_t* __restrict__ kept, uint8_t* __restrict__ raw_frame0, int wp,
-                                                  int* __restrict__ hist, int* __restrict__ band_count)
+// wave-aggregated append of up to four flagged items per lane to an LDS list: one atomic per wavefront
+__device__ __forceinline__ void append4(unsigned bits, const uint16_t (&val)[4], uint16_t* __restrict__ list, int* __restrict__ counter, int lane)
 {
-    constexpr int TW = FT_W + 8, TH = FT_H + 2 * FH, TP = TW;        // window starts 4 pixels left of the tile (aligned)
-    __shared__ __attribute__((aligned(4))) uint8_t tile[TH * TP + 8];
-    __shared__ __attribute__((aligned(4))) uint8_t sc[SCH * SCP];     // scores of the tile and its ring
+    unsigned long long bal[4];
+    int tot = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { bal[b] = __ballot((bits >> b) & 1u); tot += __popcll(bal[b]); }
+    if (tot == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(counter, tot);
+    base = __shfl(base, 0, 64);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        if ((bits >> b) & 1u) list[base + __popcll(bal[b] & ((1ull << lane) - 1ull))] = val[b];
+        base += __popcll(bal[b]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride,
+                                                        int threshold, int border, uint8_t* __restrict__ raw_frame0, int wp,
+                                                        int2* __restrict__ raw, size_t raw_cap, int* __restrict__ n_raw)
+{
+    constexpr int TP = FTW;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[FTH * TP + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[SCH * SCP];    // scores of the tile and its ring
     __shared__ uint16_t cand[SCH * SCP];                              // pixels that survive the compass test
-    __shared__ int lh[256];
-    __shared__ int n_cand, n_kept;
+    __shared__ uint16_t cand2[SCH * SCP];                             // ... and the opposite-pair test
+    __shared__ int2 kl[F_MAXKP];
+    __shared__ int n_cand, n_cand2, n_kept, s_base;
     const int f = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const uint8_t* I = img + (size_t)f * frame_stride;
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
-    if (tid == 0) { n_cand = 0; n_kept = 0; }
-    lh[tid] = 0;
-    for (int e = tid; e < SCH * SCP / 4; e += 256) reinterpret_cast<uint32_t*>(sc)[e] = 0u;
-    stage_window<TW, TH, TP, false>(tile, I, w, h, stride, x0 - 4, y0 - FH, TW, TH);
-    __syncthreads();
-    // Phase 1, every pixel of the 66x34 region: the compass test.  Any arc of 9 contiguous ring pixels contains two
-    // NEIGHBOURING compass points (ring positions 0, 4, 8, 12), so a corner needs two neighbouring compass pixels both darker
-    // or both brighter than the centre by more than the threshold -- a necessary condition costing 4 ring pixels.  Survivors
-    // (a few per cent to ~20 %) are appended to an LDS list; the full 16-pixel score is then computed on the compacted list,
-    // where every lane of a wavefront has real work.  Region pixel (rx, ry) = image (x0 - 1 + rx, y0 - 1 + ry) = tile byte
-    // (rx + 3, ry + 3); a thread takes four consecutive rx (17 groups per row, the last one half empty).
-    for (int qi = tid; qi < 17 * SCH; qi += 256) {
-        const int ry = qi / 17, q = qi % 17;
-        const int y = y0 - 1 + ry;
-        const bool row_ok = y >= 3 && y < h - 3;
-        uint32_t m0 = 0, m1 = 0, m2 = 0, u0 = 0, u1 = 0, d0_ = 0, d1_ = 0;
-        if (row_ok) {
-            const uint32_t* mp = reinterpret_cast<const uint32_t*>(&tile[(ry + 3) * TP + 4 * q]);
-            m0 = mp[0]; m1 = mp[1]; m2 = mp[2];
-            const uint32_t* up = reinterpret_cast<const uint32_t*>(&tile[(ry + 6) * TP + 4 * q]);   // row y + 3 (ring 0)
-            const uint32_t* dn = reinterpret_cast<const uint32_t*>(&tile[(ry + 0) * TP + 4 * q]);   // row y - 3 (ring 8)
-            u0 = up[0]; u1 = up[1]; d0_ = dn[0]; d1_ = dn[1];
+    ORB_CLK_BEGIN();
+    if (tid == 0) { n_cand = 0; n_cand2 = 0; n_kept = 0; }
+    for (int e = tid; e < SCH * SCP / 16; e += 256) reinterpret_cast<uint4*>(sc)[e] = make_uint4(0u, 0u, 0u, 0u);
+    {   // window rows y0 - 4 .. y0 + FT_H + 3, columns x0 - 16 .. x0 + 79: six 16-byte pieces per row, one per thread
+        static_assert(FTH * (FTW / 16) <= 256, "one 128-bit load per thread");
+        const bool aligned16 = ((stride & 15) == 0) && ((reinterpret_cast<uintptr_t>(I) & 15) == 0);
+        if (tid < FTH * (FTW / 16)) {
+            const int ty = tid / (FTW / 16), tq = tid % (FTW / 16);
+            const int gx = x0 - FWX + 16 * tq, gy = y0 - FH + ty;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (gy >= 0 && gy < h) {
+                const uint8_t* rowp = I + (size_t)gy * stride;
+                if (aligned16 && gx >= 0 && gx + 15 < w) v = *reinterpret_cast<const uint4*>(rowp + gx);
+                else if (gx + 15 >= 0 && gx < w) {
+                    uint32_t d[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+                    for (int b = 0; b < 16; ++b) { const int x = gx + b; if (x >= 0 && x < w) d[b >> 2] |= (uint32_t)rowp[x] << (8 * (b & 3)); }
+                    v = make_uint4(d[0], d[1], d[2], d[3]);
+                }
+            }
+            *reinterpret_cast<uint4*>(tile + ty * TP + 16 * tq) = v;
         }
-        // the four centres are bytes 3..6 of (m0, m1, m2); N / S are bytes 3..6 of the rows three above / below; E and W are the
-        // centre row three bytes on.  Two pixels at a time in packed 16-bit arithmetic: a corner needs two neighbouring compass
-        // points both darker (min of the pair of differences > t) or both brighter (max of the pair < -t).
+    }
+    __syncthreads();
+    ORB_CLK(0);
+    // Phase 1.  Region pixel (rx, ry) = image (x0 - 1 + rx, y0 - 1 + ry) = tile byte (rx + 15, ry + 3); a thread takes four
+    // consecutive rx.
+    for (int qi = tid; qi < FNQ * SCH; qi += 256) {
+        const int ry = qi / FNQ, q = qi - ry * FNQ;
+        const int y = y0 - 1 + ry;
         unsigned passbits = 0;
-        if (row_ok) {
+        if (y >= 3 && y < h - 3) {
+            const uint32_t* mp = reinterpret_cast<const uint32_t*>(&tile[(ry + 3) * TP + 4 * q + 12]);
+            const uint32_t m0 = mp[0], m1 = mp[1], m2 = mp[2];
+            const uint32_t* up = reinterpret_cast<const uint32_t*>(&tile[(ry + 6) * TP + 4 * q + 12]);   // row y + 3 (ring 0)
+            const uint32_t* dn = reinterpret_cast<const uint32_t*>(&tile[(ry + 0) * TP + 4 * q + 12]);   // row y - 3 (ring 8)
+            const uint32_t u0 = up[0], u1 = up[1], d0_ = dn[0], d1_ = dn[1];
+            // the four centres are bytes 3..6 of (m0, m1, m2); N / S are bytes 3..6 of the rows three above / below; E and W are the
+            // centre row three bytes on.  Two pixels at a time in packed 16-bit arithmetic.
             const short2_t T1 = (short2_t){ (short)(threshold + 1), (short)(threshold + 1) }, T = (short2_t){ (short)threshold, (short)threshold };
 #pragma unroll
             for (int hp = 0; hp < 2; ++hp) {
@@ -178,15 +252,14 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ im
                     const uint32_t r = __builtin_amdgcn_perm(hi, lo, sel);
                     short2_t o; __builtin_memcpy(&o, &r, 4); return o;
                 };
-                // pixels 2 hp, 2 hp + 1 of the group: centre bytes 3 + 2 hp .., east 6 + 2 hp .., west 2 hp .. of (m0, m1, m2)
                 const short2_t V = hp == 0 ? pair16(m1, m0, 3) : pair16(m2, m1, 1);
                 const short2_t Ee = hp == 0 ? pair16(m2, m1, 2) : pair16(0u, m2, 0);
                 const short2_t Ww = hp == 0 ? pair16(m1, m0, 0) : pair16(m1, m0, 2);
                 const short2_t Nn = hp == 0 ? pair16(u1, u0, 3) : pair16(0u, u1, 1);
                 const short2_t Ss = hp == 0 ? pair16(d1_, d0_, 3) : pair16(0u, d1_, 1);
                 const short2_t dN = V - Nn, dE = V - Ee, dS = V - Ss, dW = V - Ww;
-                const short2_t dark = pmax(pmax(pmin(dN, dE), pmin(dE, dS)), pmax(pmin(dS, dW), pmin(dW, dN)));
-                const short2_t bright = pmin(pmin(pmax(dN, dE), pmax(dE, dS)), pmin(pmax(dS, dW), pmax(dW, dN)));
+                // two neighbouring compass points both darker: (N or S) and (E or W)
+                const short2_t dark = pmin(pmax(dN, dS), pmax(dE, dW)), bright = pmax(pmin(dN, dS), pmin(dE, dW));
                 const short2_t xd = dark - T1, xb = bright + T;                       // dark > t  <=>  xd >= 0 ; bright < -t  <=>  xb < 0
                 uint32_t ud, ub;
                 __builtin_memcpy(&ud, &xd, 4); __builtin_memcpy(&ub, &xb, 4);
@@ -195,41 +268,58 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ im
                 passbits |= ((sg >> 31) & 1u) << (2 * hp + 1);
             }
         }
+        uint16_t pos[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int rx = 4 * q + b, x = x0 - 1 + rx;
-            const bool pass = ((passbits >> b) & 1u) && rx < SCW && x >= 3 && x < w - 3;
-            const unsigned long long bal = __ballot(pass);
-            if (bal) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&n_cand, __popcll(bal));
-                base = __shfl(base, 0, 64);
-                if (pass) cand[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(ry * SCP + rx);
-            }
+            if (!(rx < SCW && x >= 3 && x < w - 3)) passbits &= ~(1u << b);
+            pos[b] = (uint16_t)(ry * SCP + rx);
+        }
+        append4(passbits, pos, cand, &n_cand, lane);
+    }
+    __syncthreads();
+    ORB_CLK(1);
+    // Phase 2a: opposite-pair test
+    const int nc = n_cand;
+    for (int c0 = 0; c0 < nc; c0 += 256) {
+        const int c = c0 + tid;
+        int p = 0;
+        bool pass = false;
+        if (c < nc) {
+            p = cand[c];
+            const int ry = p / SCP, rx = p % SCP;
+            pass = fast_pair_test(&tile[(ry + 3) * TP + rx + 15], TP, threshold);
+        }
+        const unsigned long long bal = __ballot(pass);
+        if (bal) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&n_cand2, __popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (pass) cand2[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)p;
         }
     }
     __syncthreads();
-    // Phase 2: exact score of the survivors
-    const int nc = n_cand;
-    for (int c = tid; c < nc; c += 256) {
-        const int p = cand[c];
+    // Phase 2b: exact score of the survivors
+    const int nc2 = n_cand2;
+    for (int c = tid; c < nc2; c += 256) {
+        const int p = cand2[c];
         const int ry = p / SCP, rx = p % SCP;
-        sc[p + SC_OFF] = (uint8_t)fast_score_at(&tile[(ry + 3) * TP + rx + 3], TP, threshold);
+        sc[p + SC_OFF] = (uint8_t)fast_score_at(&tile[(ry + 3) * TP + rx + 15], TP, threshold);
     }
     __syncthreads();
-    // Phase 3: strict 3x3 maximum among the raw scores + RunByImageBorder; one 32-bit store per quad of the kept map
+    ORB_CLK(2);
+    // Phase 3: strict 3x3 maximum among the raw scores + RunByImageBorder
     const int lo = border > 3 ? border : 3;
-    uint8_t* K = kept + (size_t)f * wp * h;
-    int mine = 0;
 #pragma unroll
-    for (int i = 0; i < FT_W * FT_H / 4 / 256; ++i) {
+    for (int i = 0; i < (FT_W * FT_H / 4 + 255) / 256; ++i) {
         const int qi = tid + 256 * i;
+        if (qi >= FT_W * FT_H / 4) break;
         const int ly = qi / (FT_W / 4), lq = qi % (FT_W / 4);
         const int y = y0 + ly, xq = x0 + 4 * lq;
         if (y >= h || xq >= wp) continue;
         const uint8_t* c0 = &sc[(ly + 1) * SCP + 4 * lq + 1 + SC_OFF];           // dword-aligned: the four scores in one LDS read
         const uint32_t raw4 = *reinterpret_cast<const uint32_t*>(c0);
-        uint32_t kept4 = 0;
+        if (f == 0 && raw_frame0) *reinterpret_cast<uint32_t*>(raw_frame0 + (size_t)y * wp + xq) = raw4;
         if (raw4 != 0u && y >= lo && y < h - lo) {                              // most quads hold no corner at all
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -238,327 +328,324 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ im
                 if (s == 0 || x < lo || x >= w - lo) continue;
                 const uint8_t* p = c0 + b;
                 const bool keep = s > p[-1] && s > p[1] && s > p[-SCP - 1] && s > p[-SCP] && s > p[-SCP + 1] && s > p[SCP - 1] && s > p[SCP] && s > p[SCP + 1];
-                if (keep) { kept4 |= (uint32_t)s << (8 * b); ++mine; atomicAdd(&lh[s], 1); }
+                if (keep) kl[atomicAdd(&n_kept, 1)] = make_int2(x | (y << 16), s);
             }
         }
-        *reinterpret_cast<uint32_t*>(K + (size_t)y * wp + xq) = kept4;
-        if (f == 0 && raw_frame0) *reinterpret_cast<uint32_t*>(raw_frame0 + (size_t)y * wp + xq) = raw4;
     }
-    if (mine) atomicAdd(&n_kept, mine);
     __syncthreads();
-    if (lh[tid]) atomicAdd(&hist[f * 256 + tid], lh[tid]);
-    if (tid == 0 && n_kept) atomicAdd(&band_count[f * gridDim.y + blockIdx.y], n_kept);
-}
-
-// ---------------------------------------------------------------------------------------------
-// NMS + border cull + raster-order compaction.  A workgroup owns NMS_ROWS full image rows (a contiguous
-// raster segment); pass 1 counts (and builds the response histogram), pass 2 writes at the scanned offsets.
-// A thread examines 4 adjacent pixels from nine 32-bit loads.
-// ---------------------------------------------------------------------------------------------
-// exclusive scan of the per-workgroup counts of one frame (single wavefront per frame; n_wg is small)
-__global__ __launch_bounds__(64) void k_scan_counts(const int* __restrict__ wg_count, int n_wg, int* __restrict__ wg_off, int* __restrict__ n_raw)
-{
-    const int f = blockIdx.x, lane = threadIdx.x;
-    int base = 0;
-    for (int b = 0; b < n_wg; b += 64) {
-        const int i = b + lane;
-        int v = i < n_wg ? wg_count[f * n_wg + i] : 0;
-        int incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        if (i < n_wg) wg_off[f * n_wg + i] = base + incl - v;
-        base += __shfl(incl, 63, 64);
-    }
-    if (lane == 0) n_raw[f] = base;
-}
-
-__global__ __launch_bounds__(256) void k_nms_emit(const uint8_t* __restrict__ score, int w, int h, int wp, int border, int rows_per_wg,
-                                                  const int* __restrict__ wg_off, int2* __restrict__ raw, size_t raw_cap)   // score = the KEPT map of k_fast_nms
-{
-    __shared__ int wave_cnt[4];
-    __shared__ int base_s;
-    const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint8_t* Sc = score + (size_t)f * wp * h;
-    int2* out = raw + (size_t)f * raw_cap;
-    if (tid == 0) base_s = wg_off[f * gridDim.x + blockIdx.x];
+    const int nk = n_kept;
+    if (nk == 0) { ORB_CLK(3); return; }
+    if (tid == 0) s_base = atomicAdd(&n_raw[f], nk);
     __syncthreads();
-    const int y0 = blockIdx.x * rows_per_wg;
-    const int y1 = min(y0 + rows_per_wg, h);
-    const int qpr = wp / 4;
-    const int q_end = y1 * qpr;
-    for (int qb = y0 * qpr; qb < q_end; qb += 1024) {
-        const int q0 = qb + 4 * tid;                 // this thread's four consecutive quads (thread order = raster order)
-        uint32_t c4[4] = { 0, 0, 0, 0 };
-        if (q0 + 3 < q_end) { const uint4 v = *reinterpret_cast<const uint4*>(Sc + (size_t)q0 * 4); c4[0] = v.x; c4[1] = v.y; c4[2] = v.z; c4[3] = v.w; }
-        else for (int j = 0; j < 4; ++j) if (q0 + j < q_end) c4[j] = *reinterpret_cast<const uint32_t*>(Sc + (size_t)(q0 + j) * 4);
-        int m[4] = { 0, 0, 0, 0 }, resp[4][4];
-        int mine = 0;
-        if ((c4[0] | c4[1] | c4[2] | c4[3]) != 0u) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (c4[j] == 0u) continue;
-                // every non-zero byte of the kept map is a keypoint; its value is the response
-#pragma unroll
-                for (int b = 0; b < 4; ++b) { resp[j][b] = (int)((c4[j] >> (8 * b)) & 0xffu); if (resp[j][b]) m[j] |= 1 << b; }
-                mine += __popc(m[j]);
-            }
-        }
-        // exclusive prefix of `mine` over the wavefront
-        int incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        if (lane == 63) wave_cnt[wave] = incl;
-        __syncthreads();
-        int off = base_s + incl - mine;
-        for (int w2 = 0; w2 < wave; ++w2) off += wave_cnt[w2];
-        if (mine) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (!m[j]) continue;
-                const int q = q0 + j, xq = 4 * (q % qpr), y = q / qpr;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) if (m[j] & (1 << b)) out[off++] = make_int2((xq + b) | (y << 16), resp[j][b]);
-            }
-        }
-        __syncthreads();
-        if (tid == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
-    }
+    int2* out = raw + (size_t)f * raw_cap + s_base;
+    for (int i = tid; i < nk; i += 256) out[i] = kl[i];
+    ORB_CLK(3);
 }
 
 // ---------------------------------------------------------------------------------------------
-// selection: one workgroup (1024 threads) per frame.
+// selection: one workgroup (1024 threads) per frame.  The input list has no order; every result below is a function of the
+// set (histogram, bounding box, cell lists, minima), and the output position is the rank in a TOTAL order whose last tie-break
+// is the raster position -- what "index in raster order" was when the list was emitted row by row.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int block_scan_excl(int v, int* sh /* 17 ints */, int& total)
+constexpr int SEL_T = 1024;                     // threads
+constexpr int SEL_CAP = 2048, SEL_CELLS = 1024; // LDS working set: candidates after RetainBest, grid cells
+constexpr int SEL_REG = 4;                      // list entries a thread keeps in registers (4096 per frame; more are re-read from HBM)
+constexpr int SEL_HCOPIES = 16;                 // interleaved copies of the response histogram (same-bin lanes spread over banks)
+
+__device__ __forceinline__ int wave_scan_incl(int v, int lane)
 {
-    // exclusive scan over 1024 threads (16 waves) in thread order
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+    return v;
+}
+
+// exclusive scan over the 1024 threads in thread order; sh = 16 ints
+__device__ __forceinline__ int block_scan_excl(int v, int* sh, int& total)
+{
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    const int incl = wave_scan_incl(v, lane);
     __syncthreads();
     if (lane == 63) sh[wave] = incl;
     __syncthreads();
     int woff = 0, tot = 0;
-    for (int q = 0; q < 16; ++q) { if (q < wave) woff += sh[q]; tot += sh[q]; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const int c = sh[q]; if (q < wave) woff += c; tot += c; }
     total = tot;
     return woff + incl - v;
 }
 
-__global__ __launch_bounds__(1024) void k_select(OrbSelectArgs a)
+__device__ __forceinline__ mage_keypoint make_kp(int2 r, float size_f)
+{
+    mage_keypoint k = { (float)(r.x & 0xffff), (float)(r.x >> 16), size_f, 0.0f, (float)r.y, 0, -1 };
+    return k;
+}
+
+// isqrt for the ring bound (values < 2^31)
+__device__ __forceinline__ int isqrt_floor(int v)
+{
+    int r = (int)sqrtf((float)v);
+    while (r * r > v) --r;
+    while ((r + 1) * (r + 1) <= v) ++r;
+    return r;
+}
+
+__global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
 {
 #pragma clang fp contract(off)          // float results feed comparisons that must match the CPU restatement: plain IEEE operations, never an FMA
-    __shared__ int sh[32];
-    __shared__ int lhist[256];
-    __shared__ int s_cut;
+    __shared__ int sh[16];
+    __shared__ int lhist[256 * SEL_HCOPIES];
+    __shared__ int suffix[257];
+    __shared__ int s_mnt, s_cut;
     __shared__ int s_minX, s_maxX, s_minY, s_maxY, s_minS;
-    const int f = blockIdx.x, tid = threadIdx.x;
-    // Working set of the suppression (candidates, cell index, radii): in LDS whenever it fits -- the ring search chases
-    // cell -> member -> candidate, three dependent reads per visited point, and is pure latency when they go to L2.
-    constexpr int SEL_CAP = 2048, SEL_CELLS = 1024;
-    __shared__ int2 l_cand[SEL_CAP];
-    __shared__ int l_cellcnt[SEL_CELLS + 1], l_cellfill[SEL_CELLS + 1], l_cellmem[SEL_CAP], l_rad[SEL_CAP];
-    __shared__ int s_M;
+    __shared__ __attribute__((aligned(16))) unsigned long long l_cand[SEL_CAP];      // candidates in cell order: pos | response << 32
+    __shared__ __attribute__((aligned(16))) unsigned long long l_key[SEL_CAP];
+    __shared__ int l_cellstart[SEL_CELLS + 1], l_cellfill[SEL_CELLS];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int2* raw = a.raw + (size_t)f * a.raw_cap;
-    int2* cand = a.cand + (size_t)f * a.raw_cap;
-    int* cellcnt = a.cell_start + (size_t)f * (a.ncells + 1);
-    int* cellfill = a.cell_fill + (size_t)f * (a.ncells + 1);
-    int* cellmem = a.cell_members + (size_t)f * a.raw_cap;
-    int* rad = a.radius + (size_t)f * a.raw_cap;
     mage_keypoint* okp = a.out_kp + (size_t)f * a.capacity;
     const int n_raw = a.n_raw[f];
     const float size_f = (float)a.patch_size * 1.0f;
-    if (n_raw <= a.nfeatures) {
-        const int n = min(n_raw, a.capacity);
-        for (int i = tid; i < n; i += 1024) {
-            const int2 r = raw[i];
-            mage_keypoint k = { (float)(r.x & 0xffff), (float)(r.x >> 16), size_f, 0.0f, (float)r.y, 0, -1 };
-            okp[i] = k;
-        }
-        if (tid == 0) a.out_count[f] = n;
-        return;
-    }
-    // ---- RetainBestFeatures: whole histogram bins from 255 downwards.  suffix[i] = number of responses >= i, by a parallel
-    // scan (a single thread walking the 256 bins three times cost ~45 us of dependent LDS reads per frame); the two
-    // thresholds of OpenCVModified.cpp:571-617 are then "largest bin whose suffix count reaches the quota".
-    __shared__ int s_mnt;
-    if (tid < 256) lhist[tid] = a.hist[f * 256 + tid];
+    const int N = a.nfeatures;
+    ORB_CLK_BEGIN();
+    // the list entries of this thread (thread t owns entries t, t + 1024, ...)
+    int2 rr[SEL_REG];
+#pragma unroll
+    for (int k = 0; k < SEL_REG; ++k) { const int i = tid + SEL_T * k; rr[k] = i < n_raw ? raw[i] : make_int2(0, -1); }
+    for (int e = tid; e < 256 * SEL_HCOPIES; e += SEL_T) lhist[e] = 0;
     if (tid == 0) { s_mnt = -1; s_cut = -1; s_minX = 1 << 30; s_maxX = -1; s_minY = 1 << 30; s_maxY = -1; s_minS = 1 << 30; }
     __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {                      // Hillis-Steele suffix sum over 256 bins
-        int v = 0;
-        if (tid < 256) v = lhist[tid] + (tid + o < 256 ? lhist[tid + o] : 0);
-        __syncthreads();
-        if (tid < 256) lhist[tid] = v;
-        __syncthreads();
+    if (tid == 0) a.n_raw[f] = 0;                       // the cursor of this frame, left at zero for the next launch of k_fast_keypoints
+
+    // Keeps every entry as the reference's early returns do (fewer detections than the quota): output in raster order = rank by
+    // position.  `get(i)` reads entry i of the set, n of them.
+    auto emit_all_by_position = [&](auto get, int n) {
+        for (int i = tid; i < n; i += SEL_T) {
+            const int2 r = get(i);
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += (unsigned)get(j).x < (unsigned)r.x ? 1 : 0;      // pos = x | y << 16 is the raster order
+            if (rank < a.capacity) okp[rank] = make_kp(r, size_f);
+        }
+        if (tid == 0) a.out_count[f] = min(n, a.capacity);
+    };
+    if (n_raw <= N) {
+        if (n_raw <= SEL_CAP) {
+            for (int i = tid; i < n_raw; i += SEL_T) { const int2 r = raw[i]; l_cand[i] = (unsigned long long)(unsigned)r.x | ((unsigned long long)(unsigned)r.y << 32); }
+            __syncthreads();
+            emit_all_by_position([&](int i) { const unsigned long long v = l_cand[i]; return make_int2((int)(unsigned)v, (int)(v >> 32)); }, n_raw);
+        } else emit_all_by_position([&](int i) { return raw[i]; }, n_raw);
+        return;
     }
+    // ---- RetainBestFeatures (OpenCVModified.cpp:571-617): whole histogram bins from 255 downwards.  Histogram of the responses
+    // with LDS atomics on 16 interleaved copies (most responses sit in a handful of low bins), suffix[i] = number of
+    // responses >= i, and the two thresholds are "largest bin whose suffix count reaches the quota".
+    auto for_each_entry = [&](auto fn) {
+#pragma unroll
+        for (int k = 0; k < SEL_REG; ++k) if (tid + SEL_T * k < n_raw) fn(rr[k]);
+        for (int i = tid + SEL_T * SEL_REG; i < n_raw; i += SEL_T) fn(raw[i]);
+    };
+    for_each_entry([&](int2 r) { atomicAdd(&lhist[(r.y & 255) * SEL_HCOPIES + (lane & (SEL_HCOPIES - 1))], 1); });
+    __syncthreads();
+    {
+        int v = 0;
+        if (tid < 256) {
+            const int4* hp = reinterpret_cast<const int4*>(&lhist[tid * SEL_HCOPIES]);
+#pragma unroll
+            for (int k = 0; k < SEL_HCOPIES / 4; ++k) { const int4 c = hp[k]; v += c.x + c.y + c.z + c.w; }
+        }
+        // suffix sum over the 256 bins = total - exclusive prefix
+        int tot;
+        const int excl = block_scan_excl(v, sh, tot);
+        if (tid < 256) suffix[tid] = tot - excl;
+        if (tid == 0) suffix[256] = 0;
+    }
+    __syncthreads();
     const int min_thr = a.fast_threshold;
-    if (tid < 256 && tid >= min_thr && lhist[tid] >= a.nfeatures) atomicMax(&s_mnt, tid);
+    if (tid < 256 && tid >= min_thr && suffix[tid] >= N) atomicMax(&s_mnt, tid);
     __syncthreads();
     const int mnt = s_mnt >= 0 ? s_mnt : min_thr;
     const int lower = max((int)((float)mnt * a.feature_strength), min_thr);
-    if (tid < 256 && tid >= lower && lhist[tid] >= a.max_num) atomicMax(&s_cut, tid);
+    if (tid < 256 && tid >= lower && suffix[tid] >= a.max_num) atomicMax(&s_cut, tid);
     __syncthreads();
-    if (tid == 0) {
-        if (s_cut < 0) s_cut = lower;
-        s_M = s_cut < 256 ? lhist[s_cut] : 0;                // how many candidates the compaction below will keep
-    }
-    __syncthreads();
-    const int cut = s_cut;
-    if (s_M <= SEL_CAP && a.ncells <= SEL_CELLS) { cand = l_cand; cellcnt = l_cellcnt; cellfill = l_cellfill; cellmem = l_cellmem; rad = l_rad; }
-    int mbase = 0;
-    for (int i0 = 0; i0 < n_raw; i0 += 1024) {          // ordered compaction (raster order is kept: choice C1)
-        const int i = i0 + tid;
-        int2 r = make_int2(0, -1);
-        if (i < n_raw) r = raw[i];
-        const int keep = (i < n_raw && r.y >= cut) ? 1 : 0;
-        int tot;
-        const int off = block_scan_excl(keep, sh, tot);
-        if (keep) cand[mbase + off] = r;
-        {   // bounding box and weakest response: reduce inside the wavefront first, one LDS atomic per wavefront and quantity
-            int mnx = keep ? (r.x & 0xffff) : (1 << 30), mxx = keep ? (r.x & 0xffff) : -1;
-            int mny = keep ? (r.x >> 16) : (1 << 30), mxy = keep ? (r.x >> 16) : -1, mns = keep ? r.y : (1 << 30);
+    const int cut = s_cut >= 0 ? s_cut : lower;
+    const int M = cut < 256 ? suffix[cut] : 0;          // how many candidates RetainBest keeps
+    ORB_CLK(10);
+    // bounding box and weakest response of the kept set
+    {
+        int mnx = 1 << 30, mxx = -1, mny = 1 << 30, mxy = -1, mns = 1 << 30;
+        for_each_entry([&](int2 r) {
+            if (r.y >= cut) {
+                const int x = r.x & 0xffff, y = r.x >> 16;
+                mnx = min(mnx, x); mxx = max(mxx, x); mny = min(mny, y); mxy = max(mxy, y); mns = min(mns, r.y);
+            }
+        });
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                mnx = min(mnx, __shfl_xor(mnx, o, 64)); mxx = max(mxx, __shfl_xor(mxx, o, 64));
-                mny = min(mny, __shfl_xor(mny, o, 64)); mxy = max(mxy, __shfl_xor(mxy, o, 64)); mns = min(mns, __shfl_xor(mns, o, 64));
-            }
-            if ((tid & 63) == 0 && mxx >= 0) {
-                atomicMin(&s_minX, mnx); atomicMax(&s_maxX, mxx); atomicMin(&s_minY, mny); atomicMax(&s_maxY, mxy); atomicMin(&s_minS, mns);
-            }
+        for (int o = 32; o >= 1; o >>= 1) {
+            mnx = min(mnx, __shfl_xor(mnx, o, 64)); mxx = max(mxx, __shfl_xor(mxx, o, 64));
+            mny = min(mny, __shfl_xor(mny, o, 64)); mxy = max(mxy, __shfl_xor(mxy, o, 64)); mns = min(mns, __shfl_xor(mns, o, 64));
         }
-        mbase += tot;
-        __syncthreads();
+        if (lane == 0 && mxx >= 0) {
+            atomicMin(&s_minX, mnx); atomicMax(&s_maxX, mxx); atomicMin(&s_minY, mny); atomicMax(&s_maxY, mxy); atomicMin(&s_minS, mns);
+        }
     }
-    const int M = mbase;
-    const int N = a.nfeatures;
-    __threadfence_block();
     __syncthreads();
-    if (N > M) {                                         // ANMS returns early: keep all (cannot happen: M >= N by construction)
-        const int n = min(M, a.capacity);
-        for (int i = tid; i < n; i += 1024) {
-            const int2 r = cand[i];
-            mage_keypoint k = { (float)(r.x & 0xffff), (float)(r.x >> 16), size_f, 0.0f, (float)r.y, 0, -1 };
-            okp[i] = k;
-        }
-        if (tid == 0) a.out_count[f] = n;
+    ORB_CLK(11);
+    if (N > M) {
+        // AdaptiveNonMaximalSuppresion returns its input when there is nothing to suppress (feature_strength > 1 can cut below
+        // the quota): the kept set in raster order.  Rare, so the set is simply re-filtered from HBM.
+        int2* scratch = a.cand + (size_t)f * a.raw_cap;
+        __shared__ int s_n;
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        for (int i = tid; i < n_raw; i += SEL_T) { const int2 r = raw[i]; if (r.y >= cut) scratch[atomicAdd(&s_n, 1)] = r; }
+        __threadfence_block();
+        __syncthreads();
+        emit_all_by_position([&](int i) { return scratch[i]; }, s_n);
         return;
     }
-    // The rest runs twice in the source: once on the LDS arrays (address space known to the compiler: ds_read / ds_write) and
-    // once, for oversized inputs, on the global scratch.
-    const bool in_lds = cand == l_cand;
-    auto suppress_and_rank = [&](int2* cand, int* cellcnt, int* cellfill, int* cellmem, int* rad) {
-        // ---- AdaptiveNonMaximalSuppresion
-        const int minX = s_minX, maxX = s_maxX, minY = s_minY, maxY = s_maxY;
-        const int numX = a.cells_x, numY = a.cells_y, thr = a.fast_threshold;
-        float rf;
-        {
-            const float hi = (float)a.strong_response - (float)thr;
-            float val = (float)s_minS - (float)thr;
-            val = val < 0.0f ? 0.0f : (val > hi ? hi : val);
-            float range = a.max_robust - a.min_robust;
-            if (range < 0.0f) range = 0.0f;
-            rf = a.max_robust - (val / (float)(a.strong_response - thr)) * range;
-        }
-        for (int c = tid; c <= a.ncells; c += 1024) { cellcnt[c] = 0; cellfill[c] = 0; }
+    // ---- AdaptiveNonMaximalSuppresion (OpenCVModified.cpp:144-360)
+    const int minX = s_minX, maxX = s_maxX, minY = s_minY, maxY = s_maxY;
+    const int numX = a.cells_x, numY = a.cells_y, thr = a.fast_threshold;
+    float rf;
+    {
+        const float hi = (float)a.strong_response - (float)thr;
+        float val = (float)s_minS - (float)thr;
+        val = val < 0.0f ? 0.0f : (val > hi ? hi : val);
+        float range = a.max_robust - a.min_robust;
+        if (range < 0.0f) range = 0.0f;
+        rf = a.max_robust - (val / (float)(a.strong_response - thr)) * range;
+    }
+    const int globalMaxR2 = (int)(((double)(maxX - minX)) * ((double)(maxY - minY)) / (double)N);
+    int minCellDelta2;
+    {
+        const int dx = max((maxX - minX) / numX, 1), dy = max((maxY - minY) / numY, 1);
+        const int m = min(dx, dy);
+        minCellDelta2 = m * m;
+    }
+    const bool narrow_box = (maxX - minX) < numX || (maxY - minY) < numY;
+    auto cell_of = [&](int pos) { return ((pos >> 16) - minY) * numY / (maxY + 1 - minY) * numX + ((pos & 0xffff) - minX) * numX / (maxX + 1 - minX); };
+    // The working set (candidates in cell order, cell starts, keys) lives in LDS whenever it fits; oversized inputs run the same
+    // code on the per-frame scratch in HBM.
+    const bool in_lds = M <= SEL_CAP && a.ncells <= SEL_CELLS;
+    auto suppress_and_rank = [&](unsigned long long* cand, int* cellstart, int* cellfill, unsigned long long* key) {
+        // counting sort of the kept set by grid cell: cellstart[c] .. cellstart[c + 1] are the members of cell c, and the cells of
+        // one grid row are consecutive, so a row of the search window is ONE contiguous range
+        for (int c = tid; c <= a.ncells; c += SEL_T) { cellstart[c] = 0; if (c < a.ncells) cellfill[c] = 0; }
         __syncthreads();
-        for (int i = tid; i < M; i += 1024) {
-            const int2 r = cand[i];
-            const int cx = ((r.x & 0xffff) - minX) * numX / (maxX + 1 - minX), cy = ((r.x >> 16) - minY) * numY / (maxY + 1 - minY);
-            atomicAdd(&cellcnt[cy * numX + cx + 1], 1);
-        }
+        for_each_entry([&](int2 r) { if (r.y >= cut) atomicAdd(&cellstart[cell_of(r.x) + 1], 1); });
         __syncthreads();
-        {   // cell_start = inclusive scan of the counts, in place: thread t owns cells [t*per, (t+1)*per)
-            const int per = (a.ncells + 1023) / 1024;
-            const int c0 = tid * per, c1 = min(c0 + per, a.ncells);
+        {   // inclusive scan of the counts, in place: thread t owns cells [t*per, (t+1)*per)
+            const int per = (a.ncells + SEL_T - 1) / SEL_T;
+            const int c0 = min(tid * per, a.ncells), c1 = min(c0 + per, a.ncells);
             int local = 0;
-            for (int c = c0; c < c1; ++c) local += cellcnt[c + 1];
+            for (int c = c0; c < c1; ++c) local += cellstart[c + 1];
             int tot;
             int run = block_scan_excl(local, sh, tot);
-            for (int c = c0; c < c1; ++c) { run += cellcnt[c + 1]; cellcnt[c + 1] = run; }
+            for (int c = c0; c < c1; ++c) { run += cellstart[c + 1]; cellstart[c + 1] = run; }
         }
         __threadfence_block();
         __syncthreads();
-        for (int i = tid; i < M; i += 1024) {
-            const int2 r = cand[i];
-            const int cx = ((r.x & 0xffff) - minX) * numX / (maxX + 1 - minX), cy = ((r.x >> 16) - minY) * numY / (maxY + 1 - minY);
-            const int c = cy * numX + cx;
-            cellmem[cellcnt[c] + atomicAdd(&cellfill[c], 1)] = i;     // member order inside a cell does not affect a minimum
-        }
+        for_each_entry([&](int2 r) {
+            if (r.y >= cut) {
+                const int c = cell_of(r.x);
+                cand[cellstart[c] + atomicAdd(&cellfill[c], 1)] = (unsigned long long)(unsigned)r.x | ((unsigned long long)(unsigned)r.y << 32);
+            }
+        });
         __threadfence_block();
         __syncthreads();
-        const int globalMaxR2 = (int)(((double)(maxX - minX)) * ((double)(maxY - minY)) / (double)N);
-        int minCellDelta2;
-        {
-            const int dx = max((maxX - minX) / numX, 1), dy = max((maxY - minY) / numY, 1);
-            const int m = min(dx, dy);
-            minCellDelta2 = m * m;
-        }
-        for (int i = tid; i < M; i += 1024) {
-            const int2 r = cand[i];
-            const int x = r.x & 0xffff, y = r.x >> 16;
+        ORB_CLK(12);
+        // Suppression radius of candidate i = min(globalMaxR2, min over the candidates j with response_j > response_i * rf + 0.002 of
+        // |p_i - p_j|^2).  The reference walks square rings of cells outwards and stops at ring d once (d - 1)^2 * minCellDelta2
+        // reaches the running minimum: every candidate it has not visited by then is at least that far away, so the result is
+        // exactly this minimum whatever the order of the walk.  Here: the rows of the (2 D + 1)^2 window, nearest first, each row
+        // one contiguous member range, D shrinking with the running minimum.
+        for (int i = tid; i < M; i += SEL_T) {
+            const unsigned long long me = cand[i];
+            const int pos = (int)(unsigned)me, x = pos & 0xffff, y = pos >> 16;
             const int cx = (x - minX) * numX / (maxX + 1 - minX), cy = (y - minY) * numY / (maxY + 1 - minY);
-            const float strength = (float)r.y;
-            const float s = strength * rf + 0.002f;                              // strength >= 0 always (FAST score); no FMA: contraction is off in this kernel
+            const float s = (float)(int)(me >> 32) * rf + 0.002f;               // response >= 0 always (FAST score); no FMA: contraction is off in this kernel
             int minR2 = globalMaxR2;
-            for (int d = 0; max(0, d - 1) * max(0, d - 1) * minCellDelta2 < minR2; ++d)
-                for (int yy = -d; yy <= d; ++yy) {
-                    const int cYY = yy + cy;
-                    if (cYY < 0 || cYY >= numY) continue;
-                    for (int xx = -d; xx <= d; ++xx) {
-                        const int cXX = xx + cx;
-                        if (cXX < 0 || cXX >= numX || max(abs(xx), abs(yy)) != d) continue;
-                        const int c = cYY * numX + cXX;
-                        for (int q = cellcnt[c]; q < cellcnt[c + 1]; ++q) {
-                            const int2 o = cand[cellmem[q]];
-                            if ((float)o.y > s) {
-                                const int ddx = x - (o.x & 0xffff), ddy = y - (o.x >> 16);
-                                const int rr = ddx * ddx + ddy * ddy;
-                                if (rr < minR2) minR2 = rr;
+            auto ring_max = [&](int r2) { return r2 <= 0 ? -1 : 1 + isqrt_floor((r2 - 1) / minCellDelta2); };   // largest d with max(0, d - 1)^2 * minCellDelta2 < r2
+            int D = ring_max(minR2);
+            if (narrow_box) {
+                // a bounding box narrower than the grid: cells are narrower than the one pixel minCellDelta2 assumes, the ring
+                // bound is no lower bound any more and the result depends on the walk -- walk exactly as the reference does
+                D = -1;
+                for (int d = 0; max(0, d - 1) * max(0, d - 1) * minCellDelta2 < minR2; ++d)
+                    for (int yy = -d; yy <= d; ++yy) {
+                        const int cYY = yy + cy;
+                        if (cYY < 0 || cYY >= numY) continue;
+                        for (int xx = -d; xx <= d; ++xx) {
+                            const int cXX = xx + cx;
+                            if (cXX < 0 || cXX >= numX || max(abs(xx), abs(yy)) != d) continue;
+                            const int c = cYY * numX + cXX;
+                            for (int q = cellstart[c]; q < cellstart[c + 1]; ++q) {
+                                const unsigned long long o = cand[q];
+                                if ((float)(int)(o >> 32) > s) {
+                                    const int ddx = x - (int)((unsigned)o & 0xffffu), ddy = y - (int)((unsigned)o >> 16);
+                                    const int r2 = ddx * ddx + ddy * ddy;
+                                    if (r2 < minR2) minR2 = r2;
+                                }
                             }
                         }
                     }
+            }
+            for (int k = 0; k <= 2 * D; ++k) {                                  // row offsets 0, -1, +1, -2, +2, ...
+                const int ay = (k + 1) >> 1;
+                if (ay > D) break;
+                const int cYY = cy + ((k & 1) ? -ay : ay);
+                if (cYY < 0 || cYY >= numY) continue;
+                const int xl = max(cx - D, 0), xh = min(cx + D, numX - 1);
+                const int q1 = cellstart[cYY * numX + xh + 1];
+                bool hit = false;
+                for (int q = cellstart[cYY * numX + xl]; q < q1; ++q) {
+                    const unsigned long long o = cand[q];
+                    if ((float)(int)(o >> 32) > s) {
+                        const int ddx = x - (int)((unsigned)o & 0xffffu), ddy = y - (int)((unsigned)o >> 16);
+                        const int r2 = ddx * ddx + ddy * ddy;
+                        if (r2 < minR2) { minR2 = r2; hit = true; }
+                    }
                 }
-            rad[i] = minR2;
+                if (hit) D = min(D, ring_max(minR2));
+            }
+            // total order of the output: radius desc, response desc, raster position asc
+            if (globalMaxR2 < (1 << 24))
+                key[i] = ((unsigned long long)(unsigned)minR2 << 40) | ((unsigned long long)(unsigned)(int)(me >> 32) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)pos);
+            else key[i] = (unsigned long long)(unsigned)minR2;               // compared field by field below
         }
         __threadfence_block();
         __syncthreads();
-        // ---- keep the N first in the total order (radius desc, strength desc, index asc); rank = output position (choice C2)
-        // The comparator is a lexicographic order on (radius desc, strength desc, index asc): pack it into one 64-bit key per
-        // candidate (LDS path) so that the O(M^2) rank is one wide LDS read and one compare per pair, 8 pairs in flight.
-        __shared__ unsigned long long l_key[SEL_CAP];
-        if (in_lds) {
-            for (int i = tid; i < M; i += 1024)
-                l_key[i] = ((unsigned long long)(unsigned)rad[i] << 32) | ((unsigned long long)(unsigned)l_cand[i].y << 16) | (unsigned long long)(0xFFFF - i);
-            __syncthreads();
-        }
-        for (int i = tid; i < M; i += 1024) {
+        ORB_CLK(13);
+        // ---- keep the N first of the total order; rank = output position
+        for (int i = tid; i < M; i += SEL_T) {
             int rank = 0;
-            if (in_lds) {
-                const unsigned long long ki = l_key[i];
+            const unsigned long long ki = key[i];
+            if (globalMaxR2 < (1 << 24)) {
                 int j = 0;
                 for (; j + 8 <= M; j += 8) {
-    #pragma unroll
-                    for (int u = 0; u < 8; ++u) rank += l_key[j + u] > ki;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) rank += key[j + u] > ki;
                 }
-                for (; j < M; ++j) rank += l_key[j] > ki;
+                for (; j < M; ++j) rank += key[j] > ki;
             } else {
-                const int ri = rad[i], si = cand[i].y;
+                const unsigned long long ci = cand[i];
+                const unsigned si = (unsigned)(ci >> 32), pi = (unsigned)ci;
                 for (int j = 0; j < M; ++j) {
-                    const int rj = rad[j], sj = cand[j].y;
-                    rank += (rj > ri) || (rj == ri && (sj > si || (sj == si && j < i)));
+                    const unsigned long long kj = key[j], cj = cand[j];
+                    const unsigned sj = (unsigned)(cj >> 32), pj = (unsigned)cj;
+                    rank += (kj > ki) || (kj == ki && (sj > si || (sj == si && pj < pi)));
                 }
             }
             if (rank < N && rank < a.capacity) {
-                const int2 r = cand[i];
-                mage_keypoint k = { (float)(r.x & 0xffff), (float)(r.x >> 16), size_f, 0.0f, (float)r.y, 0, -1 };
-                okp[rank] = k;
+                const unsigned long long c = cand[i];
+                okp[rank] = make_kp(make_int2((int)(unsigned)c, (int)(c >> 32)), size_f);
             }
         }
-
+        __syncthreads();
+        ORB_CLK(14);
     };
-    if (in_lds) suppress_and_rank(l_cand, l_cellcnt, l_cellfill, l_cellmem, l_rad);
-    else suppress_and_rank(cand, cellcnt, cellfill, cellmem, rad);
+    if (in_lds) suppress_and_rank(l_cand, l_cellstart, l_cellfill, l_key);
+    else suppress_and_rank(a.cand64 + (size_t)f * a.raw_cap, a.cell_start + (size_t)f * (a.ncells + 1), a.cell_fill + (size_t)f * (a.ncells + 1),
+                           a.key64 + (size_t)f * a.raw_cap);
     if (tid == 0) a.out_count[f] = min(N, a.capacity);
 }
 
@@ -566,13 +653,6 @@ __global__ __launch_bounds__(1024) void k_select(OrbSelectArgs a)
 // separable integer Gaussian, REFLECT_101, 64x16 output tile per workgroup
 // ---------------------------------------------------------------------------------------------
 constexpr int BT_W = 64, BT_H = 64, MAXR = 7;
-
-__device__ __forceinline__ int reflect101(int p, int n)
-{
-    if (n == 1) return 0;
-    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
-    return p;
-}
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride,
                                               OrbTaps taps, uint8_t* __restrict__ out, int wp)
@@ -887,26 +967,16 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
 
-void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, int border, uint8_t* kept,
-                     uint8_t* raw_frame0, int wp, int* hist, int* band_count, int n_bands, hipStream_t st)
+void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, int border, uint8_t* raw_frame0, int wp,
+                     int2* raw, size_t raw_cap, int* n_raw, hipStream_t st)
 {
-    // one tile row of k_fast_nms = one band of the emit pass: FT_H rows (orb_host.hip sizes n_bands with the same constant)
-    (void)hipMemsetAsync(hist, 0, sizeof(int) * 256 * (size_t)n_frames, st);
-    (void)hipMemsetAsync(band_count, 0, sizeof(int) * (size_t)n_bands * (size_t)n_frames, st);
-    hipLaunchKernelGGL(k_fast_nms, dim3(cdiv(wp, FT_W), cdiv(h, FT_H), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, threshold, border,
-                       kept, raw_frame0, wp, hist, band_count);
-}
-
-void orb_launch_collect(const uint8_t* kept, int w, int h, int wp, int n_frames, int border, int rows_per_wg, int n_wg, int* wg_count, int* wg_off,
-                        int* n_raw, int2* raw, size_t raw_cap, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_scan_counts, dim3(n_frames), dim3(64), 0, st, wg_count, n_wg, wg_off, n_raw);
-    hipLaunchKernelGGL(k_nms_emit, dim3(n_wg, n_frames), dim3(256), 0, st, kept, w, h, wp, border, rows_per_wg, wg_off, raw, raw_cap);
+    hipLaunchKernelGGL(k_fast_keypoints, dim3(cdiv(wp, FT_W), cdiv(h, FT_H), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, threshold, border,
+                       raw_frame0, wp, raw, raw_cap, n_raw);
 }
 
 void orb_launch_select(const OrbSelectArgs& a, int n_frames, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_select, dim3(n_frames), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_select, dim3(n_frames), dim3(SEL_T), 0, st, a);
 }
 
 void orb_launch_blur(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, const OrbTaps& taps, uint8_t* out, int wp, hipStream_t st)
@@ -941,3 +1011,13 @@ void orb_launch_brief(const uint8_t* blurred, int wp, int h, int n_frames, const
 }
 
 }  // namespace mage
+
+#ifdef MAGE_ORB_CLOCKS
+// probe build only: read (and optionally clear) the phase clocks
+extern "C" __attribute__((visibility("default"))) int mage_orb_debug_clocks(unsigned long long* out32, int reset)
+{
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(mage::g_orb_clk), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(mage::g_orb_clk), z, sizeof z) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
