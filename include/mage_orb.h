@@ -107,11 +107,14 @@ mage_status mage_orb_undistort_keypoints_device(mage_orb* h, const mage_keypoint
  * FAST score map (width x height u8) and blurred image (width x height u8). */
 mage_status mage_orb_debug_read(mage_orb* h, uint8_t* score_map, uint8_t* blurred);
 
-/* Per-stage HIP-event timings of the most recent batch call (milliseconds). */
+/* Per-stage HIP-event timings of the most recent batch call (milliseconds).  Off by default (all zero): the event packets between
+ * the kernels cost more than a one-frame batch's kernels are apart.  With the 7-tap Gaussian the blur runs inside the FAST launch:
+ * fast_ms then includes it and blur_ms is ~0. */
 typedef struct mage_orb_profile {
     double fast_ms, select_ms, blur_ms, brief_ms, total_ms;
     int    n_frames;
 } mage_orb_profile;
+mage_status mage_orb_enable_profile(mage_orb* h, int on);
 mage_status mage_orb_get_profile(const mage_orb* h, mage_orb_profile* out);
 
 #ifdef __cplusplus

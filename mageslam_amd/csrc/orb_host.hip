@@ -86,15 +86,15 @@ struct mage_orb {
     OrbTaps taps{};
     DevBuf<signed char> d_pattern;
     DevBuf<uint8_t> d_img, d_rawscore, d_blur, d_desc;     // d_rawscore: FAST scores of frame 0 (parity tests)
-    DevBuf<int> d_n_raw, d_cell_start, d_cell_fill, d_count;   // d_n_raw: per-frame cursor of d_raw; zero between calls (k_select leaves it so)
-    size_t n_raw_zeroed = 0;                                   // entries of d_n_raw known to be zero
-    DevBuf<int2> d_raw, d_cand;                                // d_cand, d_key: scratch of k_select for frames whose working set exceeds LDS
-    DevBuf<unsigned long long> d_key;
+    DevBuf<int> d_tile_count, d_cell_start, d_cell_fill, d_count;   // d_tile_count: keypoints per FAST tile, d_raw: their slots
+    DevBuf<int2> d_raw;
+    DevBuf<unsigned long long> d_cand, d_key;                  // scratch of k_select for frames whose working set exceeds LDS
     DevBuf<mage_keypoint> d_kp, d_undist, d_kp_lvl;
     DevBuf<uint8_t> d_pyr[2], d_blur_lvl, d_desc_lvl;      // pyramid levels >= 1 (ping-pong), their blurred image and per-level outputs
     DevBuf<int> d_count_lvl;
     hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     mage_orb_profile prof{};
+    bool profiling = false;          // stage events are recorded only on request: five event packets cost more than a one-frame batch's kernels are apart
     int last_w = 0, last_h = 0;
     ~mage_orb()
     {
@@ -167,17 +167,16 @@ mage_status run_level(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     const mage_orb_params& P = h->P;
     hipStream_t st = h->stream;
     const int wp = (w + 3) & ~3;                     // internal row pitch (score map, blurred image)
-    const size_t raw_cap = (size_t)w * h_img / 4 + 16;
+    int tiles_x, tiles_y, tile_cap;
+    orb_fast_tiling(w, h_img, &tiles_x, &tiles_y, &tile_cap);
+    const size_t n_tiles = (size_t)tiles_x * tiles_y;
+    const size_t scratch_cap = (size_t)w * h_img / 4 + 16;      // a strict 3x3 maximum: at most one keypoint per 2x2 block
     const int ncells = P.num_cells_x * P.num_cells_y;
     const size_t nf = (size_t)std::max(n_frames, 1);
-    MAGE_TRY(h->d_n_raw.reserve(nf));
-    if (h->n_raw_zeroed != h->d_n_raw.cap) {             // a fresh (recycled) allocation: zero every cursor once; the kernels keep them at zero
-        MAGE_HIP(hipMemsetAsync(h->d_n_raw.p, 0, sizeof(int) * h->d_n_raw.cap, st));
-        h->n_raw_zeroed = h->d_n_raw.cap;
-    }
-    MAGE_TRY(h->d_raw.reserve(nf * raw_cap));
-    MAGE_TRY(h->d_cand.reserve(nf * raw_cap));
-    MAGE_TRY(h->d_key.reserve(nf * raw_cap));
+    MAGE_TRY(h->d_tile_count.reserve(nf * n_tiles));
+    MAGE_TRY(h->d_raw.reserve(nf * n_tiles * tile_cap));
+    MAGE_TRY(h->d_cand.reserve(nf * scratch_cap));
+    MAGE_TRY(h->d_key.reserve(nf * scratch_cap));
     MAGE_TRY(h->d_cell_start.reserve(nf * (ncells + 1)));
     MAGE_TRY(h->d_cell_fill.reserve(nf * (ncells + 1)));
 
@@ -185,15 +184,16 @@ mage_status run_level(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     // RunByImageBorder: half the patch, or its hypotenuse when the patch gets rotated (OpenCVModified.cpp:709-712)
     const int half_patch = (int)P.patch_size / 2;
     const int border = P.use_orientation ? (int)std::ceil((float)half_patch * std::sqrt(2.0f)) : half_patch;
+    const bool fused_blur = orb_blur_fuses(h->taps);      // the 7-tap Gaussian rides in the FAST launch: the frame is read once for both
     orb_launch_fast(d_images, w, h_img, stride, frame_stride, n_frames, (int)std::min(P.fast_threshold, 255u), border, io.raw_frame0, wp,
-                    h->d_raw.p, raw_cap, h->d_n_raw.p, st);
+                    h->d_raw.p, h->d_tile_count.p, fused_blur ? &h->taps : nullptr, io.blur, st);
     if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[1], st));
     OrbSelectArgs a{};
-    a.raw = h->d_raw.p; a.n_raw = h->d_n_raw.p;
-    a.cand = h->d_cand.p; a.cand64 = reinterpret_cast<unsigned long long*>(h->d_cand.p); a.key64 = h->d_key.p;
+    a.raw = h->d_raw.p; a.tile_count = h->d_tile_count.p; a.n_tiles = (int)n_tiles; a.tile_cap = tile_cap;
+    a.cand64 = h->d_cand.p; a.key64 = h->d_key.p; a.scratch_cap = scratch_cap;
     a.cell_start = h->d_cell_start.p; a.cell_fill = h->d_cell_fill.p;
     a.out_kp = io.kp; a.out_count = io.count;
-    a.raw_cap = raw_cap; a.ncells = ncells; a.cells_x = P.num_cells_x; a.cells_y = P.num_cells_y;
+    a.ncells = ncells; a.cells_x = P.num_cells_x; a.cells_y = P.num_cells_y;
     a.nfeatures = io.nfeatures; a.max_num = (int)((float)io.nfeatures * P.feature_factor_anms);
     a.fast_threshold = (int)P.fast_threshold; a.strong_response = P.strong_response_anms; a.capacity = io.capacity; a.patch_size = (int)P.patch_size;
     a.feature_strength = P.feature_strength_anms; a.min_robust = P.min_robust_factor; a.max_robust = P.max_robust_factor;
@@ -207,7 +207,7 @@ mage_status run_level(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
         orb_launch_angles(d_images, stride, frame_stride, n_frames, io.kp, io.count, io.capacity, um, st);
     }
     if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[2], st));
-    orb_launch_blur(d_images, w, h_img, stride, frame_stride, n_frames, h->taps, io.blur, wp, st);
+    if (!fused_blur) orb_launch_blur(d_images, w, h_img, stride, frame_stride, n_frames, h->taps, io.blur, wp, st);
     if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[3], st));
     if (io.capacity > 0) orb_launch_brief(io.blur, wp, h_img, n_frames, io.kp, io.count, io.capacity, h->d_pattern.p, io.desc,
                                           P.use_orientation && P.patch_size != 15 && P.patch_size != 31, st);
@@ -238,7 +238,7 @@ mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     if (n_frames == 0) return MAGE_OK;
     const int L = (int)P.nlevels;
     if (L == 1) {
-        LevelIO io{ (int)P.nfeatures, capacity, h->d_kp.p, h->d_desc.p, h->d_count.p, h->d_blur.p, h->d_rawscore.p, true };
+        LevelIO io{ (int)P.nfeatures, capacity, h->d_kp.p, h->d_desc.p, h->d_count.p, h->d_blur.p, h->d_rawscore.p, h->profiling };
         return run_level(h, d_images, n_frames, w, h_img, stride, frame_stride, io);
     }
     // pyramid layout (:564-567, :797-799) and per-level quotas (:659-669), in the reference's float arithmetic
@@ -255,7 +255,7 @@ mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
         for (int l = 0; l < L - 1; ++l) { quota[l] = (int)std::nearbyint(ndesired); sum += quota[l]; ndesired *= factor; }
         quota[L - 1] = std::max((int)P.nfeatures - sum, 0);
     }
-    MAGE_HIP(hipEventRecord(h->ev[0], st));
+    if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[0], st));
     MAGE_HIP(hipMemsetAsync(h->d_count.p, 0, sizeof(int) * nf, st));
     const uint8_t* src = d_images; int sw = w, sh = h_img, sstride = stride; size_t sfs = frame_stride;
     for (int l = 0; l < L; ++l) {
@@ -283,12 +283,13 @@ mage_status run_batch(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
         }
         src = img_l; sw = lw[l]; sh = lh[l]; sstride = stride_l; sfs = fs_l;
     }
-    for (int e = 1; e <= 4; ++e) MAGE_HIP(hipEventRecord(h->ev[e], st));     // stage split is not recorded for pyramids: total only
+    if (h->profiling) for (int e = 1; e <= 4; ++e) MAGE_HIP(hipEventRecord(h->ev[e], st));     // stage split is not recorded for pyramids: total only
     return MAGE_OK;
 }
 
 mage_status collect_profile(mage_orb* h)
 {
+    if (!h->profiling) return MAGE_OK;
     float ms = 0;
     MAGE_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); h->prof.fast_ms = ms;
     MAGE_HIP(hipEventElapsedTime(&ms, h->ev[1], h->ev[2])); h->prof.select_ms = ms;
@@ -349,6 +350,13 @@ MAGE_EXPORT mage_status mage_orb_detect_batch_device(mage_orb* h, const uint8_t*
         *keypoints_device = h->d_kp.p; *descriptors_device = h->d_desc.p; *counts_device = h->d_count.p;
         return n_frames > 0 ? collect_profile(h) : MAGE_OK;
     });
+}
+
+MAGE_EXPORT mage_status mage_orb_enable_profile(mage_orb* h, int on)
+{
+    if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+    h->profiling = on != 0;
+    return MAGE_OK;
 }
 
 MAGE_EXPORT mage_status mage_orb_debug_read(mage_orb* h, uint8_t* score_map, uint8_t* blurred)

@@ -11,10 +11,11 @@ namespace mage {
 struct OrbTaps { int radius; int t[15]; };          // 8-bit fixed-point Gaussian taps (sum ~ 256), radius <= 7
 
 struct OrbSelectArgs {
-    const int2* raw; int* n_raw;                              // per frame: (x | y << 16, response) in no particular order, count (reset to 0 by k_select)
-    int2* cand; unsigned long long* cand64; unsigned long long* key64; int* cell_start; int* cell_fill;   // scratch in HBM for oversized frames, per frame
+    const int2* raw; const int* tile_count;                   // per frame: n_tiles x tile_cap slots of (x | y << 16, response), entries per tile
+    int n_tiles, tile_cap;
+    unsigned long long* cand64; unsigned long long* key64; int* cell_start; int* cell_fill;   // scratch in HBM for oversized frames, per frame
+    size_t scratch_cap;                                       // entries of cand64 / key64 per frame
     mage_keypoint* out_kp; int* out_count;
-    size_t raw_cap;
     int ncells, cells_x, cells_y;
     int nfeatures, max_num, fast_threshold, strong_response, capacity, patch_size;
     float feature_strength, min_robust, max_robust;
@@ -22,10 +23,13 @@ struct OrbSelectArgs {
 
 // wp = internal row pitch of the blurred image / raw score map (w rounded up to 4)
 constexpr int ORB_MAX_LEVELS = 16;   // pyramid depth accepted by mage_orb_create
-// FAST + NMS + border cull: appends the keypoints of every frame to raw[frame] (cursor n_raw[frame], which must be 0 on entry);
-// raw scores of frame 0 (optional, parity tests)
+// FAST + NMS + border cull, one workgroup per image tile: the keypoints of tile t of a frame go to raw[(frame * n_tiles + t) * tile_cap ...],
+// their number to tile_count[frame * n_tiles + t]; raw scores of frame 0 (optional, parity tests)
+void orb_fast_tiling(int w, int h, int* tiles_x, int* tiles_y, int* tile_cap);
+// With `taps` (only when orb_blur_fuses(taps): the 7-tap kernel) the same launch also writes the blurred image and orb_launch_blur is not needed.
+bool orb_blur_fuses(const OrbTaps& taps);
 void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, int border, uint8_t* raw_frame0, int wp,
-                     int2* raw, size_t raw_cap, int* n_raw, hipStream_t st);
+                     int2* raw, int* tile_count, const OrbTaps* taps, uint8_t* blurred, hipStream_t st);
 // cv::resize(INTER_LINEAR) of n_frames u8 images (OpenCV 3.4.0 fixed-point arithmetic) and the per-frame concatenation of a level's results
 void orb_launch_resize(const uint8_t* src, int sw, int sh, int sstride, size_t sframe, uint8_t* dst, int dw, int dh, int dpitch, size_t dframe, int n_frames,
                        hipStream_t st);

@@ -151,10 +151,10 @@ __device__ __forceinline__ void stage_window(uint8_t* __restrict__ tile, const u
 }
 
 // ---------------------------------------------------------------------------------------------
-// FAST-9/16 + 3x3 non-maximum suppression + border cull, one 64 x 24 pixel tile per workgroup; what reaches HBM is the list of
-// keypoints, (x | y << 16, response) per frame in NO particular order (an atomic cursor per frame): everything downstream is a
-// function of the SET (k_select ranks with the raster position inside its key), so the score map, the raster-order emit pass and
-// the per-band counts of the first version are gone.
+// FAST-9/16 + 3x3 non-maximum suppression + border cull, one 64 x 24 pixel tile per workgroup; what reaches HBM is the tile's
+// keypoints, (x | y << 16, response), in the tile's own F_MAXKP slots of the frame's list plus their count, in NO particular order
+// inside a tile: everything downstream is a function of the SET (k_select ranks with the raster position inside its key), so the
+// score map, the raster-order emit pass and the per-band counts of the first version are gone.
 //   stage    the tile and a 4-pixel halo (3 ring + 1 score ring), one 128-bit load per thread
 //   phase 1  compass test on the tile and a one-pixel ring (66 x 26): any 9-arc contains two NEIGHBOURING compass points (ring
 //            positions 0, 4, 8, 12), so a corner needs two neighbouring compass pixels both darker or both brighter than the
@@ -168,38 +168,53 @@ constexpr int FWX = 16;                                 // the window starts 16 
 constexpr int FTW = FT_W + 2 * FWX, FTH = FT_H + 2 * FH; // staged window
 constexpr int SCW = FT_W + 2, SCH = FT_H + 2, SCP = 72; // score region and its LDS pitch
 constexpr int SC_OFF = 3;                               // region pixel rx sits at byte rx + 3 of its row: the tile's quads are dword-aligned
-constexpr int FNQ = (SCW + 3) / 4;                      // quads per region row (17, the last one half empty)
 constexpr int F_MAXKP = FT_W * FT_H / 4;                // a strict 3x3 maximum leaves at most one keypoint per 2x2 block
 
-// wave-aggregated append of up to four flagged items per lane to an LDS list: one atomic per wavefront
-__device__ __forceinline__ void append4(unsigned bits, const uint16_t (&val)[4], uint16_t* __restrict__ list, int* __restrict__ counter, int lane)
+// wave-aggregated append to an LDS list: lane l contributes the positions pos0 + j of the set bits j of its 8-bit mask.  The
+// exclusive prefix of the lanes' counts comes from ballots over the bits of the count, one atomic per wavefront reserves the
+// range, and every lane issues its eight stores unconditionally -- the unset ones go to a dump slot -- so there is no divergent
+// code at all.
+__device__ __forceinline__ void append8(unsigned bits, int pos0, uint16_t* __restrict__ list, int dump, int* __restrict__ counter, int lane)
 {
-    unsigned long long bal[4];
-    int tot = 0;
+    const int c = __popc(bits);
+    int pre = 0, tot = 0;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { bal[b] = __ballot((bits >> b) & 1u); tot += __popcll(bal[b]); }
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long bal = __ballot((c >> k) & 1);
+        pre += __popcll(bal & ((1ull << lane) - 1ull)) << k;
+        tot += __popcll(bal) << k;
+    }
     if (tot == 0) return;
     int base = 0;
     if (lane == 0) base = atomicAdd(counter, tot);
-    base = __shfl(base, 0, 64);
+    int off = __shfl(base, 0, 64) + pre;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        if ((bits >> b) & 1u) list[base + __popcll(bal[b] & ((1ull << lane) - 1ull))] = val[b];
-        base += __popcll(bal[b]);
+    for (int j = 0; j < 8; ++j) {
+        const bool on = (bits >> j) & 1u;
+        list[on ? off : dump] = (uint16_t)(pos0 + j);
+        off += on ? 1 : 0;
     }
 }
 
+// BLUR: the 7-tap Gaussian of the same tile (what k_blur computes) from the same staged window -- the image is read from HBM once
+// for both.  Out-of-image window pixels are then REFLECTED instead of zero; FAST never looks at them (its centres keep 3 pixels
+// from the image edge).
+template <bool BLUR>
 __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride,
                                                         int threshold, int border, uint8_t* __restrict__ raw_frame0, int wp,
-                                                        int2* __restrict__ raw, size_t raw_cap, int* __restrict__ n_raw)
+                                                        int2* __restrict__ raw, int* __restrict__ tile_count, OrbTaps taps, uint8_t* __restrict__ blurred)
 {
     constexpr int TP = FTW;
+    constexpr int HROWS = FT_H + 6;                                   // row sums the vertical pass of the blur needs
+    constexpr int NCAND = SCH * SCP > HROWS * FT_W ? SCH * SCP : HROWS * FT_W;   // the two candidate lists (2 x 16 bit) share their bytes with the row sums (32 bit)
     __shared__ __attribute__((aligned(16))) uint8_t tile[FTH * TP + 16];
     __shared__ __attribute__((aligned(16))) uint8_t sc[SCH * SCP];    // scores of the tile and its ring
-    __shared__ uint16_t cand[SCH * SCP];                              // pixels that survive the compass test
-    __shared__ uint16_t cand2[SCH * SCP];                             // ... and the opposite-pair test
+    __shared__ __attribute__((aligned(16))) uint16_t cand_both[2 * NCAND];
+    uint16_t* const cand = cand_both;                                 // pixels that survive the compass test
+    uint16_t* const cand2 = cand_both + NCAND;                        // ... and the opposite-pair test
+    int* const hrow = reinterpret_cast<int*>(cand_both);              // BLUR, after phase 2b: horizontal 7-tap sums of window rows 1 .. HROWS
     __shared__ int2 kl[F_MAXKP];
-    __shared__ int n_cand, n_cand2, n_kept, s_base;
+    __shared__ int n_cand, n_cand2, n_kept;
     const int f = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const uint8_t* I = img + (size_t)f * frame_stride;
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
@@ -213,13 +228,17 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
             const int ty = tid / (FTW / 16), tq = tid % (FTW / 16);
             const int gx = x0 - FWX + 16 * tq, gy = y0 - FH + ty;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (gy >= 0 && gy < h) {
-                const uint8_t* rowp = I + (size_t)gy * stride;
+            if (BLUR || (gy >= 0 && gy < h)) {
+                const uint8_t* rowp = I + (size_t)(BLUR ? reflect101(gy, h) : gy) * stride;
                 if (aligned16 && gx >= 0 && gx + 15 < w) v = *reinterpret_cast<const uint4*>(rowp + gx);
-                else if (gx + 15 >= 0 && gx < w) {
+                else if (BLUR || (gx + 15 >= 0 && gx < w)) {
                     uint32_t d[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
-                    for (int b = 0; b < 16; ++b) { const int x = gx + b; if (x >= 0 && x < w) d[b >> 2] |= (uint32_t)rowp[x] << (8 * (b & 3)); }
+                    for (int b = 0; b < 16; ++b) {
+                        const int x = gx + b;
+                        if (BLUR) d[b >> 2] |= (uint32_t)rowp[reflect101(x, w)] << (8 * (b & 3));
+                        else if (x >= 0 && x < w) d[b >> 2] |= (uint32_t)rowp[x] << (8 * (b & 3));
+                    }
                     v = make_uint4(d[0], d[1], d[2], d[3]);
                 }
             }
@@ -228,35 +247,34 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
     }
     __syncthreads();
     ORB_CLK(0);
-    // Phase 1.  Region pixel (rx, ry) = image (x0 - 1 + rx, y0 - 1 + ry) = tile byte (rx + 15, ry + 3); a thread takes four
-    // consecutive rx.
-    for (int qi = tid; qi < FNQ * SCH; qi += 256) {
-        const int ry = qi / FNQ, q = qi - ry * FNQ;
+    // Phase 1.  Region pixel (rx, ry) = image (x0 - 1 + rx, y0 - 1 + ry) = tile byte (rx + 15, ry + 3); a thread takes EIGHT
+    // consecutive rx: 9 groups per region row (SCP = 72 = 9 x 8, so the list position of pixel j of group e is 8 e + j) and
+    // 9 x SCH groups in all -- one pass of the workgroup.
+    static_assert(SCP == 8 * ((SCW + 7) / 8) && (SCP / 8) * SCH <= 256, "one group of eight region pixels per thread");
+    {
+        const int e = tid, ry = e / (SCP / 8), o = e - ry * (SCP / 8);
         const int y = y0 - 1 + ry;
         unsigned passbits = 0;
-        if (y >= 3 && y < h - 3) {
-            const uint32_t* mp = reinterpret_cast<const uint32_t*>(&tile[(ry + 3) * TP + 4 * q + 12]);
-            const uint32_t m0 = mp[0], m1 = mp[1], m2 = mp[2];
-            const uint32_t* up = reinterpret_cast<const uint32_t*>(&tile[(ry + 6) * TP + 4 * q + 12]);   // row y + 3 (ring 0)
-            const uint32_t* dn = reinterpret_cast<const uint32_t*>(&tile[(ry + 0) * TP + 4 * q + 12]);   // row y - 3 (ring 8)
-            const uint32_t u0 = up[0], u1 = up[1], d0_ = dn[0], d1_ = dn[1];
-            // the four centres are bytes 3..6 of (m0, m1, m2); N / S are bytes 3..6 of the rows three above / below; E and W are the
-            // centre row three bytes on.  Two pixels at a time in packed 16-bit arithmetic.
+        if (e < (SCP / 8) * SCH && y >= 3 && y < h - 3) {
+            // bytes 8 o + 12 .. 8 o + 27 of the centre row: centre j is byte 3 + j, its W neighbour byte j, its E neighbour byte 6 + j;
+            // N / S are bytes 3 + j of the rows three above / below
+            const uint32_t* mp = reinterpret_cast<const uint32_t*>(&tile[(ry + 3) * TP + 8 * o + 12]);
+            const uint32_t* up = reinterpret_cast<const uint32_t*>(&tile[(ry + 6) * TP + 8 * o + 12]);   // row y + 3 (ring 0)
+            const uint32_t* dn = reinterpret_cast<const uint32_t*>(&tile[(ry + 0) * TP + 8 * o + 12]);   // row y - 3 (ring 8)
+            const uint32_t mc[4] = { mp[0], mp[1], mp[2], mp[3] }, mu[3] = { up[0], up[1], up[2] }, md[3] = { dn[0], dn[1], dn[2] };
             const short2_t T1 = (short2_t){ (short)(threshold + 1), (short)(threshold + 1) }, T = (short2_t){ (short)threshold, (short)threshold };
 #pragma unroll
-            for (int hp = 0; hp < 2; ++hp) {
-                // two adjacent bytes j, j + 1 (0 <= j <= 6) of the 8 bytes hi:lo, zero-extended to 16 bits each (v_perm_b32:
-                // selector 0..3 = bytes of lo, 4..7 = bytes of hi, 0x0c = zero)
-                auto pair16 = [&](uint32_t hi, uint32_t lo, int j) -> short2_t {
-                    const uint32_t sel = 0x0c000c00u | (uint32_t)j | ((uint32_t)(j + 1) << 16);
-                    const uint32_t r = __builtin_amdgcn_perm(hi, lo, sel);
-                    short2_t o; __builtin_memcpy(&o, &r, 4); return o;
+            for (int hp = 0; hp < 4; ++hp) {
+                // bytes i, i + 1 of a group of dwords, zero-extended to 16 bits each (v_perm_b32: selector 0..3 = bytes of the
+                // second operand, 4..7 = bytes of the first, 0x0c = zero)
+                auto pair16 = [&](const uint32_t* g, int i) -> short2_t {
+                    const int d = i >> 2, k = i & 3;
+                    const uint32_t r = k < 3 ? __builtin_amdgcn_perm(0u, g[d], 0x0c000c00u | (uint32_t)k | ((uint32_t)(k + 1) << 16))
+                                             : __builtin_amdgcn_perm(g[d + 1], g[d], 0x0c040c03u);
+                    short2_t q; __builtin_memcpy(&q, &r, 4); return q;
                 };
-                const short2_t V = hp == 0 ? pair16(m1, m0, 3) : pair16(m2, m1, 1);
-                const short2_t Ee = hp == 0 ? pair16(m2, m1, 2) : pair16(0u, m2, 0);
-                const short2_t Ww = hp == 0 ? pair16(m1, m0, 0) : pair16(m1, m0, 2);
-                const short2_t Nn = hp == 0 ? pair16(u1, u0, 3) : pair16(0u, u1, 1);
-                const short2_t Ss = hp == 0 ? pair16(d1_, d0_, 3) : pair16(0u, d1_, 1);
+                const short2_t V = pair16(mc, 3 + 2 * hp), Ee = pair16(mc, 6 + 2 * hp), Ww = pair16(mc, 2 * hp);
+                const short2_t Nn = pair16(mu, 3 + 2 * hp), Ss = pair16(md, 3 + 2 * hp);
                 const short2_t dN = V - Nn, dE = V - Ee, dS = V - Ss, dW = V - Ww;
                 // two neighbouring compass points both darker: (N or S) and (E or W)
                 const short2_t dark = pmin(pmax(dN, dS), pmax(dE, dW)), bright = pmax(pmin(dN, dS), pmin(dE, dW));
@@ -267,15 +285,12 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
                 passbits |= ((sg >> 15) & 1u) << (2 * hp);
                 passbits |= ((sg >> 31) & 1u) << (2 * hp + 1);
             }
+            // pixels of the group that are region pixels and FAST centres: rx < SCW, 3 <= x < w - 3
+            const int xs = x0 - 1 + 8 * o;
+            const int jl = min(max(3 - xs, 0), 8), jh = min(max(min(SCW - 8 * o, w - 3 - xs), 0), 8);
+            passbits &= ((1u << jh) - 1u) & ~((1u << jl) - 1u);
         }
-        uint16_t pos[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int rx = 4 * q + b, x = x0 - 1 + rx;
-            if (!(rx < SCW && x >= 3 && x < w - 3)) passbits &= ~(1u << b);
-            pos[b] = (uint16_t)(ry * SCP + rx);
-        }
-        append4(passbits, pos, cand, &n_cand, lane);
+        append8(passbits, 8 * e, cand, NCAND - 1, &n_cand, lane);
     }
     __syncthreads();
     ORB_CLK(1);
@@ -321,25 +336,82 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
         const uint32_t raw4 = *reinterpret_cast<const uint32_t*>(c0);
         if (f == 0 && raw_frame0) *reinterpret_cast<uint32_t*>(raw_frame0 + (size_t)y * wp + xq) = raw4;
         if (raw4 != 0u && y >= lo && y < h - lo) {                              // most quads hold no corner at all
+            // the 3 x 6 neighbourhood of the quad in six more aligned reads issued together (a chain of byte reads behind
+            // short-circuit tests is eight LDS latencies in a row): row r as bytes x - 1 .. x + 4 of a 64-bit value
+            const uint32_t* cq = reinterpret_cast<const uint32_t*>(c0);
+            auto row6 = [](uint32_t L, uint32_t C, uint32_t R) { return (unsigned long long)(L >> 24) | ((unsigned long long)C << 8) | ((unsigned long long)(R & 0xffu) << 40); };
+            const unsigned long long ra = row6(cq[-SCP / 4 - 1], cq[-SCP / 4], cq[-SCP / 4 + 1]);
+            const unsigned long long rc = row6(cq[-1], raw4, cq[1]);
+            const unsigned long long rb = row6(cq[SCP / 4 - 1], cq[SCP / 4], cq[SCP / 4 + 1]);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int s = (int)((raw4 >> (8 * b)) & 0xffu);
                 const int x = xq + b;
-                if (s == 0 || x < lo || x >= w - lo) continue;
-                const uint8_t* p = c0 + b;
-                const bool keep = s > p[-1] && s > p[1] && s > p[-SCP - 1] && s > p[-SCP] && s > p[-SCP + 1] && s > p[SCP - 1] && s > p[SCP] && s > p[SCP + 1];
-                if (keep) kl[atomicAdd(&n_kept, 1)] = make_int2(x | (y << 16), s);
+                auto byte = [](unsigned long long v, int i) { return (int)((v >> (8 * i)) & 0xffu); };
+                const int m = max(max(max(byte(ra, b), byte(ra, b + 1)), max(byte(ra, b + 2), byte(rc, b))),
+                                  max(max(byte(rc, b + 2), byte(rb, b)), max(byte(rb, b + 1), byte(rb, b + 2))));
+                if (s > m && x >= lo && x < w - lo) kl[atomicAdd(&n_kept, 1)] = make_int2(x | (y << 16), s);     // s > m >= 0: a corner, strictly above its 8 neighbours
             }
         }
     }
+    if (BLUR) {
+        // horizontal pass (the candidate lists are dead): four outputs per thread from three aligned 32-bit LDS reads; each output
+        // is two 4-way byte dot products (v_dot4_u32_u8) over windows cut out of the 12 bytes with v_alignbyte
+        const uint32_t T0 = (uint32_t)taps.t[0] | ((uint32_t)taps.t[1] << 8) | ((uint32_t)taps.t[2] << 16) | ((uint32_t)taps.t[3] << 24);
+        const uint32_t T1 = (uint32_t)taps.t[4] | ((uint32_t)taps.t[5] << 8) | ((uint32_t)taps.t[6] << 16);
+        for (int e = tid; e < HROWS * (FT_W / 4); e += 256) {
+            const int ty = e / (FT_W / 4), tq = e % (FT_W / 4);
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(&tile[(ty + 1) * TP + FWX - 4 + 4 * tq]);   // bytes o .. o + 11, o = image x - 4; output j starts at o + 1 + j
+            const uint32_t A = sp[0], B = sp[1], C = sp[2];
+            int4 o;
+            o.x = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 1), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 1), T0, 0u, false), false);
+            o.y = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 2), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 2), T0, 0u, false), false);
+            o.z = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 3), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 3), T0, 0u, false), false);
+            o.w = (int)__builtin_amdgcn_udot4(C, T1, __builtin_amdgcn_udot4(B, T0, 0u, false), false);
+            *reinterpret_cast<int4*>(&hrow[ty * FT_W + 4 * tq]) = o;
+        }
+    }
     __syncthreads();
+    // the tile's keypoints go to the tile's own slots of the frame's list: no cursor, no atomic, nothing to clear between launches
     const int nk = n_kept;
-    if (nk == 0) { ORB_CLK(3); return; }
-    if (tid == 0) s_base = atomicAdd(&n_raw[f], nk);
-    __syncthreads();
-    int2* out = raw + (size_t)f * raw_cap + s_base;
+    const size_t t = ((size_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (tid == 0) tile_count[t] = nk;
+    int2* out = raw + t * F_MAXKP;
     for (int i = tid; i < nk; i += 256) out[i] = kl[i];
     ORB_CLK(3);
+    if (BLUR) {
+        // vertical pass: a thread owns four pixel columns and two consecutive rows, reads the eight row sums they need once and
+        // packs one 32-bit store per row; products fit 24 bits (tap <= 255, row sum < 2^16)
+        static_assert(FT_H % 2 == 0 && (FT_H / 2) * (FT_W / 4) <= 256, "one 4 x 2 pixel patch per thread");
+        uint8_t* O = blurred + (size_t)f * wp * h;
+        const int tq = tid % (FT_W / 4), strip = tid / (FT_W / 4);
+        const int xq = x0 + 4 * tq;
+        if (strip < FT_H / 2 && xq < wp) {
+            int4 hv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hv[i] = *reinterpret_cast<const int4*>(&hrow[(strip * 2 + i) * FT_W + 4 * tq]);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int y = y0 + strip * 2 + o;
+                if (y >= h) break;
+                int acc4[4] = { 0, 0, 0, 0 };
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    acc4[0] = (__mul24(taps.t[k], hv[o + k].x) + acc4[0]); acc4[1] = (__mul24(taps.t[k], hv[o + k].y) + acc4[1]);
+                    acc4[2] = (__mul24(taps.t[k], hv[o + k].z) + acc4[2]); acc4[3] = (__mul24(taps.t[k], hv[o + k].w) + acc4[3]);
+                }
+                uint32_t packed = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (xq + b >= w) continue;
+                    const int v = (acc4[b] + (1 << 15)) >> 16;
+                    packed |= (uint32_t)(v > 255 ? 255 : v) << (8 * b);
+                }
+                *reinterpret_cast<uint32_t*>(O + (size_t)y * wp + xq) = packed;
+            }
+        }
+        ORB_CLK(4);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -393,6 +465,7 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
 {
 #pragma clang fp contract(off)          // float results feed comparisons that must match the CPU restatement: plain IEEE operations, never an FMA
     __shared__ int sh[16];
+    __shared__ int chunk_start[SEL_T + 1];
     __shared__ int lhist[256 * SEL_HCOPIES];
     __shared__ int suffix[257];
     __shared__ int s_mnt, s_cut;
@@ -401,20 +474,40 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
     __shared__ __attribute__((aligned(16))) unsigned long long l_key[SEL_CAP];
     __shared__ int l_cellstart[SEL_CELLS + 1], l_cellfill[SEL_CELLS];
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int2* raw = a.raw + (size_t)f * a.raw_cap;
+    const int2* raw = a.raw + (size_t)f * a.n_tiles * a.tile_cap;
+    const int* tcount = a.tile_count + (size_t)f * a.n_tiles;
     mage_keypoint* okp = a.out_kp + (size_t)f * a.capacity;
-    const int n_raw = a.n_raw[f];
     const float size_f = (float)a.patch_size * 1.0f;
     const int N = a.nfeatures;
     ORB_CLK_BEGIN();
+    for (int e = tid; e < 256 * SEL_HCOPIES; e += SEL_T) lhist[e] = 0;
+    if (tid == 0) { s_mnt = -1; s_cut = -1; s_minX = 1 << 30; s_maxX = -1; s_minY = 1 << 30; s_maxY = -1; s_minS = 1 << 30; }
+    // The frame's list is ragged: tile t holds tcount[t] entries in slots t * tile_cap ...  Thread c owns the tiles [c per, (c + 1) per)
+    // (one tile at 640 x 480); chunk_start[c] = entries before them, so entry i of the frame lives in the chunk found by a binary
+    // search and a walk over at most `per` counts.
+    const int per = (a.n_tiles + SEL_T - 1) / SEL_T;
+    {
+        const int t0 = min(tid * per, a.n_tiles), t1 = min(t0 + per, a.n_tiles);
+        int local = 0;
+        for (int t = t0; t < t1; ++t) local += tcount[t];
+        int tot;
+        const int excl = block_scan_excl(local, sh, tot);
+        chunk_start[tid] = excl;
+        if (tid == 0) chunk_start[SEL_T] = tot;
+    }
+    __syncthreads();
+    const int n_raw = chunk_start[SEL_T];
+    auto entry = [&](int i) -> int2 {
+        int lo = 0, hi = SEL_T;                          // chunk_start[lo] <= i < chunk_start[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_start[mid] <= i) lo = mid; else hi = mid; }
+        int off = i - chunk_start[lo], t = lo * per;
+        if (per > 1) for (int c; off >= (c = tcount[t]); ++t) off -= c;
+        return raw[(size_t)t * a.tile_cap + off];
+    };
     // the list entries of this thread (thread t owns entries t, t + 1024, ...)
     int2 rr[SEL_REG];
 #pragma unroll
-    for (int k = 0; k < SEL_REG; ++k) { const int i = tid + SEL_T * k; rr[k] = i < n_raw ? raw[i] : make_int2(0, -1); }
-    for (int e = tid; e < 256 * SEL_HCOPIES; e += SEL_T) lhist[e] = 0;
-    if (tid == 0) { s_mnt = -1; s_cut = -1; s_minX = 1 << 30; s_maxX = -1; s_minY = 1 << 30; s_maxY = -1; s_minS = 1 << 30; }
-    __syncthreads();
-    if (tid == 0) a.n_raw[f] = 0;                       // the cursor of this frame, left at zero for the next launch of k_fast_keypoints
+    for (int k = 0; k < SEL_REG; ++k) { const int i = tid + SEL_T * k; rr[k] = i < n_raw ? entry(i) : make_int2(0, -1); }
 
     // Keeps every entry as the reference's early returns do (fewer detections than the quota): output in raster order = rank by
     // position.  `get(i)` reads entry i of the set, n of them.
@@ -429,10 +522,10 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
     };
     if (n_raw <= N) {
         if (n_raw <= SEL_CAP) {
-            for (int i = tid; i < n_raw; i += SEL_T) { const int2 r = raw[i]; l_cand[i] = (unsigned long long)(unsigned)r.x | ((unsigned long long)(unsigned)r.y << 32); }
+            for (int i = tid; i < n_raw; i += SEL_T) { const int2 r = entry(i); l_cand[i] = (unsigned long long)(unsigned)r.x | ((unsigned long long)(unsigned)r.y << 32); }
             __syncthreads();
             emit_all_by_position([&](int i) { const unsigned long long v = l_cand[i]; return make_int2((int)(unsigned)v, (int)(v >> 32)); }, n_raw);
-        } else emit_all_by_position([&](int i) { return raw[i]; }, n_raw);
+        } else emit_all_by_position(entry, n_raw);
         return;
     }
     // ---- RetainBestFeatures (OpenCVModified.cpp:571-617): whole histogram bins from 255 downwards.  Histogram of the responses
@@ -441,7 +534,7 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
     auto for_each_entry = [&](auto fn) {
 #pragma unroll
         for (int k = 0; k < SEL_REG; ++k) if (tid + SEL_T * k < n_raw) fn(rr[k]);
-        for (int i = tid + SEL_T * SEL_REG; i < n_raw; i += SEL_T) fn(raw[i]);
+        for (int i = tid + SEL_T * SEL_REG; i < n_raw; i += SEL_T) fn(entry(i));
     };
     for_each_entry([&](int2 r) { atomicAdd(&lhist[(r.y & 255) * SEL_HCOPIES + (lane & (SEL_HCOPIES - 1))], 1); });
     __syncthreads();
@@ -492,11 +585,11 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
     if (N > M) {
         // AdaptiveNonMaximalSuppresion returns its input when there is nothing to suppress (feature_strength > 1 can cut below
         // the quota): the kept set in raster order.  Rare, so the set is simply re-filtered from HBM.
-        int2* scratch = a.cand + (size_t)f * a.raw_cap;
+        int2* scratch = reinterpret_cast<int2*>(a.cand64 + (size_t)f * a.scratch_cap);
         __shared__ int s_n;
         if (tid == 0) s_n = 0;
         __syncthreads();
-        for (int i = tid; i < n_raw; i += SEL_T) { const int2 r = raw[i]; if (r.y >= cut) scratch[atomicAdd(&s_n, 1)] = r; }
+        for (int i = tid; i < n_raw; i += SEL_T) { const int2 r = entry(i); if (r.y >= cut) scratch[atomicAdd(&s_n, 1)] = r; }
         __threadfence_block();
         __syncthreads();
         emit_all_by_position([&](int i) { return scratch[i]; }, s_n);
@@ -644,8 +737,8 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
         ORB_CLK(14);
     };
     if (in_lds) suppress_and_rank(l_cand, l_cellstart, l_cellfill, l_key);
-    else suppress_and_rank(a.cand64 + (size_t)f * a.raw_cap, a.cell_start + (size_t)f * (a.ncells + 1), a.cell_fill + (size_t)f * (a.ncells + 1),
-                           a.key64 + (size_t)f * a.raw_cap);
+    else suppress_and_rank(a.cand64 + (size_t)f * a.scratch_cap, a.cell_start + (size_t)f * (a.ncells + 1), a.cell_fill + (size_t)f * (a.ncells + 1),
+                           a.key64 + (size_t)f * a.scratch_cap);
     if (tid == 0) a.out_count[f] = min(N, a.capacity);
 }
 
@@ -967,11 +1060,21 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
 
-void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, int border, uint8_t* raw_frame0, int wp,
-                     int2* raw, size_t raw_cap, int* n_raw, hipStream_t st)
+void orb_fast_tiling(int w, int h, int* tiles_x, int* tiles_y, int* tile_cap)
 {
-    hipLaunchKernelGGL(k_fast_keypoints, dim3(cdiv(wp, FT_W), cdiv(h, FT_H), n_frames), dim3(256), 0, st, img, w, h, stride, frame_stride, threshold, border,
-                       raw_frame0, wp, raw, raw_cap, n_raw);
+    *tiles_x = cdiv((w + 3) & ~3, FT_W); *tiles_y = cdiv(h, FT_H); *tile_cap = F_MAXKP;
+}
+
+bool orb_blur_fuses(const OrbTaps& taps) { return taps.radius == 3 && taps.t[3] < 256; }
+
+void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, int border, uint8_t* raw_frame0, int wp,
+                     int2* raw, int* tile_count, const OrbTaps* taps, uint8_t* blurred, hipStream_t st)
+{
+    const dim3 grid(cdiv(wp, FT_W), cdiv(h, FT_H), n_frames);
+    if (taps) hipLaunchKernelGGL(k_fast_keypoints<true>, grid, dim3(256), 0, st, img, w, h, stride, frame_stride, threshold, border, raw_frame0, wp, raw, tile_count,
+                                 *taps, blurred);
+    else hipLaunchKernelGGL(k_fast_keypoints<false>, grid, dim3(256), 0, st, img, w, h, stride, frame_stride, threshold, border, raw_frame0, wp, raw, tile_count,
+                            OrbTaps{}, blurred);
 }
 
 void orb_launch_select(const OrbSelectArgs& a, int n_frames, hipStream_t st)

@@ -49,6 +49,7 @@ def _declare():
     L.mage_orb_detect_batch_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.mage_orb_debug_read.argtypes = [vp, vp, vp]
     L.mage_orb_get_profile.argtypes = [vp, C.POINTER(OrbProfile)]
+    L.mage_orb_enable_profile.argtypes = [vp, C.c_int]
     L.mage_orb_undistort_keypoints.argtypes = [vp, vp, C.c_int, C.POINTER(UndistortParams)]
     L.mage_orb_undistort_keypoints_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(UndistortParams)]
     L.mage_hamming256.argtypes = [_u8, _u8]; L.mage_hamming256.restype = C.c_int
@@ -145,6 +146,10 @@ class OrbDetector:
         s = np.zeros((h, w), np.uint8); b = np.zeros((h, w), np.uint8)
         check(self._L.mage_orb_debug_read(self._h, s.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
         return s, b
+
+    def enable_profile(self, on: bool = True) -> None:
+        """Stage timings (HIP events between the kernels) are recorded only after this; off by default."""
+        check(self._L.mage_orb_enable_profile(self._h, int(on)))
 
     def profile(self) -> OrbProfile:
         p = OrbProfile()

@@ -42,8 +42,12 @@ def main():
         t0 = time.perf_counter()
         for _ in range(reps):
             kp, de, cn = det.detect_batch_device(imgs.data_ptr(), 2 * batch, W, H, CAP)
-        wall = (time.perf_counter() - t0) / reps
+        wall = (time.perf_counter() - t0) / reps                        # as a caller sees it: no stage events
+        det.enable_profile(True)
+        for _ in range(2):
+            kp, de, cn = det.detect_batch_device(imgs.data_ptr(), 2 * batch, W, H, CAP)
         p = det.profile()
+        det.enable_profile(False)
         fps = 2 * batch / wall
         alg_bytes = 2 * batch * (W * H * 3 + CAP * 512 + CAP * 60)      # FAST read, blur read+write, BRIEF gathers, outputs
         # matching: first `batch` frames against the second `batch` frames, descriptors stay in HBM

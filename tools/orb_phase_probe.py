@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development probe: where the cycles of k_fast_nms / k_select go.
+"""Development probe: where the cycles of k_fast_keypoints / k_select go.
 
 Builds a SECOND copy of the library with -DMAGE_ORB_CLOCKS (mageslam_amd/_probe/libmageslam_hip_clk.so: thread 0 of every
 workgroup adds the shader-clock time of each phase to a device array), runs the ORB detector of config 2 on it at batch 1 and
@@ -32,7 +32,7 @@ def build():
     subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROBE_LIB, *objs])
 
 
-FAST = {0: "zero + stage window", 1: "compass test + compaction", 2: "exact score of survivors", 3: "3x3 NMS + kept map + histogram"}
+FAST = {0: "zero + stage window", 1: "compass test + compaction", 2: "pair test + exact score of survivors", 3: "3x3 NMS + horizontal blur pass + keypoint output", 4: "vertical blur pass"}
 SELECT = {10: "histogram suffix scan + thresholds", 11: "compaction of candidates + bounding box", 12: "cell binning", 13: "ring search (radii)", 14: "rank + output"}
 
 
@@ -49,6 +49,7 @@ def main():
     base = [frames.frame_pair(500 + i) for i in range(8)]
     allf = np.concatenate([np.stack([p[0] for p in base]), np.stack([p[1] for p in base])])
     det = OrbDetector()
+    det.enable_profile(True)
     out = {}
     for nf in (1, 512):
         imgs = torch.from_numpy(allf[np.arange(nf) % 16]).cuda().contiguous()
@@ -63,7 +64,7 @@ def main():
         torch.cuda.synchronize()
         assert L.mage_orb_debug_clocks(buf, 1) == 0
         p = det.profile()
-        for name, tab in (("k_fast_nms", FAST), ("k_select", SELECT)):
+        for name, tab in (("k_fast_keypoints", FAST), ("k_select", SELECT)):
             tot = sum(buf[i] for i in tab) or 1
             out[f"{name} frames={nf}"] = {v: round(buf[i] / tot, 3) for i, v in tab.items()}
             out[f"{name} frames={nf}"]["ticks_all_sampled_workgroups"] = tot
