@@ -749,15 +749,19 @@ __global__ __launch_bounds__(256) void k_import_poses(double* __restrict__ pose0
 __device__ __forceinline__ bool last_block_arrives(int* __restrict__ counter, int n_blocks)
 {
     __shared__ int is_last;
-    __threadfence();                                  // this block's partials: visible device-wide before the count
+    // Every wavefront waits until its own stores have reached L2; then ONE release fence in thread 0 writes this XCD's L2 back
+    // (the blocks of a launch sit on different XCDs) before the count.  __threadfence() in every thread costs a write-back per
+    // wavefront and, at a few dozen blocks per launch, more than the kernels' arithmetic.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = prev == n_blocks - 1;
         if (is_last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
     }
     __syncthreads();
-    if (is_last) __threadfence();
+    if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return is_last != 0;
 }
 // sum of partial[0..n) in a fixed order by one block; result to *out (all 256 threads call)

@@ -5,6 +5,8 @@
 // LDS as 4 x u64 per descriptor (<= 2 x 14 KB at 440 features), every thread owns query rows and walks the
 // other set with xor + v_bcnt; best / second-best / in-radius count are kept per row, then the mutual check and
 // an ordered compaction emit cv::DMatch records in ascending query order.  Batched over pairs on blockIdx.x.
+#include <cstdlib>
+
 #include "orb_kernels.h"
 
 namespace mage {
@@ -74,6 +76,115 @@ __global__ __launch_bounds__(MT) void k_match(const uint8_t* __restrict__ descA,
         }
         __syncthreads();
         if (tid == 0) { int s = 0; for (int w = 0; w < MT / 64; ++w) s += wave_cnt[w]; base_s += s; }
+        __syncthreads();
+    }
+    if (tid == 0) counts[p] = base_s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same Match for FEW pairs (what the tracker submits: one or two per frame): one workgroup per pair leaves 255 compute units
+// idle for the 2 x nA x nB distances, so a pair is spread over ceil(capA / 64) + ceil(capB / 64) workgroups.  A workgroup owns 64
+// rows of one direction -- one per lane -- and stages the other set in LDS; its eight wavefronts walk interleaved eighths of that
+// set (every lane of a wavefront reads the same descriptor: a broadcast), their (best, second best, in-radius count) are merged
+// through LDS, and the workgroup that finishes LAST for its pair runs the mutual check and the ordered compaction.  Same results
+// as k_match bit for bit: a tie for the best goes to the lower index, as the sequential scan does.
+// ---------------------------------------------------------------------------------------------
+constexpr int MR = 64, MW = 8;      // rows per workgroup, wavefronts (each walks every MW-th descriptor of the other set)
+
+struct RowBest { int d1, t1, d2, cnt; };
+
+__device__ __forceinline__ RowBest merge_best(const RowBest a, const RowBest b)
+{
+    RowBest r;
+    const bool b_wins = b.d1 < a.d1 || (b.d1 == a.d1 && b.t1 < a.t1);
+    r.d2 = min(min(a.d2, b.d2), max(a.d1, b.d1));
+    r.d1 = min(a.d1, b.d1);
+    r.t1 = b_wins ? b.t1 : a.t1;
+    r.cnt = a.cnt + b.cnt;
+    return r;
+}
+
+__global__ __launch_bounds__(MR * MW) void k_match_rows(const uint8_t* __restrict__ descA, const int* __restrict__ countsA, int capA,
+                                                        const uint8_t* __restrict__ descB, const int* __restrict__ countsB, int capB,
+                                                        int max_dist, int min_diff, int* __restrict__ scratch, mage_dmatch* __restrict__ out, int cap_out,
+                                                        int* __restrict__ counts, int* __restrict__ done, int groupsA, int use_lds)
+{
+    extern __shared__ ulonglong4 sm[];
+    __shared__ int4 part[MW][MR];
+    __shared__ int wave_cnt[MW];
+    __shared__ int base_s, is_last;
+    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nA = countsA[p], nB = countsB[p];
+    const ulonglong4* A = reinterpret_cast<const ulonglong4*>(descA + (size_t)p * capA * 32);
+    const ulonglong4* B = reinterpret_cast<const ulonglong4*>(descB + (size_t)p * capB * 32);
+    int* f = scratch + (size_t)p * (capA + capB) * 2;    // f[q] best train, f[capA + q] distance
+    int* g = f + 2 * capA;                              // g[t] best query
+    mage_dmatch* o = out + (size_t)p * cap_out;
+    const bool dirA = (int)blockIdx.x < groupsA;
+    const int row0 = (dirA ? (int)blockIdx.x : (int)blockIdx.x - groupsA) * MR;
+    const int nQ = dirA ? nA : nB, nT = dirA ? nB : nA;
+    if (nA > 0 && nB > 0 && row0 < nQ) {
+        const ulonglong4* Q = dirA ? A : B;
+        const ulonglong4* T = dirA ? B : A;
+        if (use_lds) {
+            for (int i = tid; i < nT; i += MR * MW) sm[i] = T[i];
+            __syncthreads();
+            T = sm;
+        }
+        const int row = row0 + lane;
+        RowBest st = { 1 << 30, 1 << 30, 1 << 30, 0 };
+        if (row < nQ) {
+            const ulonglong4 q = Q[row];
+            for (int t = wave; t < nT; t += MW) {
+                const ulonglong4 v = T[t];
+                const int d = __popcll(q.x ^ v.x) + __popcll(q.y ^ v.y) + __popcll(q.z ^ v.z) + __popcll(q.w ^ v.w);
+                if (d <= max_dist) {
+                    ++st.cnt;
+                    if (d < st.d1) { st.d2 = st.d1; st.d1 = d; st.t1 = t; }
+                    else if (d < st.d2) st.d2 = d;
+                }
+            }
+        }
+        part[wave][lane] = make_int4(st.d1, st.t1, st.d2, st.cnt);
+        __syncthreads();
+        if (wave == 0 && row < nQ) {
+#pragma unroll
+            for (int w = 1; w < MW; ++w) { const int4 v = part[w][lane]; st = merge_best(st, RowBest{ v.x, v.y, v.z, v.w }); }
+            const bool none = st.cnt == 0 || (st.cnt > 1 && (st.d2 - st.d1) < min_diff);
+            if (dirA) { f[row] = none ? -1 : st.t1; f[capA + row] = none ? 0 : st.d1; }
+            else g[row] = none ? -1 : st.t1;
+        }
+    }
+    // The last workgroup of the pair to get here sees every row's result.  Only wavefront 0 stored results, so ONE release fence in
+    // its thread 0 (write-back of this XCD's L2, the pairs' workgroups sit on different XCDs) publishes them before the count; a
+    // fence in every wavefront would cost eight write-backs per workgroup.
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const int prev = __hip_atomic_fetch_add(&done[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = prev == (int)gridDim.x - 1;
+        if (is_last) __hip_atomic_store(&done[p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
+        base_s = 0;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (nA == 0 || nB == 0) { if (tid == 0) counts[p] = 0; return; }
+    for (int q0 = 0; q0 < nA; q0 += MR * MW) {
+        const int q = q0 + tid;
+        int t = -1;
+        if (q < nA) { t = f[q]; if (t >= 0 && g[t] != q) t = -1; }
+        const unsigned long long bal = __ballot(t >= 0);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (t >= 0 && off + before < cap_out) {
+            mage_dmatch m = { q, t, -1, (float)f[capA + q] };
+            o[off + before] = m;
+        }
+        __syncthreads();
+        if (tid == 0) { int sum = 0; for (int w = 0; w < MW; ++w) sum += wave_cnt[w]; base_s += sum; }
         __syncthreads();
     }
     if (tid == 0) counts[p] = base_s;
@@ -253,11 +364,23 @@ void radius_match_launch(const mage_keypoint* qk, int nq, const float2* qpos, co
 void match_init_device()
 {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_DESC * 32);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_DESC * 32);
 }
 
+// `done`: one int per pair, zero on entry (the kernel leaves it so).  Few pairs are spread over many workgroups each; from a few
+// hundred pairs on the one-workgroup-per-pair kernel fills the device by itself and stages each set once.
 void match_launch(int n_pairs, const uint8_t* descA, const int* countsA, int capA, const uint8_t* descB, const int* countsB, int capB,
-                  int max_dist, int min_diff, int* scratch, mage_dmatch* out, int cap_out, int* counts, hipStream_t st)
+                  int max_dist, int min_diff, int* scratch, mage_dmatch* out, int cap_out, int* counts, int* done, hipStream_t st)
 {
+    static const int split_below = [] { const char* e = std::getenv("MAGE_MATCH_SPLIT_BELOW"); return e ? std::atoi(e) : 256; }();
+    const int groupsA = (capA + MR - 1) / MR, groupsB = (capB + MR - 1) / MR;
+    if (n_pairs < split_below && groupsA + groupsB > 0) {
+        const int cap_t = capA > capB ? capA : capB;          // the staged set is the OTHER side's
+        const int rows_lds = cap_t <= 2 * LDS_DESC ? 1 : 0;
+        hipLaunchKernelGGL(k_match_rows, dim3(groupsA + groupsB, n_pairs), dim3(MR * MW), rows_lds ? (size_t)cap_t * 32 : 0, st, descA, countsA, capA, descB, countsB,
+                           capB, max_dist, min_diff, scratch, out, cap_out, counts, done, groupsA, rows_lds);
+        return;
+    }
     const int use_lds = (capA + capB) <= 2 * LDS_DESC ? 1 : 0;
     const size_t lds = use_lds ? (size_t)(capA + capB) * 32 : 0;
     hipLaunchKernelGGL(k_match, dim3(n_pairs), dim3(MT), lds, st, descA, countsA, capA, descB, countsB, capB, max_dist, min_diff, scratch, out,

@@ -438,7 +438,8 @@ struct mage_matcher {
     int device = 0;
     hipStream_t stream = nullptr;
     DevBuf<uint8_t> d_A, d_B;
-    DevBuf<int> d_cA, d_cB, d_scratch, d_counts;
+    DevBuf<int> d_cA, d_cB, d_scratch, d_counts, d_done;       // d_done: per-pair arrival counters of k_match_rows, zero between launches
+    size_t done_zeroed = 0;
     DevBuf<mage_dmatch> d_out;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     double last_ms = 0;
@@ -497,9 +498,14 @@ mage_status run_match(mage_matcher* h, int n_pairs, const uint8_t* dA, const int
     MAGE_TRY(h->d_scratch.reserve(np * (size_t)(capA + capB) * 2 + 4));
     MAGE_TRY(h->d_out.reserve(np * (size_t)std::max(cap_out, 1)));
     MAGE_TRY(h->d_counts.reserve(np));
+    MAGE_TRY(h->d_done.reserve(np));
+    if (h->done_zeroed != h->d_done.cap) {               // a fresh (recycled) allocation: zero once, the kernel keeps the counters at zero
+        MAGE_HIP(hipMemsetAsync(h->d_done.p, 0, sizeof(int) * h->d_done.cap, h->stream));
+        h->done_zeroed = h->d_done.cap;
+    }
     if (n_pairs == 0) return MAGE_OK;
     MAGE_HIP(hipEventRecord(h->e0, h->stream));
-    match_launch(n_pairs, dA, dcA, capA, dB, dcB, capB, max_dist, min_diff, h->d_scratch.p, h->d_out.p, cap_out, h->d_counts.p, h->stream);
+    match_launch(n_pairs, dA, dcA, capA, dB, dcB, capB, max_dist, min_diff, h->d_scratch.p, h->d_out.p, cap_out, h->d_counts.p, h->d_done.p, h->stream);
     MAGE_HIP(hipEventRecord(h->e1, h->stream));
     return MAGE_OK;
 }

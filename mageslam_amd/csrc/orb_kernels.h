@@ -46,8 +46,7 @@ void orb_launch_brief(const uint8_t* blurred, int wp, int h, int n_frames, const
 // Hamming brute-force two-way matcher: one workgroup per pair.
 void match_init_device();   // once per device: opt k_match into its LDS staging size
 void match_launch(int n_pairs, const uint8_t* descA, const int* countsA, int capA, const uint8_t* descB, const int* countsB, int capB,
-                  int max_dist, int min_diff, int* scratch /* n_pairs x (capA + capB) x 2 ints */, mage_dmatch* out, int cap_out, int* counts,
-                  hipStream_t st);
+                  int max_dist, int min_diff, int* scratch, mage_dmatch* out, int cap_out, int* counts, int* done, hipStream_t st);
 
 // RadiusMatch: one (query set, target set) problem per launch.
 // cv::undistortPoints constants in float64 (camera matrix entries, 1/fx, 1/fy, k1 k2 p1 p2 k3 k4 k5 k6, P row-major)
