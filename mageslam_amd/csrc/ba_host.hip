@@ -260,6 +260,7 @@ struct mage_ba {
     DevBuf<int> d_lm_ptr, d_lm_pt, d_lm_wptr, d_w_hc, d_w_lm, d_camE_ptr, d_camE, d_camS_ptr, d_camS, d_blk_ptr;
     DevBuf<int2> d_blk_ij, d_con;
     DevBuf<int> d_blk_order;
+    bool dup_slots = false;            // some landmark is observed twice by one free camera
     DevBuf<double> d_errL, d_U, d_bc, d_V, d_bp, d_W, d_Dinv, d_db, d_S, d_y, d_xc, d_xl, d_partial, d_scal, d_Linv;
     DevBuf<uint8_t> d_flagL, d_L_active;
     DevBuf<int> d_T_kind, d_tc_hc, d_tc_ptr, d_tc_item, d_tp_ptr, d_tp_item;
@@ -568,6 +569,14 @@ mage_status initialize_optimization(mage_ba* h)
             }
         }
     });
+    // several observations of one landmark by one free camera share a W slot (their blocks are summed in order); the small-problem
+    // linearisation gives every observation its own lane only when that never happens
+    h->dup_slots = true;
+    if (nfc * 6 <= 128) {                       // only the small-problem path asks (ba_small_applies)
+        long long slot_obs = 0;
+        for (size_t i = 0; i < (size_t)nL; ++i) slot_obs += L_slot[i] >= 0 ? 1 : 0;
+        h->dup_slots = slot_obs != (long long)nw;
+    }
     MAGE_TRY(push(h->d_L_uv, L_uv, nL)); MAGE_TRY(push(h->d_L_info, L_info, nL)); MAGE_TRY(push(h->d_L_cam, L_cam, nL));
     MAGE_TRY(push(h->d_L_pt, L_pt, nL)); MAGE_TRY(push(h->d_L_slot, L_slot, nL));
     MAGE_TRY(push(h->d_w_hc, w_hc, nw)); MAGE_TRY(push(h->d_w_lm, w_lm, nw));
@@ -753,7 +762,9 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(h->d_y.reserve(n_pad));
     MAGE_TRY(h->d_xc.reserve(n_pad));
     MAGE_TRY(h->d_xl.reserve((size_t)nlm * 4 + 1));
-    MAGE_TRY(h->d_partial.reserve(std::max<size_t>(3 * 1024, (size_t)nb_l + nb_c) + 16));
+    // two-level reductions: one double per block of the widest launch; the small-problem linearisation (8 lanes per landmark, 4 blocks
+    // per camera) also parks the cameras' partial (U, b_c) sums behind its chi2 partials
+    MAGE_TRY(h->d_partial.reserve(std::max<size_t>(4 * 1024, std::max<size_t>((size_t)nb_l + nb_c, (size_t)nlm * 8 / 256 + (size_t)nfc * 4 * 29 + 8)) + 16));
     MAGE_TRY(h->d_scal.reserve(SC_COUNT));
     MAGE_TRY(h->d_Linv.reserve(chol_workspace_doubles(n_pad)));
     MAGE_TRY(h->d_queue.reserve(chol_sync_ints(n_pad) + 1));
@@ -767,7 +778,7 @@ mage_status initialize_optimization(mage_ba* h)
 
     tm.mark("reserve + sync");
     BaDeviceView& v = h->view;
-    v.n_cams = nc; v.n_pts = np; v.n_L = nL; v.n_lm = nlm; v.n_fc = nfc; v.n_w = nw; v.n_blk = nblk;
+    v.n_cams = nc; v.n_pts = np; v.n_L = nL; v.n_lm = nlm; v.n_fc = nfc; v.n_w = nw; v.n_blk = nblk; v.dup_slots = h->dup_slots ? 1 : 0;
     v.points_free = points_free ? 1 : 0; v.n_pad = n_pad;
     v.camK = h->d_camK.p; v.cam2hc = h->d_cam2hc.p; v.hc2cam = h->d_hc2cam.p;
     v.L_uv = h->d_L_uv.p; v.L_info = h->d_L_info.p; v.L_cam = h->d_L_cam.p; v.L_pt = h->d_L_pt.p; v.L_slot = h->d_L_slot.p; v.L_edge = h->d_L_edge.p; v.L_active = h->d_L_active.p;

@@ -23,6 +23,7 @@ struct BaDeviceView {
     int n_blk;                // non-empty upper 6x6 blocks of the reduced camera matrix
     int points_free;          // 0 when BundlerParameters::ArePointsFixed
     int n_pad;                // padded order of the reduced camera system (multiple of the tile)
+    int dup_slots;            // 1 when some landmark is observed twice by one free camera (several observations share a W slot)
 
     // ---- state (current = accepted estimate, trial = LM candidate; swapped on accept)
     double* pose_cur;   double* pose_trial;   // n_cams x 8 : qx qy qz qw tx ty tz pad

@@ -774,9 +774,8 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ partial
 }
 
 // (V_l + lambda I)^-1 in the cofactor form of k_lm_invert (same operations, same order)
-__device__ __forceinline__ void lm_dinv(const BaDeviceView& v, int l, double lambda, double D[6])
+__device__ __forceinline__ void lm_dinv_from(const double* Vl, double lambda, double D[6])
 {
-    const double* Vl = v.V + (size_t)l * 6;
     const double m00 = Vl[0] + lambda, m01 = Vl[1], m02 = Vl[2], m11 = Vl[3] + lambda, m12 = Vl[4], m22 = Vl[5] + lambda;
     const double c00 = m11 * m22 - m12 * m12;
     const double c10 = m12 * m02 - m22 * m01;
@@ -788,16 +787,91 @@ __device__ __forceinline__ void lm_dinv(const BaDeviceView& v, int l, double lam
     D[4] = (m02 * m01 - m00 * m12) * id;
     D[5] = (m00 * m11 - m01 * m01) * id;
 }
+__device__ __forceinline__ void lm_dinv(const BaDeviceView& v, int l, double lambda, double D[6]) { lm_dinv_from(v.V + (size_t)l * 6, lambda, D); }
+
+// Lanes per landmark and workgroups per camera of the linearisation below: a landmark has ~10 observations and a camera of a local
+// window ~2500, and a thread that walks them one after another waits out three dependent loads per observation with nothing else
+// on its compute unit to hide them (a local BA is ~200 wavefronts on 256 compute units).
+constexpr int SMALL_LPL = 8, SMALL_CPC = 4;
 
 __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double delta, int nbL, int want_maxdiag, int* __restrict__ counter)
 {
     __shared__ double sm[4];
     __shared__ double part[4][28];
+    __shared__ double udiag[128];
     const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_blocks = gridDim.x;
+    const int nbC = v.n_fc * SMALL_CPC;
+    double* cam_part = v.partial + n_blocks;           // n_fc x SMALL_CPC x 28 partial (U, b_c) sums, behind the chi2 partials
     double chi = 0;                                    // this thread's share of the robust chi2 (one role per problem kind owns it)
-    if (bid < nbL) {
-        // ---- landmark role: k_linearize_lm, plus the residuals / chi2 k_error would have produced
+    if (bid < nbL && !v.dup_slots) {
+        // ---- landmark role, SMALL_LPL lanes per landmark: lane `sub` takes observations beg + sub, beg + sub + 8, ...; every
+        // observation owns its W block (no two share a slot), V_l and b_l are summed over the lanes in a fixed tree
+        const int gl = bid * 256 + tid, l = gl / SMALL_LPL, sub = gl % SMALL_LPL;
+        double V[6] = { 0, 0, 0, 0, 0, 0 }, bp[3] = { 0, 0, 0 };
+        if (l < v.n_lm) {
+            const int pt = v.lm_pt[l];
+            const double X = v.pt_cur[(size_t)pt * 4], Y = v.pt_cur[(size_t)pt * 4 + 1], Z = v.pt_cur[(size_t)pt * 4 + 2];
+            const int end = v.lm_ptr[l + 1];
+            for (int i = v.lm_ptr[l] + sub; i < end; i += SMALL_LPL) {
+                const int slot = v.L_slot[i];
+                double Wacc[18];
+#pragma unroll
+                for (int k = 0; k < 18; ++k) Wacc[k] = 0;
+                if (v.L_active[i]) {
+                    const int cam = v.L_cam[i];
+                    PoseD P = load_pose(v.pose_cur, cam);
+                    EdgeGeom g = edge_geom(P, v.camK, cam, X, Y, Z, v.L_uv[i]);
+                    *reinterpret_cast<double2*>(v.errL + (size_t)i * 2) = make_double2(g.e0, g.e1);
+                    const double f = v.camK[cam * 4];
+                    const double info = (double)v.L_info[i];
+                    double rho0, rho1;
+                    huber(info * (g.e0 * g.e0 + g.e1 * g.e1), delta, rho0, rho1);
+                    chi += rho0;
+                    const double w = info * rho1;
+                    const double r0 = -info * g.e0 * rho1, r1 = -info * g.e1 * rho1;
+                    double R[9], Jp[6];
+                    q_to_R(P.qx, P.qy, P.qz, P.qw, R);
+                    jac_point(g, f, R, Jp);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) bp[a] += Jp[a] * r0 + Jp[3 + a] * r1;
+                    V[0] += Jp[0] * w * Jp[0] + Jp[3] * w * Jp[3];
+                    V[1] += Jp[0] * w * Jp[1] + Jp[3] * w * Jp[4];
+                    V[2] += Jp[0] * w * Jp[2] + Jp[3] * w * Jp[5];
+                    V[3] += Jp[1] * w * Jp[1] + Jp[4] * w * Jp[4];
+                    V[4] += Jp[1] * w * Jp[2] + Jp[4] * w * Jp[5];
+                    V[5] += Jp[2] * w * Jp[2] + Jp[5] * w * Jp[5];
+                    if (slot >= 0) {
+                        double Jc[12];
+                        jac_pose(g, f, Jc);
+#pragma unroll
+                        for (int a = 0; a < 6; ++a)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) Wacc[a * 3 + c] += Jc[a] * w * Jp[c] + Jc[6 + a] * w * Jp[3 + c];
+                    }
+                }
+                if (slot >= 0) {
+                    double2* Wd = reinterpret_cast<double2*>(v.W + (size_t)slot * 18);                // 144-byte block, 16-byte aligned: nine 128-bit stores
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) Wd[k] = make_double2(Wacc[2 * k], Wacc[2 * k + 1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < SMALL_LPL; m <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) V[k] += __shfl_xor(V[k], m, 64);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) bp[k] += __shfl_xor(bp[k], m, 64);
+        }
+        if (l < v.n_lm && sub == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v.V[(size_t)l * 6 + k] = V[k];
+            v.bp[(size_t)l * 4 + 0] = bp[0]; v.bp[(size_t)l * 4 + 1] = bp[1]; v.bp[(size_t)l * 4 + 2] = bp[2]; v.bp[(size_t)l * 4 + 3] = 0;
+        }
+    } else if (bid < nbL) {
+        // ---- landmark role, one thread per landmark (some observations share a W slot: their blocks are summed in order):
+        // k_linearize_lm, plus the residuals / chi2 k_error would have produced
         const int l = bid * 256 + tid;
         if (l < v.n_lm) {
             const int pt = v.lm_pt[l];
@@ -859,9 +933,10 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
             for (int k = 0; k < 6; ++k) v.V[(size_t)l * 6 + k] = V[k];
             v.bp[(size_t)l * 4 + 0] = bp[0]; v.bp[(size_t)l * 4 + 1] = bp[1]; v.bp[(size_t)l * 4 + 2] = bp[2]; v.bp[(size_t)l * 4 + 3] = 0;
         }
-    } else if (bid < nbL + v.n_fc) {
-        // ---- camera role: k_linearize_cam<true> (one workgroup per camera); owns the chi2 when the points are fixed
-        const int hc = bid - nbL;
+    } else if (bid < nbL + nbC) {
+        // ---- camera role: k_linearize_cam<true>, SMALL_CPC workgroups per camera, each a contiguous quarter of the camera's
+        // observations; the last block adds the quarters in order.  Owns the chi2 when the points are fixed
+        const int hc = (bid - nbL) / SMALL_CPC, quarter = (bid - nbL) % SMALL_CPC;
         const int cam = v.hc2cam[hc];
         PoseD P = load_pose(v.pose_cur, cam);
         const double f = v.camK[cam * 4];
@@ -870,7 +945,9 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
         for (int k = 0; k < 21; ++k) A[k] = 0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) b[k] = 0;
-        for (int idx = v.camE_ptr[hc] + wave * WAVE + lane; idx < v.camE_ptr[hc + 1]; idx += 4 * WAVE) {
+        const int e0 = v.camE_ptr[hc], ne = v.camE_ptr[hc + 1] - e0, per = (ne + SMALL_CPC - 1) / SMALL_CPC;
+        const int q0 = e0 + min(quarter * per, ne), q1 = e0 + min((quarter + 1) * per, ne);
+        for (int idx = q0 + wave * WAVE + lane; idx < q1; idx += 4 * WAVE) {
             const int i = v.camE[idx];
             if (!v.L_active[i]) continue;
             const int pt = v.L_pt[i];
@@ -904,18 +981,7 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
             for (int k = 0; k < 6; ++k) part[wave][21 + k] = b[k];
         }
         __syncthreads();
-        if (tid == 0) {
-            int k = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int c = 0; c <= a; ++c) {
-                    const double val = ((part[0][k] + part[1][k]) + part[2][k]) + part[3][k];
-                    v.U[(size_t)hc * 36 + a * 6 + c] = val; v.U[(size_t)hc * 36 + c * 6 + a] = val; ++k;
-                }
-#pragma unroll
-            for (int a = 0; a < 6; ++a) v.bc[(size_t)hc * 6 + a] = ((part[0][21 + a] + part[1][21 + a]) + part[2][21 + a]) + part[3][21 + a];
-        }
+        if (tid < 27) cam_part[(size_t)(bid - nbL) * 28 + tid] = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
     } else {
         // ---- zero role: S (n_pad x n_pad), y, identity on the padded tail of the diagonal
         const int n = v.n_fc * 6, np = v.n_pad;
@@ -928,10 +994,24 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
     if (tid == 0) v.partial[bid] = r;
     if (!last_block_arrives(counter, n_blocks)) return;
     fold_partials(v.partial, n_blocks, v.scal + SC_CHI, sm);
+    // U and b_c of every camera from its quarters, in order
+    for (int e = tid; e < v.n_fc * 27; e += 256) {
+        const int hc = e / 27, k = e % 27;
+        const double* q = cam_part + (size_t)hc * SMALL_CPC * 28 + k;
+        const double val = ((q[0] + q[28]) + q[56]) + q[84];
+        if (k < 21) {
+            int a = 0, rem = k;                          // k = a (a + 1) / 2 + c, c <= a
+            while (rem > a) { rem -= a + 1; ++a; }
+            const int c = rem;
+            v.U[(size_t)hc * 36 + a * 6 + c] = val; v.U[(size_t)hc * 36 + c * 6 + a] = val;
+            if (a == c) udiag[hc * 6 + a] = val;
+        } else v.bc[(size_t)hc * 6 + (k - 21)] = val;
+    }
+    __syncthreads();
     if (want_maxdiag) {
         double m = 0;
         const int nU = v.n_fc * 6, nV = v.points_free ? v.n_lm * 3 : 0;
-        for (int i = tid; i < nU; i += 256) m = fmax(m, fabs(v.U[(size_t)(i / 6) * 36 + (i % 6) * 7]));
+        for (int i = tid; i < nU; i += 256) m = fmax(m, fabs(udiag[i]));
         for (int i = tid; i < nV; i += 256) {
             const int l = i / 3, d = i % 3;
             m = fmax(m, fabs(v.V[(size_t)l * 6 + (d == 0 ? 0 : d == 1 ? 3 : 5)]));
@@ -957,12 +1037,22 @@ __global__ __launch_bounds__(256) void k_small_schur(BaDeviceView v, double lamb
         double acc[36];
 #pragma unroll
         for (int k = 0; k < 36; ++k) acc[k] = 0;
-        for (int c = v.blk_ptr[b] + first; c < v.blk_ptr[b + 1]; c += stride) {
-            const int2 sab = v.con[c];
+        // the index chain (contribution -> slots -> landmark) of the NEXT contribution is fetched while this one is computed: a
+        // thread has ~5 contributions and nothing else on its compute unit hides three dependent loads each.  (Issuing the loads
+        // of all of a thread's contributions in bulk, 8-way unrolled, was slower: 44 us against 34 us.)
+        const int c_end = v.blk_ptr[b + 1];
+        int c = v.blk_ptr[b] + first;
+        int2 sab_next = make_int2(0, 0);
+        int l_next = 0;
+        if (c < c_end) { sab_next = v.con[c]; l_next = v.w_lm[sab_next.x]; }
+        for (; c < c_end; c += stride) {
+            const int2 sab = sab_next;
+            const int l_cur = l_next;
+            if (c + stride < c_end) { sab_next = v.con[c + stride]; l_next = v.w_lm[sab_next.x]; }
             const double2* Wa2 = reinterpret_cast<const double2*>(v.W + (size_t)sab.x * 18);
             const double2* Wb2 = reinterpret_cast<const double2*>(v.W + (size_t)sab.y * 18);
             double D[6];
-            lm_dinv(v, v.w_lm[sab.x], lambda, D);
+            lm_dinv(v, l_cur, lambda, D);
             const double d00 = D[0], d01 = D[1], d02 = D[2], d11 = D[3], d12 = D[4], d22 = D[5];
             double wa[18], wb[18];
 #pragma unroll
@@ -1444,8 +1534,8 @@ bool ba_small_applies(const BaDeviceView& v)
 static int small_error_blocks(const BaDeviceView& v) { return v.n_L > 0 ? std::min(cdiv(v.n_L, 256), RED_BLOCKS) : 1; }
 void ba_small_linearize(const BaDeviceView& v, double delta, bool want_maxdiag, int* counter, hipStream_t st)
 {
-    const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm, 256) : 0;
-    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + v.n_fc + 1), dim3(256), 0, st, v, delta, nbL, want_maxdiag ? 1 : 0, counter);
+    const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm * (v.dup_slots ? 1 : SMALL_LPL), 256) : 0;
+    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + v.n_fc * SMALL_CPC + 1), dim3(256), 0, st, v, delta, nbL, want_maxdiag ? 1 : 0, counter);
 }
 void ba_small_solve_trial(const BaDeviceView& v, double lambda, double delta, double* linv_ws, int* counter, hipStream_t st)
 {
