@@ -135,6 +135,23 @@ def test_edge_cases_match_oracle():
     assert len(k) == 100 and np.array_equal(kp_xyr(k), kp_xyr(ko)) and np.array_equal(d, do)
 
 
+@pytest.mark.parametrize("shape, kw", [
+    ((1200, 1600), dict(nfeatures=3000)),                                   # 25 x 50 FAST tiles (> 1024: several per thread of the selection), working set beyond LDS
+    ((1200, 1600), dict(nfeatures=3000, feature_strength_anms=1.0, feature_factor_anms=1.0)),
+    ((700, 1100), dict(nfeatures=2500, num_cells_x=40, num_cells_y=40)),    # more grid cells than the LDS index holds
+    ((480, 640), dict(nfeatures=5000)),                                     # fewer detections than the quota: everything is kept, in raster order
+    ((60, 400), dict(nfeatures=30, num_cells_x=64, num_cells_y=64)),        # bounding box narrower than the grid in y: the reference's ring walk, step by step
+])
+def test_selection_fallback_paths_match_oracle(shape, kw):
+    h, w = shape
+    img = frames.make_frame(0x51 + h, width=w, height=h)
+    okw = {"feature_factor_anms": "feature_factor", "feature_strength_anms": "feature_strength", "num_cells_x": "cells_x", "num_cells_y": "cells_y"}
+    k, d = OrbDetector(**kw).DetectAndCompute(img)
+    ko, do = O.orb_detect(img, O.OrbParams.defaults(**{okw.get(a, a): b for a, b in kw.items()}))
+    assert len(k) == len(ko) and len(k) > 0
+    assert np.array_equal(kp_xyr(k), kp_xyr(ko)) and np.array_equal(d, do)
+
+
 def test_unsupported_settings_are_refused():
     from mageslam_amd._lib import MageError
     for kw in (dict(nlevels=17), dict(nlevels=2, scale_factor=1.0), dict(patch_size=200)):
@@ -179,6 +196,32 @@ def test_match_batch_ragged_pairs():
     for p in range(npairs):
         mo = O.match(A[p, : cA[p]], B[p, : cB[p]], 60, 1)
         assert cnt[p] == len(mo) and np.array_equal(out[p, : cnt[p]], mo)
+
+
+def test_match_few_pairs_and_many_pairs_take_different_kernels_same_records():
+    """Below 256 pairs a pair is spread over several workgroups (k_match_rows: lane per row, last workgroup finishes), from 256
+    on one workgroup takes a pair (k_match).  320 ragged pairs through the second, their first 7 through the first, every pair
+    against the oracle; sets larger than one row group (64) and near-duplicate descriptors so that ties for the best occur."""
+    rng = np.random.default_rng(77)
+    npairs, cap = 320, 96
+    centres = rng.integers(0, 256, (6, 32)).astype(np.uint8)
+    A = centres[rng.integers(0, 6, (npairs, cap))].copy()
+    A ^= np.packbits((rng.random((npairs, cap, 32, 8)) < 0.02).astype(np.uint8), axis=3).reshape(npairs, cap, 32)
+    B = A[:, ::-1].copy()
+    B ^= np.packbits((rng.random((npairs, cap, 32, 8)) < 0.01).astype(np.uint8), axis=3).reshape(npairs, cap, 32)
+    cA = rng.integers(0, cap + 1, npairs).astype(np.int32); cB = rng.integers(0, cap + 1, npairs).astype(np.int32)
+    cA[:3] = [cap, 0, 65]; cB[:3] = [cap, 40, 1]
+    mt = Matcher()
+    out_many, cnt_many = mt.MatchBatch(A, cA, B, cB, 40, 1)
+    out_few, cnt_few = mt.MatchBatch(A[:7], cA[:7], B[:7], cB[:7], 40, 1)
+    for p in range(npairs):
+        mo = O.match(A[p, : cA[p]], B[p, : cB[p]], 40, 1)
+        assert cnt_many[p] == len(mo) and np.array_equal(out_many[p, : cnt_many[p]], mo), p
+        if p < 7:
+            assert cnt_few[p] == len(mo) and np.array_equal(out_few[p, : cnt_few[p]], mo), p
+    # the arrival counters are back at zero: a second call on the same handle gives the same records
+    out2, cnt2 = mt.MatchBatch(A[:7], cA[:7], B[:7], cB[:7], 40, 1)
+    assert np.array_equal(cnt2, cnt_few) and all(np.array_equal(out2[p, : cnt2[p]], out_few[p, : cnt_few[p]]) for p in range(7))
 
 
 @pytest.mark.parametrize("case", range(16))
