@@ -85,6 +85,7 @@ struct mage_orb {
     mage_orb_params P{};
     OrbTaps taps{};
     DevBuf<signed char> d_pattern;
+    int pattern_radius = 0;         // largest |coordinate| of the sampling table
     DevBuf<uint8_t> d_img, d_rawscore, d_blur, d_desc;     // d_rawscore: FAST scores of frame 0 (parity tests)
     DevBuf<int> d_tile_count, d_cell_start, d_cell_fill, d_count;   // d_tile_count: keypoints per FAST tile, d_raw: their slots
     DevBuf<int2> d_raw;
@@ -140,6 +141,9 @@ MAGE_EXPORT mage_status mage_orb_create(const mage_orb_params* params, mage_orb*
         for (auto& e : h->ev) MAGE_HIP(hipEventCreate(&e));
         std::vector<signed char> pat;
         expand_pattern(p.patch_size, pat);
+        // the table rows a keypoint can select: row 0 only without orientation (the patch then stays inside RunByImageBorder's margin)
+        const size_t used = p.use_orientation ? pat.size() : std::min<size_t>(pat.size(), 1024);
+        for (size_t i = 0; i < used; ++i) h->pattern_radius = std::max(h->pattern_radius, std::abs((int)pat[i]));
         MAGE_TRY(h->d_pattern.upload(pat.data(), pat.size(), h->stream));
         MAGE_HIP(hipStreamSynchronize(h->stream));
         *out = h.release();
@@ -209,7 +213,7 @@ mage_status run_level(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[2], st));
     if (!fused_blur) orb_launch_blur(d_images, w, h_img, stride, frame_stride, n_frames, h->taps, io.blur, wp, st);
     if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[3], st));
-    if (io.capacity > 0) orb_launch_brief(io.blur, wp, h_img, n_frames, io.kp, io.count, io.capacity, h->d_pattern.p, io.desc,
+    if (io.capacity > 0) orb_launch_brief(io.blur, wp, h_img, n_frames, io.kp, io.count, io.capacity, h->d_pattern.p, h->pattern_radius, io.desc,
                                           P.use_orientation && P.patch_size != 15 && P.patch_size != 31, st);
     if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[4], st));
     return MAGE_OK;

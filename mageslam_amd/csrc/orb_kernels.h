@@ -41,7 +41,7 @@ struct OrbUmax { int half; int umax[18]; };         // row extents of the orient
 void orb_launch_angles(const uint8_t* img, int stride, size_t frame_stride, int n_frames, mage_keypoint* kps, const int* counts, int capacity,
                        const OrbUmax& um, hipStream_t st);
 void orb_launch_brief(const uint8_t* blurred, int wp, int h, int n_frames, const mage_keypoint* kps, const int* counts, int capacity,
-                      const signed char* pattern, uint8_t* desc, bool rotate_random, hipStream_t st);
+                      const signed char* pattern, int pattern_radius /* largest |coordinate| in the table */, uint8_t* desc, bool rotate_random, hipStream_t st);
 
 // Hamming brute-force two-way matcher: one workgroup per pair.
 void match_init_device();   // once per device: opt k_match into its LDS staging size

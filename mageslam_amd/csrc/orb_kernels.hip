@@ -60,19 +60,30 @@ __device__ __forceinline__ void fast_ring(const uint8_t* __restrict__ c, int TP,
     }
 }
 
-// High-speed test on the whole ring: a 9-arc contains one pixel of every opposite pair, so a corner needs every pair to have a
-// member darker than the centre by more than t, or every pair a brighter one.  ~8 % of the pixels of a textured frame pass.
-__device__ __forceinline__ bool fast_pair_test(const uint8_t* __restrict__ c, int TP, int t)
+// Second screen, on the EVEN ring positions (the compass points and the four diagonals): 9 contiguous ring pixels contain at
+// least 4 consecutive even positions, so a corner needs 4 consecutive even pixels all darker than the centre by more than t, or
+// all brighter.  Nine byte reads and ~45 operations; ~11 % of the pixels of a textured frame pass (the opposite-pair test on all
+// 16 pixels passes ~8 % but costs twice as much on the ~21 % it is run on).
+__device__ __forceinline__ bool fast_even4_test(const uint8_t* __restrict__ c, int TP, int t)
 {
-    short2_t P[8], Q[8];
-    fast_ring(c, TP, P, Q);
-    short2_t all_dark = pmax(P[0], Q[0]), all_bright = pmin(P[0], Q[0]);     // both halves equal: max / min of the pair
+    const int v = c[0];
+    // even positions 0, 2, 4, 6 and their opposites 8, 10, 12, 14: (0, 3) (2, 2) (3, 0) (2, -2) / (0, -3) (-2, -2) (-3, 0) (-2, 2)
+    const int ex[4] = { 0, 2, 3, 2 }, ey[4] = { 3, 2, 0, -2 };
+    short2_t P[4];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) {
-        all_dark = pmin(all_dark, pmax(P[k], Q[k]));                 // smallest pair-maximum
-        all_bright = pmax(all_bright, pmin(P[k], Q[k]));             // largest pair-minimum
+    for (int j = 0; j < 4; ++j) P[j] = (short2_t){ (short)(v - (int)c[ey[j] * TP + ex[j]]), (short)(v - (int)c[-ey[j] * TP - ex[j]]) };
+    // windows of 2 then 4 consecutive even positions: register j holds the windows starting at even position j (low half) and j + 4 (high half)
+    short2_t A2[4], B2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const short2_t nx = j < 3 ? P[j + 1] : swap16(P[0]); A2[j] = pmin(P[j], nx); B2[j] = pmax(P[j], nx); }
+    short2_t dark = (short2_t){ (short)-32768, (short)-32768 }, bright = (short2_t){ (short)32767, (short)32767 };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const short2_t na = j < 2 ? A2[j + 2] : swap16(A2[j - 2]), nb = j < 2 ? B2[j + 2] : swap16(B2[j - 2]);
+        dark = pmax(dark, pmin(A2[j], na));            // largest window minimum of (v - ring)
+        bright = pmin(bright, pmax(B2[j], nb));        // smallest window maximum
     }
-    return (int)all_dark.x > t || (int)all_bright.x < -t;
+    return max((int)dark.x, (int)dark.y) > t || min((int)bright.x, (int)bright.y) < -t;
 }
 
 // score = max over the 16 arcs of 9 contiguous ring pixels of the arc's minimum margin, for darker and for brighter rings; a
@@ -159,7 +170,7 @@ __device__ __forceinline__ void stage_window(uint8_t* __restrict__ tile, const u
 //   phase 1  compass test on the tile and a one-pixel ring (66 x 26): any 9-arc contains two NEIGHBOURING compass points (ring
 //            positions 0, 4, 8, 12), so a corner needs two neighbouring compass pixels both darker or both brighter than the
 //            centre by more than the threshold: (N or S) and (E or W).  Survivors (~20 %) go to an LDS list.
-//   phase 2a opposite-pair test on the list (all 16 ring pixels); survivors (~8 %) go to a second list
+//   phase 2a the same idea on the eight even ring positions (4 consecutive ones) on the list; survivors (~11 %) go to a second list
 //   phase 2b the exact score on the second list, where every lane of a wavefront has real work
 //   phase 3  strict 3x3 maximum among the raw scores + RunByImageBorder, append
 // ---------------------------------------------------------------------------------------------
@@ -211,15 +222,16 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
     __shared__ __attribute__((aligned(16))) uint8_t sc[SCH * SCP];    // scores of the tile and its ring
     __shared__ __attribute__((aligned(16))) uint16_t cand_both[2 * NCAND];
     uint16_t* const cand = cand_both;                                 // pixels that survive the compass test
-    uint16_t* const cand2 = cand_both + NCAND;                        // ... and the opposite-pair test
+    uint16_t* const cand2 = cand_both + NCAND;                        // ... and the even-position test
     int* const hrow = reinterpret_cast<int*>(cand_both);              // BLUR, after phase 2b: horizontal 7-tap sums of window rows 1 .. HROWS
     __shared__ int2 kl[F_MAXKP];
-    __shared__ int n_cand, n_cand2, n_kept;
+    __shared__ uint16_t nzq[FT_W * FT_H / 4];
+    __shared__ int n_cand, n_cand2, n_kept, n_nzq;
     const int f = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const uint8_t* I = img + (size_t)f * frame_stride;
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
     ORB_CLK_BEGIN();
-    if (tid == 0) { n_cand = 0; n_cand2 = 0; n_kept = 0; }
+    if (tid == 0) { n_cand = 0; n_cand2 = 0; n_kept = 0; n_nzq = 0; }
     for (int e = tid; e < SCH * SCP / 16; e += 256) reinterpret_cast<uint4*>(sc)[e] = make_uint4(0u, 0u, 0u, 0u);
     {   // window rows y0 - 4 .. y0 + FT_H + 3, columns x0 - 16 .. x0 + 79: six 16-byte pieces per row, one per thread
         static_assert(FTH * (FTW / 16) <= 256, "one 128-bit load per thread");
@@ -263,6 +275,7 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
             const uint32_t* dn = reinterpret_cast<const uint32_t*>(&tile[(ry + 0) * TP + 8 * o + 12]);   // row y - 3 (ring 8)
             const uint32_t mc[4] = { mp[0], mp[1], mp[2], mp[3] }, mu[3] = { up[0], up[1], up[2] }, md[3] = { dn[0], dn[1], dn[2] };
             const short2_t T1 = (short2_t){ (short)(threshold + 1), (short)(threshold + 1) }, T = (short2_t){ (short)threshold, (short)threshold };
+            uint32_t signs = 0;
 #pragma unroll
             for (int hp = 0; hp < 4; ++hp) {
                 // bytes i, i + 1 of a group of dwords, zero-extended to 16 bits each (v_perm_b32: selector 0..3 = bytes of the
@@ -281,10 +294,9 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
                 const short2_t xd = dark - T1, xb = bright + T;                       // dark > t  <=>  xd >= 0 ; bright < -t  <=>  xb < 0
                 uint32_t ud, ub;
                 __builtin_memcpy(&ud, &xd, 4); __builtin_memcpy(&ub, &xb, 4);
-                const uint32_t sg = (~ud | ub) & 0x80008000u;
-                passbits |= ((sg >> 15) & 1u) << (2 * hp);
-                passbits |= ((sg >> 31) & 1u) << (2 * hp + 1);
+                signs |= ((~ud | ub) & 0x80008000u) >> (15 - 2 * hp);     // pixel 2 hp -> bit 2 hp, pixel 2 hp + 1 -> bit 16 + 2 hp
             }
+            passbits = (signs | (signs >> 15)) & 0xffu;
             // pixels of the group that are region pixels and FAST centres: rx < SCW, 3 <= x < w - 3
             const int xs = x0 - 1 + 8 * o;
             const int jl = min(max(3 - xs, 0), 8), jh = min(max(min(SCW - 8 * o, w - 3 - xs), 0), 8);
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
     }
     __syncthreads();
     ORB_CLK(1);
-    // Phase 2a: opposite-pair test
+    // Phase 2a: even-position test
     const int nc = n_cand;
     for (int c0 = 0; c0 < nc; c0 += 256) {
         const int c = c0 + tid;
@@ -303,7 +315,7 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
         if (c < nc) {
             p = cand[c];
             const int ry = p / SCP, rx = p % SCP;
-            pass = fast_pair_test(&tile[(ry + 3) * TP + rx + 15], TP, threshold);
+            pass = fast_even4_test(&tile[(ry + 3) * TP + rx + 15], TP, threshold);
         }
         const unsigned long long bal = __ballot(pass);
         if (bal) {
@@ -323,35 +335,28 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
     }
     __syncthreads();
     ORB_CLK(2);
-    // Phase 3: strict 3x3 maximum among the raw scores + RunByImageBorder
+    // Phase 3a: the quads of the tile that hold a corner at all (~13 %) go to a list; phase 3b below runs the 3x3 test on the list
+    // with full wavefronts (run in place, nearly every wavefront pays the whole test for one or two lanes)
     const int lo = border > 3 ? border : 3;
 #pragma unroll
     for (int i = 0; i < (FT_W * FT_H / 4 + 255) / 256; ++i) {
         const int qi = tid + 256 * i;
-        if (qi >= FT_W * FT_H / 4) break;
-        const int ly = qi / (FT_W / 4), lq = qi % (FT_W / 4);
-        const int y = y0 + ly, xq = x0 + 4 * lq;
-        if (y >= h || xq >= wp) continue;
-        const uint8_t* c0 = &sc[(ly + 1) * SCP + 4 * lq + 1 + SC_OFF];           // dword-aligned: the four scores in one LDS read
-        const uint32_t raw4 = *reinterpret_cast<const uint32_t*>(c0);
-        if (f == 0 && raw_frame0) *reinterpret_cast<uint32_t*>(raw_frame0 + (size_t)y * wp + xq) = raw4;
-        if (raw4 != 0u && y >= lo && y < h - lo) {                              // most quads hold no corner at all
-            // the 3 x 6 neighbourhood of the quad in six more aligned reads issued together (a chain of byte reads behind
-            // short-circuit tests is eight LDS latencies in a row): row r as bytes x - 1 .. x + 4 of a 64-bit value
-            const uint32_t* cq = reinterpret_cast<const uint32_t*>(c0);
-            auto row6 = [](uint32_t L, uint32_t C, uint32_t R) { return (unsigned long long)(L >> 24) | ((unsigned long long)C << 8) | ((unsigned long long)(R & 0xffu) << 40); };
-            const unsigned long long ra = row6(cq[-SCP / 4 - 1], cq[-SCP / 4], cq[-SCP / 4 + 1]);
-            const unsigned long long rc = row6(cq[-1], raw4, cq[1]);
-            const unsigned long long rb = row6(cq[SCP / 4 - 1], cq[SCP / 4], cq[SCP / 4 + 1]);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int s = (int)((raw4 >> (8 * b)) & 0xffu);
-                const int x = xq + b;
-                auto byte = [](unsigned long long v, int i) { return (int)((v >> (8 * i)) & 0xffu); };
-                const int m = max(max(max(byte(ra, b), byte(ra, b + 1)), max(byte(ra, b + 2), byte(rc, b))),
-                                  max(max(byte(rc, b + 2), byte(rb, b)), max(byte(rb, b + 1), byte(rb, b + 2))));
-                if (s > m && x >= lo && x < w - lo) kl[atomicAdd(&n_kept, 1)] = make_int2(x | (y << 16), s);     // s > m >= 0: a corner, strictly above its 8 neighbours
+        bool nz = false;
+        if (qi < FT_W * FT_H / 4) {
+            const int ly = qi / (FT_W / 4), lq = qi % (FT_W / 4);
+            const int y = y0 + ly, xq = x0 + 4 * lq;
+            if (y < h && xq < wp) {
+                const uint32_t raw4 = *reinterpret_cast<const uint32_t*>(&sc[(ly + 1) * SCP + 4 * lq + 1 + SC_OFF]);   // dword-aligned: four scores in one LDS read
+                if (f == 0 && raw_frame0) *reinterpret_cast<uint32_t*>(raw_frame0 + (size_t)y * wp + xq) = raw4;
+                nz = raw4 != 0u && y >= lo && y < h - lo;
             }
+        }
+        const unsigned long long bal = __ballot(nz);
+        if (bal) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&n_nzq, __popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (nz) nzq[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)qi;
         }
     }
     if (BLUR) {
@@ -372,17 +377,38 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
         }
     }
     __syncthreads();
-    // the tile's keypoints go to the tile's own slots of the frame's list: no cursor, no atomic, nothing to clear between launches
-    const int nk = n_kept;
-    const size_t t = ((size_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (tid == 0) tile_count[t] = nk;
-    int2* out = raw + t * F_MAXKP;
-    for (int i = tid; i < nk; i += 256) out[i] = kl[i];
     ORB_CLK(3);
+    // Phase 3b on the last wavefront (the vertical blur pass below occupies the first three): strict 3x3 maximum among the raw
+    // scores + RunByImageBorder for the listed quads
+    if (tid >= 192) {
+        const int nq = n_nzq;
+        for (int c = tid - 192; c < nq; c += 64) {
+            const int qi = nzq[c];
+            const int ly = qi / (FT_W / 4), lq = qi % (FT_W / 4);
+            const int y = y0 + ly, xq = x0 + 4 * lq;
+            // the 3 x 6 neighbourhood of the quad in nine aligned reads issued together (a chain of byte reads behind short-circuit
+            // tests is eight LDS latencies in a row): row r as bytes x - 1 .. x + 4 of a 64-bit value
+            const uint32_t* cq = reinterpret_cast<const uint32_t*>(&sc[(ly + 1) * SCP + 4 * lq + 1 + SC_OFF]);
+            const uint32_t raw4 = cq[0];
+            auto row6 = [](uint32_t L, uint32_t C, uint32_t R) { return (unsigned long long)(L >> 24) | ((unsigned long long)C << 8) | ((unsigned long long)(R & 0xffu) << 40); };
+            const unsigned long long ra = row6(cq[-SCP / 4 - 1], cq[-SCP / 4], cq[-SCP / 4 + 1]);
+            const unsigned long long rc = row6(cq[-1], raw4, cq[1]);
+            const unsigned long long rb = row6(cq[SCP / 4 - 1], cq[SCP / 4], cq[SCP / 4 + 1]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int s = (int)((raw4 >> (8 * b)) & 0xffu);
+                const int x = xq + b;
+                auto byte = [](unsigned long long v, int i) { return (int)((v >> (8 * i)) & 0xffu); };
+                const int m = max(max(max(byte(ra, b), byte(ra, b + 1)), max(byte(ra, b + 2), byte(rc, b))),
+                                  max(max(byte(rc, b + 2), byte(rb, b)), max(byte(rb, b + 1), byte(rb, b + 2))));
+                if (s > m && x >= lo && x < w - lo) kl[atomicAdd(&n_kept, 1)] = make_int2(x | (y << 16), s);     // s > m >= 0: a corner, strictly above its 8 neighbours
+            }
+        }
+    }
     if (BLUR) {
         // vertical pass: a thread owns four pixel columns and two consecutive rows, reads the eight row sums they need once and
         // packs one 32-bit store per row; products fit 24 bits (tap <= 255, row sum < 2^16)
-        static_assert(FT_H % 2 == 0 && (FT_H / 2) * (FT_W / 4) <= 256, "one 4 x 2 pixel patch per thread");
+        static_assert(FT_H % 2 == 0 && (FT_H / 2) * (FT_W / 4) <= 192, "one 4 x 2 pixel patch per thread of the first three wavefronts");
         uint8_t* O = blurred + (size_t)f * wp * h;
         const int tq = tid % (FT_W / 4), strip = tid / (FT_W / 4);
         const int xq = x0 + 4 * tq;
@@ -410,8 +436,15 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
                 *reinterpret_cast<uint32_t*>(O + (size_t)y * wp + xq) = packed;
             }
         }
-        ORB_CLK(4);
     }
+    __syncthreads();
+    // the tile's keypoints go to the tile's own slots of the frame's list: no cursor, no atomic, nothing to clear between launches
+    const int nk = n_kept;
+    const size_t t = ((size_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (tid == 0) tile_count[t] = nk;
+    int2* out = raw + t * F_MAXKP;
+    for (int i = tid; i < nk; i += 256) out[i] = kl[i];
+    ORB_CLK(4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1011,7 +1044,8 @@ __global__ __launch_bounds__(256) void k_brief_rotated(const uint8_t* __restrict
     if ((lane & 1) == 0) desc[((size_t)f * capacity + k) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
 }
 
-__global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blurred, int wp, int h, const mage_keypoint* __restrict__ kps,
+// byte gathers straight from the blurred image: kept for patches too large for the LDS form below
+__global__ __launch_bounds__(256) void k_brief_gather(const uint8_t* __restrict__ blurred, int wp, int h, const mage_keypoint* __restrict__ kps,
                                                const int* __restrict__ counts, int capacity, const signed char* __restrict__ pattern,
                                                uint8_t* __restrict__ desc)
 {
@@ -1051,6 +1085,58 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blurr
         int nib = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) nib |= (t[q][2 * b] < t[q][2 * b + 1]) << b;
+        const int hi = __shfl_down(nib, 1, 64);
+        if ((lane & 1) == 0 && k0 + q < n) desc[((size_t)f * capacity + k0 + q) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+    }
+}
+
+// The (2 R + 1)^2 patch of every keypoint (R = largest |coordinate| of the table) is first copied to LDS by rows -- aligned 32-bit
+// loads, a row is one or two cache lines -- and the 512 samples are LDS byte reads: eight 64-lane byte GATHERS per keypoint from L2
+// kept the texture addresser busy for ~11 cycles each, two row-wise loads and eight LDS reads do not (0.52 -> 0.28 ms per 2048 frames).
+__global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blurred, int wp, int h, const mage_keypoint* __restrict__ kps,
+                                               const int* __restrict__ counts, int capacity, const signed char* __restrict__ pattern,
+                                               uint8_t* __restrict__ desc, int R, int ndw, int lanes_per_row_log2)
+{
+    extern __shared__ uint8_t patches[];                // [wavefront][keypoint of the wavefront][row][4 ndw]
+    const int f = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k0 = (blockIdx.x * 4 + wave) * BRIEF_KPW;
+    const int n = counts[f];
+    if (k0 >= n) return;
+    const uint8_t* frame = blurred + (size_t)f * wp * h;
+    const int rows = 2 * R + 1, pitch = 4 * ndw, patch_bytes = rows * pitch;
+    uint8_t* mine = patches + (size_t)wave * BRIEF_KPW * patch_bytes;
+    // cvRound of an integer-valued float; angleIncrement = cvRound(angle / 12) % 30 picks the pre-rotated table row
+    // (OpenCVModified.cpp:523-532; angle is 0 unless UseOrientation)
+    int inc[BRIEF_KPW], off[BRIEF_KPW];                 // table row; LDS offset of the patch centre
+    const int lr = lane >> lanes_per_row_log2, ld = lane & ((1 << lanes_per_row_log2) - 1), rows_per_pass = 64 >> lanes_per_row_log2;
+#pragma unroll
+    for (int q = 0; q < BRIEF_KPW; ++q) {
+        const int k = min(k0 + q, n - 1);
+        const mage_keypoint kp = kps[(size_t)f * capacity + k];
+        const int x = (int)rintf(kp.x), y = (int)rintf(kp.y);
+        inc[q] = (int)rintf(kp.angle / 12.0f) % 30;
+        const int ax = (x - R) & ~3;                    // the patch lies inside the image (RunByImageBorder), the aligned reads inside the padded rows
+        off[q] = q * patch_bytes + R * pitch + (x - ax);
+        const uint8_t* src = frame + (size_t)(y - R) * wp + ax;
+        if (ld < ndw)
+            for (int r = lr; r < rows; r += rows_per_pass)
+                *reinterpret_cast<uint32_t*>(mine + q * patch_bytes + r * pitch + 4 * ld) = *reinterpret_cast<const uint32_t*>(src + (size_t)r * wp + 4 * ld);
+    }
+    // this lane's four pairs of the table row: 16 signed bytes, one 128-bit load (rows are 1024 bytes, lane * 16 is aligned)
+    int4 pr = *reinterpret_cast<const int4*>(pattern + inc[0] * 1024 + lane * 16);
+#pragma unroll
+    for (int q = 0; q < BRIEF_KPW; ++q) {
+        if (q > 0 && inc[q] != inc[q - 1]) pr = *reinterpret_cast<const int4*>(pattern + inc[q] * 1024 + lane * 16);
+        const int w4[4] = { pr.x, pr.y, pr.z, pr.w };
+        const uint8_t* c = mine + off[q];
+        int nib = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int x0 = (int)(signed char)(w4[b] & 0xff), y0 = (int)(signed char)((w4[b] >> 8) & 0xff);
+            const int x1 = (int)(signed char)((w4[b] >> 16) & 0xff), y1 = (int)(signed char)((w4[b] >> 24) & 0xff);
+            nib |= ((int)c[y0 * pitch + x0] < (int)c[y1 * pitch + x1]) << b;
+        }
         const int hi = __shfl_down(nib, 1, 64);
         if ((lane & 1) == 0 && k0 + q < n) desc[((size_t)f * capacity + k0 + q) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
     }
@@ -1107,10 +1193,15 @@ void orb_launch_angles(const uint8_t* img, int stride, size_t frame_stride, int 
 }
 
 void orb_launch_brief(const uint8_t* blurred, int wp, int h, int n_frames, const mage_keypoint* kps, const int* counts, int capacity,
-                      const signed char* pattern, uint8_t* desc, bool rotate_random, hipStream_t st)
+                      const signed char* pattern, int pattern_radius, uint8_t* desc, bool rotate_random, hipStream_t st)
 {
-    if (rotate_random) hipLaunchKernelGGL(k_brief_rotated, dim3(cdiv(capacity, 4), n_frames), dim3(256), 0, st, blurred, wp, h, kps, counts, capacity, pattern, desc);
-    else hipLaunchKernelGGL(k_brief, dim3(cdiv(capacity, 4 * BRIEF_KPW), n_frames), dim3(256), 0, st, blurred, wp, h, kps, counts, capacity, pattern, desc);
+    if (rotate_random) { hipLaunchKernelGGL(k_brief_rotated, dim3(cdiv(capacity, 4), n_frames), dim3(256), 0, st, blurred, wp, h, kps, counts, capacity, pattern, desc); return; }
+    const int R = pattern_radius, ndw = (2 * R + 1 + 3 + 3) / 4;          // a row of 2 R + 1 bytes starting up to 3 bytes into its first dword
+    int lg = 0;
+    while ((1 << lg) < ndw) ++lg;
+    const size_t lds = (size_t)4 * BRIEF_KPW * (2 * R + 1) * 4 * ndw;
+    if (lds > 48 * 1024) { hipLaunchKernelGGL(k_brief_gather, dim3(cdiv(capacity, 4 * BRIEF_KPW), n_frames), dim3(256), 0, st, blurred, wp, h, kps, counts, capacity, pattern, desc); return; }
+    hipLaunchKernelGGL(k_brief, dim3(cdiv(capacity, 4 * BRIEF_KPW), n_frames), dim3(256), lds, st, blurred, wp, h, kps, counts, capacity, pattern, desc, R, ndw, lg);
 }
 
 }  // namespace mage
