@@ -1124,19 +1124,26 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blurr
                 *reinterpret_cast<uint32_t*>(mine + q * patch_bytes + r * pitch + 4 * ld) = *reinterpret_cast<const uint32_t*>(src + (size_t)r * wp + 4 * ld);
     }
     // this lane's four pairs of the table row: 16 signed bytes, one 128-bit load (rows are 1024 bytes, lane * 16 is aligned)
-    int4 pr = *reinterpret_cast<const int4*>(pattern + inc[0] * 1024 + lane * 16);
-#pragma unroll
-    for (int q = 0; q < BRIEF_KPW; ++q) {
-        if (q > 0 && inc[q] != inc[q - 1]) pr = *reinterpret_cast<const int4*>(pattern + inc[q] * 1024 + lane * 16);
+    // ... decoded to LDS offsets once per table row: without orientation every keypoint uses row 0
+    int o0[4], o1[4];
+    auto decode = [&](int row) {
+        const int4 pr = *reinterpret_cast<const int4*>(pattern + row * 1024 + lane * 16);
         const int w4[4] = { pr.x, pr.y, pr.z, pr.w };
-        const uint8_t* c = mine + off[q];
-        int nib = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int x0 = (int)(signed char)(w4[b] & 0xff), y0 = (int)(signed char)((w4[b] >> 8) & 0xff);
             const int x1 = (int)(signed char)((w4[b] >> 16) & 0xff), y1 = (int)(signed char)((w4[b] >> 24) & 0xff);
-            nib |= ((int)c[y0 * pitch + x0] < (int)c[y1 * pitch + x1]) << b;
+            o0[b] = y0 * pitch + x0; o1[b] = y1 * pitch + x1;
         }
+    };
+    decode(inc[0]);
+#pragma unroll
+    for (int q = 0; q < BRIEF_KPW; ++q) {
+        if (q > 0 && inc[q] != inc[q - 1]) decode(inc[q]);
+        const uint8_t* c = mine + off[q];
+        int nib = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) nib |= ((int)c[o0[b]] < (int)c[o1[b]]) << b;
         const int hi = __shfl_down(nib, 1, 64);
         if ((lane & 1) == 0 && k0 + q < n) desc[((size_t)f * capacity + k0 + q) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
     }
