@@ -409,19 +409,26 @@ __global__ void k_pad_diag(double* S, int n, int n_pad)
 }
 
 // One wavefront per non-empty upper block (i <= j).  Workgroups go to the eight XCDs round-robin and every XCD has its own
-// L2, so the slot -> block table (blk_order) hands workgroup w the blocks of rows i with i % 8 == w % 8: camera i's W blocks
-// are then fetched into ONE L2 instead of eight, and consecutive rows of an XCD share most of their column cameras (measured:
-// L2 misses per launch 15.4 M -> see DESIGN.md 5).  Placement only: any table is correct.  Each lane owns a strided subset of the block's
+// L2, so the slot -> block table (blk_order, ba_host.hip) hands the workgroups of XCD x a CONTIGUOUS run of block rows (runs cut
+// at equal shares of the contributions): camera i's W blocks are then fetched into ONE L2 instead of eight, and consecutive rows
+// of an XCD share most of their column cameras.  Placement only: any table is correct.  Each lane owns a strided subset of the block's
 // landmark contributions, forms (W_a D^-1) W_b^T in registers, then the 36 partial sums are combined
 // with a butterfly.  The block is written to the lower triangle of S (column-major), i.e. as the
 // transposed (j, i) block, plus the full diagonal block.
 // SPLIT = false: one wavefront (= one workgroup) per block.  SPLIT = true (few blocks, each with thousands of contributions:
 // local BA): four wavefronts share a block, contributions dealt out 64 at a time, the four partial blocks added in wavefront order.
-template <bool SPLIT>
+// STAGED: the W blocks of a wavefront's 64 contributions are fetched COOPERATIVELY -- nine consecutive lanes read the nine 16-byte
+// pieces of one 144-byte block, so a wave-wide load touches ~14 cache lines instead of 64 -- into the wavefront's LDS area in
+// piece-major order, and every lane then picks up its own two blocks from LDS without bank conflicts.  The texture addresser
+// handles about one cache line per cycle: lane-per-contribution gathers are 18 loads x 64 lines per 64 contributions, the
+// cooperative form 18 x ~14.  Measured at the 1k-pose map: 258 -> 246 us (the kernel is bound by the latency of its misses at
+// 8 wavefronts per compute unit, not by the addresser).  Same arithmetic in the same order: the results are bit-identical
+// (tools/ab_schur.py; MAGE_BA_SCHUR_GATHER=1 selects the old loads).
+template <bool SPLIT, bool STAGED>
 __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block(BaDeviceView v, double lambda)
 {
     constexpr int NW = SPLIT ? 4 : SCHUR_WAVES;
-    __shared__ double red[NW][64 * 37];
+    __shared__ __attribute__((aligned(16))) double red[NW][64 * 37];      // 18944 bytes per wavefront = 128 blocks x 144 + 128 slot indices x 4
     __shared__ double part[SPLIT ? 4 : 1][36];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int b;
@@ -434,23 +441,48 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block(
         b = v.blk_order[slot];
         if (b < 0) return;
     }
-    const int first = SPLIT ? wave * WAVE + lane : lane, stride = SPLIT ? 4 * WAVE : WAVE;
+    const int stride = SPLIT ? 4 * WAVE : WAVE;
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0;
-    for (int c = v.blk_ptr[b] + first; c < v.blk_ptr[b + 1]; c += stride) {
-        const int2 sab = v.con[c];
+    const int c_end = v.blk_ptr[b + 1];
+    double2* stg = reinterpret_cast<double2*>(red[wave]);                 // [piece 0..8][block 0..127], then 128 slot indices
+    int* sl = reinterpret_cast<int*>(red[wave]) + 128 * 36;
+    for (int c0 = v.blk_ptr[b] + (SPLIT ? wave * WAVE : 0); c0 < c_end; c0 += stride) {      // uniform per wavefront
+        const int c = c0 + lane;
+        const bool live = c < c_end;
+        const int2 sab = live ? v.con[c] : make_int2(0, 0);               // idle lanes read slot 0 (valid memory) and add nothing
         // 144-byte W blocks and 48-byte D^-1 records are 16-byte aligned: 128-bit loads (21 per contribution instead of 42)
-        const double2* Wa2 = reinterpret_cast<const double2*>(v.W + (size_t)sab.x * 18);
-        const double2* Wb2 = reinterpret_cast<const double2*>(v.W + (size_t)sab.y * 18);
         const double2* D2 = reinterpret_cast<const double2*>(v.Dinv + (size_t)v.w_lm[sab.x] * 6);
         const double2 da = D2[0], db = D2[1], dc = D2[2];
         const double d00 = da.x, d01 = da.y, d02 = db.x, d11 = db.y, d12 = dc.x, d22 = dc.y;
         double wa[18], wb[18];
+        if (STAGED) {
+            sl[lane] = sab.x; sl[64 + lane] = sab.y;
+            double2 piece[18];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { const double2 t = Wa2[k]; wa[2 * k] = t.x; wa[2 * k + 1] = t.y; }
+            for (int i = 0; i < 18; ++i) {
+                const int q = i * 64 + lane, blk = (q * 7282) >> 16, part = q - 9 * blk;          // q / 9 for q < 1152
+                piece[i] = reinterpret_cast<const double2*>(v.W + (size_t)sl[blk] * 18)[part];
+            }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { const double2 t = Wb2[k]; wb[2 * k] = t.x; wb[2 * k + 1] = t.y; }
+            for (int i = 0; i < 18; ++i) {
+                const int q = i * 64 + lane, blk = (q * 7282) >> 16, part = q - 9 * blk;
+                stg[part * 128 + blk] = piece[i];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { const double2 t = stg[k * 128 + lane]; wa[2 * k] = t.x; wa[2 * k + 1] = t.y; }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { const double2 t = stg[k * 128 + 64 + lane]; wb[2 * k] = t.x; wb[2 * k + 1] = t.y; }
+        } else {
+            const double2* Wa2 = reinterpret_cast<const double2*>(v.W + (size_t)sab.x * 18);
+            const double2* Wb2 = reinterpret_cast<const double2*>(v.W + (size_t)sab.y * 18);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { const double2 t = Wa2[k]; wa[2 * k] = t.x; wa[2 * k + 1] = t.y; }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { const double2 t = Wb2[k]; wb[2 * k] = t.x; wb[2 * k + 1] = t.y; }
+        }
+        if (!live) continue;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const double a0 = wa[r * 3], a1 = wa[r * 3 + 1], a2 = wa[r * 3 + 2];
@@ -1500,8 +1532,14 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st)
     if (v.n_pad > n) hipLaunchKernelGGL(k_pad_diag, dim3(cdiv(v.n_pad - n, 128)), dim3(128), 0, st, v.S, n, v.n_pad);
     if (v.points_free && v.n_lm > 0) hipLaunchKernelGGL(k_lm_invert, dim3(cdiv(v.n_lm, 256)), dim3(256), 0, st, v, lambda);
     if (v.n_blk > 0) {
-        if (v.n_blk <= SPLIT_BLOCKS_BELOW) hipLaunchKernelGGL(k_schur_block<true>, dim3(v.n_blk), dim3(256), 0, st, v, lambda);
-        else hipLaunchKernelGGL(k_schur_block<false>, dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda);
+        static const bool gather = std::getenv("MAGE_BA_SCHUR_GATHER") != nullptr;      // the lane-per-contribution loads, for comparison
+        if (v.n_blk <= SPLIT_BLOCKS_BELOW) {
+            if (gather) hipLaunchKernelGGL((k_schur_block<true, false>), dim3(v.n_blk), dim3(256), 0, st, v, lambda);
+            else hipLaunchKernelGGL((k_schur_block<true, true>), dim3(v.n_blk), dim3(256), 0, st, v, lambda);
+        } else {
+            if (gather) hipLaunchKernelGGL((k_schur_block<false, false>), dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda);
+            else hipLaunchKernelGGL((k_schur_block<false, true>), dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda);
+        }
     }
     tether_launch_schur(v, st);
     if (v.n_fc > 0) {
