@@ -43,3 +43,16 @@ def test_product_package_never_imports_the_oracle():
     for path in glob.glob(os.path.join(ROOT, "mageslam_amd", "**", "*"), recursive=True):
         if path.endswith((".py", ".hip", ".h", ".cpp")):
             assert not pat.search(open(path, errors="ignore").read()), path
+
+
+def test_cpp_shims_compile_without_a_gpu(tmp_path):
+    """include/BundlerLib.h, OrbDetector.h and FeatureMatcher.h are header-only C++ over the C ABI: their example callers compile
+    with the host compiler alone (linking and running them is the GPU suite's job)."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        pytest.skip("no host C++ compiler")
+    for src in ("shim_example.cpp", "shim_local_ba.cpp", "shim_orb_match.cpp"):
+        subprocess.run([cxx, "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "tools", src),
+                        "-o", str(tmp_path / (src + ".o"))], check=True, capture_output=True, timeout=300)

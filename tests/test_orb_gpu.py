@@ -442,3 +442,52 @@ def test_random_pattern_with_orientation_matches_oracle(gold, patch, name, extra
     ko, do = O.orb_detect(img, O.OrbParams.defaults(**{okw.get(a, a): b for a, b in kw.items()}), cap=max(440, kw.get("nfeatures", 440)))
     assert len(k) > 100
     assert np.array_equal(k, ko) and np.array_equal(d, do)
+
+
+def test_cpp_front_end_shims_compile_and_agree_with_the_mirror(tmp_path):
+    """include/OrbDetector.h + include/FeatureMatcher.h (the reference's OrbDetector / mage::OrbFeatureDetector classes and the
+    Match / RadiusMatch / GetDescriptorDistance functions over the C ABI): tools/shim_orb_match.cpp, written against the two headers
+    with stand-ins that have cv::KeyPoint / cv::DMatch / cv::Mat's layouts, builds with the host compiler alone and returns, record
+    for record, what the Python mirror (itself checked against the oracle above) returns."""
+    import os
+    import shutil
+    import subprocess
+    from mageslam_amd.orb import UndistortParams
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        pytest.skip("no host C++ compiler")
+    exe = str(tmp_path / "shim_orb_match")
+    lib_dir = os.path.join(root, "mageslam_amd")
+    subprocess.run([cxx, "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "shim_orb_match.cpp"),
+                    "-L" + lib_dir, "-lmageslam_hip", "-Wl,-rpath," + lib_dir, "-o", exe], check=True, capture_output=True, timeout=300)
+    a, b = frames.frame_pair(23)
+    a.tofile(tmp_path / "a.raw"); b.tofile(tmp_path / "b.raw")
+    r = subprocess.run([exe, str(tmp_path / "a.raw"), str(tmp_path / "b.raw"), "640", "480"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = [ln.split() for ln in r.stdout.splitlines()]
+    det, mt = OrbDetector(), Matcher()
+    ka, da = det.DetectAndCompute(a)
+    kb, db = det.DetectAndCompute(b)
+    K = np.array([500, 0, 320, 0, 500, 240, 0, 0, 1], np.float32); Kn = np.array([480, 0, 320, 0, 480, 240, 0, 0, 1], np.float32)
+    kb = det.UndistortKeypoints(kb, UndistortParams.make(K.reshape(3, 3), np.array([0.08, -0.02, 0.001, -0.0005, 0.004], np.float32), Kn.reshape(3, 3)))
+    assert rows[0] == ["A", str(len(ka)), "B", str(len(kb))]
+    tag = lambda t: [x[1:] for x in rows if x[0] == t]
+    sig = lambda d: int(d[0]) | (int(d[31]) << 8)
+    for got, k, d in ((tag("ka"), ka, da), (tag("kb"), kb, db)):
+        assert len(got) == len(k)
+        for g, kk, dd in zip(got, k, d):
+            assert np.float32(g[0]) == kk["x"] and np.float32(g[1]) == kk["y"] and float(g[2]) == kk["response"] and int(g[3]) == sig(dd)
+    maskA = np.ones(len(ka), np.uint8); maskA[::5] = 0
+    m = mt.Match(da, db, maskA, None, 40, 2)
+    assert [[int(x[0]), int(x[1]), int(x[2]), float(x[3])] for x in tag("m")] == [[int(q["queryIdx"]), int(q["trainIdx"]), int(q["imgIdx"]), float(q["distance"])] for q in m]
+    over = np.stack([ka["x"] + np.float32(1.5), ka["y"] - np.float32(0.5)], axis=1).astype(np.float32)
+    rm = mt.RadiusMatch(ka, da, kb, db, 12.0, 50, 1, query_position_overrides=over)
+    assert [[int(x[0]), int(x[1]), float(x[3])] for x in tag("r")] == [[int(q["queryIdx"]), int(q["trainIdx"]), float(q["distance"])] for q in rm]
+    singles = []
+    for i in range(min(20, len(ka))):
+        one = mt.RadiusMatch(ka[i:i + 1], da[i:i + 1], kb, db, 12.0, 50, 1)
+        if len(one):
+            singles.append([i, int(one[0]["trainIdx"]), float(one[0]["distance"])])
+    assert [[int(x[0]), int(x[1]), float(x[2])] for x in tag("s")] == singles
+    assert tag("dist") == [[str(GetDescriptorDistance(da[0], db[0])), "0"]]
