@@ -263,12 +263,17 @@ struct mage_ba {
     bool dup_slots = false;            // some landmark is observed twice by one free camera
     DevBuf<double> d_errL, d_U, d_bc, d_V, d_bp, d_W, d_Dinv, d_db, d_S, d_y, d_xc, d_xl, d_partial, d_scal, d_Linv;
     DevBuf<uint8_t> d_flagL, d_L_active;
+    uint32_t* d_out_ids = nullptr;      // outliers of the last post-pass (original observation indices, unordered): they live BEHIND the scalars
+                                        // in d_scal, so the first OUT_PREFIX of them come back in the scalars' read-back; cursor = the int behind the small-path counter
+    int out_cursor = 0;                 // value of that cursor (it only grows between structure builds)
+    size_t out_expect = 0;              // outliers of the previous post-pass: sizes the prefix that rides the next read-back
     DevBuf<int> d_T_kind, d_tc_hc, d_tc_ptr, d_tc_item, d_tp_ptr, d_tp_item;
     DevBuf<int2> d_T_cam, d_T_fixed, d_tp_ij;
     DevBuf<double> d_T_meas, d_T_w, d_T_out;
     int n_active_tethers = 0;
     DevBuf<int> d_queue;
-    void* h_pinned = nullptr; size_t h_pinned_bytes = 0;     // one pinned block (from the cache) holding the two mirrors below
+    void* h_pinned = nullptr; size_t h_pinned_bytes = 0;     // one pinned block (from the cache) holding the mirrors below
+    uint32_t* h_out_ids = nullptr;      // first OUT_PREFIX outlier ids of the last post-pass: they ride the scalar read-back
     double* h_scal = nullptr;           // pinned mirror of d_scal
     DevBuf<PoseLmResult> d_pose_lm;     // pose-only problems: the record the one-launch solve leaves
     PoseLmResult* h_pose_lm = nullptr;  // pinned mirror
@@ -303,12 +308,17 @@ struct mage_ba {
 
 namespace {
 
+constexpr size_t OUT_PREFIX = 4096;      // outlier ids copied back together with the post-pass scalars (16 KB); a longer list takes a second copy
+constexpr size_t SC_PAD = 16;            // doubles reserved for the scalars in d_scal / the pinned mirror; the outlier ids follow
+static_assert(SC_COUNT <= SC_PAD, "scalar block");
+
 mage_status ensure_pinned_mirrors(mage_ba* h)
 {
     if (h->h_pinned) return MAGE_OK;
-    const size_t off = (SC_COUNT * sizeof(double) + 255) & ~(size_t)255;
+    const size_t off = (SC_PAD * sizeof(double) + OUT_PREFIX * sizeof(uint32_t) + 255) & ~(size_t)255;      // scalars, then the id prefix: one copy
     MAGE_TRY(cached_pinned_alloc(&h->h_pinned, off + sizeof(PoseLmResult), &h->h_pinned_bytes));
     h->h_scal = static_cast<double*>(h->h_pinned);
+    h->h_out_ids = reinterpret_cast<uint32_t*>(h->h_scal + SC_PAD);
     h->h_pose_lm = reinterpret_cast<PoseLmResult*>(static_cast<char*>(h->h_pinned) + off);
     return MAGE_OK;
 }
@@ -765,10 +775,12 @@ mage_status initialize_optimization(mage_ba* h)
     // two-level reductions: one double per block of the widest launch; the small-problem linearisation (8 lanes per landmark, 4 blocks
     // per camera) also parks the cameras' partial (U, b_c) sums behind its chi2 partials
     MAGE_TRY(h->d_partial.reserve(std::max<size_t>(4 * 1024, std::max<size_t>((size_t)nb_l + nb_c, (size_t)nlm * 8 / 256 + (size_t)nfc * 4 * 29 + 8)) + 16));
-    MAGE_TRY(h->d_scal.reserve(SC_COUNT));
+    MAGE_TRY(h->d_scal.reserve(SC_PAD + ((size_t)nL + 2) / 2 + 1));          // scalars, then up to n_L outlier ids (32-bit)
+    h->d_out_ids = reinterpret_cast<uint32_t*>(h->d_scal.p + SC_PAD);
+    h->out_cursor = 0;                                                        // d_queue (with the cursor) is zeroed below
     MAGE_TRY(h->d_Linv.reserve(chol_workspace_doubles(n_pad)));
-    MAGE_TRY(h->d_queue.reserve(chol_sync_ints(n_pad) + 1));
-    MAGE_HIP(hipMemsetAsync(h->d_queue.p, 0, (chol_sync_ints(n_pad) + 1) * sizeof(int), st));       // recycled memory arrives dirty
+    MAGE_TRY(h->d_queue.reserve(chol_sync_ints(n_pad) + 2));                                          // + the small-path counter + the outlier cursor
+    MAGE_HIP(hipMemsetAsync(h->d_queue.p, 0, (chol_sync_ints(n_pad) + 2) * sizeof(int), st));       // recycled memory arrives dirty
     MAGE_TRY(h->d_flagL.reserve((size_t)nL + 1));
     MAGE_TRY(h->d_L_active.reserve((size_t)nL + 1));
     MAGE_HIP(hipMemsetAsync(h->d_L_active.p, 1, (size_t)nL + 1, st));
@@ -814,9 +826,10 @@ mage_status initialize_optimization(mage_ba* h)
 // The LM control flow needs three scalars on the host per trial; the GPU idles while they travel.  A blocking
 // hipStreamSynchronize parks the thread and costs 20-30 us of wake-up latency per read, so the host polls the event instead
 // (the step is a few milliseconds: spinning that long is the cheaper side of the trade).
-mage_status read_scalars(mage_ba* h)
+mage_status read_scalars(mage_ba* h, size_t outlier_prefix = 0)
 {
-    MAGE_HIP(hipMemcpyAsync(h->h_scal, h->d_scal.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    const size_t bytes = outlier_prefix ? SC_PAD * sizeof(double) + outlier_prefix * sizeof(uint32_t) : SC_COUNT * sizeof(double);
+    MAGE_HIP(hipMemcpyAsync(h->h_scal, h->d_scal.p, bytes, hipMemcpyDeviceToHost, h->stream));
     MAGE_HIP(hipEventRecord(h->ev[3], h->stream));
     for (;;) {
         const hipError_t e = hipEventQuery(h->ev[3]);
@@ -1312,7 +1325,8 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
         const BaDeviceView& v = h->view;
         double err_sum = 0, cnt = 0;
         size_t nout = 0;
-        bool in_one_launch = false;
+        bool in_one_launch = false, ids_from_device = false;
+        size_t out_prefix = 0;
         if (n_iter > 0) {
             // StepOptimizer's entry conditions (BundlerLib.cpp:132-149), then: a pose-only problem runs the whole call in one launch
             if (h->dirty) MAGE_TRY(initialize_optimization(h));
@@ -1359,22 +1373,41 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
             }
             // post-pass over the active observations of the last initialisation
             if (v.n_L == 0 || h->L_edge_host.empty()) return MAGE_OK;     // count == 0 -> NaN
-            if (ba_small_applies(v)) ba_small_classify(v, (double)max_err_sq, h->d_flagL.p, h->d_queue.p + chol_sync_ints(v.n_pad), h->stream);
-            else ba_launch_classify(v, (double)max_err_sq, h->d_flagL.p, h->stream);
-            MAGE_TRY(read_scalars(h));
+            int* small_counter = h->d_queue.p + chol_sync_ints(v.n_pad);
+            if (ba_small_applies(v)) ba_small_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, small_counter, h->stream);
+            else ba_launch_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, h->stream);
+            // the first OUT_PREFIX ids of the list ride the same read-back as the three sums (usually that is the whole list)
+            ids_from_device = true;
+            // (a run that removed outliers last time will again: twice that many, at least 64, at most OUT_PREFIX; a 16 KB copy is ~8 us
+            // slower than a 100-byte one, so a run without outliers does not pay for it)
+            const size_t prefix = std::min<size_t>(std::min<size_t>(OUT_PREFIX, (size_t)v.n_L), std::max<size_t>(64, 2 * h->out_expect));
+            MAGE_TRY(read_scalars(h, prefix));
             err_sum = h->h_scal[SC_ERRSUM]; cnt = h->h_scal[SC_ERRCNT];
             nout = (size_t)h->h_scal[SC_NOUT];
+            h->out_cursor += (int)nout;
+            h->out_expect = nout;
+            out_prefix = prefix;
         }
         if (mean_sq_err) *mean_sq_err = (float)(err_sum / cnt);
         if (nout > 0) {
-            h->flag_host.resize(v.n_L);
-            MAGE_HIP(hipMemcpyAsync(h->flag_host.data(), h->d_flagL.p, (size_t)v.n_L, hipMemcpyDeviceToHost, h->stream));
-            MAGE_HIP(hipStreamSynchronize(h->stream));
             // The whole list stays in the handle (mage_ba_get_outliers): a caller whose buffer was too small loses nothing --
             // the reference appends to a std::vector and its callers drop these associations from the map (BundleAdjust.cpp:316-320).
             std::vector<uint32_t>& ids = h->last_outliers;
-            ids.reserve(nout);
-            for (int i = 0; i < v.n_L; ++i) if (h->flag_host[i]) ids.push_back(h->L_edge_host[i]);
+            if (ids_from_device) {
+                ids.resize(nout);
+                const size_t first = std::min<size_t>(nout, out_prefix);
+                std::copy(h->h_out_ids, h->h_out_ids + first, ids.begin());
+                if (nout > first) {
+                    MAGE_HIP(hipMemcpyAsync(ids.data() + first, h->d_out_ids + first, (nout - first) * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+                    MAGE_HIP(hipStreamSynchronize(h->stream));
+                }
+            } else {
+                h->flag_host.resize(v.n_L);
+                MAGE_HIP(hipMemcpyAsync(h->flag_host.data(), h->d_flagL.p, (size_t)v.n_L, hipMemcpyDeviceToHost, h->stream));
+                MAGE_HIP(hipStreamSynchronize(h->stream));
+                ids.reserve(nout);
+                for (int i = 0; i < v.n_L; ++i) if (h->flag_host[i]) ids.push_back(h->L_edge_host[i]);
+            }
             std::sort(ids.begin(), ids.end());
             for (size_t i = 0; i < ids.size(); ++i) {
                 h->obs[ids[i]].removed = 1;                                  // removeEdge

@@ -84,7 +84,7 @@ void ba_launch_linearize(const BaDeviceView& v, double huber_delta, hipStream_t 
 void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st);                                       // -> scal[SC_MAXDIAG]
 void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st);                          // Dinv,db,S,y
 void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st);                         // xl, trial state, scal[SC_SCALE]
-void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flag_by_edge, hipStream_t st); // scal[SC_ERRSUM..SC_NOUT]
+void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, hipStream_t st); // scal[SC_ERRSUM..SC_NOUT]
 
 // Small problems (reduced camera system of order <= 128, no tethers): one LM trial in five launches instead of ~22
 // (ba_kernels.hip, "SMALL PROBLEMS").  `counter` is one zero-initialised device int owned by the handle (the kernels leave it 0).
@@ -92,7 +92,7 @@ bool ba_small_applies(const BaDeviceView& v);
 void ba_small_init_device();                                                                          // once per device: LDS opt-in
 void ba_small_linearize(const BaDeviceView& v, double huber_delta, bool want_maxdiag, int* counter, hipStream_t st);   // U,bc,V,bp,W, S/y zeroed, scal[SC_CHI] (+ SC_MAXDIAG)
 void ba_small_solve_trial(const BaDeviceView& v, double lambda, double huber_delta, double* linv_ws, int* counter, hipStream_t st);    // S, y, xc, trial state, SC_SCALE, SC_CHI_TRIAL, SC_CHOL_OK/STALL
-void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flag_by_edge, int* counter, hipStream_t st);
+void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, hipStream_t st);
 
 // Pose-only problems (points fixed): the whole StepBundleAdjustment call in ONE launch (ba_kernels.hip, "POSE-ONLY problems").
 constexpr int POSE_LM_MAX_ITERS = 16;

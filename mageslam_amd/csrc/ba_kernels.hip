@@ -715,12 +715,15 @@ __global__ __launch_bounds__(256) void k_pose_update(BaDeviceView v, double lamb
 // outlier classification (BundlerLib.cpp:384-427): uses the residuals of the LAST error evaluation
 // (errL) and the KEPT estimates for the in-front-of-camera test, exactly as the reference does.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_classify(BaDeviceView v, double max_err_sq, uint8_t* __restrict__ flagL, int nb)
+// Outliers are appended (in no particular order; the host sorts them) to out_ids as ORIGINAL observation indices: what crosses
+// PCIe is the list, not a flag per observation.  The cursor *out_count only ever grows between structure builds; out_base is its
+// value before this launch (the host has read every earlier count), so nothing has to be cleared.
+__global__ __launch_bounds__(256) void k_classify(BaDeviceView v, double max_err_sq, uint32_t* __restrict__ out_ids, int* __restrict__ out_count, int out_base, int nb)
 {
     __shared__ double sm[4];
     double es = 0, ec = 0, no = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n_L; i += gridDim.x * 256) {
-        if (!v.L_active[i]) { flagL[i] = 0; continue; }
+        if (!v.L_active[i]) continue;
         const double2 e = *reinterpret_cast<const double2*>(v.errL + (size_t)i * 2);
         const double ss = e.x * e.x + e.y * e.y;
         const int cam = v.L_cam[i], pt = v.L_pt[i];
@@ -731,8 +734,7 @@ __global__ __launch_bounds__(256) void k_classify(BaDeviceView v, double max_err
         const double* X = v.pt_cur + (size_t)pt * 4;
         const double dot = (X[0] - wx) * fx + (X[1] - wy) * fy + (X[2] - wz) * fz;
         const bool out = (dot <= 0) || (ss > max_err_sq);
-        flagL[i] = out ? 1 : 0;
-        if (out) { no += 1.0; v.L_active[i] = 0; }          // removeEdge: the observation leaves the graph on the device right here
+        if (out) { no += 1.0; v.L_active[i] = 0; out_ids[atomicAdd(out_count, 1) - out_base] = v.L_edge[i]; }   // removeEdge: the observation leaves the graph on the device right here
         else { es += ss; ec += 1.0; }
     }
     double r0 = block_sum<4>(es, sm);
@@ -1233,12 +1235,13 @@ __global__ __launch_bounds__(256) void k_small_error(BaDeviceView v, int trial, 
 }
 
 // k_classify with the three reductions folded in
-__global__ __launch_bounds__(256) void k_small_classify(BaDeviceView v, double max_err_sq, uint8_t* __restrict__ flagL, int* __restrict__ counter)
+__global__ __launch_bounds__(256) void k_small_classify(BaDeviceView v, double max_err_sq, uint32_t* __restrict__ out_ids, int* __restrict__ out_count,
+                                                        int out_base, int* __restrict__ counter)
 {
     __shared__ double sm[4];
     double es = 0, ec = 0, no = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n_L; i += gridDim.x * 256) {
-        if (!v.L_active[i]) { flagL[i] = 0; continue; }
+        if (!v.L_active[i]) continue;
         const double2 e = *reinterpret_cast<const double2*>(v.errL + (size_t)i * 2);
         const double ss = e.x * e.x + e.y * e.y;
         const int cam = v.L_cam[i], pt = v.L_pt[i];
@@ -1249,8 +1252,7 @@ __global__ __launch_bounds__(256) void k_small_classify(BaDeviceView v, double m
         const double* X = v.pt_cur + (size_t)pt * 4;
         const double dot = (X[0] - wx) * fx + (X[1] - wy) * fy + (X[2] - wz) * fz;
         const bool out = (dot <= 0) || (ss > max_err_sq);
-        flagL[i] = out ? 1 : 0;
-        if (out) { no += 1.0; v.L_active[i] = 0; }
+        if (out) { no += 1.0; v.L_active[i] = 0; out_ids[atomicAdd(out_count, 1) - out_base] = v.L_edge[i]; }
         else { es += ss; ec += 1.0; }
     }
     const int nb = gridDim.x;
@@ -1584,9 +1586,9 @@ void ba_small_solve_trial(const BaDeviceView& v, double lambda, double delta, do
     hipLaunchKernelGGL(k_small_update, dim3(nbL + cdiv(v.n_fc, 256)), dim3(256), 0, st, v, lambda, nbL, counter);
     hipLaunchKernelGGL(k_small_error, dim3(small_error_blocks(v)), dim3(256), 0, st, v, 1, delta, counter);
 }
-void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flagL, int* counter, hipStream_t st)
+void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_small_classify, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, flagL, counter);
+    hipLaunchKernelGGL(k_small_classify, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, counter);
 }
 void ba_small_init_device() {}
 
@@ -1609,10 +1611,10 @@ void ba_launch_import_poses(double* pose0, double* pose1, const uint32_t* cam, c
     if (n) hipLaunchKernelGGL(k_import_poses, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, st, pose0, pose1, cam, row, n, block);
 }
 
-void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint8_t* flagL, hipStream_t st)
+void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, hipStream_t st)
 {
     int nb = v.n_L > 0 ? (cdiv(v.n_L, 256) < RED_BLOCKS ? cdiv(v.n_L, 256) : RED_BLOCKS) : 1;
-    hipLaunchKernelGGL(k_classify, dim3(nb), dim3(256), 0, st, v, max_err_sq, flagL, nb);
+    hipLaunchKernelGGL(k_classify, dim3(nb), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, nb);
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
 }
 
