@@ -25,18 +25,26 @@ WORKER = textwrap.dedent("""
 """) % ROOT
 
 
-def test_two_rank_gloo_roundtrip(tmp_path):
+def _free_port():
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    return port
+
+
+def test_two_rank_gloo_roundtrip(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for attempt in range(2):            # the port is free when probed, not reserved: one retry if something else took it meanwhile
+        port = _free_port()
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        res = [p.communicate(timeout=180) + (p.returncode,) for p in procs]
+        if all(rc == 0 for _, _, rc in res) or attempt == 1:
+            break
     outs = []
-    for p in procs:
-        o, e = p.communicate(timeout=180)
-        assert p.returncode == 0, e[-2000:]
+    for o, e, rc in res:
+        assert rc == 0, e[-2000:]
         outs.append(__import__("json").loads(o.strip().splitlines()[-1]))
     outs.sort(key=lambda d: d["rank"])
     assert outs[0]["owned"] == [0, 2, 4] and outs[1]["owned"] == [1, 3]
@@ -66,11 +74,13 @@ def test_rccl_bring_up_failure_falls_back_to_gloo_under_torchrun(tmp_path):
     if torch.cuda.is_available():
         import pytest
         pytest.skip("needs a box without GPUs so that RCCL bring-up fails")
-    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     script = tmp_path / "worker.py"
     script.write_text(FALLBACK_WORKER)
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=300)
+    for attempt in range(2):
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, timeout=300)
+        if p.returncode == 0:
+            break
     assert p.returncode == 0, p.stderr[-3000:]
     outs = [__import__("json").loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(outs) == 2 and all(d["el"] == 2.0 and d["n"] == 14 and d["rmse"] == 0.5 for d in outs)

@@ -80,17 +80,20 @@ WORKER = textwrap.dedent("""
 def test_two_ranks_over_gloo_equal_one_rank_bit_for_bit(tmp_path):
     _, m, _ = _run(4, 6, overlap=2)
     want = hashlib.sha256(m.pose_block().tobytes()).hexdigest()
-    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for attempt in range(2):            # the port is free when probed, not reserved: one retry if something else took it meanwhile
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        res = [p.communicate(timeout=300) + (p.returncode,) for p in procs]
+        if all(rc == 0 for _, _, rc in res) or attempt == 1:
+            break
     outs = []
-    for p in procs:
-        o, e = p.communicate(timeout=300)
-        assert p.returncode == 0, e[-3000:]
+    for o, e, rc in res:
+        assert rc == 0, e[-3000:]
         outs.append(json.loads(o.strip().splitlines()[-1]))
     outs.sort(key=lambda d: d["rank"])
     assert outs[0]["mine"] == [0, 1] and outs[1]["mine"] == [2, 3]

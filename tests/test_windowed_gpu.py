@@ -165,12 +165,15 @@ WORKER = textwrap.dedent("""
 def test_two_ranks_sharing_the_gpu_equal_one_rank_bit_for_bit(tmp_path):
     m, _ = _run("hip", 4, 5)
     want = _sha(m.pose_block())
-    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, MAGE_TEST_OUT=str(tmp_path)))
+    for attempt in range(2):            # the port is free when probed, not reserved: one retry if something else took it meanwhile
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, MAGE_TEST_OUT=str(tmp_path)))
+        if p.returncode == 0:
+            break
     assert p.returncode == 0, p.stderr[-3000:]
     outs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
     assert [o["mine"] for o in outs] == [[0, 1], [2, 3]] and all(o["on_device"] for o in outs)
