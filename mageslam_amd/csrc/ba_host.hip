@@ -581,10 +581,15 @@ mage_status initialize_optimization(mage_ba* h)
     });
     // several observations of one landmark by one free camera share a W slot (their blocks are summed in order); the small-problem
     // linearisation gives every observation its own lane only when that never happens
-    h->dup_slots = true;
-    if (nfc * 6 <= 128) {                       // only the small-problem path asks (ba_small_applies)
+    {
+        std::vector<long long> part_count(lm_parts, 0);
+        parallel_ranges(nlm, lm_parts, [&](int l0, int l1, int part) {
+            long long c = 0;
+            for (int i = lm_ptr[l0]; i < lm_ptr[l1]; ++i) c += L_slot[i] >= 0 ? 1 : 0;
+            part_count[part] = c;
+        });
         long long slot_obs = 0;
-        for (size_t i = 0; i < (size_t)nL; ++i) slot_obs += L_slot[i] >= 0 ? 1 : 0;
+        for (long long c : part_count) slot_obs += c;
         h->dup_slots = slot_obs != (long long)nw;
     }
     MAGE_TRY(push(h->d_L_uv, L_uv, nL)); MAGE_TRY(push(h->d_L_info, L_info, nL)); MAGE_TRY(push(h->d_L_cam, L_cam, nL));
@@ -774,7 +779,7 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(h->d_xl.reserve((size_t)nlm * 4 + 1));
     // two-level reductions: one double per block of the widest launch; the small-problem linearisation (8 lanes per landmark, 4 blocks
     // per camera) also parks the cameras' partial (U, b_c) sums behind its chi2 partials
-    MAGE_TRY(h->d_partial.reserve(std::max<size_t>(4 * 1024, std::max<size_t>((size_t)nb_l + nb_c, (size_t)nlm * 8 / 256 + (size_t)nfc * 4 * 29 + 8)) + 16));
+    MAGE_TRY(h->d_partial.reserve(std::max<size_t>(4 * 1024, std::max<size_t>((size_t)nb_l + nb_c, (size_t)nlm * 8 / 256 + (size_t)nfc * 4 * 29 + 8)) + 16));          // (the fused large-problem form needs nlm / 32 + nfc entries: covered)
     MAGE_TRY(h->d_scal.reserve(SC_PAD + ((size_t)nL + 2) / 2 + 1));          // scalars, then up to n_L outlier ids (32-bit)
     h->d_out_ids = reinterpret_cast<uint32_t*>(h->d_scal.p + SC_PAD);
     h->out_cursor = 0;                                                        // d_queue (with the cursor) is zeroed below
@@ -851,6 +856,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
     int* counter = h->d_queue.p + chol_sync_ints(v.n_pad);       // one int behind the factorisation's counters, zero between launches
     if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[0], st));
     if (small) ba_small_linearize(v, huber, h->iteration == 0, counter, st);
+    else if (ba_fused_linearize_applies(v)) ba_fused_linearize(v, huber, counter, st);
     else {
         ba_launch_error(v, false, huber, st);
         ba_launch_linearize(v, huber, st);

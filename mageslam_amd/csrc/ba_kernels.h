@@ -90,6 +90,8 @@ void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_
 // (ba_kernels.hip, "SMALL PROBLEMS").  `counter` is one zero-initialised device int owned by the handle (the kernels leave it 0).
 bool ba_small_applies(const BaDeviceView& v);
 void ba_small_init_device();                                                                          // once per device: LDS opt-in
+bool ba_fused_linearize_applies(const BaDeviceView& v);                                              // large, tether-free, one observation per W slot
+void ba_fused_linearize(const BaDeviceView& v, double huber_delta, int* counter, hipStream_t st);    // = ba_launch_error(current) + ba_launch_linearize in one launch
 void ba_small_linearize(const BaDeviceView& v, double huber_delta, bool want_maxdiag, int* counter, hipStream_t st);   // U,bc,V,bp,W, S/y zeroed, scal[SC_CHI] (+ SC_MAXDIAG)
 void ba_small_solve_trial(const BaDeviceView& v, double lambda, double huber_delta, double* linv_ws, int* counter, hipStream_t st);    // S, y, xc, trial state, SC_SCALE, SC_CHI_TRIAL, SC_CHOL_OK/STALL
 void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, hipStream_t st);

@@ -828,15 +828,19 @@ __device__ __forceinline__ void lm_dinv(const BaDeviceView& v, int l, double lam
 // on its compute unit to hide them (a local BA is ~200 wavefronts on 256 compute units).
 constexpr int SMALL_LPL = 8, SMALL_CPC = 4;
 
-__global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double delta, int nbL, int want_maxdiag, int* __restrict__ counter)
+// cpc = workgroups per camera: SMALL_CPC for the few cameras of a small problem (their quarters are added by the last block), 1 for
+// the large-problem use of the same kernel (ba_fused_linearize: hundreds of cameras, the workgroup writes U and b_c itself);
+// zero_role = 0 drops the S / y zero-fill block (large systems clear S with k_zero_lower).
+__global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double delta, int nbL, int want_maxdiag, int* __restrict__ counter, int cpc,
+                                                         int zero_role)
 {
     __shared__ double sm[4];
     __shared__ double part[4][28];
     __shared__ double udiag[128];
     const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_blocks = gridDim.x;
-    const int nbC = v.n_fc * SMALL_CPC;
-    double* cam_part = v.partial + n_blocks;           // n_fc x SMALL_CPC x 28 partial (U, b_c) sums, behind the chi2 partials
+    const int nbC = v.n_fc * cpc;
+    double* cam_part = v.partial + n_blocks;           // n_fc x cpc x 28 partial (U, b_c) sums, behind the chi2 partials
     double chi = 0;                                    // this thread's share of the robust chi2 (one role per problem kind owns it)
     if (bid < nbL && !v.dup_slots) {
         // ---- landmark role, SMALL_LPL lanes per landmark: lane `sub` takes observations beg + sub, beg + sub + 8, ...; every
@@ -970,7 +974,7 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
     } else if (bid < nbL + nbC) {
         // ---- camera role: k_linearize_cam<true>, SMALL_CPC workgroups per camera, each a contiguous quarter of the camera's
         // observations; the last block adds the quarters in order.  Owns the chi2 when the points are fixed
-        const int hc = (bid - nbL) / SMALL_CPC, quarter = (bid - nbL) % SMALL_CPC;
+        const int hc = (bid - nbL) / cpc, quarter = (bid - nbL) % cpc;
         const int cam = v.hc2cam[hc];
         PoseD P = load_pose(v.pose_cur, cam);
         const double f = v.camK[cam * 4];
@@ -979,7 +983,7 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
         for (int k = 0; k < 21; ++k) A[k] = 0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) b[k] = 0;
-        const int e0 = v.camE_ptr[hc], ne = v.camE_ptr[hc + 1] - e0, per = (ne + SMALL_CPC - 1) / SMALL_CPC;
+        const int e0 = v.camE_ptr[hc], ne = v.camE_ptr[hc + 1] - e0, per = (ne + cpc - 1) / cpc;
         const int q0 = e0 + min(quarter * per, ne), q1 = e0 + min((quarter + 1) * per, ne);
         for (int idx = q0 + wave * WAVE + lane; idx < q1; idx += 4 * WAVE) {
             const int i = v.camE[idx];
@@ -1015,8 +1019,21 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
             for (int k = 0; k < 6; ++k) part[wave][21 + k] = b[k];
         }
         __syncthreads();
-        if (tid < 27) cam_part[(size_t)(bid - nbL) * 28 + tid] = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
-    } else {
+        if (cpc > 1) {
+            if (tid < 27) cam_part[(size_t)(bid - nbL) * 28 + tid] = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+        } else if (tid == 0) {
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int c = 0; c <= a; ++c) {
+                    const double val = ((part[0][k] + part[1][k]) + part[2][k]) + part[3][k];
+                    v.U[(size_t)hc * 36 + a * 6 + c] = val; v.U[(size_t)hc * 36 + c * 6 + a] = val; ++k;
+                }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) v.bc[(size_t)hc * 6 + a] = ((part[0][21 + a] + part[1][21 + a]) + part[2][21 + a]) + part[3][21 + a];
+        }
+    } else if (zero_role) {
         // ---- zero role: S (n_pad x n_pad), y, identity on the padded tail of the diagonal
         const int n = v.n_fc * 6, np = v.n_pad;
         for (int i = tid; i < np * np; i += 256) v.S[i] = 0.0;
@@ -1026,6 +1043,10 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
     }
     const double r = block_sum<4>(chi, sm);
     if (tid == 0) v.partial[bid] = r;
+    // Large problems (cpc == 1) fold the chi2 partials in a launch of their own: the "last block" pattern needs a release fence per
+    // block -- a write-back of the XCD's L2 -- and with thousands of blocks streaming 144 MB of W through those L2s that fence
+    // costs more than the whole kernel (0.32 ms against 0.13 for the three separate kernels).
+    if (cpc == 1) return;
     if (!last_block_arrives(counter, n_blocks)) return;
     fold_partials(v.partial, n_blocks, v.scal + SC_CHI, sm);
     // U and b_c of every camera from its quarters, in order
@@ -1575,7 +1596,21 @@ static int small_error_blocks(const BaDeviceView& v) { return v.n_L > 0 ? std::m
 void ba_small_linearize(const BaDeviceView& v, double delta, bool want_maxdiag, int* counter, hipStream_t st)
 {
     const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm * (v.dup_slots ? 1 : SMALL_LPL), 256) : 0;
-    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + v.n_fc * SMALL_CPC + 1), dim3(256), 0, st, v, delta, nbL, want_maxdiag ? 1 : 0, counter);
+    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + v.n_fc * SMALL_CPC + 1), dim3(256), 0, st, v, delta, nbL, want_maxdiag ? 1 : 0, counter, SMALL_CPC, 1);
+}
+// The same kernel for LARGE tether-free problems in which every observation owns its W block: k_error + k_linearize_lm +
+// k_linearize_cam in one launch -- the residuals are computed once, a landmark's observations by eight lanes, the chi2 folded by the
+// last block.  S is cleared by ba_launch_schur, max |diag| comes from ba_launch_maxdiag.
+bool ba_fused_linearize_applies(const BaDeviceView& v)
+{
+    static const bool off = std::getenv("MAGE_BA_NO_FUSED_LINEARIZE") != nullptr;
+    return !off && !v.dup_slots && v.n_T == 0 && v.n_fc > 0 && v.n_L > 0;
+}
+void ba_fused_linearize(const BaDeviceView& v, double delta, int* counter, hipStream_t st)
+{
+    const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm * SMALL_LPL, 256) : 0;
+    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + v.n_fc), dim3(256), 0, st, v, delta, nbL, 0, counter, 1, 0);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nbL + v.n_fc, 1, v.scal + SC_CHI, 1);
 }
 void ba_small_solve_trial(const BaDeviceView& v, double lambda, double delta, double* linv_ws, int* counter, hipStream_t st)
 {
