@@ -46,25 +46,12 @@ __device__ __forceinline__ short2_t swap16(short2_t v) { return __builtin_shuffl
 __device__ __forceinline__ short2_t pmin(short2_t a, short2_t b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ short2_t pmax(short2_t a, short2_t b) { return __builtin_elementwise_max(a, b); }
 
-// the 16 ring differences v - ring[k] as packed opposite pairs: P[k] = (d[k], d[k + 8]), Q[k] = (d[k + 8], d[k])
-__device__ __forceinline__ void fast_ring(const uint8_t* __restrict__ c, int TP, short2_t (&P)[8], short2_t (&Q)[8])
-{
-    const int v = c[0];
-    const int ox[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
-    const int oy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int lo = v - (int)c[oy[k] * TP + ox[k]], hi = v - (int)c[oy[k + 8] * TP + ox[k + 8]];
-        P[k] = (short2_t){ (short)lo, (short)hi };
-        Q[k] = (short2_t){ (short)hi, (short)lo };
-    }
-}
-
 // Second screen, on the EVEN ring positions (the compass points and the four diagonals): 9 contiguous ring pixels contain at
 // least 4 consecutive even positions, so a corner needs 4 consecutive even pixels all darker than the centre by more than t, or
 // all brighter.  Nine byte reads and ~45 operations; ~11 % of the pixels of a textured frame pass (the opposite-pair test on all
 // 16 pixels passes ~8 % but costs twice as much on the ~21 % it is run on).
-__device__ __forceinline__ bool fast_even4_test(const uint8_t* __restrict__ c, int TP, int t)
+// Returns bit 0 = a darker run exists, bit 1 = a brighter run exists (0 = not a corner).
+__device__ __forceinline__ int fast_even4_test(const uint8_t* __restrict__ c, int TP, int t)
 {
     const int v = c[0];
     // even positions 0, 2, 4, 6 and their opposites 8, 10, 12, 14: (0, 3) (2, 2) (3, 0) (2, -2) / (0, -3) (-2, -2) (-3, 0) (-2, 2)
@@ -83,42 +70,40 @@ __device__ __forceinline__ bool fast_even4_test(const uint8_t* __restrict__ c, i
         dark = pmax(dark, pmin(A2[j], na));            // largest window minimum of (v - ring)
         bright = pmin(bright, pmax(B2[j], nb));        // smallest window maximum
     }
-    return max((int)dark.x, (int)dark.y) > t || min((int)bright.x, (int)bright.y) < -t;
+    return (max((int)dark.x, (int)dark.y) > t ? 1 : 0) | (min((int)bright.x, (int)bright.y) < -t ? 2 : 0);
 }
 
-// score = max over the 16 arcs of 9 contiguous ring pixels of the arc's minimum margin, for darker and for brighter rings; a
-// pixel is a corner iff that maximum exceeds the threshold, and its score is maximum - 1 (identical to the reference's
-// threshold-table pre-test + min/max ladder, which computes the same quantity).
-__device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ c, int TP, int t)
+// The corner score for ONE polarity: D[k] = v - ring[k] (darker ring) or ring[k] - v (brighter ring), m = max over the 16 arcs of 9
+// contiguous ring pixels of the arc's minimum; the pixel is a corner of that polarity iff m > t, with score m - 1 (identical to the
+// reference's threshold-table pre-test + min/max ladder, which computes max(m_darker, m_brighter)).  A pixel cannot hold a darker
+// and a brighter 9-arc at once (18 > 16 ring pixels), so only the polarity the even-position screen left open can exceed the
+// threshold: one min ladder on packed pairs (register k = ring pixel k and its opposite; a rotation of the ring is "next
+// register", crossing position 7 -> 8 a swap of the halves) instead of a min and a max ladder.
+__device__ __forceinline__ int fast_score_polar(const uint8_t* __restrict__ c, int TP, bool brighter)
 {
-    short2_t P[8], Q[8];
-    fast_ring(c, TP, P, Q);
-    // windowed minima / maxima by doubling: windows of 2, 4, 8 ring positions, then 9
-    short2_t A2[8], B2[8], A4[8], B4[8], A8[8], B8[8];
+    const int v = c[0];
+    const int ox[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
+    const int oy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
+    short2_t P[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const short2_t nx = k < 7 ? P[k + 1] : Q[0];                 // positions k+1 and k+9
-        A2[k] = pmin(P[k], nx); B2[k] = pmax(P[k], nx);
+        const int a = (int)c[oy[k] * TP + ox[k]], b = (int)c[oy[k + 8] * TP + ox[k + 8]];
+        const uint32_t ring = (uint32_t)a | ((uint32_t)b << 16), cen = (uint32_t)v * 0x00010001u;
+        const uint32_t lhs = brighter ? ring : cen, rhs = brighter ? cen : ring;
+        short2_t L, R; __builtin_memcpy(&L, &lhs, 4); __builtin_memcpy(&R, &rhs, 4);
+        P[k] = L - R;
     }
+    short2_t A2[8], A4[8], A8[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const short2_t na = k < 6 ? A2[k + 2] : swap16(A2[k - 6]), nb = k < 6 ? B2[k + 2] : swap16(B2[k - 6]);
-        A4[k] = pmin(A2[k], na); B4[k] = pmax(B2[k], nb);
-    }
+    for (int k = 0; k < 8; ++k) A2[k] = pmin(P[k], k < 7 ? P[k + 1] : swap16(P[0]));
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const short2_t na = k < 4 ? A4[k + 4] : swap16(A4[k - 4]), nb = k < 4 ? B4[k + 4] : swap16(B4[k - 4]);
-        A8[k] = pmin(A4[k], na); B8[k] = pmax(B4[k], nb);
-    }
-    // arcs of 9: window of 8 starting at k plus position k + 8 (the opposite pixel = the swapped pair)
-    short2_t dark = pmin(A8[0], Q[0]), bright = pmax(B8[0], Q[0]);
+    for (int k = 0; k < 8; ++k) A4[k] = pmin(A2[k], k < 6 ? A2[k + 2] : swap16(A2[k - 6]));
 #pragma unroll
-    for (int k = 1; k < 8; ++k) {
-        dark = pmax(dark, pmin(A8[k], Q[k]));          // darker ring: largest arc minimum of (v - ring)
-        bright = pmin(bright, pmax(B8[k], Q[k]));      // brighter ring: smallest arc maximum of (v - ring)
-    }
-    const int m = max(max((int)dark.x, (int)dark.y), -min((int)bright.x, (int)bright.y));
-    return m > t ? m - 1 : 0;
+    for (int k = 0; k < 8; ++k) A8[k] = pmin(A4[k], k < 4 ? A4[k + 4] : swap16(A4[k - 4]));
+    short2_t best = pmin(A8[0], swap16(P[0]));
+#pragma unroll
+    for (int k = 1; k < 8; ++k) best = pmax(best, pmin(A8[k], swap16(P[k])));
+    return max((int)best.x, (int)best.y);
 }
 
 __device__ __forceinline__ int reflect101(int p, int n)
@@ -306,32 +291,37 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
     }
     __syncthreads();
     ORB_CLK(1);
-    // Phase 2a: even-position test
+    // Phase 2a: even-position test.  A survivor is listed once per polarity that is still possible (bit 12 = brighter ring), so
+    // that phase 2b runs ONE min ladder per entry; the few pixels with both polarities open get two entries.
     const int nc = n_cand;
     for (int c0 = 0; c0 < nc; c0 += 256) {
         const int c = c0 + tid;
-        int p = 0;
-        bool pass = false;
+        int p = 0, polar = 0;
         if (c < nc) {
             p = cand[c];
             const int ry = p / SCP, rx = p % SCP;
-            pass = fast_even4_test(&tile[(ry + 3) * TP + rx + 15], TP, threshold);
+            polar = fast_even4_test(&tile[(ry + 3) * TP + rx + 15], TP, threshold);
         }
-        const unsigned long long bal = __ballot(pass);
-        if (bal) {
+        const unsigned long long bal0 = __ballot(polar & 1), bal1 = __ballot(polar & 2);
+        if (bal0 | bal1) {
             int base = 0;
-            if (lane == 0) base = atomicAdd(&n_cand2, __popcll(bal));
+            const int n0 = __popcll(bal0);
+            if (lane == 0) base = atomicAdd(&n_cand2, n0 + __popcll(bal1));
             base = __shfl(base, 0, 64);
-            if (pass) cand2[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)p;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (polar & 1) cand2[base + __popcll(bal0 & below)] = (uint16_t)p;
+            if (polar & 2) cand2[base + n0 + __popcll(bal1 & below)] = (uint16_t)(p | 0x1000);
         }
     }
     __syncthreads();
-    // Phase 2b: exact score of the survivors
+    // Phase 2b: exact score of the survivors.  Only a corner is written (the tile of scores starts at zero), and a pixel cannot be a
+    // corner in both polarities, so its two entries never write both.
     const int nc2 = n_cand2;
     for (int c = tid; c < nc2; c += 256) {
-        const int p = cand2[c];
+        const int pc = cand2[c], p = pc & 0xfff;
         const int ry = p / SCP, rx = p % SCP;
-        sc[p + SC_OFF] = (uint8_t)fast_score_at(&tile[(ry + 3) * TP + rx + 15], TP, threshold);
+        const int m = fast_score_polar(&tile[(ry + 3) * TP + rx + 15], TP, (pc & 0x1000) != 0);
+        if (m > threshold) sc[p + SC_OFF] = (uint8_t)(m - 1);
     }
     __syncthreads();
     ORB_CLK(2);
