@@ -210,13 +210,13 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
     uint16_t* const cand2 = cand_both + NCAND;                        // ... and the even-position test
     int* const hrow = reinterpret_cast<int*>(cand_both);              // BLUR, after phase 2b: horizontal 7-tap sums of window rows 1 .. HROWS
     __shared__ int2 kl[F_MAXKP];
-    __shared__ uint16_t nzq[FT_W * FT_H / 4];
-    __shared__ int n_cand, n_cand2, n_kept, n_nzq;
+    __shared__ uint16_t corners[FT_W * FT_H];
+    __shared__ int n_cand, n_cand2, n_kept, n_corner;
     const int f = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const uint8_t* I = img + (size_t)f * frame_stride;
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
     ORB_CLK_BEGIN();
-    if (tid == 0) { n_cand = 0; n_cand2 = 0; n_kept = 0; n_nzq = 0; }
+    if (tid == 0) { n_cand = 0; n_cand2 = 0; n_kept = 0; n_corner = 0; }
     for (int e = tid; e < SCH * SCP / 16; e += 256) reinterpret_cast<uint4*>(sc)[e] = make_uint4(0u, 0u, 0u, 0u);
     {   // window rows y0 - 4 .. y0 + FT_H + 3, columns x0 - 16 .. x0 + 79: six 16-byte pieces per row, one per thread
         static_assert(FTH * (FTW / 16) <= 256, "one 128-bit load per thread");
@@ -321,32 +321,26 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
         const int pc = cand2[c], p = pc & 0xfff;
         const int ry = p / SCP, rx = p % SCP;
         const int m = fast_score_polar(&tile[(ry + 3) * TP + rx + 15], TP, (pc & 0x1000) != 0);
-        if (m > threshold) sc[p + SC_OFF] = (uint8_t)(m - 1);
+        const bool corner = m > threshold;
+        if (corner) sc[p + SC_OFF] = (uint8_t)(m - 1);
+        // the corners of the tile proper (not of its ring) are what phase 3 has to look at: a list, ~3 % of the pixels
+        const unsigned long long bal = __ballot(corner && rx >= 1 && rx <= FT_W && ry >= 1 && ry <= FT_H);
+        if (bal) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&n_corner, __popcll(bal));
+            base = __shfl(base, 0, 64);
+            if ((bal >> lane) & 1ull) corners[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)p;
+        }
     }
     __syncthreads();
     ORB_CLK(2);
-    // Phase 3a: the quads of the tile that hold a corner at all (~13 %) go to a list; phase 3b below runs the 3x3 test on the list
-    // with full wavefronts (run in place, nearly every wavefront pays the whole test for one or two lanes)
     const int lo = border > 3 ? border : 3;
-#pragma unroll
-    for (int i = 0; i < (FT_W * FT_H / 4 + 255) / 256; ++i) {
-        const int qi = tid + 256 * i;
-        bool nz = false;
-        if (qi < FT_W * FT_H / 4) {
+    if (f == 0 && raw_frame0) {                          // parity tests read the raw score map of frame 0
+        for (int qi = tid; qi < FT_W * FT_H / 4; qi += 256) {
             const int ly = qi / (FT_W / 4), lq = qi % (FT_W / 4);
             const int y = y0 + ly, xq = x0 + 4 * lq;
-            if (y < h && xq < wp) {
-                const uint32_t raw4 = *reinterpret_cast<const uint32_t*>(&sc[(ly + 1) * SCP + 4 * lq + 1 + SC_OFF]);   // dword-aligned: four scores in one LDS read
-                if (f == 0 && raw_frame0) *reinterpret_cast<uint32_t*>(raw_frame0 + (size_t)y * wp + xq) = raw4;
-                nz = raw4 != 0u && y >= lo && y < h - lo;
-            }
-        }
-        const unsigned long long bal = __ballot(nz);
-        if (bal) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&n_nzq, __popcll(bal));
-            base = __shfl(base, 0, 64);
-            if (nz) nzq[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)qi;
+            if (y < h && xq < wp)
+                *reinterpret_cast<uint32_t*>(raw_frame0 + (size_t)y * wp + xq) = *reinterpret_cast<const uint32_t*>(&sc[(ly + 1) * SCP + 4 * lq + 1 + SC_OFF]);
         }
     }
     if (BLUR) {
@@ -368,31 +362,19 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
     }
     __syncthreads();
     ORB_CLK(3);
-    // Phase 3b on the last wavefront (the vertical blur pass below occupies the first three): strict 3x3 maximum among the raw
-    // scores + RunByImageBorder for the listed quads
+    // Phase 3 on the last wavefront (the vertical blur pass below occupies the first three): strict 3x3 maximum among the raw scores
+    // + RunByImageBorder, one lane per listed corner, its eight neighbours in eight independent byte reads
     if (tid >= 192) {
-        const int nq = n_nzq;
-        for (int c = tid - 192; c < nq; c += 64) {
-            const int qi = nzq[c];
-            const int ly = qi / (FT_W / 4), lq = qi % (FT_W / 4);
-            const int y = y0 + ly, xq = x0 + 4 * lq;
-            // the 3 x 6 neighbourhood of the quad in nine aligned reads issued together (a chain of byte reads behind short-circuit
-            // tests is eight LDS latencies in a row): row r as bytes x - 1 .. x + 4 of a 64-bit value
-            const uint32_t* cq = reinterpret_cast<const uint32_t*>(&sc[(ly + 1) * SCP + 4 * lq + 1 + SC_OFF]);
-            const uint32_t raw4 = cq[0];
-            auto row6 = [](uint32_t L, uint32_t C, uint32_t R) { return (unsigned long long)(L >> 24) | ((unsigned long long)C << 8) | ((unsigned long long)(R & 0xffu) << 40); };
-            const unsigned long long ra = row6(cq[-SCP / 4 - 1], cq[-SCP / 4], cq[-SCP / 4 + 1]);
-            const unsigned long long rc = row6(cq[-1], raw4, cq[1]);
-            const unsigned long long rb = row6(cq[SCP / 4 - 1], cq[SCP / 4], cq[SCP / 4 + 1]);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int s = (int)((raw4 >> (8 * b)) & 0xffu);
-                const int x = xq + b;
-                auto byte = [](unsigned long long v, int i) { return (int)((v >> (8 * i)) & 0xffu); };
-                const int m = max(max(max(byte(ra, b), byte(ra, b + 1)), max(byte(ra, b + 2), byte(rc, b))),
-                                  max(max(byte(rc, b + 2), byte(rb, b)), max(byte(rb, b + 1), byte(rb, b + 2))));
-                if (s > m && x >= lo && x < w - lo) kl[atomicAdd(&n_kept, 1)] = make_int2(x | (y << 16), s);     // s > m >= 0: a corner, strictly above its 8 neighbours
-            }
+        const int ncn = n_corner;
+        for (int c = tid - 192; c < ncn; c += 64) {
+            const int p = corners[c];
+            const int ry = p / SCP, rx = p % SCP;
+            const int x = x0 - 1 + rx, y = y0 - 1 + ry;
+            const uint8_t* q = &sc[p + SC_OFF];
+            const int s = q[0];
+            const int m = max(max(max((int)q[-SCP - 1], (int)q[-SCP]), max((int)q[-SCP + 1], (int)q[-1])),
+                              max(max((int)q[1], (int)q[SCP - 1]), max((int)q[SCP], (int)q[SCP + 1])));
+            if (s > m && x >= lo && x < w - lo && y >= lo && y < h - lo) kl[atomicAdd(&n_kept, 1)] = make_int2(x | (y << 16), s);
         }
     }
     if (BLUR) {
@@ -732,6 +714,8 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
         __syncthreads();
         ORB_CLK(13);
         // ---- keep the N first of the total order; rank = output position
+        // (A counting sort by radius that leaves only candidates of equal radius to compare was tried: its six barriers and two atomic
+        // passes cost more than this loop, 34 k cycles against 18 k per frame.)
         for (int i = tid; i < M; i += SEL_T) {
             int rank = 0;
             const unsigned long long ki = key[i];
