@@ -1,6 +1,7 @@
 // mage_common.h -- status plumbing and small RAII helpers shared by the host side of libmageslam_hip.so
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <cstdarg>
 #include <cstdio>
@@ -46,6 +47,23 @@ inline mage_status fail(mage_status s, const char* fmt, ...)
 // Makes `device` the calling thread's current HIP device for the lifetime of the object and puts the caller's device back
 // afterwards: a host process that drives several GPUs from one thread (or keeps its own HIP work on another device) must not
 // find its current device changed by a library call or by a handle's destructor.
+// Wait for everything queued on `st` so far.  hipStreamSynchronize may put the thread to sleep and costs tens of microseconds
+// to wake; a frame's worth of front-end work is ~50 us, so the wait first polls an event for a short while (the BA scalar
+// read-back does the same) and only then blocks.
+inline hipError_t wait_stream_briefly_spinning(hipStream_t st, hipEvent_t ev, int spin_us = 300)
+{
+    hipError_t e = hipEventRecord(ev, st);
+    if (e != hipSuccess) return e;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        e = hipEventQuery(ev);
+        if (e == hipSuccess) return hipSuccess;
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+    }
+    return hipEventSynchronize(ev);
+}
+
 struct DeviceScope {
     int prev = -1;
     bool changed = false;

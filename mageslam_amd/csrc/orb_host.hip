@@ -329,7 +329,7 @@ MAGE_EXPORT mage_status mage_orb_detect_batch(mage_orb* h, const uint8_t* images
             MAGE_HIP(hipMemcpyAsync(keypoints, h->d_kp.p, sizeof(mage_keypoint) * (size_t)n_frames * capacity, hipMemcpyDeviceToHost, h->stream));
             MAGE_HIP(hipMemcpyAsync(descriptors32, h->d_desc.p, (size_t)n_frames * capacity * 32, hipMemcpyDeviceToHost, h->stream));
         }
-        MAGE_HIP(hipStreamSynchronize(h->stream));
+        MAGE_HIP(wait_stream_briefly_spinning(h->stream, h->ev[5]));
         return collect_profile(h);
     });
 }
@@ -350,7 +350,7 @@ MAGE_EXPORT mage_status mage_orb_detect_batch_device(mage_orb* h, const uint8_t*
         if (stride < width) return fail(MAGE_ERR_INVALID_ARGUMENT, "stride < width");
         MAGE_DEVICE_SCOPE(h->device);
         MAGE_TRY(run_batch(h, images_device, n_frames, width, height, stride, frame_stride, capacity));
-        MAGE_HIP(hipStreamSynchronize(h->stream));
+        MAGE_HIP(wait_stream_briefly_spinning(h->stream, h->ev[5]));
         *keypoints_device = h->d_kp.p; *descriptors_device = h->d_desc.p; *counts_device = h->d_count.p;
         return n_frames > 0 ? collect_profile(h) : MAGE_OK;
     });
@@ -445,7 +445,7 @@ struct mage_matcher {
     DevBuf<int> d_cA, d_cB, d_scratch, d_counts, d_done;       // d_done: per-pair arrival counters of k_match_rows, zero between launches
     size_t done_zeroed = 0;
     DevBuf<mage_dmatch> d_out;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e_wait = nullptr;
     double last_ms = 0;
     ~mage_matcher()
     {
@@ -453,6 +453,7 @@ struct mage_matcher {
         if (stream) (void)hipStreamSynchronize(stream);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
+        if (e_wait) (void)hipEventDestroy(e_wait);
         cached_stream_release(device, stream);
     }
 };
@@ -483,7 +484,7 @@ MAGE_EXPORT mage_status mage_matcher_create(int device, mage_matcher** out)
         h->device = dev;
         MAGE_DEVICE_SCOPE(dev);
         MAGE_TRY(cached_stream_acquire(dev, &h->stream));
-        MAGE_HIP(hipEventCreate(&h->e0)); MAGE_HIP(hipEventCreate(&h->e1));
+        MAGE_HIP(hipEventCreate(&h->e0)); MAGE_HIP(hipEventCreate(&h->e1)); MAGE_HIP(hipEventCreateWithFlags(&h->e_wait, hipEventDisableTiming));
         match_init_device();
         *out = h.release();
         return MAGE_OK;
@@ -538,7 +539,7 @@ MAGE_EXPORT mage_status mage_match_bf_batch(mage_matcher* h, int n_pairs, const 
         MAGE_TRY(run_match(h, n_pairs, h->d_A.p, h->d_cA.p, capA, h->d_B.p, h->d_cB.p, capB, max_dist, min_diff, cap_out));
         MAGE_HIP(hipMemcpyAsync(counts, h->d_counts.p, sizeof(int) * (size_t)n_pairs, hipMemcpyDeviceToHost, st));
         if (cap_out) MAGE_HIP(hipMemcpyAsync(out, h->d_out.p, sizeof(mage_dmatch) * (size_t)n_pairs * cap_out, hipMemcpyDeviceToHost, st));
-        MAGE_HIP(hipStreamSynchronize(st));
+        MAGE_HIP(wait_stream_briefly_spinning(st, h->e_wait));
         float ms = 0;
         MAGE_HIP(hipEventElapsedTime(&ms, h->e0, h->e1));
         h->last_ms = ms;
@@ -588,7 +589,7 @@ MAGE_EXPORT mage_status mage_match_bf_batch_device(mage_matcher* h, int n_pairs,
         if (!h || !descA_dev || !descB_dev || !countsA_dev || !countsB_dev || !out_dev || !counts_dev) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
         MAGE_DEVICE_SCOPE(h->device);
         MAGE_TRY(run_match(h, n_pairs, descA_dev, countsA_dev, capA, descB_dev, countsB_dev, capB, max_dist, min_diff, cap_out));
-        MAGE_HIP(hipStreamSynchronize(h->stream));
+        MAGE_HIP(wait_stream_briefly_spinning(h->stream, h->e_wait));
         if (n_pairs > 0) { float ms = 0; MAGE_HIP(hipEventElapsedTime(&ms, h->e0, h->e1)); h->last_ms = ms; }
         *out_dev = h->d_out.p; *counts_dev = h->d_counts.p;
         return MAGE_OK;
