@@ -445,6 +445,11 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block(
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0;
+    // A diagonal block's contributions are the camera's own slots (a, a): the same pass over W also gives the camera's part of the
+    // reduced right-hand side, b_s = b_c - sum W D^-1 b_p (k_schur_rhs read every W block a second time for it)
+    const int2 ij = v.blk_ij[b];
+    const bool diag = ij.x == ij.y;
+    double yv[6] = { 0, 0, 0, 0, 0, 0 };
     const int c_end = v.blk_ptr[b + 1];
     double2* stg = reinterpret_cast<double2*>(red[wave]);                 // [piece 0..8][block 0..127], then 128 slot indices
     int* sl = reinterpret_cast<int*>(red[wave]) + 128 * 36;
@@ -453,7 +458,8 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block(
         const bool live = c < c_end;
         const int2 sab = live ? v.con[c] : make_int2(0, 0);               // idle lanes read slot 0 (valid memory) and add nothing
         // 144-byte W blocks and 48-byte D^-1 records are 16-byte aligned: 128-bit loads (21 per contribution instead of 42)
-        const double2* D2 = reinterpret_cast<const double2*>(v.Dinv + (size_t)v.w_lm[sab.x] * 6);
+        const int lm = v.w_lm[sab.x];
+        const double2* D2 = reinterpret_cast<const double2*>(v.Dinv + (size_t)lm * 6);
         const double2 da = D2[0], db = D2[1], dc = D2[2];
         const double d00 = da.x, d01 = da.y, d02 = db.x, d11 = db.y, d12 = dc.x, d22 = dc.y;
         double wa[18], wb[18];
@@ -483,6 +489,13 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block(
             for (int k = 0; k < 9; ++k) { const double2 t = Wb2[k]; wb[2 * k] = t.x; wb[2 * k + 1] = t.y; }
         }
         if (!live) continue;
+        if (diag) {
+            const double2* db2 = reinterpret_cast<const double2*>(v.db + (size_t)lm * 4);
+            const double2 dba = db2[0];
+            const double e0 = dba.x, e1 = dba.y, e2 = db2[1].x;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) yv[r] += wa[r * 3] * e0 + wa[r * 3 + 1] * e1 + wa[r * 3 + 2] * e2;
+        }
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const double a0 = wa[r * 3], a1 = wa[r * 3 + 1], a2 = wa[r * 3 + 2];
@@ -501,7 +514,6 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int2 ij = v.blk_ij[b];
     // lane k < 36 writes entry (r, c) of the block
     double val = 0;
     if (lane < 36) {
@@ -512,12 +524,33 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block(
         }
         val = (s0 + s1) + (s2 + s3);
     }
+    double yval = 0;
+    if (diag) {                                           // uniform per workgroup
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < 6; ++k) R[lane * 7 + k] = yv[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 6) {
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int j = 0; j < 64; j += 4) { s0 += R[(j + 0) * 7 + lane]; s1 += R[(j + 1) * 7 + lane]; s2 += R[(j + 2) * 7 + lane]; s3 += R[(j + 3) * 7 + lane]; }
+            yval = (s0 + s1) + (s2 + s3);
+        }
+    }
     if (SPLIT) {
+        __shared__ double ypart[4][6];
         if (lane < 36) part[wave][lane] = val;
+        if (diag && lane < 6) ypart[wave][lane] = yval;
         __syncthreads();
         if (wave != 0) return;
         if (lane < 36) val = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        if (diag && lane < 6) yval = ((ypart[0][lane] + ypart[1][lane]) + ypart[2][lane]) + ypart[3][lane];
     }
+    if (diag && lane < 6) v.y[ij.x * 6 + lane] = v.bc[(size_t)ij.x * 6 + lane] - yval;
     if (lane < 36) {
         const int r = lane / 6, c = lane % 6;
         if (ij.x == ij.y) {
@@ -1551,7 +1584,10 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st)
     const int n = v.n_fc * 6;
     if (v.n_pad >= 1024) hipLaunchKernelGGL(k_zero_lower, dim3(std::max(1, v.n_pad / 2048), v.n_pad), dim3(256), 0, st, v.S, v.n_pad, 128);
     else (void)hipMemsetAsync(v.S, 0, (size_t)v.n_pad * v.n_pad * sizeof(double), st);
+    // the diagonal blocks of k_schur_block also write their camera's reduced rhs; a camera without a block (no free landmark) keeps b_c
+    const bool rhs_in_blocks = v.points_free && v.n_blk > 0;
     (void)hipMemsetAsync(v.y, 0, (size_t)v.n_pad * sizeof(double), st);
+    if (rhs_in_blocks && n > 0) (void)hipMemcpyAsync(v.y, v.bc, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
     if (v.n_pad > n) hipLaunchKernelGGL(k_pad_diag, dim3(cdiv(v.n_pad - n, 128)), dim3(128), 0, st, v.S, n, v.n_pad);
     if (v.points_free && v.n_lm > 0) hipLaunchKernelGGL(k_lm_invert, dim3(cdiv(v.n_lm, 256)), dim3(256), 0, st, v, lambda);
     if (v.n_blk > 0) {
@@ -1565,7 +1601,7 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st)
         }
     }
     tether_launch_schur(v, st);
-    if (v.n_fc > 0) {
+    if (v.n_fc > 0 && !rhs_in_blocks) {
         if (v.n_fc <= SPLIT_CAMERAS_BELOW) hipLaunchKernelGGL(k_schur_rhs<true>, dim3(v.n_fc), dim3(256), 0, st, v);
         else hipLaunchKernelGGL(k_schur_rhs<false>, dim3(xcd_camera_grid(v.n_fc)), dim3(256), 0, st, v);
     }
