@@ -97,6 +97,23 @@ def test_medium_reduced_systems_match_oracle(n_cams):
     _compare_with_oracle(s, False, [([1.8], 25.0), ([0.9], 16.0), ([0.9], 9.0)])
 
 
+def test_large_path_variants_match_oracle():
+    """The large-problem launch sequence in the shapes that take its alternative kernels: points fixed with more cameras than the
+    one-launch pose solver takes (camera side of the fused linearisation alone, k_schur_rhs with no W block at all), a landmark
+    seen twice by one camera (shared W slots: the three separate linearisation kernels), and tethers on a system beyond the small
+    path (tether kernels after the separate linearisation)."""
+    s = scene.make_scene(n_cams=80, n_pts=600, n_obs=6000, seed=0x5EED0B01, fixed=(), outlier_frac=0.02)
+    _compare_with_oracle(s, True, [([1.8, 1.8], 25.0), ([0.9], 9.0)])
+    s = scene.make_scene(n_cams=40, n_pts=500, n_obs=5000, seed=0x5EED0B02, outlier_frac=0.02)
+    s.obs_cam = s.obs_cam.copy()
+    dup = np.nonzero(s.obs_pt[:-1] == s.obs_pt[1:])[0][::9]
+    s.obs_cam[dup + 1] = s.obs_cam[dup]                       # the same (camera, point) twice
+    _compare_with_oracle(s, False, [([1.8], 30.0), ([0.9, 0.9], 12.0)], rtol=1e-8)
+    s = scene.make_scene(n_cams=36, n_pts=400, n_obs=3600, seed=0x5EED0B03, outlier_frac=0.0)
+    s.tethers = scene.make_tethers(s, n_dist=3, n_rot=2, n_xf=3, seed=0x7E7E0B03)
+    _compare_with_oracle(s, False, [([1.8], 1e30), ([0.9], 1e30)], rtol=1e-6)
+
+
 def test_concurrent_handles_on_separate_threads():
     """SURVEY 8b threading contract: every BundlerLib instance is thread-confined, several run concurrently on different
     threads (mapping, loop closure, tracking).  Four handles, each on its own thread and HIP stream, interleaved on one
