@@ -744,54 +744,66 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
 // solve, ~40 us for any n <= 128) becomes ~3 us per 16 columns.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_small_solve(const double* __restrict__ S, const double* __restrict__ y, double* __restrict__ x, int n, int ld,
-                                                     double* __restrict__ Linv_ws, double* __restrict__ ok, double* __restrict__ stall)
+                                                     double* __restrict__ Linv_ws, double* __restrict__ ok, double* __restrict__ stall, int inv_in_lds)
 {
     extern __shared__ double sm[];
-    double* A = sm;
-    double* Li = sm + TILE * LDC;
-    __shared__ double rhs[TILE], xc[NB];
     const int tid = threadIdx.x;
     const int nblk = (n + NB - 1) / NB, np = nblk * NB;          // S carries the identity beyond n (it is padded to a whole tile)
-    for (int e = tid; e < np * np; e += 256) { const int c = e / np, r = e % np; A[c * LDC + r] = S[(size_t)c * ld + r]; }
+    // LDS: the leading np columns of the tile, the two block inverses the factorisation juggles and -- when it fits (np <= 112) --
+    // all block inverses, so that the substitutions never leave LDS (from the global workspace every block step paid an L2 round trip)
+    double* A = sm;
+    double* Li = sm + np * LDC;
+    double* Linv = inv_in_lds ? Li + 2 * NB * NB : Linv_ws;
+    __shared__ double rhs[TILE], xc[NB];
+    {   // column-major copy, two doubles per load (np is a multiple of 16), eight loads in flight per thread
+        const int half = np / 2, total = np * half;
+        for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < total) { const int c = e / half, r2 = e - c * half; v[u] = *reinterpret_cast<const double2*>(S + (size_t)c * ld + 2 * r2); } }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < total) { const int c = e / half, r2 = e - c * half; *reinterpret_cast<double2*>(A + c * LDC + 2 * r2) = v[u]; } }
+        }
+    }
     for (int i = tid; i < np; i += 256) rhs[i] = y[i];
     __syncthreads();
-    const bool failed = potrf_tile_lds<true>(A, Li, Linv_ws, tid, nblk);
+    const bool failed = potrf_tile_lds<true>(A, Li, Linv, tid, nblk);
     __threadfence_block();
     __syncthreads();
-    // forward substitution L z = rhs
+    // forward substitution L z = rhs (four partial sums per product: a dependent f64 FMA costs ~25 cycles on a lone wavefront)
     for (int cb = 0; cb < nblk; ++cb) {
         if (tid < NB) {
-            double acc = 0;
+            double p[4] = { 0, 0, 0, 0 };
 #pragma unroll
-            for (int q = 0; q < NB; ++q) acc = __builtin_fma(Linv_ws[cb * NB * NB + tid * NB + q], rhs[cb * NB + q], acc);
-            xc[tid] = acc;
+            for (int q = 0; q < NB; ++q) p[q & 3] = __builtin_fma(Linv[cb * NB * NB + tid * NB + q], rhs[cb * NB + q], p[q & 3]);
+            xc[tid] = (p[0] + p[1]) + (p[2] + p[3]);
         }
         __syncthreads();
         if (tid < NB) rhs[cb * NB + tid] = xc[tid];
         const int r = (cb + 1) * NB + tid;
         if (r < np) {
-            double acc = rhs[r];
+            double p[4] = { rhs[r], 0, 0, 0 };
 #pragma unroll
-            for (int q = 0; q < NB; ++q) acc = __builtin_fma(-A[(cb * NB + q) * LDC + r], xc[q], acc);
-            rhs[r] = acc;
+            for (int q = 0; q < NB; ++q) p[q & 3] = __builtin_fma(-A[(cb * NB + q) * LDC + r], xc[q], p[q & 3]);
+            rhs[r] = (p[0] + p[1]) + (p[2] + p[3]);
         }
         __syncthreads();
     }
     // backward substitution L^T x = z
     for (int cb = nblk - 1; cb >= 0; --cb) {
         if (tid < NB) {
-            double acc = 0;
+            double p[4] = { 0, 0, 0, 0 };
 #pragma unroll
-            for (int q = 0; q < NB; ++q) acc = __builtin_fma(Linv_ws[cb * NB * NB + q * NB + tid], rhs[cb * NB + q], acc);
-            xc[tid] = acc;
+            for (int q = 0; q < NB; ++q) p[q & 3] = __builtin_fma(Linv[cb * NB * NB + q * NB + tid], rhs[cb * NB + q], p[q & 3]);
+            xc[tid] = (p[0] + p[1]) + (p[2] + p[3]);
         }
         __syncthreads();
         if (tid < NB) rhs[cb * NB + tid] = xc[tid];
         if (tid < cb * NB) {
-            double acc = rhs[tid];
+            double p[4] = { rhs[tid], 0, 0, 0 };
 #pragma unroll
-            for (int q = 0; q < NB; ++q) acc = __builtin_fma(-A[tid * LDC + cb * NB + q], xc[q], acc);
-            rhs[tid] = acc;
+            for (int q = 0; q < NB; ++q) p[q & 3] = __builtin_fma(-A[tid * LDC + cb * NB + q], xc[q], p[q & 3]);
+            rhs[tid] = (p[0] + p[1]) + (p[2] + p[3]);
         }
         __syncthreads();
     }
@@ -825,8 +837,11 @@ void chol_init_device()
 
 void chol_small_solve(const double* S, const double* y, double* x, int n, int ld, double* Linv_ws, double* ok, double* stall, hipStream_t st)
 {
-    const size_t lds_diag = ((size_t)TILE * LDC + 2 * NB * NB) * sizeof(double);
-    hipLaunchKernelGGL(k_small_solve, dim3(1), dim3(256), lds_diag, st, S, y, x, n, ld, Linv_ws, ok, stall);
+    const int nblk = (n + NB - 1) / NB, np = nblk * NB;
+    const size_t with_inv = ((size_t)np * LDC + 2 * NB * NB + (size_t)nblk * NB * NB) * sizeof(double);
+    const bool inv_in_lds = with_inv + 4096 <= 160 * 1024;          // + the kernel's static LDS
+    const size_t lds = inv_in_lds ? with_inv : ((size_t)np * LDC + 2 * NB * NB) * sizeof(double);
+    hipLaunchKernelGGL(k_small_solve, dim3(1), dim3(256), lds, st, S, y, x, n, ld, Linv_ws, ok, stall, inv_in_lds ? 1 : 0);
 }
 
 // Right-looking factorisation.  Step k = one k_trsm_panel launch + one k_syrk_update launch; the diagonal
