@@ -65,11 +65,11 @@ def _compare_with_oracle(s, points_fixed, calls, rtol=1e-9):
         if np.isnan(ro):
             assert np.isnan(rg)
         else:
-            assert abs(rg - ro) <= 1e-6 * abs(ro)
+            assert abs(rg - ro) <= 1e-6 * abs(ro) + 1e-12             # (an exact fit leaves a mean square error of ~1e-16: rounding noise)
         tg, to = g.trace(), o.trace()
         assert [(t["code"], t["trials"]) for t in tg] == [(t["code"], t["trials"]) for t in to]
         for a, b in zip(tg, to):
-            assert abs(a["chi_after"] - b["chi_after"]) <= rtol * max(b["chi_after"], 1e-300)
+            assert abs(a["chi_after"] - b["chi_after"]) <= rtol * b["chi_after"] + 1e-12
             assert abs(a["lam"] - b["lam"]) <= rtol * b["lam"]
     np.testing.assert_allclose(g.poses_f64(), o.poses_f64(), rtol=rtol, atol=rtol)
     np.testing.assert_allclose(g.points_f64(), o.points_f64(), rtol=rtol, atol=rtol)
