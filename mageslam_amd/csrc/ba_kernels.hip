@@ -365,8 +365,20 @@ __global__ __launch_bounds__(256) void k_reduce_max(const double* __restrict__ i
 // ---------------------------------------------------------------------------------------------
 // (V + lambda I)^-1 in the cofactor form Eigen uses for fixed 3x3 (the inverse of a symmetric matrix
 // computed that way is bitwise symmetric, so 6 values are stored), and D^-1 b_p.
-__global__ __launch_bounds__(256) void k_lm_invert(BaDeviceView v, double lambda)
+// Blocks [0, nb_lm): (V_l + lambda I)^-1 and D^-1 b_p per landmark.  The blocks behind them prepare the reduced system's small
+// arrays in the same launch (they were a memset, a copy and a kernel of their own, ~4 us each on the stream): y = b_c (the diagonal
+// blocks of k_schur_block subtract the landmark part; y_from_bc = 0: plain zero) with a zero tail, and the identity on the padded
+// tail of S's diagonal so that the padded system stays SPD.
+__global__ __launch_bounds__(256) void k_lm_invert(BaDeviceView v, double lambda, int nb_lm, int y_from_bc)
 {
+    if ((int)blockIdx.x >= nb_lm) {
+        const int n = v.n_fc * 6;
+        for (int i = ((int)blockIdx.x - nb_lm) * 256 + threadIdx.x; i < v.n_pad; i += ((int)gridDim.x - nb_lm) * 256) {
+            v.y[i] = (i < n && y_from_bc) ? v.bc[i] : 0.0;
+            if (i >= n) v.S[(size_t)i * v.n_pad + i] = 1.0;
+        }
+        return;
+    }
     const int l = blockIdx.x * 256 + threadIdx.x;
     if (l >= v.n_lm) return;
     const double* Vl = v.V + (size_t)l * 6;
@@ -401,12 +413,6 @@ __global__ __launch_bounds__(256) void k_zero_lower(double* __restrict__ S, int 
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) col[i] = make_double2(0.0, 0.0);
 }
 
-// identity on the padded tail of the diagonal so the padded system stays SPD
-__global__ void k_pad_diag(double* S, int n, int n_pad)
-{
-    const int i = n + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_pad) S[(size_t)i * n_pad + i] = 1.0;
-}
 
 // One wavefront per non-empty upper block (i <= j).  Workgroups go to the eight XCDs round-robin and every XCD has its own
 // L2, so the slot -> block table (blk_order, ba_host.hip) hands the workgroups of XCD x a CONTIGUOUS run of block rows (runs cut
@@ -1581,15 +1587,14 @@ void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st)
 
 void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st)
 {
-    const int n = v.n_fc * 6;
     if (v.n_pad >= 1024) hipLaunchKernelGGL(k_zero_lower, dim3(std::max(1, v.n_pad / 2048), v.n_pad), dim3(256), 0, st, v.S, v.n_pad, 128);
     else (void)hipMemsetAsync(v.S, 0, (size_t)v.n_pad * v.n_pad * sizeof(double), st);
     // the diagonal blocks of k_schur_block also write their camera's reduced rhs; a camera without a block (no free landmark) keeps b_c
     const bool rhs_in_blocks = v.points_free && v.n_blk > 0;
-    (void)hipMemsetAsync(v.y, 0, (size_t)v.n_pad * sizeof(double), st);
-    if (rhs_in_blocks && n > 0) (void)hipMemcpyAsync(v.y, v.bc, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
-    if (v.n_pad > n) hipLaunchKernelGGL(k_pad_diag, dim3(cdiv(v.n_pad - n, 128)), dim3(128), 0, st, v.S, n, v.n_pad);
-    if (v.points_free && v.n_lm > 0) hipLaunchKernelGGL(k_lm_invert, dim3(cdiv(v.n_lm, 256)), dim3(256), 0, st, v, lambda);
+    {
+        const int nb_lm = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm, 256) : 0;
+        hipLaunchKernelGGL(k_lm_invert, dim3(nb_lm + std::max(1, std::min(8, cdiv(v.n_pad, 256)))), dim3(256), 0, st, v, lambda, nb_lm, rhs_in_blocks ? 1 : 0);
+    }
     if (v.n_blk > 0) {
         static const bool gather = std::getenv("MAGE_BA_SCHUR_GATHER") != nullptr;      // the lane-per-contribution loads, for comparison
         if (v.n_blk <= SPLIT_BLOCKS_BELOW) {
