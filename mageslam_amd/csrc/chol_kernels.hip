@@ -33,6 +33,7 @@ constexpr int NB = 16;               // inner block (one MFMA tile)
 constexpr int NBLK = TILE / NB;      // 8
 constexpr int LDC = TILE + 16;       // LDS column pitch (doubles): consecutive k columns land 32 banks apart
 typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned long long X_SENTINEL = 0x7FF4DEADBEEF0001ull;   // "not published yet" in x (k_bsolve_persist): a signalling-NaN pattern no computation produces
 
 __device__ __forceinline__ double readlane_d(double v, int lane)
 {
@@ -380,13 +381,17 @@ __device__ __forceinline__ void store_tile_lower(double* __restrict__ T, const d
 // factors it while wavefronts 1-3 apply the rest of the trailing update (look-ahead inside the tile).
 // Stand-alone form (first tile); later tiles are factored inside k_syrk_update (see there).
 // ---------------------------------------------------------------------------------------------
+// It also opens the solve: ok = 1, stall = 0, and x pre-filled with the sentinel the backward substitution polls for (they were
+// three launches of their own in front of this one).
 __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int ld, int k, double* __restrict__ Linv_k,
-                                                    double* __restrict__ ok)
+                                                    double* __restrict__ ok, double* __restrict__ stall, unsigned long long* __restrict__ x_fill, int n_fill)
 {
     extern __shared__ double sm[];
     double* A = sm;                       // column-major: A[c * LDC + r]
     double* Li = sm + TILE * LDC;         // 2 x (16 x 16): inverse of the current / next diagonal block
     const int tid = threadIdx.x;
+    if (tid == 0) { *ok = 1.0; *stall = 0.0; }
+    for (int i = tid; i < n_fill; i += 256) x_fill[i] = X_SENTINEL;
     double* T = S + (size_t)(k * TILE) * ld + (size_t)k * TILE;
     load_tile<LDC>(A, T, ld, tid);
     __syncthreads();
@@ -656,13 +661,7 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
 // and the dispatch order is then what guarantees progress.  Polls are bounded; a time-out sets *stall, which the host turns
 // into MAGE_ERR_DEVICE (it is never folded into the "matrix not positive definite" outcome, which steers the LM loop).
 // ---------------------------------------------------------------------------------------------
-constexpr unsigned long long X_SENTINEL = 0x7FF4DEADBEEF0001ull;
 
-__global__ void k_fill_u64(unsigned long long* __restrict__ p, int n, unsigned long long v)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
 
 __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict__ S, const double* __restrict__ y, double* __restrict__ x,
                                                         int ld, int nt, const double* __restrict__ Linv, double* __restrict__ stall, long long* __restrict__ dbg)
@@ -811,7 +810,6 @@ __global__ __launch_bounds__(256) void k_small_solve(const double* __restrict__ 
     if (tid == 0) { *ok = failed ? 0.0 : 1.0; *stall = 0.0; }
 }
 
-__global__ void k_set_scalar(double* p, double v) { *p = v; }
 
 }  // namespace
 
@@ -854,10 +852,7 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
     const size_t lds_panel = (size_t)TILE * (TILE + 2) * sizeof(double);
     const size_t linv_stride = (size_t)NBLK * NB * NB;
     double* stall = ws.stall ? ws.stall : ok + 1;     // callers without a slot of their own pass a two-element ok
-    hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, st, ok, 1.0);
-    hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, st, stall, 0.0);
-    hipLaunchKernelGGL(k_fill_u64, dim3((n_pad + 255) / 256), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(x), n_pad, X_SENTINEL);
-    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), lds_diag, st, S, n_pad, 0, ws.Linv, ok);
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), lds_diag, st, S, n_pad, 0, ws.Linv, ok, stall, reinterpret_cast<unsigned long long*>(x), n_pad);
     for (int k = 0; k < nt; ++k) {
         const int m = nt - k - 1;             // tile rows below panel k
         hipLaunchKernelGGL(k_trsm_panel, dim3(m * NBLK + 1), dim3(64), 0, st, S, y, n_pad, k, nt, ws.Linv + (size_t)k * linv_stride, ws.sync, 0);
