@@ -614,15 +614,19 @@ __global__ __launch_bounds__(256) void k_schur_rhs(BaDeviceView v)
 // ---------------------------------------------------------------------------------------------
 // back substitution, state update, scale = sum x (lambda x + b)
 // ---------------------------------------------------------------------------------------------
+// BACKSUB_LPL lanes per landmark: lane `sub` takes the landmark's W blocks s0 + sub, s0 + sub + 8, ... (a landmark has ~10 of them and a
+// thread that walks them alone waits out ten dependent 144-byte reads with 1.5 workgroups per compute unit to hide them), the three
+// sums are added over the lanes in a fixed tree, lane 0 of the group finishes the landmark.
+constexpr int BACKSUB_LPL = 8;
 __global__ __launch_bounds__(256) void k_backsub(BaDeviceView v, double lambda)
 {
     __shared__ double sm[4];
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int gl = blockIdx.x * 256 + threadIdx.x, l = gl / BACKSUB_LPL, sub = gl % BACKSUB_LPL;
     double sc = 0;
+    double c0 = 0, c1 = 0, c2 = 0;
     if (l < v.n_lm) {
-        const double b0 = v.bp[(size_t)l * 4], b1 = v.bp[(size_t)l * 4 + 1], b2 = v.bp[(size_t)l * 4 + 2];
-        double c0 = b0, c1 = b1, c2 = b2;
-        for (int s = v.lm_wptr[l]; s < v.lm_wptr[l + 1]; ++s) {
+        const int s1 = v.lm_wptr[l + 1];
+        for (int s = v.lm_wptr[l] + sub; s < s1; s += BACKSUB_LPL) {
             const double2* W2 = reinterpret_cast<const double2*>(v.W + (size_t)s * 18);
             const double2* x2 = reinterpret_cast<const double2*>(v.xc + (size_t)v.w_hc[s] * 6);
             double W[18], x[6];
@@ -636,6 +640,12 @@ __global__ __launch_bounds__(256) void k_backsub(BaDeviceView v, double lambda)
                 c0 += W[r * 3] * mx; c1 += W[r * 3 + 1] * mx; c2 += W[r * 3 + 2] * mx;
             }
         }
+    }
+#pragma unroll
+    for (int m = 1; m < BACKSUB_LPL; m <<= 1) { c0 += __shfl_xor(c0, m, 64); c1 += __shfl_xor(c1, m, 64); c2 += __shfl_xor(c2, m, 64); }
+    if (l < v.n_lm && sub == 0) {
+        const double b0 = v.bp[(size_t)l * 4], b1 = v.bp[(size_t)l * 4 + 1], b2 = v.bp[(size_t)l * 4 + 2];
+        c0 += b0; c1 += b1; c2 += b2;
         const double* D = v.Dinv + (size_t)l * 6;
         const double x0 = D[0] * c0 + D[1] * c1 + D[2] * c2;
         const double x1 = D[1] * c0 + D[3] * c1 + D[4] * c2;
@@ -1616,7 +1626,7 @@ void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st)
 {
     int nb_l = 0;
     if (v.points_free && v.n_lm > 0) {
-        nb_l = cdiv(v.n_lm, 256);
+        nb_l = cdiv(v.n_lm * BACKSUB_LPL, 256);
         hipLaunchKernelGGL(k_backsub, dim3(nb_l), dim3(256), 0, st, v, lambda);
     }
     int nb_c = 0;
