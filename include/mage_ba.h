@@ -111,6 +111,38 @@ mage_status mage_ba_import_poses_device(mage_ba* h, const double* block_device, 
 /* Blocks until everything enqueued on the handle's stream has finished (the handle's stream is private). */
 mage_status mage_ba_synchronize(mage_ba* h);
 
+/* ---- Landmark-sharded solve of ONE map on several GPUs (SURVEY 8e "exact algorithm"; no counterpart in the reference, whose
+ * optimiser is single-threaded g2o behind StepOptimizer::Step, BundlerLib.cpp:132-149).
+ * Every rank creates a handle, gives it ALL cameras (same order, same fixed flags, same poses) and only ITS OWN share of the map
+ * points with every observation of those points (and any share of the tether edges: each edge on exactly one rank), then calls
+ * mage_ba_set_landmark_shard before the first step.  mage_ba_step must then be called by all ranks together with the same arguments.
+ * Per Levenberg-Marquardt trial a rank builds the camera system of its own landmarks -- U_r, b_r and -sum W V^-1 W^T over its
+ * landmarks; the damping of the camera blocks is added by rank 0 alone -- and the ranks ADD them: one call of `allreduce` on the
+ * lower tiles of S packed behind each other with the right-hand side at the end (6n(6n+128)/2 + 6n doubles for n free cameras; 148 MB at
+ * 1 000 poses).  Every rank then factorises the same matrix (bit-identical results on identical devices), moves the cameras, and
+ * back-substitutes its own landmarks.  Besides that call a trial exchanges two scalars (chi^2 of the trial, the gain denominator), an
+ * iteration one (chi^2) plus, when lambda is seeded, the diagonal of U (6n doubles) and its maximum, and a step the three sums of
+ * the outlier pass and one flag: a step's mean error is the map's, the outlier list a rank gets holds its own observations, and
+ * the optimiser re-initialises on all ranks when any rank removed one (BundlerLib.cpp:135-138).  Every free camera is part of
+ * the system on every rank whether or not the rank (or anyone) observes it; a map without a free camera is refused
+ * (MAGE_ERR_UNSUPPORTED: its landmarks are independent, run them unsharded).  The small-problem and pose-only fast paths are off.
+ *
+ * allreduce(user, buffer, count, op, stream): in-place all-reduce over the ranks of `count` doubles at DEVICE address `buffer`
+ * (op 0: sum, 1: max), ordered after the work already enqueued on the HIP stream `stream` and before any enqueued later --
+ * ncclAllReduce(buffer, buffer, count, ncclDouble, op, comm, stream) is exactly that (tools/sharded_rccl.cpp).  Every rank
+ * must receive the same bytes (RCCL's ring and tree algorithms do).  Non-zero return = failure (the step returns MAGE_ERR_DEVICE).
+ * n_ranks = 0 switches sharding off. */
+typedef int (*mage_ba_allreduce_fn)(void* user, double* buffer_device, size_t count, int op, void* stream);
+mage_status mage_ba_set_landmark_shard(mage_ba* h, int rank, int n_ranks, mage_ba_allreduce_fn allreduce, void* user);
+/* Who owns which map point: owner[p] in [0, n_ranks), the heaviest point (k (k + 1) / 2 blocks of S for k observations: SURVEY 8e)
+ * first onto the lightest rank, ties to the lower point index / lower rank -- a pure function of its arguments, so every rank
+ * computes the same table on its own.  Host only (no device needed). */
+mage_status mage_ba_partition_landmarks(size_t n_points, size_t n_observations, const uint32_t* point_index, int n_ranks, int32_t* owner);
+/* All-reduce among buffers ONE process can address -- several handles on one device, or devices with peer access enabled:
+ * every bufs[r][i] becomes the op over r (sum in rank order) of bufs[r][i]; enqueued on `stream`, whose device runs the kernel.
+ * The building block of an `allreduce` callback for a process that drives all shards itself (mageslam_amd/sharded.py ThreadGroup). */
+mage_status mage_device_allreduce_local(double* const* bufs_device, int n_bufs, size_t count, int op, void* stream);
+
 mage_status mage_ba_set_observations_bulk(mage_ba* h, size_t count, const float* uv2, const uint32_t* camera_index,
                                           const uint32_t* point_index, const float* information_scalar);
 

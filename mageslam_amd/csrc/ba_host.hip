@@ -18,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <queue>
 #include <vector>
 
 #include "ba_kernels.h"
@@ -287,6 +288,11 @@ struct mage_ba {
     size_t n_x_exp = 0, n_x_imp = 0;
     hipEvent_t ev_x[2] = { nullptr, nullptr };
 
+    // ---- landmark-sharded map (mage_ba_set_landmark_shard): this handle holds the landmarks of one rank
+    int shard_rank = 0, shard_ranks = 0;                    // 0 ranks: not sharded
+    mage_ba_allreduce_fn shard_reduce = nullptr; void* shard_user = nullptr;
+    DevBuf<double> d_xchg;                                  // lower tiles of S packed + y: what the ranks add per trial
+
     // ---- diagnostics
     std::vector<mage_ba_iter_stats> stats;
     bool profiling = false;
@@ -494,7 +500,7 @@ mage_status initialize_optimization(mage_ba* h)
     const int nL = (int)active.size();
     std::vector<int> cam2hc(nc, -1), hc2cam;
     for (int i = 0; i < nc; ++i)
-        if (cam_deg[i] > 0 && !h->cams[i].fixed) { cam2hc[i] = (int)hc2cam.size(); hc2cam.push_back(i); }
+        if ((cam_deg[i] > 0 || h->shard_ranks > 0) && !h->cams[i].fixed) { cam2hc[i] = (int)hc2cam.size(); hc2cam.push_back(i); }   // sharded: the ranks' systems must have one shape
     const int nfc = (int)hc2cam.size();
     std::vector<int> pt2lm(np, -1), lm_pt;
     for (int i = 0; i < np; ++i)
@@ -502,6 +508,10 @@ mage_status initialize_optimization(mage_ba* h)
     const int nlm = (int)lm_pt.size();
     const bool points_free = !h->points_fixed;
     h->useless = (nfc + (points_free ? nlm : 0)) == 0;
+    if (h->shard_ranks > 0) {
+        if (nfc == 0) return fail(MAGE_ERR_UNSUPPORTED, "a landmark-sharded map needs a free camera (without one the landmarks are independent: solve them unsharded)");
+        h->useless = false;              // a rank without landmarks still takes part in every exchange
+    }
 
     tm.mark("active sets");
     hipStream_t st = h->stream;
@@ -775,6 +785,7 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(h->d_db.reserve((size_t)nlm * 4 + 1));
     MAGE_TRY(h->d_S.reserve((size_t)n_pad * n_pad));
     MAGE_TRY(h->d_y.reserve(n_pad));
+    if (h->shard_ranks > 0) MAGE_TRY(h->d_xchg.reserve(ba_packed_doubles(n_pad)));
     MAGE_TRY(h->d_xc.reserve(n_pad));
     MAGE_TRY(h->d_xl.reserve((size_t)nlm * 4 + 1));
     // two-level reductions: one double per block of the widest launch; the small-problem linearisation (8 lanes per landmark, 4 blocks
@@ -852,7 +863,14 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
     hipStream_t st = h->stream;
     BaDeviceView& v = h->view;
     mage_ba_iter_stats tr{};
-    const bool small = ba_small_applies(v);
+    const bool sharded = h->shard_ranks > 0;
+    const bool small = !sharded && ba_small_applies(v);
+    // landmark-sharded map: rank 0 alone damps the camera blocks and pads the diagonal, the ranks' systems are added
+    const bool adds_damping = !sharded || h->shard_rank == 0;
+    auto all_reduce = [&](double* buf, size_t count, int op) -> mage_status {
+        if (h->shard_reduce(h->shard_user, buf, count, op, (void*)st) != 0) return fail(MAGE_ERR_DEVICE, "landmark-sharded map: the all-reduce callback failed");
+        return MAGE_OK;
+    };
     int* counter = h->d_queue.p + chol_sync_ints(v.n_pad);       // one int behind the factorisation's counters, zero between launches
     if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[0], st));
     if (small) ba_small_linearize(v, huber, h->iteration == 0, counter, st);
@@ -866,8 +884,15 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
     // The chi2 of the current estimate is only needed on the host together with the first trial's (rho); it has its own
     // scalar slot, so after the first iteration of a run no host round trip separates linearisation from the solve.
     // Iteration 0 needs max |diag| on the host to seed lambda.
+    if (sharded) MAGE_TRY(all_reduce(v.scal + SC_CHI, 1, 0));
     if (h->iteration == 0) {
-        if (!small) ba_launch_maxdiag(v, st);
+        if (sharded) {
+            // max |diag| of the WHOLE map's Hessian: U's diagonal is a sum over the ranks, V's is a rank's own
+            ba_launch_gather_udiag(v, h->d_xchg.p, st);
+            MAGE_TRY(all_reduce(h->d_xchg.p, (size_t)v.n_fc * 6, 0));
+            ba_launch_maxdiag(v, st, h->d_xchg.p);
+            MAGE_TRY(all_reduce(v.scal + SC_MAXDIAG, 1, 1));
+        } else if (!small) ba_launch_maxdiag(v, st);
         MAGE_TRY(read_scalars(h));
         h->lambda = h->user_lambda > 0 ? h->user_lambda : 1e-5 * h->h_scal[SC_MAXDIAG];
         h->ni = 2;
@@ -884,12 +909,21 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
             ba_small_solve_trial(v, lambda, huber, h->d_Linv.p, counter, st);
             if (h->profiling) { MAGE_HIP(hipEventRecord(h->ev[1], st)); MAGE_HIP(hipEventRecord(h->ev[2], st)); }
         } else {
-            ba_launch_schur(v, lambda, st);
+            ba_launch_schur(v, lambda, adds_damping ? lambda : 0.0, adds_damping ? 1.0 : 0.0, st);
+            if (sharded) {
+                ba_launch_pack_lower(v, h->d_xchg.p, true, st);
+                MAGE_TRY(all_reduce(h->d_xchg.p, ba_packed_doubles(v.n_pad), 0));
+                ba_launch_pack_lower(v, h->d_xchg.p, false, st);
+            }
             if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[1], st));
             chol_factor_solve(v.S, v.y, v.xc, v.n_pad, ws, v.scal + SC_CHOL_OK, st);
             if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[2], st));
-            ba_launch_update(v, lambda, st);
+            ba_launch_update(v, lambda, adds_damping ? lambda : 0.0, st);
             ba_launch_error(v, true, huber, st);
+            if (sharded) {
+                MAGE_TRY(all_reduce(v.scal + SC_SCALE, 1, 0));
+                MAGE_TRY(all_reduce(v.scal + SC_CHI_TRIAL, 1, 0));
+            }
         }
         if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[3], st));
         MAGE_TRY(read_scalars(h));
@@ -951,7 +985,7 @@ mage_status step_optimizer(mage_ba* h, double huber, bool* cont)
         // as if it had been dropped from the index map.
         h->iteration = 0;
         h->soft_dirty = false;
-        if (h->n_active_remaining <= 0 && h->n_active_tethers == 0) h->useless = true;
+        if (h->n_active_remaining <= 0 && h->n_active_tethers == 0 && h->shard_ranks == 0) h->useless = true;
     }
     if (h->useless) { *cont = false; return MAGE_OK; }
     int r = LM_OK;
@@ -1333,10 +1367,25 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
         size_t nout = 0;
         bool in_one_launch = false, ids_from_device = false;
         size_t out_prefix = 0;
+        const bool sharded = h->shard_ranks > 0;
+        if (sharded && !h->shard_reduce) return fail(MAGE_ERR_INVALID_ARGUMENT, "landmark-sharded map without an all-reduce callback");
+        if (sharded && n_iter == 0 && h->dirty) MAGE_TRY(initialize_optimization(h));     // the post-pass below is collective
         if (n_iter > 0) {
             // StepOptimizer's entry conditions (BundlerLib.cpp:132-149), then: a pose-only problem runs the whole call in one launch
+            const bool reinit = h->dirty || h->soft_dirty;
             if (h->dirty) MAGE_TRY(initialize_optimization(h));
-            if (!h->dirty && !h->useless && v.n_L > 0 && ba_pose_lm_applies(v, n_iter)) {
+            if (sharded) {
+                // the graph changes between steps only (outliers removed, a camera fixed): the ranks agree ONCE per step whether
+                // the optimiser starts over -- the reference does when anything changed (BundlerLib.cpp:135-138), and here
+                // "anything" includes another rank's observations
+                h->h_scal[SC_SHARD_FLAG] = reinit ? 1.0 : 0.0;
+                MAGE_HIP(hipMemcpyAsync(h->d_scal.p + SC_SHARD_FLAG, h->h_scal + SC_SHARD_FLAG, sizeof(double), hipMemcpyHostToDevice, h->stream));
+                if (h->shard_reduce(h->shard_user, h->d_scal.p + SC_SHARD_FLAG, 1, 1, (void*)h->stream) != 0)
+                    return fail(MAGE_ERR_DEVICE, "landmark-sharded map: the all-reduce callback failed");
+                MAGE_TRY(read_scalars(h));
+                if (h->h_scal[SC_SHARD_FLAG] != 0.0) { h->iteration = 0; h->soft_dirty = false; }
+            }
+            if (!sharded && !h->dirty && !h->useless && v.n_L > 0 && ba_pose_lm_applies(v, n_iter)) {
                 if (h->soft_dirty) {
                     h->iteration = 0; h->soft_dirty = false;
                     if (h->n_active_remaining <= 0 && h->n_active_tethers == 0) h->useless = true;
@@ -1378,18 +1427,25 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
                 if (!cont) break;
             }
             // post-pass over the active observations of the last initialisation
-            if (v.n_L == 0 || h->L_edge_host.empty()) return MAGE_OK;     // count == 0 -> NaN
+            if (!sharded && (v.n_L == 0 || h->L_edge_host.empty())) return MAGE_OK;     // count == 0 -> NaN
             int* small_counter = h->d_queue.p + chol_sync_ints(v.n_pad);
-            if (ba_small_applies(v)) ba_small_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, small_counter, h->stream);
+            if (!sharded && ba_small_applies(v)) ba_small_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, small_counter, h->stream);
             else ba_launch_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, h->stream);
             // the first OUT_PREFIX ids of the list ride the same read-back as the three sums (usually that is the whole list)
             ids_from_device = true;
             // (a run that removed outliers last time will again: twice that many, at least 64, at most OUT_PREFIX; a 16 KB copy is ~8 us
             // slower than a 100-byte one, so a run without outliers does not pay for it)
             const size_t prefix = std::min<size_t>(std::min<size_t>(OUT_PREFIX, (size_t)v.n_L), std::max<size_t>(64, 2 * h->out_expect));
+            if (sharded) {
+                // the mean error is the map's, the list a rank's own; whether anything was removed ANYWHERE decides the re-initialisation
+                MAGE_HIP(hipMemcpyAsync(h->d_scal.p + SC_NOUT_OWN, h->d_scal.p + SC_NOUT, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+                if (h->shard_reduce(h->shard_user, h->d_scal.p + SC_ERRSUM, 3, 0, (void*)h->stream) != 0)
+                    return fail(MAGE_ERR_DEVICE, "landmark-sharded map: the all-reduce callback failed");
+            }
             MAGE_TRY(read_scalars(h, prefix));
             err_sum = h->h_scal[SC_ERRSUM]; cnt = h->h_scal[SC_ERRCNT];
-            nout = (size_t)h->h_scal[SC_NOUT];
+            nout = (size_t)h->h_scal[sharded ? SC_NOUT_OWN : SC_NOUT];
+            if (sharded && h->h_scal[SC_NOUT] > 0) h->soft_dirty = true;
             h->out_cursor += (int)nout;
             h->out_expect = nout;
             out_prefix = prefix;
@@ -1433,6 +1489,53 @@ MAGE_EXPORT mage_status mage_ba_get_outliers(const mage_ba* h, uint32_t* outlier
     *count = h->last_outliers.size();
     for (size_t i = 0; outliers && i < h->last_outliers.size() && i < capacity; ++i) outliers[i] = h->last_outliers[i];
     return MAGE_OK;
+}
+
+// ---- landmark-sharded maps (include/mage_ba.h)
+MAGE_EXPORT mage_status mage_ba_set_landmark_shard(mage_ba* h, int rank, int n_ranks, mage_ba_allreduce_fn allreduce, void* user)
+{
+    if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+    if (n_ranks < 0 || (n_ranks > 0 && (rank < 0 || rank >= n_ranks || !allreduce))) return fail(MAGE_ERR_INVALID_ARGUMENT, "rank %d of %d ranks, callback %p", rank, n_ranks, (void*)allreduce);
+    if ((h->shard_ranks > 0) != (n_ranks > 0)) h->dirty = true;            // which cameras are in the system depends on it
+    h->shard_rank = n_ranks > 0 ? rank : 0; h->shard_ranks = n_ranks;
+    h->shard_reduce = n_ranks > 0 ? allreduce : nullptr; h->shard_user = user;
+    return MAGE_OK;
+}
+
+MAGE_EXPORT mage_status mage_ba_partition_landmarks(size_t n_points, size_t n_observations, const uint32_t* point_index, int n_ranks, int32_t* owner)
+{
+    return guarded([&]() -> mage_status {
+        if (n_ranks < 1 || (n_observations && !point_index) || (n_points && !owner)) return fail(MAGE_ERR_INVALID_ARGUMENT, "bad argument");
+        std::vector<uint64_t> k(n_points, 0);
+        for (size_t e = 0; e < n_observations; ++e) {
+            if (point_index[e] >= n_points) return fail(MAGE_ERR_INVALID_ARGUMENT, "observation %zu refers to point %u of %zu", e, point_index[e], n_points);
+            k[point_index[e]]++;
+        }
+        // heaviest point first (k (k + 1) / 2 blocks of S; ties: lower index) onto the lightest rank (ties: lower rank)
+        std::vector<uint32_t> order(n_points);
+        for (size_t i = 0; i < n_points; ++i) { order[i] = (uint32_t)i; k[i] = k[i] * (k[i] + 1) / 2; }
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return k[a] > k[b]; });
+        typedef std::pair<uint64_t, int> Load;
+        std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+        for (int r = 0; r < n_ranks; ++r) heap.push({ 0, r });
+        for (uint32_t p : order) {
+            Load l = heap.top(); heap.pop();
+            owner[p] = l.second;
+            heap.push({ l.first + k[p], l.second });
+        }
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_device_allreduce_local(double* const* bufs_device, int n_bufs, size_t count, int op, void* stream)
+{
+    return guarded([&]() -> mage_status {
+        if (!bufs_device || n_bufs < 1 || (op != 0 && op != 1)) return fail(MAGE_ERR_INVALID_ARGUMENT, "bad argument");
+        for (int k = 0; k < n_bufs; ++k) if (!bufs_device[k] && count) return fail(MAGE_ERR_INVALID_ARGUMENT, "null buffer %d", k);
+        if (!ba_launch_allreduce_local(bufs_device, n_bufs, count, op, (hipStream_t)stream)) return fail(MAGE_ERR_UNSUPPORTED, "at most 16 buffers");
+        MAGE_HIP(hipGetLastError());
+        return MAGE_OK;
+    });
 }
 
 // ---- device-resident pose exchange (window-sharded maps; include/mage_ba.h)

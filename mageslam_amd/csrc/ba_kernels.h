@@ -76,14 +76,23 @@ enum TetherKind { TETHER_DISTANCE = 0, TETHER_ROTATION = 1, TETHER_TRANSFORM = 2
 constexpr int TETHER_OUT_STRIDE = 120;
 
 // SC_CHI: robust chi2 of the current estimate; SC_CHI_TRIAL: of the LM candidate (separate slots: one host read fetches both)
-enum Scal { SC_CHI = 0, SC_SCALE = 1, SC_MAXDIAG = 2, SC_CHOL_OK = 3, SC_ERRSUM = 4, SC_ERRCNT = 5, SC_NOUT = 6, SC_CHI_TRIAL = 7, SC_CHOL_STALL = 8, SC_COUNT = 9 };
+enum Scal { SC_CHI = 0, SC_SCALE = 1, SC_MAXDIAG = 2, SC_CHOL_OK = 3, SC_ERRSUM = 4, SC_ERRCNT = 5, SC_NOUT = 6, SC_CHI_TRIAL = 7, SC_CHOL_STALL = 8,
+            SC_SHARD_FLAG = 9, SC_NOUT_OWN = 10,      // landmark-sharded maps: "some rank re-initialises", this rank's outlier count (SC_NOUT then holds the map's)
+            SC_COUNT = 11 };
 
 // All launchers enqueue on `st` and return immediately.
 void ba_launch_error(const BaDeviceView& v, bool trial, double huber_delta, hipStream_t st);         // -> scal[SC_CHI] / scal[SC_CHI_TRIAL]
 void ba_launch_linearize(const BaDeviceView& v, double huber_delta, hipStream_t st);                 // U,bc,V,bp,W
-void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st);                                       // -> scal[SC_MAXDIAG]
+void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st, const double* udiag_sum = nullptr);                                       // -> scal[SC_MAXDIAG]
 void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st);                          // Dinv,db,S,y
 void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st);                         // xl, trial state, scal[SC_SCALE]
+// landmark-sharded maps (include/mage_ba.h: mage_ba_set_landmark_shard)
+void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, double pad_diag, hipStream_t st);
+void ba_launch_update(const BaDeviceView& v, double lambda, double lambda_cam, hipStream_t st);
+size_t ba_packed_doubles(int n_pad);                                                                   // lower tiles of S + y
+void ba_launch_pack_lower(const BaDeviceView& v, double* packed, bool to_packed, hipStream_t st);
+void ba_launch_gather_udiag(const BaDeviceView& v, double* out6_per_camera, hipStream_t st);
+bool ba_launch_allreduce_local(double* const* bufs, int n, size_t count, int op, hipStream_t st);
 void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, hipStream_t st); // scal[SC_ERRSUM..SC_NOUT]
 
 // Small problems (reduced camera system of order <= 128, no tethers): one LM trial in five launches instead of ~22

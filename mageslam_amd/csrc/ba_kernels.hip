@@ -334,12 +334,13 @@ __global__ __launch_bounds__(256) void k_linearize_cam(BaDeviceView v, double de
 
 // max |diagonal| over pose and landmark blocks (computeLambdaInit, A.4): grid-stride partial maxima, then one block folds them
 // (a single block over 100 k landmarks took 345 us -- and lambda is re-seeded after every outlier removal)
-__global__ __launch_bounds__(256) void k_maxdiag(BaDeviceView v)
+// udiag: the diagonal of U as 6 doubles per free camera when it was summed over the ranks of a landmark-sharded map (null: read U)
+__global__ __launch_bounds__(256) void k_maxdiag(BaDeviceView v, const double* __restrict__ udiag)
 {
     __shared__ double sm[4];
     double m = 0;
     const int nU = v.n_fc * 6, nV = v.points_free ? v.n_lm * 3 : 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nU; i += gridDim.x * 256) m = fmax(m, fabs(v.U[(size_t)(i / 6) * 36 + (i % 6) * 7]));
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nU; i += gridDim.x * 256) m = fmax(m, fabs(udiag ? udiag[i] : v.U[(size_t)(i / 6) * 36 + (i % 6) * 7]));
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nV; i += gridDim.x * 256) {
         const int l = i / 3, d = i % 3;
         m = fmax(m, fabs(v.V[(size_t)l * 6 + (d == 0 ? 0 : d == 1 ? 3 : 5)]));
@@ -369,13 +370,14 @@ __global__ __launch_bounds__(256) void k_reduce_max(const double* __restrict__ i
 // arrays in the same launch (they were a memset, a copy and a kernel of their own, ~4 us each on the stream): y = b_c (the diagonal
 // blocks of k_schur_block subtract the landmark part; y_from_bc = 0: plain zero) with a zero tail, and the identity on the padded
 // tail of S's diagonal so that the padded system stays SPD.
-__global__ __launch_bounds__(256) void k_lm_invert(BaDeviceView v, double lambda, int nb_lm, int y_from_bc)
+// pad_diag: 1 (0 on the ranks of a landmark-sharded map that do not add the camera damping: the shards' matrices are summed).
+__global__ __launch_bounds__(256) void k_lm_invert(BaDeviceView v, double lambda, int nb_lm, int y_from_bc, double pad_diag)
 {
     if ((int)blockIdx.x >= nb_lm) {
         const int n = v.n_fc * 6;
         for (int i = ((int)blockIdx.x - nb_lm) * 256 + threadIdx.x; i < v.n_pad; i += ((int)gridDim.x - nb_lm) * 256) {
             v.y[i] = (i < n && y_from_bc) ? v.bc[i] : 0.0;
-            if (i >= n) v.S[(size_t)i * v.n_pad + i] = 1.0;
+            if (i >= n) v.S[(size_t)i * v.n_pad + i] = pad_diag;
         }
         return;
     }
@@ -413,6 +415,43 @@ __global__ __launch_bounds__(256) void k_zero_lower(double* __restrict__ S, int 
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) col[i] = make_double2(0.0, 0.0);
 }
 
+// Landmark-sharded maps: what the ranks add up is the part of S the factorisation reads (same trapezoid as k_zero_lower), packed
+// column after column, with the right-hand side behind it.  Column c of tile column t starts at 128 (t n_pad - 128 t (t - 1) / 2)
+// + (c % 128)(n_pad - 128 t).  TO_PACKED = false copies back.
+template <bool TO_PACKED>
+__global__ __launch_bounds__(256) void k_pack_lower(double* __restrict__ S, double* __restrict__ y, double* __restrict__ packed, int n_pad, int tile)
+{
+    const int c = blockIdx.y;
+    if (c == n_pad) {                                       // the extra "column": y
+        double* py = packed + (size_t)n_pad * (n_pad + tile) / 2;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n_pad; i += gridDim.x * 256) { if (TO_PACKED) py[i] = y[i]; else y[i] = py[i]; }
+        return;
+    }
+    const int t = c / tile, r0 = t * tile;
+    const size_t off = (size_t)tile * ((size_t)t * n_pad - (size_t)tile * t * (t - 1) / 2) + (size_t)(c - r0) * (n_pad - r0);
+    double2* col = reinterpret_cast<double2*>(S + (size_t)c * n_pad + r0);
+    double2* pk = reinterpret_cast<double2*>(packed + off);
+    const int n2 = (n_pad - r0) / 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) { if (TO_PACKED) pk[i] = col[i]; else col[i] = pk[i]; }
+}
+
+__global__ __launch_bounds__(256) void k_gather_udiag(BaDeviceView v, double* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < v.n_fc * 6) out[i] = v.U[(size_t)(i / 6) * 36 + (i % 6) * 7];
+}
+
+// mage_device_allreduce_local: every buffer becomes the sum in rank order (or the maximum) of all of them
+constexpr int LOCAL_REDUCE_MAX = 16;
+struct LocalReduceArgs { double* buf[LOCAL_REDUCE_MAX]; int n; };
+__global__ __launch_bounds__(256) void k_allreduce_local(LocalReduceArgs a, size_t count, int op)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        double r = a.buf[0][i];
+        for (int k = 1; k < a.n; ++k) { const double x = a.buf[k][i]; r = op == 0 ? r + x : fmax(r, x); }
+        for (int k = 0; k < a.n; ++k) a.buf[k][i] = r;
+    }
+}
 
 // One wavefront per non-empty upper block (i <= j).  Workgroups go to the eight XCDs round-robin and every XCD has its own
 // L2, so the slot -> block table (blk_order, ba_host.hip) hands the workgroups of XCD x a CONTIGUOUS run of block rows (runs cut
@@ -1587,15 +1626,40 @@ void ba_launch_linearize(const BaDeviceView& v, double delta, hipStream_t st)
     tether_launch_linearize(v, st);
 }
 
-void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st)
+void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st, const double* udiag_sum)
 {
     const int work = v.n_fc * 6 + (v.points_free ? v.n_lm * 3 : 0);
     const int nb = std::max(1, std::min(256, (work + 1023) / 1024));
-    hipLaunchKernelGGL(k_maxdiag, dim3(nb), dim3(256), 0, st, v);
+    hipLaunchKernelGGL(k_maxdiag, dim3(nb), dim3(256), 0, st, v, udiag_sum);
     hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, st, v.partial, nb, v.scal + SC_MAXDIAG);
 }
 
-void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st)
+size_t ba_packed_doubles(int n_pad) { return (size_t)n_pad * (n_pad + 128) / 2 + (size_t)n_pad; }
+void ba_launch_pack_lower(const BaDeviceView& v, double* packed, bool to_packed, hipStream_t st)
+{
+    const dim3 grid(std::max(1, v.n_pad / 2048), v.n_pad + 1);
+    if (to_packed) hipLaunchKernelGGL(k_pack_lower<true>, grid, dim3(256), 0, st, v.S, v.y, packed, v.n_pad, 128);
+    else hipLaunchKernelGGL(k_pack_lower<false>, grid, dim3(256), 0, st, v.S, v.y, packed, v.n_pad, 128);
+}
+void ba_launch_gather_udiag(const BaDeviceView& v, double* out, hipStream_t st)
+{
+    if (v.n_fc > 0) hipLaunchKernelGGL(k_gather_udiag, dim3(cdiv(v.n_fc * 6, 256)), dim3(256), 0, st, v, out);
+}
+bool ba_launch_allreduce_local(double* const* bufs, int n, size_t count, int op, hipStream_t st)
+{
+    if (n < 1 || n > LOCAL_REDUCE_MAX) return false;
+    if (count == 0) return true;
+    LocalReduceArgs a{};
+    for (int k = 0; k < n; ++k) a.buf[k] = bufs[k];
+    a.n = n;
+    const int nb = (int)std::min<size_t>(2048, (count + 255) / 256);
+    hipLaunchKernelGGL(k_allreduce_local, dim3(nb), dim3(256), 0, st, a, count, op);
+    return true;
+}
+
+void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st) { ba_launch_schur(v, lambda, lambda, 1.0, st); }
+// lambda_cam: the damping of the camera blocks (lambda; 0 on the ranks of a landmark-sharded map that leave it to rank 0)
+void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, double pad_diag, hipStream_t st)
 {
     if (v.n_pad >= 1024) hipLaunchKernelGGL(k_zero_lower, dim3(std::max(1, v.n_pad / 2048), v.n_pad), dim3(256), 0, st, v.S, v.n_pad, 128);
     else (void)hipMemsetAsync(v.S, 0, (size_t)v.n_pad * v.n_pad * sizeof(double), st);
@@ -1603,16 +1667,16 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st)
     const bool rhs_in_blocks = v.points_free && v.n_blk > 0;
     {
         const int nb_lm = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm, 256) : 0;
-        hipLaunchKernelGGL(k_lm_invert, dim3(nb_lm + std::max(1, std::min(8, cdiv(v.n_pad, 256)))), dim3(256), 0, st, v, lambda, nb_lm, rhs_in_blocks ? 1 : 0);
+        hipLaunchKernelGGL(k_lm_invert, dim3(nb_lm + std::max(1, std::min(8, cdiv(v.n_pad, 256)))), dim3(256), 0, st, v, lambda, nb_lm, rhs_in_blocks ? 1 : 0, pad_diag);
     }
     if (v.n_blk > 0) {
         static const bool gather = std::getenv("MAGE_BA_SCHUR_GATHER") != nullptr;      // the lane-per-contribution loads, for comparison
         if (v.n_blk <= SPLIT_BLOCKS_BELOW) {
-            if (gather) hipLaunchKernelGGL((k_schur_block<true, false>), dim3(v.n_blk), dim3(256), 0, st, v, lambda);
-            else hipLaunchKernelGGL((k_schur_block<true, true>), dim3(v.n_blk), dim3(256), 0, st, v, lambda);
+            if (gather) hipLaunchKernelGGL((k_schur_block<true, false>), dim3(v.n_blk), dim3(256), 0, st, v, lambda_cam);
+            else hipLaunchKernelGGL((k_schur_block<true, true>), dim3(v.n_blk), dim3(256), 0, st, v, lambda_cam);
         } else {
-            if (gather) hipLaunchKernelGGL((k_schur_block<false, false>), dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda);
-            else hipLaunchKernelGGL((k_schur_block<false, true>), dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda);
+            if (gather) hipLaunchKernelGGL((k_schur_block<false, false>), dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda_cam);
+            else hipLaunchKernelGGL((k_schur_block<false, true>), dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda_cam);
         }
     }
     tether_launch_schur(v, st);
@@ -1622,7 +1686,8 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st)
     }
 }
 
-void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st)
+void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st) { ba_launch_update(v, lambda, lambda, st); }
+void ba_launch_update(const BaDeviceView& v, double lambda, double lambda_cam, hipStream_t st)
 {
     int nb_l = 0;
     if (v.points_free && v.n_lm > 0) {
@@ -1632,7 +1697,7 @@ void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st)
     int nb_c = 0;
     if (v.n_fc > 0) {
         nb_c = cdiv(v.n_fc, 256);
-        hipLaunchKernelGGL(k_pose_update, dim3(nb_c), dim3(256), 0, st, v, lambda, nb_l);
+        hipLaunchKernelGGL(k_pose_update, dim3(nb_c), dim3(256), 0, st, v, lambda_cam, nb_l);
     }
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb_l + nb_c, 1, v.scal + SC_SCALE, 1);
 }
