@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--ranks", type=int, default=2, help="threads mode only")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pts", type=int, default=0, help="override the configuration's number of map points")
+    ap.add_argument("--obs", type=int, default=0, help="override the configuration's number of observations")
     a = ap.parse_args()
     from mageslam_amd import dist as mdist, scene, sharded
     from mageslam_amd.bundler import BundlerLib, load_scene
@@ -32,7 +34,12 @@ def main():
     def bulk(b, s):
         load_scene(b, s, bulk=True)
 
-    s = scene.make_config(a.config)
+    over = {}
+    if a.pts:
+        over["n_pts"] = a.pts
+    if a.obs:
+        over["n_obs"] = a.obs
+    s = scene.make_config(a.config, **over)
     info = mdist.rank_info()
     out = {"config": a.config, "n_cams": s.n_cams, "n_pts": s.n_pts, "n_obs": s.n_obs}
     if info.world > 1:
@@ -68,14 +75,34 @@ def main():
         mse1 = g.StepBundleAdjustment([0.9], 1e30, [])
     t_single = (time.perf_counter() - t0) / a.steps
     g.close()
-    t0 = time.perf_counter()
-    res = sharded.solve_on_threads(s, a.ranks, BundlerLib, bulk, calls)
-    t_all = time.perf_counter() - t0
-    trials = sum(t["trials"] for c in res["traces"][0] for t in c)
-    out.update(mode="threads-on-one-gpu", ranks=a.ranks, wall_s_including_setup=t_all, all_reduce_calls=res["group"].calls,
-               exchanged_MB_per_trial=8e-6 * res["group"].doubles / max(trials, 1), trials=trials,
-               rmse_px=float(np.sqrt(res["mse"][0][-1])), single_handle_ms_per_iteration=1e3 * t_single,
-               single_handle_rmse_px=float(np.sqrt(mse1)))
+    import threading
+    group = sharded.ThreadGroup(a.ranks)
+    owner = sharded.partition_landmarks(s.obs_pt, s.n_pts, a.ranks)
+    shards = [sharded.ShardedBundler(s, r, a.ranks, BundlerLib, bulk, group.callback(r), owner) for r in range(a.ranks)]
+    gate = threading.Barrier(a.ranks + 1)
+    mse, trials = [0.0] * a.ranks, [0] * a.ranks
+
+    def run(r):
+        for _ in range(a.warmup):
+            shards[r].StepBundleAdjustment([0.9], 1e30, [])
+        gate.wait(); gate.wait()
+        for _ in range(a.steps):
+            mse[r] = shards[r].StepBundleAdjustment([0.9], 1e30, [])
+            trials[r] += sum(t["trials"] for t in shards[r].trace())
+        gate.wait()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(a.ranks)]
+    for t in th:
+        t.start()
+    gate.wait()
+    d0, t0 = group.doubles, time.perf_counter()
+    gate.wait(); gate.wait()
+    dt = time.perf_counter() - t0
+    for t in th:
+        t.join()
+    out.update(mode="threads-on-one-gpu", ranks=a.ranks, ms_per_iteration=1e3 * dt / a.steps, trials=trials[0],
+               exchanged_MB_per_trial=8e-6 * (group.doubles - d0) / max(trials[0], 1), rmse_px=float(np.sqrt(mse[0])),
+               single_handle_ms_per_iteration=1e3 * t_single, single_handle_rmse_px=float(np.sqrt(mse1)))
     print(json.dumps(out))
 
 
