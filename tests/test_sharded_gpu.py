@@ -114,6 +114,36 @@ def test_rejected_trials_are_rejected_on_every_rank():
     _check_against(res, dict(poses=g.poses_f64(), points=g.points_f64(), outliers=outs, mse=mses, traces=traces), 2, 1e-7)
 
 
+@pytest.mark.parametrize("case", range(16))
+def test_randomised_graph_shapes(case):
+    """The shapes of test_ba_gpu.py's differential test -- shuffled and thinned observation lists, duplicate (camera, point) pairs,
+    random fixed flags, points that lose all observations, cameras nobody observes, tethers, fixed points -- split over 2..4 ranks
+    (more ranks than some shapes have landmarks per rank) against the single handle, which takes its small-problem path here."""
+    rng = np.random.default_rng(0x5A4D + case)
+    n_cams = int(rng.integers(3, 14)); n_pts = int(rng.integers(6, 80)); K = int(rng.integers(2, min(n_cams, 6) + 1))
+    s = scene.make_scene(n_cams=n_cams, n_pts=n_pts, n_obs=n_pts * K, seed=0x5EED3000 + case, fixed=(), outlier_frac=0.05 * (case % 3))
+    idx = rng.permutation(s.n_obs)
+    idx = idx[rng.random(s.n_obs) > 0.1]
+    dup = rng.choice(idx, size=max(1, len(idx) // 8))
+    idx = np.concatenate([idx, dup])
+    s.obs_uv, s.obs_cam, s.obs_pt, s.obs_info = s.obs_uv[idx], s.obs_cam[idx], s.obs_pt[idx], s.obs_info[idx]
+    s.obs_uv = s.obs_uv.copy(); s.obs_uv[len(idx) - len(dup):] += rng.normal(0, 0.5, (len(dup), 2)).astype(np.float32)
+    s.n_obs = len(idx)
+    fixed = rng.random(n_cams) < 0.3
+    fixed[int(rng.integers(0, n_cams))] = True
+    if fixed.all():
+        fixed[int(rng.integers(0, n_cams))] = False                 # a sharded map needs a free camera
+    s.cam_fixed = fixed
+    tethered = case % 3 == 2
+    if tethered:
+        s.tethers = scene.make_tethers(s, n_dist=2, n_rot=1, n_xf=2, seed=0x7E7E0200 + case)
+    points_fixed = case % 8 == 7
+    n_ranks = 2 + case % 3
+    calls = [([1.8], 30.0), ([0.9, 0.9], 16.0), ([0.9], 9.0)]
+    res = sharded.solve_on_threads(s, n_ranks, lambda: BundlerLib(points_fixed), _bulk, calls)
+    _check_against(res, _single(s, calls, points_fixed), n_ranks, 1e-6 if tethered else 1e-8)
+
+
 def test_full_size_map_on_two_ranks():
     """BASELINE.json configs[3] (1 000 poses / 100 k points / 1 M observations): 148 MB per exchange."""
     s = scene.make_config("global")
