@@ -200,6 +200,18 @@ def main() -> int:
                            "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0} for k, (ms, by) in stages.items()},
             "traffic": None,
         }
+        try:   # HBM bytes per LM iteration of the three stages from the committed PMC passes (tools/pmc_stage_traffic.py)
+            sj = json.load(open(os.path.join(ROOT, "profiles", "ba_stage_traffic.json")))
+            if args.workload == "global":
+                hb = line["roofline_hbm"]
+                hb["traffic"] = float(sj["total_hbm_bytes_per_iteration"])
+                for k, v in sj["stages_hbm_bytes_per_iteration"].items():
+                    if k in hb["stages"]:
+                        hb["stages"][k]["traffic"] = float(v)
+                hb["traffic_source"] = ("committed profile (profiles/ba_stage_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                        "bench.py on the 1k-pose map), not measured in this run")
+        except Exception:  # noqa: BLE001 - the profile is optional
+            pass
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0, N = 1 only
             try:
                 line["cpu_baseline"] = cpu_baseline(args.workload)
