@@ -927,7 +927,7 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
     __shared__ double udiag[128];
     const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_blocks = gridDim.x;
-    const int nbC = v.n_fc * cpc;
+    const int nbC = cpc == 1 ? ((v.n_fc + 7) / 8) * 8 + 8 : v.n_fc * cpc;       // cpc == 1: runs of cameras per XCD (camera role below)
     double* cam_part = v.partial + n_blocks;           // n_fc x cpc x 28 partial (U, b_c) sums, behind the chi2 partials
     double chi = 0;                                    // this thread's share of the robust chi2 (one role per problem kind owns it)
     if (bid < nbL && !v.dup_slots) {
@@ -1062,7 +1062,16 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
     } else if (bid < nbL + nbC) {
         // ---- camera role: k_linearize_cam<true>, SMALL_CPC workgroups per camera, each a contiguous quarter of the camera's
         // observations; the last block adds the quarters in order.  Owns the chi2 when the points are fixed
-        const int hc = (bid - nbL) / cpc, quarter = (bid - nbL) % cpc;
+        int hc = (bid - nbL) / cpc;
+        const int quarter = (bid - nbL) % cpc;
+        if (cpc == 1) {
+            // large problems: workgroups go to the eight XCDs round-robin by their index in the GRID, and a camera's observation
+            // records are gathered from lines it shares with the cameras next to it -- so XCD x takes the contiguous run of cameras
+            // [x run, (x + 1) run) and those lines are fetched into one L2 instead of eight (263 -> ~150 MB of L2 misses per launch)
+            const int x = bid & 7, first = nbL + ((x - (nbL & 7) + 8) & 7), run = (v.n_fc + 7) >> 3, within = (bid - first) >> 3;
+            hc = (bid >= first && within < run) ? x * run + within : v.n_fc;
+            if (hc >= v.n_fc) { if (tid == 0) v.partial[bid] = 0.0; return; }       // (cpc == 1: no last-block fold below)
+        }
         const int cam = v.hc2cam[hc];
         PoseD P = load_pose(v.pose_cur, cam);
         const double f = v.camK[cam * 4];
@@ -1725,8 +1734,9 @@ bool ba_fused_linearize_applies(const BaDeviceView& v)
 void ba_fused_linearize(const BaDeviceView& v, double delta, int* counter, hipStream_t st)
 {
     const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm * SMALL_LPL, 256) : 0;
-    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + v.n_fc), dim3(256), 0, st, v, delta, nbL, 0, counter, 1, 0);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nbL + v.n_fc, 1, v.scal + SC_CHI, 1);
+    const int nbC = ((v.n_fc + 7) / 8) * 8 + 8;          // every XCD gets ceil(n_fc / 8) camera workgroups wherever its first one falls
+    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + nbC), dim3(256), 0, st, v, delta, nbL, 0, counter, 1, 0);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nbL + nbC, 1, v.scal + SC_CHI, 1);
 }
 void ba_small_solve_trial(const BaDeviceView& v, double lambda, double delta, double* linv_ws, int* counter, hipStream_t st)
 {
