@@ -262,7 +262,7 @@ struct mage_ba {
     DevBuf<int2> d_blk_ij, d_con;
     DevBuf<int> d_blk_order;
     bool dup_slots = false;            // some landmark is observed twice by one free camera
-    DevBuf<double> d_errL, d_U, d_bc, d_V, d_bp, d_W, d_Dinv, d_db, d_S, d_y, d_xc, d_xl, d_partial, d_scal, d_Linv;
+    DevBuf<double> d_errL, d_U, d_bc, d_V, d_bp, d_W, d_Dinv, d_db, d_S, d_y, d_xc, d_xl, d_partial, d_scal, d_Linv, d_camR;
     DevBuf<uint8_t> d_flagL, d_L_active;
     uint32_t* d_out_ids = nullptr;      // outliers of the last post-pass (original observation indices, unordered): they live BEHIND the scalars
                                         // in d_scal, so the first OUT_PREFIX of them come back in the scalars' read-back; cursor = the int behind the small-path counter
@@ -778,6 +778,7 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(h->d_errL.reserve((size_t)nL * 2 + 2));
     MAGE_TRY(h->d_U.reserve((size_t)nfc * 36 + 1));
     MAGE_TRY(h->d_bc.reserve((size_t)nfc * 6 + 1));
+    MAGE_TRY(h->d_camR.reserve((size_t)nfc * 12 + 2));
     MAGE_TRY(h->d_V.reserve((size_t)nlm * 6 + 1));
     MAGE_TRY(h->d_bp.reserve((size_t)nlm * 4 + 1));
     MAGE_TRY(h->d_W.reserve((size_t)nw * 18 + 1));
@@ -820,6 +821,7 @@ mage_status initialize_optimization(mage_ba* h)
     v.tp_ij = h->d_tp_ij.p; v.tp_ptr = h->d_tp_ptr.p; v.tp_item = h->d_tp_item.p;
     h->n_active_tethers = nT;
     v.errL = h->d_errL.p; v.U = h->d_U.p; v.bc = h->d_bc.p; v.V = h->d_V.p; v.bp = h->d_bp.p; v.W = h->d_W.p;
+    v.compact = 0; v.camR = h->d_camR.p;
     v.Dinv = h->d_Dinv.p; v.db = h->d_db.p; v.S = h->d_S.p; v.y = h->d_y.p; v.xc = h->d_xc.p; v.xl = h->d_xl.p;
     v.partial = h->d_partial.p; v.scal = h->d_scal.p;
     refresh_view_state(h);
@@ -828,9 +830,12 @@ mage_status initialize_optimization(mage_ba* h)
     h->prof.factor_flops_each = (double)n * n * n / 3.0;      // algorithmic: the system's order, not the padded one
     {   // algorithmic bytes of the HBM-bound stages for this problem (each array counted once per stage)
         const double dL = nL, dW = nw, dP = nlm, dC = nfc;
-        h->prof.linearize_bytes_each = dL * (3 * 24 + 16 + 4) + dW * 144 + dP * (80 + 3 * 32) + dC * 336;
-        h->prof.schur_bytes_each = dP * (160 + 48 + 32) + 2 * 144 * dW + 8.0 * (double)ncon + 288.0 * nblk + 4.0 * (double)n_pad * n_pad;
-        h->prof.update_bytes_each = 144 * dW + dP * (32 + 48 + 32 + 64 + 32) + dL * 40;
+        // a W slot is 144 bytes materialised, 32 in the compact form lm_solve selects for large tether-free problems (ba_kernels.h)
+        const bool compact_w = points_free && !h->dup_slots && nT == 0 && nfc * 6 > 128 && h->shard_ranks >= 0 && ba_compact_w_enabled();
+        const double bW = compact_w ? 32.0 : 144.0;
+        h->prof.linearize_bytes_each = dL * (3 * 24 + 16 + 4) + dW * bW + dP * (80 + 3 * 32) + dC * 336;
+        h->prof.schur_bytes_each = dP * (160 + 48 + 32) + 2 * bW * dW + 8.0 * (double)ncon + 288.0 * nblk + 4.0 * (double)n_pad * n_pad;
+        h->prof.update_bytes_each = bW * dW + dP * (32 + 48 + 32 + 64 + 32) + dL * 40;
     }
     h->iteration = 0;
     h->dirty = false;
@@ -873,6 +878,8 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
     };
     int* counter = h->d_queue.p + chol_sync_ints(v.n_pad);       // one int behind the factorisation's counters, zero between launches
     if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[0], st));
+    // W in its compact form (x/z, y/z, 1/z, weight per slot: ba_kernels.h) whenever the fused linearisation writes it
+    v.compact = (!small && v.points_free && ba_fused_linearize_applies(v) && ba_compact_w_enabled()) ? 1 : 0;
     if (small) ba_small_linearize(v, huber, h->iteration == 0, counter, st);
     else if (ba_fused_linearize_applies(v)) ba_fused_linearize(v, huber, counter, st);
     else {

@@ -608,6 +608,146 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block(
     }
 }
 
+// COMPACT form of the W blocks (BaDeviceView::compact): a slot holds (a, b, iz, w) = x/z, y/z, 1/z of the point in the slot's camera
+// and the observation's robust weight.  With the camera's focal length f and rotation R (camR, uniform per block):
+//     Jc  = f [ a b, -(1 + a^2), b, -iz, 0, a iz ;  1 + b^2, -a b, -a, 0, -iz, b iz ]         (2 x 6, jac_pose)
+//     Q   = w Jp = -w iz f [ R_0 - a R_2 ; R_1 - b R_2 ]                                        (2 x 3, jac_point; R_k = row k of R)
+//     W   = Jc^T Q                                                                              (6 x 3, rank 2)
+// so a contribution W_a D W_b^T = Jc_a^T (Q_a D Q_b^T) Jc_b goes through a 2 x 2 middle: the same ~220 operations as the product of
+// materialised blocks, on 112 gathered bytes instead of 336 (9 loads instead of 23), and the linearisation writes 32 bytes per
+// observation instead of 144.  Same block -> workgroup placement, same reduction over the lanes, same outputs as k_schur_block.
+struct CamConst { double f, R[9]; };
+__device__ __forceinline__ CamConst load_cam_const(const double* __restrict__ camR, int hc)
+{
+    const double2* p = reinterpret_cast<const double2*>(camR + (size_t)hc * 12);
+    const double2 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+    CamConst k;
+    k.f = a.x; k.R[0] = a.y; k.R[1] = b.x; k.R[2] = b.y; k.R[3] = c.x; k.R[4] = c.y; k.R[5] = d.x; k.R[6] = d.y; k.R[7] = e.x; k.R[8] = e.y;
+    return k;
+}
+// Jc rows (J0, J1) and Q rows (Q0, Q1) of a slot
+__device__ __forceinline__ void slot_factors(const CamConst& k, double a, double b, double iz, double w, double J0[6], double J1[6], double Q0[3], double Q1[3])
+{
+    const double f = k.f, af = a * f, bf = b * f, izf = iz * f;
+    J0[0] = a * bf;        J0[1] = -(f + a * af); J0[2] = bf;  J0[3] = -izf; J0[4] = 0;    J0[5] = a * izf;
+    J1[0] = f + b * bf;    J1[1] = -(a * bf);     J1[2] = -af; J1[3] = 0;    J1[4] = -izf; J1[5] = b * izf;
+    const double s = -(w * izf);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { Q0[c] = s * (k.R[c] - a * k.R[6 + c]); Q1[c] = s * (k.R[3 + c] - b * k.R[6 + c]); }
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block_compact(BaDeviceView v, double lambda)
+{
+    constexpr int NW = SPLIT ? 4 : SCHUR_WAVES;
+    __shared__ double red[NW][64 * 37];
+    __shared__ double part[SPLIT ? 4 : 1][36];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int b;
+    if (SPLIT) {
+        b = (int)blockIdx.x;
+        if (b >= v.n_blk) return;
+    } else {
+        const int slot = blockIdx.x * SCHUR_WAVES + wave;
+        if (slot >= v.n_blk_slots) return;
+        b = v.blk_order[slot];
+        if (b < 0) return;
+    }
+    b = __builtin_amdgcn_readfirstlane(b);
+    const int stride = SPLIT ? 4 * WAVE : WAVE;
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = 0;
+    const int2 ij = v.blk_ij[b];
+    const bool diag = ij.x == ij.y;
+    const CamConst ci = load_cam_const(v.camR, ij.x), cj = load_cam_const(v.camR, ij.y);
+    double yv[6] = { 0, 0, 0, 0, 0, 0 };
+    const int c_end = v.blk_ptr[b + 1];
+    const double2* G2 = reinterpret_cast<const double2*>(v.W);
+    for (int c = v.blk_ptr[b] + (SPLIT ? wave * WAVE : 0) + lane; c < c_end; c += stride) {
+        const int2 sab = v.con[c];
+        const int lm = v.w_lm[sab.x];
+        const double2* D2 = reinterpret_cast<const double2*>(v.Dinv + (size_t)lm * 6);
+        const double2 da = D2[0], db = D2[1], dc = D2[2];
+        const double2 ga0 = G2[(size_t)sab.x * 2], ga1 = G2[(size_t)sab.x * 2 + 1];
+        const double2 gb0 = G2[(size_t)sab.y * 2], gb1 = G2[(size_t)sab.y * 2 + 1];
+        const double d00 = da.x, d01 = da.y, d02 = db.x, d11 = db.y, d12 = dc.x, d22 = dc.y;
+        double Ja0[6], Ja1[6], Qa0[3], Qa1[3], Jb0[6], Jb1[6], Qb0[3], Qb1[3];
+        slot_factors(ci, ga0.x, ga0.y, ga1.x, ga1.y, Ja0, Ja1, Qa0, Qa1);
+        slot_factors(cj, gb0.x, gb0.y, gb1.x, gb1.y, Jb0, Jb1, Qb0, Qb1);
+        if (diag) {
+            const double2* db2 = reinterpret_cast<const double2*>(v.db + (size_t)lm * 4);
+            const double2 dba = db2[0];
+            const double e0 = dba.x, e1 = dba.y, e2 = db2[1].x;
+            const double s0 = Qa0[0] * e0 + Qa0[1] * e1 + Qa0[2] * e2, s1 = Qa1[0] * e0 + Qa1[1] * e1 + Qa1[2] * e2;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) yv[r] += Ja0[r] * s0 + Ja1[r] * s1;
+        }
+        // M = Qa D Qb^T (2 x 2)
+        const double t00 = Qa0[0] * d00 + Qa0[1] * d01 + Qa0[2] * d02, t01 = Qa0[0] * d01 + Qa0[1] * d11 + Qa0[2] * d12, t02 = Qa0[0] * d02 + Qa0[1] * d12 + Qa0[2] * d22;
+        const double t10 = Qa1[0] * d00 + Qa1[1] * d01 + Qa1[2] * d02, t11 = Qa1[0] * d01 + Qa1[1] * d11 + Qa1[2] * d12, t12 = Qa1[0] * d02 + Qa1[1] * d12 + Qa1[2] * d22;
+        const double m00 = t00 * Qb0[0] + t01 * Qb0[1] + t02 * Qb0[2], m01 = t00 * Qb1[0] + t01 * Qb1[1] + t02 * Qb1[2];
+        const double m10 = t10 * Qb0[0] + t11 * Qb0[1] + t12 * Qb0[2], m11 = t10 * Qb1[0] + t11 * Qb1[1] + t12 * Qb1[2];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const double n0 = Ja0[r] * m00 + Ja1[r] * m10, n1 = Ja0[r] * m01 + Ja1[r] * m11;
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) acc[r * 6 + cc] += n0 * Jb0[cc] + n1 * Jb1[cc];
+        }
+    }
+    double* R = red[wave];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) R[lane * 37 + k] = acc[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double val = 0;
+    if (lane < 36) {
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for (int j = 0; j < 64; j += 4) {
+            s0 += R[(j + 0) * 37 + lane]; s1 += R[(j + 1) * 37 + lane]; s2 += R[(j + 2) * 37 + lane]; s3 += R[(j + 3) * 37 + lane];
+        }
+        val = (s0 + s1) + (s2 + s3);
+    }
+    double yval = 0;
+    if (diag) {                                           // uniform per workgroup
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < 6; ++k) R[lane * 7 + k] = yv[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 6) {
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int j = 0; j < 64; j += 4) { s0 += R[(j + 0) * 7 + lane]; s1 += R[(j + 1) * 7 + lane]; s2 += R[(j + 2) * 7 + lane]; s3 += R[(j + 3) * 7 + lane]; }
+            yval = (s0 + s1) + (s2 + s3);
+        }
+    }
+    if (SPLIT) {
+        __shared__ double ypart[4][6];
+        if (lane < 36) part[wave][lane] = val;
+        if (diag && lane < 6) ypart[wave][lane] = yval;
+        __syncthreads();
+        if (wave != 0) return;
+        if (lane < 36) val = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        if (diag && lane < 6) yval = ((ypart[0][lane] + ypart[1][lane]) + ypart[2][lane]) + ypart[3][lane];
+    }
+    if (diag && lane < 6) v.y[ij.x * 6 + lane] = v.bc[(size_t)ij.x * 6 + lane] - yval;
+    if (lane < 36) {
+        const int r = lane / 6, c = lane % 6;
+        if (ij.x == ij.y) {
+            double u = v.U[(size_t)ij.x * 36 + r * 6 + c] + (r == c ? lambda : 0.0);
+            v.S[(size_t)(ij.x * 6 + c) * v.n_pad + (ij.x * 6 + r)] = u - val;
+        } else {
+            v.S[(size_t)(ij.x * 6 + r) * v.n_pad + (ij.y * 6 + c)] = -val;
+        }
+    }
+}
+
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_schur_rhs(BaDeviceView v)
 {
@@ -666,6 +806,20 @@ __global__ __launch_bounds__(256) void k_backsub(BaDeviceView v, double lambda)
     if (l < v.n_lm) {
         const int s1 = v.lm_wptr[l + 1];
         for (int s = v.lm_wptr[l] + sub; s < s1; s += BACKSUB_LPL) {
+            if (v.compact) {          // W^T x = Q^T (Jc x), uniform branch
+                const int hc = v.w_hc[s];
+                const double2* G2 = reinterpret_cast<const double2*>(v.W + (size_t)s * 4);
+                const double2 g0 = G2[0], g1 = G2[1];
+                const double2* x2 = reinterpret_cast<const double2*>(v.xc + (size_t)hc * 6);
+                const double2 xa = x2[0], xb = x2[1], xd = x2[2];
+                const CamConst k = load_cam_const(v.camR, hc);
+                double J0[6], J1[6], Q0[3], Q1[3];
+                slot_factors(k, g0.x, g0.y, g1.x, g1.y, J0, J1, Q0, Q1);
+                const double u0 = -(J0[0] * xa.x + J0[1] * xa.y + J0[2] * xb.x + J0[3] * xb.y + J0[4] * xd.x + J0[5] * xd.y);
+                const double u1 = -(J1[0] * xa.x + J1[1] * xa.y + J1[2] * xb.x + J1[3] * xb.y + J1[4] * xd.x + J1[5] * xd.y);
+                c0 += Q0[0] * u0 + Q1[0] * u1; c1 += Q0[1] * u0 + Q1[1] * u1; c2 += Q0[2] * u0 + Q1[2] * u1;
+                continue;
+            }
             const double2* W2 = reinterpret_cast<const double2*>(v.W + (size_t)s * 18);
             const double2* x2 = reinterpret_cast<const double2*>(v.xc + (size_t)v.w_hc[s] * 6);
             double W[18], x[6];
@@ -944,6 +1098,7 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
                 double Wacc[18];
 #pragma unroll
                 for (int k = 0; k < 18; ++k) Wacc[k] = 0;
+                double cg0 = 0, cg1 = 0, cg2 = 0, cg3 = 0;          // COMPACT form of the slot (an inactive observation weighs nothing)
                 if (v.L_active[i]) {
                     const int cam = v.L_cam[i];
                     PoseD P = load_pose(v.pose_cur, cam);
@@ -955,6 +1110,7 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
                     huber(info * (g.e0 * g.e0 + g.e1 * g.e1), delta, rho0, rho1);
                     chi += rho0;
                     const double w = info * rho1;
+                    cg0 = g.x / g.z; cg1 = g.y / g.z; cg2 = 1.0 / g.z; cg3 = w;
                     const double r0 = -info * g.e0 * rho1, r1 = -info * g.e1 * rho1;
                     double R[9], Jp[6];
                     q_to_R(P.qx, P.qy, P.qz, P.qw, R);
@@ -967,7 +1123,7 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
                     V[3] += Jp[1] * w * Jp[1] + Jp[4] * w * Jp[4];
                     V[4] += Jp[1] * w * Jp[2] + Jp[4] * w * Jp[5];
                     V[5] += Jp[2] * w * Jp[2] + Jp[5] * w * Jp[5];
-                    if (slot >= 0) {
+                    if (slot >= 0 && !v.compact) {
                         double Jc[12];
                         jac_pose(g, f, Jc);
 #pragma unroll
@@ -977,9 +1133,14 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
                     }
                 }
                 if (slot >= 0) {
-                    double2* Wd = reinterpret_cast<double2*>(v.W + (size_t)slot * 18);                // 144-byte block, 16-byte aligned: nine 128-bit stores
+                    if (v.compact) {
+                        double2* Gd = reinterpret_cast<double2*>(v.W + (size_t)slot * 4);
+                        Gd[0] = make_double2(cg0, cg1); Gd[1] = make_double2(cg2, cg3);
+                    } else {
+                        double2* Wd = reinterpret_cast<double2*>(v.W + (size_t)slot * 18);            // 144-byte block, 16-byte aligned: nine 128-bit stores
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) Wd[k] = make_double2(Wacc[2 * k], Wacc[2 * k + 1]);
+                        for (int k = 0; k < 9; ++k) Wd[k] = make_double2(Wacc[2 * k], Wacc[2 * k + 1]);
+                    }
                 }
             }
         }
@@ -1075,6 +1236,14 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
         const int cam = v.hc2cam[hc];
         PoseD P = load_pose(v.pose_cur, cam);
         const double f = v.camK[cam * 4];
+        if (v.compact && quarter == 0 && tid == 0) {
+            double R[9];
+            q_to_R(P.qx, P.qy, P.qz, P.qw, R);
+            double* cr = v.camR + (size_t)hc * 12;
+            cr[0] = f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) cr[1 + k] = R[k];
+        }
         double A[21], b[6];
 #pragma unroll
         for (int k = 0; k < 21; ++k) A[k] = 0;
@@ -1678,7 +1847,10 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, do
         const int nb_lm = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm, 256) : 0;
         hipLaunchKernelGGL(k_lm_invert, dim3(nb_lm + std::max(1, std::min(8, cdiv(v.n_pad, 256)))), dim3(256), 0, st, v, lambda, nb_lm, rhs_in_blocks ? 1 : 0, pad_diag);
     }
-    if (v.n_blk > 0) {
+    if (v.n_blk > 0 && v.compact) {
+        if (v.n_blk <= SPLIT_BLOCKS_BELOW) hipLaunchKernelGGL(k_schur_block_compact<true>, dim3(v.n_blk), dim3(256), 0, st, v, lambda_cam);
+        else hipLaunchKernelGGL(k_schur_block_compact<false>, dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda_cam);
+    } else if (v.n_blk > 0) {
         static const bool gather = std::getenv("MAGE_BA_SCHUR_GATHER") != nullptr;      // the lane-per-contribution loads, for comparison
         if (v.n_blk <= SPLIT_BLOCKS_BELOW) {
             if (gather) hipLaunchKernelGGL((k_schur_block<true, false>), dim3(v.n_blk), dim3(256), 0, st, v, lambda_cam);
@@ -1726,6 +1898,11 @@ void ba_small_linearize(const BaDeviceView& v, double delta, bool want_maxdiag, 
 // The same kernel for LARGE tether-free problems in which every observation owns its W block: k_error + k_linearize_lm +
 // k_linearize_cam in one launch -- the residuals are computed once, a landmark's observations by eight lanes, the chi2 folded by the
 // last block.  S is cleared by ba_launch_schur, max |diag| comes from ba_launch_maxdiag.
+bool ba_compact_w_enabled()
+{
+    static const bool off = std::getenv("MAGE_BA_MATERIAL_W") != nullptr;
+    return !off;
+}
 bool ba_fused_linearize_applies(const BaDeviceView& v)
 {
     static const bool off = std::getenv("MAGE_BA_NO_FUSED_LINEARIZE") != nullptr;
