@@ -625,6 +625,20 @@ __device__ __forceinline__ CamConst load_cam_const(const double* __restrict__ ca
     k.f = a.x; k.R[0] = a.y; k.R[1] = b.x; k.R[2] = b.y; k.R[3] = c.x; k.R[4] = c.y; k.R[5] = d.x; k.R[6] = d.y; k.R[7] = e.x; k.R[8] = e.y;
     return k;
 }
+__device__ __forceinline__ double uniform_d(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ CamConst uniform_cam_const(const CamConst& k)
+{
+    CamConst u;
+    u.f = uniform_d(k.f);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) u.R[i] = uniform_d(k.R[i]);
+    return u;
+}
 // Jc rows (J0, J1) and Q rows (Q0, Q1) of a slot
 __device__ __forceinline__ void slot_factors(const CamConst& k, double a, double b, double iz, double w, double J0[6], double J1[6], double Q0[3], double Q1[3])
 {
@@ -640,7 +654,7 @@ template <bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block_compact(BaDeviceView v, double lambda)
 {
     constexpr int NW = SPLIT ? 4 : SCHUR_WAVES;
-    __shared__ double red[NW][64 * 37];
+    __shared__ double red[NW][32 * 37];      // the two halves of a wavefront are added in registers first: 9.5 KB per wavefront
     __shared__ double part[SPLIT ? 4 : 1][36];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int b;
@@ -660,7 +674,7 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block_
     for (int k = 0; k < 36; ++k) acc[k] = 0;
     const int2 ij = v.blk_ij[b];
     const bool diag = ij.x == ij.y;
-    const CamConst ci = load_cam_const(v.camR, ij.x), cj = load_cam_const(v.camR, ij.y);
+    const CamConst ci = uniform_cam_const(load_cam_const(v.camR, ij.x)), cj = uniform_cam_const(load_cam_const(v.camR, ij.y));   // in SGPRs: 40 VGPRs less
     double yv[6] = { 0, 0, 0, 0, 0, 0 };
     const int c_end = v.blk_ptr[b + 1];
     const double2* G2 = reinterpret_cast<const double2*>(v.W);
@@ -681,23 +695,29 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block_
             const double e0 = dba.x, e1 = dba.y, e2 = db2[1].x;
             const double s0 = Qa0[0] * e0 + Qa0[1] * e1 + Qa0[2] * e2, s1 = Qa1[0] * e0 + Qa1[1] * e1 + Qa1[2] * e2;
 #pragma unroll
-            for (int r = 0; r < 6; ++r) yv[r] += Ja0[r] * s0 + Ja1[r] * s1;
+            for (int r = 0; r < 6; ++r) yv[r] += r == 4 ? Ja1[r] * s1 : r == 3 ? Ja0[r] * s0 : Ja0[r] * s0 + Ja1[r] * s1;
         }
         // M = Qa D Qb^T (2 x 2)
         const double t00 = Qa0[0] * d00 + Qa0[1] * d01 + Qa0[2] * d02, t01 = Qa0[0] * d01 + Qa0[1] * d11 + Qa0[2] * d12, t02 = Qa0[0] * d02 + Qa0[1] * d12 + Qa0[2] * d22;
         const double t10 = Qa1[0] * d00 + Qa1[1] * d01 + Qa1[2] * d02, t11 = Qa1[0] * d01 + Qa1[1] * d11 + Qa1[2] * d12, t12 = Qa1[0] * d02 + Qa1[1] * d12 + Qa1[2] * d22;
         const double m00 = t00 * Qb0[0] + t01 * Qb0[1] + t02 * Qb0[2], m01 = t00 * Qb1[0] + t01 * Qb1[1] + t02 * Qb1[2];
         const double m10 = t10 * Qb0[0] + t11 * Qb0[1] + t12 * Qb0[2], m11 = t10 * Qb1[0] + t11 * Qb1[1] + t12 * Qb1[2];
+        // (Jc has two structural zeros, J0[4] and J1[3]: the products with them are left out by hand -- the compiler may not drop 0 * x)
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-            const double n0 = Ja0[r] * m00 + Ja1[r] * m10, n1 = Ja0[r] * m01 + Ja1[r] * m11;
+            const double n0 = r == 4 ? Ja1[r] * m10 : r == 3 ? Ja0[r] * m00 : Ja0[r] * m00 + Ja1[r] * m10;
+            const double n1 = r == 4 ? Ja1[r] * m11 : r == 3 ? Ja0[r] * m01 : Ja0[r] * m01 + Ja1[r] * m11;
 #pragma unroll
-            for (int cc = 0; cc < 6; ++cc) acc[r * 6 + cc] += n0 * Jb0[cc] + n1 * Jb1[cc];
+            for (int cc = 0; cc < 6; ++cc) acc[r * 6 + cc] += cc == 4 ? n1 * Jb1[cc] : cc == 3 ? n0 * Jb0[cc] : n0 * Jb0[cc] + n1 * Jb1[cc];
         }
     }
     double* R = red[wave];
 #pragma unroll
-    for (int k = 0; k < 36; ++k) R[lane * 37 + k] = acc[k];
+    for (int k = 0; k < 36; ++k) acc[k] += __shfl_xor(acc[k], 32, 64);
+    if (lane < 32) {
+#pragma unroll
+        for (int k = 0; k < 36; ++k) R[lane * 37 + k] = acc[k];
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -705,7 +725,7 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block_
     if (lane < 36) {
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
-        for (int j = 0; j < 64; j += 4) {
+        for (int j = 0; j < 32; j += 4) {
             s0 += R[(j + 0) * 37 + lane]; s1 += R[(j + 1) * 37 + lane]; s2 += R[(j + 2) * 37 + lane]; s3 += R[(j + 3) * 37 + lane];
         }
         val = (s0 + s1) + (s2 + s3);
@@ -716,14 +736,18 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block_
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int k = 0; k < 6; ++k) R[lane * 7 + k] = yv[k];
+        for (int k = 0; k < 6; ++k) yv[k] += __shfl_xor(yv[k], 32, 64);
+        if (lane < 32) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) R[lane * 7 + k] = yv[k];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane < 6) {
             double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
-            for (int j = 0; j < 64; j += 4) { s0 += R[(j + 0) * 7 + lane]; s1 += R[(j + 1) * 7 + lane]; s2 += R[(j + 2) * 7 + lane]; s3 += R[(j + 3) * 7 + lane]; }
+            for (int j = 0; j < 32; j += 4) { s0 += R[(j + 0) * 7 + lane]; s1 += R[(j + 1) * 7 + lane]; s2 += R[(j + 2) * 7 + lane]; s3 += R[(j + 3) * 7 + lane]; }
             yval = (s0 + s1) + (s2 + s3);
         }
     }
