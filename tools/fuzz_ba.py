@@ -45,6 +45,11 @@ def one(case, rng):
         s.tethers = scene.make_tethers(s, n_dist=int(rng.integers(0, 3)), n_rot=int(rng.integers(0, 3)), n_xf=int(rng.integers(1, 3)), seed=0x7E7E9000 + case)
     points_fixed = rng.random() < 0.25
     hub = [float(rng.choice([0.9, 1.8, 4.0]))] * int(rng.integers(1, 5))
+    # a free camera seen through fewer than three points has a pose the observations do not determine (damping and tethers alone hold
+    # it): rounding differences are then amplified without bound, and neither side is "right" -- not a parity case
+    per_cam = np.bincount(s.obs_cam.astype(np.int64), minlength=n_cams)
+    if (~fixed).any() and per_cam[~fixed].min() < 3 and (points_fixed or tethered):
+        return "skipped (a free camera with fewer than three observations)"
     calls = [(hub, float(rng.choice([1e30, 30.0, 9.0])))] + [([0.9], float(rng.choice([1e30, 16.0, 5.0])))] * int(rng.integers(0, 3))
     try:
         T._compare_with_oracle(s, points_fixed, calls, rtol=1e-6 if tethered else 1e-8)
