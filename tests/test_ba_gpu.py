@@ -114,6 +114,41 @@ def test_large_path_variants_match_oracle():
     _compare_with_oracle(s, False, [([1.8], 1e30), ([0.9], 1e30)], rtol=1e-6)
 
 
+def test_compact_and_materialised_w_agree(tmp_path):
+    """Large tether-free problems keep W as 32-byte rank-2 factors; MAGE_BA_MATERIAL_W=1 (read once per process, hence
+    the child) materialises the 6x3 blocks instead.  Same algebra, different association: the states agree to rounding, the integer
+    outputs exactly."""
+    import json, os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, json
+        sys.path.insert(0, %r)
+        import numpy as np
+        from mageslam_amd import scene
+        from mageslam_amd.bundler import BundlerLib, load_scene
+        s = scene.make_scene(n_cams=60, n_pts=6000, n_obs=60000, seed=0x5EED0B10, outlier_frac=0.01)
+        b = BundlerLib(False); load_scene(b, s, bulk=True)
+        outs, tr = [], []
+        for hub, thr in [([1.8], 25.0), ([0.9, 0.9], 16.0), ([0.9], 9.0)]:
+            o = []; b.StepBundleAdjustment(hub, thr, o); outs.append(o); tr.append([(t["code"], t["trials"], t["chi_after"]) for t in b.trace()])
+        np.save(sys.argv[1], np.concatenate([b.poses_f64().ravel(), b.points_f64().ravel()]))
+        print("RESULT " + json.dumps(dict(outs=outs, tr=tr)))
+    """) % root
+    res = {}
+    for tag, env in (("compact", {}), ("material", {"MAGE_BA_MATERIAL_W": "1"})):
+        f = str(tmp_path / (tag + ".npy"))
+        p = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+        res[tag] = (np.load(f), json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    a, b = res["compact"], res["material"]
+    assert a[1]["outs"] == b[1]["outs"]
+    assert [[t[:2] for t in c] for c in a[1]["tr"]] == [[t[:2] for t in c] for c in b[1]["tr"]]
+    for ca, cb in zip(a[1]["tr"], b[1]["tr"]):
+        for ta, tb in zip(ca, cb):
+            assert abs(ta[2] - tb[2]) <= 1e-10 * tb[2]
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-9, atol=1e-10)
+
+
 def test_concurrent_handles_on_separate_threads():
     """SURVEY 8b threading contract: every BundlerLib instance is thread-confined, several run concurrently on different
     threads (mapping, loop closure, tracking).  Four handles, each on its own thread and HIP stream, interleaved on one
