@@ -830,8 +830,8 @@ mage_status initialize_optimization(mage_ba* h)
     h->prof.factor_flops_each = (double)n * n * n / 3.0;      // algorithmic: the system's order, not the padded one
     {   // algorithmic bytes of the HBM-bound stages for this problem (each array counted once per stage)
         const double dL = nL, dW = nw, dP = nlm, dC = nfc;
-        // a W slot is 144 bytes materialised, 32 in the compact form lm_solve selects for large tether-free problems (ba_kernels.h)
-        const bool compact_w = points_free && !h->dup_slots && nT == 0 && nfc * 6 > 128 && h->shard_ranks >= 0 && ba_compact_w_enabled();
+        // a W slot is 144 bytes materialised, 32 in the compact form lm_solve selects for large problems without shared slots (ba_kernels.h)
+        const bool compact_w = points_free && !h->dup_slots && (nfc * 6 > 128 || nT > 0 || h->shard_ranks > 0) && h->shard_ranks >= 0 && ba_compact_w_enabled();
         const double bW = compact_w ? 32.0 : 144.0;
         h->prof.linearize_bytes_each = dL * (3 * 24 + 16 + 4) + dW * bW + dP * (80 + 3 * 32) + dC * 336;
         h->prof.schur_bytes_each = dP * (160 + 48 + 32) + 2 * bW * dW + 8.0 * (double)ncon + 288.0 * nblk + 4.0 * (double)n_pad * n_pad;

@@ -63,7 +63,7 @@ struct BaDeviceView {
     double* V; double* bp; // n_lm x 6 (sym: 00 01 02 11 12 22), n_lm x 4
     double* W;             // n_w x 18  (6x3 row-major); in COMPACT form the same memory holds n_w x 4: x/z, y/z, 1/z of the point in the
                            // slot's camera and the observation's robust weight -- W = Jc^T w Jp is a function of those and of the camera
-    int compact;           // 1: large tether-free problems without shared slots keep W in that form (set per LM iteration by the host)
+    int compact;           // 1: large problems without shared slots keep W in that form (set per LM iteration by the host)
     double* camR;          // n_fc x 12 : f and the rotation R (row-major) of every free camera at the linearisation point (COMPACT form)
     double* Dinv; double* db;  // n_lm x 6, n_lm x 4
     double* S;             // n_pad x n_pad column-major, lower triangle valid
@@ -103,7 +103,7 @@ void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_
 bool ba_small_applies(const BaDeviceView& v);
 void ba_small_init_device();                                                                          // once per device: LDS opt-in
 bool ba_compact_w_enabled();                                                                          // false with MAGE_BA_MATERIAL_W=1 (A/B, tests)
-bool ba_fused_linearize_applies(const BaDeviceView& v);                                              // large, tether-free, one observation per W slot
+bool ba_fused_linearize_applies(const BaDeviceView& v);                                              // large, one observation per W slot
 void ba_fused_linearize(const BaDeviceView& v, double huber_delta, int* counter, hipStream_t st);    // = ba_launch_error(current) + ba_launch_linearize in one launch
 void ba_small_linearize(const BaDeviceView& v, double huber_delta, bool want_maxdiag, int* counter, hipStream_t st);   // U,bc,V,bp,W, S/y zeroed, scal[SC_CHI] (+ SC_MAXDIAG)
 void ba_small_solve_trial(const BaDeviceView& v, double lambda, double huber_delta, double* linv_ws, int* counter, hipStream_t st);    // S, y, xc, trial state, SC_SCALE, SC_CHI_TRIAL, SC_CHOL_OK/STALL

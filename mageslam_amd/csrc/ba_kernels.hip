@@ -1919,7 +1919,7 @@ void ba_small_linearize(const BaDeviceView& v, double delta, bool want_maxdiag, 
     const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm * (v.dup_slots ? 1 : SMALL_LPL), 256) : 0;
     hipLaunchKernelGGL(k_small_linearize, dim3(nbL + v.n_fc * SMALL_CPC + 1), dim3(256), 0, st, v, delta, nbL, want_maxdiag ? 1 : 0, counter, SMALL_CPC, 1);
 }
-// The same kernel for LARGE tether-free problems in which every observation owns its W block: k_error + k_linearize_lm +
+// The same kernel for LARGE problems in which every observation owns its W block: k_error + k_linearize_lm +
 // k_linearize_cam in one launch -- the residuals are computed once, a landmark's observations by eight lanes, the chi2 folded by the
 // last block.  S is cleared by ba_launch_schur, max |diag| comes from ba_launch_maxdiag.
 bool ba_compact_w_enabled()
@@ -1930,7 +1930,7 @@ bool ba_compact_w_enabled()
 bool ba_fused_linearize_applies(const BaDeviceView& v)
 {
     static const bool off = std::getenv("MAGE_BA_NO_FUSED_LINEARIZE") != nullptr;
-    return !off && !v.dup_slots && v.n_T == 0 && v.n_fc > 0 && v.n_L > 0;
+    return !off && !v.dup_slots && v.n_fc > 0 && v.n_L > 0;
 }
 void ba_fused_linearize(const BaDeviceView& v, double delta, int* counter, hipStream_t st)
 {
@@ -1938,6 +1938,8 @@ void ba_fused_linearize(const BaDeviceView& v, double delta, int* counter, hipSt
     const int nbC = ((v.n_fc + 7) / 8) * 8 + 8;          // every XCD gets ceil(n_fc / 8) camera workgroups wherever its first one falls
     hipLaunchKernelGGL(k_small_linearize, dim3(nbL + nbC), dim3(256), 0, st, v, delta, nbL, 0, counter, 1, 0);
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nbL + nbC, 1, v.scal + SC_CHI, 1);
+    tether_launch_error(v, false, st);          // the pose-pose edges add their chi2, U and b_c on top (nothing is launched without them)
+    tether_launch_linearize(v, st);
 }
 void ba_small_solve_trial(const BaDeviceView& v, double lambda, double delta, double* linv_ws, int* counter, hipStream_t st)
 {
