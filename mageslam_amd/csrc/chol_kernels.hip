@@ -77,6 +77,22 @@ __device__ __forceinline__ void load_tile(double* __restrict__ dst, const double
     }
 }
 
+// Two LDS layouts of a diagonal tile, both column-major inside a 16x16 block:
+//   LayLDC     the whole 128 x 128 square with column pitch LDC (147 KB): the small dense solve, which also substitutes out of it;
+//   LayPacked  the 36 blocks of the lower triangle behind each other (block (rb, cb), rb >= cb, at (rb (rb + 1) / 2 + cb) * 256):
+//              72 KB, so that TWO workgroups of the trailing update fit a compute unit beside the one that factors the next
+//              diagonal tile (LDS is sized per launch, not per workgroup).  Register r of lane l of an MFMA operand / accumulator
+//              is element 64 r + l of its block: every wave-wide LDS access is 512 contiguous bytes.
+struct LayLDC {
+    static constexpr int PITCH = LDC;
+    static __device__ __forceinline__ int blk(int rb, int cb) { return cb * NB * LDC + rb * NB; }
+};
+struct LayPacked {
+    static constexpr int PITCH = NB;
+    static __device__ __forceinline__ int blk(int rb, int cb) { return (rb * (rb + 1) / 2 + cb) * (NB * NB); }
+};
+constexpr int PACKED_TILE_DOUBLES = (NBLK * (NBLK + 1) / 2) * NB * NB;      // 9216
+
 // ---------------------------------------------------------------------------------------------
 // 16x16 diagonal block at A(p0, p0): Cholesky in registers by one wavefront, together with the inverse of the factor.
 // Lane l (mod 16; the four 16-lane rows of the wavefront run identical copies) owns ROW l of the block (a[c] = A[l][c])
@@ -189,12 +205,14 @@ __device__ __forceinline__ void fb_column(double (&a)[NB], double (&x)[NB], doub
     h = hn; q4 = q4n; e0 = e0n; a2 = a2n; x2 = x2n;
 }
 
-__device__ __noinline__ bool factor_block16(double* __restrict__ A, int p0, int lane, double* __restrict__ Li, double* __restrict__ Linv_out)
+// B: the block (element (r, c) at B[c * PITCH + r])
+template <int PITCH>
+__device__ __noinline__ bool factor_block16(double* __restrict__ B, int lane, double* __restrict__ Li, double* __restrict__ Linv_out)
 {
     const int l = lane & 15;
     double a[NB], x[NB];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) { a[c] = A[(p0 + c) * LDC + p0 + l]; x[c] = (l == c) ? 1.0 : 0.0; }
+    for (int c = 0; c < NB; ++c) { a[c] = B[c * PITCH + l]; x[c] = (l == c) ? 1.0 : 0.0; }
     const double d0 = dpp_bcast_nop<0>(a[0]);
     double dmin = d0;
     double sq, rs;
@@ -214,7 +232,7 @@ __device__ __noinline__ bool factor_block16(double* __restrict__ A, int p0, int 
     // stored inverse for diagonal blocks, the updates only touch blocks below them, S's upper triangle is never referenced).
     if (lane < NB) {
 #pragma unroll
-        for (int c = 0; c < NB; ++c) A[(p0 + c) * LDC + p0 + l] = a[c];
+        for (int c = 0; c < NB; ++c) B[c * PITCH + l] = a[c];
 #pragma unroll
         for (int i = 0; i < NB; ++i) Li[i * NB + l] = x[i];
     }
@@ -222,43 +240,53 @@ __device__ __noinline__ bool factor_block16(double* __restrict__ A, int p0, int 
     return __builtin_amdgcn_ballot_w64(!(dmin > 0.0)) != 0;
 }
 
-// one 16x16 tile of the in-LDS trailing update: C(ri.., cj..) -= X(ri.., p0..p0+15) X(cj.., p0..p0+15)^T.
-// D[m][n] = C[row ri + n][col cj + m]: the accumulator's lane&15 direction is the LDS-contiguous one.
-__device__ __forceinline__ void lds_update_tile(double* __restrict__ A, int ri, int cj, int p0, int lane)
+// element of register r of an MFMA operand / accumulator inside a block
+template <class LAY>
+__device__ __forceinline__ int frag(int r, int lane) { return (4 * r + (lane >> 4)) * LAY::PITCH + (lane & 15); }
+
+// one 16x16 block of the in-LDS trailing update: block (bi, bj) -= X(bi, bp) X(bj, bp)^T.
+// D[m][n] = C[row n][col m] of the block: the accumulator's lane&15 direction is the LDS-contiguous one.
+template <class LAY>
+__device__ __forceinline__ void lds_update_tile(double* __restrict__ A, int bi, int bj, int bp, int lane)
 {
+    double* C = A + LAY::blk(bi, bj);
+    const double* Xa = A + LAY::blk(bj, bp);
+    const double* Xb = A + LAY::blk(bi, bp);
     double4_t acc;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = A[(cj + (lane >> 4) + 4 * r) * LDC + ri + (lane & 15)];
+    for (int r = 0; r < 4; ++r) acc[r] = C[frag<LAY>(r, lane)];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const double aop = -A[(p0 + 4 * r + (lane >> 4)) * LDC + cj + (lane & 15)];
-        const double bop = A[(p0 + 4 * r + (lane >> 4)) * LDC + ri + (lane & 15)];
+        const double aop = -Xa[frag<LAY>(r, lane)];
+        const double bop = Xb[frag<LAY>(r, lane)];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) A[(cj + (lane >> 4) + 4 * r) * LDC + ri + (lane & 15)] = acc[r];
+    for (int r = 0; r < 4; ++r) C[frag<LAY>(r, lane)] = acc[r];
 }
 
-// Left-looking form of the same update: C(ri.., cj..) -= sum over the nk column blocks 0, 16, .., 16 (nk - 1) of
-// X(ri.., p..p+15) X(cj.., p..p+15)^T, accumulator loaded and stored once, operand reads of block k + 1 in flight
-// while block k's MFMAs run.
-__device__ __forceinline__ void lds_update_tile_left(double* __restrict__ A, int ri, int cj, int nk, int lane)
+// Left-looking form of the same update: block (bi, bj) -= sum over the nk column blocks kb = 0 .. nk - 1 of
+// X(bi, kb) X(bj, kb)^T, accumulator loaded and stored once, operand reads of block kb + 1 in flight
+// while block kb's MFMAs run.
+template <class LAY>
+__device__ __forceinline__ void lds_update_tile_left(double* __restrict__ A, int bi, int bj, int nk, int lane)
 {
+    double* C = A + LAY::blk(bi, bj);
     double4_t acc;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = A[(cj + (lane >> 4) + 4 * r) * LDC + ri + (lane & 15)];
+    for (int r = 0; r < 4; ++r) acc[r] = C[frag<LAY>(r, lane)];
     double aop[2][4], bop[2][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        aop[0][r] = -A[(4 * r + (lane >> 4)) * LDC + cj + (lane & 15)];
-        bop[0][r] = A[(4 * r + (lane >> 4)) * LDC + ri + (lane & 15)];
+        aop[0][r] = -A[LAY::blk(bj, 0) + frag<LAY>(r, lane)];
+        bop[0][r] = A[LAY::blk(bi, 0) + frag<LAY>(r, lane)];
     }
     for (int kb = 0; kb < nk; kb += 2) {
         if (kb + 1 < nk) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                aop[1][r] = -A[((kb + 1) * NB + 4 * r + (lane >> 4)) * LDC + cj + (lane & 15)];
-                bop[1][r] = A[((kb + 1) * NB + 4 * r + (lane >> 4)) * LDC + ri + (lane & 15)];
+                aop[1][r] = -A[LAY::blk(bj, kb + 1) + frag<LAY>(r, lane)];
+                bop[1][r] = A[LAY::blk(bi, kb + 1) + frag<LAY>(r, lane)];
             }
         }
 #pragma unroll
@@ -267,8 +295,8 @@ __device__ __forceinline__ void lds_update_tile_left(double* __restrict__ A, int
             if (kb + 2 < nk) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    aop[0][r] = -A[((kb + 2) * NB + 4 * r + (lane >> 4)) * LDC + cj + (lane & 15)];
-                    bop[0][r] = A[((kb + 2) * NB + 4 * r + (lane >> 4)) * LDC + ri + (lane & 15)];
+                    aop[0][r] = -A[LAY::blk(bj, kb + 2) + frag<LAY>(r, lane)];
+                    bop[0][r] = A[LAY::blk(bi, kb + 2) + frag<LAY>(r, lane)];
                 }
             }
 #pragma unroll
@@ -276,7 +304,7 @@ __device__ __forceinline__ void lds_update_tile_left(double* __restrict__ A, int
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) A[(cj + (lane >> 4) + 4 * r) * LDC + ri + (lane & 15)] = acc[r];
+    for (int r = 0; r < 4; ++r) C[frag<LAY>(r, lane)] = acc[r];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -286,16 +314,15 @@ __device__ __forceinline__ void lds_update_tile_left(double* __restrict__ A, int
 // ---------------------------------------------------------------------------------------------
 // Factor the LDS-resident tile A (column-major, pitch LDC) in place; Li = 2 x 256 doubles of LDS scratch.
 // PARTIAL: only the leading nblk 16-column blocks are factored (the rest of the tile is the identity padding of a small system).
-template <bool PARTIAL>
+template <bool PARTIAL, class LAY>
 __device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __restrict__ Li, double* __restrict__ Linv_k, int tid, int nblk = NBLK)
 {
     const int NBK = PARTIAL ? nblk : NBLK;
     const int lane = tid & 63, wave = tid >> 6;
     bool failed = false;
-    if (wave == 0) failed = factor_block16(A, 0, lane, Li, Linv_k);
+    if (wave == 0) failed = factor_block16<LAY::PITCH>(A + LAY::blk(0, 0), lane, Li, Linv_k);
     __syncthreads();
     for (int s = 0; s < NBK; ++s) {
-        const int p0 = s * NB;
         const double* Lc = Li + (s & 1) * NB * NB;
         if (wave == 3) {                           // block inverse s -> global workspace (read by k_trsm_panel / k_bsolve_persist)
             const double4_t v = *reinterpret_cast<const double4_t*>(Lc + lane * 4);
@@ -309,38 +336,39 @@ __device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __re
         if (wave == 0) {
             // strip 0 and the next diagonal block in one go: the strip's result registers ARE both MFMA operands of
             // D -= Y^T Y (register r of a lane is element [4r + (lane >> 4)][lane & 15] of Y = operand chunk r of either side)
-            const int r0 = p0 + NB;
+            double* Xs = A + LAY::blk(s + 1, s);          // strip 0: block row s + 1 of block column s
+            double* Dn = A + LAY::blk(s + 1, s + 1);      // the next diagonal block
             double4_t acc = { 0, 0, 0, 0 }, dg;
             double aop[4], bop[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 aop[r] = Lc[(lane & 15) * NB + 4 * r + (lane >> 4)];
-                bop[r] = A[(p0 + 4 * r + (lane >> 4)) * LDC + r0 + (lane & 15)];
+                bop[r] = Xs[frag<LAY>(r, lane)];
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dg[r] = A[(r0 + (lane >> 4) + 4 * r) * LDC + r0 + (lane & 15)];
+            for (int r = 0; r < 4; ++r) dg[r] = Dn[frag<LAY>(r, lane)];
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[r], bop[r], acc, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) A[(p0 + (lane >> 4) + 4 * r) * LDC + r0 + (lane & 15)] = acc[r];
+            for (int r = 0; r < 4; ++r) Xs[frag<LAY>(r, lane)] = acc[r];
 #pragma unroll
             for (int r = 0; r < 4; ++r) dg = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[r], acc[r], dg, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) A[(r0 + (lane >> 4) + 4 * r) * LDC + r0 + (lane & 15)] = dg[r];
+            for (int r = 0; r < 4; ++r) Dn[frag<LAY>(r, lane)] = dg[r];
             __builtin_amdgcn_s_waitcnt(0xc07f);
         } else {
             for (int t = wave; t < nstrips; t += 3) {
-                const int r0 = p0 + NB + t * NB;
+                double* Xs = A + LAY::blk(s + 1 + t, s);
                 double4_t acc = { 0, 0, 0, 0 };
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double aop = Lc[(lane & 15) * NB + 4 * r + (lane >> 4)];
-                    const double bop = A[(p0 + 4 * r + (lane >> 4)) * LDC + r0 + (lane & 15)];
+                    const double bop = Xs[frag<LAY>(r, lane)];
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): all operand reads of this strip are done before it is overwritten
 #pragma unroll
-                for (int r = 0; r < 4; ++r) A[(p0 + (lane >> 4) + 4 * r) * LDC + r0 + (lane & 15)] = acc[r];
+                for (int r = 0; r < 4; ++r) Xs[frag<LAY>(r, lane)] = acc[r];
             }
         }
         __syncthreads();
@@ -350,13 +378,13 @@ __device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __re
         //   wavefronts 1-3  block column s+1 below the diagonal, LEFT-looking: tile (i, s+1) -= sum_{k <= s} Y_ik Y_{s+1,k}^T
         //                   (these are the strips of the next step), and the later diagonal blocks (i, i) -= Y_is Y_is^T.
         if (wave == 0) {
-            failed |= factor_block16(A, p0 + NB, lane, Li + ((s + 1) & 1) * NB * NB, Linv_k + (s + 1) * NB * NB);
+            failed |= factor_block16<LAY::PITCH>(A + LAY::blk(s + 1, s + 1), lane, Li + ((s + 1) & 1) * NB * NB, Linv_k + (s + 1) * NB * NB);
         } else {
             const int nrow = NBK - 2 - s;                 // block rows s+2 .. 7
             for (int t = wave - 1; t < 2 * nrow; t += 3) {
                 const int i = s + 2 + (t >> 1);
-                if ((t & 1) == 0) lds_update_tile_left(A, i * NB, p0 + NB, s + 1, lane);
-                else lds_update_tile(A, i * NB, i * NB, p0, lane);
+                if ((t & 1) == 0) lds_update_tile_left<LAY>(A, i, s + 1, s + 1, lane);
+                else lds_update_tile<LAY>(A, i, i, s, lane);
             }
         }
         __syncthreads();
@@ -375,6 +403,43 @@ __device__ __forceinline__ void store_tile_lower(double* __restrict__ T, const d
     }
 }
 
+// The same two copies for LayPacked: the 36 lower blocks, 128-bit pieces along a block's columns, 18 per thread in two batches.
+__device__ __forceinline__ void block_of_index(int t, int& rb, int& cb)          // t = rb (rb + 1) / 2 + cb, 0 <= t < 36
+{
+    rb = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15) + (t >= 21) + (t >= 28);
+    cb = t - rb * (rb + 1) / 2;
+}
+__device__ __forceinline__ void load_tile_packed(double* __restrict__ dst, const double* __restrict__ src, int ld, int tid)
+{
+    constexpr int PIECES = PACKED_TILE_DOUBLES / 2, BATCH = 9;       // 4608 pieces = 256 threads x 18
+#pragma unroll
+    for (int b0 = 0; b0 < PIECES / 256; b0 += BATCH) {
+        double2 v[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e = (b0 + u) * 256 + tid, t = e >> 7, w = e & 127;      // block t, piece w: column w >> 3, rows 2 (w & 7) ..
+            int rb, cb;
+            block_of_index(t, rb, cb);
+            v[u] = *reinterpret_cast<const double2*>(src + (size_t)(cb * NB + (w >> 3)) * ld + rb * NB + 2 * (w & 7));
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e = (b0 + u) * 256 + tid;
+            *reinterpret_cast<double2*>(dst + 2 * e) = v[u];
+        }
+    }
+}
+__device__ __forceinline__ void store_tile_packed(double* __restrict__ T, const double* __restrict__ A, int ld, int tid)
+{
+#pragma unroll 6
+    for (int b0 = 0; b0 < PACKED_TILE_DOUBLES / 2 / 256; ++b0) {
+        const int e = b0 * 256 + tid, t = e >> 7, w = e & 127;
+        int rb, cb;
+        block_of_index(t, rb, cb);
+        *reinterpret_cast<double2*>(T + (size_t)(cb * NB + (w >> 3)) * ld + rb * NB + 2 * (w & 7)) = *reinterpret_cast<const double2*>(A + 2 * e);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // diagonal tile, LDS-resident, blocked by 16.  Per block s: the rows below are solved on the matrix
 // cores with the block inverse (Y = Linv A^T); then wavefront 0 updates only the NEXT diagonal block and
@@ -387,16 +452,16 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int 
                                                     double* __restrict__ ok, double* __restrict__ stall, unsigned long long* __restrict__ x_fill, int n_fill)
 {
     extern __shared__ double sm[];
-    double* A = sm;                       // column-major: A[c * LDC + r]
-    double* Li = sm + TILE * LDC;         // 2 x (16 x 16): inverse of the current / next diagonal block
+    double* A = sm;                       // LayPacked: the 36 lower blocks
+    double* Li = sm + PACKED_TILE_DOUBLES;   // 2 x (16 x 16): inverse of the current / next diagonal block
     const int tid = threadIdx.x;
     if (tid == 0) { *ok = 1.0; *stall = 0.0; }
     for (int i = tid; i < n_fill; i += 256) x_fill[i] = X_SENTINEL;
     double* T = S + (size_t)(k * TILE) * ld + (size_t)k * TILE;
-    load_tile<LDC>(A, T, ld, tid);
+    load_tile_packed(A, T, ld, tid);
     __syncthreads();
-    const bool failed = potrf_tile_lds<false>(A, Li, Linv_k, tid);
-    store_tile_lower(T, A, ld, tid);
+    const bool failed = potrf_tile_lds<false, LayPacked>(A, Li, Linv_k, tid);
+    store_tile_packed(T, A, ld, tid);
     if (tid == 0 && failed) *ok = 0.0;
 }
 
@@ -607,10 +672,10 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
         __syncthreads();
         double* A = sm;
         double* T = S + (size_t)(j0 * TILE) * ld + (size_t)j0 * TILE;
-        load_tile<LDC>(A, T, ld, tid);
+        load_tile_packed(A, T, ld, tid);
         __syncthreads();
-        const bool failed = potrf_tile_lds<false>(A, sm + TILE * LDC, Linv_next, tid);
-        store_tile_lower(T, A, ld, tid);
+        const bool failed = potrf_tile_lds<false, LayPacked>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
+        store_tile_packed(T, A, ld, tid);
         if (tid == 0 && failed) *ok = 0.0;
         return;
     }
@@ -766,7 +831,7 @@ __global__ __launch_bounds__(256) void k_small_solve(const double* __restrict__ 
     }
     for (int i = tid; i < np; i += 256) rhs[i] = y[i];
     __syncthreads();
-    const bool failed = potrf_tile_lds<true>(A, Li, Linv, tid, nblk);
+    const bool failed = potrf_tile_lds<true, LayLDC>(A, Li, Linv, tid, nblk);
     __threadfence_block();
     __syncthreads();
     // forward substitution L z = rhs (four partial sums per product: a dependent f64 FMA costs ~25 cycles on a lone wavefront)
@@ -825,12 +890,13 @@ void chol_init_device()
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         g_n_cu = prop.multiProcessorCount;
-    const size_t lds_diag = ((size_t)TILE * LDC + 2 * NB * NB) * sizeof(double);
+    const size_t lds_diag = ((size_t)PACKED_TILE_DOUBLES + 2 * NB * NB) * sizeof(double);
+    const size_t lds_small = ((size_t)TILE * LDC + 2 * NB * NB) * sizeof(double);
     const size_t lds_panel = (size_t)TILE * (TILE + 2) * sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bsolve_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_panel);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
 }
 
 void chol_small_solve(const double* S, const double* y, double* x, int n, int ld, double* Linv_ws, double* ok, double* stall, hipStream_t st)
@@ -848,7 +914,7 @@ void chol_small_solve(const double* S, const double* y, double* x, int n, int ld
 void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWorkspace& ws, double* ok, hipStream_t st)
 {
     const int nt = n_pad / TILE;
-    const size_t lds_diag = ((size_t)TILE * LDC + 2 * NB * NB) * sizeof(double);
+    const size_t lds_diag = ((size_t)PACKED_TILE_DOUBLES + 2 * NB * NB) * sizeof(double);
     const size_t lds_panel = (size_t)TILE * (TILE + 2) * sizeof(double);
     const size_t linv_stride = (size_t)NBLK * NB * NB;
     double* stall = ws.stall ? ws.stall : ok + 1;     // callers without a slot of their own pass a two-element ok
