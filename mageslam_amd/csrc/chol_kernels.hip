@@ -23,6 +23,7 @@
 //     transposed unknown (Y = X^T) so that results chain from MFMA to MFMA without leaving registers.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include "chol_kernels.h"
 
 namespace mage {
@@ -540,6 +541,9 @@ __global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, doubl
 // ---------------------------------------------------------------------------------------------
 // out[a][b][r] = C - sum_k L(col0.., k) L(row0.., k)^T for the (16 SUB) x (16 SUB) block whose first element is
 // S(row0, col0); D layout: element (row0 + 16 b + (lane & 15), col0 + 16 a + (lane >> 4) + 4 r).
+template <int SUBM, int SUBN, int KSTEPS, bool C_FIRST>
+__device__ __forceinline__ void update_rect(const double* __restrict__ S, int ld, int k, int row0, int col0, int lane, double4_t (&out)[SUBM][SUBN]);
+
 template <int SUB, int KSTEPS>
 __device__ __forceinline__ void update_block(const double* __restrict__ S, int ld, int k, int row0, int col0, int lane, double4_t (&out)[SUB][SUB])
 {
@@ -588,6 +592,47 @@ __device__ __forceinline__ void update_block(const double* __restrict__ S, int l
     for (int a = 0; a < SUB; ++a)
 #pragma unroll
         for (int b = 0; b < SUB; ++b) out[a][b] = cv[a][b] + acc[a][b];
+}
+
+// Rectangular form: (16 SUBM) columns x (16 SUBN) rows.  C_FIRST: the accumulators START as the C block (loaded before the first
+// operand chunk; no second register set for C) -- the form for two wavefronts per SIMD, where the registers are what is scarce.
+template <int SUBM, int SUBN, int KSTEPS, bool C_FIRST>
+__device__ __forceinline__ void update_rect(const double* __restrict__ S, int ld, int k, int row0, int col0, int lane, double4_t (&out)[SUBM][SUBN])
+{
+    const double* Pn = S + (size_t)(k * TILE + (lane >> 4)) * ld + row0 + (lane & 15);
+    const double* Pm = S + (size_t)(k * TILE + (lane >> 4)) * ld + col0 + (lane & 15);
+    const double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
+    constexpr int NCH = TILE / (4 * KSTEPS);
+    double av[2][KSTEPS][SUBM], bv[2][KSTEPS][SUBN];
+    auto load_chunk = [&](int buf, int kc) {
+#pragma unroll
+        for (int s4 = 0; s4 < KSTEPS; ++s4) {
+            const size_t off = (size_t)(kc + s4 * 4) * ld;
+#pragma unroll
+            for (int q = 0; q < SUBM; ++q) av[buf][s4][q] = Pm[off + q * 16];
+#pragma unroll
+            for (int q = 0; q < SUBN; ++q) bv[buf][s4][q] = Pn[off + q * 16];
+        }
+    };
+    load_chunk(0, 0);
+#pragma unroll
+    for (int a = 0; a < SUBM; ++a)
+#pragma unroll
+        for (int b = 0; b < SUBN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[a][b][r] = C_FIRST ? C[(size_t)(a * 16 + 4 * r) * ld + b * 16] : 0.0;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < NCH) load_chunk(buf ^ 1, (ch + 1) * 4 * KSTEPS);
+#pragma unroll
+        for (int s4 = 0; s4 < KSTEPS; ++s4)
+#pragma unroll
+            for (int a = 0; a < SUBM; ++a)
+#pragma unroll
+                for (int b = 0; b < SUBN; ++b)
+                    out[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[buf][s4][a], bv[buf][s4][b], out[a][b], 0, 0, 0);
+    }
 }
 
 // Grid of the trailing update of step k (tiles (i, j), j0 = k + 1 <= j <= i < nt), in dispatch order:
@@ -705,6 +750,84 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
     double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = out[a][b][r];
+}
+
+__global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
+                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int n_q4)
+{
+    extern __shared__ double sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j0 = k + 1, mt = nt - j0;
+    const int n_tiles = mt * (mt + 1) / 2;
+    const int first_rhs = NDIAG + 2 * (n_tiles - 1);              // tile indices 1 .. n_tiles - 1, two workgroups (column halves) each
+    const int bid = blockIdx.x;
+    if (bid >= first_rhs) {
+        const int i = k + 1 + (bid - first_rhs);
+        if (i >= nt) return;
+        const double* Lik = S + (size_t)(k * TILE) * ld + (size_t)i * TILE;
+        const double* yk = y + (size_t)k * TILE;
+        for (int r = tid; r < TILE; r += 256) {
+            double acc = 0;
+#pragma unroll 8
+            for (int c = 0; c < TILE; ++c) acc = __builtin_fma(Lik[(size_t)c * ld + r], yk[c], acc);
+            y[(size_t)i * TILE + r] -= acc;
+        }
+        return;
+    }
+    if (bid < NDIAG) {
+        // 16x16 block u = 4 bid + wave of the lower triangle of the diagonal tile, (bi, bj), bi >= bj
+        const int u = bid * 4 + wave;
+        int bi, bj;
+        tile_of_index(u, bi, bj);
+        const int row0 = j0 * TILE + bi * NB, col0 = j0 * TILE + bj * NB;
+        double4_t out[1][1];
+        update_block<1, 32>(S, ld, k, row0, col0, lane, out);
+        double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(size_t)(4 * r) * ld] = out[0][0][r];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (bid != 0) {
+            // publish: all stores of the workgroup done -> agent-scope release -> count
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        // block 0: wait for the eight others (bounded spin; relaxed polls, one acquire), pull the tile, factor it
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NDIAG - 1 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
+            if (spins >= (1 << 24)) *stall = 1.0;        // a producer never arrived: reported as a device error (never folded into "not positive definite")
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        double* A = sm;
+        double* T = S + (size_t)(j0 * TILE) * ld + (size_t)j0 * TILE;
+        load_tile_packed(A, T, ld, tid);
+        __syncthreads();
+        const bool failed = potrf_tile_lds<false, LayPacked>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
+        store_tile_packed(T, A, ld, tid);
+        if (tid == 0 && failed) *ok = 0.0;
+        return;
+    }
+    // half of tile index 1 + (bid - NDIAG) / 2: 128 rows x 64 columns, a wavefront 64 x 32, accumulators loaded from C
+    const int q = bid - NDIAG;
+    int rt, ct;
+    tile_of_index(1 + (q >> 1), rt, ct);
+    if (rt == ct && (q & 1) && (wave & 1) == 0) return;          // diagonal tile: rows 0-63 of columns 64-127 lie above the diagonal
+    const int row0 = (j0 + rt) * TILE + (wave & 1) * 64, col0 = (j0 + ct) * TILE + (q & 1) * 64 + (wave >> 1) * 32;
+    double4_t out[2][4];
+    update_rect<2, 4, 4, true>(S, ld, k, row0, col0, lane, out);
+    double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -895,6 +1018,7 @@ void chol_init_device()
     const size_t lds_panel = (size_t)TILE * (TILE + 2) * sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bsolve_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_panel);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
 }
@@ -925,7 +1049,15 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
         if (m > 0) {
             const int n_tiles = m * (m + 1) / 2;
             const int n_q4 = syrk_quartered_tiles(n_tiles, g_n_cu);
-            hipLaunchKernelGGL(k_syrk_update, dim3(NDIAG + (n_tiles - 1 - n_q4) + 4 * n_q4 + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
+            // Two forms of the trailing update.  While it is what takes the time (more than ~1.5 rounds of whole tiles) the half-tile
+            // form runs two workgroups per compute unit (239 registers, the packed 78 KB of LDS): 94 / 86 / 84 us on the first columns
+            // against 104 / 91 / 89.  Once the chain (diagonal update, hand-off, in-tile factorisation: ~29 us) is what takes the time,
+            // the workgroup that factors must not share its compute unit: the whole-tile form (382 registers: one workgroup per unit).
+            static const int bulk2_min_tiles = std::getenv("MAGE_CHOL_BULK2_MIN_TILES") ? std::atoi(std::getenv("MAGE_CHOL_BULK2_MIN_TILES")) : 400;
+            const bool bulk2 = n_tiles >= bulk2_min_tiles;
+            if (bulk2) hipLaunchKernelGGL(k_syrk_update2, dim3(NDIAG + 2 * (n_tiles - 1) + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
+                                          ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, 0);
+            else hipLaunchKernelGGL(k_syrk_update, dim3(NDIAG + (n_tiles - 1 - n_q4) + 4 * n_q4 + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
                                ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, n_q4);
         }
     }
