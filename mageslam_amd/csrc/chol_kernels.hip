@@ -635,6 +635,76 @@ __device__ __forceinline__ void update_rect(const double* __restrict__ S, int ld
     }
 }
 
+// NOT THE DEFAULT (MAGE_CHOL_BULK2_STAGED=1 selects it): measured 3.01 ms per factorisation against 2.87 for the form that reads its
+// operands per wavefront -- eight barriers per task and the LDS round trip cost more than the halved L2 traffic returns.
+// Half tile (128 rows x 64 columns) by one workgroup with the panel operands STAGED THROUGH LDS: per 16 panel columns the 128 + 64
+// operand rows are fetched once by the workgroup (six 128-bit loads per thread, in flight while the previous chunk is multiplied)
+// instead of once per wavefront -- a 64 x 32 wavefront tile needs 0.19 operand bytes per flop from L2, which two wavefronts per SIMD
+// on 256 compute units cannot be fed; through LDS it is 0.094 from L2.  LDS: 2 buffers x 16 x 208 doubles (pitch 208: the four
+// k rows of a fragment read land on alternating bank halves) = 52 KB of the 78 KB every workgroup of the launch owns anyway.
+constexpr int ST_KC = 16, ST_PITCH = 208;
+// piece u of a thread: panel column kk = e / 96 of the chunk, 128-bit piece w = e % 96 of its 192 operand rows (e = 256 u + tid)
+__device__ __forceinline__ const double2* st_src(const double* __restrict__ Pn, const double* __restrict__ Pm, int ld, int ch, int tid, int u)
+{
+    const int e = u * 256 + tid, kk = e / 96, w = e - kk * 96;
+    return reinterpret_cast<const double2*>((w < 64 ? Pn + 2 * w : Pm + 2 * (w - 64)) + (size_t)(ch * ST_KC + kk) * ld);
+}
+__device__ __forceinline__ double2* st_dst(double* __restrict__ buf, int tid, int u)
+{
+    const int e = u * 256 + tid, kk = e / 96, w = e - kk * 96;
+    return reinterpret_cast<double2*>(buf + kk * ST_PITCH + 2 * w);
+}
+#define ST_FETCH(ch) do { s0 = *st_src(Pn, Pm, ld, ch, tid, 0); s1 = *st_src(Pn, Pm, ld, ch, tid, 1); s2 = *st_src(Pn, Pm, ld, ch, tid, 2); \
+                          s3 = *st_src(Pn, Pm, ld, ch, tid, 3); s4 = *st_src(Pn, Pm, ld, ch, tid, 4); s5 = *st_src(Pn, Pm, ld, ch, tid, 5); } while (0)
+#define ST_PARK(buf) do { *st_dst(buf, tid, 0) = s0; *st_dst(buf, tid, 1) = s1; *st_dst(buf, tid, 2) = s2; \
+                          *st_dst(buf, tid, 3) = s3; *st_dst(buf, tid, 4) = s4; *st_dst(buf, tid, 5) = s5; } while (0)
+__device__ __forceinline__ void update_half_tile_staged(double* __restrict__ S, int ld, int k, int R0, int C0, double* __restrict__ sm, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const double* Pn = S + (size_t)(k * TILE) * ld + R0;       // 128 operand rows (the tile's rows) of panel column kk at Pn[kk * ld + row]
+    const double* Pm = S + (size_t)(k * TILE) * ld + C0;       // 64 operand rows (the tile's columns)
+    double2 s0, s1, s2, s3, s4, s5;         // (scalars: as an array the six pieces were kept in scratch memory)
+    ST_FETCH(0);
+    const int row0 = (wave & 1) * 64, col0 = (wave >> 1) * 32;
+    double* C = S + (size_t)(C0 + col0 + (lane >> 4)) * ld + R0 + row0 + (lane & 15);
+    double4_t acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = C[(size_t)(a * 16 + 4 * r) * ld + b * 16];
+    ST_PARK(sm);
+    __syncthreads();
+    constexpr int NCH = TILE / ST_KC;
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+        const double* buf = sm + (ch & 1) * ST_KC * ST_PITCH;
+        if (ch + 1 < NCH) ST_FETCH(ch + 1);
+        const double* fb = buf + (lane >> 4) * ST_PITCH + (lane & 15);
+#pragma unroll
+        for (int s4 = 0; s4 < ST_KC / 4; ++s4) {
+            double av[2], bv[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) av[a] = -fb[s4 * 4 * ST_PITCH + 128 + col0 + a * 16];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[b] = fb[s4 * 4 * ST_PITCH + row0 + b * 16];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        if (ch + 1 < NCH) ST_PARK(sm + ((ch + 1) & 1) * ST_KC * ST_PITCH);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = acc[a][b][r];
+}
+
 // Grid of the trailing update of step k (tiles (i, j), j0 = k + 1 <= j <= i < nt), in dispatch order:
 //   blocks 0..8   the NEXT diagonal tile (j0, j0): its 36 lower 16x16 blocks, one per wavefront (32 dependent MFMAs
 //                 each instead of one wavefront grinding through a 64x64 quadrant: the tile is on the critical path).
@@ -821,17 +891,21 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
     const int q = bid - NDIAG;
     int rt, ct;
     tile_of_index(1 + (q >> 1), rt, ct);
-    if (rt == ct && (q & 1) && (wave & 1) == 0) return;          // diagonal tile: rows 0-63 of columns 64-127 lie above the diagonal
-    const int row0 = (j0 + rt) * TILE + (wave & 1) * 64, col0 = (j0 + ct) * TILE + (q & 1) * 64 + (wave >> 1) * 32;
-    double4_t out[2][4];
-    update_rect<2, 4, 4, true>(S, ld, k, row0, col0, lane, out);
-    double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
+    if (n_q4) {                                                   // n_q4 != 0 (the default): operands straight from L2 per wavefront
+        if (rt == ct && (q & 1) && (wave & 1) == 0) return;      // diagonal tile: rows 0-63 of columns 64-127 lie above the diagonal
+        const int row0 = (j0 + rt) * TILE + (wave & 1) * 64, col0 = (j0 + ct) * TILE + (q & 1) * 64 + (wave >> 1) * 32;
+        double4_t out[2][4];
+        update_rect<2, 4, 4, true>(S, ld, k, row0, col0, lane, out);
+        double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = out[a][b][r];
+                for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = out[a][b][r];
+        return;
+    }
+    update_half_tile_staged(S, ld, k, (j0 + rt) * TILE, (j0 + ct) * TILE + (q & 1) * 64, sm, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1055,8 +1129,9 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
             // the workgroup that factors must not share its compute unit: the whole-tile form (382 registers: one workgroup per unit).
             static const int bulk2_min_tiles = std::getenv("MAGE_CHOL_BULK2_MIN_TILES") ? std::atoi(std::getenv("MAGE_CHOL_BULK2_MIN_TILES")) : 400;
             const bool bulk2 = n_tiles >= bulk2_min_tiles;
+            static const bool unstaged = std::getenv("MAGE_CHOL_BULK2_STAGED") == nullptr;     // staging the operands through LDS measured SLOWER (3.01 ms against 2.87): kept for the record
             if (bulk2) hipLaunchKernelGGL(k_syrk_update2, dim3(NDIAG + 2 * (n_tiles - 1) + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
-                                          ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, 0);
+                                          ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, unstaged ? 1 : 0);
             else hipLaunchKernelGGL(k_syrk_update, dim3(NDIAG + (n_tiles - 1 - n_q4) + 4 * n_q4 + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
                                ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, n_q4);
         }
