@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j0 = k + 1, mt = nt - j0;
     const int n_tiles = mt * (mt + 1) / 2;
-    const int first_rhs = NDIAG + 2 * (n_tiles - 1);              // tile indices 1 .. n_tiles - 1, two workgroups (column halves) each
+    const int first_rhs = NDIAG + 16 * ((n_tiles - 1 + 7) / 8);   // tile indices 1 .. n_tiles - 1, two workgroups (column halves) each, in groups of eight tiles
     const int bid = blockIdx.x;
     if (bid >= first_rhs) {
         const int i = k + 1 + (bid - first_rhs);
@@ -888,7 +888,12 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
         return;
     }
     // half of tile index 1 + (bid - NDIAG) / 2: 128 rows x 64 columns, a wavefront 64 x 32, accumulators loaded from C
-    const int q = bid - NDIAG;
+    // the two halves of a tile share its 128 operand rows: workgroups q and q + 8 land on the same XCD (one L2), so tile t of a group
+    // of eight tiles is served by workgroups 16 g + t and 16 g + 8 + t
+    const int q0 = bid - NDIAG;
+    const int tile_i = 8 * (q0 >> 4) + (q0 & 7);
+    if (tile_i >= n_tiles - 1) return;
+    const int q = 2 * tile_i + ((q0 >> 3) & 1);
     int rt, ct;
     tile_of_index(1 + (q >> 1), rt, ct);
     if (n_q4) {                                                   // n_q4 != 0 (the default): operands straight from L2 per wavefront
@@ -1130,7 +1135,7 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
             static const int bulk2_min_tiles = std::getenv("MAGE_CHOL_BULK2_MIN_TILES") ? std::atoi(std::getenv("MAGE_CHOL_BULK2_MIN_TILES")) : 400;
             const bool bulk2 = n_tiles >= bulk2_min_tiles;
             static const bool unstaged = std::getenv("MAGE_CHOL_BULK2_STAGED") == nullptr;     // staging the operands through LDS measured SLOWER (3.01 ms against 2.87): kept for the record
-            if (bulk2) hipLaunchKernelGGL(k_syrk_update2, dim3(NDIAG + 2 * (n_tiles - 1) + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
+            if (bulk2) hipLaunchKernelGGL(k_syrk_update2, dim3(NDIAG + 16 * ((n_tiles - 1 + 7) / 8) + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
                                           ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, unstaged ? 1 : 0);
             else hipLaunchKernelGGL(k_syrk_update, dim3(NDIAG + (n_tiles - 1 - n_q4) + 4 * n_q4 + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
                                ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, n_q4);
