@@ -1,7 +1,7 @@
 // Cycle probe for the diagonal-tile factorisation pieces (development tool).
 #include "../mageslam_amd/csrc/chol_kernels.hip"
 #ifndef FACTOR_BLOCK
-#define FACTOR_BLOCK factor_block16
+#define FACTOR_BLOCK factor_block16<LDC>
 #endif
 #include <cstdio>
 #include <cmath>
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_probe(const double* __restrict__ S, int
     load_tile<LDC>(A, S, ld, tid);
     __syncthreads();
     long long t3 = clock64();
-    f |= potrf_tile_lds(A, Li, Linv, tid);
+    f |= potrf_tile_lds<false, LayLDC>(A, Li, Linv, tid);       // (the library's full-tile kernels use LayPacked; the probe keeps the square layout)
     long long t4 = clock64();
     __syncthreads();
     store_tile_lower(const_cast<double*>(S) + (size_t)ld * ld, A, ld, tid);      // second ld x ld matrix of the buffer receives L
