@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void k_probe(const double* __restrict__ S, int
     __syncthreads();
     long long t0 = clock64();
     bool f = false;
-    if (wave == 0) f = FACTOR_BLOCK(A, 0, lane, Li, Linv);
+    if (wave == 0) f = FACTOR_BLOCK(A, lane, Li, Linv);        // block (0, 0) of the tile
     long long t1 = clock64();
     __syncthreads();
     long long t2 = clock64();
