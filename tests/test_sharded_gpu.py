@@ -293,3 +293,42 @@ def test_two_processes_sharing_the_gpu_equal_the_threads_form(tmp_path):
         own = res["owner"] == r
         points[own] = pr[own]
     assert np.array_equal(points, res["points"])
+
+
+NCCL_WORKER = textwrap.dedent("""
+    import sys, json, os
+    sys.path.insert(0, %r); sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    from mageslam_amd import scene, sharded
+    from mageslam_amd.bundler import BundlerLib, load_scene
+    from test_sharded_gpu import PROC_SCENE, _sha
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%%s" %% sys.argv[1], rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    s = scene.make_scene(**PROC_SCENE)
+    group = sharded.TorchGroup(dist, 0)
+    sb = sharded.ShardedBundler(s, 0, 1, lambda: BundlerLib(False, 0), lambda b, sc: load_scene(b, sc, bulk=True), group.callback())
+    outs = []
+    for _ in range(3):
+        o = []
+        sb.StepBundleAdjustment([0.9], 16.0, o); outs.append(o)
+    print("RESULT " + json.dumps(dict(sha=_sha(sb.poses_f64()), outliers=outs, calls=group.calls)), flush=True)
+    dist.destroy_process_group()
+""") % (ROOT, os.path.join(ROOT, "tests"))
+
+
+def test_torch_rccl_callback_on_one_rank(tmp_path):
+    """The RCCL form of the torch.distributed callback (dist.all_reduce on a tensor aliasing the solver's buffer, issued under the
+    solver's stream as an ExternalStream, no host synchronisation): a one-rank communicator must leave the unsharded solve's bits."""
+    s = scene.make_scene(**PROC_SCENE)
+    ref = _single(s, [([0.9], 16.0)] * 3)
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER)
+    for attempt in range(2):
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        p = subprocess.run([sys.executable, str(script), str(port)], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        if p.returncode == 0:
+            break
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert out["sha"] == _sha(ref["poses"]) and out["outliers"] == ref["outliers"] and out["calls"] > 0
