@@ -393,18 +393,8 @@ __device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __re
     return failed;
 }
 
-// LDS tile -> global (the block row of the diagonal and everything below it; the strict upper part of S is never read)
-__device__ __forceinline__ void store_tile_lower(double* __restrict__ T, const double* __restrict__ A, int ld, int tid)
-{
-#pragma unroll 4
-    for (int b0 = 0; b0 < (TILE * TILE / 2) / 256; ++b0) {
-        const int e = (b0 * 256 + tid) * 2;
-        const int c = e / TILE, r = e % TILE;
-        if (r + 1 >= c) *reinterpret_cast<double2*>(T + (size_t)c * ld + r) = *reinterpret_cast<const double2*>(A + c * LDC + r);
-    }
-}
-
-// The same two copies for LayPacked: the 36 lower blocks, 128-bit pieces along a block's columns, 18 per thread in two batches.
+// Global <-> LDS copies of a diagonal tile for LayPacked: the 36 lower blocks, 128-bit pieces along a block's columns, 18 per thread in
+// two batches (the strict upper part of S is never read or written).
 __device__ __forceinline__ void block_of_index(int t, int& rb, int& cb)          // t = rb (rb + 1) / 2 + cb, 0 <= t < 36
 {
     rb = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15) + (t >= 21) + (t >= 28);
@@ -827,7 +817,7 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
 }
 
 __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
-                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int n_q4)
+                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int unstaged)
 {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -896,7 +886,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
     const int q = 2 * tile_i + ((q0 >> 3) & 1);
     int rt, ct;
     tile_of_index(1 + (q >> 1), rt, ct);
-    if (n_q4) {                                                   // n_q4 != 0 (the default): operands straight from L2 per wavefront
+    if (unstaged) {                                               // the default: operands straight from L2 per wavefront
         if (rt == ct && (q & 1) && (wave & 1) == 0) return;      // diagonal tile: rows 0-63 of columns 64-127 lie above the diagonal
         const int row0 = (j0 + rt) * TILE + (wave & 1) * 64, col0 = (j0 + ct) * TILE + (q & 1) * 64 + (wave >> 1) * 32;
         double4_t out[2][4];

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_probe(const double* __restrict__ S, int
     f |= potrf_tile_lds<false, LayLDC>(A, Li, Linv, tid);       // (the library's full-tile kernels use LayPacked; the probe keeps the square layout)
     long long t4 = clock64();
     __syncthreads();
-    store_tile_lower(const_cast<double*>(S) + (size_t)ld * ld, A, ld, tid);      // second ld x ld matrix of the buffer receives L
+    for (int e = tid; e < TILE * TILE; e += 256) { const int c = e / TILE, r = e % TILE; if (r >= c) (const_cast<double*>(S) + (size_t)ld * ld)[(size_t)c * ld + r] = A[c * LDC + r]; }      // second ld x ld matrix of the buffer receives L
     if (tid == 0) { out[0] = t1 - t0; out[1] = t2 - t1; out[2] = t4 - t3; out[3] = f; }
     if (tid == 64) { out[4] = t1 - t0; }
 }
