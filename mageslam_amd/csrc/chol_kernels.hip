@@ -463,18 +463,16 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int 
 // Y stays in registers (result -> B operand identity).  No LDS, no barriers.  The last workgroup
 // solves the rhs row y_k with the same code (a strip with one live row).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
-                                                   const double* __restrict__ Linv_k, int* __restrict__ queue, int queue_start)
+// One strip of the panel solve of tile column k: strip < n_strips = a 16-row strip of the tiles below the diagonal, strip == n_strips =
+// the rhs row y_k (a strip with one live row).
+__device__ __forceinline__ void trsm_strip(double* __restrict__ S, double* __restrict__ y, int ld, int k, int strip, bool is_rhs,
+                                           const double* __restrict__ Linv_k, int lane)
 {
-    const int lane = threadIdx.x;
-    if (blockIdx.x == 0 && lane == 0) *queue = queue_start;     // work queue of the trailing update that follows this launch
-    const int n_strips = (nt - k - 1) * NBLK;
-    const bool is_rhs = (int)blockIdx.x == n_strips;
     double* base;          // element (n = strip row, col) lives at base[col * cstride]; for the rhs strip only n == 0 exists
     size_t cstride;
     bool live;
     if (!is_rhs) {
-        base = S + (size_t)(k * TILE) * ld + (size_t)(k + 1) * TILE + blockIdx.x * NB + (lane & 15);
+        base = S + (size_t)(k * TILE) * ld + (size_t)(k + 1) * TILE + strip * NB + (lane & 15);
         cstride = (size_t)ld;
         live = true;
     } else {
@@ -518,6 +516,15 @@ __global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, doubl
             for (int r = 0; r < 4; ++r) base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] = yc[r];
         }
     }
+}
+
+__global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
+                                                   const double* __restrict__ Linv_k, int* __restrict__ queue, int queue_start)
+{
+    const int lane = threadIdx.x;
+    if (blockIdx.x == 0 && lane == 0) { queue[0] = queue_start; if (k == 0) { queue[1] = 0; queue[2] = 0; } }     // hand-off counters of the launches that follow
+    const int n_strips = (nt - k - 1) * NBLK;
+    trsm_strip(S, y, ld, k, (int)blockIdx.x, (int)blockIdx.x == n_strips, Linv_k, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -722,8 +729,34 @@ __device__ __forceinline__ void tile_of_index(int t, int& rt, int& ct)
     ct = t - rt * (rt + 1) / 2;
 }
 
+// ---- panel solve merged into the trailing update's launch (flag[0]: arrivals at the split diagonal tile, flag[1]: the last tile
+// column whose diagonal tile is factored and in memory, flag[2]: parts of first-column tiles written, cumulative over the launches of a
+// factorisation; k_trsm_panel of column 0 zeroes all three).  Producers: every store of the workgroup done, ONE agent-scope release
+// (an L2 write-back), then the count.  Consumers (the strips, dispatched behind every producer they wait for): relaxed polls, one acquire.
+__device__ __forceinline__ void publish_column_part(int* __restrict__ flag, int tid)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(flag + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void wait_for_column(int* __restrict__ flag, int j0, int col_target, double* __restrict__ stall, int lane)
+{
+    if (lane == 0) {
+        int spins = 0;
+        while ((__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < j0 ||
+                __hip_atomic_load(flag + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < col_target) && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+        if (spins >= (1 << 22)) *stall = 1.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
-                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int n_q4)
+                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int n_q4, int merge, int col_target)
 {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -732,6 +765,13 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
     const int n_whole = n_tiles - 1 - n_q4;                       // tile indices 1 .. n_whole
     const int first_q4 = NDIAG + n_whole, first_rhs = first_q4 + 4 * n_q4;
     const int bid = blockIdx.x;
+    if (bid >= first_rhs + mt) {
+        // ---- merged panel solve of tile column j0 (merge != 0): one strip per workgroup (wavefront 0), behind everything it waits for
+        if (wave != 0) return;
+        wait_for_column(flag, j0, col_target, stall, lane);
+        trsm_strip(S, y, ld, j0, bid - (first_rhs + mt), false, Linv_next, lane);
+        return;
+    }
     if (bid >= first_rhs) {
         const int i = k + 1 + (bid - first_rhs);
         if (i >= nt) return;
@@ -742,6 +782,14 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
 #pragma unroll 8
             for (int c = 0; c < TILE; ++c) acc = __builtin_fma(Lik[(size_t)c * ld + r], yk[c], acc);
             y[(size_t)i * TILE + r] -= acc;
+        }
+        if (merge && i == j0) {
+            // the rhs row of the merged panel solve: y_j0 is this workgroup's own (just updated), L_j0j0 comes from workgroup 0
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (wave != 0) return;
+            wait_for_column(flag, j0, 0, stall, lane);
+            trsm_strip(S, y, ld, j0, 0, true, Linv_next, lane);
         }
         return;
     }
@@ -773,6 +821,7 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NDIAG - 1 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
             if (spins >= (1 << 24)) *stall = 1.0;        // a producer never arrived: reported as a device error (never folded into "not positive definite")
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (merge) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // no panel-solve launch follows to reset it
         }
         __syncthreads();
         double* A = sm;
@@ -782,6 +831,14 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
         const bool failed = potrf_tile_lds<false, LayPacked>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
         store_tile_packed(T, A, ld, tid);
         if (tid == 0 && failed) *ok = 0.0;
+        if (merge) {      // L_j0j0 and its block inverses are in memory: the strips of this launch may start
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_store(flag + 1, j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         return;
     }
     if (bid >= first_q4) {
@@ -800,6 +857,7 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = out[a][b][r];
+        if (merge && ct == 0) publish_column_part(flag, tid);
         return;
     }
     int rt, ct;
@@ -814,6 +872,7 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = out[a][b][r];
+    if (merge && ct == 0) publish_column_part(flag, tid);
 }
 
 __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
@@ -1112,24 +1171,36 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
     const size_t linv_stride = (size_t)NBLK * NB * NB;
     double* stall = ws.stall ? ws.stall : ok + 1;     // callers without a slot of their own pass a two-element ok
     hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), lds_diag, st, S, n_pad, 0, ws.Linv, ok, stall, reinterpret_cast<unsigned long long*>(x), n_pad);
-    for (int k = 0; k < nt; ++k) {
-        const int m = nt - k - 1;             // tile rows below panel k
-        hipLaunchKernelGGL(k_trsm_panel, dim3(m * NBLK + 1), dim3(64), 0, st, S, y, n_pad, k, nt, ws.Linv + (size_t)k * linv_stride, ws.sync, 0);
-        if (m > 0) {
-            const int n_tiles = m * (m + 1) / 2;
-            const int n_q4 = syrk_quartered_tiles(n_tiles, g_n_cu);
-            // Two forms of the trailing update.  While it is what takes the time (more than ~1.5 rounds of whole tiles) the half-tile
-            // form runs two workgroups per compute unit (239 registers, the packed 78 KB of LDS): 94 / 86 / 84 us on the first columns
-            // against 104 / 91 / 89.  Once the chain (diagonal update, hand-off, in-tile factorisation: ~29 us) is what takes the time,
-            // the workgroup that factors must not share its compute unit: the whole-tile form (382 registers: one workgroup per unit).
-            static const int bulk2_min_tiles = std::getenv("MAGE_CHOL_BULK2_MIN_TILES") ? std::atoi(std::getenv("MAGE_CHOL_BULK2_MIN_TILES")) : 400;
-            const bool bulk2 = n_tiles >= bulk2_min_tiles;
-            static const bool unstaged = std::getenv("MAGE_CHOL_BULK2_STAGED") == nullptr;     // staging the operands through LDS measured SLOWER (3.01 ms against 2.87): kept for the record
-            if (bulk2) hipLaunchKernelGGL(k_syrk_update2, dim3(NDIAG + 16 * ((n_tiles - 1 + 7) / 8) + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
-                                          ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, unstaged ? 1 : 0);
-            else hipLaunchKernelGGL(k_syrk_update, dim3(NDIAG + (n_tiles - 1 - n_q4) + 4 * n_q4 + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
-                               ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, n_q4);
+    // Column 0's panel solve is a launch of its own (it also zeroes the hand-off counters).  After that, step k = the trailing update
+    // by column k, which factors the diagonal tile of column k + 1 inside -- and, in the whole-tile form, also SOLVES column k + 1's
+    // panel inside (strips at the end of the grid, waiting for the factored tile and for the first-column tiles of this very launch):
+    // while the update dominates the strips run beside its last tiles, afterwards they save the launch boundary (~10 us per column
+    // on the chain either way).  The half-tile form is followed by a panel-solve launch as before.
+    static const bool merge_off = std::getenv("MAGE_CHOL_NO_MERGED_TRSM") != nullptr;
+    hipLaunchKernelGGL(k_trsm_panel, dim3((nt - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, 0, nt, ws.Linv, ws.sync, 0);
+    int col_total = 0;
+    for (int k = 0; k + 1 < nt; ++k) {
+        const int m = nt - k - 1;             // tile rows below panel k = tile rows of the trailing matrix
+        const int n_tiles = m * (m + 1) / 2;
+        const int n_q4 = syrk_quartered_tiles(n_tiles, g_n_cu);
+        // Two forms of the trailing update.  While it is what takes the time (more than ~1.5 rounds of whole tiles) the half-tile
+        // form runs two workgroups per compute unit (239 registers, the packed 78 KB of LDS): 94 / 86 / 84 us on the first columns
+        // against 104 / 91 / 89.  Once the chain (diagonal update, hand-off, in-tile factorisation: ~29 us) is what takes the time,
+        // the workgroup that factors must not share its compute unit: the whole-tile form (382 registers: one workgroup per unit).
+        static const int bulk2_min_tiles = std::getenv("MAGE_CHOL_BULK2_MIN_TILES") ? std::atoi(std::getenv("MAGE_CHOL_BULK2_MIN_TILES")) : 400;
+        const bool bulk2 = n_tiles >= bulk2_min_tiles;
+        static const bool unstaged = std::getenv("MAGE_CHOL_BULK2_STAGED") == nullptr;     // staging the operands through LDS measured SLOWER (3.01 ms against 2.87): kept for the record
+        bool merged = false;
+        if (bulk2) hipLaunchKernelGGL(k_syrk_update2, dim3(NDIAG + 16 * ((n_tiles - 1 + 7) / 8) + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
+                                      ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, unstaged ? 1 : 0);
+        else {
+            merged = !merge_off;
+            const int n_whole = n_tiles - 1 - n_q4;
+            if (merged) for (int rt = 1; rt < m; ++rt) col_total += (rt * (rt + 1) / 2 <= n_whole) ? 1 : 4;      // workgroups that write a part of column k + 1
+            hipLaunchKernelGGL(k_syrk_update, dim3(NDIAG + n_whole + 4 * n_q4 + m + (merged ? (m - 1) * NBLK : 0)), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
+                               ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, n_q4, merged ? 1 : 0, col_total);
         }
+        if (!merged) hipLaunchKernelGGL(k_trsm_panel, dim3((m - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, k + 1, nt, ws.Linv + (size_t)(k + 1) * linv_stride, ws.sync, 0);
     }
     // backward substitution: one persistent launch (needs every workgroup resident: nt <= 256 compute units)
     hipLaunchKernelGGL(k_bsolve_persist, dim3(nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, stall, ws.dbg);
