@@ -791,7 +791,7 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(h->d_xl.reserve((size_t)nlm * 4 + 1));
     // two-level reductions: one double per block of the widest launch; the small-problem linearisation (8 lanes per landmark, 4 blocks
     // per camera) also parks the cameras' partial (U, b_c) sums behind its chi2 partials
-    MAGE_TRY(h->d_partial.reserve(std::max<size_t>(4 * 1024, std::max<size_t>((size_t)nb_l + nb_c, (size_t)nlm * 8 / 256 + (size_t)nfc * 4 * 29 + 8)) + 16));          // (the fused large-problem form needs nlm / 32 + nfc entries: covered)
+    MAGE_TRY(h->d_partial.reserve(std::max<size_t>(4 * 1024, std::max<size_t>((size_t)nb_l + nb_c, (size_t)nlm * 16 / 256 + (size_t)nfc * 4 * 29 + 8)) + 16));          // (the fused large-problem form needs nlm / 32 + nfc entries: covered)
     MAGE_TRY(h->d_scal.reserve(SC_PAD + ((size_t)nL + 2) / 2 + 1));          // scalars, then up to n_L outlier ids (32-bit)
     h->d_out_ids = reinterpret_cast<uint32_t*>(h->d_scal.p + SC_PAD);
     h->out_cursor = 0;                                                        // d_queue (with the cursor) is zeroed below

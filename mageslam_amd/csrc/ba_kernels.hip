@@ -915,7 +915,7 @@ __device__ __forceinline__ void R_to_q(const double m[9], double c[4])
 }
 
 // pose <- exp(x) * pose for one free camera (VertexSE3Expmap::oplusImpl, appendix A.1); returns its share of the scale term
-__device__ __forceinline__ double pose_update_one(const BaDeviceView& v, double lambda, int hc)
+__device__ __forceinline__ double pose_update_compute(const BaDeviceView& v, double lambda, int hc, PoseD& O)
 {
     double sc = 0;
     const int cam = v.hc2cam[hc];
@@ -953,7 +953,6 @@ __device__ __forceinline__ double pose_update_one(const BaDeviceView& v, double 
     // result = E * P : t = E.t + E.r * P.t ; r = E.r * P.r ; normalise
     double rx, ry, rz;
     q_rot(q[0], q[1], q[2], q[3], P.tx, P.ty, P.tz, rx, ry, rz);
-    PoseD O;
     O.tx = ex + rx; O.ty = ey + ry; O.tz = ez + rz;
     O.qw = q[3] * P.qw - q[0] * P.qx - q[1] * P.qy - q[2] * P.qz;
     O.qx = q[3] * P.qx + q[0] * P.qw + q[1] * P.qz - q[2] * P.qy;
@@ -962,7 +961,13 @@ __device__ __forceinline__ double pose_update_one(const BaDeviceView& v, double 
     if (O.qw < 0) { O.qx = -O.qx; O.qy = -O.qy; O.qz = -O.qz; O.qw = -O.qw; }
     n = sqrt(O.qx * O.qx + O.qy * O.qy + O.qz * O.qz + O.qw * O.qw);
     O.qx /= n; O.qy /= n; O.qz /= n; O.qw /= n;
-    store_pose(v.pose_trial, cam, O);
+    return sc;
+}
+__device__ __forceinline__ double pose_update_one(const BaDeviceView& v, double lambda, int hc)
+{
+    PoseD O;
+    const double sc = pose_update_compute(v, lambda, hc, O);
+    store_pose(v.pose_trial, v.hc2cam[hc], O);
     return sc;
 }
 
@@ -1545,6 +1550,82 @@ __global__ __launch_bounds__(256) void k_small_error(BaDeviceView v, int trial, 
     fold_partials(v.partial, gridDim.x, v.scal + (trial ? SC_CHI_TRIAL : SC_CHI), sm);
 }
 
+// k_small_update + k_small_error in one launch (points free).  Every workgroup recomputes the trial poses of the <= 21 free cameras
+// into LDS (workgroup 0 also stores them); SMALL_LPL lanes per landmark share its W slots for the back-substitution (fixed shuffle
+// tree, as k_backsub), every lane then holds the trial point and evaluates its share of the landmark's observations against the
+// trial poses -- the residuals k_small_error would have read the trial state back for.  The last workgroup folds both sums.
+__global__ __launch_bounds__(256) void k_small_update_error(BaDeviceView v, double lambda, double delta, int* __restrict__ counter)
+{
+    __shared__ double sm[4];
+    __shared__ PoseD lp[24];
+    const int bid = blockIdx.x, tid = threadIdx.x, n_blocks = gridDim.x;
+    double sc = 0, chi = 0;
+    if (tid < v.n_fc) {
+        PoseD O;
+        const double s = pose_update_compute(v, lambda, tid, O);
+        lp[tid] = O;
+        if (bid == 0) { store_pose(v.pose_trial, v.hc2cam[tid], O); sc = s; }
+    }
+    __syncthreads();
+    const int gl = bid * 256 + tid, l = gl / SMALL_LPL, sub = gl % SMALL_LPL;
+    const bool live = l < v.n_lm;
+    double c0 = 0, c1 = 0, c2 = 0;
+    if (live) {
+        const int s1 = v.lm_wptr[l + 1];
+        for (int s = v.lm_wptr[l] + sub; s < s1; s += SMALL_LPL) {
+            const double2* W2 = reinterpret_cast<const double2*>(v.W + (size_t)s * 18);
+            const double2* x2 = reinterpret_cast<const double2*>(v.xc + (size_t)v.w_hc[s] * 6);
+            double W[18], xx[6];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { const double2 t = W2[k]; W[2 * k] = t.x; W[2 * k + 1] = t.y; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const double2 t = x2[k]; xx[2 * k] = t.x; xx[2 * k + 1] = t.y; }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const double mx = -xx[r];
+                c0 += W[r * 3] * mx; c1 += W[r * 3 + 1] * mx; c2 += W[r * 3 + 2] * mx;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < SMALL_LPL; m <<= 1) { c0 += __shfl_xor(c0, m, 64); c1 += __shfl_xor(c1, m, 64); c2 += __shfl_xor(c2, m, 64); }
+    if (live) {
+        const double b0 = v.bp[(size_t)l * 4], b1 = v.bp[(size_t)l * 4 + 1], b2 = v.bp[(size_t)l * 4 + 2];
+        c0 += b0; c1 += b1; c2 += b2;
+        double D[6];
+        lm_dinv(v, l, lambda, D);
+        const double x0 = D[0] * c0 + D[1] * c1 + D[2] * c2;
+        const double x1 = D[1] * c0 + D[3] * c1 + D[4] * c2;
+        const double x2 = D[2] * c0 + D[4] * c1 + D[5] * c2;
+        const int pt = v.lm_pt[l];
+        const double* pc = v.pt_cur + (size_t)pt * 4;
+        const double X = pc[0] + x0, Y = pc[1] + x1, Z = pc[2] + x2;
+        if (sub == 0) {
+            double* pt_t = v.pt_trial + (size_t)pt * 4;
+            pt_t[0] = X; pt_t[1] = Y; pt_t[2] = Z;
+            sc += x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
+        }
+        const int end = v.lm_ptr[l + 1];
+        for (int i = v.lm_ptr[l] + sub; i < end; i += SMALL_LPL) {
+            if (!v.L_active[i]) continue;
+            const int cam = v.L_cam[i], hc = v.cam2hc[cam];
+            const PoseD P = hc >= 0 ? lp[hc] : load_pose(v.pose_cur, cam);       // a fixed camera's trial pose is its pose
+            EdgeGeom g = edge_geom(P, v.camK, cam, X, Y, Z, v.L_uv[i]);
+            *reinterpret_cast<double2*>(v.errL + (size_t)i * 2) = make_double2(g.e0, g.e1);
+            double rho0, rho1;
+            huber((double)v.L_info[i] * (g.e0 * g.e0 + g.e1 * g.e1), delta, rho0, rho1);
+            chi += rho0;
+        }
+    }
+    const double r0 = block_sum<4>(sc, sm);
+    const double r1 = block_sum<4>(chi, sm);
+    if (tid == 0) { v.partial[bid] = r0; v.partial[n_blocks + bid] = r1; }
+    if (!last_block_arrives(counter, n_blocks)) return;
+    fold_partials(v.partial, n_blocks, v.scal + SC_SCALE, sm);
+    __syncthreads();
+    fold_partials(v.partial + n_blocks, n_blocks, v.scal + SC_CHI_TRIAL, sm);
+}
+
 // k_classify with the three reductions folded in
 __global__ __launch_bounds__(256) void k_small_classify(BaDeviceView v, double max_err_sq, uint32_t* __restrict__ out_ids, int* __restrict__ out_count,
                                                         int out_base, int* __restrict__ counter)
@@ -1946,6 +2027,11 @@ void ba_small_solve_trial(const BaDeviceView& v, double lambda, double delta, do
     const int n = v.n_fc * 6;
     hipLaunchKernelGGL(k_small_schur, dim3(v.n_blk + v.n_fc), dim3(256), 0, st, v, lambda);
     chol_small_solve(v.S, v.y, v.xc, n, v.n_pad, linv_ws, v.scal + SC_CHOL_OK, v.scal + SC_CHOL_STALL, st);
+    static const bool unfused = std::getenv("MAGE_BA_SMALL_UNFUSED_UPDATE") != nullptr;
+    if (v.points_free && v.n_lm > 0 && !unfused) {        // back-substitution, state update and the trial's residuals in one launch
+        hipLaunchKernelGGL(k_small_update_error, dim3(cdiv(v.n_lm * SMALL_LPL, 256)), dim3(256), 0, st, v, lambda, delta, counter);
+        return;
+    }
     const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm, 256) : 0;
     hipLaunchKernelGGL(k_small_update, dim3(nbL + cdiv(v.n_fc, 256)), dim3(256), 0, st, v, lambda, nbL, counter);
     hipLaunchKernelGGL(k_small_error, dim3(small_error_blocks(v)), dim3(256), 0, st, v, 1, delta, counter);
