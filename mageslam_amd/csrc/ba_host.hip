@@ -925,8 +925,11 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
             if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[1], st));
             chol_factor_solve(v.S, v.y, v.xc, v.n_pad, ws, v.scal + SC_CHOL_OK, st);
             if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[2], st));
-            ba_launch_update(v, lambda, adds_damping ? lambda : 0.0, st);
-            ba_launch_error(v, true, huber, st);
+            if (ba_update_and_trial_error_fuses(v)) ba_launch_update_and_trial_error(v, lambda, adds_damping ? lambda : 0.0, huber, st);
+            else {
+                ba_launch_update(v, lambda, adds_damping ? lambda : 0.0, st);
+                ba_launch_error(v, true, huber, st);
+            }
             if (sharded) {
                 MAGE_TRY(all_reduce(v.scal + SC_SCALE, 1, 0));
                 MAGE_TRY(all_reduce(v.scal + SC_CHI_TRIAL, 1, 0));

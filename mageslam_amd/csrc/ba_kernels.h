@@ -92,6 +92,8 @@ void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st);    
 // landmark-sharded maps (include/mage_ba.h: mage_ba_set_landmark_shard)
 void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, double pad_diag, hipStream_t st);
 void ba_launch_update(const BaDeviceView& v, double lambda, double lambda_cam, hipStream_t st);
+bool ba_update_and_trial_error_fuses(const BaDeviceView& v);                                             // free points: update + trial chi2 in three launches
+void ba_launch_update_and_trial_error(const BaDeviceView& v, double lambda, double lambda_cam, double huber_delta, hipStream_t st);
 size_t ba_packed_doubles(int n_pad);                                                                   // lower tiles of S + y
 void ba_launch_pack_lower(const BaDeviceView& v, double* packed, bool to_packed, hipStream_t st);
 void ba_launch_gather_udiag(const BaDeviceView& v, double* out6_per_camera, hipStream_t st);

@@ -821,7 +821,11 @@ __global__ __launch_bounds__(256) void k_schur_rhs(BaDeviceView v)
 // thread that walks them alone waits out ten dependent 144-byte reads with 1.5 workgroups per compute unit to hide them), the three
 // sums are added over the lanes in a fixed tree, lane 0 of the group finishes the landmark.
 constexpr int BACKSUB_LPL = 8;
-__global__ __launch_bounds__(256) void k_backsub(BaDeviceView v, double lambda)
+// WITH_ERROR: every lane of the landmark's group ends with the trial point and evaluates its share of the landmark's observations
+// against the trial poses (k_pose_update has run): the residuals and chi2 partials of k_error(trial) without reading the trial state
+// back, in partial[chi_off + block].
+template <bool WITH_ERROR>
+__global__ __launch_bounds__(256) void k_backsub(BaDeviceView v, double lambda, double delta, int chi_off)
 {
     __shared__ double sm[4];
     const int gl = blockIdx.x * 256 + threadIdx.x, l = gl / BACKSUB_LPL, sub = gl % BACKSUB_LPL;
@@ -860,23 +864,44 @@ __global__ __launch_bounds__(256) void k_backsub(BaDeviceView v, double lambda)
     }
 #pragma unroll
     for (int m = 1; m < BACKSUB_LPL; m <<= 1) { c0 += __shfl_xor(c0, m, 64); c1 += __shfl_xor(c1, m, 64); c2 += __shfl_xor(c2, m, 64); }
-    if (l < v.n_lm && sub == 0) {
+    double chi = 0;
+    if (l < v.n_lm && (WITH_ERROR || sub == 0)) {
         const double b0 = v.bp[(size_t)l * 4], b1 = v.bp[(size_t)l * 4 + 1], b2 = v.bp[(size_t)l * 4 + 2];
         c0 += b0; c1 += b1; c2 += b2;
         const double* D = v.Dinv + (size_t)l * 6;
         const double x0 = D[0] * c0 + D[1] * c1 + D[2] * c2;
         const double x1 = D[1] * c0 + D[3] * c1 + D[4] * c2;
         const double x2 = D[2] * c0 + D[4] * c1 + D[5] * c2;
-        double* xl = v.xl + (size_t)l * 4;
-        xl[0] = x0; xl[1] = x1; xl[2] = x2; xl[3] = 0;
         const int pt = v.lm_pt[l];
         const double* pc = v.pt_cur + (size_t)pt * 4;
-        double* pt_t = v.pt_trial + (size_t)pt * 4;
-        pt_t[0] = pc[0] + x0; pt_t[1] = pc[1] + x1; pt_t[2] = pc[2] + x2;
-        sc = x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
+        const double X = pc[0] + x0, Y = pc[1] + x1, Z = pc[2] + x2;
+        if (sub == 0) {
+            double* xl = v.xl + (size_t)l * 4;
+            xl[0] = x0; xl[1] = x1; xl[2] = x2; xl[3] = 0;
+            double* pt_t = v.pt_trial + (size_t)pt * 4;
+            pt_t[0] = X; pt_t[1] = Y; pt_t[2] = Z;
+            sc = x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
+        }
+        if (WITH_ERROR) {
+            const int end = v.lm_ptr[l + 1];
+            for (int i = v.lm_ptr[l] + sub; i < end; i += BACKSUB_LPL) {
+                if (!v.L_active[i]) continue;
+                const int cam = v.L_cam[i];
+                const PoseD P = load_pose(v.pose_trial, cam);
+                EdgeGeom g = edge_geom(P, v.camK, cam, X, Y, Z, v.L_uv[i]);
+                *reinterpret_cast<double2*>(v.errL + (size_t)i * 2) = make_double2(g.e0, g.e1);
+                double rho0, rho1;
+                huber((double)v.L_info[i] * (g.e0 * g.e0 + g.e1 * g.e1), delta, rho0, rho1);
+                chi += rho0;
+            }
+        }
     }
-    double r = block_sum<4>(sc, sm);
+    const double r = block_sum<4>(sc, sm);
     if (threadIdx.x == 0) v.partial[blockIdx.x] = r;
+    if (WITH_ERROR) {
+        const double r1 = block_sum<4>(chi, sm);
+        if (threadIdx.x == 0) v.partial[chi_off + blockIdx.x] = r1;
+    }
 }
 
 __device__ __forceinline__ void m3mul(const double A[9], const double B[9], double C[9])
@@ -972,14 +997,17 @@ __device__ __forceinline__ double pose_update_one(const BaDeviceView& v, double 
 }
 
 // every free camera; one thread per camera; scale partials
-__global__ __launch_bounds__(256) void k_pose_update(BaDeviceView v, double lambda, int part_off)
+__global__ __launch_bounds__(256) void k_pose_update(BaDeviceView v, double lambda, int part_off, int zero_off)
 {
     __shared__ double sm[4];
     const int hc = blockIdx.x * 256 + threadIdx.x;
     double sc = 0;
     if (hc < v.n_fc) sc = pose_update_one(v, lambda, hc);
     double r = block_sum<4>(sc, sm);
-    if (threadIdx.x == 0) v.partial[part_off + blockIdx.x] = r;
+    if (threadIdx.x == 0) {
+        v.partial[part_off + blockIdx.x] = r;
+        if (zero_off >= 0) v.partial[zero_off + blockIdx.x] = 0.0;       // this row of the second sum of a fused reduction
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1972,18 +2000,37 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, do
     }
 }
 
+// Back-substitution + state update + the trial's chi2 for problems with free points: k_pose_update first (the trial poses), then
+// k_backsub<true> (trial points, scale partials, the residuals of every observation against the trial state), one k_reduce_sum
+// for both scalars, the tether edges' chi2 on top.  = ba_launch_update + ba_launch_error(trial) in three launches instead of five.
+bool ba_update_and_trial_error_fuses(const BaDeviceView& v)
+{
+    static const bool off = std::getenv("MAGE_BA_UNFUSED_TRIAL_ERROR") != nullptr;
+    return !off && v.points_free && v.n_lm > 0 && v.n_fc > 0;
+}
+void ba_launch_update_and_trial_error(const BaDeviceView& v, double lambda, double lambda_cam, double delta, hipStream_t st)
+{
+    const int nb_l = cdiv(v.n_lm * BACKSUB_LPL, 256), nb_c = cdiv(v.n_fc, 256), n = nb_l + nb_c;
+    hipLaunchKernelGGL(k_pose_update, dim3(nb_c), dim3(256), 0, st, v, lambda_cam, nb_l, n + nb_l);       // scale partials nb_l .. n, chi2 partials of those rows: zero
+    hipLaunchKernelGGL(k_backsub<true>, dim3(nb_l), dim3(256), 0, st, v, lambda, delta, n);
+    // partial = [scale: n][chi2: n] -> scal[SC_SCALE], scal[SC_SCALE + 6] = scal[SC_CHI_TRIAL]
+    static_assert(SC_CHI_TRIAL - SC_SCALE == 6, "the two outputs of the fused reduction");
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, n, SC_CHI_TRIAL - SC_SCALE, v.scal + SC_SCALE, 2);
+    tether_launch_error(v, true, st);
+}
+
 void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st) { ba_launch_update(v, lambda, lambda, st); }
 void ba_launch_update(const BaDeviceView& v, double lambda, double lambda_cam, hipStream_t st)
 {
     int nb_l = 0;
     if (v.points_free && v.n_lm > 0) {
         nb_l = cdiv(v.n_lm * BACKSUB_LPL, 256);
-        hipLaunchKernelGGL(k_backsub, dim3(nb_l), dim3(256), 0, st, v, lambda);
+        hipLaunchKernelGGL(k_backsub<false>, dim3(nb_l), dim3(256), 0, st, v, lambda, 0.0, 0);
     }
     int nb_c = 0;
     if (v.n_fc > 0) {
         nb_c = cdiv(v.n_fc, 256);
-        hipLaunchKernelGGL(k_pose_update, dim3(nb_c), dim3(256), 0, st, v, lambda_cam, nb_l);
+        hipLaunchKernelGGL(k_pose_update, dim3(nb_c), dim3(256), 0, st, v, lambda_cam, nb_l, -1);
     }
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb_l + nb_c, 1, v.scal + SC_SCALE, 1);
 }
