@@ -465,13 +465,19 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int 
 // ---------------------------------------------------------------------------------------------
 // One strip of the panel solve of tile column k: strip < n_strips = a 16-row strip of the tiles below the diagonal, strip == n_strips =
 // the rhs row y_k (a strip with one live row).
+// inv_out != nullptr: the strip is rows 16 strip .. of the IDENTITY and the result, rows of L_kk^-T, goes to inv_out (element
+// (row, col) at inv_out[col * inv_pitch + row]; the backward solve builds the tile's inverse this way, in LDS).
 __device__ __forceinline__ void trsm_strip(double* __restrict__ S, double* __restrict__ y, int ld, int k, int strip, bool is_rhs,
-                                           const double* __restrict__ Linv_k, int lane)
+                                           const double* __restrict__ Linv_k, int lane, double* inv_out = nullptr, int inv_pitch = 0)
 {
     double* base;          // element (n = strip row, col) lives at base[col * cstride]; for the rhs strip only n == 0 exists
     size_t cstride;
     bool live;
-    if (!is_rhs) {
+    if (inv_out) {
+        base = inv_out + strip * NB + (lane & 15);
+        cstride = (size_t)inv_pitch;
+        live = true;
+    } else if (!is_rhs) {
         base = S + (size_t)(k * TILE) * ld + (size_t)(k + 1) * TILE + strip * NB + (lane & 15);
         cstride = (size_t)ld;
         live = true;
@@ -484,7 +490,9 @@ __device__ __forceinline__ void trsm_strip(double* __restrict__ S, double* __res
 #pragma unroll
     for (int c = 0; c < NBLK; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Acc[c][r] = live ? base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] : 0.0;
+        for (int r = 0; r < 4; ++r)
+            Acc[c][r] = inv_out ? ((strip * NB + (lane & 15)) == (c * NB + (lane >> 4) + 4 * r) ? 1.0 : 0.0)
+                                : live ? base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] : 0.0;
     // operand (row = 16c + (lane&15), col = 16j + 4r + (lane>>4)) of L_kk
     const double* Lop = S + (size_t)(k * TILE + (lane >> 4)) * ld + (size_t)k * TILE + (lane & 15);
     const double* Lio = Linv_k + (lane & 15) * NB + (lane >> 4);
@@ -984,27 +992,45 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
 {
     extern __shared__ double sm[];
     constexpr int LDB = TILE + 2;
-    double* T = sm;                        // L_jj, column-major (T[c * LDB + r])
-    __shared__ double Li[NBLK * NB * NB];
+    double* T = sm;                        // first L_jj^-T, then the off-diagonal tile staged for the NEXT arrival; column-major, pitch LDB
     __shared__ double ys[TILE], xk[TILE];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = nt - 1 - (int)blockIdx.x;                     // the last tile column is dispatched first
-    load_tile<LDB>(T, S + (size_t)(j * TILE) * ld + (size_t)j * TILE, ld, tid);
-    for (int e = tid; e < NBLK * NB * NB; e += 256) Li[e] = Linv[(size_t)j * NBLK * NB * NB + e];
     if (tid < TILE) ys[tid] = y[(size_t)j * TILE + tid];
-    // thread (c, half) owns rows half*64 .. +63 of column c of the current off-diagonal tile
-    const int c = tid >> 1, half = tid & 1;
-    double2 tile[32];
-    auto prefetch = [&](int k) {
-        const double* src = S + (size_t)(j * TILE + c) * ld + (size_t)k * TILE + half * 64;
-#pragma unroll
-        for (int u = 0; u < 32; ++u) tile[u] = *reinterpret_cast<const double2*>(src + 2 * u);
-    };
-    if (j < nt - 1) prefetch(nt - 1);
+    // The tile's inverse by the panel solve's strip code on the rows of the identity (two strips per wavefront, ~10 us, while every
+    // column but the last two is waiting anyway): the end of a hop is then one product from registers, not eight substitution steps.
+    trsm_strip(const_cast<double*>(S), nullptr, ld, j, wave, false, Linv + (size_t)j * NBLK * NB * NB, lane, T, LDB);
+    trsm_strip(const_cast<double*>(S), nullptr, ld, j, wave + 4, false, Linv + (size_t)j * NBLK * NB * NB, lane, T, LDB);
     __syncthreads();
-    if (dbg && tid == 0) dbg[j * 4 + 0] = wall_clock64();
-
-    if (dbg && tid == 0) dbg[j * 4 + 1] = wall_clock64();
+    // thread (c, half) owns rows half * 64 .. +63 of column c of the current off-diagonal tile, and columns half * 64 .. of row c of the inverse
+    const int c = tid >> 1, half = tid & 1;
+    double minv[64], tile[64];
+#pragma unroll
+    for (int q = 0; q < 64; ++q) minv[q] = T[(half * 64 + q) * LDB + c];
+    __syncthreads();                       // T is free
+    // The solve is a pipeline clocked by how fast a column consumes the x_k, one 128-KB tile each, and a wavefront's loads return in
+    // order (a poll issued behind a tile fetch cannot return before it has landed).  So the tiles travel global -> LDS by the
+    // load-to-LDS path of wavefronts 2-3 (one fully coalesced 1-KB column per instruction, no registers), a whole arrival ahead;
+    // every thread takes its share from LDS into registers; and wavefronts 0-1, which poll, never have a tile load in flight.
+    auto stage = [&](int k) {              // wavefronts 2-3: tile (k, j) -> T
+        const double* g = S + (size_t)(j * TILE + (wave - 2) * 64) * ld + (size_t)k * TILE + lane * 2;
+#pragma unroll 8
+        for (int q = 0; q < 64; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)q * ld),
+                                             (__attribute__((address_space(3))) void*)(T + ((wave - 2) * 64 + q) * LDB), 16, 0, 0);
+    };
+    auto take = [&]() {                    // T -> registers
+#pragma unroll
+        for (int q = 0; q < 64; ++q) tile[q] = T[c * LDB + half * 64 + q];
+    };
+    if (j < nt - 1) {
+        if (wave >= 2) { stage(nt - 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __syncthreads();
+        take();
+        __syncthreads();
+        if (wave >= 2 && nt - 2 > j) stage(nt - 2);
+    }
+    if (dbg && tid == 0) { dbg[j * 4 + 0] = wall_clock64(); dbg[j * 4 + 1] = dbg[j * 4 + 0]; }
     for (int k = nt - 1; k > j; --k) {
         if (k == j + 1 && dbg && tid == 0) dbg[j * 4 + 2] = wall_clock64();
         if (tid < TILE) {
@@ -1016,37 +1042,34 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
             xk[tid] = __longlong_as_double((long long)v);
         }
         __syncthreads();
-        double acc = 0;
+        double a0 = 0, a1 = 0;
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            acc = __builtin_fma(tile[u].x, xk[half * 64 + 2 * u], acc);
-            acc = __builtin_fma(tile[u].y, xk[half * 64 + 2 * u + 1], acc);
+        for (int q = 0; q < 64; q += 2) {
+            a0 = __builtin_fma(tile[q], xk[half * 64 + q], a0);
+            a1 = __builtin_fma(tile[q + 1], xk[half * 64 + q + 1], a1);
         }
-        if (k - 1 > j) prefetch(k - 1);
+        double acc = a0 + a1;
         acc += __shfl_xor(acc, 1, 64);
         if (half == 0) ys[c] -= acc;
-        __syncthreads();
+        if (k - 1 > j) {
+            if (wave >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile k - 1 has landed in T
+            __syncthreads();
+            take();
+            __syncthreads();
+            if (wave >= 2 && k - 2 > j) stage(k - 2);
+        } else __syncthreads();
     }
-    // x_j = L_jj^-T ys: eight blocked steps with the stored 16x16 block inverses
-    {
-        for (int cb = NBLK - 1; cb >= 0; --cb) {
-            if (tid < NB) {                    // x_c = Linv_cc^T ys_c
-                double acc = 0;
+    {   // x_j = L_jj^-T ys
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
-                for (int n = 0; n < NB; ++n) acc = __builtin_fma(Li[cb * NB * NB + n * NB + tid], ys[cb * NB + n], acc);
-                xk[cb * NB + tid] = acc;
-            }
-            __syncthreads();
-            if (tid < cb * NB) {               // ys[q] -= sum_n L[16 cb + n][q] x_c[n]   for q < 16 cb
-                double acc = ys[tid];
-#pragma unroll
-                for (int n = 0; n < NB; ++n) acc = __builtin_fma(-T[tid * LDB + cb * NB + n], xk[cb * NB + n], acc);
-                ys[tid] = acc;
-            }
-            __syncthreads();
+        for (int q = 0; q < 64; q += 4) {
+            a0 = __builtin_fma(minv[q + 0], ys[half * 64 + q + 0], a0); a1 = __builtin_fma(minv[q + 1], ys[half * 64 + q + 1], a1);
+            a2 = __builtin_fma(minv[q + 2], ys[half * 64 + q + 2], a2); a3 = __builtin_fma(minv[q + 3], ys[half * 64 + q + 3], a3);
         }
-        if (tid < TILE)
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(x + (size_t)j * TILE + tid), (unsigned long long)__double_as_longlong(xk[tid]),
+        double acc = (a0 + a1) + (a2 + a3);
+        acc += __shfl_xor(acc, 1, 64);
+        if (half == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(x + (size_t)j * TILE + c), (unsigned long long)__double_as_longlong(acc),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (dbg && tid == 0) dbg[j * 4 + 3] = wall_clock64();
