@@ -234,6 +234,14 @@ typedef struct mage_ba_profile {
 mage_status mage_ba_enable_profiling(mage_ba* h, int enable);
 mage_status mage_ba_get_profile(const mage_ba* h, mage_ba_profile* out);
 
+/* One list of the graph structure as it sits in HBM after the first step (names as in mageslam_amd/csrc/ba_kernels.h:
+ * "cam2hc", "hc2cam", "L_edge", "L_uv", "L_info", "L_cam", "L_pt", "L_slot", "lm_ptr", "lm_pt", "lm_wptr", "w_hc", "w_lm", "camE_ptr",
+ * "camE", "camS_ptr", "camS", "blk_ptr", "blk_ij", "con", "blk_order"; "sizes" = 12 ints: n_L, n_lm, n_fc, n_w, n_blk, n_blk_slots,
+ * n_con, dup_slots, n_pad, built_on_device, 0, 0).  *bytes = the list's size; it is copied when capacity_bytes suffices.
+ * The structure is what g2o's initializeOptimization + buildStructure produce (BundlerLib.cpp:156-166); it is built on the
+ * device by default and on the host with MAGE_BA_BUILD=host -- the tests compare the two element for element. */
+mage_status mage_ba_debug_structure(mage_ba* h, const char* name, void* out, size_t capacity_bytes, size_t* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,7 @@ def _declare():
     L.mage_ba_get_iter_stats.argtypes = [vp, C.POINTER(IterStats), sz, C.POINTER(sz)]
     L.mage_ba_enable_profiling.argtypes = [vp, C.c_int]
     L.mage_ba_get_profile.argtypes = [vp, C.POINTER(Profile)]
+    L.mage_ba_debug_structure.argtypes = [vp, C.c_char_p, C.c_void_p, sz, C.POINTER(sz)]
     L.mage_release_cached_memory.argtypes = []
     L.mage_release_cached_memory.restype = None
     _declared = True
@@ -240,6 +241,19 @@ class BundlerLib:
                 for a in arr[: n.value]]
 
     def enable_profiling(self, on=True): check(self._L.mage_ba_enable_profiling(self._h, int(on)))
+
+    STRUCTURE_LISTS = ("cam2hc", "hc2cam", "L_edge", "L_uv", "L_info", "L_cam", "L_pt", "L_slot", "lm_ptr", "lm_pt", "lm_wptr", "w_hc",
+                       "w_lm", "camE_ptr", "camE", "camS_ptr", "camS", "blk_ptr", "blk_ij", "con", "blk_order")
+
+    def structure(self, name: str) -> np.ndarray:
+        """mage_ba_debug_structure: one list of the graph structure as it sits in HBM (int32 / uint32 views; "L_uv", "L_info" float32;
+        "sizes": n_L, n_lm, n_fc, n_w, n_blk, n_blk_slots, n_con, dup_slots, n_pad, built_on_device)."""
+        n = C.c_size_t(0)
+        check(self._L.mage_ba_debug_structure(self._h, name.encode(), None, 0, C.byref(n)))
+        buf = np.zeros(max(n.value, 1), np.uint8)
+        check(self._L.mage_ba_debug_structure(self._h, name.encode(), buf.ctypes.data, buf.size, C.byref(n)))
+        raw = buf[: n.value]
+        return raw.view(np.float32) if name in ("L_uv", "L_info") else raw.view(np.int32)
 
     def profile(self) -> Profile:
         p = Profile()

@@ -21,6 +21,7 @@
 #include <queue>
 #include <vector>
 
+#include "ba_build.h"
 #include "ba_kernels.h"
 #include "chol_kernels.h"
 #include "mage_common.h"
@@ -186,11 +187,7 @@ struct HostTether {                 // one EdgeScaleConstraint / EdgeRotationCon
     double q[4] = { 0, 0, 0, 1 }, t[3] = { 0, 0, 0 }, dist = 0, w = 0;
     uint8_t set = 0;
 };
-struct HostObs {
-    float u = 0, v = 0, info = 0;
-    uint32_t cam = 0, pt = 0;
-    uint8_t set = 0, removed = 0;
-};
+typedef ObsRecord HostObs;          // ba_build.h: kept in pinned memory, uploaded as it is when the structure is built on the device
 
 // float32 rotation matrix (column-major) -> float32 quaternion -> normalise -> float64 -> SE3Quat
 // normalisation; the chain BundlerLib.cpp:270-273 runs through Eigen.
@@ -238,7 +235,7 @@ struct mage_ba {
     std::vector<HostCam> cams;
     std::vector<double> pts;            // n x 3
     std::vector<uint8_t> pt_set;
-    std::vector<HostObs> obs;
+    PinnedVec<HostObs> obs;
     std::vector<HostTether> teth[3];    // FixedDistance / RelativeRotation / RelativeTransform constraints
     bool cams_allocated = false, pts_allocated = false, obs_allocated = false, teth_allocated[3] = { false, false, false };
 
@@ -273,6 +270,12 @@ struct mage_ba {
     DevBuf<double> d_T_meas, d_T_w, d_T_out;
     int n_active_tethers = 0;
     DevBuf<int> d_queue;
+    // ---- device build of the structure (ba_build.h): the raw records and its scratch
+    DevBuf<ObsRecord> d_obs_raw; DevBuf<uint8_t> d_cam_fixed; DevBuf<int> d_cam_extra;
+    DevBuf<int> d_b_cam_deg, d_b_pt_deg, d_b_pt2lm, d_b_L_hc, d_b_L_lm, d_b_where, d_b_hist;
+    DevBuf<unsigned long long> d_b_bucket, d_b_scan, d_b_row;
+    DevBuf<BuildCounts> d_b_counts;
+    bool built_on_device = false;
     void* h_pinned = nullptr; size_t h_pinned_bytes = 0;     // one pinned block (from the cache) holding the mirrors below
     uint32_t* h_out_ids = nullptr;      // first OUT_PREFIX outlier ids of the last post-pass: they ride the scalar read-back
     double* h_scal = nullptr;           // pinned mirror of d_scal
@@ -450,29 +453,34 @@ struct PhaseTimer {
     }
 };
 
-mage_status initialize_optimization(mage_ba* h)
-{
-    PhaseTimer tm;
-    MAGE_DEVICE_SCOPE(h->device);
-    const int nc = (int)h->cams.size(), np = (int)h->pt_set.size();
-    // Lists that go to the device are built in pinned memory and copied as soon as they are complete, so the DMA overlaps
-    // the rest of the build; small ones are staged through the same arena.  ONE synchronisation at the end releases it.
-    PinnedArena arena;
-    if (!h->state_on_device) MAGE_TRY(upload_state(h, &arena));
-    else {
-        // Trials only write the entities that are in the system, and accepting a trial swaps the two
-        // state buffers; an entity that just left the system (all its observations removed) must
-        // therefore hold its kept estimate in BOTH buffers.
-        if (nc) MAGE_HIP(hipMemcpyAsync(h->d_pose[h->cur ^ 1].p, h->d_pose[h->cur].p, (size_t)nc * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        if (np) MAGE_HIP(hipMemcpyAsync(h->d_pt[h->cur ^ 1].p, h->d_pt[h->cur].p, (size_t)np * 4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    }
-    tm.mark("state upload");
-    const size_t no = h->obs.size();
+struct ListSizes {
+    int nL = 0, nfc = 0, nlm = 0, nw = 0, nblk = 0, n_blk_slots = 0;
+    size_t ncon = 0;
+    bool dup_slots = false;
+};
 
+// Which twin builds the lists (ba_build.h).  MAGE_BA_BUILD=host|device forces one (A/B, tests); by default the device builds
+// everything except the tracker's per-frame pose-only problems (a few hundred observations of fixed points: the three short host
+// loops cost less than the two read-backs of the device build).
+bool use_device_build(const mage_ba* h, size_t n_obs)
+{
+    const char* e = std::getenv("MAGE_BA_BUILD");
+    if (e && e[0] == 'h') return false;
+    if (e && e[0] == 'd') return true;
+    return !h->points_fixed && n_obs >= 1024;
+}
+
+// The lists on the host (the A/B twin of ba_build.hip): SparseOptimizer::initializeOptimization + BlockSolver::buildStructure,
+// re-expressed as flat CSR arrays.
+mage_status build_lists_host(mage_ba* h, PinnedArena& arena, const std::vector<int>& cam_extra_deg, PhaseTimer& tm, ListSizes& Z,
+                             std::vector<int>& cam2hc, std::vector<uint32_t>& L_edge)
+{
+    const int nc = (int)h->cams.size(), np = (int)h->pt_set.size();
+    const size_t no = h->obs.size();
     // active observations: set, not removed, not (camera fixed and points fixed)
     std::vector<uint32_t> active;
     active.reserve(no);
-    std::vector<int> cam_deg(nc, 0), pt_deg(np, 0);
+    std::vector<int> cam_deg(cam_extra_deg), pt_deg(np, 0);
     for (size_t e = 0; e < no; ++e) {
         const HostObs& o = h->obs[e];
         if (!o.set || o.removed) continue;
@@ -480,25 +488,9 @@ mage_status initialize_optimization(mage_ba* h)
         active.push_back((uint32_t)e);
         cam_deg[o.cam]++; pt_deg[o.pt]++;
     }
-    // tether edges: active unless both endpoints are fixed (OptimizableGraph::Edge::allVerticesFixed); they keep a
-    // free camera in the system even when it has no observation
-    std::vector<int> T_kind; std::vector<int2> T_cam, T_fixed; std::vector<double> T_meas, T_w;
-    for (int k = 0; k < 3; ++k)
-        for (const HostTether& t : h->teth[k]) {
-            if (!t.set) continue;
-            if (h->cams[t.c0].fixed && h->cams[t.c1].fixed) continue;
-            T_kind.push_back(k);
-            T_cam.push_back(make_int2((int)t.c0, (int)t.c1));
-            T_fixed.push_back(make_int2(h->cams[t.c0].fixed ? 1 : 0, h->cams[t.c1].fixed ? 1 : 0));
-            for (int a = 0; a < 4; ++a) T_meas.push_back(t.q[a]);
-            for (int a = 0; a < 3; ++a) T_meas.push_back(t.t[a]);
-            T_meas.push_back(t.dist);
-            T_w.push_back(t.w);
-            cam_deg[t.c0]++; cam_deg[t.c1]++;
-        }
-    const int nT = (int)T_kind.size();
     const int nL = (int)active.size();
-    std::vector<int> cam2hc(nc, -1), hc2cam;
+    std::vector<int> hc2cam;
+    cam2hc.assign(nc, -1);
     for (int i = 0; i < nc; ++i)
         if ((cam_deg[i] > 0 || h->shard_ranks > 0) && !h->cams[i].fixed) { cam2hc[i] = (int)hc2cam.size(); hc2cam.push_back(i); }   // sharded: the ranks' systems must have one shape
     const int nfc = (int)hc2cam.size();
@@ -507,11 +499,6 @@ mage_status initialize_optimization(mage_ba* h)
         if (pt_deg[i] > 0) { pt2lm[i] = (int)lm_pt.size(); lm_pt.push_back(i); }
     const int nlm = (int)lm_pt.size();
     const bool points_free = !h->points_fixed;
-    h->useless = (nfc + (points_free ? nlm : 0)) == 0;
-    if (h->shard_ranks > 0) {
-        if (nfc == 0) return fail(MAGE_ERR_UNSUPPORTED, "a landmark-sharded map needs a free camera (without one the landmarks are independent: solve them unsharded)");
-        h->useless = false;              // a rank without landmarks still takes part in every exchange
-    }
 
     tm.mark("active sets");
     hipStream_t st = h->stream;
@@ -533,7 +520,7 @@ mage_status initialize_optimization(mage_ba* h)
     std::vector<int> lm_ptr(nlm + 1, 0);
     for (int a = 0; a < nL; ++a) lm_ptr[pt2lm[h->obs[active[a]].pt] + 1]++;
     for (int l = 0; l < nlm; ++l) lm_ptr[l + 1] += lm_ptr[l];
-    std::vector<uint32_t> L_edge(nL);
+    L_edge.assign(nL, 0);
     {
         std::vector<int> fill(lm_ptr.begin(), lm_ptr.end() - 1);
         for (int a = 0; a < nL; ++a) L_edge[fill[pt2lm[h->obs[active[a]].pt]]++] = active[a];
@@ -600,7 +587,7 @@ mage_status initialize_optimization(mage_ba* h)
         });
         long long slot_obs = 0;
         for (long long c : part_count) slot_obs += c;
-        h->dup_slots = slot_obs != (long long)nw;
+        Z.dup_slots = slot_obs != (long long)nw;
     }
     MAGE_TRY(push(h->d_L_uv, L_uv, nL)); MAGE_TRY(push(h->d_L_info, L_info, nL)); MAGE_TRY(push(h->d_L_cam, L_cam, nL));
     MAGE_TRY(push(h->d_L_pt, L_pt, nL)); MAGE_TRY(push(h->d_L_slot, L_slot, nL));
@@ -722,8 +709,181 @@ mage_status initialize_optimization(mage_ba* h)
             for (size_t q2 = 0; q2 < per[x].size(); ++q2) blk_order[((q2 / G) * XCD + x) * G + (q2 % G)] = per[x][q2];
     }
     MAGE_TRY(push_vec(h->d_blk_order, blk_order));
-
     tm.mark("schur contributions");
+    Z.nL = nL; Z.nfc = nfc; Z.nlm = nlm; Z.nw = nw; Z.nblk = nblk; Z.n_blk_slots = (int)blk_order.size(); Z.ncon = ncon;
+    return MAGE_OK;
+}
+
+// Small device -> host read-back in the middle of a build: copy, then poll (a blocking synchronise costs 20-30 us of wake-up).
+mage_status read_back(mage_ba* h, void* dst_pinned, const void* src_device, size_t bytes)
+{
+    MAGE_HIP(hipMemcpyAsync(dst_pinned, src_device, bytes, hipMemcpyDeviceToHost, h->stream));
+    MAGE_HIP(hipEventRecord(h->ev[3], h->stream));
+    for (;;) {
+        const hipError_t e = hipEventQuery(h->ev[3]);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) MAGE_HIP(e);
+    }
+    return MAGE_OK;
+}
+
+// The lists on the device (ba_build.hip): the records go up as the setters left them, two small read-backs bring the sizes back.
+mage_status build_lists_device(mage_ba* h, PinnedArena& arena, const std::vector<int>& cam_extra_deg, bool have_tethers, PhaseTimer& tm,
+                               ListSizes& Z, std::vector<int>& cam2hc)
+{
+    static_assert(SCHUR_WAVES == 1, "the device build lays the slot -> block table out for one wavefront per workgroup");
+    const int nc = (int)h->cams.size(), np = (int)h->pt_set.size();
+    const size_t no = h->obs.size();
+    hipStream_t st = h->stream;
+    BuildArgs a{};
+    // ---- inputs
+    MAGE_TRY(h->d_obs_raw.reserve(no + 1));
+    if (no) MAGE_HIP(hipMemcpyAsync(h->d_obs_raw.p, h->obs.data(), no * sizeof(ObsRecord), hipMemcpyHostToDevice, st));   // pinned: one DMA
+    uint8_t* fixed = nullptr;
+    MAGE_TRY(arena.take((size_t)nc + 1, &fixed));
+    for (int i = 0; i < nc; ++i) fixed[i] = h->cams[i].fixed;
+    MAGE_TRY(h->d_cam_fixed.upload(fixed, (size_t)nc + 1, st));
+    if (have_tethers) {
+        int* extra = nullptr;
+        MAGE_TRY(arena.take((size_t)nc + 1, &extra));
+        std::memcpy(extra, cam_extra_deg.data(), (size_t)nc * sizeof(int));
+        MAGE_TRY(h->d_cam_extra.upload(extra, (size_t)nc + 1, st));
+    }
+    a.obs = h->d_obs_raw.p; a.n_obs = (int)no;
+    a.cam_fixed = h->d_cam_fixed.p; a.n_cams = nc; a.cam_extra_deg = have_tethers ? h->d_cam_extra.p : nullptr;
+    a.n_pts = np; a.points_fixed = h->points_fixed ? 1 : 0; a.keep_all_free_cameras = h->shard_ranks > 0 ? 1 : 0;
+    // ---- outputs and scratch of phase 1, sized by what was allocated through the surface
+    const size_t lm_max = std::min<size_t>((size_t)np, no);
+    MAGE_TRY(h->d_cam2hc.reserve((size_t)nc + 1)); MAGE_TRY(h->d_hc2cam.reserve((size_t)nc + 1));
+    MAGE_TRY(h->d_L_uv.reserve(no + 1)); MAGE_TRY(h->d_L_info.reserve(no + 1)); MAGE_TRY(h->d_L_cam.reserve(no + 1)); MAGE_TRY(h->d_L_pt.reserve(no + 1));
+    MAGE_TRY(h->d_L_slot.reserve(no + 1)); MAGE_TRY(h->d_L_edge.reserve(no + 1));
+    MAGE_TRY(h->d_lm_ptr.reserve(lm_max + 2)); MAGE_TRY(h->d_lm_pt.reserve(lm_max + 1)); MAGE_TRY(h->d_lm_wptr.reserve(lm_max + 2));
+    MAGE_TRY(h->d_w_hc.reserve(no + 1)); MAGE_TRY(h->d_w_lm.reserve(no + 1));
+    MAGE_TRY(h->d_b_cam_deg.reserve((size_t)nc + 1)); MAGE_TRY(h->d_b_pt_deg.reserve((size_t)np + 1)); MAGE_TRY(h->d_b_pt2lm.reserve((size_t)np + 1));
+    MAGE_TRY(h->d_b_bucket.reserve(no + 1)); MAGE_TRY(h->d_b_L_hc.reserve(no + 1)); MAGE_TRY(h->d_b_L_lm.reserve(no + 1)); MAGE_TRY(h->d_b_where.reserve(no + 1));
+    MAGE_TRY(h->d_b_scan.reserve(build_scan_tmp_elems(std::max<size_t>(std::max<size_t>(no, (size_t)np), (size_t)nc))));
+    MAGE_TRY(h->d_b_counts.reserve(1));
+    a.cam2hc = h->d_cam2hc.p; a.hc2cam = h->d_hc2cam.p;
+    a.L_uv = h->d_L_uv.p; a.L_info = h->d_L_info.p; a.L_cam = h->d_L_cam.p; a.L_pt = h->d_L_pt.p; a.L_slot = h->d_L_slot.p; a.L_edge = h->d_L_edge.p;
+    a.lm_ptr = h->d_lm_ptr.p; a.lm_pt = h->d_lm_pt.p; a.lm_wptr = h->d_lm_wptr.p; a.w_hc = h->d_w_hc.p; a.w_lm = h->d_w_lm.p;
+    a.cam_deg = h->d_b_cam_deg.p; a.pt_deg = h->d_b_pt_deg.p; a.pt2lm = h->d_b_pt2lm.p;
+    a.bucket = h->d_b_bucket.p; a.L_hc = h->d_b_L_hc.p; a.L_lm = h->d_b_L_lm.p; a.where = h->d_b_where.p;
+    a.scan_tmp = h->d_b_scan.p; a.counts = h->d_b_counts.p;
+    build_launch_phase1(a, st);
+    BuildCounts* hc = nullptr;
+    MAGE_TRY(arena.take(1, &hc));
+    MAGE_TRY(read_back(h, hc, a.counts, sizeof(BuildCounts)));
+    tm.mark("device: index maps, landmark order, slots");
+    Z.nL = hc->n_L; Z.nfc = hc->n_fc; Z.nlm = hc->n_lm; Z.nw = hc->n_w; Z.ncon = (size_t)hc->n_con;
+    Z.dup_slots = hc->slot_obs != hc->n_w;
+    if (Z.ncon > (size_t)0x7fffffff)
+        return fail(MAGE_ERR_UNSUPPORTED, "%zu Schur contributions exceed the 32-bit index range of the block lists (tracks too long)", Z.ncon);
+    if (Z.nfc * 6 > CHOL_MAX_ORDER) return fail(MAGE_ERR_UNSUPPORTED, "reduced camera system of order %d exceeds %d (one resident workgroup per tile column)", Z.nfc * 6, CHOL_MAX_ORDER);
+    if (have_tethers) {                      // the tether gather lists are built on the host from the index map (a few entries)
+        int* c2h = nullptr;
+        MAGE_TRY(arena.take((size_t)nc + 1, &c2h));
+        MAGE_TRY(read_back(h, c2h, a.cam2hc, (size_t)nc * sizeof(int)));
+        cam2hc.assign(c2h, c2h + nc);
+    }
+    // ---- per-camera views and the rows of S
+    const int nfc = Z.nfc;
+    const size_t blk_max = std::min<size_t>((size_t)nfc * ((size_t)nfc + 1) / 2, Z.ncon + (size_t)nfc);
+    MAGE_TRY(h->d_camE.reserve((size_t)Z.nL + 1)); MAGE_TRY(h->d_camS.reserve((size_t)Z.nw + 1));
+    MAGE_TRY(h->d_camE_ptr.reserve((size_t)nfc + 2)); MAGE_TRY(h->d_camS_ptr.reserve((size_t)nfc + 2));
+    const int nb_hist = std::max(build_split_blocks((int)no, nfc), build_split_blocks(Z.nw, nfc));
+    MAGE_TRY(h->d_b_hist.reserve((size_t)nb_hist * (size_t)std::max(nfc, 1) + 1));
+    MAGE_TRY(h->d_b_row.reserve((size_t)nfc + 2));
+    MAGE_TRY(h->d_con.reserve(Z.ncon + 1));
+    MAGE_TRY(h->d_blk_ptr.reserve(blk_max + 2)); MAGE_TRY(h->d_blk_ij.reserve(blk_max + 1));
+    a.camE_ptr = h->d_camE_ptr.p; a.camE = h->d_camE.p; a.camS_ptr = h->d_camS_ptr.p; a.camS = h->d_camS.p;
+    a.hist = h->d_b_hist.p; a.row = h->d_b_row.p; a.con = h->d_con.p; a.blk_ptr = h->d_blk_ptr.p; a.blk_ij = h->d_blk_ij.p;
+    if (nfc > 0) {
+        build_launch_camera_views(a, nfc, Z.nw, st);
+        build_launch_row_count(a, nfc, st);
+        build_launch_row_fill(a, nfc, st);
+        MAGE_TRY(read_back(h, hc, a.counts, sizeof(BuildCounts)));
+        Z.nblk = hc->n_blk;
+        Z.n_blk_slots = hc->xcd_longest * 8;
+        MAGE_TRY(h->d_blk_order.reserve((size_t)Z.n_blk_slots + 1));
+        a.blk_order = h->d_blk_order.p;
+        build_launch_blk_order(a, Z.n_blk_slots, st);
+    } else {
+        // no free camera: empty camera views (the offset arrays are still read)
+        MAGE_HIP(hipMemsetAsync(h->d_camE_ptr.p, 0, 2 * sizeof(int), st)); MAGE_HIP(hipMemsetAsync(h->d_camS_ptr.p, 0, 2 * sizeof(int), st));
+        MAGE_HIP(hipMemsetAsync(h->d_blk_ptr.p, 0, 2 * sizeof(int), st));
+        MAGE_TRY(h->d_blk_order.reserve(1));
+        Z.nblk = 0; Z.n_blk_slots = 0;
+    }
+    MAGE_HIP(hipGetLastError());
+    tm.mark("device: camera views, block lists");
+    return MAGE_OK;
+}
+
+mage_status initialize_optimization(mage_ba* h)
+{
+    PhaseTimer tm;
+    MAGE_DEVICE_SCOPE(h->device);
+    const int nc = (int)h->cams.size(), np = (int)h->pt_set.size();
+    // Lists that go to the device are built in pinned memory and copied as soon as they are complete, so the DMA overlaps
+    // the rest of the build; small ones are staged through the same arena.  ONE synchronisation at the end releases it.
+    PinnedArena arena;
+    if (!h->state_on_device) MAGE_TRY(upload_state(h, &arena));
+    else {
+        // Trials only write the entities that are in the system, and accepting a trial swaps the two
+        // state buffers; an entity that just left the system (all its observations removed) must
+        // therefore hold its kept estimate in BOTH buffers.
+        if (nc) MAGE_HIP(hipMemcpyAsync(h->d_pose[h->cur ^ 1].p, h->d_pose[h->cur].p, (size_t)nc * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if (np) MAGE_HIP(hipMemcpyAsync(h->d_pt[h->cur ^ 1].p, h->d_pt[h->cur].p, (size_t)np * 4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+    tm.mark("state upload");
+
+    // tether edges: active unless both endpoints are fixed (OptimizableGraph::Edge::allVerticesFixed); they keep a
+    // free camera in the system even when it has no observation
+    std::vector<int> T_kind; std::vector<int2> T_cam, T_fixed; std::vector<double> T_meas, T_w;
+    std::vector<int> cam_extra_deg(nc, 0);
+    for (int k = 0; k < 3; ++k)
+        for (const HostTether& t : h->teth[k]) {
+            if (!t.set) continue;
+            if (h->cams[t.c0].fixed && h->cams[t.c1].fixed) continue;
+            T_kind.push_back(k);
+            T_cam.push_back(make_int2((int)t.c0, (int)t.c1));
+            T_fixed.push_back(make_int2(h->cams[t.c0].fixed ? 1 : 0, h->cams[t.c1].fixed ? 1 : 0));
+            for (int a = 0; a < 4; ++a) T_meas.push_back(t.q[a]);
+            for (int a = 0; a < 3; ++a) T_meas.push_back(t.t[a]);
+            T_meas.push_back(t.dist);
+            T_w.push_back(t.w);
+            cam_extra_deg[t.c0]++; cam_extra_deg[t.c1]++;
+        }
+    const int nT = (int)T_kind.size();
+
+    ListSizes Z;
+    std::vector<int> cam2hc;
+    std::vector<uint32_t> L_edge;
+    const bool on_device = use_device_build(h, h->obs.size());
+    if (on_device) MAGE_TRY(build_lists_device(h, arena, cam_extra_deg, nT > 0, tm, Z, cam2hc));
+    else MAGE_TRY(build_lists_host(h, arena, cam_extra_deg, tm, Z, cam2hc, L_edge));
+    const int nL = Z.nL, nfc = Z.nfc, nlm = Z.nlm, nw = Z.nw, nblk = Z.nblk;
+    const size_t ncon = Z.ncon;
+    h->dup_slots = Z.dup_slots;
+    const bool points_free = !h->points_fixed;
+    h->useless = (nfc + (points_free ? nlm : 0)) == 0;
+    if (h->shard_ranks > 0) {
+        if (nfc == 0) return fail(MAGE_ERR_UNSUPPORTED, "a landmark-sharded map needs a free camera (without one the landmarks are independent: solve them unsharded)");
+        h->useless = false;              // a rank without landmarks still takes part in every exchange
+    }
+    hipStream_t st = h->stream;
+    auto push = [&](auto& dbuf, const auto* src, size_t count) -> mage_status {
+        MAGE_TRY(dbuf.reserve(count));
+        if (count) MAGE_HIP(hipMemcpyAsync(dbuf.p, src, count * sizeof(*src), hipMemcpyHostToDevice, st));
+        return MAGE_OK;
+    };
+    auto push_vec = [&](auto& dbuf, const auto& vec) -> mage_status {
+        typename std::remove_reference<decltype(vec)>::type::value_type* q = nullptr;
+        MAGE_TRY(arena.take(vec.size(), &q));
+        if (!vec.empty()) std::memcpy(q, vec.data(), vec.size() * sizeof(*q));
+        return push(dbuf, q, vec.size());
+    };
+
     // tether gather lists: per camera (tether, side) and per free-camera pair i < j (tether, transposed), tether order kept
     std::vector<int> tc_hc, tc_ptr{ 0 }, tc_item, tp_ptr{ 0 }, tp_item; std::vector<int2> tp_ij;
     if (nT > 0) {
@@ -814,7 +974,7 @@ mage_status initialize_optimization(mage_ba* h)
     v.lm_ptr = h->d_lm_ptr.p; v.lm_pt = h->d_lm_pt.p; v.lm_wptr = h->d_lm_wptr.p; v.w_hc = h->d_w_hc.p; v.w_lm = h->d_w_lm.p;
     v.camE_ptr = h->d_camE_ptr.p; v.camE = h->d_camE.p; v.camS_ptr = h->d_camS_ptr.p; v.camS = h->d_camS.p;
     v.blk_ptr = h->d_blk_ptr.p; v.blk_ij = h->d_blk_ij.p; v.con = h->d_con.p;
-    v.blk_order = h->d_blk_order.p; v.n_blk_slots = (int)blk_order.size();
+    v.blk_order = h->d_blk_order.p; v.n_blk_slots = Z.n_blk_slots;
     v.n_T = nT; v.n_tc = (int)tc_hc.size(); v.n_tp = (int)tp_ij.size();
     v.T_kind = h->d_T_kind.p; v.T_cam = h->d_T_cam.p; v.T_fixed = h->d_T_fixed.p; v.T_meas = h->d_T_meas.p; v.T_w = h->d_T_w.p; v.T_out = h->d_T_out.p;
     v.tc_hc = h->d_tc_hc.p; v.tc_ptr = h->d_tc_ptr.p; v.tc_item = h->d_tc_item.p;
@@ -825,7 +985,8 @@ mage_status initialize_optimization(mage_ba* h)
     v.Dinv = h->d_Dinv.p; v.db = h->d_db.p; v.S = h->d_S.p; v.y = h->d_y.p; v.xc = h->d_xc.p; v.xl = h->d_xl.p;
     v.partial = h->d_partial.p; v.scal = h->d_scal.p;
     refresh_view_state(h);
-    h->L_edge_host.swap(L_edge);
+    h->L_edge_host.swap(L_edge);          // device build: empty, fetched if the pose-only path ever needs it (mage_ba_step)
+    h->built_on_device = on_device;
     h->prof.system_order = n; h->prof.padded_order = n_pad;
     h->prof.factor_flops_each = (double)n * n * n / 3.0;      // algorithmic: the system's order, not the padded one
     {   // algorithmic bytes of the HBM-bound stages for this problem (each array counted once per stage)
@@ -1101,6 +1262,7 @@ MAGE_EXPORT mage_status mage_ba_create(const mage_ba_params* params, mage_ba** o
         MAGE_HIP(hipEventCreateWithFlags(&h->ev[3], hipEventDisableTiming));       // the scalar read-back's event; the others: ensure_events
         chol_init_device();
         ba_small_init_device();
+        build_init_device();
         *out = h.release();
         return MAGE_OK;
     });
@@ -1240,7 +1402,7 @@ MAGE_EXPORT mage_status mage_ba_alloc_observations(mage_ba* h, size_t count)
         if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
         if (h->obs_allocated) return fail(MAGE_ERR_INVALID_ARGUMENT, "observations can only be allocated once");
         if (count > 0x7fffffffull) return fail(MAGE_ERR_INVALID_ARGUMENT, "too many observations");
-        h->obs.assign(count, HostObs());
+        MAGE_TRY(h->obs.assign(count, HostObs()));
         h->obs_allocated = true;
         return MAGE_OK;
     });
@@ -1437,7 +1599,7 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
                 if (!cont) break;
             }
             // post-pass over the active observations of the last initialisation
-            if (!sharded && (v.n_L == 0 || h->L_edge_host.empty())) return MAGE_OK;     // count == 0 -> NaN
+            if (!sharded && v.n_L == 0) return MAGE_OK;     // count == 0 -> NaN
             int* small_counter = h->d_queue.p + chol_sync_ints(v.n_pad);
             if (!sharded && ba_small_applies(v)) ba_small_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, small_counter, h->stream);
             else ba_launch_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, h->stream);
@@ -1476,6 +1638,10 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
             } else {
                 h->flag_host.resize(v.n_L);
                 MAGE_HIP(hipMemcpyAsync(h->flag_host.data(), h->d_flagL.p, (size_t)v.n_L, hipMemcpyDeviceToHost, h->stream));
+                if (h->L_edge_host.size() != (size_t)v.n_L) {          // lists built on the device: the position -> observation map comes back once
+                    h->L_edge_host.resize(v.n_L);
+                    MAGE_HIP(hipMemcpyAsync(h->L_edge_host.data(), h->d_L_edge.p, (size_t)v.n_L * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+                }
                 MAGE_HIP(hipStreamSynchronize(h->stream));
                 ids.reserve(nout);
                 for (int i = 0; i < v.n_L; ++i) if (h->flag_host[i]) ids.push_back(h->L_edge_host[i]);
@@ -1705,6 +1871,63 @@ MAGE_EXPORT mage_status mage_ba_get_iter_stats(const mage_ba* h, mage_ba_iter_st
     *count = h->stats.size();
     for (size_t i = 0; out && i < h->stats.size() && i < capacity; ++i) out[i] = h->stats[i];
     return MAGE_OK;
+}
+
+// DIAGNOSTIC: one list of the graph structure as it sits on the device (tests compare the host and the device build with it).
+MAGE_EXPORT mage_status mage_ba_debug_structure(mage_ba* h, const char* name, void* out, size_t capacity_bytes, size_t* bytes)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !name || !bytes) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (h->dirty) return fail(MAGE_ERR_INVALID_ARGUMENT, "the structure is built by the first step");
+        MAGE_DEVICE_SCOPE(h->device);
+        const BaDeviceView& v = h->view;
+        const std::string n(name);
+        const void* src = nullptr; size_t nb = 0;
+        int ncon = 0;
+        if (v.n_blk > 0) {
+            MAGE_HIP(hipMemcpyAsync(&ncon, v.blk_ptr + v.n_blk, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            MAGE_HIP(hipStreamSynchronize(h->stream));
+        }
+        const int sizes[12] = { v.n_L, v.n_lm, v.n_fc, v.n_w, v.n_blk, v.n_blk_slots, ncon, v.dup_slots, v.n_pad, h->built_on_device ? 1 : 0, 0, 0 };
+        if (n == "sizes") { src = nullptr; nb = sizeof(sizes); }
+        else if (n == "cam2hc") { src = v.cam2hc; nb = (size_t)v.n_cams * 4; }
+        else if (n == "hc2cam") { src = v.hc2cam; nb = (size_t)v.n_fc * 4; }
+        else if (n == "L_edge") { src = v.L_edge; nb = (size_t)v.n_L * 4; }
+        else if (n == "L_uv") { src = v.L_uv; nb = (size_t)v.n_L * 8; }
+        else if (n == "L_info") { src = v.L_info; nb = (size_t)v.n_L * 4; }
+        else if (n == "L_cam") { src = v.L_cam; nb = (size_t)v.n_L * 4; }
+        else if (n == "L_pt") { src = v.L_pt; nb = (size_t)v.n_L * 4; }
+        else if (n == "L_slot") { src = v.L_slot; nb = (size_t)v.n_L * 4; }
+        else if (n == "lm_ptr") { src = v.lm_ptr; nb = (size_t)(v.n_lm + 1) * 4; }
+        else if (n == "lm_pt") { src = v.lm_pt; nb = (size_t)v.n_lm * 4; }
+        else if (n == "lm_wptr") { src = v.lm_wptr; nb = (size_t)(v.n_lm + 1) * 4; }
+        else if (n == "w_hc") { src = v.w_hc; nb = (size_t)v.n_w * 4; }
+        else if (n == "w_lm") { src = v.w_lm; nb = (size_t)v.n_w * 4; }
+        else if (n == "camE_ptr") { src = v.camE_ptr; nb = (size_t)(v.n_fc + 1) * 4; }
+        else if (n == "camS_ptr") { src = v.camS_ptr; nb = (size_t)(v.n_fc + 1) * 4; }
+        else if (n == "camS") { src = v.camS; nb = (size_t)v.n_w * 4; }
+        else if (n == "blk_ptr") { src = v.blk_ptr; nb = (size_t)(v.n_blk + 1) * 4; }
+        else if (n == "blk_ij") { src = v.blk_ij; nb = (size_t)v.n_blk * 8; }
+        else if (n == "con") { src = v.con; nb = (size_t)ncon * 8; }
+        else if (n == "blk_order") { src = v.blk_order; nb = (size_t)v.n_blk_slots * 4; }
+        else if (n == "camE") {
+            int ne = 0;
+            if (v.n_fc > 0) {
+                MAGE_HIP(hipMemcpyAsync(&ne, v.camE_ptr + v.n_fc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+                MAGE_HIP(hipStreamSynchronize(h->stream));
+            }
+            src = v.camE; nb = (size_t)ne * 4;
+        }
+        else return fail(MAGE_ERR_INVALID_ARGUMENT, "unknown list '%s'", name);
+        *bytes = nb;
+        if (!out || capacity_bytes < nb) return MAGE_OK;
+        if (n == "sizes") { std::memcpy(out, sizes, nb); return MAGE_OK; }
+        if (nb) {
+            MAGE_HIP(hipMemcpyAsync(out, src, nb, hipMemcpyDeviceToHost, h->stream));
+            MAGE_HIP(hipStreamSynchronize(h->stream));
+        }
+        return MAGE_OK;
+    });
 }
 
 MAGE_EXPORT mage_status mage_ba_enable_profiling(mage_ba* h, int enable)

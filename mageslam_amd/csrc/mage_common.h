@@ -133,6 +133,40 @@ struct PinnedArena {
     }
 };
 
+// A fixed-size array in pinned host memory (from the pinned cache): what the host keeps AND what is uploaded as it is -- the
+// observation records of a handle go to the device with one DMA straight from where the setters wrote them.
+template <typename T>
+struct PinnedVec {
+    T* p = nullptr;
+    size_t n = 0, bytes = 0;
+    PinnedVec() = default;
+    PinnedVec(const PinnedVec&) = delete;
+    PinnedVec& operator=(const PinnedVec&) = delete;
+    ~PinnedVec() { if (p) cached_pinned_release(p, bytes); }
+    mage_status assign(size_t count, const T& v)
+    {
+        if (count * sizeof(T) > bytes) {
+            if (p) { cached_pinned_release(p, bytes); p = nullptr; bytes = 0; }
+            void* q = nullptr;
+            MAGE_TRY(cached_pinned_alloc(&q, std::max<size_t>(count, 1) * sizeof(T), &bytes));
+            p = static_cast<T*>(q);
+        }
+        n = count;
+        std::fill(p, p + count, v);
+        return MAGE_OK;
+    }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+    T* begin() { return p; }
+    T* end() { return p + n; }
+    const T* begin() const { return p; }
+    const T* end() const { return p + n; }
+};
+
 // Grow-only device buffer.
 template <typename T>
 struct DevBuf {

@@ -25,6 +25,7 @@ struct Window {
     // result of the last step
     float mse = NAN;
     size_t n_outliers = 0;
+    size_t n_removed = 0;                        // observations removed by the outlier passes of EARLIER steps (they no longer count in mse)
     mage_status status = MAGE_OK;
     std::string error;
 };
@@ -50,6 +51,7 @@ struct mage_wmap {
     double* block = nullptr;                     // n_cams x 8 f64, device
     mage_allreduce_fn allreduce = nullptr;
     void* allreduce_ctx = nullptr;
+    bool exchanged = false;                      // the block holds the map only after the first exchange
 
     ~mage_wmap()
     {
@@ -166,6 +168,10 @@ MAGE_EXPORT mage_status mage_wmap_outer_iteration(mage_wmap* h, float huber, flo
     return guarded_w([&]() -> mage_status {
         if (!h || inner < 1) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle or inner < 1");
         if (mean_sq_err) *mean_sq_err = NAN;
+        // Without the exchange the block rows of the other ranks' windows would stay zero and be imported as poses
+        // (zero quaternion, zero translation) into every overlap / halo camera: refuse instead of corrupting the map.
+        if (h->P.world > 1 && !h->allreduce)
+            return fail(MAGE_ERR_INVALID_ARGUMENT, "a map sharded over %d ranks needs an all-reduce callback (mage_wmap_set_allreduce) before the first outer iteration", h->P.world);
         MAGE_DEVICE_SCOPE(h->device);
         // 1. the owned windows, independent between exchanges: `threads` host threads take them from a shared counter
         const std::vector<float> widths((size_t)inner, huber);
@@ -193,9 +199,13 @@ MAGE_EXPORT mage_status mage_wmap_outer_iteration(mage_wmap* h, float huber, flo
         for (int w : h->mine) {
             const Window& win = h->windows[w];
             if (win.status != MAGE_OK) return fail(win.status, "window %d: %s", w, win.error.c_str());
-            const size_t n = win.n_obs - win.n_outliers;
+            // the step's mean is over the observations that were active when it ran and were not classified as outliers by it:
+            // everything removed by earlier steps is out of the graph (BundlerLib.cpp:386-446)
+            const size_t gone = win.n_removed + win.n_outliers;
+            const size_t n = win.n_obs > gone ? win.n_obs - gone : 0;
             if (n > 0 && std::isfinite(win.mse)) { err_sum += (double)win.mse * (double)n; n_sum += n; }
         }
+        for (int w : h->mine) h->windows[w].n_removed += h->windows[w].n_outliers;
         if (mean_sq_err && n_sum) *mean_sq_err = err_sum / (double)n_sum;
         // 2. the exchange: zero, publish the owned rows, sum over the ranks, re-seed what each window does not own -- all in
         //    stream order on the device (every export / import is ordered as if enqueued on xstream)
@@ -210,6 +220,7 @@ MAGE_EXPORT mage_status mage_wmap_outer_iteration(mage_wmap* h, float huber, flo
             MAGE_TRY(mage_ba_import_poses_device(ba, h->block, h->xstream));
             if (lam > 0) MAGE_TRY(mage_ba_set_lambda(ba, lam));      // the damping carries over, as MappingWorker carries it from one BA to the next
         }
+        h->exchanged = true;
         return MAGE_OK;
     });
 }
@@ -218,6 +229,7 @@ MAGE_EXPORT mage_status mage_wmap_get_pose_block(mage_wmap* h, double* poses8)
 {
     return guarded_w([&]() -> mage_status {
         if (!h || !poses8) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (!h->exchanged) return fail(MAGE_ERR_INVALID_ARGUMENT, "the pose block is defined after the first outer iteration (nothing has been published yet)");
         MAGE_DEVICE_SCOPE(h->device);
         MAGE_HIP(hipMemcpyAsync(poses8, h->block, h->n_cams * 8 * sizeof(double), hipMemcpyDeviceToHost, h->xstream));
         MAGE_HIP(hipStreamSynchronize(h->xstream));

@@ -97,7 +97,9 @@ class WindowedMap:
             load(b, self.windows[w].scene)
             self.bundlers[w] = b
         self.on_device = bool(self.mine) and hasattr(self.bundlers[self.mine[0]], "ExportPosesDevice") and device is not None
-        self.block = np.zeros((scene.n_cams, 8))          # host copy of the pose block as of the last exchange
+        self.block = None                                 # host copy of the pose block as of the last exchange (None: fetch / none yet)
+        self.exchanged = False                            # the block is the MAP only after the first exchange (before it: nothing published)
+        self.removed = {w: 0 for w in self.mine}          # observations the outlier passes of earlier steps took out, per window
         if self.on_device:
             import torch
             self._torch = torch
@@ -115,7 +117,10 @@ class WindowedMap:
         def step(w):
             out: list = []
             mse = self.bundlers[w].StepBundleAdjustment([huber] * inner, max_err_sq, out)
-            return float(mse), self.windows[w].scene.n_obs - len(out)
+            # the step's mean is over what was active when it ran minus what it classified as outliers (BundlerLib.cpp:386-446)
+            n = self.windows[w].scene.n_obs - self.removed[w] - len(out)
+            self.removed[w] += len(out)
+            return float(mse), n
 
         # The windows of a rank are independent between exchanges: stepped from concurrent host threads, each handle on its
         # own stream, the chain-bound tail of one factorisation overlaps the matrix-core bulk of another.
@@ -133,6 +138,7 @@ class WindowedMap:
         return err_sum / n_sum if n_sum else float("nan")
 
     def exchange(self) -> None:
+        self.exchanged = True
         if self.on_device:
             return self._exchange_device()
         block = np.zeros((self.scene.n_cams, 8))
@@ -185,6 +191,9 @@ class WindowedMap:
 
     def pose_block(self) -> np.ndarray:
         """(n_cams, 8) float64 rows qx qy qz qw tx ty tz 0 of the whole map as of the last exchange."""
+        if not self.exchanged:
+            # before the first exchange nothing has been published: zero rows would read as identity rotations at the origin
+            raise RuntimeError("the pose block is defined after the first exchange (outer_iteration() or exchange())")
         if self.block is None:
             self.block = self.tblock.cpu().numpy()
         return self.block

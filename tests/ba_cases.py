@@ -68,3 +68,27 @@ def run_case(bundler, load_scene, name, rtol_state=1e-9, rtol_chi=1e-9):
     np.testing.assert_allclose(R0.reshape(3, 3).T, z["exp_R"][-1].astype(np.float32), atol=1e-6)
     np.testing.assert_allclose(bundler.GetPoint(3), z["exp_X"][3].astype(np.float32), rtol=1e-6, atol=1e-6)
     return bundler
+
+
+def random_graph_scene(case):
+    """Scene number `case` of the differential structure tests: the observation list shuffled, thinned, with duplicate (camera,
+    point) pairs, random fixed flags and (every third case) tethers.  Returns (scene, points_fixed, tethered)."""
+    from mageslam_amd import scene as _scene
+    rng = np.random.default_rng(0xBA5E + case)
+    n_cams = int(rng.integers(2, 14)); n_pts = int(rng.integers(6, 80)); K = int(rng.integers(2, min(n_cams, 6) + 1))
+    s = _scene.make_scene(n_cams=n_cams, n_pts=n_pts, n_obs=n_pts * K, seed=0x5EED2000 + case, fixed=(), outlier_frac=0.05 * (case % 3))
+    idx = rng.permutation(s.n_obs)                                  # BundleAdjust.cpp feeds observations in map order, not by point
+    idx = idx[rng.random(s.n_obs) > 0.1]                            # some points lose observations (a few lose all of them)
+    dup = rng.choice(idx, size=max(1, len(idx) // 8))               # the same (camera, point) observed twice
+    idx = np.concatenate([idx, dup])
+    s.obs_uv, s.obs_cam, s.obs_pt, s.obs_info = s.obs_uv[idx], s.obs_cam[idx], s.obs_pt[idx], s.obs_info[idx]
+    s.obs_uv = s.obs_uv.copy(); s.obs_uv[len(idx) - len(dup):] += rng.normal(0, 0.5, (len(dup), 2)).astype(np.float32)
+    s.n_obs = len(idx)
+    fixed = rng.random(n_cams) < 0.3
+    fixed[int(rng.integers(0, n_cams))] = True                      # at least one anchor
+    s.cam_fixed = fixed
+    tethered = case % 3 == 2 and n_cams >= 3
+    if tethered:
+        s.tethers = _scene.make_tethers(s, n_dist=2, n_rot=1, n_xf=2, seed=0x7E7E0100 + case)
+    points_fixed = case % 8 == 7
+    return s, points_fixed, tethered

@@ -244,23 +244,8 @@ def test_randomised_graph_shapes_match_oracle(case):
     """Differential test of the structure build: scenes whose observation list is shuffled, thinned, carries duplicate
     (camera, point) pairs, random fixed flags and (every third case) tethers; HIP and oracle must agree on every integer
     output and to 1e-8 on the state (tethered cases: the numeric-Jacobian tolerance of ba_cases.py)."""
-    rng = np.random.default_rng(0xBA5E + case)
-    n_cams = int(rng.integers(2, 14)); n_pts = int(rng.integers(6, 80)); K = int(rng.integers(2, min(n_cams, 6) + 1))
-    s = scene.make_scene(n_cams=n_cams, n_pts=n_pts, n_obs=n_pts * K, seed=0x5EED2000 + case, fixed=(), outlier_frac=0.05 * (case % 3))
-    idx = rng.permutation(s.n_obs)                                  # BundleAdjust.cpp feeds observations in map order, not by point
-    idx = idx[rng.random(s.n_obs) > 0.1]                            # some points lose observations (a few lose all of them)
-    dup = rng.choice(idx, size=max(1, len(idx) // 8))               # the same (camera, point) observed twice
-    idx = np.concatenate([idx, dup])
-    s.obs_uv, s.obs_cam, s.obs_pt, s.obs_info = s.obs_uv[idx], s.obs_cam[idx], s.obs_pt[idx], s.obs_info[idx]
-    s.obs_uv = s.obs_uv.copy(); s.obs_uv[len(idx) - len(dup):] += rng.normal(0, 0.5, (len(dup), 2)).astype(np.float32)
-    s.n_obs = len(idx)
-    fixed = rng.random(n_cams) < 0.3
-    fixed[int(rng.integers(0, n_cams))] = True                      # at least one anchor
-    s.cam_fixed = fixed
-    tethered = case % 3 == 2 and n_cams >= 3
-    if tethered:
-        s.tethers = scene.make_tethers(s, n_dist=2, n_rot=1, n_xf=2, seed=0x7E7E0100 + case)
-    points_fixed = case % 8 == 7
+    from ba_cases import random_graph_scene
+    s, points_fixed, tethered = random_graph_scene(case)
     calls = [([1.8], 30.0), ([0.9, 0.9], 16.0), ([0.9], 9.0)]
     _compare_with_oracle(s, points_fixed, calls, rtol=1e-6 if tethered else 1e-8)
 
