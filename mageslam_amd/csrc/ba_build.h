@@ -55,29 +55,32 @@ struct BuildArgs {
     int* cam_deg; int* pt_deg; int* pt2lm;         // n_cams, n_pts (pt_deg doubles as the fill cursor of the bucket pass), n_pts
     unsigned long long* bucket;                    // n_obs keys (camera key << 32 | observation)
     int* L_hc; int* L_lm; int* where;              // per position: hessian camera or -1, landmark; per observation: position or -1
+    int* w_end;                                    // per slot: one past the last slot of its landmark
     unsigned long long* scan_tmp;                  // block sums of the scans
-    int* hist;                                     // multi-split histograms: blocks x n_fc
+    int* hist;                                     // stable splits: chunk histograms (both splits), then the group totals
     unsigned long long* row;                       // per row of S: (blocks << 40 | contributions), then their exclusive scan
     BuildCounts* counts;
 };
 
 constexpr int BUILD_SCAN_BLOCK = 2048;             // elements per workgroup of the scans
+constexpr int BUILD_ROW_KC = 12;                   // the row kernels read this many entries of w_hc past a slot unconditionally: pad w_hc by it
 inline size_t build_scan_tmp_elems(size_t n) { return (n + BUILD_SCAN_BLOCK - 1) / BUILD_SCAN_BLOCK + 2; }
-int build_split_blocks(int n_items, int n_fc);     // workgroups (one wavefront each) of a stable split by camera
+// counts, cam_deg and pt_deg sit behind each other in ONE allocation so that one fill clears them:
+//   [BuildCounts | cam_deg: n_cams + 1 ints | pt_deg: n_pts + 1 ints]
+inline size_t build_zeroed_bytes(int n_cams, int n_pts) { return sizeof(BuildCounts) + ((size_t)n_cams + 1 + (size_t)n_pts + 1) * sizeof(int); }
+size_t build_hist_ints(int n_obs, int n_fc_max);   // `hist` of the stable splits by camera (both splits, with their group totals)
 int build_row_waves(int n_fc);                     // wavefronts per row of S in the block-list kernels
 
 void build_init_device();                          // once per device: LDS opt-in of the row kernels
 
-// Phase 1 (sizes known: allocated cameras / points / observations): index maps, landmark order, slots.  Leaves n_L, n_fc, n_lm,
-// n_w, slot_obs and n_con in *counts.
-void build_launch_phase1(const BuildArgs& a, hipStream_t st);
-// Phase 2 (n_fc, n_w known on the host): per-camera views.
-void build_launch_camera_views(const BuildArgs& a, int n_fc, int n_w, hipStream_t st);
-// Phase 3 (n_con known: `con` allocated): rows of S -> row[], n_blk; then (blk arrays allocated for the bound n_blk_max) the
-// block lists, and the XCD runs in *counts.
-void build_launch_row_count(const BuildArgs& a, int n_fc, hipStream_t st);
-void build_launch_row_fill(const BuildArgs& a, int n_fc, hipStream_t st);
-// Phase 4 (n_blk, xcd_first known): the slot -> block table of k_schur_block.
+// Phase 1, everything whose size the host can bound from what was allocated through the surface (n_fc_max = cameras that are
+// not fixed): index maps, landmark order, slots, per-camera views, and the rows of S COUNTED.  Leaves n_L, n_fc, n_lm, n_w,
+// slot_obs, n_blk and n_con in *counts -- the one read-back a small problem needs.
+void build_launch_phase1(const BuildArgs& a, int n_fc_max, hipStream_t st);
+// Phase 2 (`con`, `blk_ptr`, `blk_ij` allocated): the block lists; want_xcd_runs: also the XCD runs of k_schur_block in *counts
+// (the second read-back, large problems only).
+void build_launch_row_fill(const BuildArgs& a, int n_fc, bool want_xcd_runs, hipStream_t st);
+// Phase 3 (xcd_first known): the slot -> block table of k_schur_block.
 void build_launch_blk_order(const BuildArgs& a, int n_blk_slots, hipStream_t st);
 
 }  // namespace mage

@@ -272,10 +272,11 @@ struct mage_ba {
     DevBuf<int> d_queue;
     // ---- device build of the structure (ba_build.h): the raw records and its scratch
     DevBuf<ObsRecord> d_obs_raw; DevBuf<uint8_t> d_cam_fixed; DevBuf<int> d_cam_extra;
-    DevBuf<int> d_b_cam_deg, d_b_pt_deg, d_b_pt2lm, d_b_L_hc, d_b_L_lm, d_b_where, d_b_hist;
+    DevBuf<int> d_b_pt2lm, d_b_L_hc, d_b_L_lm, d_b_where, d_b_hist, d_b_w_end;
     DevBuf<unsigned long long> d_b_bucket, d_b_scan, d_b_row;
-    DevBuf<BuildCounts> d_b_counts;
+    DevBuf<unsigned char> d_b_zeroed;             // [BuildCounts | cam_deg | pt_deg]: cleared by one fill
     bool built_on_device = false;
+    PinnedArena build_arena;            // staging of the last structure build: released at the next completed read-back (no synchronisation of its own)
     void* h_pinned = nullptr; size_t h_pinned_bytes = 0;     // one pinned block (from the cache) holding the mirrors below
     uint32_t* h_out_ids = nullptr;      // first OUT_PREFIX outlier ids of the last post-pass: they ride the scalar read-back
     double* h_scal = nullptr;           // pinned mirror of d_scal
@@ -346,16 +347,26 @@ mage_status download_state(const mage_ba* hc)
     mage_ba* h = const_cast<mage_ba*>(hc);
     if (!h->state_on_device || h->host_state_fresh) return MAGE_OK;
     MAGE_DEVICE_SCOPE(h->device);
-    // fixed points never change on the device: only the poses come back then (the tracker's per-frame call)
-    std::vector<double> pose(h->cams.size() * 8), pts(h->points_fixed ? 0 : h->pt_set.size() * 4);
-    if (!pose.empty()) MAGE_HIP(hipMemcpyAsync(pose.data(), h->d_pose[h->cur].p, pose.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (!pts.empty()) MAGE_HIP(hipMemcpyAsync(pts.data(), h->d_pt[h->cur].p, pts.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    MAGE_HIP(hipStreamSynchronize(h->stream));
+    // fixed points never change on the device: only the poses come back then (the tracker's per-frame call).  Pinned staging and
+    // a polled event: a copy into pageable memory goes through the runtime's own staging and a blocking synchronise (~50 us more
+    // on the local-BA problem, where the caller reads the state back after every optimisation, BundleAdjust.cpp:318-347)
+    const size_t n_pose = h->cams.size() * 8, n_pts = h->points_fixed ? 0 : h->pt_set.size() * 4;
+    PinnedArena stage;
+    double *pose = nullptr, *pts = nullptr;
+    MAGE_TRY(stage.take(n_pose + 1, &pose)); MAGE_TRY(stage.take(n_pts + 1, &pts));
+    if (n_pose) MAGE_HIP(hipMemcpyAsync(pose, h->d_pose[h->cur].p, n_pose * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (n_pts) MAGE_HIP(hipMemcpyAsync(pts, h->d_pt[h->cur].p, n_pts * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MAGE_HIP(hipEventRecord(h->ev[3], h->stream));
+    for (;;) {
+        const hipError_t e = hipEventQuery(h->ev[3]);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) MAGE_HIP(e);
+    }
     for (size_t i = 0; i < h->cams.size(); ++i) {
         for (int a = 0; a < 4; ++a) h->cams[i].q[a] = pose[i * 8 + a];
         for (int a = 0; a < 3; ++a) h->cams[i].t[a] = pose[i * 8 + 4 + a];
     }
-    for (size_t i = 0; i * 4 < pts.size(); ++i)
+    for (size_t i = 0; i * 4 < n_pts; ++i)
         for (int a = 0; a < 3; ++a) h->pts[i * 3 + a] = pts[i * 4 + a];
     h->host_state_fresh = true;
     return MAGE_OK;
@@ -753,28 +764,39 @@ mage_status build_lists_device(mage_ba* h, PinnedArena& arena, const std::vector
     a.cam_fixed = h->d_cam_fixed.p; a.n_cams = nc; a.cam_extra_deg = have_tethers ? h->d_cam_extra.p : nullptr;
     a.n_pts = np; a.points_fixed = h->points_fixed ? 1 : 0; a.keep_all_free_cameras = h->shard_ranks > 0 ? 1 : 0;
     // ---- outputs and scratch of phase 1, sized by what was allocated through the surface
+    int n_fc_max = 0;
+    for (int i = 0; i < nc; ++i) n_fc_max += h->cams[i].fixed ? 0 : 1;
+    if (n_fc_max * 6 > CHOL_MAX_ORDER && h->shard_ranks == 0) n_fc_max = std::min(n_fc_max, nc);      // (refused below once the exact count is known)
     const size_t lm_max = std::min<size_t>((size_t)np, no);
     MAGE_TRY(h->d_cam2hc.reserve((size_t)nc + 1)); MAGE_TRY(h->d_hc2cam.reserve((size_t)nc + 1));
     MAGE_TRY(h->d_L_uv.reserve(no + 1)); MAGE_TRY(h->d_L_info.reserve(no + 1)); MAGE_TRY(h->d_L_cam.reserve(no + 1)); MAGE_TRY(h->d_L_pt.reserve(no + 1));
     MAGE_TRY(h->d_L_slot.reserve(no + 1)); MAGE_TRY(h->d_L_edge.reserve(no + 1));
     MAGE_TRY(h->d_lm_ptr.reserve(lm_max + 2)); MAGE_TRY(h->d_lm_pt.reserve(lm_max + 1)); MAGE_TRY(h->d_lm_wptr.reserve(lm_max + 2));
-    MAGE_TRY(h->d_w_hc.reserve(no + 1)); MAGE_TRY(h->d_w_lm.reserve(no + 1));
-    MAGE_TRY(h->d_b_cam_deg.reserve((size_t)nc + 1)); MAGE_TRY(h->d_b_pt_deg.reserve((size_t)np + 1)); MAGE_TRY(h->d_b_pt2lm.reserve((size_t)np + 1));
+    MAGE_TRY(h->d_w_hc.reserve(no + 1 + BUILD_ROW_KC)); MAGE_TRY(h->d_w_lm.reserve(no + 1)); MAGE_TRY(h->d_b_w_end.reserve(no + 1));
+    MAGE_TRY(h->d_camE.reserve(no + 1)); MAGE_TRY(h->d_camS.reserve(no + 1));
+    MAGE_TRY(h->d_camE_ptr.reserve((size_t)n_fc_max + 2)); MAGE_TRY(h->d_camS_ptr.reserve((size_t)n_fc_max + 2));
+    MAGE_TRY(h->d_b_zeroed.reserve(build_zeroed_bytes(nc, np))); MAGE_TRY(h->d_b_pt2lm.reserve((size_t)np + 1));
     MAGE_TRY(h->d_b_bucket.reserve(no + 1)); MAGE_TRY(h->d_b_L_hc.reserve(no + 1)); MAGE_TRY(h->d_b_L_lm.reserve(no + 1)); MAGE_TRY(h->d_b_where.reserve(no + 1));
     MAGE_TRY(h->d_b_scan.reserve(build_scan_tmp_elems(std::max<size_t>(std::max<size_t>(no, (size_t)np), (size_t)nc))));
-    MAGE_TRY(h->d_b_counts.reserve(1));
+    MAGE_TRY(h->d_b_hist.reserve(build_hist_ints((int)no, n_fc_max)));
+    MAGE_TRY(h->d_b_row.reserve((size_t)n_fc_max + 2));
     a.cam2hc = h->d_cam2hc.p; a.hc2cam = h->d_hc2cam.p;
     a.L_uv = h->d_L_uv.p; a.L_info = h->d_L_info.p; a.L_cam = h->d_L_cam.p; a.L_pt = h->d_L_pt.p; a.L_slot = h->d_L_slot.p; a.L_edge = h->d_L_edge.p;
     a.lm_ptr = h->d_lm_ptr.p; a.lm_pt = h->d_lm_pt.p; a.lm_wptr = h->d_lm_wptr.p; a.w_hc = h->d_w_hc.p; a.w_lm = h->d_w_lm.p;
-    a.cam_deg = h->d_b_cam_deg.p; a.pt_deg = h->d_b_pt_deg.p; a.pt2lm = h->d_b_pt2lm.p;
-    a.bucket = h->d_b_bucket.p; a.L_hc = h->d_b_L_hc.p; a.L_lm = h->d_b_L_lm.p; a.where = h->d_b_where.p;
-    a.scan_tmp = h->d_b_scan.p; a.counts = h->d_b_counts.p;
-    build_launch_phase1(a, st);
+    a.camE_ptr = h->d_camE_ptr.p; a.camE = h->d_camE.p; a.camS_ptr = h->d_camS_ptr.p; a.camS = h->d_camS.p;
+    a.counts = reinterpret_cast<BuildCounts*>(h->d_b_zeroed.p);
+    a.cam_deg = reinterpret_cast<int*>(a.counts + 1); a.pt_deg = a.cam_deg + nc + 1;
+    a.pt2lm = h->d_b_pt2lm.p;
+    a.bucket = h->d_b_bucket.p; a.L_hc = h->d_b_L_hc.p; a.L_lm = h->d_b_L_lm.p; a.where = h->d_b_where.p; a.w_end = h->d_b_w_end.p;
+    a.scan_tmp = h->d_b_scan.p; a.hist = h->d_b_hist.p; a.row = h->d_b_row.p;
+    tm.mark("device: uploads + reserves");
+    build_launch_phase1(a, n_fc_max, st);
+    tm.mark("device: phase 1 enqueued");
     BuildCounts* hc = nullptr;
     MAGE_TRY(arena.take(1, &hc));
     MAGE_TRY(read_back(h, hc, a.counts, sizeof(BuildCounts)));
-    tm.mark("device: index maps, landmark order, slots");
-    Z.nL = hc->n_L; Z.nfc = hc->n_fc; Z.nlm = hc->n_lm; Z.nw = hc->n_w; Z.ncon = (size_t)hc->n_con;
+    tm.mark("device: maps, landmark order, slots, camera views, rows counted");
+    Z.nL = hc->n_L; Z.nfc = hc->n_fc; Z.nlm = hc->n_lm; Z.nw = hc->n_w; Z.ncon = (size_t)hc->n_con; Z.nblk = hc->n_blk;
     Z.dup_slots = hc->slot_obs != hc->n_w;
     if (Z.ncon > (size_t)0x7fffffff)
         return fail(MAGE_ERR_UNSUPPORTED, "%zu Schur contributions exceed the 32-bit index range of the block lists (tracks too long)", Z.ncon);
@@ -785,28 +807,27 @@ mage_status build_lists_device(mage_ba* h, PinnedArena& arena, const std::vector
         MAGE_TRY(read_back(h, c2h, a.cam2hc, (size_t)nc * sizeof(int)));
         cam2hc.assign(c2h, c2h + nc);
     }
-    // ---- per-camera views and the rows of S
+    // ---- the block lists of S
     const int nfc = Z.nfc;
-    const size_t blk_max = std::min<size_t>((size_t)nfc * ((size_t)nfc + 1) / 2, Z.ncon + (size_t)nfc);
-    MAGE_TRY(h->d_camE.reserve((size_t)Z.nL + 1)); MAGE_TRY(h->d_camS.reserve((size_t)Z.nw + 1));
-    MAGE_TRY(h->d_camE_ptr.reserve((size_t)nfc + 2)); MAGE_TRY(h->d_camS_ptr.reserve((size_t)nfc + 2));
-    const int nb_hist = std::max(build_split_blocks((int)no, nfc), build_split_blocks(Z.nw, nfc));
-    MAGE_TRY(h->d_b_hist.reserve((size_t)nb_hist * (size_t)std::max(nfc, 1) + 1));
-    MAGE_TRY(h->d_b_row.reserve((size_t)nfc + 2));
     MAGE_TRY(h->d_con.reserve(Z.ncon + 1));
-    MAGE_TRY(h->d_blk_ptr.reserve(blk_max + 2)); MAGE_TRY(h->d_blk_ij.reserve(blk_max + 1));
-    a.camE_ptr = h->d_camE_ptr.p; a.camE = h->d_camE.p; a.camS_ptr = h->d_camS_ptr.p; a.camS = h->d_camS.p;
-    a.hist = h->d_b_hist.p; a.row = h->d_b_row.p; a.con = h->d_con.p; a.blk_ptr = h->d_blk_ptr.p; a.blk_ij = h->d_blk_ij.p;
+    MAGE_TRY(h->d_blk_ptr.reserve((size_t)Z.nblk + 2)); MAGE_TRY(h->d_blk_ij.reserve((size_t)Z.nblk + 1));
+    a.con = h->d_con.p; a.blk_ptr = h->d_blk_ptr.p; a.blk_ij = h->d_blk_ij.p;
+    // the slot -> block table is k_schur_block's (large problems): the small-problem path walks the blocks in order
+    // (same predicate as ba_small_applies; a forced build mode is a test comparing every list)
+    const bool small_path = nfc > 0 && nfc * 6 <= 128 && !have_tethers && Z.nL <= (1 << 20) && h->shard_ranks == 0 && std::getenv("MAGE_BA_NO_SMALL_PATH") == nullptr;
+    const bool want_xcd = !small_path || std::getenv("MAGE_BA_BUILD") != nullptr;
     if (nfc > 0) {
-        build_launch_camera_views(a, nfc, Z.nw, st);
-        build_launch_row_count(a, nfc, st);
-        build_launch_row_fill(a, nfc, st);
-        MAGE_TRY(read_back(h, hc, a.counts, sizeof(BuildCounts)));
-        Z.nblk = hc->n_blk;
-        Z.n_blk_slots = hc->xcd_longest * 8;
-        MAGE_TRY(h->d_blk_order.reserve((size_t)Z.n_blk_slots + 1));
-        a.blk_order = h->d_blk_order.p;
-        build_launch_blk_order(a, Z.n_blk_slots, st);
+        build_launch_row_fill(a, nfc, want_xcd, st);
+        if (want_xcd) {
+            MAGE_TRY(read_back(h, hc, a.counts, sizeof(BuildCounts)));
+            Z.n_blk_slots = hc->xcd_longest * 8;
+            MAGE_TRY(h->d_blk_order.reserve((size_t)Z.n_blk_slots + 1));
+            a.blk_order = h->d_blk_order.p;
+            build_launch_blk_order(a, Z.n_blk_slots, st);
+        } else {
+            MAGE_TRY(h->d_blk_order.reserve(1));
+            Z.n_blk_slots = 0;
+        }
     } else {
         // no free camera: empty camera views (the offset arrays are still read)
         MAGE_HIP(hipMemsetAsync(h->d_camE_ptr.p, 0, 2 * sizeof(int), st)); MAGE_HIP(hipMemsetAsync(h->d_camS_ptr.p, 0, 2 * sizeof(int), st));
@@ -825,8 +846,11 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_DEVICE_SCOPE(h->device);
     const int nc = (int)h->cams.size(), np = (int)h->pt_set.size();
     // Lists that go to the device are built in pinned memory and copied as soon as they are complete, so the DMA overlaps
-    // the rest of the build; small ones are staged through the same arena.  ONE synchronisation at the end releases it.
-    PinnedArena arena;
+    // the rest of the build; small ones are staged through the same arena.  The arena is the handle's and goes back to the cache
+    // when the first LM trial's scalars have come back (read_scalars): the build ends without a synchronisation of its own, so the
+    // first iteration's launches queue up behind the last build kernels.
+    PinnedArena& arena = h->build_arena;
+    if (!arena.blocks.empty()) { MAGE_HIP(hipStreamSynchronize(h->stream)); arena.release(); }
     if (!h->state_on_device) MAGE_TRY(upload_state(h, &arena));
     else {
         // Trials only write the entities that are in the system, and accepting a trial swaps the two
@@ -963,9 +987,8 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_HIP(hipMemsetAsync(h->d_L_active.p, 1, (size_t)nL + 1, st));
     MAGE_TRY(ensure_pinned_mirrors(h));
     MAGE_HIP(hipMemsetAsync(h->d_errL.p, 0, ((size_t)nL * 2 + 2) * sizeof(double), st));
-    MAGE_HIP(hipStreamSynchronize(st));   // the pinned arena goes back to the cache
 
-    tm.mark("reserve + sync");
+    tm.mark("reserve");
     BaDeviceView& v = h->view;
     v.n_cams = nc; v.n_pts = np; v.n_L = nL; v.n_lm = nlm; v.n_fc = nfc; v.n_w = nw; v.n_blk = nblk; v.dup_slots = h->dup_slots ? 1 : 0;
     v.points_free = points_free ? 1 : 0; v.n_pad = n_pad;
@@ -1018,6 +1041,7 @@ mage_status read_scalars(mage_ba* h, size_t outlier_prefix = 0)
         if (e == hipSuccess) break;
         if (e != hipErrorNotReady) MAGE_HIP(e);
     }
+    if (!h->build_arena.blocks.empty()) h->build_arena.release();      // everything staged for the structure build has been consumed
     return MAGE_OK;
 }
 
@@ -1434,7 +1458,24 @@ MAGE_EXPORT mage_status mage_ba_set_observations_bulk(mage_ba* h, size_t count, 
         if (!h || !uv2 || !cam || !pt || !info) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
         if (count > h->obs.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "count %zu exceeds allocated observations %zu", count, h->obs.size());
         h->dirty = true;
-        for (size_t i = 0; i < count; ++i) MAGE_TRY(set_obs(h, i, uv2[i * 2], uv2[i * 2 + 1], cam[i], pt[i], info[i]));
+        // a million records are 24 MB written and 20 MB read: a few host threads, each on its own range (large maps only)
+        const int parts = parts_for((int)std::min<size_t>(count, 0x7fffffff), 131072);
+        if (parts <= 1) {
+            for (size_t i = 0; i < count; ++i) MAGE_TRY(set_obs(h, i, uv2[i * 2], uv2[i * 2 + 1], cam[i], pt[i], info[i]));
+            return MAGE_OK;
+        }
+        const size_t nc = h->cams.size(), np = h->pt_set.size();
+        std::vector<long long> bad(parts, -1);
+        HostObs* obs = h->obs.data();
+        parallel_ranges((int)count, parts, [&](int i0, int i1, int part) {
+            for (int i = i0; i < i1; ++i) {
+                if (cam[i] >= nc || pt[i] >= np) { if (bad[part] < 0) bad[part] = i; continue; }
+                HostObs& o = obs[i];
+                o.u = uv2[(size_t)i * 2]; o.v = uv2[(size_t)i * 2 + 1]; o.info = info[i]; o.cam = cam[i]; o.pt = pt[i]; o.set = 1; o.removed = 0;
+            }
+        });
+        for (long long b : bad)
+            if (b >= 0) return set_obs(h, (size_t)b, uv2[b * 2], uv2[b * 2 + 1], cam[b], pt[b], info[b]);      // reports the first offender of the lowest range
         return MAGE_OK;
     });
 }
@@ -1577,6 +1618,7 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
                         if (e == hipSuccess) break;
                         if (e != hipErrorNotReady) MAGE_HIP(e);
                     }
+                    if (!h->build_arena.blocks.empty()) h->build_arena.release();
                     const PoseLmResult& r = *h->h_pose_lm;
                     h->lambda = r.lambda; h->ni = r.ni; h->iteration = r.iteration;
                     if (r.flips & 1) { h->cur ^= 1; refresh_view_state(h); }
