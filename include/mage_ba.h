@@ -131,6 +131,11 @@ mage_status mage_ba_synchronize(mage_ba* h);
  * (op 0: sum, 1: max), ordered after the work already enqueued on the HIP stream `stream` and before any enqueued later --
  * ncclAllReduce(buffer, buffer, count, ncclDouble, op, comm, stream) is exactly that (tools/sharded_rccl.cpp).  Every rank
  * must receive the same bytes (RCCL's ring and tree algorithms do).  Non-zero return = failure (the step returns MAGE_ERR_DEVICE).
+ * Failures are collective where the library can make them so: a rank that cannot build its part of the problem (out of memory,
+ * an unsupported shape) or whose dense solve reports a stalled hand-off tells the others through the step's flag / the trial's
+ * scalars, and mage_ba_step returns an error on EVERY rank at the same point.  A failing `allreduce` callback cannot be made
+ * collective by the library (the communicator itself is broken): the caller must abort the communicator (ncclCommAbort) so that
+ * the other ranks leave their pending collective.
  * n_ranks = 0 switches sharding off. */
 typedef int (*mage_ba_allreduce_fn)(void* user, double* buffer_device, size_t count, int op, void* stream);
 mage_status mage_ba_set_landmark_shard(mage_ba* h, int rank, int n_ranks, mage_ba_allreduce_fn allreduce, void* user);

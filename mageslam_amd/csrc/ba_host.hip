@@ -1117,7 +1117,11 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
             }
             if (sharded) {
                 MAGE_TRY(all_reduce(v.scal + SC_SCALE, 1, 0));
-                MAGE_TRY(all_reduce(v.scal + SC_CHI_TRIAL, 1, 0));
+                // chi2 of the trial and, in the same call, the "hand-off timed out" flag of the dense solve (adjacent scalars): a
+                // rank whose solve stalled makes EVERY rank return MAGE_ERR_DEVICE below instead of leaving the others in the
+                // next all-reduce
+                static_assert(SC_CHOL_STALL == SC_CHI_TRIAL + 1, "the trial's chi2 and the stall flag travel together");
+                MAGE_TRY(all_reduce(v.scal + SC_CHI_TRIAL, 2, 0));
             }
         }
         if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[3], st));
@@ -1582,22 +1586,39 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
         size_t out_prefix = 0;
         const bool sharded = h->shard_ranks > 0;
         if (sharded && !h->shard_reduce) return fail(MAGE_ERR_INVALID_ARGUMENT, "landmark-sharded map without an all-reduce callback");
-        if (sharded && n_iter == 0 && h->dirty) MAGE_TRY(initialize_optimization(h));     // the post-pass below is collective
-        if (n_iter > 0) {
-            // StepOptimizer's entry conditions (BundlerLib.cpp:132-149), then: a pose-only problem runs the whole call in one launch
+        {
+            // StepOptimizer's entry conditions (BundlerLib.cpp:132-149).  A landmark-sharded map enters collectively: the ranks
+            // agree ONCE per step (a) that every rank has its structure -- a rank whose build failed (out of memory, an
+            // unsupported shape) must not leave the others waiting in the next all-reduce, so the flag carries the failure and
+            // ALL ranks abandon the step -- and (b) whether the optimiser starts over: the reference does when anything changed
+            // (BundlerLib.cpp:135-138), and here "anything" includes another rank's observations.
             const bool reinit = h->dirty || h->soft_dirty;
-            if (h->dirty) MAGE_TRY(initialize_optimization(h));
+            mage_status init_rc = MAGE_OK;
+            std::string init_err;
+            if (h->dirty && (n_iter > 0 || sharded)) {          // (sharded, no iteration: the post-pass below is collective too)
+                init_rc = initialize_optimization(h);
+                if (init_rc != MAGE_OK) {
+                    if (!sharded) return init_rc;
+                    init_err = last_error_ref();
+                }
+            }
             if (sharded) {
-                // the graph changes between steps only (outliers removed, a camera fixed): the ranks agree ONCE per step whether
-                // the optimiser starts over -- the reference does when anything changed (BundlerLib.cpp:135-138), and here
-                // "anything" includes another rank's observations
-                h->h_scal[SC_SHARD_FLAG] = reinit ? 1.0 : 0.0;
+                if (init_rc != MAGE_OK) {                        // whatever the build got to: the flag needs the scalar block and its mirror
+                    if (h->d_scal.reserve(SC_PAD + 2) != MAGE_OK || ensure_pinned_mirrors(h) != MAGE_OK) { last_error_ref() = init_err; return init_rc; }
+                }
+                h->h_scal[SC_SHARD_FLAG] = init_rc != MAGE_OK ? 2.0 : (reinit ? 1.0 : 0.0);
                 MAGE_HIP(hipMemcpyAsync(h->d_scal.p + SC_SHARD_FLAG, h->h_scal + SC_SHARD_FLAG, sizeof(double), hipMemcpyHostToDevice, h->stream));
                 if (h->shard_reduce(h->shard_user, h->d_scal.p + SC_SHARD_FLAG, 1, 1, (void*)h->stream) != 0)
                     return fail(MAGE_ERR_DEVICE, "landmark-sharded map: the all-reduce callback failed");
                 MAGE_TRY(read_scalars(h));
-                if (h->h_scal[SC_SHARD_FLAG] != 0.0) { h->iteration = 0; h->soft_dirty = false; }
+                if (h->h_scal[SC_SHARD_FLAG] >= 2.0) {
+                    if (init_rc != MAGE_OK) { last_error_ref() = init_err; return init_rc; }
+                    return fail(MAGE_ERR_DEVICE, "landmark-sharded map: another rank could not build its part of the problem; the step was abandoned on every rank");
+                }
+                if (h->h_scal[SC_SHARD_FLAG] != 0.0 && n_iter > 0) { h->iteration = 0; h->soft_dirty = false; }
             }
+        }
+        if (n_iter > 0) {
             if (!sharded && !h->dirty && !h->useless && v.n_L > 0 && ba_pose_lm_applies(v, n_iter)) {
                 if (h->soft_dirty) {
                     h->iteration = 0; h->soft_dirty = false;

@@ -202,6 +202,8 @@ def _run_rccl(tmp_path, world, scene_path, steps, huber, thr, tag):
     if not os.path.exists(exe):
         import __graft_entry__ as G
         G.build_tools()
+    if not os.path.exists(exe):
+        pytest.skip("tools/_bin/sharded_rccl was not built (no RCCL on the build machine)")
     idf, outp = str(tmp_path / f"id_{tag}"), str(tmp_path / f"state_{tag}")
     procs = []
     for r in range(world):
