@@ -10,6 +10,21 @@ A "step" is one Levenberg-Marquardt iteration = one BundlerLib::StepBundleAdjust
 Huber width (all its damped trials, plus the reference's outlier-classification pass).  Inputs are
 resident in HBM when the timed region starts (the problem is uploaded and the graph structure is
 built during warm-up).  Rank 0 prints ONE JSON line.
+
+After the headline's timed region (never inside it) the same process measures, each bounded to seconds, what the other
+BASELINE.json configurations and a caller of the reference see, and reports it under "extra" (N = 1) and "strong_scaling" (any N):
+  extra.config2              ORB frames/s and matcher pairs/s at batch 1 / 64 / 1024 with the stage's HBM fraction, CPU oracle beside
+  extra.config3              local BA: steady ms per LM iteration AND create -> set -> one iteration -> read back -> destroy (the
+                             reference builds a bundler per optimisation, BundleAdjust.cpp:293, 348-351; its default local BA is
+                             ONE iteration, MageSettings.h:42-44), the reference's 10-call caller loop, CPU oracle beside
+  extra.config4_end_to_end   loop-closure global BA as Console configures it (25 iterations in one call, console.cpp:115-120)
+                             including create / set / structure build / read back / destroy, g2o's own lambda start
+  extra.sustained            >= 2 s of headline steps (scene re-loaded every 20 so that they stay single-trial), per-block spread;
+                             the same from g2o's own lambda start; one handle stepped 120 times without re-loading
+  extra.concurrent_handles   1 / 2 / 4 sub-maps stepped concurrently on this GPU (aggregate LM iterations/s: a labelled secondary)
+  extra.config5_windowed_1gpu / strong_scaling   ONE 8k-pose map in 8 keyframe windows, 8 / N windows per rank, pose block
+                             all-reduced in HBM (RCCL when N > 1): outer iterations/s -- the strong-scaling curve's point for this N
+--no-extras skips them; --submaps-per-gpu K steps K sub-maps per GPU concurrently in the replica mode (a labelled secondary).
 """
 from __future__ import annotations
 
@@ -86,6 +101,363 @@ def cpu_baseline(workload: str, min_iterations: int = 2, max_seconds: float = 45
     return res
 
 
+
+# ======================================================================================================================
+# extras: measured after the headline's timed region, each bounded to seconds; a failure is recorded, never raised
+# ======================================================================================================================
+def _finite(x):
+    """JSON has no NaN / Infinity: non-finite numbers become null."""
+    if isinstance(x, float):
+        return x if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    return x
+
+
+def _median_ms(xs):
+    return round(1e3 * float(np.median(xs)), 4)
+
+
+def _read_back(b):
+    """What the caller does after an optimisation: every pose and every map point (BundleAdjust.cpp:318-347)."""
+    b.GetPosesBulk()
+    (b.GetPointsBulk if hasattr(b, "GetPointsBulk") else b.points_f64)()
+
+
+def _one_shot(make, load, s, n_steps_per_call, hubers, thr, lam=None, calls=1):
+    """create -> Set* -> `calls` x StepBundleAdjustment(hubers) -> read the state back -> destroy; returns seconds per phase."""
+    t0 = time.perf_counter()
+    b = make()
+    t1 = time.perf_counter()
+    load(b, s)
+    if lam:
+        b.SetCurrentLambda(lam)
+    t2 = time.perf_counter()
+    out: list = []
+    mse = b.StepBundleAdjustment(hubers, thr, out)
+    t3 = time.perf_counter()
+    for _ in range(calls - 1):
+        mse = b.StepBundleAdjustment(hubers, thr, out)
+    t4 = time.perf_counter()
+    _read_back(b)
+    t5 = time.perf_counter()
+    b.close()
+    t6 = time.perf_counter()
+    return dict(create=t1 - t0, set=t2 - t1, first_call=t3 - t2, more_calls=t4 - t3, get=t5 - t4, destroy=t6 - t5, total=t6 - t0, mse=float(mse))
+
+
+def _caller_loop(make, load, s, huber=0.9):
+    """The reference's local-BA caller (BA-16, BundleAdjust.cpp:281-354): a bundler per run, 10 calls of one iteration each with
+    the outlier threshold shrinking by MaxOutlierErrorScaleFactor^2 per call, then the state read back."""
+    t0 = time.perf_counter()
+    b = make()
+    load(b, s)
+    thr, out = 7.25, []
+    for _ in range(10):
+        b.StepBundleAdjustment([huber], thr, out)
+        thr *= 0.95 * 0.95
+    _read_back(b)
+    b.close()
+    return time.perf_counter() - t0, len(out)
+
+
+def extra_config3(device):
+    from mageslam_amd import scene
+    from mageslam_amd.bundler import BundlerLib, load_scene
+    s = scene.make_scene(**WORKLOADS["local"])
+    so = scene.make_scene(**WORKLOADS["local"], outlier_frac=0.02)
+    make = lambda: BundlerLib(False, device=device)
+    load = lambda b, sc: load_scene(b, sc, bulk=True)
+    for _ in range(3):
+        _one_shot(make, load, s, 1, [0.9], 1e30)
+    shots = [_one_shot(make, load, s, 1, [0.9], 1e30) for _ in range(40)]
+    one = {k + "_ms": _median_ms([r[k] for r in shots]) for k in ("create", "set", "first_call", "get", "destroy", "total")}
+    # steady state: structure built, nothing removed, no re-seed of lambda
+    b = make(); load(b, s)
+    for _ in range(2):
+        b.StepBundleAdjustment([0.9], 1e30, [])
+    t0 = time.perf_counter()
+    n = 8
+    for _ in range(n):
+        b.StepBundleAdjustment([0.9], 1e30, [])
+    steady = (time.perf_counter() - t0) / n
+    trials = [t["trials"] for t in b.trace()]
+    b.close()
+    for _ in range(2):
+        _caller_loop(make, load, so)
+    loops = [_caller_loop(make, load, so) for _ in range(20)]
+    return {"workload": "local: 20 keyframes / 5000 points / 50000 observations, Huber 0.9, 7 keyframes fixed",
+            "steady_ms_per_lm_iteration": round(1e3 * steady, 4), "steady_last_trials": trials,
+            "one_iteration_bundler_create_to_destroy": one,
+            "caller_loop_10_calls_ms": _median_ms([t for t, _ in loops]), "caller_loop_outliers_removed": loops[-1][1],
+            "structure_build": "device (mageslam_amd/csrc/ba_build.hip)" if os.environ.get("MAGE_BA_BUILD", "d")[0] == "d" else "host"}
+
+
+def cpu_baseline_config3():
+    """The CPU oracle on the same local-BA legs (one thread, like the reference's g2o path)."""
+    from mageslam_amd import scene
+    from oracle.oracle import OracleBundler, load_scene_bulk
+    s = scene.make_scene(**WORKLOADS["local"])
+    so = scene.make_scene(**WORKLOADS["local"], outlier_frac=0.02)
+    make = lambda: OracleBundler(False)
+    shots = [_one_shot(make, load_scene_bulk, s, 1, [0.9], 1e30) for _ in range(5)]
+    b = make(); load_scene_bulk(b, s)
+    b.StepBundleAdjustment([0.9], 1e30, [])
+    t0 = time.perf_counter()
+    for _ in range(5):
+        b.StepBundleAdjustment([0.9], 1e30, [])
+    steady = (time.perf_counter() - t0) / 5
+    loops = [_caller_loop(make, load_scene_bulk, so) for _ in range(3)]
+    return {"kind": "port", "cores": 1, "steady_ms_per_lm_iteration": round(1e3 * steady, 3),
+            "one_iteration_bundler_create_to_destroy_ms": _median_ms([r["total"] for r in shots]),
+            "caller_loop_10_calls_ms": _median_ms([t for t, _ in loops])}
+
+
+def extra_config4_end_to_end(device):
+    from mageslam_amd import scene
+    from mageslam_amd.bundler import BundlerLib, load_scene
+    s = scene.make_scene(**WORKLOADS["global"])
+    make = lambda: BundlerLib(False, device=device)
+    load = lambda b, sc: load_scene(b, sc, bulk=True)
+    _one_shot(make, load, s, 25, [0.372231] * 25, 7.25)
+    runs = [_one_shot(make, load, s, 25, [0.372231] * 25, 7.25) for _ in range(3)]
+    first = [_one_shot(make, load, s, 1, [HUBER], 1e30) for _ in range(5)]
+    return {"workload": "global: 1000 / 100000 / 1000000, ONE StepBundleAdjustment call of 25 iterations, Huber 0.372231, "
+                        "MaxOutlierError 7.25 (console.cpp:115-120), g2o's own lambda start, create -> destroy",
+            "total_ms": _median_ms([r["total"] for r in runs]), "set_ms": _median_ms([r["set"] for r in runs]),
+            "step_call_ms": _median_ms([r["first_call"] for r in runs]), "get_ms": _median_ms([r["get"] for r in runs]),
+            "rmse_px": round(float(np.sqrt(runs[-1]["mse"])), 5),
+            "one_iteration_bundler": {"first_step_ms_structure_build_plus_one_iteration": _median_ms([r["first_call"] for r in first]),
+                                      "create_to_destroy_ms": _median_ms([r["total"] for r in first])}}
+
+
+def extra_sustained(device, min_seconds=2.0):
+    from mageslam_amd import scene
+    from mageslam_amd.bundler import BundlerLib, load_scene
+    s = scene.make_scene(**WORKLOADS["global"])
+
+    def blocks(lam, seconds):
+        per_block, trials, steps = [], 0, 0
+        t_all = time.perf_counter()
+        while sum(per_block) < seconds and time.perf_counter() - t_all < 4 * seconds + 5:
+            b = BundlerLib(False, device=device)
+            load_scene(b, s, bulk=True)
+            if lam:
+                b.SetCurrentLambda(lam)
+            out: list = []
+            for _ in range(3):
+                b.StepBundleAdjustment([HUBER], 1e30, out)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                b.StepBundleAdjustment([HUBER], 1e30, out)
+                trials += sum(t["trials"] for t in b.trace())
+            per_block.append(time.perf_counter() - t0)
+            steps += 20
+            b.close()
+        ms = [1e3 * t / 20 for t in per_block]
+        return {"steps": steps, "timed_seconds": round(sum(per_block), 3), "wall_seconds": round(time.perf_counter() - t_all, 3),
+                "ms_per_step": round(float(np.mean(ms)), 4), "ms_per_step_first_block": round(ms[0], 4), "ms_per_step_last_block": round(ms[-1], 4),
+                "ms_per_step_min_block": round(min(ms), 4), "ms_per_step_max_block": round(max(ms), 4),
+                "lm_iterations_per_s": round(1e3 / float(np.mean(ms)), 2), "trials_per_iteration": round(trials / steps, 4)}
+
+    res = {"seeded_lambda_5e6": blocks(LAMBDA_SEED["global"], min_seconds), "g2o_default_lambda": blocks(None, min_seconds / 2)}
+    # one handle, no re-load: the map converges after ~30 iterations and LM then takes extra damped trials per iteration
+    b = BundlerLib(False, device=device)
+    load_scene(b, s, bulk=True)
+    b.SetCurrentLambda(LAMBDA_SEED["global"])
+    out: list = []
+    tr = []
+    t0 = time.perf_counter()
+    n_steps = 120
+    for _ in range(n_steps):
+        b.StepBundleAdjustment([HUBER], 1e30, out)
+        tr.append(b.trace()[-1]["trials"])
+    el = time.perf_counter() - t0
+    res["one_handle_120_steps_no_reload"] = {"seconds": round(el, 3), "ms_per_step": round(1e3 * el / n_steps, 4),
+                                             "trials_per_iteration": round(float(np.mean(tr)), 4),
+                                             "ms_per_trial": round(1e3 * el / max(sum(tr), 1), 4),
+                                             "trials_first_30": round(float(np.mean(tr[:30])), 3), "trials_last_30": round(float(np.mean(tr[-30:])), 3),
+                                             "note": "the map has converged after ~30 iterations; every later iteration then ends in g2o's 10 rejected trials (Terminate), "
+                                                     "so ms_per_trial, not ms_per_step, is the comparable figure"}
+    b.close()
+    return res
+
+
+def extra_concurrent_handles(device, counts=(1, 2, 4), steps=12):
+    import threading
+    from mageslam_amd import scene
+    from mageslam_amd.bundler import BundlerLib, load_scene
+    res = {}
+    bs = []
+    for i in range(max(counts)):
+        s = scene.make_scene(**dict(WORKLOADS["global"], seed=WORKLOADS["global"]["seed"] + 0x100 * i))
+        b = BundlerLib(False, device=device)
+        load_scene(b, s, bulk=True)
+        b.SetCurrentLambda(LAMBDA_SEED["global"])
+        for _ in range(2):
+            b.StepBundleAdjustment([HUBER], 1e30, [])
+        bs.append(b)
+    for hn in counts:
+        gate = threading.Barrier(hn + 1)
+
+        def work(i):
+            gate.wait()
+            for _ in range(steps):
+                bs[i].StepBundleAdjustment([HUBER], 1e30, [])
+        th = [threading.Thread(target=work, args=(i,)) for i in range(hn)]
+        for t in th:
+            t.start()
+        gate.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        res[str(hn)] = {"lm_iterations_per_s_aggregate": round(hn * steps / dt, 2), "ms_per_iteration_per_handle": round(1e3 * dt / steps, 4)}
+    for b in bs:
+        b.close()
+    res["note"] = "independent 1k-pose sub-maps on concurrent host threads, one stream each; the headline stays ONE sub-map per GPU"
+    return res
+
+
+def extra_config2(device):
+    import threading
+    import torch
+    from mageslam_amd import frames
+    from mageslam_amd.orb import Matcher, OrbDetector
+    W, H, CAP = 640, 480, 440
+    base = [frames.frame_pair(500 + i) for i in range(8)]
+    a_set = np.stack([p[0] for p in base]); b_set = np.stack([p[1] for p in base])
+    det, mt = OrbDetector(device=device), Matcher(device=device)
+    res = {"workload": "640x480 synthetic frame pairs, default extractor settings (440 keypoints), MaxHammingDistance 30 / MinHammingDifference 1",
+           "batches": {}}
+    for batch in (1, 64, 1024):
+        imgs = torch.from_numpy(np.concatenate([a_set, b_set])[np.arange(2 * batch) % 16]).to(f"cuda:{device}").contiguous()
+        torch.cuda.synchronize()
+        for _ in range(2):
+            kp, de, cn = det.detect_batch_device(imgs.data_ptr(), 2 * batch, W, H, CAP)
+        reps = 20 if batch < 1024 else 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            kp, de, cn = det.detect_batch_device(imgs.data_ptr(), 2 * batch, W, H, CAP)
+        wall = (time.perf_counter() - t0) / reps
+        det.enable_profile(True)
+        for _ in range(2):
+            kp, de, cn = det.detect_batch_device(imgs.data_ptr(), 2 * batch, W, H, CAP)
+        p = det.profile()
+        det.enable_profile(False)
+        fps2 = None
+        if batch >= 64:        # two detectors fed from two host threads (the reference's ImageAnalyzer runs one per camera thread)
+            dets = [det, OrbDetector(device=device)]
+            for d in dets:
+                d.detect_batch_device(imgs.data_ptr(), 2 * batch, W, H, CAP)
+            gate = threading.Barrier(3)
+
+            def loop(d):
+                gate.wait()
+                for _ in range(reps):
+                    d.detect_batch_device(imgs.data_ptr(), 2 * batch, W, H, CAP)
+                gate.wait()
+            th = [threading.Thread(target=loop, args=(d,)) for d in dets]
+            for t in th:
+                t.start()
+            gate.wait(); t0 = time.perf_counter(); gate.wait()
+            fps2 = 2 * reps * 2 * batch / (time.perf_counter() - t0)
+            for t in th:
+                t.join()
+            kp, de, cn = det.detect_batch_device(imgs.data_ptr(), 2 * batch, W, H, CAP)
+        alg_bytes = 2 * batch * (W * H * 3 + CAP * 512 + CAP * 60)      # FAST read, blur read + write, BRIEF gathers, outputs (SURVEY 8d: 0.92 MB / frame)
+        dA, cA = de, cn
+        dB, cB = de + batch * CAP * 32, cn + batch * 4
+        for _ in range(2):
+            mt.match_batch_device(batch, dA, cA, CAP, dB, cB, CAP, 30, 1)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            mt.match_batch_device(batch, dA, cA, CAP, dB, cB, CAP, 30, 1)
+        mwall = (time.perf_counter() - t0) / reps
+        res["batches"][str(batch)] = {
+            "frames_per_s": round(2 * batch / wall, 1), "frames_per_s_two_detectors": None if fps2 is None else round(fps2, 1),
+            "ms_per_batch_of_frames": round(1e3 * wall, 4), "frames_in_batch": 2 * batch,
+            "stage_ms": {"fast_blur": round(p.fast_ms + p.blur_ms, 4), "select": round(p.select_ms, 4), "brief": round(p.brief_ms, 4), "events_total": round(p.total_ms, 4)},
+            "hbm_frac_algorithmic": round(alg_bytes / (p.total_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+            "pairs_per_s": round(batch / mwall, 1), "match_kernel_ms": round(mt.last_kernel_ms(), 4),
+            "match_gdistances_per_s": round(batch * 2 * CAP * CAP / (mt.last_kernel_ms() * 1e-3) / 1e9, 2)}
+    return res
+
+
+def cpu_baseline_config2(seconds=2.0):
+    """The CPU oracle on the same frames (one thread; the reference runs OpenCV single-threaded, cv::setNumThreads(0))."""
+    from mageslam_amd import frames
+    from oracle import oracle as O
+    base = [frames.frame_pair(500 + i) for i in range(4)]
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < seconds:
+        O.orb_detect(base[n % 4][0]); n += 1
+    fps = n / (time.perf_counter() - t0)
+    ka, da = O.orb_detect(base[0][0]); kb, db = O.orb_detect(base[0][1])
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < seconds:
+        O.match(da, db, 30, 1); n += 1
+    return {"kind": "port", "cores": 1, "frames_per_s": round(fps, 1), "pairs_per_s": round(n / (time.perf_counter() - t0), 1),
+            "sample": f"{seconds:.0f} s of oracle/orb_oracle.c on 640x480 frames + {seconds:.0f} s of oracle/match_oracle.c on one 440 x 440 pair"}
+
+
+def strong_scaling_windowed(device, dist, rank, world, poses=8000, windows=8, overlap=10, iters=10, warmup=2, threads=4):
+    """BASELINE.json configs[4], second form: ONE 8k-pose map cut into 8 keyframe windows, 8 / N windows per rank; an outer
+    iteration = one LM iteration in every window + the all-reduce of the (poses x 8) f64 pose block in HBM (RCCL when N > 1)."""
+    import torch
+    from mageslam_amd import dist as D, scene
+    from mageslam_amd.bundler import BundlerLib, load_scene
+    from mageslam_amd.windowed import WindowedMap
+    t0 = time.perf_counter()
+    s = scene.make_scene(n_cams=poses, n_pts=100 * poses, n_obs=1000 * poses, seed=0x5EED0008)
+    t1 = time.perf_counter()
+    m = WindowedMap(s, windows, lambda: BundlerLib(False, device=device), lambda b, sc: load_scene(b, sc, bulk=True), rank=rank, world=world,
+                    dist=dist, overlap=overlap, exchange_device=D.stats_device(device), threads=threads, device=device)
+    t2 = time.perf_counter()
+    errs = [m.outer_iteration(HUBER) for _ in range(warmup)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    errs += [m.outer_iteration(HUBER) for _ in range(iters)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t3
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=D.stats_device(device))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    for b in m.bundlers.values():
+        b.close()
+    return {"metric": "outer iterations/s of ONE windowed map (every window takes one LM iteration, then the pose-block exchange)",
+            "workload": f"one map of {poses} poses / {100 * poses} points / {1000 * poses} observations in {windows} keyframe windows, overlap {overlap}",
+            "scaling": "strong", "n_gpus": world, "windows_per_rank": len(m.mine), "windows_in_flight_per_rank": min(threads, max(len(m.mine), 1)),
+            "value": round(iters / el, 3), "unit": "outer iterations/s", "ms_per_outer_iteration": round(1e3 * el / iters, 3),
+            "lm_window_iterations_per_s": round(iters * windows / el, 2), "exchange_bytes_per_iteration": poses * 64,
+            "exchange": ("RCCL all-reduce of the pose block in HBM" if D.init.backend == "nccl" else
+                         ("gloo all-reduce through the host" if dist is not None else "single rank: the block never leaves HBM, no collective")),
+            "mse_of_rank0_windows": [round(float(e), 5) for e in errs], "scene_s": round(t1 - t0, 1), "cut_and_load_s": round(t2 - t1, 1)}
+
+
+def run_extras(device) -> dict:
+    legs = (("config3", lambda: extra_config3(device)), ("config3_cpu_baseline", cpu_baseline_config3),
+            ("config4_end_to_end", lambda: extra_config4_end_to_end(device)), ("sustained", lambda: extra_sustained(device)),
+            ("concurrent_handles", lambda: extra_concurrent_handles(device)),
+            ("config2", lambda: extra_config2(device)), ("config2_cpu_baseline", cpu_baseline_config2))
+    out = {}
+    for name, fn in legs:
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except Exception as e:  # noqa: BLE001 - an extra is a report, never a reason to lose the headline
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        out[name]["wall_s"] = round(time.perf_counter() - t0, 2)
+    return out
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +465,8 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="global", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra configurations measured after the headline")
+    ap.add_argument("--submaps-per-gpu", type=int, default=1, help="replica mode: K independent sub-maps stepped concurrently per GPU (a labelled secondary)")
     args = ap.parse_args()
 
     import torch
@@ -141,6 +515,33 @@ def main() -> int:
     elapsed = time.perf_counter() - t0
     elapsed, total_steps, worst_rmse = D.reduce_stats(dist, elapsed, args.steps, float(np.sqrt(mse)), device=D.stats_device(device))
     prof = b.profile()
+    b.close()                                       # the headline's handle: its buffers go back to the cache before the extras
+
+    # ---- after the timed region: the strong-scaling point of this N (every rank takes part), then rank 0's extras at N = 1
+    strong = None
+    if not args.no_extras and args.workload == "global":
+        t_s = time.perf_counter()
+        try:
+            strong = strong_scaling_windowed(device, dist, rank, world)
+        except Exception as e:  # noqa: BLE001 - a report, never a reason to lose the headline
+            strong = {"error": f"{type(e).__name__}: {e}"}
+        strong["wall_s"] = round(time.perf_counter() - t_s, 2)
+    secondary = None
+    if args.submaps_per_gpu > 1 and args.workload == "global":
+        # replica mode with K sub-maps per GPU: every rank steps K independent sub-maps from K host threads; aggregate over ranks
+        try:
+            r = extra_concurrent_handles(device, counts=(args.submaps_per_gpu,), steps=max(args.steps, 4))[str(args.submaps_per_gpu)]
+            agg, _, _ = D.reduce_stats(dist, r["ms_per_iteration_per_handle"] * 1e-3, 0, 0.0, device=D.stats_device(device))
+            secondary = {"submaps_per_gpu": args.submaps_per_gpu, "n_gpus": world,
+                         "lm_iterations_per_s_aggregate": round(world * args.submaps_per_gpu / agg, 2),
+                         "note": "LABELLED SECONDARY: K independent 1k-pose sub-maps stepped concurrently per GPU (max over ranks of the per-iteration time); the headline `value` stays one sub-map per GPU"}
+        except Exception as e:  # noqa: BLE001
+            secondary = {"error": f"{type(e).__name__}: {e}"}
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "global":
+        extra = run_extras(device)
+        if strong is not None:
+            extra["config5_windowed_1gpu"] = strong
 
     if rank == 0:
         value = total_steps / elapsed
@@ -217,7 +618,15 @@ def main() -> int:
                 line["cpu_baseline"] = cpu_baseline(args.workload)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "LM iterations/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(line), flush=True)
+        if strong is not None:
+            line["strong_scaling"] = strong
+        if secondary is not None:
+            line["replica_submaps_per_gpu"] = secondary
+        if extra is not None:
+            line["extra"] = extra
+        line["lambda_note"] = ("value is measured with SetCurrentLambda(5e6) (single-trial iterations, SURVEY 8d); from g2o's own lambda start the same "
+                               "window takes more trials per iteration: see extra.sustained.g2o_default_lambda")
+        print(json.dumps(_finite(line)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
