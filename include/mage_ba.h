@@ -236,6 +236,8 @@ typedef struct mage_ba_profile {
     double   update_ms_total;
     double   update_bytes_each;
 } mage_ba_profile;
+/* enable: 0 off; 1 every stage bracketed by event records (seven per LM trial: each costs a few microseconds of idle stream);
+ * 2 only the dense factorisation + solves (two per trial) -- what a timed run keeps on.  Enabling resets the sums. */
 mage_status mage_ba_enable_profiling(mage_ba* h, int enable);
 mage_status mage_ba_get_profile(const mage_ba* h, mage_ba_profile* out);
 

@@ -174,10 +174,13 @@ class BundlerLib:
 
     def StepBundleAdjustment(self, huber_width_per_iteration, max_error_square, outliers: list) -> float:
         hw = np.ascontiguousarray(huber_width_per_iteration, np.float32)
-        buf = np.zeros(max(self.n_obs, 1), np.uint32)
+        buf = getattr(self, "_out_buf", None)
+        if buf is None or buf.size < max(self.n_obs, 1):          # one buffer per handle, sized like the reference's ReserveOutliers
+            buf = self._out_buf = np.zeros(max(self.n_obs, 1), np.uint32)
         n, mse = C.c_size_t(0), C.c_float(0)
         check(self._L.mage_ba_step(self._h, hw, hw.size, float(max_error_square), buf, buf.size, C.byref(n), C.byref(mse)))
-        outliers.extend(int(x) for x in buf[: min(n.value, buf.size)])
+        if n.value:
+            outliers.extend(buf[: min(n.value, buf.size)].tolist())
         return float(mse.value)
 
     def GetOutliers(self) -> list:
@@ -234,13 +237,17 @@ class BundlerLib:
         return pts
 
     def trace(self):
-        arr = (IterStats * 64)()
+        arr = getattr(self, "_stats_buf", None)
+        if arr is None:
+            arr = self._stats_buf = (IterStats * 64)()
         n = C.c_size_t(0)
         check(self._L.mage_ba_get_iter_stats(self._h, arr, 64, C.byref(n)))
         return [dict(code=a.code, trials=a.trials, chi_before=a.chi2_before, chi_after=a.chi2_after, lam=a.lambda_)
                 for a in arr[: n.value]]
 
-    def enable_profiling(self, on=True): check(self._L.mage_ba_enable_profiling(self._h, int(on)))
+    def enable_profiling(self, on=True):
+        """True / 1: every stage of an LM iteration bracketed by HIP events; 2: only the dense factorisation + solves; False: off."""
+        check(self._L.mage_ba_enable_profiling(self._h, int(on)))
 
     STRUCTURE_LISTS = ("cam2hc", "hc2cam", "L_edge", "L_uv", "L_info", "L_cam", "L_pt", "L_slot", "lm_ptr", "lm_pt", "lm_wptr", "w_hc",
                        "w_lm", "camE_ptr", "camE", "camS_ptr", "camS", "blk_ptr", "blk_ij", "con", "blk_order")

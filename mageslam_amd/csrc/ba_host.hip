@@ -299,7 +299,8 @@ struct mage_ba {
 
     // ---- diagnostics
     std::vector<mage_ba_iter_stats> stats;
-    bool profiling = false;
+    bool profiling = false;             // stage events on: every stage of an LM iteration is bracketed
+    bool profiling_factor = false;      // only the dense factorisation + solves is bracketed (two event records per trial)
     mage_ba_profile prof{};
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
     hipEvent_t ev_p[4] = { nullptr, nullptr, nullptr, nullptr };     // profiling only: linearise begin / end, update begin / end
@@ -1047,8 +1048,17 @@ mage_status read_scalars(mage_ba* h, size_t outlier_prefix = 0)
 
 enum { LM_OK = 0, LM_TERMINATE = 1, LM_FAIL = 2 };
 
+// What mage_ba_step tells the LM solve about the call it is part of, so that the outlier pass can be queued behind the last
+// trial instead of waiting for the host (ba_launch_classify_after_trial): one host round trip per StepBundleAdjustment call.
+struct PostPassPlan {
+    bool last_iteration = false;     // in: no LM iteration follows in this call
+    double max_err_sq = 0;           // in
+    size_t prefix = 0;               // in: outlier ids that ride the scalars' read-back
+    bool done = false;               // out: the post-pass ran on the device and its sums / ids are in the pinned mirror
+};
+
 // OptimizationAlgorithmLevenberg::solve (appendix A.4); scalars only cross PCIe.
-mage_status lm_solve(mage_ba* h, double huber, int* result)
+mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan = nullptr)
 {
     hipStream_t st = h->stream;
     BaDeviceView& v = h->view;
@@ -1093,6 +1103,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
     bool have_chi = false;
     double rho = 0;
     int qmax = 0;
+    bool speculated = false;
     CholWorkspace ws{ h->d_Linv.p, h->d_queue.p, nullptr, v.scal + SC_CHOL_STALL };
     do {
         const double lambda = h->lambda;
@@ -1107,13 +1118,22 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
                 MAGE_TRY(all_reduce(h->d_xchg.p, ba_packed_doubles(v.n_pad), 0));
                 ba_launch_pack_lower(v, h->d_xchg.p, false, st);
             }
-            if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[1], st));
+            if (h->profiling || h->profiling_factor) MAGE_HIP(hipEventRecord(h->ev[1], st));
             chol_factor_solve(v.S, v.y, v.xc, v.n_pad, ws, v.scal + SC_CHOL_OK, st);
-            if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[2], st));
+            if (h->profiling || h->profiling_factor) MAGE_HIP(hipEventRecord(h->ev[2], st));
             if (ba_update_and_trial_error_fuses(v)) ba_launch_update_and_trial_error(v, lambda, adds_damping ? lambda : 0.0, huber, st);
             else {
                 ba_launch_update(v, lambda, adds_damping ? lambda : 0.0, st);
                 ba_launch_error(v, true, huber, st);
+            }
+            if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[3], st));        // end of the update stage (before the queued outlier pass)
+            if (plan && !sharded) {
+                // the outlier pass rides behind the trial: it runs only if this turns out to be the call's last trial
+                ClassifyAfterTrial c{};
+                c.chi_ref = currentChi; c.chi_on_device = have_chi ? 0 : 1; c.trials_done = qmax + 1; c.last_iteration = plan->last_iteration ? 1 : 0;
+                int* small_counter = h->d_queue.p + chol_sync_ints(v.n_pad);
+                ba_launch_classify_after_trial(v, c, plan->max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, st);
+                speculated = true;
             }
             if (sharded) {
                 MAGE_TRY(all_reduce(v.scal + SC_SCALE, 1, 0));
@@ -1124,8 +1144,8 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
                 MAGE_TRY(all_reduce(v.scal + SC_CHI_TRIAL, 2, 0));
             }
         }
-        if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[3], st));
-        MAGE_TRY(read_scalars(h));
+        if (h->profiling && small) MAGE_HIP(hipEventRecord(h->ev_p[3], st));
+        MAGE_TRY(read_scalars(h, speculated ? plan->prefix : 0));
         if (h->profiling) {
             float ms = 0;
             if (!lin_timed) {
@@ -1137,6 +1157,9 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
             h->prof.update_ms_total += ms; h->prof.update_launches++;
             MAGE_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
             h->prof.schur_ms_total += ms; h->prof.schur_launches++;
+        }
+        if (h->profiling || (h->profiling_factor && !small)) {
+            float ms = 0;
             MAGE_HIP(hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
             h->prof.factor_ms_total += ms; h->prof.n_factorizations++;
         }
@@ -1169,11 +1192,13 @@ mage_status lm_solve(mage_ba* h, double huber, int* result)
     tr.code = (qmax == 10 || rho == 0) ? LM_TERMINATE : LM_OK;
     if (h->stats.size() < 64) h->stats.push_back(tr);
     *result = tr.code;
+    // the queued outlier pass ran iff the device took the same decision as the loop above: "over, and (last iteration or Terminate)"
+    if (plan) plan->done = speculated && (plan->last_iteration || tr.code == LM_TERMINATE) && h->h_scal[SC_SPEC_DONE] == 1.0;
     return MAGE_OK;
 }
 
 // StepOptimizer::Step  (BundlerLib.cpp:132-149)
-mage_status step_optimizer(mage_ba* h, double huber, bool* cont)
+mage_status step_optimizer(mage_ba* h, double huber, bool* cont, PostPassPlan* plan = nullptr)
 {
     if (h->dirty) MAGE_TRY(initialize_optimization(h));
     else if (h->soft_dirty) {
@@ -1190,7 +1215,7 @@ mage_status step_optimizer(mage_ba* h, double huber, bool* cont)
     int r = LM_OK;
     PhaseTimer tm;
     const bool first = h->iteration == 0;
-    MAGE_TRY(lm_solve(h, huber, &r));
+    MAGE_TRY(lm_solve(h, huber, &r, plan));
     if (first) tm.mark("first LM iteration");
     h->iteration++;
     *cont = (r == LM_OK);
@@ -1656,28 +1681,42 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
             }
         }
         if (!in_one_launch) {
+            // the first OUT_PREFIX ids of the outlier list ride the same read-back as the three sums (usually that is the whole list:
+            // a run that removed outliers last time will again -- twice that many, at least 64, at most OUT_PREFIX; a 16 KB copy is ~8 us
+            // slower than a 100-byte one, so a run without outliers does not pay for it)
+            const size_t out_expect = h->out_expect;
+            auto prefix_now = [&]() { return std::min<size_t>(std::min<size_t>(OUT_PREFIX, (size_t)h->view.n_L), std::max<size_t>(64, 2 * out_expect)); };
+            static const bool no_spec = std::getenv("MAGE_BA_NO_QUEUED_POSTPASS") != nullptr;
+            bool post_done = false;
+            size_t prefix = 0;
             for (size_t it = 0; it < n_iter; ++it) {
                 bool cont = true;
-                MAGE_TRY(step_optimizer(h, (double)huber[it], &cont));
+                PostPassPlan plan;
+                // large-problem path of an unsharded map: the outlier pass is queued behind every trial that may be the call's last
+                // (the structure must exist: a dirty graph is built first, inside step_optimizer, and then has no queued pass yet --
+                // its first trial is queued only on the next iteration; the classic pass below covers it)
+                const bool can_plan = !no_spec && !sharded && !h->dirty && !h->useless && v.n_L > 0 && !ba_small_applies(v);
+                if (can_plan) { plan.last_iteration = it + 1 == n_iter; plan.max_err_sq = (double)max_err_sq; plan.prefix = prefix_now(); }
+                MAGE_TRY(step_optimizer(h, (double)huber[it], &cont, can_plan ? &plan : nullptr));
+                if (can_plan && plan.done) { post_done = true; prefix = plan.prefix; }
                 if (!cont) break;
             }
             // post-pass over the active observations of the last initialisation
             if (!sharded && v.n_L == 0) return MAGE_OK;     // count == 0 -> NaN
             int* small_counter = h->d_queue.p + chol_sync_ints(v.n_pad);
-            if (!sharded && ba_small_applies(v)) ba_small_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, small_counter, h->stream);
-            else ba_launch_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, h->stream);
-            // the first OUT_PREFIX ids of the list ride the same read-back as the three sums (usually that is the whole list)
             ids_from_device = true;
-            // (a run that removed outliers last time will again: twice that many, at least 64, at most OUT_PREFIX; a 16 KB copy is ~8 us
-            // slower than a 100-byte one, so a run without outliers does not pay for it)
-            const size_t prefix = std::min<size_t>(std::min<size_t>(OUT_PREFIX, (size_t)v.n_L), std::max<size_t>(64, 2 * h->out_expect));
+            if (!post_done) {
+                if (!sharded && ba_small_applies(v)) ba_small_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, small_counter, h->stream);
+                else ba_launch_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, h->stream);
+                prefix = prefix_now();
+            }
             if (sharded) {
                 // the mean error is the map's, the list a rank's own; whether anything was removed ANYWHERE decides the re-initialisation
                 MAGE_HIP(hipMemcpyAsync(h->d_scal.p + SC_NOUT_OWN, h->d_scal.p + SC_NOUT, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
                 if (h->shard_reduce(h->shard_user, h->d_scal.p + SC_ERRSUM, 3, 0, (void*)h->stream) != 0)
                     return fail(MAGE_ERR_DEVICE, "landmark-sharded map: the all-reduce callback failed");
             }
-            MAGE_TRY(read_scalars(h, prefix));
+            if (!post_done) MAGE_TRY(read_scalars(h, prefix));
             err_sum = h->h_scal[SC_ERRSUM]; cnt = h->h_scal[SC_ERRCNT];
             nout = (size_t)h->h_scal[sharded ? SC_NOUT_OWN : SC_NOUT];
             if (sharded && h->h_scal[SC_NOUT] > 0) h->soft_dirty = true;
@@ -2000,7 +2039,8 @@ MAGE_EXPORT mage_status mage_ba_enable_profiling(mage_ba* h, int enable)
         DeviceScope scope(h->device);
         if (ensure_events(h->ev, 3, hipEventDefault) != MAGE_OK || ensure_events(h->ev_p, 4, hipEventDefault) != MAGE_OK) return MAGE_ERR_DEVICE;
     }
-    h->profiling = enable != 0;
+    h->profiling = enable == 1;
+    h->profiling_factor = enable == 2;
     h->prof.n_factorizations = 0; h->prof.factor_ms_total = 0; h->prof.schur_launches = 0; h->prof.schur_ms_total = 0;
     h->prof.linearize_launches = 0; h->prof.linearize_ms_total = 0; h->prof.update_launches = 0; h->prof.update_ms_total = 0;
     return MAGE_OK;

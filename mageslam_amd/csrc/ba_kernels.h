@@ -81,7 +81,8 @@ constexpr int TETHER_OUT_STRIDE = 120;
 // SC_CHI: robust chi2 of the current estimate; SC_CHI_TRIAL: of the LM candidate (separate slots: one host read fetches both)
 enum Scal { SC_CHI = 0, SC_SCALE = 1, SC_MAXDIAG = 2, SC_CHOL_OK = 3, SC_ERRSUM = 4, SC_ERRCNT = 5, SC_NOUT = 6, SC_CHI_TRIAL = 7, SC_CHOL_STALL = 8,
             SC_SHARD_FLAG = 9, SC_NOUT_OWN = 10,      // landmark-sharded maps: "some rank re-initialises", this rank's outlier count (SC_NOUT then holds the map's)
-            SC_COUNT = 11 };
+            SC_SPEC_DONE = 11,                        // 1.0: the post-pass queued behind the trial (ba_launch_classify_after_trial) found the call finished and ran
+            SC_COUNT = 12 };
 
 // All launchers enqueue on `st` and return immediately.
 void ba_launch_error(const BaDeviceView& v, bool trial, double huber_delta, hipStream_t st);         // -> scal[SC_CHI] / scal[SC_CHI_TRIAL]
@@ -99,6 +100,17 @@ void ba_launch_pack_lower(const BaDeviceView& v, double* packed, bool to_packed,
 void ba_launch_gather_udiag(const BaDeviceView& v, double* out6_per_camera, hipStream_t st);
 bool ba_launch_allreduce_local(double* const* bufs, int n, size_t count, int op, hipStream_t st);
 void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, hipStream_t st); // scal[SC_ERRSUM..SC_NOUT]
+// The same post-pass queued BEHIND an LM trial, before the host has seen the trial's scalars: every workgroup repeats the host's
+// decision (OptimizationAlgorithmLevenberg::solve) from scal[] -- accepted / rejected, trial loop over or not -- and
+// classifies only when this StepBundleAdjustment call has taken its last trial (it then reads the KEPT estimate: the trial's
+// buffers when accepted, the current ones when not; residuals are the last trial's either way, BundlerLib.cpp:386-425).  Otherwise
+// it leaves everything untouched and scal[SC_SPEC_DONE] = 0.  One host round trip per call instead of two.
+struct ClassifyAfterTrial {
+    double chi_ref; int chi_on_device;    // chi2 of the current estimate: scal[SC_CHI] (first trial of an iteration) or the host's value
+    int trials_done;                      // trials of this iteration including the one just queued
+    int last_iteration;                   // no LM iteration follows in this call
+};
+void ba_launch_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, hipStream_t st);
 
 // Small problems (reduced camera system of order <= 128, no tethers): one LM trial in five launches instead of ~22
 // (ba_kernels.hip, "SMALL PROBLEMS").  `counter` is one zero-initialised device int owned by the handle (the kernels leave it 0).

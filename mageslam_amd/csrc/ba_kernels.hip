@@ -1017,20 +1017,38 @@ __global__ __launch_bounds__(256) void k_pose_update(BaDeviceView v, double lamb
 // Outliers are appended (in no particular order; the host sorts them) to out_ids as ORIGINAL observation indices: what crosses
 // PCIe is the list, not a flag per observation.  The cursor *out_count only ever grows between structure builds; out_base is its
 // value before this launch (the host has read every earlier count), so nothing has to be cleared.
-__global__ __launch_bounds__(256) void k_classify(BaDeviceView v, double max_err_sq, uint32_t* __restrict__ out_ids, int* __restrict__ out_count, int out_base, int nb)
+template <bool AFTER_TRIAL>
+__global__ __launch_bounds__(256) void k_classify(BaDeviceView v, double max_err_sq, uint32_t* __restrict__ out_ids, int* __restrict__ out_count, int out_base, int nb,
+                                                  ClassifyAfterTrial spec)
 {
     __shared__ double sm[4];
+    const double* pose_kept = v.pose_cur;
+    const double* pt_kept = v.pt_cur;
+    if (AFTER_TRIAL) {
+        // the host's decision, from the same scalars in the same arithmetic (lm_solve in ba_host.hip)
+        const bool ok2 = v.scal[SC_CHOL_OK] != 0.0 && v.scal[SC_CHOL_STALL] == 0.0;
+        const double temp = v.scal[SC_CHI_TRIAL];
+        const double cur = spec.chi_on_device ? v.scal[SC_CHI] : spec.chi_ref;
+        const double rho = ok2 ? (cur - temp) / (v.scal[SC_SCALE] + 1e-3) : -1.0;
+        const bool accept = ok2 && rho > 0 && isfinite(temp);
+        const bool loop_over = !(rho < 0 && spec.trials_done < 10);
+        const bool terminate = spec.trials_done == 10 || rho == 0;
+        const bool fin = v.scal[SC_CHOL_STALL] == 0.0 && loop_over && (spec.last_iteration || terminate);
+        if (blockIdx.x == 0 && threadIdx.x == 0) v.scal[SC_SPEC_DONE] = fin ? 1.0 : 0.0;
+        if (!fin) return;
+        if (accept) { pose_kept = v.pose_trial; pt_kept = v.pt_trial; }
+    }
     double es = 0, ec = 0, no = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n_L; i += gridDim.x * 256) {
         if (!v.L_active[i]) continue;
         const double2 e = *reinterpret_cast<const double2*>(v.errL + (size_t)i * 2);
         const double ss = e.x * e.x + e.y * e.y;
         const int cam = v.L_cam[i], pt = v.L_pt[i];
-        PoseD P = load_pose(v.pose_cur, cam);
+        PoseD P = load_pose(pose_kept, cam);
         double wx, wy, wz, fx, fy, fz;
         q_rot(-P.qx, -P.qy, -P.qz, P.qw, -P.tx, -P.ty, -P.tz, wx, wy, wz);   // camera centre
         q_rot(-P.qx, -P.qy, -P.qz, P.qw, 0.0, 0.0, 1.0, fx, fy, fz);        // forward axis in world
-        const double* X = v.pt_cur + (size_t)pt * 4;
+        const double* X = pt_kept + (size_t)pt * 4;
         const double dot = (X[0] - wx) * fx + (X[1] - wy) * fy + (X[2] - wz) * fz;
         const bool out = (dot <= 0) || (ss > max_err_sq);
         if (out) { no += 1.0; v.L_active[i] = 0; out_ids[atomicAdd(out_count, 1) - out_base] = v.L_edge[i]; }   // removeEdge: the observation leaves the graph on the device right here
@@ -2111,7 +2129,14 @@ void ba_launch_import_poses(double* pose0, double* pose1, const uint32_t* cam, c
 void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, hipStream_t st)
 {
     int nb = v.n_L > 0 ? (cdiv(v.n_L, 256) < RED_BLOCKS ? cdiv(v.n_L, 256) : RED_BLOCKS) : 1;
-    hipLaunchKernelGGL(k_classify, dim3(nb), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, nb);
+    hipLaunchKernelGGL(k_classify<false>, dim3(nb), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, nb, ClassifyAfterTrial{});
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
+}
+void ba_launch_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, hipStream_t st)
+{
+    int nb = v.n_L > 0 ? (cdiv(v.n_L, 256) < RED_BLOCKS ? cdiv(v.n_L, 256) : RED_BLOCKS) : 1;
+    hipLaunchKernelGGL(k_classify<true>, dim3(nb), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, nb, c);
+    // (when the kernel found the call unfinished the three sums below are sums of stale partials: nobody reads them then)
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
 }
 
