@@ -737,6 +737,27 @@ __device__ __forceinline__ void tile_of_index(int t, int& rt, int& ct)
     ct = t - rt * (rt + 1) / 2;
 }
 
+// Tiles of the lower triangle (mt tile rows) in BAND order: bands of SYRK_BAND tile rows, inside a band column by column (so that
+// consecutive tiles share their column block and all tiles of a band share its few row blocks).  u = 0 is tile (0, 0).
+constexpr int SYRK_BAND = 4;
+__device__ __forceinline__ void tile_of_band_order(int u, int mt, int& rt, int& ct)
+{
+    int r0, c0;
+    tile_of_index(u, r0, c0);                        // r0 = the row whose row-major run holds u: bands start at row boundaries
+    const int R0 = (r0 / SYRK_BAND) * SYRK_BAND;
+    const int h = min(SYRK_BAND, mt - R0);
+    int v = u - R0 * (R0 + 1) / 2;
+    const int full = (R0 + 1) * h;                   // columns 0 .. R0 carry all h rows of the band
+    if (v < full) { ct = v / h; rt = R0 + v % h; return; }
+    v -= full;
+    rt = R0 + h - 1; ct = rt;
+    for (int d = 1; d < h; ++d) {                    // columns R0 + d: rows R0 + d .. R0 + h - 1
+        const int cnt = h - d;
+        if (v < cnt) { ct = R0 + d; rt = R0 + d + v; return; }
+        v -= cnt;
+    }
+}
+
 // ---- panel solve merged into the trailing update's launch (flag[0]: arrivals at the split diagonal tile, flag[1]: the last tile
 // column whose diagonal tile is factored and in memory, flag[2]: parts of first-column tiles written, cumulative over the launches of a
 // factorisation; k_trsm_panel of column 0 zeroes all three).  Producers: every store of the workgroup done, ONE agent-scope release
@@ -944,16 +965,29 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
         if (tid == 0 && failed) *ok = 0.0;
         return;
     }
-    // half of tile index 1 + (bid - NDIAG) / 2: 128 rows x 64 columns, a wavefront 64 x 32, accumulators loaded from C
-    // the two halves of a tile share its 128 operand rows: workgroups q and q + 8 land on the same XCD (one L2), so tile t of a group
-    // of eight tiles is served by workgroups 16 g + t and 16 g + 8 + t
+    // half of a tile: 128 rows x 64 columns, a wavefront 64 x 32, accumulators loaded from C.
+    // Which half: workgroups go to the eight XCDs round-robin and every XCD has its own 4 MB L2, while the operands of a launch are
+    // ONE tile column of L ((nt - k - 1) x 128 KB: 6 MB in the first columns).  Dealing tiles out in linear order makes every XCD
+    // touch every row block of that column (L2 hit rate 56 %).  With bit 1 of `unstaged` set, XCD x (= workgroups with q0 % 8 == x)
+    // instead takes the x-th CONTIGUOUS eighth of the half-tile tasks in band order (tile_of_band_order: bands of SYRK_BAND tile rows,
+    // column by column inside a band): a band's row blocks stay in that L2 while its column blocks stream through once (hit rate 65 %,
+    // memory-side reads -27 %) -- measured, and no faster (see chol_factor_solve), so linear order stays the default.  The two halves of
+    // a tile are consecutive tasks of one XCD either way.  Placement only: any order gives the same numbers.
     const int q0 = bid - NDIAG;
-    const int tile_i = 8 * (q0 >> 4) + (q0 & 7);
-    if (tile_i >= n_tiles - 1) return;
-    const int q = 2 * tile_i + ((q0 >> 3) & 1);
-    int rt, ct;
-    tile_of_index(1 + (q >> 1), rt, ct);
-    if (unstaged) {                                               // the default: operands straight from L2 per wavefront
+    int rt, ct, q;
+    if (unstaged & 2) {
+        const int n_task = 2 * (n_tiles - 1), per = (n_task + 7) / 8;
+        q = (q0 & 7) * per + (q0 >> 3);
+        if ((q0 >> 3) >= per || q >= n_task) return;
+        tile_of_band_order(1 + (q >> 1), mt, rt, ct);
+    } else {
+        // (the two halves of a tile on one XCD, tiles in linear order: workgroups 16 g + t and 16 g + 8 + t serve tile 8 g + t)
+        const int tile_i = 8 * (q0 >> 4) + (q0 & 7);
+        if (tile_i >= n_tiles - 1) return;
+        q = 2 * tile_i + ((q0 >> 3) & 1);
+        tile_of_index(1 + (q >> 1), rt, ct);
+    }
+    if (unstaged & 1) {                                           // the default: operands straight from L2 per wavefront
         if (rt == ct && (q & 1) && (wave & 1) == 0) return;      // diagonal tile: rows 0-63 of columns 64-127 lie above the diagonal
         const int row0 = (j0 + rt) * TILE + (wave & 1) * 64, col0 = (j0 + ct) * TILE + (q & 1) * 64 + (wave >> 1) * 32;
         double4_t out[2][4];
@@ -1214,8 +1248,12 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
         const bool bulk2 = n_tiles >= bulk2_min_tiles;
         static const bool unstaged = std::getenv("MAGE_CHOL_BULK2_STAGED") == nullptr;     // staging the operands through LDS measured SLOWER (3.01 ms against 2.87): kept for the record
         bool merged = false;
+        // Band placement (tile_of_band_order) is OFF by default: it does what it is for -- L2 hit rate of the launch 56 -> 65 %, memory-side
+        // reads -27 % (profiles/r03_chol_pmc.txt) -- but the matrix cores are busy 49.7 % of the launch either way and the factorisation
+        // takes 2.731 ms against 2.710: the update is not waiting for its operands' misses.  MAGE_CHOL_XCD_BANDS=1 selects it.
+        static const bool xcd_bands = std::getenv("MAGE_CHOL_XCD_BANDS") != nullptr;
         if (bulk2) hipLaunchKernelGGL(k_syrk_update2, dim3(NDIAG + 16 * ((n_tiles - 1 + 7) / 8) + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
-                                      ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, unstaged ? 1 : 0);
+                                      ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, (unstaged ? 1 : 0) | (xcd_bands ? 2 : 0));
         else {
             merged = !merge_off;
             const int n_whole = n_tiles - 1 - n_q4;
