@@ -15,6 +15,7 @@ struct CholWorkspace {
 size_t chol_workspace_doubles(int n_pad);
 inline size_t chol_sync_ints(int n_pad) { return (size_t)(n_pad / CHOL_TILE) + 2; }
 constexpr int CHOL_MAX_ORDER = 256 * CHOL_TILE;   // the persistent backward solve needs one resident workgroup per tile column
+void chol_report_stall(int code);   // the host saw *stall = code (1 split diagonal tile, 2 merged panel solve, 3 backward solve): adapts the schedule
 void chol_init_device();   // once per device (after hipSetDevice): opt the LDS-heavy kernels in
 
 // Factor S = L L^T in place (lower triangle, column-major, n_pad multiple of CHOL_TILE) and solve

@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "chol_kernels.h"
+#include <atomic>
 
 namespace mage {
 namespace {
@@ -720,6 +721,8 @@ __device__ __forceinline__ void update_half_tile_staged(double* __restrict__ S, 
 //   quarter tiles when the last round of whole tiles would occupy at most half of the compute units (n_q4 tiles), those
 //                 tiles are cut into four 64x64 blocks, 32x32 per wavefront, so the round ends in a quarter of the time.
 //   last m blocks rhs update y_i -= L_ik y_k.
+std::atomic<bool> g_merge_disabled{ false };   // see chol_factor_solve
+
 constexpr int NDIAG = 9;           // workgroups on the next diagonal tile: 36 lower 16x16 blocks / 4 wavefronts
 
 __host__ __device__ inline int syrk_quartered_tiles(int n_tiles /* incl. the diagonal one */, int n_cu)
@@ -778,7 +781,7 @@ __device__ __forceinline__ void wait_for_column(int* __restrict__ flag, int j0, 
         int spins = 0;
         while ((__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < j0 ||
                 __hip_atomic_load(flag + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < col_target) && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
-        if (spins >= (1 << 22)) *stall = 1.0;
+        if (spins >= (1 << 22)) *stall = 2.0;           // (the value names the wait that ran out: 1 split diagonal tile, 2 merged panel solve, 3 backward solve)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __builtin_amdgcn_wave_barrier();
@@ -1072,7 +1075,7 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
             unsigned long long v;
             int spins = 0;
             while ((v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == X_SENTINEL && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
-            if (v == X_SENTINEL) *stall = 1.0;           // the producer column never published: reported as a device error
+            if (v == X_SENTINEL) *stall = 3.0;           // the producer column never published: reported as a device error
             xk[tid] = __longlong_as_double((long long)v);
         }
         __syncthreads();
@@ -1192,6 +1195,11 @@ size_t chol_workspace_doubles(int n_pad) { return (size_t)(n_pad / TILE) * NBLK 
 // are per device); called from mage_ba_create after hipSetDevice.
 int g_n_cu = 256;        // compute units of the device the library was initialised on (gfx950: 256)
 
+void chol_report_stall(int code)
+{
+    if (code == 2) g_merge_disabled.store(true, std::memory_order_relaxed);
+}
+
 void chol_init_device()
 {
     int dev = 0;
@@ -1233,7 +1241,11 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
     // panel inside (strips at the end of the grid, waiting for the factored tile and for the first-column tiles of this very launch):
     // while the update dominates the strips run beside its last tiles, afterwards they save the launch boundary (~10 us per column
     // on the chain either way).  The half-tile form is followed by a panel-solve launch as before.
-    static const bool merge_off = std::getenv("MAGE_CHOL_NO_MERGED_TRSM") != nullptr;
+    // (g_merge_disabled: a strip's wait ran out once in this process -- chol_report_stall -- which only happens when SEVERAL PROCESSES
+    // share the GPU: the hardware scheduler then saves and restores workgroups, and the waiting strips, one per compute unit because of
+    // the launch's 151 KB of LDS, can keep the producers they wait for from being restored.  From then on the panel solve is its own launch.)
+    static const bool merge_env_off = std::getenv("MAGE_CHOL_NO_MERGED_TRSM") != nullptr;
+    const bool merge_off = merge_env_off || g_merge_disabled.load(std::memory_order_relaxed);
     hipLaunchKernelGGL(k_trsm_panel, dim3((nt - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, 0, nt, ws.Linv, ws.sync, 0);
     int col_total = 0;
     for (int k = 0; k + 1 < nt; ++k) {

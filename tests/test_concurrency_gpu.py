@@ -112,3 +112,22 @@ def test_four_tiled_solves_two_detectors_and_a_matcher_at_once():
         assert log == log0, f"handle {i}: LM trace differs from its solo run"
         assert out == out0
         assert np.array_equal(P, P0) and np.array_equal(X, X0), f"handle {i}: state differs bitwise from its solo run"
+
+
+def test_two_processes_oversubscribing_the_gpu_lose_no_step():
+    """Several PROCESSES on one GPU (not how the library is deployed -- one process per GPU -- but what a shared development box
+    does): the hardware scheduler time-slices them by saving and restoring workgroups, and a waiting panel-solve strip can then keep
+    the producer it waits for off its compute unit until the bounded wait runs out.  The trial is re-run from the unchanged
+    linearisation and the process switches to separate panel-solve launches (chol_report_stall): every step must succeed."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "stall_probe.py"), "3", "25", tag], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for tag in ("A", "B")]
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, (out + err)[-2000:]
+        res = json.loads([l for l in out.splitlines() if "{" in l][-1].split(" ", 1)[1])
+        assert res["errors"] == [] and res["handles"] == 3 and res["steps"] == 25, res
