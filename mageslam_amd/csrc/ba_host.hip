@@ -1114,7 +1114,13 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
         if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[0], st));
         if (small) {
             ba_small_solve_trial(v, lambda, huber, h->d_Linv.p, counter, st);
-            if (h->profiling) { MAGE_HIP(hipEventRecord(h->ev[1], st)); MAGE_HIP(hipEventRecord(h->ev[2], st)); }
+            if (h->profiling) { MAGE_HIP(hipEventRecord(h->ev[1], st)); MAGE_HIP(hipEventRecord(h->ev[2], st)); MAGE_HIP(hipEventRecord(h->ev_p[3], st)); }
+            if (plan) {      // the outlier pass rides behind the trial (see the large-problem branch)
+                ClassifyAfterTrial c{};
+                c.chi_ref = currentChi; c.chi_on_device = have_chi ? 0 : 1; c.trials_done = qmax + 1; c.last_iteration = plan->last_iteration ? 1 : 0;
+                ba_small_classify_after_trial(v, c, plan->max_err_sq, h->d_out_ids, counter + 1, h->out_cursor, counter, st);
+                speculated = true;
+            }
         } else {
             ba_launch_schur(v, lambda, adds_damping ? lambda : 0.0, adds_damping ? 1.0 : 0.0, st);
             if (sharded) {
@@ -1148,7 +1154,6 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
                 MAGE_TRY(all_reduce(v.scal + SC_CHI_TRIAL, 2, 0));
             }
         }
-        if (h->profiling && small) MAGE_HIP(hipEventRecord(h->ev_p[3], st));
         MAGE_TRY(read_scalars(h, speculated ? plan->prefix : 0));
         if (h->profiling) {
             float ms = 0;
@@ -1706,10 +1711,10 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
             for (size_t it = 0; it < n_iter; ++it) {
                 bool cont = true;
                 PostPassPlan plan;
-                // large-problem path of an unsharded map: the outlier pass is queued behind every trial that may be the call's last
+                // unsharded maps (both the large- and the small-problem path): the outlier pass is queued behind every trial that may be the call's last
                 // (the structure must exist: a dirty graph is built first, inside step_optimizer, and then has no queued pass yet --
                 // its first trial is queued only on the next iteration; the classic pass below covers it)
-                const bool can_plan = !no_spec && !sharded && !h->dirty && !h->useless && v.n_L > 0 && !ba_small_applies(v);
+                const bool can_plan = !no_spec && !sharded && !h->dirty && !h->useless && v.n_L > 0;
                 if (can_plan) { plan.last_iteration = it + 1 == n_iter; plan.max_err_sq = (double)max_err_sq; plan.prefix = prefix_now(); }
                 MAGE_TRY(step_optimizer(h, (double)huber[it], &cont, can_plan ? &plan : nullptr));
                 if (can_plan && plan.done) { post_done = true; prefix = plan.prefix; }

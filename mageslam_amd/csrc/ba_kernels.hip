@@ -1017,6 +1017,21 @@ __global__ __launch_bounds__(256) void k_pose_update(BaDeviceView v, double lamb
 // Outliers are appended (in no particular order; the host sorts them) to out_ids as ORIGINAL observation indices: what crosses
 // PCIe is the list, not a flag per observation.  The cursor *out_count only ever grows between structure builds; out_base is its
 // value before this launch (the host has read every earlier count), so nothing has to be cleared.
+// The host's decision on an LM trial, repeated on the device from the same scalars in the same arithmetic (lm_solve in ba_host.hip):
+// is this StepBundleAdjustment call over with the trial just evaluated, and which estimate is kept?
+__device__ __forceinline__ bool call_is_over(const BaDeviceView& v, const ClassifyAfterTrial& spec, bool& accept)
+{
+    const bool stalled = v.scal[SC_CHOL_STALL] != 0.0;
+    const bool ok2 = v.scal[SC_CHOL_OK] != 0.0 && !stalled;
+    const double temp = v.scal[SC_CHI_TRIAL];
+    const double cur = spec.chi_on_device ? v.scal[SC_CHI] : spec.chi_ref;
+    const double rho = ok2 ? (cur - temp) / (v.scal[SC_SCALE] + 1e-3) : -1.0;
+    accept = ok2 && rho > 0 && isfinite(temp);
+    const bool loop_over = !(rho < 0 && spec.trials_done < 10);
+    const bool terminate = spec.trials_done == 10 || rho == 0;
+    return !stalled && loop_over && (spec.last_iteration || terminate);
+}
+
 template <bool AFTER_TRIAL>
 __global__ __launch_bounds__(256) void k_classify(BaDeviceView v, double max_err_sq, uint32_t* __restrict__ out_ids, int* __restrict__ out_count, int out_base, int nb,
                                                   ClassifyAfterTrial spec)
@@ -1025,15 +1040,8 @@ __global__ __launch_bounds__(256) void k_classify(BaDeviceView v, double max_err
     const double* pose_kept = v.pose_cur;
     const double* pt_kept = v.pt_cur;
     if (AFTER_TRIAL) {
-        // the host's decision, from the same scalars in the same arithmetic (lm_solve in ba_host.hip)
-        const bool ok2 = v.scal[SC_CHOL_OK] != 0.0 && v.scal[SC_CHOL_STALL] == 0.0;
-        const double temp = v.scal[SC_CHI_TRIAL];
-        const double cur = spec.chi_on_device ? v.scal[SC_CHI] : spec.chi_ref;
-        const double rho = ok2 ? (cur - temp) / (v.scal[SC_SCALE] + 1e-3) : -1.0;
-        const bool accept = ok2 && rho > 0 && isfinite(temp);
-        const bool loop_over = !(rho < 0 && spec.trials_done < 10);
-        const bool terminate = spec.trials_done == 10 || rho == 0;
-        const bool fin = v.scal[SC_CHOL_STALL] == 0.0 && loop_over && (spec.last_iteration || terminate);
+        bool accept;
+        const bool fin = call_is_over(v, spec, accept);
         if (blockIdx.x == 0 && threadIdx.x == 0) v.scal[SC_SPEC_DONE] = fin ? 1.0 : 0.0;
         if (!fin) return;
         if (accept) { pose_kept = v.pose_trial; pt_kept = v.pt_trial; }
@@ -1673,21 +1681,31 @@ __global__ __launch_bounds__(256) void k_small_update_error(BaDeviceView v, doub
 }
 
 // k_classify with the three reductions folded in
+template <bool AFTER_TRIAL>
 __global__ __launch_bounds__(256) void k_small_classify(BaDeviceView v, double max_err_sq, uint32_t* __restrict__ out_ids, int* __restrict__ out_count,
-                                                        int out_base, int* __restrict__ counter)
+                                                        int out_base, int* __restrict__ counter, ClassifyAfterTrial spec)
 {
     __shared__ double sm[4];
+    const double* pose_kept = v.pose_cur;
+    const double* pt_kept = v.pt_cur;
+    if (AFTER_TRIAL) {
+        bool accept;
+        const bool fin = call_is_over(v, spec, accept);
+        if (blockIdx.x == 0 && threadIdx.x == 0) v.scal[SC_SPEC_DONE] = fin ? 1.0 : 0.0;
+        if (!fin) return;                                   // every workgroup alike: the arrival counter stays untouched
+        if (accept) { pose_kept = v.pose_trial; pt_kept = v.pt_trial; }
+    }
     double es = 0, ec = 0, no = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n_L; i += gridDim.x * 256) {
         if (!v.L_active[i]) continue;
         const double2 e = *reinterpret_cast<const double2*>(v.errL + (size_t)i * 2);
         const double ss = e.x * e.x + e.y * e.y;
         const int cam = v.L_cam[i], pt = v.L_pt[i];
-        PoseD P = load_pose(v.pose_cur, cam);
+        PoseD P = load_pose(pose_kept, cam);
         double wx, wy, wz, fx, fy, fz;
         q_rot(-P.qx, -P.qy, -P.qz, P.qw, -P.tx, -P.ty, -P.tz, wx, wy, wz);
         q_rot(-P.qx, -P.qy, -P.qz, P.qw, 0.0, 0.0, 1.0, fx, fy, fz);
-        const double* X = v.pt_cur + (size_t)pt * 4;
+        const double* X = pt_kept + (size_t)pt * 4;
         const double dot = (X[0] - wx) * fx + (X[1] - wy) * fy + (X[2] - wz) * fz;
         const bool out = (dot <= 0) || (ss > max_err_sq);
         if (out) { no += 1.0; v.L_active[i] = 0; out_ids[atomicAdd(out_count, 1) - out_base] = v.L_edge[i]; }
@@ -2103,7 +2121,11 @@ void ba_small_solve_trial(const BaDeviceView& v, double lambda, double delta, do
 }
 void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_small_classify, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, counter);
+    hipLaunchKernelGGL(k_small_classify<false>, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, counter, ClassifyAfterTrial{});
+}
+void ba_small_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_small_classify<true>, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, counter, c);
 }
 void ba_small_init_device() {}
 
