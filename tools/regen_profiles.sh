@@ -14,7 +14,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 python "$root/bench.py" > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
 rm -rf "$out/${tag}_prof"
-timeout 600 rocprofv3 --kernel-trace -d "$out/${tag}_prof" -o b -- python "$root/bench.py" --no-cpu-baseline > "$out/${tag}_bench_under_rocprof.json" 2>> "$out/${tag}_bench.err"
+timeout 600 rocprofv3 --kernel-trace -d "$out/${tag}_prof" -o b -- python "$root/bench.py" --no-cpu-baseline --no-extras > "$out/${tag}_bench_under_rocprof.json" 2>> "$out/${tag}_bench.err"
 python "$root/tools/rocpd_stats.py" "$(find "$out/${tag}_prof" -name '*.db' | head -1)" > "$out/${tag}_bench_kernel_stats.txt"
 for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf "$out/${tag}_pmc_$c"
@@ -25,7 +25,7 @@ python "$root/tools/pmc_to_traffic.py" "$(find "$out/${tag}_pmc_FETCH_SIZE" -nam
 rm -rf "$out/${tag}_pmc_FETCH_SIZE" "$out/${tag}_pmc_WRITE_SIZE"
 # HBM traffic of the HBM-bound stages of an LM iteration: the same two passes over the bench itself
 for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --pmc $c -d "$out/${tag}_pmc_$c" -o p -- python "$root/bench.py" --no-cpu-baseline > /dev/null 2>> "$out/${tag}_bench.err"
+    timeout 600 rocprofv3 --pmc $c -d "$out/${tag}_pmc_$c" -o p -- python "$root/bench.py" --no-cpu-baseline --no-extras > /dev/null 2>> "$out/${tag}_bench.err"
 done
 python "$root/tools/pmc_stage_traffic.py" "$(find "$out/${tag}_pmc_FETCH_SIZE" -name '*.db' | head -1)" "$(find "$out/${tag}_pmc_WRITE_SIZE" -name '*.db' | head -1)" > "$out/ba_stage_traffic.json"
 rm -rf "$out/${tag}_prof" "$out/${tag}_pmc_FETCH_SIZE" "$out/${tag}_pmc_WRITE_SIZE"
