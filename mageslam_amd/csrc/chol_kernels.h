@@ -8,13 +8,14 @@ constexpr int CHOL_TILE = 128;
 
 struct CholWorkspace {
     double* Linv;      // chol_workspace_doubles(n_pad): inverses of the 16x16 diagonal blocks of L, per tile
-    int* sync;         // chol_sync_ints(n_pad) ints: [0] arrival counter of the split diagonal tile
+    int* sync;         // chol_sync_ints(n_pad) ints: [0] arrival counter of the split diagonal tile, [1] last tile column factored, [2] parts of first-column tiles written, [3] progress inside the tile being factored
     long long* dbg = nullptr;   // development only: 4 x nt time stamps of the backward solve (tools/chol_test.hip)
     double* stall = nullptr;    // device double: set to 1.0 when a bounded cross-workgroup wait timed out (a device fault, not a property of S)
 };
 size_t chol_workspace_doubles(int n_pad);
-inline size_t chol_sync_ints(int n_pad) { return (size_t)(n_pad / CHOL_TILE) + 2; }
+inline size_t chol_sync_ints(int n_pad) { return (size_t)(n_pad / CHOL_TILE) + 4; }
 constexpr int CHOL_MAX_ORDER = 256 * CHOL_TILE;   // the persistent backward solve needs one resident workgroup per tile column
+void chol_debug_syrk_stamps(long long* out32, bool reset);   // development only (tools/chol_test.hip, CHOL_DBG=1 CHOL_DBG_COL=k)
 void chol_report_stall(int code);   // the host saw *stall = code (1 split diagonal tile, 2 merged panel solve, 3 backward solve): adapts the schedule
 void chol_init_device();   // once per device (after hipSetDevice): opt the LDS-heavy kernels in
 

@@ -316,8 +316,21 @@ __device__ __forceinline__ void lds_update_tile_left(double* __restrict__ A, int
 // ---------------------------------------------------------------------------------------------
 // Factor the LDS-resident tile A (column-major, pitch LDC) in place; Li = 2 x 256 doubles of LDS scratch.
 // PARTIAL: only the leading nblk 16-column blocks are factored (the rest of the tile is the identity padding of a small system).
-template <bool PARTIAL, class LAY>
-__device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __restrict__ Li, double* __restrict__ Linv_k, int tid, int nblk = NBLK)
+// PUBLISH (the merged, pipelined panel solve of k_syrk_update): the factoring workgroup makes its progress visible to the strips of
+// the same launch block column by block column instead of tile by tile -- with no flag and no wait.  At the top of iteration s
+// (diagonal block s factored, block column s - 1 final) wavefront 3 writes the inverse of block s to its place in the workspace and
+// wavefronts 1-3 deal out the blocks (i, s - 1), i >= s, to a scratch copy of the tile's sub-diagonal blocks (LPUB_TILE_DOUBLES per
+// tile, block (c, j) at (c (c - 1) / 2 + j) * 256, column-major), all with agent-scope stores that go THROUGH to memory.  Both areas
+// were filled with X_SENTINEL when the factorisation started (k_trsm_panel of column 0), and a strip simply polls the operand values
+// it is about to use until none of them is the sentinel -- what the backward solve does with x.  Waiting for the stores to drain
+// before raising a flag made the publishing wavefront late at the iteration's barrier (+2 ... +6 us per tile on the critical path).
+constexpr int LPUB_BLOCKS = NBLK * (NBLK - 1) / 2;            // 28 sub-diagonal blocks
+constexpr int LPUB_TILE_DOUBLES = LPUB_BLOCKS * NB * NB;      // 7168
+struct TilePublish { double* Lpub; };                         // this tile's scratch blocks (nullptr: not publishing)
+
+template <bool PARTIAL, class LAY, bool PUBLISH = false>
+__device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __restrict__ Li, double* __restrict__ Linv_k, int tid, int nblk = NBLK,
+                                            TilePublish pub = TilePublish{ nullptr })
 {
     const int NBK = PARTIAL ? nblk : NBLK;
     const int lane = tid & 63, wave = tid >> 6;
@@ -327,8 +340,21 @@ __device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __re
     for (int s = 0; s < NBK; ++s) {
         const double* Lc = Li + (s & 1) * NB * NB;
         if (wave == 3) {                           // block inverse s -> global workspace (read by k_trsm_panel / k_bsolve_persist)
-            const double4_t v = *reinterpret_cast<const double4_t*>(Lc + lane * 4);
-            *reinterpret_cast<double4_t*>(Linv_k + s * NB * NB + lane * 4) = v;
+            if (PUBLISH) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) __hip_atomic_store(Linv_k + s * NB * NB + lane * 4 + q, Lc[lane * 4 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const double4_t v = *reinterpret_cast<const double4_t*>(Lc + lane * 4);
+                *reinterpret_cast<double4_t*>(Linv_k + s * NB * NB + lane * 4) = v;
+            }
+        }
+        if (PUBLISH && wave >= 1 && s > 0) {       // block column s - 1 is final: its blocks below the diagonal go out, dealt over wavefronts 1-3
+            for (int i = s + wave - 1; i < NBK; i += 3) {
+                const double* Bl = A + LAY::blk(i, s - 1);
+                double* G = pub.Lpub + (size_t)(i * (i - 1) / 2 + (s - 1)) * NB * NB;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) __hip_atomic_store(G + (4 * r + (lane >> 4)) * NB + (lane & 15), Bl[frag<LAY>(r, lane)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         if (s == NBK - 1) break;
         // rows below block s:  Y = Linv * A^T per 16-row strip; Y[m][n] = X[row r0 + n][col p0 + m].
@@ -527,11 +553,104 @@ __device__ __forceinline__ void trsm_strip(double* __restrict__ S, double* __res
     }
 }
 
+// The same strip for the MERGED panel solve, pipelined against the factorisation of L_kk that runs in the same launch (TilePublish):
+// step c needs the inverse of diagonal block c and the blocks (c, j < c); it reads them from where the factoring workgroup writes them
+// through to memory and polls each batch of four values until none is the sentinel.  Operands come through agent-scope loads (they
+// bypass this XCD's L2).  What is left behind the last publication of a tile is one fetch, two products and a store.
+__device__ __forceinline__ bool lane_has_sentinel(const double (&v)[4])
+{
+    bool pending = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pending |= (unsigned long long)__double_as_longlong(v[r]) == X_SENTINEL;
+    return pending;
+}
+
+__device__ __forceinline__ void trsm_strip_pipelined(double* __restrict__ S, double* __restrict__ y, int ld, int k, int strip, bool is_rhs,
+                                                     const double* __restrict__ Linv_k, const double* __restrict__ Lpub, double* __restrict__ stall, int lane)
+{
+    double* base;
+    size_t cstride;
+    bool live;
+    if (!is_rhs) {
+        base = S + (size_t)(k * TILE) * ld + (size_t)(k + 1) * TILE + strip * NB + (lane & 15);
+        cstride = (size_t)ld;
+        live = true;
+    } else {
+        base = y + (size_t)k * TILE;
+        cstride = 1;
+        live = (lane & 15) == 0;
+    }
+    double4_t Acc[NBLK];
+#pragma unroll
+    for (int c = 0; c < NBLK; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Acc[c][r] = live ? base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] : 0.0;
+    // operand element (row = lane & 15, column = 4 r + (lane >> 4)) of a published block; of the row-major block inverse
+    const double* Lop = Lpub + (lane >> 4) * NB + (lane & 15);
+    const double* Lio = Linv_k + (lane & 15) * NB + (lane >> 4);
+    // Every operand is fetched up front, as in the unpipelined strip: what has been published by now arrives with ONE memory
+    // latency; what has not shows the sentinel and is polled for when its step comes.
+    double lop[NBLK][NBLK][4], lio[NBLK][4];
+#pragma unroll
+    for (int c = 0; c < NBLK; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lio[c][r] = __hip_atomic_load(Lio + c * NB * NB + 4 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < c; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                lop[c][j][r] = __hip_atomic_load(Lop + (size_t)(c * (c - 1) / 2 + j) * NB * NB + (size_t)r * 4 * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    double4_t Y[NBLK];
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < NBLK; ++c) {
+        // the operands of THIS step, all together: re-read (after a pause -- two hundred strips polling back to back take a measurable
+        // share of the fabric away from the factoring workgroup) until none of them shows the sentinel
+        for (int spins = 0; ok; ++spins) {
+            bool pending = lane_has_sentinel(lio[c]);
+#pragma unroll
+            for (int j = 0; j < c; ++j) pending |= lane_has_sentinel(lop[c][j]);
+            if (!__any(pending)) break;
+            if (spins >= (1 << 18)) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lio[c][r] = __hip_atomic_load(Lio + c * NB * NB + 4 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < c; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    lop[c][j][r] = __hip_atomic_load(Lop + (size_t)(c * (c - 1) / 2 + j) * NB * NB + (size_t)r * 4 * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        double4_t acc = Acc[c];
+#pragma unroll
+        for (int j = 0; j < c; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lop[c][j][r], Y[j][r], acc, 0, 0, 0);
+        double4_t yc = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yc = __builtin_amdgcn_mfma_f64_16x16x4f64(lio[c][r], acc[r], yc, 0, 0, 0);
+        Y[c] = yc;
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] = yc[r];
+        }
+    }
+    if (!ok && lane == 0) *stall = 2.0;
+}
+
 __global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
                                                    const double* __restrict__ Linv_k, int* __restrict__ queue, int queue_start)
 {
     const int lane = threadIdx.x;
-    if (blockIdx.x == 0 && lane == 0) { queue[0] = queue_start; if (k == 0) { queue[1] = 0; queue[2] = 0; } }     // hand-off counters of the launches that follow
+    if (blockIdx.x == 0 && lane == 0) { queue[0] = 0; if (k == 0) { queue[1] = 0; queue[2] = 0; queue[3] = 0; } }     // hand-off counters of the launches that follow (queue_start < 0: also fill the pipelined strips' sentinels)
+    if (k == 0 && queue_start < 0) {
+        // what the pipelined panel solves of the later columns poll: the block inverses of tiles 1 .. nt - 1 and every tile's scratch
+        // blocks start as the sentinel (this launch is the second of a factorisation; those areas are first written 19+ launches later)
+        unsigned long long* W = reinterpret_cast<unsigned long long*>(const_cast<double*>(Linv_k));
+        const size_t first = (size_t)NBLK * NB * NB, total = (size_t)nt * (NBLK * NB * NB + LPUB_TILE_DOUBLES);
+        for (size_t i = first + (size_t)blockIdx.x * 64 + lane; i < total; i += (size_t)gridDim.x * 64) W[i] = X_SENTINEL;
+    }
     const int n_strips = (nt - k - 1) * NBLK;
     trsm_strip(S, y, ld, k, (int)blockIdx.x, (int)blockIdx.x == n_strips, Linv_k, lane);
 }
@@ -723,6 +842,12 @@ __device__ __forceinline__ void update_half_tile_staged(double* __restrict__ S, 
 //   last m blocks rhs update y_i -= L_ik y_k.
 std::atomic<bool> g_merge_disabled{ false };   // see chol_factor_solve
 
+// development only (tools/chol_test.hip, CHOL_DBG_COL=k): time stamps of the workgroups of ONE chain-bound launch
+__device__ long long g_syrk_dbg[32];
+__device__ __forceinline__ void dbg_set(int dbg, int slot) { if (dbg && threadIdx.x == 0) g_syrk_dbg[slot] = wall_clock64(); }
+__device__ __forceinline__ void dbg_max(int dbg, int slot) { if (dbg && threadIdx.x == 0) atomicMax((unsigned long long*)&g_syrk_dbg[slot], (unsigned long long)wall_clock64()); }
+__device__ __forceinline__ void dbg_min(int dbg, int slot) { if (dbg && threadIdx.x == 0) atomicMin((unsigned long long*)&g_syrk_dbg[slot], (unsigned long long)wall_clock64()); }
+
 constexpr int NDIAG = 9;           // workgroups on the next diagonal tile: 36 lower 16x16 blocks / 4 wavefronts
 
 __host__ __device__ inline int syrk_quartered_tiles(int n_tiles /* incl. the diagonal one */, int n_cu)
@@ -788,7 +913,8 @@ __device__ __forceinline__ void wait_for_column(int* __restrict__ flag, int j0, 
 }
 
 __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
-                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int n_q4, int merge, int col_target)
+                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int n_q4, int merge, int col_target,
+                                                     int dbg, double* __restrict__ Lpub_next)
 {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -800,8 +926,20 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
     if (bid >= first_rhs + mt) {
         // ---- merged panel solve of tile column j0 (merge != 0): one strip per workgroup (wavefront 0), behind everything it waits for
         if (wave != 0) return;
+        dbg_min(dbg, 6);
+        if (merge == 2) {      // pipelined against the factorisation of L_j0j0 (TilePublish): only the first-column tiles must be complete
+            wait_for_column(flag, 0, col_target, stall, lane);
+            dbg_max(dbg, 7);
+            trsm_strip_pipelined(S, y, ld, j0, bid - (first_rhs + mt), false, Linv_next, Lpub_next, stall, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg_max(dbg, 8);
+            return;
+        }
         wait_for_column(flag, j0, col_target, stall, lane);
+        dbg_max(dbg, 7);
         trsm_strip(S, y, ld, j0, bid - (first_rhs + mt), false, Linv_next, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg_max(dbg, 8);
         return;
     }
     if (bid >= first_rhs) {
@@ -820,12 +958,14 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (wave != 0) return;
+            if (merge == 2) { trsm_strip_pipelined(S, y, ld, j0, 0, true, Linv_next, Lpub_next, stall, lane); return; }
             wait_for_column(flag, j0, 0, stall, lane);
             trsm_strip(S, y, ld, j0, 0, true, Linv_next, lane);
         }
         return;
     }
     if (bid < NDIAG) {
+        if (bid == 0) dbg_set(dbg, 0);
         // 16x16 block u = 4 bid + wave of the lower triangle of the diagonal tile, (bi, bj), bi >= bj
         const int u = bid * 4 + wave;
         int bi, bj;
@@ -848,6 +988,7 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
             return;
         }
         // block 0: wait for the eight others (bounded spin; relaxed polls, one acquire), pull the tile, factor it
+        dbg_set(dbg, 1);
         if (tid == 0) {
             int spins = 0;
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NDIAG - 1 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
@@ -856,14 +997,19 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
             if (merge) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // no panel-solve launch follows to reset it
         }
         __syncthreads();
+        dbg_set(dbg, 2);
         double* A = sm;
         double* T = S + (size_t)(j0 * TILE) * ld + (size_t)j0 * TILE;
         load_tile_packed(A, T, ld, tid);
         __syncthreads();
-        const bool failed = potrf_tile_lds<false, LayPacked>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
+        dbg_set(dbg, 3);
+        const bool failed = merge == 2 ? potrf_tile_lds<false, LayPacked, true>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid, NBLK, TilePublish{ Lpub_next })
+                                       : potrf_tile_lds<false, LayPacked>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
+        dbg_set(dbg, 4);
         store_tile_packed(T, A, ld, tid);
         if (tid == 0 && failed) *ok = 0.0;
-        if (merge) {      // L_j0j0 and its block inverses are in memory: the strips of this launch may start
+        if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_set(dbg, 5); }
+        if (merge == 1) {      // L_j0j0 and its block inverses are in memory: the strips of this launch may start (pipelined strips need no release: write-through)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
@@ -905,6 +1051,7 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
 #pragma unroll
             for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = out[a][b][r];
     if (merge && ct == 0) publish_column_part(flag, tid);
+    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_max(dbg, ct == 0 ? 10 : 9); }
 }
 
 __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
@@ -1189,11 +1336,22 @@ __global__ __launch_bounds__(256) void k_small_solve(const double* __restrict__ 
 
 }  // namespace
 
-size_t chol_workspace_doubles(int n_pad) { return (size_t)(n_pad / TILE) * NBLK * NB * NB; }
+// per tile column: the inverses of its eight diagonal blocks, then (behind all of those) the scratch copy of its 28 sub-diagonal blocks
+size_t chol_workspace_doubles(int n_pad) { return (size_t)(n_pad / TILE) * (NBLK * NB * NB + LPUB_TILE_DOUBLES); }
 
 // Kernels that need more than the default dynamic-LDS limit must be opted in once per device (function attributes
 // are per device); called from mage_ba_create after hipSetDevice.
 int g_n_cu = 256;        // compute units of the device the library was initialised on (gfx950: 256)
+
+void chol_debug_syrk_stamps(long long* out32, bool reset)
+{
+    if (reset) {
+        long long init[32];
+        for (int i = 0; i < 32; ++i) init[i] = 0;
+        init[6] = 0x7fffffffffffffffLL;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_syrk_dbg), init, sizeof(init));
+    } else (void)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_syrk_dbg), 32 * sizeof(long long));
+}
 
 void chol_report_stall(int code)
 {
@@ -1246,8 +1404,10 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
     // the launch's 151 KB of LDS, can keep the producers they wait for from being restored.  From then on the panel solve is its own launch.)
     static const bool merge_env_off = std::getenv("MAGE_CHOL_NO_MERGED_TRSM") != nullptr;
     const bool merge_off = merge_env_off || g_merge_disabled.load(std::memory_order_relaxed);
-    hipLaunchKernelGGL(k_trsm_panel, dim3((nt - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, 0, nt, ws.Linv, ws.sync, 0);
+    static const bool pipelined_fill = std::getenv("MAGE_CHOL_PIPELINED_TRSM") != nullptr;
+    hipLaunchKernelGGL(k_trsm_panel, dim3((nt - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, 0, nt, ws.Linv, ws.sync, pipelined_fill ? -1 : 0);
     int col_total = 0;
+    static const int dbg_col = std::getenv("CHOL_DBG_COL") ? std::atoi(std::getenv("CHOL_DBG_COL")) : -1;
     for (int k = 0; k + 1 < nt; ++k) {
         const int m = nt - k - 1;             // tile rows below panel k = tile rows of the trailing matrix
         const int n_tiles = m * (m + 1) / 2;
@@ -1270,8 +1430,15 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
             merged = !merge_off;
             const int n_whole = n_tiles - 1 - n_q4;
             if (merged) for (int rt = 1; rt < m; ++rt) col_total += (rt * (rt + 1) / 2 <= n_whole) ? 1 : 4;      // workgroups that write a part of column k + 1
+            // Pipelined strips (trsm_strip_pipelined) are OFF by default: measured (CHOL_DBG_COL time stamps, tools/chol_test) they end
+            // 3.5 us after the tile is factored instead of 9.9 in the last columns (launch 38.8 -> 36.8 us), but every strip then reads
+            // the same 56 KB of L_kk past the L2 (agent-scope loads; 200 strips in the first chain-bound columns: launch 41.8 -> 52.8 us)
+            // and their polling takes fabric bandwidth from the factoring workgroup (tile load 1.4 -> 3.6 us): 2.80 ms per factorisation
+            // against 2.71.  One release + one acquire per strip and L2-cached reads of the broadcast operand stay.
+            static const bool pipelined = std::getenv("MAGE_CHOL_PIPELINED_TRSM") != nullptr;
             hipLaunchKernelGGL(k_syrk_update, dim3(NDIAG + n_whole + 4 * n_q4 + m + (merged ? (m - 1) * NBLK : 0)), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
-                               ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, n_q4, merged ? 1 : 0, col_total);
+                               ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, n_q4, merged ? (pipelined ? 2 : 1) : 0, col_total,
+                               (ws.dbg && dbg_col == k) ? 1 : 0, ws.Linv + (size_t)nt * linv_stride + (size_t)(k + 1) * LPUB_TILE_DOUBLES);
         }
         if (!merged) hipLaunchKernelGGL(k_trsm_panel, dim3((m - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, k + 1, nt, ws.Linv + (size_t)(k + 1) * linv_stride, ws.sync, 0);
     }
