@@ -97,6 +97,14 @@ def test_device_build_long_tracks_and_many_cameras():
     assert z[2] == 150
 
 
+def test_device_build_more_than_1024_free_cameras():
+    """1 300 cameras (1 298 free): the camera scan, the split offsets and the row scans run more than one round of their 1 024-thread
+    workgroups, a row of S has up to 1 298 columns (one wavefront per row in the fill kernel)."""
+    s = scene.make_scene(n_cams=1300, n_pts=13000, n_obs=13000 * 8, seed=0x5EED3002, spacing=0.1)
+    z = _assert_same_build(s, False, [([1.8], 1e30), ([1.8], 1e30)])
+    assert z[2] == 1298 and z[0] == 104000
+
+
 def test_device_build_global_config():
     """BASELINE.json configs[3]: 1k poses / 100k points / 1M observations, 5.5 M Schur contributions in ~21 k blocks."""
     s = scene.make_config("global")
