@@ -464,7 +464,8 @@ __device__ __forceinline__ void load_columns(const int* w_hc, int sa, int* jj)
     const int4_a4 x = q[0], y = q[1], z = q[2];
     jj[0] = x.x; jj[1] = x.y; jj[2] = x.z; jj[3] = x.w; jj[4] = y.x; jj[5] = y.y; jj[6] = y.z; jj[7] = y.w; jj[8] = z.x; jj[9] = z.y; jj[10] = z.z; jj[11] = z.w;
 }
-constexpr int ROW_KC = BUILD_ROW_KC;      // columns of a slot kept in registers across the phases of the scatter (longer tracks re-read)
+constexpr int ROW_KC = BUILD_ROW_KC;
+constexpr int ROW_PF = 4;                 // slots (row_count) / 64-slot batches (row_fill) whose load chains are in flight together      // columns of a slot kept in registers across the phases of the scatter (longer tracks re-read)
 
 __device__ __forceinline__ void row_part(int n_slots, int nw, int wave, int* b, int* e)
 {
@@ -484,14 +485,23 @@ __global__ __launch_bounds__(1024) void k_build_row_count(BuildArgs a)
     for (int c = threadIdx.x; c < n_fc; c += T) cnt[c] = 0;
     __syncthreads();
     const int s0 = a.camS_ptr[i], ns = a.camS_ptr[i + 1] - s0;
-    for (int k = threadIdx.x; k < ns; k += T) {
-        const int sa = a.camS[s0 + k];
-        const int end = a.w_end[sa];
-        int jj[ROW_KC];                                        // speculative: w_hc is padded by ROW_KC entries
-        load_columns(a.w_hc, sa, jj);
+    // The chain slot -> end of its landmark -> its columns is two dependent loads; a thread's slots are fetched ROW_PF at a time so
+    // that their chains are in flight together (the loop was a chain per slot: three round trips to L2 per thread on a local BA).
+    for (int k0 = threadIdx.x; k0 < ns; k0 += ROW_PF * T) {
+        int sa[ROW_PF], end[ROW_PF], jj[ROW_PF][ROW_KC];
 #pragma unroll
-        for (int t = 0; t < ROW_KC; ++t) if (sa + t < end) atomicAdd(&cnt[jj[t]], 1);
-        for (int sb = sa + ROW_KC; sb < end; ++sb) atomicAdd(&cnt[a.w_hc[sb]], 1);
+        for (int u = 0; u < ROW_PF; ++u) sa[u] = k0 + u * T < ns ? a.camS[s0 + k0 + u * T] : 0;
+#pragma unroll
+        for (int u = 0; u < ROW_PF; ++u) {
+            end[u] = k0 + u * T < ns ? a.w_end[sa[u]] : 0;     // (an idle slot reads slot 0's columns and uses none of them)
+            load_columns(a.w_hc, sa[u], jj[u]);                // speculative: w_hc is padded by ROW_KC entries
+        }
+#pragma unroll
+        for (int u = 0; u < ROW_PF; ++u) {
+#pragma unroll
+            for (int t = 0; t < ROW_KC; ++t) if (sa[u] + t < end[u]) atomicAdd(&cnt[jj[u][t]], 1);
+            for (int sb = sa[u] + ROW_KC; sb < end[u]; ++sb) atomicAdd(&cnt[a.w_hc[sb]], 1);
+        }
     }
     __syncthreads();
     u64 v = 0;
@@ -534,14 +544,37 @@ __global__ __launch_bounds__(NW * WAVE) void k_build_row_fill(BuildArgs a, int n
     int pb, pe;
     row_part(ns, NW, wave, &pb, &pe);
     int* mine = part + (size_t)wave * n_fc;
-    for (int k = pb + lane; k < pe; k += WAVE) {
-        const int sa = a.camS[s0 + k];
-        const int end = a.w_end[sa];
-        int jj[ROW_KC];
-        load_columns(a.w_hc, sa, jj);
+    // Up to PF batches of 64 slots per wavefront (rows of up to PF * 64 * NW slots: every case measured) are fetched ONCE, all
+    // chains in flight together, and kept in registers for both passes; longer rows re-read batch by batch.
+    constexpr int PF = NW >= 16 ? 3 : ROW_PF;                                        // (1024 threads leave a wavefront 128 registers)
+    const bool resident = ((ns + NW - 1) / NW + WAVE - 1) / WAVE <= PF;              // the same for every wavefront of the workgroup
+    int rsa[PF], rend[PF], rjj[PF][ROW_KC];
+    if (resident) {
 #pragma unroll
-        for (int t = 0; t < ROW_KC; ++t) if (sa + t < end) atomicAdd(&mine[jj[t]], 1);
-        for (int sb = sa + ROW_KC; sb < end; ++sb) atomicAdd(&mine[a.w_hc[sb]], 1);
+        for (int u = 0; u < PF; ++u) rsa[u] = pb + u * WAVE + lane < pe ? a.camS[s0 + pb + u * WAVE + lane] : 0;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            rend[u] = pb + u * WAVE + lane < pe ? a.w_end[rsa[u]] : 0;
+            load_columns(a.w_hc, rsa[u], rjj[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+#pragma unroll
+            for (int t = 0; t < ROW_KC; ++t) {
+                if (rsa[u] + t < rend[u]) atomicAdd(&mine[rjj[u][t]], 1); else rjj[u][t] = -1;
+            }
+            for (int sb = rsa[u] + ROW_KC; sb < rend[u]; ++sb) atomicAdd(&mine[a.w_hc[sb]], 1);
+        }
+    } else {
+        for (int k = pb + lane; k < pe; k += WAVE) {
+            const int sa = a.camS[s0 + k];
+            const int end = a.w_end[sa];
+            int jj[ROW_KC];
+            load_columns(a.w_hc, sa, jj);
+#pragma unroll
+            for (int t = 0; t < ROW_KC; ++t) if (sa + t < end) atomicAdd(&mine[jj[t]], 1);
+            for (int sb = sa + ROW_KC; sb < end; ++sb) atomicAdd(&mine[a.w_hc[sb]], 1);
+        }
     }
     __syncthreads();
     // columns: totals, the wavefronts' shares turned into offsets inside the block, then block index / offset by a scan over j
@@ -577,20 +610,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_build_row_fill(BuildArgs a, int n
     // contribution inside its block among the batch = lower lanes that hold the same column: one bitmap per column.
     u64* bm = bitmap + (size_t)wave * n_fc;
     const u64 lt = lanemask_lt(), me = 1ull << lane;
-    for (int k0 = pb; k0 < pe; k0 += WAVE) {
-        const int k = k0 + lane;
-        int sa = 0, end = 0;
-        int jj[ROW_KC];
-#pragma unroll
-        for (int t = 0; t < ROW_KC; ++t) jj[t] = -1;
-        if (k < pe) {
-            sa = a.camS[s0 + k];
-            end = a.w_end[sa];
-            load_columns(a.w_hc, sa, jj);
-        }
-        const int nk = end - sa;
-#pragma unroll
-        for (int t = 0; t < ROW_KC; ++t) if (t >= nk) jj[t] = -1;
+    auto scatter_batch = [&](int sa, int end, int (&jj)[ROW_KC]) {
 #pragma unroll
         for (int t = 0; t < ROW_KC; ++t) if (jj[t] >= 0) atomicOr(&bm[jj[t]], me);
         for (int sb = sa + ROW_KC; sb < end; ++sb) atomicOr(&bm[a.w_hc[sb]], me);
@@ -629,6 +649,28 @@ __global__ __launch_bounds__(NW * WAVE) void k_build_row_fill(BuildArgs a, int n
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    if (resident) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (pb + u * WAVE < pe) scatter_batch(rsa[u], rend[u], rjj[u]);          // uniform per wavefront
+    } else {
+        for (int k0 = pb; k0 < pe; k0 += WAVE) {
+            const int k = k0 + lane;
+            int sa = 0, end = 0;
+            int jj[ROW_KC];
+#pragma unroll
+            for (int t = 0; t < ROW_KC; ++t) jj[t] = -1;
+            if (k < pe) {
+                sa = a.camS[s0 + k];
+                end = a.w_end[sa];
+                load_columns(a.w_hc, sa, jj);
+            }
+            const int nk = end - sa;
+#pragma unroll
+            for (int t = 0; t < ROW_KC; ++t) if (t >= nk) jj[t] = -1;
+            scatter_batch(sa, end, jj);
+        }
     }
 }
 

@@ -236,6 +236,8 @@ struct mage_ba {
     std::vector<double> pts;            // n x 3
     std::vector<uint8_t> pt_set;
     PinnedVec<HostObs> obs;
+    bool obs_unfilled = false;          // AllocateObservations left the records uninitialised: a bulk setter that covers all of them need not
+                                        // pay for clearing 24 bytes per record first (ensure_obs_filled clears them before anybody else looks)
     std::vector<HostTether> teth[3];    // FixedDistance / RelativeRotation / RelativeTransform constraints
     bool cams_allocated = false, pts_allocated = false, obs_allocated = false, teth_allocated[3] = { false, false, false };
 
@@ -319,6 +321,13 @@ struct mage_ba {
 };
 
 namespace {
+
+void ensure_obs_filled(mage_ba* h)
+{
+    if (!h->obs_unfilled) return;
+    std::fill(h->obs.begin(), h->obs.end(), HostObs());
+    h->obs_unfilled = false;
+}
 
 constexpr size_t OUT_PREFIX = 4096;      // outlier ids copied back together with the post-pass scalars (16 KB); a longer list takes a second copy
 constexpr size_t SC_PAD = 16;            // doubles reserved for the scalars in d_scal / the pinned mirror; the outlier ids follow
@@ -851,6 +860,7 @@ mage_status initialize_optimization(mage_ba* h)
     // the rest of the build; small ones are staged through the same arena.  The arena is the handle's and goes back to the cache
     // when the first LM trial's scalars have come back (read_scalars): the build ends without a synchronisation of its own, so the
     // first iteration's launches queue up behind the last build kernels.
+    ensure_obs_filled(h);
     PinnedArena& arena = h->build_arena;
     if (!arena.blocks.empty()) { MAGE_HIP(hipStreamSynchronize(h->stream)); arena.release(); }
     if (!h->state_on_device) MAGE_TRY(upload_state(h, &arena));
@@ -1088,7 +1098,18 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
     // scalar slot, so after the first iteration of a run no host round trip separates linearisation from the solve.
     // Iteration 0 needs max |diag| on the host to seed lambda.
     if (sharded) MAGE_TRY(all_reduce(v.scal + SC_CHI, 1, 0));
-    if (h->iteration == 0) {
+    // lambda of a (re-)initialised optimiser (iteration 0): the user's value when set (BundlerLib.cpp:123-130), else g2o's
+    // tau * max |diag|.  The small-problem path seeds it ON THE DEVICE -- its trial kernels take "lambda < 0" as "1e-5 * SC_MAXDIAG" --
+    // and the host learns the value from the first trial's read-back: no round trip between linearisation and the first trial (a
+    // one-iteration local BA is ~0.45 ms, a round trip 15 us of it).  With a user lambda nothing needs reading at all.
+    bool seed_on_device = false;
+    if (h->iteration == 0 && h->user_lambda > 0 && !sharded) {
+        h->lambda = h->user_lambda;
+        h->ni = 2;
+    } else if (h->iteration == 0 && small) {
+        seed_on_device = true;
+        h->ni = 2;
+    } else if (h->iteration == 0) {
         if (sharded) {
             // max |diag| of the WHOLE map's Hessian: U's diagonal is a sum over the ranks, V's is a rank's own
             ba_launch_gather_udiag(v, h->d_xchg.p, st);
@@ -1110,7 +1131,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
     bool again = false;
     do {
         again = false;
-        const double lambda = h->lambda;
+        const double lambda = seed_on_device ? -1.0 : h->lambda;
         if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[0], st));
         if (small) {
             ba_small_solve_trial(v, lambda, huber, h->d_Linv.p, counter, st);
@@ -1184,6 +1205,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
             if (++stall_retries <= 3) { h->stall_retries_total++; again = true; continue; }       // lambda unchanged, qmax not advanced
             return fail(MAGE_ERR_DEVICE, "dense solve: a cross-workgroup hand-off timed out four times in a row (device stalled or oversubscribed); the trial was not evaluated");
         }
+        if (seed_on_device) { h->lambda = 1e-5 * h->h_scal[SC_MAXDIAG]; seed_on_device = false; }      // the value the device used (the same product)
         const bool ok2 = h->h_scal[SC_CHOL_OK] != 0.0;
         if (!have_chi) { currentChi = h->h_scal[SC_CHI]; tr.chi2_before = currentChi; have_chi = true; }
         double tempChi = h->h_scal[SC_CHI_TRIAL];
@@ -1474,7 +1496,8 @@ MAGE_EXPORT mage_status mage_ba_alloc_observations(mage_ba* h, size_t count)
         if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
         if (h->obs_allocated) return fail(MAGE_ERR_INVALID_ARGUMENT, "observations can only be allocated once");
         if (count > 0x7fffffffull) return fail(MAGE_ERR_INVALID_ARGUMENT, "too many observations");
-        MAGE_TRY(h->obs.assign(count, HostObs()));
+        MAGE_TRY(h->obs.resize_uninitialized(count));      // cleared lazily: see obs_unfilled
+        h->obs_unfilled = true;
         h->obs_allocated = true;
         return MAGE_OK;
     });
@@ -1495,6 +1518,7 @@ MAGE_EXPORT mage_status mage_ba_set_observation(mage_ba* h, size_t idx, const fl
         if (!h || !uv) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
         if (idx >= h->obs.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "observation index %zu out of range (%zu)", idx, h->obs.size());
         h->dirty = true;
+        ensure_obs_filled(h);
         return set_obs(h, idx, uv[0], uv[1], cam, pt, info);
     });
 }
@@ -1506,10 +1530,20 @@ MAGE_EXPORT mage_status mage_ba_set_observations_bulk(mage_ba* h, size_t count, 
         if (!h || !uv2 || !cam || !pt || !info) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
         if (count > h->obs.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "count %zu exceeds allocated observations %zu", count, h->obs.size());
         h->dirty = true;
+        // AllocateObservations left the records uninitialised (obs_unfilled): when this call covers all of them there is nothing to
+        // clear first -- unless an index is out of range, in which case the records from the offender on are cleared before the error
+        // is returned ("never set")
+        const bool covers_all = h->obs_unfilled && count == h->obs.size();
+        if (!covers_all) ensure_obs_filled(h);
+        auto clear_from = [&](size_t first) { std::fill(h->obs.begin() + first, h->obs.end(), HostObs()); h->obs_unfilled = false; };
         // a million records are 24 MB written and 20 MB read: a few host threads, each on its own range (large maps only)
         const int parts = parts_for((int)std::min<size_t>(count, 0x7fffffff), 131072);
         if (parts <= 1) {
-            for (size_t i = 0; i < count; ++i) MAGE_TRY(set_obs(h, i, uv2[i * 2], uv2[i * 2 + 1], cam[i], pt[i], info[i]));
+            for (size_t i = 0; i < count; ++i) {
+                const mage_status st = set_obs(h, i, uv2[i * 2], uv2[i * 2 + 1], cam[i], pt[i], info[i]);
+                if (st != MAGE_OK) { if (covers_all) clear_from(i); return st; }
+            }
+            h->obs_unfilled = false;
             return MAGE_OK;
         }
         const size_t nc = h->cams.size(), np = h->pt_set.size();
@@ -1523,7 +1557,14 @@ MAGE_EXPORT mage_status mage_ba_set_observations_bulk(mage_ba* h, size_t count, 
             }
         });
         for (long long b : bad)
-            if (b >= 0) return set_obs(h, (size_t)b, uv2[b * 2], uv2[b * 2 + 1], cam[b], pt[b], info[b]);      // reports the first offender of the lowest range
+            if (b >= 0) {
+                if (covers_all) {      // the threads skipped their offenders: those records (and nothing else) are still uninitialised
+                    for (size_t i = 0; i < count; ++i) if (cam[i] >= nc || pt[i] >= np) h->obs[i] = HostObs();
+                    h->obs_unfilled = false;
+                }
+                return set_obs(h, (size_t)b, uv2[b * 2], uv2[b * 2 + 1], cam[b], pt[b], info[b]);      // reports the first offender of the lowest range
+            }
+        h->obs_unfilled = false;
         return MAGE_OK;
     });
 }

@@ -1432,6 +1432,8 @@ __global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double 
 // blocks [n_blk, n_blk + n_fc): the reduced rhs of one camera (k_schur_rhs<true>, D^-1 b_p formed in place)
 __global__ __launch_bounds__(256) void k_small_schur(BaDeviceView v, double lambda)
 {
+    if (lambda < 0) lambda = 1e-5 * v.scal[SC_MAXDIAG];      // first trial after a (re-)initialisation: g2o's tau * max |diag| (A.4), seeded without a host round trip
+
     __shared__ double red[4][64 * 37];
     __shared__ double part[4][36];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1536,6 +1538,8 @@ __global__ __launch_bounds__(256) void k_small_schur(BaDeviceView v, double lamb
 // blocks [0, nbL): k_backsub with D^-1 formed in place; blocks [nbL, nbL + nbC): k_pose_update; last block adds the scale partials
 __global__ __launch_bounds__(256) void k_small_update(BaDeviceView v, double lambda, int nbL, int* __restrict__ counter)
 {
+    if (lambda < 0) lambda = 1e-5 * v.scal[SC_MAXDIAG];      // first trial after a (re-)initialisation: g2o's tau * max |diag| (A.4), seeded without a host round trip
+
     __shared__ double sm[4];
     const int bid = blockIdx.x;
     double sc = 0;
@@ -1610,6 +1614,8 @@ __global__ __launch_bounds__(256) void k_small_error(BaDeviceView v, int trial, 
 // trial poses -- the residuals k_small_error would have read the trial state back for.  The last workgroup folds both sums.
 __global__ __launch_bounds__(256) void k_small_update_error(BaDeviceView v, double lambda, double delta, int* __restrict__ counter)
 {
+    if (lambda < 0) lambda = 1e-5 * v.scal[SC_MAXDIAG];      // first trial after a (re-)initialisation: g2o's tau * max |diag| (A.4), seeded without a host round trip
+
     __shared__ double sm[4];
     __shared__ PoseD lp[24];
     const int bid = blockIdx.x, tid = threadIdx.x, n_blocks = gridDim.x;

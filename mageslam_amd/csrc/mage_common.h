@@ -155,6 +155,18 @@ struct PinnedVec {
         std::fill(p, p + count, v);
         return MAGE_OK;
     }
+    // the same without initialising the elements: for a caller that is about to overwrite all of them (or fills them later)
+    mage_status resize_uninitialized(size_t count)
+    {
+        if (count * sizeof(T) > bytes) {
+            if (p) { cached_pinned_release(p, bytes); p = nullptr; bytes = 0; }
+            void* q = nullptr;
+            MAGE_TRY(cached_pinned_alloc(&q, std::max<size_t>(count, 1) * sizeof(T), &bytes));
+            p = static_cast<T*>(q);
+        }
+        n = count;
+        return MAGE_OK;
+    }
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
     T* data() { return p; }
