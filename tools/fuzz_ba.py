@@ -55,6 +55,23 @@ def one(case, rng):
         T._compare_with_oracle(s, points_fixed, calls, rtol=1e-6 if tethered else 1e-8)
     except AssertionError:
         print("   shape:", dict(n_cams=n_cams, n_pts=n_pts, K=K, n_obs=s.n_obs, fixed=int(fixed.sum()), tethered=tethered, points_fixed=points_fixed, calls=calls), flush=True)
+        # which switch, if any, makes the same scene agree: the structure build's twin, the classic outlier pass, a looser tolerance
+        for name, env, tol in (("MAGE_BA_BUILD=host", {"MAGE_BA_BUILD": "host"}, None), ("MAGE_BA_BUILD=device", {"MAGE_BA_BUILD": "device"}, None),
+                               ("MAGE_BA_NO_QUEUED_POSTPASS=1", {"MAGE_BA_NO_QUEUED_POSTPASS": "1"}, None), ("rtol 1e-5", {}, 1e-5)):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                T._compare_with_oracle(s, points_fixed, calls, rtol=tol or (1e-6 if tethered else 1e-8))
+                verdict = "agrees"
+            except AssertionError as e:
+                verdict = "still differs: " + str(e)[:120].replace("\n", " ")
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            print(f"   with {name}: {verdict}", flush=True)
         raise
     return None
 
