@@ -6,7 +6,7 @@
 // the block lists of the reduced camera matrix.  The reference rebuilds this for EVERY optimisation -- a bundler lives for one
 // BundleAdjust call (BundleAdjust.cpp:293, 348-351) and its default local BA is one LM iteration (MageSettings.h:42-44) -- so
 // the build is on the caller's critical path, not set-up.  The host build of ba_host.hip stays as the A/B twin
-// (MAGE_BA_BUILD=host); both produce the same lists, element for element (tests/test_ba_gpu.py).
+// (MAGE_BA_BUILD=host); both produce the same lists, element for element (tests/test_ba_build_gpu.py).
 //
 // Every list is a deterministic function of the Set* records: counts and offsets come from integer atomics and scans, orders
 // from keys that are total orders (observation index, slot index), never from arrival order.
@@ -24,7 +24,7 @@ struct ObsRecord {
 };
 static_assert(sizeof(ObsRecord) == 24, "ObsRecord layout");
 
-// Sizes the device build leaves for the host (one small read-back in the middle, one at the end).
+// Sizes the device build leaves for the host: one read-back when the rows of S are counted, a second one (large problems: the XCD runs) at the end.
 struct BuildCounts {
     int n_L, n_fc, n_lm, n_w;          // active observations, free cameras in the system, landmarks, W slots
     int slot_obs;                      // observations that own or share a slot (!= n_w: some slot is shared)
