@@ -1755,7 +1755,9 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
                 // unsharded maps (both the large- and the small-problem path): the outlier pass is queued behind every trial that may be the call's last
                 // (the structure must exist: a dirty graph is built first, inside step_optimizer, and then has no queued pass yet --
                 // its first trial is queued only on the next iteration; the classic pass below covers it)
-                const bool can_plan = !no_spec && !sharded && !h->dirty && !h->useless && v.n_L > 0;
+                // (only behind the trials of the call's LAST iteration: an earlier iteration ends the call only when it returns Terminate,
+                // which the classic pass below covers -- queueing behind every trial of a 25-iteration call would be 50 idle launches)
+                const bool can_plan = !no_spec && !sharded && !h->dirty && !h->useless && v.n_L > 0 && it + 1 == n_iter;
                 if (can_plan) { plan.last_iteration = it + 1 == n_iter; plan.max_err_sq = (double)max_err_sq; plan.prefix = prefix_now(); }
                 MAGE_TRY(step_optimizer(h, (double)huber[it], &cont, can_plan ? &plan : nullptr));
                 if (can_plan && plan.done) { post_done = true; prefix = plan.prefix; }
