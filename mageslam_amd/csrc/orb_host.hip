@@ -85,6 +85,9 @@ struct mage_orb {
     mage_orb_params P{};
     OrbTaps taps{};
     DevBuf<signed char> d_pattern;
+    DevBuf<unsigned long long> d_blur_tab;   // tap matrices of the matrix-core blur (orb_blur_mfma_table); empty: the taps do not fit it
+    int blur_c2 = 0;
+    bool blur_on_matrix_cores = false;
     int pattern_radius = 0;         // largest |coordinate| of the sampling table
     DevBuf<uint8_t> d_img, d_rawscore, d_blur, d_desc;     // d_rawscore: FAST scores of frame 0 (parity tests)
     DevBuf<int> d_tile_count, d_cell_start, d_cell_fill, d_count;   // d_tile_count: keypoints per FAST tile, d_raw: their slots
@@ -145,6 +148,12 @@ MAGE_EXPORT mage_status mage_orb_create(const mage_orb_params* params, mage_orb*
         const size_t used = p.use_orientation ? pat.size() : std::min<size_t>(pat.size(), 1024);
         for (size_t i = 0; i < used; ++i) h->pattern_radius = std::max(h->pattern_radius, std::abs((int)pat[i]));
         MAGE_TRY(h->d_pattern.upload(pat.data(), pat.size(), h->stream));
+        unsigned long long blur_tab[192];
+        const char* blur_env = std::getenv("MAGE_ORB_BLUR");           // "valu": the vector-ALU form of the fused blur (A/B tests)
+        if (!(blur_env && std::strcmp(blur_env, "valu") == 0) && orb_blur_mfma_table(h->taps, blur_tab, &h->blur_c2)) {
+            MAGE_TRY(h->d_blur_tab.upload(blur_tab, 192, h->stream));
+            h->blur_on_matrix_cores = true;
+        }
         MAGE_HIP(hipStreamSynchronize(h->stream));
         *out = h.release();
         return MAGE_OK;
@@ -190,7 +199,7 @@ mage_status run_level(mage_orb* h, const uint8_t* d_images, int n_frames, int w,
     const int border = P.use_orientation ? (int)std::ceil((float)half_patch * std::sqrt(2.0f)) : half_patch;
     const bool fused_blur = orb_blur_fuses(h->taps);      // the 7-tap Gaussian rides in the FAST launch: the frame is read once for both
     orb_launch_fast(d_images, w, h_img, stride, frame_stride, n_frames, (int)std::min(P.fast_threshold, 255u), border, io.raw_frame0, wp,
-                    h->d_raw.p, h->d_tile_count.p, fused_blur ? &h->taps : nullptr, io.blur, st);
+                    h->d_raw.p, h->d_tile_count.p, fused_blur ? &h->taps : nullptr, h->blur_on_matrix_cores ? h->d_blur_tab.p : nullptr, h->blur_c2, io.blur, st);
     if (io.record_events) MAGE_HIP(hipEventRecord(h->ev[1], st));
     OrbSelectArgs a{};
     a.raw = h->d_raw.p; a.tile_count = h->d_tile_count.p; a.n_tiles = (int)n_tiles; a.tile_cap = tile_cap;

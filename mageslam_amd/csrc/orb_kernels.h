@@ -28,8 +28,10 @@ constexpr int ORB_MAX_LEVELS = 16;   // pyramid depth accepted by mage_orb_creat
 void orb_fast_tiling(int w, int h, int* tiles_x, int* tiles_y, int* tile_cap);
 // With `taps` (only when orb_blur_fuses(taps): the 7-tap kernel) the same launch also writes the blurred image and orb_launch_blur is not needed.
 bool orb_blur_fuses(const OrbTaps& taps);
+// blur_tab / blur_c2 (orb_blur_mfma_table, 192 entries in device memory): the fused blur runs on the matrix cores; null: on the vector ALUs.
+bool orb_blur_mfma_table(const OrbTaps& taps, unsigned long long* tab192, int* c2);
 void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, int border, uint8_t* raw_frame0, int wp,
-                     int2* raw, int* tile_count, const OrbTaps* taps, uint8_t* blurred, hipStream_t st);
+                     int2* raw, int* tile_count, const OrbTaps* taps, const unsigned long long* blur_tab, int blur_c2, uint8_t* blurred, hipStream_t st);
 // cv::resize(INTER_LINEAR) of n_frames u8 images (OpenCV 3.4.0 fixed-point arithmetic) and the per-frame concatenation of a level's results
 void orb_launch_resize(const uint8_t* src, int sw, int sh, int sstride, size_t sframe, uint8_t* dst, int dw, int dh, int dpitch, size_t dframe, int n_frames,
                        hipStream_t st);

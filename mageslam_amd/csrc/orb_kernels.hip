@@ -34,6 +34,14 @@ __device__ unsigned long long g_orb_clk[32];
 #define ORB_CLK(i) do { } while (0)
 #endif
 
+// Development only (tools/orb_ablate.py): bit 0 runs the compass arithmetic twice, bit 1 the even-position test, bit 2 the exact
+// score, bit 3 launches the kernel without the blur, bit 4 takes the blur's tap matrices from the lane number instead of
+// memory, bit 5 leaves its stores out -- what a phase costs where it stands.  0 in the product.
+#ifndef MAGE_ORB_ABLATE
+#define MAGE_ORB_ABLATE 0
+#endif
+#define ORB_LAUNDER(x) asm volatile("" : "+v"(x))
+
 constexpr int FT_W = 64, FT_H = 24;   // output tile of k_fast_keypoints: 640 x 480 = 10 x 20 workgroups per frame
 
 // The ring differences fit 16 bits, so the score runs on PACKED pairs: register k holds (d[k], d[k + 8]) -- a ring pixel and its
@@ -195,10 +203,15 @@ __device__ __forceinline__ void append8(unsigned bits, int pos0, uint16_t* __res
 // BLUR: the 7-tap Gaussian of the same tile (what k_blur computes) from the same staged window -- the image is read from HBM once
 // for both.  Out-of-image window pixels are then REFLECTED instead of zero; FAST never looks at them (its centres keep 3 pixels
 // from the image edge).
-template <bool BLUR>
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+constexpr int BLUR_NONE = 0, BLUR_VALU = 1, BLUR_MFMA = 2;
+
+template <int BLUR>
 __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_stride,
                                                         int threshold, int border, uint8_t* __restrict__ raw_frame0, int wp,
-                                                        int2* __restrict__ raw, int* __restrict__ tile_count, OrbTaps taps, uint8_t* __restrict__ blurred)
+                                                        int2* __restrict__ raw, int* __restrict__ tile_count, OrbTaps taps, uint8_t* __restrict__ blurred,
+                                                        const unsigned long long* __restrict__ blur_tab, int blur_c2)
 {
     constexpr int TP = FTW;
     constexpr int HROWS = FT_H + 6;                                   // row sums the vertical pass of the blur needs
@@ -216,34 +229,51 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
     const uint8_t* I = img + (size_t)f * frame_stride;
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
     ORB_CLK_BEGIN();
-    if (tid == 0) { n_cand = 0; n_cand2 = 0; n_kept = 0; n_corner = 0; }
-    for (int e = tid; e < SCH * SCP / 16; e += 256) reinterpret_cast<uint4*>(sc)[e] = make_uint4(0u, 0u, 0u, 0u);
-    {   // window rows y0 - 4 .. y0 + FT_H + 3, columns x0 - 16 .. x0 + 79: six 16-byte pieces per row, one per thread
-        static_assert(FTH * (FTW / 16) <= 256, "one 128-bit load per thread");
-        const bool aligned16 = ((stride & 15) == 0) && ((reinterpret_cast<uintptr_t>(I) & 15) == 0);
+    // window rows y0 - 4 .. y0 + FT_H + 3, columns x0 - 16 .. x0 + 79: six 16-byte pieces per row, one per thread.  (Measured and
+    // left out: 2 / 4 / 5 / 10 vertically adjacent tiles per workgroup with the next window fetched into registers while the
+    // current tile is worked on -- a workgroup spends 28 % of its life waiting for its window -- 1.76 / 1.77 / 1.76 / 1.78 /
+    // 1.80 ms: with eight wavefronts per SIMD resident the wait is already covered by the other workgroups.)
+    static_assert(FTH * (FTW / 16) <= 256, "one 128-bit load per thread");
+    const bool aligned16 = ((stride & 15) == 0) && ((reinterpret_cast<uintptr_t>(I) & 15) == 0);
+    const int wty = tid / (FTW / 16), wtq = tid % (FTW / 16);
+    auto load_window = [&](int wy0) -> uint4 {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (tid < FTH * (FTW / 16)) {
-            const int ty = tid / (FTW / 16), tq = tid % (FTW / 16);
-            const int gx = x0 - FWX + 16 * tq, gy = y0 - FH + ty;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            const int gx = x0 - FWX + 16 * wtq, gy = wy0 - FH + wty;
             if (BLUR || (gy >= 0 && gy < h)) {
                 const uint8_t* rowp = I + (size_t)(BLUR ? reflect101(gy, h) : gy) * stride;
                 if (aligned16 && gx >= 0 && gx + 15 < w) v = *reinterpret_cast<const uint4*>(rowp + gx);
                 else if (BLUR || (gx + 15 >= 0 && gx < w)) {
-                    uint32_t d[4] = { 0u, 0u, 0u, 0u };
+                    // the frame's edge columns or an unaligned frame: byte by byte, one dword at a time (a rolled loop: this path
+                    // must not set the register count of the kernel)
+#pragma unroll 1
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t dq = 0;
 #pragma unroll
-                    for (int b = 0; b < 16; ++b) {
-                        const int x = gx + b;
-                        if (BLUR) d[b >> 2] |= (uint32_t)rowp[reflect101(x, w)] << (8 * (b & 3));
-                        else if (x >= 0 && x < w) d[b >> 2] |= (uint32_t)rowp[x] << (8 * (b & 3));
+                        for (int b = 0; b < 4; ++b) {
+                            const int x = gx + 4 * q + b;
+                            if (BLUR) dq |= (uint32_t)rowp[reflect101(x, w)] << (8 * b);
+                            else if (x >= 0 && x < w) dq |= (uint32_t)rowp[x] << (8 * b);
+                        }
+                        if (q == 0) v.x = dq; else if (q == 1) v.y = dq; else if (q == 2) v.z = dq; else v.w = dq;
                     }
-                    v = make_uint4(d[0], d[1], d[2], d[3]);
                 }
             }
-            *reinterpret_cast<uint4*>(tile + ty * TP + 16 * tq) = v;
         }
-    }
+        return v;
+    };
+    const uint4 window = load_window(y0);
+    if (tid == 0) { n_cand = 0; n_cand2 = 0; n_kept = 0; n_corner = 0; }
+    for (int e = tid; e < SCH * SCP / 16; e += 256) reinterpret_cast<uint4*>(sc)[e] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < FTH * (FTW / 16)) *reinterpret_cast<uint4*>(tile + wty * TP + 16 * wtq) = window;
     __syncthreads();
     ORB_CLK(0);
+    // The comparisons of phases 1 and 2a are 32-bit subtractions and bitwise logic on TWO 16-bit fields per register (the
+    // operations that issue in 2 cycles on this part; packed 16-bit min / max take 4, tools/valu_rate.hip).  With a guard bit per
+    // field no borrow crosses it: bit 15 of (V + 0x8000 - t - 1) - R is set iff R < V - t (R darker than the centre by more than
+    // t), bit 15 of (V + 0x8000 + t) - R iff R <= V + t (R NOT brighter by more than t).
+    const uint32_t tc = (uint32_t)min(max(threshold, 0), 255);        // beyond 255 nothing passes, as at 255
+    const uint32_t kd = (0x8000u - tc - 1u) * 0x00010001u, kb = (0x8000u + tc) * 0x00010001u;
     // Phase 1.  Region pixel (rx, ry) = image (x0 - 1 + rx, y0 - 1 + ry) = tile byte (rx + 15, ry + 3); a thread takes EIGHT
     // consecutive rx: 9 groups per region row (SCP = 72 = 9 x 8, so the list position of pixel j of group e is 8 e + j) and
     // 9 x SCH groups in all -- one pass of the workgroup.
@@ -259,27 +289,27 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
             const uint32_t* up = reinterpret_cast<const uint32_t*>(&tile[(ry + 6) * TP + 8 * o + 12]);   // row y + 3 (ring 0)
             const uint32_t* dn = reinterpret_cast<const uint32_t*>(&tile[(ry + 0) * TP + 8 * o + 12]);   // row y - 3 (ring 8)
             const uint32_t mc[4] = { mp[0], mp[1], mp[2], mp[3] }, mu[3] = { up[0], up[1], up[2] }, md[3] = { dn[0], dn[1], dn[2] };
-            const short2_t T1 = (short2_t){ (short)(threshold + 1), (short)(threshold + 1) }, T = (short2_t){ (short)threshold, (short)threshold };
+            // two pixels per register, one in each 16-bit half (kd, kb above)
             uint32_t signs = 0;
 #pragma unroll
+            for (int twice = 0; twice < ((MAGE_ORB_ABLATE & 1) ? 2 : 1); ++twice)
+#pragma unroll
             for (int hp = 0; hp < 4; ++hp) {
+                if (twice) { uint32_t* q = const_cast<uint32_t*>(mc); ORB_LAUNDER(q[0]); ORB_LAUNDER(q[1]); ORB_LAUNDER(q[2]); ORB_LAUNDER(q[3]); }
                 // bytes i, i + 1 of a group of dwords, zero-extended to 16 bits each (v_perm_b32: selector 0..3 = bytes of the
                 // second operand, 4..7 = bytes of the first, 0x0c = zero)
-                auto pair16 = [&](const uint32_t* g, int i) -> short2_t {
+                auto pair16 = [&](const uint32_t* g, int i) -> uint32_t {
                     const int d = i >> 2, k = i & 3;
-                    const uint32_t r = k < 3 ? __builtin_amdgcn_perm(0u, g[d], 0x0c000c00u | (uint32_t)k | ((uint32_t)(k + 1) << 16))
-                                             : __builtin_amdgcn_perm(g[d + 1], g[d], 0x0c040c03u);
-                    short2_t q; __builtin_memcpy(&q, &r, 4); return q;
+                    return k < 3 ? __builtin_amdgcn_perm(0u, g[d], 0x0c000c00u | (uint32_t)k | ((uint32_t)(k + 1) << 16))
+                                 : __builtin_amdgcn_perm(g[d + 1], g[d], 0x0c040c03u);
                 };
-                const short2_t V = pair16(mc, 3 + 2 * hp), Ee = pair16(mc, 6 + 2 * hp), Ww = pair16(mc, 2 * hp);
-                const short2_t Nn = pair16(mu, 3 + 2 * hp), Ss = pair16(md, 3 + 2 * hp);
-                const short2_t dN = V - Nn, dE = V - Ee, dS = V - Ss, dW = V - Ww;
-                // two neighbouring compass points both darker: (N or S) and (E or W)
-                const short2_t dark = pmin(pmax(dN, dS), pmax(dE, dW)), bright = pmax(pmin(dN, dS), pmin(dE, dW));
-                const short2_t xd = dark - T1, xb = bright + T;                       // dark > t  <=>  xd >= 0 ; bright < -t  <=>  xb < 0
-                uint32_t ud, ub;
-                __builtin_memcpy(&ud, &xd, 4); __builtin_memcpy(&ub, &xb, 4);
-                signs |= ((~ud | ub) & 0x80008000u) >> (15 - 2 * hp);     // pixel 2 hp -> bit 2 hp, pixel 2 hp + 1 -> bit 16 + 2 hp
+                const uint32_t V = pair16(mc, 3 + 2 * hp), Ee = pair16(mc, 6 + 2 * hp), Ww = pair16(mc, 2 * hp);
+                const uint32_t Nn = pair16(mu, 3 + 2 * hp), Ss = pair16(md, 3 + 2 * hp);
+                const uint32_t Vd = V + kd, Vb = V + kb;
+                // two neighbouring compass points both darker, or both brighter: (N or S) and (E or W)
+                const uint32_t dark = ((Vd - Nn) | (Vd - Ss)) & ((Vd - Ee) | (Vd - Ww));
+                const uint32_t not_bright = ((Vb - Nn) & (Vb - Ss)) | ((Vb - Ee) & (Vb - Ww));
+                signs |= ((dark | ~not_bright) & 0x80008000u) >> (15 - 2 * hp);      // pixel 2 hp -> bit 2 hp, pixel 2 hp + 1 -> bit 16 + 2 hp
             }
             passbits = (signs | (signs >> 15)) & 0xffu;
             // pixels of the group that are region pixels and FAST centres: rx < SCW, 3 <= x < w - 3
@@ -292,7 +322,11 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
     __syncthreads();
     ORB_CLK(1);
     // Phase 2a: even-position test.  A survivor is listed once per polarity that is still possible (bit 12 = brighter ring), so
-    // that phase 2b runs ONE min ladder per entry; the few pixels with both polarities open get two entries.
+    // that phase 2b runs ONE min ladder per entry; the few pixels with both polarities open get two entries.  (Measured and left
+    // out: the EXACT FAST-9 decision here as bit arithmetic -- sixteen guard-bit subtractions per polarity, the flags gathered into a
+    // ring mask, three shift-and-and steps; bit-exact, and phase 2b shrinks to the ~3 % that are corners -- but it reads 17 ring
+    // bytes per candidate where this test reads 9, and the byte gathers from LDS, not the arithmetic, are what a candidate costs:
+    // FAST 1.83 -> 2.02 ms.)
     const int nc = n_cand;
     for (int c0 = 0; c0 < nc; c0 += 256) {
         const int c = c0 + tid;
@@ -301,6 +335,7 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
             p = cand[c];
             const int ry = p / SCP, rx = p % SCP;
             polar = fast_even4_test(&tile[(ry + 3) * TP + rx + 15], TP, threshold);
+            if (MAGE_ORB_ABLATE & 2) { int off = (ry + 3) * TP + rx + 15; ORB_LAUNDER(off); polar |= fast_even4_test(&tile[off], TP, threshold); }
         }
         const unsigned long long bal0 = __ballot(polar & 1), bal1 = __ballot(polar & 2);
         if (bal0 | bal1) {
@@ -320,7 +355,8 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
     for (int c = tid; c < nc2; c += 256) {
         const int pc = cand2[c], p = pc & 0xfff;
         const int ry = p / SCP, rx = p % SCP;
-        const int m = fast_score_polar(&tile[(ry + 3) * TP + rx + 15], TP, (pc & 0x1000) != 0);
+        int m = fast_score_polar(&tile[(ry + 3) * TP + rx + 15], TP, (pc & 0x1000) != 0);
+        if (MAGE_ORB_ABLATE & 4) { int off = (ry + 3) * TP + rx + 15; ORB_LAUNDER(off); m = max(m, fast_score_polar(&tile[off], TP, (pc & 0x1000) != 0)); }
         const bool corner = m > threshold;
         if (corner) sc[p + SC_OFF] = (uint8_t)(m - 1);
         // the corners of the tile proper (not of its ring) are what phase 3 has to look at: a list, ~3 % of the pixels
@@ -343,7 +379,73 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
                 *reinterpret_cast<uint32_t*>(raw_frame0 + (size_t)y * wp + xq) = *reinterpret_cast<const uint32_t*>(&sc[(ly + 1) * SCP + 4 * lq + 1 + SC_OFF]);
         }
     }
-    if (BLUR) {
+    // Phase 3: strict 3x3 maximum among the raw scores + RunByImageBorder, one lane per listed corner (~3 % of the pixels: mostly
+    // the first wavefront), its eight neighbours in eight independent byte reads
+    {
+        const int ncn = n_corner;
+        for (int c = tid; c < ncn; c += 256) {
+            const int p = corners[c];
+            const int ry = p / SCP, rx = p % SCP;
+            const int x = x0 - 1 + rx, y = y0 - 1 + ry;
+            const uint8_t* q = &sc[p + SC_OFF];
+            const int s = q[0];
+            const int m = max(max(max((int)q[-SCP - 1], (int)q[-SCP]), max((int)q[-SCP + 1], (int)q[-1])),
+                              max(max((int)q[1], (int)q[SCP - 1]), max((int)q[SCP], (int)q[SCP + 1])));
+            if (s > m && x >= lo && x < w - lo && y >= lo && y < h - lo) kl[atomicAdd(&n_kept, 1)] = make_int2(x | (y << 16), s);
+        }
+    }
+    if (BLUR == BLUR_MFMA) {
+        // The 7-tap separable Gaussian as two banded matrix products on the otherwise idle matrix cores (v_mfma_i32_16x16x32_i8):
+        // the vector ALUs, which bound this kernel, are left with the operand shuffles.  Wavefront J owns pixel columns
+        // 16 J .. 16 J + 15 of the tile.
+        //   pass 1   Hs[row][col] = sum_k (pixel[row][k] - 128) * B1[k][col] + 128  for the 32 window rows: A = eight bytes of a window
+        //            row per lane (one ds_read_b64, xor 0x80: i8 operands), B1 = the taps as a banded matrix (from blur_tab)
+        //   split    Hs fits 16 bits (taps sum <= 257): Hs = 256 hi + (lo_s + 128) with hi = Hs >> 8 and lo_s = (Hs & 255) - 128,
+        //            both i8.  The result registers of pass 1 -- lane = column, four consecutive rows each -- ARE the A operand
+        //            layout of pass 2 (lane = column, eight K slots = eight window rows), so the split is byte permutes in place.
+        //   pass 2   out[col][row] = (256 * sum_k hi[k][col] B2[k][row] + sum_k lo_s[k][col] B2[k][row] + c2) >> 16, c2 = 128 T^2 +
+        //            2^15: two products per 16 output rows, lane = output row, four consecutive columns per lane -> one
+        //            32-bit store.  Exact integer arithmetic throughout, the same value the two-pass form computes.
+        const int J = tid >> 6, g = lane >> 4, j = lane & 15;
+        const long B1 = (MAGE_ORB_ABLATE & 16) ? (long)lane * 0x0101010101010101l : (long)blur_tab[lane];
+        const long B2q[2] = { (MAGE_ORB_ABLATE & 16) ? (long)lane * 0x0102010201020102l : (long)blur_tab[64 + lane], (MAGE_ORB_ABLATE & 16) ? (long)lane * 0x0301030103010301l : (long)blur_tab[128 + lane] };
+        const long flip = (long)0x8080808080808080ull;
+        const long a0 = *reinterpret_cast<const long*>(&tile[j * TP + 16 * J + 8 + 8 * g]) ^ flip;
+        const long a1 = *reinterpret_cast<const long*>(&tile[(16 + j) * TP + 16 * J + 8 + 8 * g]) ^ flip;
+        const v4i_t c128 = { 128, 128, 128, 128 };
+        const v4i_t h0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a0, B1, c128, 0, 0, 0);
+        const v4i_t h1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a1, B1, c128, 0, 0, 0);
+        // 16-bit pairs, then the low bytes (xor 0x80: lo_s) and the high bytes of eight rows
+        const uint32_t p0 = __builtin_amdgcn_perm((uint32_t)h0[1], (uint32_t)h0[0], 0x05040100u), p1 = __builtin_amdgcn_perm((uint32_t)h0[3], (uint32_t)h0[2], 0x05040100u);
+        const uint32_t p2 = __builtin_amdgcn_perm((uint32_t)h1[1], (uint32_t)h1[0], 0x05040100u), p3 = __builtin_amdgcn_perm((uint32_t)h1[3], (uint32_t)h1[2], 0x05040100u);
+        const uint32_t lo_a = __builtin_amdgcn_perm(p1, p0, 0x06040200u) ^ 0x80808080u, lo_b = __builtin_amdgcn_perm(p3, p2, 0x06040200u) ^ 0x80808080u;
+        const uint32_t hi_a = __builtin_amdgcn_perm(p1, p0, 0x07050301u), hi_b = __builtin_amdgcn_perm(p3, p2, 0x07050301u);
+        const long A_lo = (long)((unsigned long long)lo_a | ((unsigned long long)lo_b << 32)), A_hi = (long)((unsigned long long)hi_a | ((unsigned long long)hi_b << 32));
+        uint8_t* O = blurred + (size_t)f * wp * h;
+        const int xq = x0 + 16 * J + 4 * g;
+        const v4i_t cc2 = { blur_c2, blur_c2, blur_c2, blur_c2 }, zero4 = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int Q = 0; Q < 2; ++Q) {
+            const v4i_t dl = __builtin_amdgcn_mfma_i32_16x16x32_i8(A_lo, B2q[Q], cc2, 0, 0, 0);
+            const v4i_t dh = __builtin_amdgcn_mfma_i32_16x16x32_i8(A_hi, B2q[Q], zero4, 0, 0, 0);
+            uint32_t wv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wv[r] = ((uint32_t)dh[r] << 8) + (uint32_t)dl[r];
+            // bits 16 .. 31 of each value (<= 257), saturated to a byte
+            const uint32_t q01 = __builtin_amdgcn_perm(wv[1], wv[0], 0x07060302u), q23 = __builtin_amdgcn_perm(wv[3], wv[2], 0x07060302u);
+            ushort2_t s01, s23; __builtin_memcpy(&s01, &q01, 4); __builtin_memcpy(&s23, &q23, 4);
+            const ushort2_t cap = { 255, 255 };
+            s01 = __builtin_elementwise_min(s01, cap); s23 = __builtin_elementwise_min(s23, cap);
+            uint32_t c01, c23; __builtin_memcpy(&c01, &s01, 4); __builtin_memcpy(&c23, &s23, 4);
+            uint32_t packed = __builtin_amdgcn_perm(c23, c01, 0x06040200u);
+            const int orow = 16 * Q + j, y = y0 + orow;
+            if ((MAGE_ORB_ABLATE & 32) ? packed == 0x12345678u && orow < FT_H : orow < FT_H && y < h && xq < wp) {
+                if (xq + 4 > w) packed &= xq < w ? (1u << (8 * (w - xq))) - 1u : 0u;        // bytes beyond the image width stay zero
+                *reinterpret_cast<uint32_t*>(O + (size_t)y * wp + xq) = packed;
+            }
+        }
+    }
+    if (BLUR == BLUR_VALU) {
         // horizontal pass (the candidate lists are dead): four outputs per thread from three aligned 32-bit LDS reads; each output
         // is two 4-way byte dot products (v_dot4_u32_u8) over windows cut out of the 12 bytes with v_alignbyte
         const uint32_t T0 = (uint32_t)taps.t[0] | ((uint32_t)taps.t[1] << 8) | ((uint32_t)taps.t[2] << 16) | ((uint32_t)taps.t[3] << 24);
@@ -359,25 +461,8 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
             o.w = (int)__builtin_amdgcn_udot4(C, T1, __builtin_amdgcn_udot4(B, T0, 0u, false), false);
             *reinterpret_cast<int4*>(&hrow[ty * FT_W + 4 * tq]) = o;
         }
-    }
-    __syncthreads();
-    ORB_CLK(3);
-    // Phase 3 on the last wavefront (the vertical blur pass below occupies the first three): strict 3x3 maximum among the raw scores
-    // + RunByImageBorder, one lane per listed corner, its eight neighbours in eight independent byte reads
-    if (tid >= 192) {
-        const int ncn = n_corner;
-        for (int c = tid - 192; c < ncn; c += 64) {
-            const int p = corners[c];
-            const int ry = p / SCP, rx = p % SCP;
-            const int x = x0 - 1 + rx, y = y0 - 1 + ry;
-            const uint8_t* q = &sc[p + SC_OFF];
-            const int s = q[0];
-            const int m = max(max(max((int)q[-SCP - 1], (int)q[-SCP]), max((int)q[-SCP + 1], (int)q[-1])),
-                              max(max((int)q[1], (int)q[SCP - 1]), max((int)q[SCP], (int)q[SCP + 1])));
-            if (s > m && x >= lo && x < w - lo && y >= lo && y < h - lo) kl[atomicAdd(&n_kept, 1)] = make_int2(x | (y << 16), s);
-        }
-    }
-    if (BLUR) {
+        __syncthreads();
+        ORB_CLK(3);
         // vertical pass: a thread owns four pixel columns and two consecutive rows, reads the eight row sums they need once and
         // packs one 32-bit store per row; products fit 24 bits (tap <= 255, row sum < 2^16)
         static_assert(FT_H % 2 == 0 && (FT_H / 2) * (FT_W / 4) <= 192, "one 4 x 2 pixel patch per thread of the first three wavefronts");
@@ -1134,14 +1219,44 @@ void orb_fast_tiling(int w, int h, int* tiles_x, int* tiles_y, int* tile_cap)
 
 bool orb_blur_fuses(const OrbTaps& taps) { return taps.radius == 3 && taps.t[3] < 256; }
 
+// The banded tap matrices of the matrix-core form of the fused blur (k_fast_keypoints<BLUR_MFMA>), as the 8-byte i8 operands of
+// v_mfma_i32_16x16x32_i8: entry [lane] = B1 (pass 1: K slot 8 g + b = window column 16 J + 8 + 8 g + b, output column j = lane & 15),
+// [64 + lane], [128 + lane] = B2 for output rows 0 .. 15 / 16 .. 31 (K slot b of lane group g = window row 4 g + b for b < 4,
+// 16 + 4 g + b - 4 otherwise; output row 16 Q + (lane & 15) sits at window row 4 + that).  False when the taps do not fit the i8 /
+// 16-bit arithmetic (a tap > 127 or a sum > 257): the caller then takes the vector-ALU form.
+bool orb_blur_mfma_table(const OrbTaps& taps, unsigned long long* tab192, int* c2)
+{
+    if (!orb_blur_fuses(taps)) return false;
+    int T = 0;
+    for (int k = 0; k < 7; ++k) { if (taps.t[k] < 0 || taps.t[k] > 127) return false; T += taps.t[k]; }
+    if (T > 257) return false;
+    auto tap = [&](int idx) -> unsigned long long { return idx >= 0 && idx <= 6 ? (unsigned long long)taps.t[idx] : 0ull; };
+    for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane >> 4, j = lane & 15;
+        unsigned long long b1 = 0, b2[2] = { 0, 0 };
+        for (int b = 0; b < 8; ++b) {
+            b1 |= tap(8 * g + b - j - 5) << (8 * b);
+            const int row = b < 4 ? 4 * g + b : 16 + 4 * g + b - 4;
+            for (int Q = 0; Q < 2; ++Q) b2[Q] |= tap(row - 1 - (16 * Q + j)) << (8 * b);
+        }
+        tab192[lane] = b1; tab192[64 + lane] = b2[0]; tab192[128 + lane] = b2[1];
+    }
+    *c2 = 128 * T * T + (1 << 15);
+    return true;
+}
+
 void orb_launch_fast(const uint8_t* img, int w, int h, int stride, size_t frame_stride, int n_frames, int threshold, int border, uint8_t* raw_frame0, int wp,
-                     int2* raw, int* tile_count, const OrbTaps* taps, uint8_t* blurred, hipStream_t st)
+                     int2* raw, int* tile_count, const OrbTaps* taps, const unsigned long long* blur_tab, int blur_c2, uint8_t* blurred, hipStream_t st)
 {
     const dim3 grid(cdiv(wp, FT_W), cdiv(h, FT_H), n_frames);
-    if (taps) hipLaunchKernelGGL(k_fast_keypoints<true>, grid, dim3(256), 0, st, img, w, h, stride, frame_stride, threshold, border, raw_frame0, wp, raw, tile_count,
-                                 *taps, blurred);
-    else hipLaunchKernelGGL(k_fast_keypoints<false>, grid, dim3(256), 0, st, img, w, h, stride, frame_stride, threshold, border, raw_frame0, wp, raw, tile_count,
-                            OrbTaps{}, blurred);
+    if (taps && blur_tab && !(MAGE_ORB_ABLATE & 8))
+        hipLaunchKernelGGL(k_fast_keypoints<BLUR_MFMA>, grid, dim3(256), 0, st, img, w, h, stride, frame_stride, threshold, border, raw_frame0, wp, raw, tile_count,
+                           *taps, blurred, blur_tab, blur_c2);
+    else if (taps && !(MAGE_ORB_ABLATE & 8))
+        hipLaunchKernelGGL(k_fast_keypoints<BLUR_VALU>, grid, dim3(256), 0, st, img, w, h, stride, frame_stride, threshold, border, raw_frame0, wp, raw, tile_count,
+                           *taps, blurred, blur_tab, blur_c2);
+    else hipLaunchKernelGGL(k_fast_keypoints<BLUR_NONE>, grid, dim3(256), 0, st, img, w, h, stride, frame_stride, threshold, border, raw_frame0, wp, raw, tile_count,
+                            OrbTaps{}, blurred, blur_tab, blur_c2);
 }
 
 void orb_launch_select(const OrbSelectArgs& a, int n_frames, hipStream_t st)
