@@ -30,11 +30,21 @@ def _deps_mtime() -> float:
     return max(os.path.getmtime(f) for f in files)
 
 
+# per-file additions: the i8 matrix-core products of the fused blur keep their accumulators in ordinary vector registers (the
+# default puts them in accumulation registers and moves all 24 results back one v_accvgpr_read at a time -- in a kernel bound by
+# vector-ALU issue)
+EXTRA_FLAGS = {"orb_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
+def flags_for(src: str) -> list[str]:
+    return FLAGS + EXTRA_FLAGS.get(os.path.basename(src), [])
+
+
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(OBJ, os.path.basename(src) + ".o")
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= _deps_mtime():
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(_deps_mtime(), os.path.getmtime(__file__)):
         return obj
-    subprocess.check_call([HIPCC, *FLAGS, "-c", src, "-o", obj])
+    subprocess.check_call([HIPCC, *flags_for(src), "-c", src, "-o", obj])
     return obj
 
 

@@ -120,6 +120,12 @@ __device__ __forceinline__ int reflect101(int p, int n)
     while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
     return p;
 }
+// the same for -n < p < 2 n - 1 (one reflection at most): two selects instead of a loop
+__device__ __forceinline__ int reflect101_once(int p, int n)
+{
+    p = p < 0 ? -p : p;
+    return p >= n ? 2 * (n - 1) - p : p;
+}
 
 // Stage a (TH x TW)-byte window of the source image, top-left at (gx0, gy0) with gx0 a multiple of 4, into LDS with
 // 32-bit loads when the source allows it (row pitch and base 4-byte aligned), bytes otherwise.  Out-of-image coordinates are
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
         if (tid < FTH * (FTW / 16)) {
             const int gx = x0 - FWX + 16 * wtq, gy = wy0 - FH + wty;
             if (BLUR || (gy >= 0 && gy < h)) {
-                const uint8_t* rowp = I + (size_t)(BLUR ? reflect101(gy, h) : gy) * stride;
+                const uint8_t* rowp = I + (size_t)(BLUR ? (h > FH ? reflect101_once(gy, h) : reflect101(gy, h)) : gy) * stride;   // gy in [-4, h + 3]
                 if (aligned16 && gx >= 0 && gx + 15 < w) v = *reinterpret_cast<const uint4*>(rowp + gx);
                 else if (BLUR || (gx + 15 >= 0 && gx < w)) {
                     // the frame's edge columns or an unaligned frame: byte by byte, one dword at a time (a rolled loop: this path

@@ -30,7 +30,7 @@ def build(bits):
     for src in B.sources():
         if os.path.basename(src) == "orb_kernels.hip":
             obj = os.path.join(PROBE_DIR, f"orb_kernels.ablate{bits}.o")
-            subprocess.check_call([B.HIPCC, *B.FLAGS, f"-DMAGE_ORB_ABLATE={bits}", "-c", src, "-o", obj])
+            subprocess.check_call([B.HIPCC, *B.flags_for(src), f"-DMAGE_ORB_ABLATE={bits}", "-c", src, "-o", obj])
         else:
             obj = os.path.join(B.OBJ, os.path.basename(src) + ".o")
         objs.append(obj)
@@ -41,7 +41,7 @@ def run_one(bits):
     import numpy as np
     import torch
     from mageslam_amd import _lib
-    _lib.LIB_PATH = lib_path(bits)
+    _lib.LIB_PATH = bits if isinstance(bits, str) else lib_path(bits)
     from mageslam_amd import frames
     from mageslam_amd.orb import OrbDetector
     base = [frames.frame_pair(500 + i) for i in range(8)]
@@ -51,7 +51,7 @@ def run_one(bits):
     nf = 2048
     imgs = torch.from_numpy(allf[np.arange(nf) % 16]).cuda().contiguous()
     ms = []
-    for i in range(8):
+    for i in range(int(os.environ.get("ORB_ABLATE_REPS", "8"))):
         det.detect_batch_device(imgs.data_ptr(), nf, 640, 480, 440)
         torch.cuda.synchronize()
         if i >= 2:
@@ -66,7 +66,7 @@ def main():
             build(int(b)); print(lib_path(int(b)))
         return
     if "--one" in sys.argv:
-        run_one(int(args[0])); return
+        run_one(int(args[0]) if args[0].isdigit() else args[0]); return   # a number: that variant; otherwise the path of a library
     for b in args:
         subprocess.call([sys.executable, os.path.abspath(__file__), "--one", b])
 

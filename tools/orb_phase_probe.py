@@ -27,7 +27,7 @@ def build():
     for src in B.sources():
         obj = os.path.join(PROBE_DIR, os.path.basename(src) + ".o")
         if not os.path.exists(obj) or os.path.getmtime(obj) < B._deps_mtime():
-            subprocess.check_call([B.HIPCC, *B.FLAGS, "-DMAGE_ORB_CLOCKS", "-c", src, "-o", obj])
+            subprocess.check_call([B.HIPCC, *B.flags_for(src), "-DMAGE_ORB_CLOCKS", "-c", src, "-o", obj])
         objs.append(obj)
     subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROBE_LIB, *objs])
 
