@@ -181,28 +181,35 @@ constexpr int SC_OFF = 3;                               // region pixel rx sits 
 constexpr int F_MAXKP = FT_W * FT_H / 4;                // a strict 3x3 maximum leaves at most one keypoint per 2x2 block
 
 // wave-aggregated append to an LDS list: lane l contributes the positions pos0 + j of the set bits j of its 8-bit mask.  The
-// exclusive prefix of the lanes' counts comes from ballots over the bits of the count, one atomic per wavefront reserves the
+// exclusive prefix of the lanes' counts is a DPP scan along the wavefront, one atomic per wavefront reserves the
 // range, and every lane issues its eight stores unconditionally -- the unset ones go to a dump slot -- so there is no divergent
 // code at all.
 __device__ __forceinline__ void append8(unsigned bits, int pos0, uint16_t* __restrict__ list, int dump, int* __restrict__ counter, int lane)
 {
     const int c = __popc(bits);
-    int pre = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const unsigned long long bal = __ballot((c >> k) & 1);
-        pre += __popcll(bal & ((1ull << lane) - 1ull)) << k;
-        tot += __popcll(bal) << k;
-    }
+    // inclusive prefix sum of the lanes' counts along the wavefront: four row_shr steps inside each row of 16 lanes, then the row
+    // totals through row_bcast:15 / row_bcast:31 -- six v_add_u32_dpp where the ballot form needed ~35 operations
+    int v = c;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    const int tot = __builtin_amdgcn_readlane(v, 63);
     if (tot == 0) return;
     int base = 0;
     if (lane == 0) base = atomicAdd(counter, tot);
-    int off = __shfl(base, 0, 64) + pre;
+    // byte offsets inside the list; a set bit stores at `off` and advances it, an unset one stores at the dump slot.  Bit j of the
+    // mask as a one-bit signed field is -1 or 0; twice that is the step of the offset and (both offsets being even) the select mask
+    unsigned off = 2u * (unsigned)(__builtin_amdgcn_readfirstlane(base) + v - c);
+    const unsigned dump2 = 2u * (unsigned)dump;
+    uint8_t* const lb = reinterpret_cast<uint8_t*>(list);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const bool on = (bits >> j) & 1u;
-        list[on ? off : dump] = (uint16_t)(pos0 + j);
-        off += on ? 1 : 0;
+        const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)bits, j, 1), m2 = m + m;
+        *reinterpret_cast<uint16_t*>(lb + ((off & m2) | (dump2 & ~m2))) = (uint16_t)(pos0 + j);
+        off -= m2;
     }
 }
 
