@@ -56,29 +56,33 @@ __device__ __forceinline__ short2_t pmax(short2_t a, short2_t b) { return __buil
 
 // Second screen, on the EVEN ring positions (the compass points and the four diagonals): 9 contiguous ring pixels contain at
 // least 4 consecutive even positions, so a corner needs 4 consecutive even pixels all darker than the centre by more than t, or
-// all brighter.  Nine byte reads and ~45 operations; ~11 % of the pixels of a textured frame pass (the opposite-pair test on all
-// 16 pixels passes ~8 % but costs twice as much on the ~21 % it is run on).
+// all brighter.  Nine byte reads; ~11 % of the pixels of a textured frame pass (the opposite-pair test on all 16 pixels passes
+// ~8 % but costs twice as much on the ~21 % it is run on).  Register j holds even positions j and j + 4 (a ring pixel and its
+// opposite) in its 16-bit halves, the comparisons are the guard-bit subtractions of phase 1 (flag = bit 15 of each half), and "four
+// consecutive flags" is bitwise logic on the registers and their half-swapped copies: window e (low half) and e + 4 (high half)
+// of { D0 D1 D2 D3 }, { D1 D2 D3 S0 }, { D2 D3 S0 S1 }, { D3 S0 S1 S2 }.  2-cycle operations but for the three swaps, where the
+// packed min / max form took ~45 4-cycle ones.
 // Returns bit 0 = a darker run exists, bit 1 = a brighter run exists (0 = not a corner).
-__device__ __forceinline__ int fast_even4_test(const uint8_t* __restrict__ c, int TP, int t)
+__device__ __forceinline__ int fast_even4_test(const uint8_t* __restrict__ c, int TP, uint32_t kd, uint32_t kb)
 {
-    const int v = c[0];
     // even positions 0, 2, 4, 6 and their opposites 8, 10, 12, 14: (0, 3) (2, 2) (3, 0) (2, -2) / (0, -3) (-2, -2) (-3, 0) (-2, 2)
     const int ex[4] = { 0, 2, 3, 2 }, ey[4] = { 3, 2, 0, -2 };
-    short2_t P[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) P[j] = (short2_t){ (short)(v - (int)c[ey[j] * TP + ex[j]]), (short)(v - (int)c[-ey[j] * TP - ex[j]]) };
-    // windows of 2 then 4 consecutive even positions: register j holds the windows starting at even position j (low half) and j + 4 (high half)
-    short2_t A2[4], B2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const short2_t nx = j < 3 ? P[j + 1] : swap16(P[0]); A2[j] = pmin(P[j], nx); B2[j] = pmax(P[j], nx); }
-    short2_t dark = (short2_t){ (short)-32768, (short)-32768 }, bright = (short2_t){ (short)32767, (short)32767 };
+    const uint32_t v2 = (uint32_t)c[0] * 0x00010001u, Vd = v2 + kd, Vb = v2 + kb;
+    uint32_t D[4], B[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const short2_t na = j < 2 ? A2[j + 2] : swap16(A2[j - 2]), nb = j < 2 ? B2[j + 2] : swap16(B2[j - 2]);
-        dark = pmax(dark, pmin(A2[j], na));            // largest window minimum of (v - ring)
-        bright = pmin(bright, pmax(B2[j], nb));        // smallest window maximum
+        const uint32_t P = (uint32_t)c[ey[j] * TP + ex[j]] | ((uint32_t)c[-ey[j] * TP - ex[j]] << 16);
+        D[j] = Vd - P;           // flag: darker than v - t
+        B[j] = Vb - P;           // flag: NOT brighter than v + t
     }
-    return (max((int)dark.x, (int)dark.y) > t ? 1 : 0) | (min((int)bright.x, (int)bright.y) < -t ? 2 : 0);
+    auto swap_halves = [](uint32_t x) -> uint32_t { return __builtin_amdgcn_alignbit(x, x, 16); };
+    const uint32_t S0 = swap_halves(D[0]), S1 = swap_halves(D[1]), S2 = swap_halves(D[2]);
+    const uint32_t d23 = D[2] & D[3], s01 = S0 & S1;
+    const uint32_t dark = (D[0] & D[1] & d23) | (D[1] & d23 & S0) | (d23 & s01) | (D[3] & s01 & S2);
+    const uint32_t T0 = swap_halves(B[0]), T1 = swap_halves(B[1]), T2 = swap_halves(B[2]);
+    const uint32_t b23 = B[2] | B[3], t01 = T0 | T1;
+    const uint32_t not_bright = (B[0] | B[1] | b23) & (B[1] | b23 | T0) & (b23 | t01) & (B[3] | t01 | T2);   // a window is all brighter iff none of its flags is set
+    return ((dark & 0x80008000u) ? 1 : 0) | ((~not_bright & 0x80008000u) ? 2 : 0);
 }
 
 // The corner score for ONE polarity: D[k] = v - ring[k] (darker ring) or ring[k] - v (brighter ring), m = max over the 16 arcs of 9
@@ -347,8 +351,8 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
         if (c < nc) {
             p = cand[c];
             const int ry = p / SCP, rx = p % SCP;
-            polar = fast_even4_test(&tile[(ry + 3) * TP + rx + 15], TP, threshold);
-            if (MAGE_ORB_ABLATE & 2) { int off = (ry + 3) * TP + rx + 15; ORB_LAUNDER(off); polar |= fast_even4_test(&tile[off], TP, threshold); }
+            polar = fast_even4_test(&tile[(ry + 3) * TP + rx + 15], TP, kd, kb);
+            if (MAGE_ORB_ABLATE & 2) { int off = (ry + 3) * TP + rx + 15; ORB_LAUNDER(off); polar |= fast_even4_test(&tile[off], TP, kd, kb); }
         }
         const unsigned long long bal0 = __ballot(polar & 1), bal1 = __ballot(polar & 2);
         if (bal0 | bal1) {
