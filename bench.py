@@ -163,6 +163,29 @@ def _caller_loop(make, load, s, huber=0.9):
     return time.perf_counter() - t0, len(out)
 
 
+def _cpp_caller_steady(s):
+    """The same one-iteration call from the reference's own kind of caller: tools/shim_local_ba.cpp (C++ against include/BundlerLib.h,
+    built by __graft_entry__.build_tools) -- median and minimum of 8 calls; None when the tool is not built."""
+    import subprocess
+    import tempfile
+    from mageslam_amd import scene
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "_bin", "shim_local_ba")
+    if not os.path.exists(exe):
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "local.scene")
+            scene.save_scene(s, path)
+            out = subprocess.run([exe, path, "0.9", "--steady", "8"], capture_output=True, text=True, timeout=120).stdout
+        for line in out.splitlines():
+            if line.startswith("steady_ms"):
+                med, mn = line.split()[1:3]
+                return {"median_ms": round(float(med), 4), "min_ms": round(float(mn), 4), "calls": 8}
+    except Exception as e:                                  # a missing compiler run-time on the box must not cost the bench line
+        return {"error": str(e)[:200]}
+    return None
+
+
 def extra_config3(device):
     from mageslam_amd import scene
     from mageslam_amd.bundler import BundlerLib, load_scene
@@ -185,11 +208,13 @@ def extra_config3(device):
     steady = (time.perf_counter() - t0) / n
     trials = [t["trials"] for t in b.trace()]
     b.close()
+    cpp = _cpp_caller_steady(s)
     for _ in range(2):
         _caller_loop(make, load, so)
     loops = [_caller_loop(make, load, so) for _ in range(20)]
     return {"workload": "local: 20 keyframes / 5000 points / 50000 observations, Huber 0.9, 7 keyframes fixed",
             "steady_ms_per_lm_iteration": round(1e3 * steady, 4), "steady_last_trials": trials,
+            "steady_ms_per_lm_iteration_cpp_caller": cpp,
             "one_iteration_bundler_create_to_destroy": one,
             "caller_loop_10_calls_ms": _median_ms([t for t, _ in loops]), "caller_loop_outliers_removed": loops[-1][1],
             "structure_build": "device (mageslam_amd/csrc/ba_build.hip)" if os.environ.get("MAGE_BA_BUILD", "d")[0] == "d" else "host"}
