@@ -84,6 +84,38 @@ def test_non_default_settings_match_oracle(kw):
     assert np.array_equal(kp_xyr(k), kp_xyr(ko)) and np.array_equal(d, do)
 
 
+@pytest.mark.parametrize("size", [(640, 480), (333, 241), (70, 50), (64, 24), (25, 31)])
+def test_matrix_core_blur_equals_vector_blur_and_oracle(size):
+    """The fused 7-tap Gaussian has two forms -- two banded i8 products on the matrix cores (default) and the two-pass v_dot4 form
+    (MAGE_ORB_BLUR=valu, read when the detector is created; also the fall-back for taps that do not fit i8): the blurred image
+    (mage_orb_debug_read), the FAST score map, the keypoints and the descriptors must be the same bytes, and equal to the oracle's.
+    Sizes: full frame, widths / heights that are no multiple of the 64 x 24 tile (partial dwords at the right edge), one tile, and a
+    frame smaller than a tile (every row and column reflected)."""
+    w, h = size
+    img = frames.make_frame(4242 + w, w, h, n_rect=30, n_disc=40)
+    kw = dict(nfeatures=200, num_cells_x=8, num_cells_y=6) if w < 640 else {}
+    old = os.environ.pop("MAGE_ORB_BLUR", None)
+    try:
+        dm = OrbDetector(**kw)
+        os.environ["MAGE_ORB_BLUR"] = "valu"
+        dv = OrbDetector(**kw)
+    finally:
+        os.environ.pop("MAGE_ORB_BLUR", None)
+        if old is not None:
+            os.environ["MAGE_ORB_BLUR"] = old
+    km, desc_m = dm.DetectAndCompute(img)
+    kv, desc_v = dv.DetectAndCompute(img)
+    sm, bm = dm.debug_read(w, h)
+    sv, bv = dv.debug_read(w, h)
+    assert np.array_equal(bm, bv), np.argwhere(bm != bv)[:5]
+    assert np.array_equal(sm, sv)
+    assert np.array_equal(kp_xyr(km), kp_xyr(kv)) and np.array_equal(desc_m, desc_v)
+    okw = {"num_cells_x": "cells_x", "num_cells_y": "cells_y"}
+    ko, do, bo = O.orb_detect(img, O.OrbParams.defaults(**{okw.get(a, a): b for a, b in kw.items()}), want_blur=True)
+    assert np.array_equal(bm, bo), np.argwhere(bm != bo)[:5]
+    assert np.array_equal(kp_xyr(km), kp_xyr(ko)) and np.array_equal(desc_m, do)
+
+
 @pytest.mark.parametrize("case", range(24))
 def test_randomised_settings_and_frames_match_oracle(case):
     """Differential test over the detector's whole parameter surface: random frame size and content, feature budget, FAST
