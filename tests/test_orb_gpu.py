@@ -116,6 +116,33 @@ def test_matrix_core_blur_equals_vector_blur_and_oracle(size):
     assert np.array_equal(kp_xyr(km), kp_xyr(ko)) and np.array_equal(desc_m, do)
 
 
+@pytest.mark.parametrize("threshold", [1, 2, 127, 128, 200, 254, 255])
+def test_extreme_thresholds_and_saturated_pixels_match_oracle(threshold):
+    """The two FAST screens compare through guard-bit subtractions on 16-bit fields ((V + 0x8000 - t - 1) - R and (V + 0x8000 + t) - R):
+    the fields must neither borrow nor carry at the ends of the ranges -- thresholds up to 255, ring / centre pixels of 0 and 255.
+    Frames: black / white blocks and isolated extreme pixels on mid grey, and uniform noise over the full range."""
+    rng = np.random.default_rng(77 + threshold)
+    w, h = 200, 120
+    a = np.full((h, w), 128, np.uint8)
+    a[10:40, 10:60] = 0; a[50:90, 30:90] = 255; a[20:30, 100:180] = 255; a[25:27, 120:160] = 0
+    for _ in range(150):
+        a[int(rng.integers(4, h - 4)), int(rng.integers(4, w - 4))] = int(rng.choice([0, 1, 254, 255]))
+    b = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    c = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
+    for img in (a, b, c):
+        kw = dict(fast_threshold=threshold, nfeatures=300, num_cells_x=8, num_cells_y=6)
+        det = OrbDetector(**kw)
+        k, d = det.DetectAndCompute(img)
+        score, _ = det.debug_read(w, h)
+        ko, do = O.orb_detect(img, O.OrbParams.defaults(fast_threshold=threshold, nfeatures=300, cells_x=8, cells_y=6))
+        assert np.array_equal(kp_xyr(k), kp_xyr(ko)), (threshold, len(k), len(ko))
+        assert np.array_equal(d, do)
+        if threshold >= 128:
+            # the literal definition on the centre pixels the detector scores (3 pixels from the border): a corner needs 9 contiguous
+            # ring pixels all > v + t or all < v - t, impossible for t = 255
+            assert threshold < 255 or not score.any()
+
+
 @pytest.mark.parametrize("case", range(24))
 def test_randomised_settings_and_frames_match_oracle(case):
     """Differential test over the detector's whole parameter surface: random frame size and content, feature budget, FAST
