@@ -31,7 +31,7 @@ def orb_case(rng, case):
     else:
         img = frames.make_frame(5000 + case, w, h, n_rect=int(rng.integers(3, 200)), n_disc=int(rng.integers(3, 300)), noise=float(rng.choice([0.0, 1.0, 2.0, 4.0])))
     patch = int(rng.choice([15, 31, 9, 21])) if case % 4 == 0 else int(rng.choice([15, 31]))
-    kw = dict(nfeatures=int(rng.integers(4, 3000 if case % 7 == 0 else 700)), fast_threshold=int(rng.integers(1, 60)), num_cells_x=int(rng.integers(1, 48)),
+    kw = dict(nfeatures=int(rng.integers(4, 3000 if case % 7 == 0 else 700)), fast_threshold=int(rng.integers(1, 256) if case % 9 == 0 else rng.integers(1, 60)), num_cells_x=int(rng.integers(1, 48)),
               num_cells_y=int(rng.integers(1, 48)), gaussian_kernel_size=int(rng.choice([1, 3, 5, 7, 7, 7, 9])), patch_size=patch,
               nlevels=int(rng.integers(1, 5)) if case % 3 == 0 else 1, scale_factor=float(rng.choice([1.2, 1.5, 2.0])), use_orientation=int(case % 5 == 0),
               feature_factor_anms=float(rng.choice([1.0, 1.5, 2.5])), feature_strength_anms=float(rng.choice([0.5, 0.9, 1.0, 1.2])),
