@@ -260,6 +260,13 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
             if (BLUR || (gy >= 0 && gy < h)) {
                 const uint8_t* rowp = I + (size_t)(BLUR ? (h > FH ? reflect101_once(gy, h) : reflect101(gy, h)) : gy) * stride;   // gy in [-4, h + 3]
                 if (aligned16 && gx >= 0 && gx + 15 < w) v = *reinterpret_cast<const uint4*>(rowp + gx);
+                else if (BLUR && (gx + 15 < 0 ? -gx < w : gx >= w && 2 * (w - 1) - gx < w && 2 * (w - 1) - gx - 15 >= 0)) {
+                    // a piece entirely beyond the left or the right edge, reflected once: sixteen consecutive pixels in reverse
+                    // order (every edge tile has such pieces; byte by byte they cost ~150 instructions per wavefront)
+                    typedef uint32_t __attribute__((aligned(1))) unaligned_u32;
+                    const unaligned_u32* src = reinterpret_cast<const unaligned_u32*>(rowp + (gx + 15 < 0 ? -gx - 15 : 2 * (w - 1) - gx - 15));
+                    v.w = __builtin_bswap32(src[0]); v.z = __builtin_bswap32(src[1]); v.y = __builtin_bswap32(src[2]); v.x = __builtin_bswap32(src[3]);
+                }
                 else if (BLUR || (gx + 15 >= 0 && gx < w)) {
                     // the frame's edge columns or an unaligned frame: byte by byte, one dword at a time (a rolled loop: this path
                     // must not set the register count of the kernel)
