@@ -36,7 +36,8 @@ __device__ unsigned long long g_orb_clk[32];
 
 // Development only (tools/orb_ablate.py): bit 0 runs the compass arithmetic twice, bit 1 the even-position test, bit 2 the exact
 // score, bit 3 launches the kernel without the blur, bit 4 takes the blur's tap matrices from the lane number instead of
-// memory, bit 5 leaves its stores out -- what a phase costs where it stands.  0 in the product.
+// memory, bit 5 leaves its stores out, bit 10 leaves the 3 x 3 maximum out, bit 12 phases 2a / 2b (empty lists), bit 13 the
+// append of phase 1 -- what a phase costs where it stands.  0 in the product.
 #ifndef MAGE_ORB_ABLATE
 #define MAGE_ORB_ABLATE 0
 #endif
@@ -341,7 +342,8 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
             const int jl = min(max(3 - xs, 0), 8), jh = min(max(min(SCW - 8 * o, w - 3 - xs), 0), 8);
             passbits &= ((1u << jh) - 1u) & ~((1u << jl) - 1u);
         }
-        append8(passbits, 8 * e, cand, NCAND - 1, &n_cand, lane);
+        if (!(MAGE_ORB_ABLATE & 8192)) append8(passbits, 8 * e, cand, NCAND - 1, &n_cand, lane);
+        else if (passbits == 0x5a5a5a5au) n_cand = 1;
     }
     __syncthreads();
     ORB_CLK(1);
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
     // ring mask, three shift-and-and steps; bit-exact, and phase 2b shrinks to the ~3 % that are corners -- but it reads 17 ring
     // bytes per candidate where this test reads 9, and the byte gathers from LDS, not the arithmetic, are what a candidate costs:
     // FAST 1.83 -> 2.02 ms.)
-    const int nc = n_cand;
+    const int nc = (MAGE_ORB_ABLATE & 4096) ? 0 : n_cand;
     for (int c0 = 0; c0 < nc; c0 += 256) {
         const int c = c0 + tid;
         int p = 0, polar = 0;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
     __syncthreads();
     // Phase 2b: exact score of the survivors.  Only a corner is written (the tile of scores starts at zero), and a pixel cannot be a
     // corner in both polarities, so its two entries never write both.
-    const int nc2 = n_cand2;
+    const int nc2 = (MAGE_ORB_ABLATE & 4096) ? 0 : n_cand2;
     for (int c = tid; c < nc2; c += 256) {
         const int pc = cand2[c], p = pc & 0xfff;
         const int ry = p / SCP, rx = p % SCP;
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
     // Phase 3: strict 3x3 maximum among the raw scores + RunByImageBorder, one lane per listed corner (~3 % of the pixels: mostly
     // the first wavefront), its eight neighbours in eight independent byte reads
     {
-        const int ncn = n_corner;
+        const int ncn = (MAGE_ORB_ABLATE & 1024) ? 0 : n_corner;
         for (int c = tid; c < ncn; c += 256) {
             const int p = corners[c];
             const int ry = p / SCP, rx = p % SCP;
