@@ -666,7 +666,7 @@ __global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, doubl
 // ---------------------------------------------------------------------------------------------
 // out[a][b][r] = C - sum_k L(col0.., k) L(row0.., k)^T for the (16 SUB) x (16 SUB) block whose first element is
 // S(row0, col0); D layout: element (row0 + 16 b + (lane & 15), col0 + 16 a + (lane >> 4) + 4 r).
-template <int SUBM, int SUBN, int KSTEPS, bool C_FIRST>
+template <int SUBM, int SUBN, int KSTEPS, bool C_FIRST, int NBUF>
 __device__ __forceinline__ void update_rect(const double* __restrict__ S, int ld, int k, int row0, int col0, int lane, double4_t (&out)[SUBM][SUBN]);
 
 template <int SUB, int KSTEPS>
@@ -720,15 +720,18 @@ __device__ __forceinline__ void update_block(const double* __restrict__ S, int l
 }
 
 // Rectangular form: (16 SUBM) columns x (16 SUBN) rows.  C_FIRST: the accumulators START as the C block (loaded before the first
-// operand chunk; no second register set for C) -- the form for two wavefronts per SIMD, where the registers are what is scarce.
-template <int SUBM, int SUBN, int KSTEPS, bool C_FIRST>
+// operand chunk; no second register set for C); otherwise they start at zero and C is added at the end, loaded behind the last
+// chunk (below) -- also within the 256 registers that two wavefronts per SIMD leave each other.
+template <int SUBM, int SUBN, int KSTEPS, bool C_FIRST, int NBUF>
 __device__ __forceinline__ void update_rect(const double* __restrict__ S, int ld, int k, int row0, int col0, int lane, double4_t (&out)[SUBM][SUBN])
 {
     const double* Pn = S + (size_t)(k * TILE + (lane >> 4)) * ld + row0 + (lane & 15);
     const double* Pm = S + (size_t)(k * TILE + (lane >> 4)) * ld + col0 + (lane & 15);
     const double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
     constexpr int NCH = TILE / (4 * KSTEPS);
-    double av[2][KSTEPS][SUBM], bv[2][KSTEPS][SUBN];
+    // NBUF operand buffers of KSTEPS panel columns x 4: NBUF - 1 chunks are in flight while one is multiplied (the loads return in
+    // order, so the wait before chunk ch leaves the later ones outstanding)
+    double av[NBUF][KSTEPS][SUBM], bv[NBUF][KSTEPS][SUBN];
     auto load_chunk = [&](int buf, int kc) {
 #pragma unroll
         for (int s4 = 0; s4 < KSTEPS; ++s4) {
@@ -739,17 +742,30 @@ __device__ __forceinline__ void update_rect(const double* __restrict__ S, int ld
             for (int q = 0; q < SUBN; ++q) bv[buf][s4][q] = Pn[off + q * 16];
         }
     };
-    load_chunk(0, 0);
+#pragma unroll
+    for (int p = 0; p < NBUF - 1; ++p) load_chunk(p, p * 4 * KSTEPS);
 #pragma unroll
     for (int a = 0; a < SUBM; ++a)
 #pragma unroll
         for (int b = 0; b < SUBN; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[a][b][r] = C_FIRST ? C[(size_t)(a * 16 + 4 * r) * ld + b * 16] : 0.0;
+    double4_t cv[SUBM][SUBN];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        const int buf = ch & 1;
-        if (ch + 1 < NCH) load_chunk(buf ^ 1, (ch + 1) * 4 * KSTEPS);
+        const int buf = ch % NBUF;
+        if (ch + NBUF - 1 < NCH) load_chunk((ch + NBUF - 1) % NBUF, (ch + NBUF - 1) * 4 * KSTEPS);
+        if (!C_FIRST && ch == NCH - 1) {
+            // the C block streams in behind the final chunk's products, into the registers the operand ring no longer needs (there is
+            // no chunk left to prefetch): in front of the first products its latency -- C comes from memory, once per launch, while the
+            // operands come from L2 -- was exposed in every task (2.72 -> 2.62 ms per factorisation at 6016)
+#pragma unroll
+            for (int a = 0; a < SUBM; ++a)
+#pragma unroll
+                for (int b = 0; b < SUBN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cv[a][b][r] = C[(size_t)(a * 16 + 4 * r) * ld + b * 16];
+        }
 #pragma unroll
         for (int s4 = 0; s4 < KSTEPS; ++s4)
 #pragma unroll
@@ -757,6 +773,12 @@ __device__ __forceinline__ void update_rect(const double* __restrict__ S, int ld
 #pragma unroll
                 for (int b = 0; b < SUBN; ++b)
                     out[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[buf][s4][a], bv[buf][s4][b], out[a][b], 0, 0, 0);
+    }
+    if (!C_FIRST) {
+#pragma unroll
+        for (int a = 0; a < SUBM; ++a)
+#pragma unroll
+            for (int b = 0; b < SUBN; ++b) out[a][b] = cv[a][b] + out[a][b];
     }
 }
 
@@ -767,6 +789,13 @@ __device__ __forceinline__ void update_rect(const double* __restrict__ S, int ld
 // instead of once per wavefront -- a 64 x 32 wavefront tile needs 0.19 operand bytes per flop from L2, which two wavefronts per SIMD
 // on 256 compute units cannot be fed; through LDS it is 0.094 from L2.  LDS: 2 buffers x 16 x 208 doubles (pitch 208: the four
 // k rows of a fragment read land on alternating bank halves) = 52 KB of the 78 KB every workgroup of the launch owns anyway.
+// operand pipeline of the half-tile update (update_rect): panel columns per chunk / 4, and chunks in the ring
+#ifndef CHOL_RECT_KSTEPS
+#define CHOL_RECT_KSTEPS 4
+#endif
+#ifndef CHOL_RECT_NBUF
+#define CHOL_RECT_NBUF 2
+#endif
 constexpr int ST_KC = 16, ST_PITCH = 208;
 // piece u of a thread: panel column kk = e / 96 of the chunk, 128-bit piece w = e % 96 of its 192 operand rows (e = 256 u + tid)
 __device__ __forceinline__ const double2* st_src(const double* __restrict__ Pn, const double* __restrict__ Pm, int ld, int ch, int tid, int u)
@@ -1141,7 +1170,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
         if (rt == ct && (q & 1) && (wave & 1) == 0) return;      // diagonal tile: rows 0-63 of columns 64-127 lie above the diagonal
         const int row0 = (j0 + rt) * TILE + (wave & 1) * 64, col0 = (j0 + ct) * TILE + (q & 1) * 64 + (wave >> 1) * 32;
         double4_t out[2][4];
-        update_rect<2, 4, 4, true>(S, ld, k, row0, col0, lane, out);
+        update_rect<2, 4, CHOL_RECT_KSTEPS, false, CHOL_RECT_NBUF>(S, ld, k, row0, col0, lane, out);
         double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
