@@ -912,7 +912,20 @@ __device__ __forceinline__ void m3mul(const double A[9], const double B[9], doub
         for (int c = 0; c < 3; ++c) C[r * 3 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c];
 }
 
-// Eigen matrix -> quaternion
+// Eigen matrix -> quaternion.  (The branch for a non-positive trace picks the largest diagonal element at run time; it is written
+// out once per choice with constant indices -- indexed by a run-time i the matrix went to scratch memory in every caller.)
+template <int I>
+__device__ __forceinline__ void R_to_q_branch(const double m[9], double c[4])
+{
+    constexpr int J = (I + 1) % 3, K = (J + 1) % 3;
+    double t = sqrt(m[I * 4] - m[J * 4] - m[K * 4] + 1.0);
+    const double ci = 0.5 * t;
+    t = 0.5 / t;
+    c[3] = (m[K * 3 + J] - m[J * 3 + K]) * t;
+    c[I] = ci;
+    c[J] = (m[J * 3 + I] + m[I * 3 + J]) * t;
+    c[K] = (m[K * 3 + I] + m[I * 3 + K]) * t;
+}
 __device__ __forceinline__ void R_to_q(const double m[9], double c[4])
 {
     double t = m[0] + m[4] + m[8];
@@ -924,18 +937,10 @@ __device__ __forceinline__ void R_to_q(const double m[9], double c[4])
     } else {
         int i = 0;
         if (m[4] > m[0]) i = 1;
-        if (m[8] > m[i * 4]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(m[i * 4] - m[j * 4] - m[k * 4] + 1.0);
-        double ci = 0.5 * t;
-        t = 0.5 / t;
-        double cw = (m[k * 3 + j] - m[j * 3 + k]) * t;
-        double cj = (m[j * 3 + i] + m[i * 3 + j]) * t;
-        double ck = (m[k * 3 + i] + m[i * 3 + k]) * t;
-        c[3] = cw;
-        c[0] = i == 0 ? ci : (j == 0 ? cj : ck);
-        c[1] = i == 1 ? ci : (j == 1 ? cj : ck);
-        c[2] = i == 2 ? ci : (j == 2 ? cj : ck);
+        if (m[8] > (i == 1 ? m[4] : m[0])) i = 2;
+        if (i == 0) R_to_q_branch<0>(m, c);
+        else if (i == 1) R_to_q_branch<1>(m, c);
+        else R_to_q_branch<2>(m, c);
     }
 }
 

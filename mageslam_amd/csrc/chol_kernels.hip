@@ -1294,8 +1294,11 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
 // substitutions in LDS with the 16x16 block inverses.  The chain of launches of the large-system path (potrf + solve + backward
 // solve, ~40 us for any n <= 128) becomes ~3 us per 16 columns.
 // ---------------------------------------------------------------------------------------------
+// (INV_IN_LDS is a template parameter, not an argument: chosen at run time, `Linv` would be a generic pointer and every read of a
+// block inverse in the substitutions a flat load)
+template <bool INV_IN_LDS>
 __global__ __launch_bounds__(256) void k_small_solve(const double* __restrict__ S, const double* __restrict__ y, double* __restrict__ x, int n, int ld,
-                                                     double* __restrict__ Linv_ws, double* __restrict__ ok, double* __restrict__ stall, int inv_in_lds)
+                                                     double* __restrict__ Linv_ws, double* __restrict__ ok, double* __restrict__ stall)
 {
     extern __shared__ double sm[];
     const int tid = threadIdx.x;
@@ -1304,14 +1307,17 @@ __global__ __launch_bounds__(256) void k_small_solve(const double* __restrict__ 
     // all block inverses, so that the substitutions never leave LDS (from the global workspace every block step paid an L2 round trip)
     double* A = sm;
     double* Li = sm + np * LDC;
-    double* Linv = inv_in_lds ? Li + 2 * NB * NB : Linv_ws;
+    double* const Linv = INV_IN_LDS ? Li + 2 * NB * NB : Linv_ws;
     __shared__ double rhs[TILE], xc[NB];
     {   // column-major copy, two doubles per load (np is a multiple of 16), eight loads in flight per thread
         const int half = np / 2, total = np * half;
         for (int e0 = tid; e0 < total; e0 += 256 * 8) {
             double2 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < total) { const int c = e / half, r2 = e - c * half; v[u] = *reinterpret_cast<const double2*>(S + (size_t)c * ld + 2 * r2); } }
+            for (int u = 0; u < 8; ++u) {          // (every element assigned on every path: a conditionally initialised array went to scratch memory)
+                const int e = e0 + 256 * u, ec = e < total ? e : 0, c = ec / half, r2 = ec - c * half;
+                v[u] = *reinterpret_cast<const double2*>(S + (size_t)c * ld + 2 * r2);
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < total) { const int c = e / half, r2 = e - c * half; *reinterpret_cast<double2*>(A + c * LDC + 2 * r2) = v[u]; } }
         }
@@ -1400,7 +1406,8 @@ void chol_init_device()
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bsolve_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_panel);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
 }
 
 void chol_small_solve(const double* S, const double* y, double* x, int n, int ld, double* Linv_ws, double* ok, double* stall, hipStream_t st)
@@ -1409,7 +1416,8 @@ void chol_small_solve(const double* S, const double* y, double* x, int n, int ld
     const size_t with_inv = ((size_t)np * LDC + 2 * NB * NB + (size_t)nblk * NB * NB) * sizeof(double);
     const bool inv_in_lds = with_inv + 4096 <= 160 * 1024;          // + the kernel's static LDS
     const size_t lds = inv_in_lds ? with_inv : ((size_t)np * LDC + 2 * NB * NB) * sizeof(double);
-    hipLaunchKernelGGL(k_small_solve, dim3(1), dim3(256), lds, st, S, y, x, n, ld, Linv_ws, ok, stall, inv_in_lds ? 1 : 0);
+    if (inv_in_lds) hipLaunchKernelGGL(k_small_solve<true>, dim3(1), dim3(256), lds, st, S, y, x, n, ld, Linv_ws, ok, stall);
+    else hipLaunchKernelGGL(k_small_solve<false>, dim3(1), dim3(256), lds, st, S, y, x, n, ld, Linv_ws, ok, stall);
 }
 
 // Right-looking factorisation.  Step k = one k_trsm_panel launch + one k_syrk_update launch; the diagonal
