@@ -494,13 +494,16 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int 
 // the rhs row y_k (a strip with one live row).
 // inv_out != nullptr: the strip is rows 16 strip .. of the IDENTITY and the result, rows of L_kk^-T, goes to inv_out (element
 // (row, col) at inv_out[col * inv_pitch + row]; the backward solve builds the tile's inverse this way, in LDS).
+// (INVERSE is a template parameter so that the destination is an LDS pointer in one instantiation and a global one in the other: as
+// a run-time choice it was a generic pointer, flat loads and stores)
+template <bool INVERSE = false>
 __device__ __forceinline__ void trsm_strip(double* __restrict__ S, double* __restrict__ y, int ld, int k, int strip, bool is_rhs,
                                            const double* __restrict__ Linv_k, int lane, double* inv_out = nullptr, int inv_pitch = 0)
 {
     double* base;          // element (n = strip row, col) lives at base[col * cstride]; for the rhs strip only n == 0 exists
     size_t cstride;
     bool live;
-    if (inv_out) {
+    if (INVERSE) {
         base = inv_out + strip * NB + (lane & 15);
         cstride = (size_t)inv_pitch;
         live = true;
@@ -518,7 +521,7 @@ __device__ __forceinline__ void trsm_strip(double* __restrict__ S, double* __res
     for (int c = 0; c < NBLK; ++c)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            Acc[c][r] = inv_out ? ((strip * NB + (lane & 15)) == (c * NB + (lane >> 4) + 4 * r) ? 1.0 : 0.0)
+            Acc[c][r] = INVERSE ? ((strip * NB + (lane & 15)) == (c * NB + (lane >> 4) + 4 * r) ? 1.0 : 0.0)
                                 : live ? base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] : 0.0;
     // operand (row = 16c + (lane&15), col = 16j + 4r + (lane>>4)) of L_kk
     const double* Lop = S + (size_t)(k * TILE + (lane >> 4)) * ld + (size_t)k * TILE + (lane & 15);
@@ -1212,8 +1215,8 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
     if (tid < TILE) ys[tid] = y[(size_t)j * TILE + tid];
     // The tile's inverse by the panel solve's strip code on the rows of the identity (two strips per wavefront, ~10 us, while every
     // column but the last two is waiting anyway): the end of a hop is then one product from registers, not eight substitution steps.
-    trsm_strip(const_cast<double*>(S), nullptr, ld, j, wave, false, Linv + (size_t)j * NBLK * NB * NB, lane, T, LDB);
-    trsm_strip(const_cast<double*>(S), nullptr, ld, j, wave + 4, false, Linv + (size_t)j * NBLK * NB * NB, lane, T, LDB);
+    trsm_strip<true>(const_cast<double*>(S), nullptr, ld, j, wave, false, Linv + (size_t)j * NBLK * NB * NB, lane, T, LDB);
+    trsm_strip<true>(const_cast<double*>(S), nullptr, ld, j, wave + 4, false, Linv + (size_t)j * NBLK * NB * NB, lane, T, LDB);
     __syncthreads();
     // thread (c, half) owns rows half * 64 .. +63 of column c of the current off-diagonal tile, and columns half * 64 .. of row c of the inverse
     const int c = tid >> 1, half = tid & 1;
