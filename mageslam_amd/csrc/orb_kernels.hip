@@ -731,7 +731,23 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
         minCellDelta2 = m * m;
     }
     const bool narrow_box = (maxX - minX) < numX || (maxY - minY) < numY;
-    auto cell_of = [&](int pos) { return ((pos >> 16) - minY) * numY / (maxY + 1 - minY) * numX + ((pos & 0xffff) - minX) * numX / (maxX + 1 - minX); };
+    // Division by the bounding box's extents (uniform per frame, non-negative dividends below 2^31): multiply-high by a magic number
+    // made once -- the compiler's general 32-bit division is ~40 vector instructions, and every candidate is divided six times.
+    // q = floor(n / d) exactly for 0 <= n < 2^31: M = floor(2^32 (2^s - d) / d) + 1 with s = ceil(log2 d), t = mulhi(n, M), q = (t + ((n - t) >> 1)) >> (s - 1)
+    struct UDiv { unsigned M; int s; };
+    auto make_udiv = [](unsigned d) -> UDiv {
+        int sft = 0;
+        while ((1u << sft) < d) ++sft;                 // d >= 1
+        const unsigned long long M = (((1ull << sft) - d) << 32) / d + 1ull;
+        return UDiv{ (unsigned)M, sft };
+    };
+    auto udiv = [](unsigned n, const UDiv& D) -> int {
+        if (D.s == 0) return (int)n;                    // d == 1
+        const unsigned t = __umulhi(n, D.M);
+        return (int)((t + ((n - t) >> 1)) >> (D.s - 1));
+    };
+    const UDiv divX = make_udiv((unsigned)(maxX + 1 - minX)), divY = make_udiv((unsigned)(maxY + 1 - minY));
+    auto cell_of = [&](int pos) { return udiv((unsigned)(((pos >> 16) - minY) * numY), divY) * numX + udiv((unsigned)(((pos & 0xffff) - minX) * numX), divX); };
     // The working set (candidates in cell order, cell starts, keys) lives in LDS whenever it fits; oversized inputs run the same
     // code on the per-frame scratch in HBM.
     const bool in_lds = M <= SEL_CAP && a.ncells <= SEL_CELLS;
@@ -770,7 +786,7 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
         for (int i = tid; i < M; i += SEL_T) {
             const unsigned long long me = cand[i];
             const int pos = (int)(unsigned)me, x = pos & 0xffff, y = pos >> 16;
-            const int cx = (x - minX) * numX / (maxX + 1 - minX), cy = (y - minY) * numY / (maxY + 1 - minY);
+            const int cx = udiv((unsigned)((x - minX) * numX), divX), cy = udiv((unsigned)((y - minY) * numY), divY);
             const float s = (float)(int)(me >> 32) * rf + 0.002f;               // response >= 0 always (FAST score); no FMA: contraction is off in this kernel
             int minR2 = globalMaxR2;
             auto ring_max = [&](int r2) { return r2 <= 0 ? -1 : 1 + isqrt_floor((r2 - 1) / minCellDelta2); };   // largest d with max(0, d - 1)^2 * minCellDelta2 < r2
