@@ -50,13 +50,22 @@ def run_one(bits):
     det.enable_profile(True)
     nf = 2048
     imgs = torch.from_numpy(allf[np.arange(nf) % 16]).cuda().contiguous()
-    ms = []
+    ms, sel, brief = [], [], []
     for i in range(int(os.environ.get("ORB_ABLATE_REPS", "8"))):
         det.detect_batch_device(imgs.data_ptr(), nf, 640, 480, 440)
         torch.cuda.synchronize()
         if i >= 2:
-            ms.append(det.profile().fast_ms)
-    print(json.dumps({"ablate": bits, "fast_ms_median": float(np.median(ms)), "fast_ms_min": float(min(ms))}))
+            p = det.profile()
+            ms.append(p.fast_ms); sel.append(p.select_ms); brief.append(p.brief_ms)
+    one = []
+    img1 = imgs[:1].contiguous()
+    for i in range(60):
+        det.detect_batch_device(img1.data_ptr(), 1, 640, 480, 440)
+        torch.cuda.synchronize()
+        if i >= 10:
+            one.append(det.profile().select_ms)
+    print(json.dumps({"ablate": bits, "fast_ms_median": float(np.median(ms)), "fast_ms_min": float(min(ms)), "select_ms_median": float(np.median(sel)),
+                      "brief_ms_median": float(np.median(brief)), "select_one_frame_us_median": 1e3 * float(np.median(one))}))
 
 
 def main():
