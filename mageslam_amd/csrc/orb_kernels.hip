@@ -540,10 +540,16 @@ constexpr int SEL_CAP = 2048, SEL_CELLS = 1024; // LDS working set: candidates a
 constexpr int SEL_REG = 4;                      // list entries a thread keeps in registers (4096 per frame; more are re-read from HBM)
 constexpr int SEL_HCOPIES = 16;                 // interleaved copies of the response histogram (same-bin lanes spread over banks)
 
-__device__ __forceinline__ int wave_scan_incl(int v, int lane)
+// inclusive prefix sum along the wavefront: four row_shr steps inside each row of 16 lanes, then the row totals through
+// row_bcast:15 / row_bcast:31 (six v_add_u32_dpp; the shuffle form was six LDS-crossbar round trips)
+__device__ __forceinline__ int wave_scan_incl(int v, int)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
     return v;
 }
 
