@@ -134,6 +134,21 @@ MFMA_KERNEL(k_mfma_i8_32, c0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, a, c0, 0
 MFMA_KERNEL(k_mfma_i8_64, c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(b4, b4, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(b4, b4, c1, 0, 0, 0); c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(b4, b4, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(b4, b4, c3, 0, 0, 0);, 4)
 MFMA_KERNEL(k_mfma_i8_32_dep, c0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, a, c0, 0, 0, 0); c0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, a, c0, 0, 0, 0); c0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, a, c0, 0, 0, 0); c0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, a, c0, 0, 0, 0);, 4)
 
+#define KERNEL64(name, STR)                                                                                                   \
+    __global__ void name(long long* out, unsigned* sink)                                                                       \
+    {                                                                                                                          \
+        unsigned long long a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, b = 0x0102030405060708ull + threadIdx.x; unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0; \
+        __syncthreads();                                                                                                       \
+        const long long t0 = clock64();                                                                                        \
+        REP64(asm volatile(STR : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b) : "vcc");) \
+        const long long t1 = clock64();                                                                                        \
+        if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = (t1 - t0);                                                        \
+        sink[threadIdx.x] = c0 + c1 + c2 + c3;                                                                                 \
+    }
+// four compares (vcc) per asm block, each followed by an add-with-carry into its own counter: 8 instructions per block
+KERNEL64(k_cmp_u64, "v_cmp_gt_u64 vcc, %4, %8\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n v_cmp_gt_u64 vcc, %5, %8\n v_addc_co_u32 %1, vcc, 0, %1, vcc\n v_cmp_gt_u64 vcc, %6, %8\n v_addc_co_u32 %2, vcc, 0, %2, vcc\n v_cmp_gt_u64 vcc, %7, %8\n v_addc_co_u32 %3, vcc, 0, %3, vcc")
+KERNEL64(k_cmp_f64, "v_cmp_gt_f64 vcc, %4, %8\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n v_cmp_gt_f64 vcc, %5, %8\n v_addc_co_u32 %1, vcc, 0, %1, vcc\n v_cmp_gt_f64 vcc, %6, %8\n v_addc_co_u32 %2, vcc, 0, %2, vcc\n v_cmp_gt_f64 vcc, %7, %8\n v_addc_co_u32 %3, vcc, 0, %3, vcc")
+
 struct Entry { const char* name; void (*fn)(long long*, unsigned*); };
 
 int main()
@@ -158,6 +173,7 @@ int main()
         { "PAIR v_cmp vcc + v_cndmask vcc (per pair)", k_pair_vcc }, { "PAIR v_cmp_e64 sgpr + v_cndmask_e64 (per pair)", k_pair_sgpr }, { "v_cmp_gt_i32_e64 sgpr", k_cmp_e64 },
         { "v_add_co_u32 vcc", k_add_co }, { "v_addc_co_u32 vcc", k_addc_co }, { "v_and_b32 literal", k_and_lit }, { "v_sub_u32 literal", k_sub_lit }, 
         { "v_lshlrev_b16", k_lshl_b16 }, { "v_lshrrev_b16", k_lshr_b16 }, { "v_pk_lshrrev_b16", k_pk_lshr_b16 }, { "v_mul_lo_u16", k_mul_lo_u16 }, { "v_mad_u16", k_mad_u16 }, { "v_cvt_pk_u8_f32", k_cvt_pk_u8 }, { "v_readlane_b32", k_readlane },
+        { "PAIR v_cmp_gt_u64 + v_addc (per pair)", k_cmp_u64 }, { "PAIR v_cmp_gt_f64 + v_addc (per pair)", k_cmp_f64 },
         { "v_mfma_i32_16x16x32_i8", k_mfma_i8_32 }, { "v_mfma_i32_16x16x64_i8", k_mfma_i8_64 }, { "v_mfma_i32_16x16x32_i8 dependent", k_mfma_i8_32_dep },
     };
     printf("%-24s %8s %8s %8s   (cycles per wave-instruction per SIMD at 1 / 2 / 4 wavefronts per SIMD)\n", "instruction", "1", "2", "4");
