@@ -149,6 +149,25 @@ MFMA_KERNEL(k_mfma_i8_32_dep, c0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, a, c
 KERNEL64(k_cmp_u64, "v_cmp_gt_u64 vcc, %4, %8\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n v_cmp_gt_u64 vcc, %5, %8\n v_addc_co_u32 %1, vcc, 0, %1, vcc\n v_cmp_gt_u64 vcc, %6, %8\n v_addc_co_u32 %2, vcc, 0, %2, vcc\n v_cmp_gt_u64 vcc, %7, %8\n v_addc_co_u32 %3, vcc, 0, %3, vcc")
 KERNEL64(k_cmp_f64, "v_cmp_gt_f64 vcc, %4, %8\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n v_cmp_gt_f64 vcc, %5, %8\n v_addc_co_u32 %1, vcc, 0, %1, vcc\n v_cmp_gt_f64 vcc, %6, %8\n v_addc_co_u32 %2, vcc, 0, %2, vcc\n v_cmp_gt_f64 vcc, %7, %8\n v_addc_co_u32 %3, vcc, 0, %3, vcc")
 
+#define KERNEL64D(name, STR)                                                                                                  \
+    __global__ void name(long long* out, unsigned* sink)                                                                       \
+    {                                                                                                                          \
+        unsigned long long a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, a4 = 4, a5 = 5, a6 = 6, a7 = 7; unsigned b = 12345u + threadIdx.x, c = 77u; \
+        __syncthreads();                                                                                                       \
+        const long long t0 = clock64();                                                                                        \
+        REP64(asm volatile(STR : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");) \
+        const long long t1 = clock64();                                                                                        \
+        if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = (t1 - t0);                                                        \
+        sink[threadIdx.x] = (unsigned)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);                                                 \
+    }
+KERNEL64D(k_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7")
+KERNEL64D(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 3, %1\n v_lshl_add_u64 %1, %1, 3, %2\n v_lshl_add_u64 %2, %2, 3, %3\n v_lshl_add_u64 %3, %3, 3, %4\n v_lshl_add_u64 %4, %4, 3, %5\n v_lshl_add_u64 %5, %5, 3, %6\n v_lshl_add_u64 %6, %6, 3, %7\n v_lshl_add_u64 %7, %7, 3, %0")
+KERNEL64D(k_lshlrev_b64, "v_lshlrev_b64 %0, 3, %0\n v_lshlrev_b64 %1, 3, %1\n v_lshlrev_b64 %2, 3, %2\n v_lshlrev_b64 %3, 3, %3\n v_lshlrev_b64 %4, 3, %4\n v_lshlrev_b64 %5, 3, %5\n v_lshlrev_b64 %6, 3, %6\n v_lshlrev_b64 %7, 3, %7")
+KERNEL64D(k_add_f64, "v_add_f64 %0, %0, %1\n v_add_f64 %1, %1, %2\n v_add_f64 %2, %2, %3\n v_add_f64 %3, %3, %4\n v_add_f64 %4, %4, %5\n v_add_f64 %5, %5, %6\n v_add_f64 %6, %6, %7\n v_add_f64 %7, %7, %0")
+KERNEL64D(k_mul_f64, "v_mul_f64 %0, %0, %1\n v_mul_f64 %1, %1, %2\n v_mul_f64 %2, %2, %3\n v_mul_f64 %3, %3, %4\n v_mul_f64 %4, %4, %5\n v_mul_f64 %5, %5, %6\n v_mul_f64 %6, %6, %7\n v_mul_f64 %7, %7, %0")
+KERNEL64D(k_fma_f64, "v_fma_f64 %0, %1, %2, %0\n v_fma_f64 %1, %2, %3, %1\n v_fma_f64 %2, %3, %4, %2\n v_fma_f64 %3, %4, %5, %3\n v_fma_f64 %4, %5, %6, %4\n v_fma_f64 %5, %6, %7, %5\n v_fma_f64 %6, %7, %0, %6\n v_fma_f64 %7, %0, %1, %7")
+KERNEL64D(k_mov_b64, "v_mov_b64 %0, %1\n v_mov_b64 %1, %2\n v_mov_b64 %2, %3\n v_mov_b64 %3, %4\n v_mov_b64 %4, %5\n v_mov_b64 %5, %6\n v_mov_b64 %6, %7\n v_mov_b64 %7, %0")
+
 struct Entry { const char* name; void (*fn)(long long*, unsigned*); };
 
 int main()
@@ -173,6 +192,7 @@ int main()
         { "PAIR v_cmp vcc + v_cndmask vcc (per pair)", k_pair_vcc }, { "PAIR v_cmp_e64 sgpr + v_cndmask_e64 (per pair)", k_pair_sgpr }, { "v_cmp_gt_i32_e64 sgpr", k_cmp_e64 },
         { "v_add_co_u32 vcc", k_add_co }, { "v_addc_co_u32 vcc", k_addc_co }, { "v_and_b32 literal", k_and_lit }, { "v_sub_u32 literal", k_sub_lit }, 
         { "v_lshlrev_b16", k_lshl_b16 }, { "v_lshrrev_b16", k_lshr_b16 }, { "v_pk_lshrrev_b16", k_pk_lshr_b16 }, { "v_mul_lo_u16", k_mul_lo_u16 }, { "v_mad_u16", k_mad_u16 }, { "v_cvt_pk_u8_f32", k_cvt_pk_u8 }, { "v_readlane_b32", k_readlane },
+        { "v_mad_u64_u32", k_mad_u64_u32 }, { "v_lshl_add_u64", k_lshl_add_u64 }, { "v_lshlrev_b64", k_lshlrev_b64 }, { "v_add_f64", k_add_f64 }, { "v_mul_f64", k_mul_f64 }, { "v_fma_f64", k_fma_f64 }, { "v_mov_b64", k_mov_b64 },
         { "PAIR v_cmp_gt_u64 + v_addc (per pair)", k_cmp_u64 }, { "PAIR v_cmp_gt_f64 + v_addc (per pair)", k_cmp_f64 },
         { "v_mfma_i32_16x16x32_i8", k_mfma_i8_32 }, { "v_mfma_i32_16x16x64_i8", k_mfma_i8_64 }, { "v_mfma_i32_16x16x32_i8 dependent", k_mfma_i8_32_dep },
     };
