@@ -1161,7 +1161,7 @@ constexpr int SMALL_LPL = 8, SMALL_CPC = 4;
 // cpc = workgroups per camera: SMALL_CPC for the few cameras of a small problem (their quarters are added by the last block), 1 for
 // the large-problem use of the same kernel (ba_fused_linearize: hundreds of cameras, the workgroup writes U and b_c itself);
 // zero_role = 0 drops the S / y zero-fill block (large systems clear S with k_zero_lower).
-__global__ __launch_bounds__(256) void k_small_linearize(BaDeviceView v, double delta, int nbL, int want_maxdiag, int* __restrict__ counter, int cpc,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_small_linearize(BaDeviceView v, double delta, int nbL, int want_maxdiag, int* __restrict__ counter, int cpc,
                                                          int zero_role)
 {
     __shared__ double sm[4];
