@@ -328,7 +328,10 @@ constexpr int LPUB_BLOCKS = NBLK * (NBLK - 1) / 2;            // 28 sub-diagonal
 constexpr int LPUB_TILE_DOUBLES = LPUB_BLOCKS * NB * NB;      // 7168
 struct TilePublish { double* Lpub; };                         // this tile's scratch blocks (nullptr: not publishing)
 
-template <bool PARTIAL, class LAY, bool PUBLISH = false>
+// PUBLISH: 0 plain stores of the block inverses (a kernel boundary or a release fence follows); 1 the block inverses written THROUGH
+// (agent-scope stores: the write-through hand-off of k_syrk_update<1, true>, no release fence follows); 2 also the sub-diagonal blocks
+// (the pipelined strips described above).
+template <bool PARTIAL, class LAY, int PUBLISH = 0>
 __device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __restrict__ Li, double* __restrict__ Linv_k, int tid, int nblk = NBLK,
                                             TilePublish pub = TilePublish{ nullptr })
 {
@@ -348,7 +351,7 @@ __device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __re
                 *reinterpret_cast<double4_t*>(Linv_k + s * NB * NB + lane * 4) = v;
             }
         }
-        if (PUBLISH && wave >= 1 && s > 0) {       // block column s - 1 is final: its blocks below the diagonal go out, dealt over wavefronts 1-3
+        if (PUBLISH == 2 && wave >= 1 && s > 0) {       // block column s - 1 is final: its blocks below the diagonal go out, dealt over wavefronts 1-3
             for (int i = s + wave - 1; i < NBK; i += 3) {
                 const double* Bl = A + LAY::blk(i, s - 1);
                 double* G = pub.Lpub + (size_t)(i * (i - 1) / 2 + (s - 1)) * NB * NB;
@@ -455,6 +458,46 @@ __device__ __forceinline__ void store_tile_packed(double* __restrict__ T, const 
         int rb, cb;
         block_of_index(t, rb, cb);
         *reinterpret_cast<double2*>(T + (size_t)(cb * NB + (w >> 3)) * ld + rb * NB + 2 * (w & 7)) = *reinterpret_cast<const double2*>(A + 2 * e);
+    }
+}
+
+// The same two copies for a tile that is HANDED OVER inside a launch (k_syrk_update<1, true>): 128-bit buffer loads / stores with the
+// sc1 bit.  An sc1 store goes through to memory and leaves no dirty line in this XCD's L2, so the producer needs no release fence (a
+// release writes back whatever the XCD's L2 holds dirty -- here the update's freshly written tiles); an sc1 load is not served from
+// this compute unit's L1, so the consumer of sc1-stored data needs no acquire fence (MI355X_MICROARCH.md, "Workgroup dispatch, XCD
+// placement & inter-workgroup visibility").  T must be wave-uniform (it is: kernel arguments and blockIdx only).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_tile_packed_wt(double* __restrict__ dst, const double* __restrict__ T, int ld, int tid)
+{
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(T), 0, (int)((size_t)TILE * ld * sizeof(double)), 0x00020000);
+    constexpr int PIECES = PACKED_TILE_DOUBLES / 2, BATCH = 9;
+#pragma unroll
+    for (int b0 = 0; b0 < PIECES / 256; b0 += BATCH) {
+        u32x4_t v[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e = (b0 + u) * 256 + tid, t = e >> 7, w = e & 127;
+            int rb, cb;
+            block_of_index(t, rb, cb);
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((size_t)(cb * NB + (w >> 3)) * ld + rb * NB + 2 * (w & 7)) * sizeof(double)), 0, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e = (b0 + u) * 256 + tid;
+            *reinterpret_cast<u32x4_t*>(dst + 2 * e) = v[u];
+        }
+    }
+}
+__device__ __forceinline__ void store_tile_packed_wt(double* __restrict__ T, const double* __restrict__ A, int ld, int tid)
+{
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(T, 0, (int)((size_t)TILE * ld * sizeof(double)), 0x00020000);
+#pragma unroll 6
+    for (int b0 = 0; b0 < PACKED_TILE_DOUBLES / 2 / 256; ++b0) {
+        const int e = b0 * 256 + tid, t = e >> 7, w = e & 127;
+        int rb, cb;
+        block_of_index(t, rb, cb);
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4_t*>(A + 2 * e), rsrc,
+                                               (int)(((size_t)(cb * NB + (w >> 3)) * ld + rb * NB + 2 * (w & 7)) * sizeof(double)), 0, 16);
     }
 }
 
@@ -640,6 +683,56 @@ __device__ __forceinline__ void trsm_strip_pipelined(double* __restrict__ S, dou
         }
     }
     if (!ok && lane == 0) *stall = 2.0;
+}
+
+// The same strip for launches in which nobody waits for it (the panel solve merged into the half-tile update, k_syrk_update2<true>):
+// the same operations in the same order as trsm_strip -- bit-identical results -- but a step's operands are fetched when the step
+// comes instead of all up front, so the strip lives within the 256 registers two workgroups per compute unit leave each other
+// (trsm_strip holds 416 operand registers).  Its memory latency, eight dependent fetches instead of one, is hidden behind the update.
+__device__ __forceinline__ void trsm_strip_lean(double* __restrict__ S, double* __restrict__ y, int ld, int k, int strip, bool is_rhs,
+                                                const double* __restrict__ Linv_k, int lane)
+{
+    double* base;
+    size_t cstride;
+    bool live;
+    if (!is_rhs) {
+        base = S + (size_t)(k * TILE) * ld + (size_t)(k + 1) * TILE + strip * NB + (lane & 15);
+        cstride = (size_t)ld;
+        live = true;
+    } else {
+        base = y + (size_t)k * TILE;
+        cstride = 1;
+        live = (lane & 15) == 0;
+    }
+    const double* Lop = S + (size_t)(k * TILE + (lane >> 4)) * ld + (size_t)k * TILE + (lane & 15);
+    const double* Lio = Linv_k + (lane & 15) * NB + (lane >> 4);
+    double4_t Y[NBLK];
+#pragma unroll
+    for (int c = 0; c < NBLK; ++c) {
+        double4_t acc;
+        double lio[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[r] = live ? base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] : 0.0;
+            lio[r] = Lio[c * NB * NB + 4 * r];
+        }
+#pragma unroll
+        for (int j = 0; j < c; ++j) {
+            double lop[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lop[r] = -Lop[(size_t)(j * NB + 4 * r) * ld + c * NB];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lop[r], Y[j][r], acc, 0, 0, 0);
+        }
+        double4_t yc = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yc = __builtin_amdgcn_mfma_f64_16x16x4f64(lio[r], acc[r], yc, 0, 0, 0);
+        Y[c] = yc;
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] = yc[r];
+        }
+    }
 }
 
 __global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
@@ -944,10 +1037,91 @@ __device__ __forceinline__ void wait_for_column(int* __restrict__ flag, int j0, 
     __builtin_amdgcn_wave_barrier();
 }
 
+// The merged strip with the write-through hand-off (k_syrk_update<1, true>; the strip is ON the chain in the columns that use it).
+// What it waits for arrives in two parts, and it no longer waits for both before touching either:
+//   1. its own rows of column j0 -- written by the update's first-column workgroups with plain stores + release + count, complete long
+//      before the tile is factored: poll flag[2], ONE acquire, fetch the rows;
+//   2. L_j0j0 and the block inverses -- written THROUGH by workgroup 0 (sc1 stores, no release fence): poll flag[1], then agent-scope
+//      loads (not served from this compute unit's L1, so no second acquire), all up front as in trsm_strip.
+// Same operations in the same order as trsm_strip: bit-identical.
+__device__ __forceinline__ bool poll_at_least(const int* __restrict__ word, int target, int lane)
+{
+    bool ok = true;
+    if (lane == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+        ok = spins < (1 << 22);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    return ok;
+}
+__device__ __forceinline__ void trsm_strip_wt(double* __restrict__ S, double* __restrict__ y, int ld, int k, int strip, bool is_rhs,
+                                              const double* __restrict__ Linv_k, int* __restrict__ flag, int col_target, double* __restrict__ stall, int lane)
+{
+    double* base;
+    size_t cstride;
+    bool live;
+    if (!is_rhs) {
+        base = S + (size_t)(k * TILE) * ld + (size_t)(k + 1) * TILE + strip * NB + (lane & 15);
+        cstride = (size_t)ld;
+        live = true;
+        if (!poll_at_least(flag + 2, col_target, lane) && lane == 0) *stall = 2.0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        base = y + (size_t)k * TILE;       // this workgroup's own row, just updated
+        cstride = 1;
+        live = (lane & 15) == 0;
+    }
+    double4_t Acc[NBLK];
+#pragma unroll
+    for (int c = 0; c < NBLK; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Acc[c][r] = live ? base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] : 0.0;
+    if (!poll_at_least(flag + 1, k, lane) && lane == 0) *stall = 2.0;
+    const double* Lop = S + (size_t)(k * TILE + (lane >> 4)) * ld + (size_t)k * TILE + (lane & 15);
+    const double* Lio = Linv_k + (lane & 15) * NB + (lane >> 4);
+    double lop[NBLK][NBLK][4], lio[NBLK][4];
+#pragma unroll
+    for (int c = 0; c < NBLK; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lio[c][r] = __hip_atomic_load(Lio + c * NB * NB + 4 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < c; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lop[c][j][r] = -__hip_atomic_load(Lop + (size_t)(j * NB + 4 * r) * ld + c * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    double4_t Y[NBLK];
+#pragma unroll
+    for (int c = 0; c < NBLK; ++c) {
+        double4_t acc = Acc[c];
+#pragma unroll
+        for (int j = 0; j < c; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lop[c][j][r], Y[j][r], acc, 0, 0, 0);
+        double4_t yc = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yc = __builtin_amdgcn_mfma_f64_16x16x4f64(lio[c][r], acc[r], yc, 0, 0, 0);
+        Y[c] = yc;
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] = yc[r];
+        }
+    }
+}
+
+// MERGE is a template parameter (0 no panel solve in the launch, 1 merged strips, 2 pipelined strips): with the three forms in one
+// body the strip roles -- ~420 live registers each -- were allocated against each other and 290 registers went to scratch memory,
+// some of it between the matrix-core operations of the strip that sits on the chain.
+// WT (with MERGE == 1): the write-through form of the two hand-offs that sit on the chain (the split diagonal tile -> workgroup 0, and
+// workgroup 0 -> the strips): sc1 stores and loads instead of release / acquire fences (load_tile_packed_wt above).
+template <int MERGE, bool WT = false>
 __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
-                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int n_q4, int merge, int col_target,
+                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int n_q4, int col_target,
                                                      int dbg, double* __restrict__ Lpub_next)
 {
+    constexpr int merge = MERGE;
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j0 = k + 1, mt = nt - j0;
@@ -959,20 +1133,27 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
         // ---- merged panel solve of tile column j0 (merge != 0): one strip per workgroup (wavefront 0), behind everything it waits for
         if (wave != 0) return;
         dbg_min(dbg, 6);
-        if (merge == 2) {      // pipelined against the factorisation of L_j0j0 (TilePublish): only the first-column tiles must be complete
+        if constexpr (MERGE == 0) return;
+        else if constexpr (MERGE == 2) {      // pipelined against the factorisation of L_j0j0 (TilePublish): only the first-column tiles must be complete
             wait_for_column(flag, 0, col_target, stall, lane);
             dbg_max(dbg, 7);
             trsm_strip_pipelined(S, y, ld, j0, bid - (first_rhs + mt), false, Linv_next, Lpub_next, stall, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_max(dbg, 8);
             return;
+        } else if constexpr (WT) {
+            trsm_strip_wt(S, y, ld, j0, bid - (first_rhs + mt), false, Linv_next, flag, col_target, stall, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg_max(dbg, 8);
+            return;
+        } else {
+            wait_for_column(flag, j0, col_target, stall, lane);
+            dbg_max(dbg, 7);
+            trsm_strip(S, y, ld, j0, bid - (first_rhs + mt), false, Linv_next, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg_max(dbg, 8);
+            return;
         }
-        wait_for_column(flag, j0, col_target, stall, lane);
-        dbg_max(dbg, 7);
-        trsm_strip(S, y, ld, j0, bid - (first_rhs + mt), false, Linv_next, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        dbg_max(dbg, 8);
-        return;
     }
     if (bid >= first_rhs) {
         const int i = k + 1 + (bid - first_rhs);
@@ -985,14 +1166,19 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
             for (int c = 0; c < TILE; ++c) acc = __builtin_fma(Lik[(size_t)c * ld + r], yk[c], acc);
             y[(size_t)i * TILE + r] -= acc;
         }
-        if (merge && i == j0) {
-            // the rhs row of the merged panel solve: y_j0 is this workgroup's own (just updated), L_j0j0 comes from workgroup 0
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (wave != 0) return;
-            if (merge == 2) { trsm_strip_pipelined(S, y, ld, j0, 0, true, Linv_next, Lpub_next, stall, lane); return; }
-            wait_for_column(flag, j0, 0, stall, lane);
-            trsm_strip(S, y, ld, j0, 0, true, Linv_next, lane);
+        if constexpr (MERGE != 0) {
+            if (i == j0) {
+                // the rhs row of the merged panel solve: y_j0 is this workgroup's own (just updated), L_j0j0 comes from workgroup 0
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (wave != 0) return;
+                if constexpr (MERGE == 2) trsm_strip_pipelined(S, y, ld, j0, 0, true, Linv_next, Lpub_next, stall, lane);
+                else if constexpr (WT) trsm_strip_wt(S, y, ld, j0, 0, true, Linv_next, flag, 0, stall, lane);
+                else {
+                    wait_for_column(flag, j0, 0, stall, lane);
+                    trsm_strip(S, y, ld, j0, 0, true, Linv_next, lane);
+                }
+            }
         }
         return;
     }
@@ -1006,46 +1192,61 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
         double4_t out[1][1];
         update_block<1, 32>(S, ld, k, row0, col0, lane, out);
         double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
+        if constexpr (WT) {
+            // written THROUGH (8-byte agent-scope stores: the accumulator layout offers nothing wider): no release fence below
 #pragma unroll
-        for (int r = 0; r < 4; ++r) C[(size_t)(4 * r) * ld] = out[0][0][r];
+            for (int r = 0; r < 4; ++r) __hip_atomic_store(C + (size_t)(4 * r) * ld, out[0][0][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(size_t)(4 * r) * ld] = out[0][0][r];
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (bid != 0) {
-            // publish: all stores of the workgroup done -> agent-scope release -> count
+            // publish: all stores of the workgroup done -> (agent-scope release, unless they went through) -> count
             if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (!WT) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             return;
         }
-        // block 0: wait for the eight others (bounded spin; relaxed polls, one acquire), pull the tile, factor it
+        // block 0: wait for the eight others (bounded spin; relaxed polls, one acquire unless the tile comes through sc1 loads), pull the tile, factor it
         dbg_set(dbg, 1);
         if (tid == 0) {
             int spins = 0;
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NDIAG - 1 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
             if (spins >= (1 << 24)) *stall = 1.0;        // a producer never arrived: reported as a device error (never folded into "not positive definite")
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if constexpr (!WT) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (merge) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // no panel-solve launch follows to reset it
         }
         __syncthreads();
         dbg_set(dbg, 2);
         double* A = sm;
         double* T = S + (size_t)(j0 * TILE) * ld + (size_t)j0 * TILE;
-        load_tile_packed(A, T, ld, tid);
+        if constexpr (WT) load_tile_packed_wt(A, T, ld, tid);
+        else load_tile_packed(A, T, ld, tid);
         __syncthreads();
         dbg_set(dbg, 3);
-        const bool failed = merge == 2 ? potrf_tile_lds<false, LayPacked, true>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid, NBLK, TilePublish{ Lpub_next })
-                                       : potrf_tile_lds<false, LayPacked>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
+        bool failed;
+        if constexpr (MERGE == 2) failed = potrf_tile_lds<false, LayPacked, 2>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid, NBLK, TilePublish{ Lpub_next });
+        else if constexpr (WT) failed = potrf_tile_lds<false, LayPacked, 1>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
+        else failed = potrf_tile_lds<false, LayPacked>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
         dbg_set(dbg, 4);
-        store_tile_packed(T, A, ld, tid);
+        if constexpr (WT) store_tile_packed_wt(T, A, ld, tid);
+        else store_tile_packed(T, A, ld, tid);
         if (tid == 0 && failed) *ok = 0.0;
         if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_set(dbg, 5); }
         if (merge == 1) {      // L_j0j0 and its block inverses are in memory: the strips of this launch may start (pipelined strips need no release: write-through)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if constexpr (!WT) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 __hip_atomic_store(flag + 1, j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -1086,14 +1287,26 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
     if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_max(dbg, ct == 0 ? 10 : 9); }
 }
 
+// MERGED (round 4): the panel solve of tile column j0 = k + 1 rides in THIS launch in the update-bound columns too, so that the
+// ~10 us panel-solve launch between two updates disappears.  What made the first attempt slower (profiles/r02_chol_schedules.md: the
+// strips as the LAST workgroups of the launch, behind the last tiles) is placement: here the first-column tiles (rt, 0) come FIRST in
+// the task order (done after the first round), workgroup 0 has factored tile (j0, j0) ~35-40 us into the launch, and the strip
+// workgroups sit in the MIDDLE of the grid (strip_pos, chosen by the host so that they are dispatched when both are long done and
+// finish well before the last tiles): nobody waits for them and they wait for nobody.  Four strips per workgroup, one per wavefront,
+// in the lean form (trsm_strip_lean: <= 256 registers).  Hand-off as in k_syrk_update<1>: the two halves of a first-column tile and
+// workgroup 0 release and count, a strip polls both counters (bounded), acquires, solves.  Same numbers in the same order as
+// k_trsm_panel: bit-identical.
+template <bool MERGED>
 __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
-                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int unstaged)
+                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int unstaged,
+                                                     int strip_pos, int strip_wgs, int col_target)
 {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j0 = k + 1, mt = nt - j0;
     const int n_tiles = mt * (mt + 1) / 2;
-    const int first_rhs = NDIAG + 16 * ((n_tiles - 1 + 7) / 8);   // tile indices 1 .. n_tiles - 1, two workgroups (column halves) each, in groups of eight tiles
+    const int n_task_wgs = 16 * ((n_tiles - 1 + 7) / 8);          // tile indices 1 .. n_tiles - 1, two workgroups (column halves) each, in groups of eight tiles
+    const int first_rhs = NDIAG + n_task_wgs + (MERGED ? strip_wgs : 0);
     const int bid = blockIdx.x;
     if (bid >= first_rhs) {
         const int i = k + 1 + (bid - first_rhs);
@@ -1105,6 +1318,16 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
 #pragma unroll 8
             for (int c = 0; c < TILE; ++c) acc = __builtin_fma(Lik[(size_t)c * ld + r], yk[c], acc);
             y[(size_t)i * TILE + r] -= acc;
+        }
+        if constexpr (MERGED) {
+            if (i == j0) {
+                // the rhs row of the merged panel solve: y_j0 is this workgroup's own (just updated), L_j0j0 comes from workgroup 0
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (wave != 0) return;
+                wait_for_column(flag, j0, 0, stall, lane);
+                trsm_strip_lean(S, y, ld, j0, 0, true, Linv_next, lane);
+            }
         }
         return;
     }
@@ -1136,6 +1359,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NDIAG - 1 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
             if (spins >= (1 << 24)) *stall = 1.0;        // a producer never arrived: reported as a device error (never folded into "not positive definite")
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (MERGED) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // no panel-solve launch follows to reset it
         }
         __syncthreads();
         double* A = sm;
@@ -1145,7 +1369,31 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
         const bool failed = potrf_tile_lds<false, LayPacked>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
         store_tile_packed(T, A, ld, tid);
         if (tid == 0 && failed) *ok = 0.0;
+        if constexpr (MERGED) {      // L_j0j0 and its block inverses are in memory: the strips of this launch may start
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(flag + 1, j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         return;
+    }
+    int q0 = bid - NDIAG;
+    if constexpr (MERGED) {
+        if (q0 >= strip_pos) {
+            if (q0 < strip_pos + strip_wgs) {
+                // ---- merged panel solve of tile column j0: strip 4 (q0 - strip_pos) + wave
+                const int strip = 4 * (q0 - strip_pos) + wave;
+                if (strip >= (mt - 1) * NBLK) return;
+                wait_for_column(flag, j0, col_target, stall, lane);
+                if (unstaged & 4) return;          // (timing experiment only: the strips' own cost)
+                trsm_strip_lean(S, y, ld, j0, strip, false, Linv_next, lane);
+                return;
+            }
+            q0 -= strip_wgs;
+        }
     }
     // half of a tile: 128 rows x 64 columns, a wavefront 64 x 32, accumulators loaded from C.
     // Which half: workgroups go to the eight XCDs round-robin and every XCD has its own 4 MB L2, while the operands of a launch are
@@ -1155,9 +1403,8 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
     // column by column inside a band): a band's row blocks stay in that L2 while its column blocks stream through once (hit rate 65 %,
     // memory-side reads -27 %) -- measured, and no faster (see chol_factor_solve), so linear order stays the default.  The two halves of
     // a tile are consecutive tasks of one XCD either way.  Placement only: any order gives the same numbers.
-    const int q0 = bid - NDIAG;
     int rt, ct, q;
-    if (unstaged & 2) {
+    if (!MERGED && (unstaged & 2)) {
         const int n_task = 2 * (n_tiles - 1), per = (n_task + 7) / 8;
         q = (q0 & 7) * per + (q0 >> 3);
         if ((q0 >> 3) >= per || q >= n_task) return;
@@ -1167,9 +1414,13 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
         const int tile_i = 8 * (q0 >> 4) + (q0 & 7);
         if (tile_i >= n_tiles - 1) return;
         q = 2 * tile_i + ((q0 >> 3) & 1);
-        tile_of_index(1 + (q >> 1), rt, ct);
+        if constexpr (MERGED) {
+            // the first-column tiles (1, 0) .. (mt - 1, 0) first, then the triangle of the others in linear order
+            if (tile_i < mt - 1) { rt = tile_i + 1; ct = 0; }
+            else { tile_of_index(tile_i - (mt - 1), rt, ct); ++rt; ++ct; }
+        } else tile_of_index(1 + (q >> 1), rt, ct);
     }
-    if (unstaged & 1) {                                           // the default: operands straight from L2 per wavefront
+    if (MERGED || (unstaged & 1)) {                               // the default: operands straight from L2 per wavefront
         if (rt == ct && (q & 1) && (wave & 1) == 0) return;      // diagonal tile: rows 0-63 of columns 64-127 lie above the diagonal
         const int row0 = (j0 + rt) * TILE + (wave & 1) * 64, col0 = (j0 + ct) * TILE + (q & 1) * 64 + (wave >> 1) * 32;
         double4_t out[2][4];
@@ -1181,6 +1432,15 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
             for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = out[a][b][r];
+        if constexpr (MERGED) {
+            if (ct == 0) {
+                if (unstaged & 8) {                // (timing experiment only: the count without the release fence)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_fetch_add(flag + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else publish_column_part(flag, tid);
+            }
+        }
         return;
     }
     update_half_tile_staged(S, ld, k, (j0 + rt) * TILE, (j0 + ct) * TILE + (q & 1) * 64, sm, tid);
@@ -1406,8 +1666,12 @@ void chol_init_device()
     const size_t lds_small = ((size_t)TILE * LDC + 2 * NB * NB) * sizeof(double);
     const size_t lds_panel = (size_t)TILE * (TILE + 2) * sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bsolve_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_panel);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
@@ -1464,8 +1728,33 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
         // reads -27 % (profiles/r03_chol_pmc.txt) -- but the matrix cores are busy 49.7 % of the launch either way and the factorisation
         // takes 2.731 ms against 2.710: the update is not waiting for its operands' misses.  MAGE_CHOL_XCD_BANDS=1 selects it.
         static const bool xcd_bands = std::getenv("MAGE_CHOL_XCD_BANDS") != nullptr;
-        if (bulk2) hipLaunchKernelGGL(k_syrk_update2, dim3(NDIAG + 16 * ((n_tiles - 1 + 7) / 8) + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
-                                      ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, (unstaged ? 1 : 0) | (xcd_bands ? 2 : 0));
+        if (bulk2) {
+            // The panel solve of column k + 1 inside this launch (k_syrk_update2<true>), its strip workgroups in the middle of the grid:
+            // the launch takes ~6 + 21.5 us per 512 half-tile tasks, workgroup 0 has tile (k + 1, k + 1) factored and in memory ~45 us in
+            // (it shares its compute unit here), and a strip workgroup needs ~15 us -- so the strips go where the dispatch stands at
+            // ~48 us, but no later than 20 us before the expected end.  MAGE_CHOL_MERGE2=0 restores the separate panel-solve launch.
+            static const bool merge2_env = std::getenv("MAGE_CHOL_MERGE2") && std::atoi(std::getenv("MAGE_CHOL_MERGE2")) != 0;
+            static const double merge2_at_us = std::getenv("MAGE_CHOL_MERGE2_AT_US") ? std::atof(std::getenv("MAGE_CHOL_MERGE2_AT_US")) : 48.0;
+            static const int merge2_dbg = std::getenv("MAGE_CHOL_MERGE2_DBG") ? (std::atoi(std::getenv("MAGE_CHOL_MERGE2_DBG")) & 12) : 0;   // timing experiments (wrong numbers)
+            const int n_task_wgs = 16 * ((n_tiles - 1 + 7) / 8);
+            const bool merge2 = merge2_env && !merge_off && !pipelined_fill && unstaged && !xcd_bands && m >= 2;
+            if (merge2) {
+                const int strip_wgs = 16 * ((2 * (m - 1) + 15) / 16);
+                const double dur_us = 6.0 + 21.5 * (double)(n_task_wgs + strip_wgs) / 512.0;
+                double f = merge2_at_us / dur_us;
+                const double f_max = 1.0 - 20.0 / dur_us;
+                if (f > f_max) f = f_max;
+                if (f < 0.3) f = 0.3;
+                int strip_pos = 16 * (int)(f * n_task_wgs / 16.0);
+                if (strip_pos > n_task_wgs) strip_pos = n_task_wgs;
+                col_total += 2 * (m - 1);
+                hipLaunchKernelGGL(k_syrk_update2<true>, dim3(NDIAG + n_task_wgs + strip_wgs + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
+                                   ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, 1 | merge2_dbg, strip_pos, strip_wgs, col_total);
+                merged = true;
+            } else
+                hipLaunchKernelGGL(k_syrk_update2<false>, dim3(NDIAG + n_task_wgs + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
+                                   ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, (unstaged ? 1 : 0) | (xcd_bands ? 2 : 0), 0, 0, 0);
+        }
         else {
             merged = !merge_off;
             const int n_whole = n_tiles - 1 - n_q4;
@@ -1476,9 +1765,16 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
             // and their polling takes fabric bandwidth from the factoring workgroup (tile load 1.4 -> 3.6 us): 2.80 ms per factorisation
             // against 2.71.  One release + one acquire per strip and L2-cached reads of the broadcast operand stay.
             static const bool pipelined = std::getenv("MAGE_CHOL_PIPELINED_TRSM") != nullptr;
-            hipLaunchKernelGGL(k_syrk_update, dim3(NDIAG + n_whole + 4 * n_q4 + m + (merged ? (m - 1) * NBLK : 0)), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
-                               ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, n_q4, merged ? (pipelined ? 2 : 1) : 0, col_total,
-                               (ws.dbg && dbg_col == k) ? 1 : 0, ws.Linv + (size_t)nt * linv_stride + (size_t)(k + 1) * LPUB_TILE_DOUBLES);
+            // the write-through form of the chain's two hand-offs (k_syrk_update<1, true>); MAGE_CHOL_WT_HANDOFF=0 restores release / acquire
+            static const bool wt_handoff = !(std::getenv("MAGE_CHOL_WT_HANDOFF") && std::atoi(std::getenv("MAGE_CHOL_WT_HANDOFF")) == 0);
+            const dim3 grid(NDIAG + n_whole + 4 * n_q4 + m + (merged ? (m - 1) * NBLK : 0));
+            const int dbg = (ws.dbg && dbg_col == k) ? 1 : 0;
+            double* const Linv_next = ws.Linv + (size_t)(k + 1) * linv_stride;
+            double* const Lpub_next = ws.Linv + (size_t)nt * linv_stride + (size_t)(k + 1) * LPUB_TILE_DOUBLES;
+            if (!merged) hipLaunchKernelGGL(k_syrk_update<0>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next);
+            else if (pipelined) hipLaunchKernelGGL(k_syrk_update<2>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next);
+            else if (wt_handoff) hipLaunchKernelGGL((k_syrk_update<1, true>), grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next);
+            else hipLaunchKernelGGL(k_syrk_update<1>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next);
         }
         if (!merged) hipLaunchKernelGGL(k_trsm_panel, dim3((m - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, k + 1, nt, ws.Linv + (size_t)(k + 1) * linv_stride, ws.sync, 0);
     }

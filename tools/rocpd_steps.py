@@ -6,9 +6,9 @@ con = sqlite3.connect(sys.argv[1]); cur = con.cursor()
 tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
 kd = next(t for t in tabs if t.startswith("rocpd_kernel_dispatch")); ks = next(t for t in tabs if t.startswith("rocpd_info_kernel_symbol"))
 rows = cur.execute(f"select s.kernel_name, d.start, d.end, d.grid_size_x from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
-rows = [(re.sub(r"\(.*", "", n).split("N_1")[-1][:24], s, e, g) for n, s, e, g in rows]
+rows = [((re.search(r"k_[a-z0-9_]+", n) or re.search(r".*", n)).group(0)[:24], s, e, g) for n, s, e, g in rows]
 last = max(i for i, r in enumerate(rows) if "bsolve" in r[0])
-first = max(i for i, r in enumerate(rows[:last]) if "fill_u64" in r[0])
+first = max(i for i, r in enumerate(rows[:last]) if "potrf_diag" in r[0])       # a factorisation opens with k_potrf_diag
 seg = rows[first:last + 1]
 prev = seg[0][1]
 out = []
