@@ -235,6 +235,11 @@ typedef struct mage_ba_profile {
     uint64_t update_launches;      /* k_backsub + k_pose_update + k_error of the trial state: once per LM trial */
     double   update_ms_total;
     double   update_bytes_each;
+    /* Health of the dense solve's in-launch hand-offs (always counted, profiling on or off).  Both stay 0 in a process that has the
+     * GPU to itself; they move when several PROCESSES oversubscribe one GPU (DESIGN.md "forward progress"): a deployment that sees
+     * them grow is paying for re-run trials and should give each process its own GPU or set MAGE_CHOL_NO_MERGED_TRSM=1. */
+    uint64_t trials_rerun_after_stall;        /* LM trials of THIS handle run again because a bounded wait between workgroups timed out */
+    uint64_t fallback_to_separate_launches;   /* 1 once this PROCESS has switched the panel solve back to its own launches after such a stall */
 } mage_ba_profile;
 /* enable: 0 off; 1 every stage bracketed by event records (seven per LM trial: each costs a few microseconds of idle stream);
  * 2 only the dense factorisation + solves (two per trial) -- what a timed run keeps on.  Enabling resets the sums. */

@@ -36,8 +36,28 @@ def _deps_mtime() -> float:
 EXTRA_FLAGS = {"orb_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
+_flag_ok: dict[tuple, bool] = {}
+
+
+def _accepted(extra: list[str]) -> bool:
+    """An internal LLVM option (-mllvm ...) is a performance hint only: a compiler build that does not know it rejects the whole
+    translation unit, so it is probed once on an empty file and dropped when refused."""
+    key = tuple(extra)
+    if key not in _flag_ok:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "probe.hip")
+            open(src, "w").write("#include <hip/hip_runtime.h>\n__global__ void k() {}\n")
+            r = subprocess.run([HIPCC, "--offload-arch=gfx950", *extra, "-c", src, "-o", os.path.join(d, "probe.o")], capture_output=True)
+            _flag_ok[key] = r.returncode == 0
+        if not _flag_ok[key]:
+            print(f"[build] {' '.join(extra)} not accepted by {HIPCC}: dropped (a performance hint only)", file=sys.stderr)
+    return _flag_ok[key]
+
+
 def flags_for(src: str) -> list[str]:
-    return FLAGS + EXTRA_FLAGS.get(os.path.basename(src), [])
+    extra = EXTRA_FLAGS.get(os.path.basename(src), [])
+    return FLAGS + (extra if not extra or _accepted(extra) else [])
 
 
 def _compile(src: str, force: bool) -> str:

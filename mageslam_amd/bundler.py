@@ -31,7 +31,8 @@ class Profile(C.Structure):
                 ("schur_launches", C.c_uint64), ("schur_ms_total", C.c_double), ("system_order", C.c_int),
                 ("padded_order", C.c_int), ("linearize_launches", C.c_uint64), ("linearize_ms_total", C.c_double),
                 ("linearize_bytes_each", C.c_double), ("schur_bytes_each", C.c_double), ("update_launches", C.c_uint64),
-                ("update_ms_total", C.c_double), ("update_bytes_each", C.c_double)]
+                ("update_ms_total", C.c_double), ("update_bytes_each", C.c_double),
+                ("trials_rerun_after_stall", C.c_uint64), ("fallback_to_separate_launches", C.c_uint64)]
 
 
 _declared = False

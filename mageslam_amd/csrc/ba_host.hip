@@ -278,6 +278,12 @@ struct mage_ba {
     DevBuf<unsigned long long> d_b_bucket, d_b_scan, d_b_row;
     DevBuf<unsigned char> d_b_zeroed;             // [BuildCounts | cam_deg | pt_deg]: cleared by one fill
     bool built_on_device = false;
+    // ---- the tracker's per-frame problems (frame_step below): one image up, one launch, one record back; no structure stays on the device
+    DevBuf<unsigned char> d_frame;
+    void* h_frame = nullptr; size_t h_frame_bytes = 0;     // pinned (from the cache): the image and, behind it, the record that comes back
+    unsigned long long edit_gen = 0;    // bumped by every edit of the graph through the surface (mark_edited)
+    unsigned long long frame_gen = 0;   // edit_gen at the last frame_step
+    bool frame_valid = false;           // the last step was a frame_step: `dirty` then only says "no structure on the device", not "graph edited"
     long long stall_retries_total = 0;  // trials re-run because a bounded hand-off of the dense solve timed out (diagnostic)
     PinnedArena build_arena;            // staging of the last structure build: released at the next completed read-back (no synchronisation of its own)
     void* h_pinned = nullptr; size_t h_pinned_bytes = 0;     // one pinned block (from the cache) holding the mirrors below
@@ -316,6 +322,7 @@ struct mage_ba {
         for (auto& e : ev_p) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_x) if (e) (void)hipEventDestroy(e);
         if (h_pinned) cached_pinned_release(h_pinned, h_pinned_bytes);      // parked, not freed: hipHostFree costs ~200 us
+        if (h_frame) cached_pinned_release(h_frame, h_frame_bytes);
         cached_stream_release(device, stream);
     }
 };
@@ -362,7 +369,7 @@ mage_status download_state(const mage_ba* hc)
     // a polled event: a copy into pageable memory goes through the runtime's own staging and a blocking synchronise (~50 us more
     // on the local-BA problem, where the caller reads the state back after every optimisation, BundleAdjust.cpp:318-347)
     const size_t n_pose = h->cams.size() * 8, n_pts = h->points_fixed ? 0 : h->pt_set.size() * 4;
-    PinnedArena stage;
+    PinnedArena stage((n_pose + n_pts + 2) * sizeof(double) + 1024);     // sized to what comes back, not the build arena's 32 MB blocks
     double *pose = nullptr, *pts = nullptr;
     MAGE_TRY(stage.take(n_pose + 1, &pose)); MAGE_TRY(stage.take(n_pts + 1, &pts));
     if (n_pose) MAGE_HIP(hipMemcpyAsync(pose, h->d_pose[h->cur].p, n_pose * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -384,13 +391,15 @@ mage_status download_state(const mage_ba* hc)
 }
 
 // A setter that arrives after stepping started: pull the estimate back so the host copy is the truth again.
+inline void mark_edited(mage_ba* h) { h->dirty = true; ++h->edit_gen; }
+
 mage_status before_host_edit(mage_ba* h)
 {
     if (h->state_on_device) {
         MAGE_TRY(download_state(h));
         h->state_on_device = false;
     }
-    h->dirty = true;
+    mark_edited(h);
     return MAGE_OK;
 }
 
@@ -825,7 +834,7 @@ mage_status build_lists_device(mage_ba* h, PinnedArena& arena, const std::vector
     a.con = h->d_con.p; a.blk_ptr = h->d_blk_ptr.p; a.blk_ij = h->d_blk_ij.p;
     // the slot -> block table is k_schur_block's (large problems): the small-problem path walks the blocks in order
     // (same predicate as ba_small_applies; a forced build mode is a test comparing every list)
-    const bool small_path = nfc > 0 && nfc * 6 <= 128 && !have_tethers && Z.nL <= (1 << 20) && h->shard_ranks == 0 && std::getenv("MAGE_BA_NO_SMALL_PATH") == nullptr;
+    const bool small_path = h->shard_ranks == 0 && ba_small_shape_applies(nfc, have_tethers ? 1 : 0, Z.nL);      // lm_solve's own predicate (a sharded map never takes the small path)
     const bool want_xcd = !small_path || std::getenv("MAGE_BA_BUILD") != nullptr;
     if (nfc > 0) {
         build_launch_row_fill(a, nfc, want_xcd, st);
@@ -1200,8 +1209,12 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
             // system, and the linearisation it came from is untouched: the trial is simply run again (Schur build, factorisation,
             // update: the same inputs, hence the same bits as an undisturbed run).  Only a repeated stall is an error.
             static const bool log_stalls = std::getenv("MAGE_BA_STALL_LOG") != nullptr;
-            if (log_stalls) std::fprintf(stderr, "[mage_ba] dense solve: wait %d timed out (1 split diagonal tile, 2 merged panel solve, 3 backward solve); trial re-run\n", (int)h->h_scal[SC_CHOL_STALL]);
-            chol_report_stall((int)h->h_scal[SC_CHOL_STALL]);       // a stalled merged panel solve switches this process to separate panel-solve launches
+            // (a landmark-sharded map all-reduces the flag with SUM beside the trial's chi2: the value is then the sum of the ranks' codes and
+            // names no wait any more -- any stall on any rank is treated as the merged panel solve's, the one that has a remedy, on EVERY rank)
+            const int stall_code = h->shard_ranks > 0 ? 2 : (int)h->h_scal[SC_CHOL_STALL];
+            if (log_stalls) std::fprintf(stderr, "[mage_ba] dense solve: wait %d timed out (1 split diagonal tile, 2 merged panel solve, 3 backward solve%s); trial re-run\n", stall_code,
+                                         h->shard_ranks > 0 ? "; sharded map: some rank's wait, reported as 2" : "");
+            chol_report_stall(stall_code);       // a stalled merged panel solve switches this process to separate panel-solve launches
             if (++stall_retries <= 3) { h->stall_retries_total++; again = true; continue; }       // lambda unchanged, qmax not advanced
             return fail(MAGE_ERR_DEVICE, "dense solve: a cross-workgroup hand-off timed out four times in a row (device stalled or oversubscribed); the trial was not evaluated");
         }
@@ -1260,6 +1273,187 @@ mage_status step_optimizer(mage_ba* h, double huber, bool* cont, PostPassPlan* p
     if (first) tm.mark("first LM iteration");
     h->iteration++;
     *cont = (r == LM_OK);
+    return MAGE_OK;
+}
+
+// =================================================================================================
+// The tracker's per-frame problems ("frame path"): BundlerParameters::ArePointsFixed, a handful of cameras, a few hundred
+// observations, ONE StepBundleAdjustment per bundler (Tracking/TrackLocalMap.cpp:421-501 builds, steps once, reads the pose and
+// destroys -- twice per frame).  The general path costs such a call ~40 device allocations from the cache, ~30 small uploads, the
+// launch and two read-backs (0.2 ms where one CPU core needs 0.04).  Here the whole problem is ONE image built in pinned memory in
+// the layout k_pose_lm reads (the lists in the order build_lists_host gives them: same sums, same bits), ONE upload, ONE launch
+// (every LM iteration with its trials and the outlier pass: ba_kernels.hip "POSE-ONLY problems"), ONE record back that also carries
+// both pose buffers -- GetPose then reads the host copy.  Nothing stays on the device: the estimate lives on the host afterwards
+// (state_on_device = false), `dirty` stays set for the general path, and whether the GRAPH was edited since is edit_gen vs
+// frame_gen (the LM state -- iteration, lambda, ni -- carries over exactly as StepOptimizer's does, BundlerLib.cpp:132-149).
+// MAGE_BA_NO_FRAME_PATH=1 (or MAGE_BA_BUILD=host|device, which the structure tests set) sends these problems down the general path.
+// =================================================================================================
+bool frame_path_enabled()
+{
+    static const bool on = std::getenv("MAGE_BA_NO_FRAME_PATH") == nullptr && std::getenv("MAGE_BA_BUILD") == nullptr && std::getenv("MAGE_BA_NO_SMALL_PATH") == nullptr;
+    return on;
+}
+
+bool frame_applies(const mage_ba* h, size_t n_iter)
+{
+    if (!frame_path_enabled() || !h->points_fixed || h->shard_ranks > 0 || h->state_on_device || !h->dirty) return false;
+    if (n_iter < 1 || n_iter > (size_t)POSE_LM_MAX_ITERS || h->profiling || h->profiling_factor) return false;
+    if (h->cams.empty() || h->cams.size() > 64 || h->obs.size() > 16384 || h->obs.size() == 0 || h->pt_set.size() > 16384) return false;
+    for (int k = 0; k < 3; ++k) if (!h->teth[k].empty()) return false;
+    return true;
+}
+
+// `*taken` = false: the problem has no free camera with an active observation (the general path knows what to return then)
+mage_status frame_step(mage_ba* h, const float* huber, size_t n_iter, float max_err_sq, bool* taken, double* err_sum, double* err_cnt, size_t* n_out)
+{
+    *taken = false;
+    ensure_obs_filled(h);
+    const int nc = (int)h->cams.size(), np = (int)h->pt_set.size();
+    const size_t no = h->obs.size();
+    // ---- the lists, in build_lists_host's order: active observations by landmark (point index ascending), inside a landmark free
+    // cameras ascending (ties: observation index) and fixed cameras last; a camera's observations in ascending observation index
+    std::vector<uint32_t> active;
+    active.reserve(no);
+    std::vector<int> cam_deg(nc, 0), pt_deg(np, 0);
+    for (size_t e = 0; e < no; ++e) {
+        const HostObs& o = h->obs[e];
+        if (!o.set || o.removed || h->cams[o.cam].fixed) continue;     // points are fixed: an observation of a fixed camera is not an edge of the problem
+        active.push_back((uint32_t)e);
+        cam_deg[o.cam]++; pt_deg[o.pt]++;
+    }
+    const int nL = (int)active.size();
+    std::vector<int> hc2cam, cam2hc(nc, -1);
+    for (int i = 0; i < nc; ++i)
+        if (cam_deg[i] > 0 && !h->cams[i].fixed) { cam2hc[i] = (int)hc2cam.size(); hc2cam.push_back(i); }
+    const int nfc = (int)hc2cam.size();
+    if (nL == 0 || nfc == 0) return MAGE_OK;
+    std::vector<int> lm_ptr(np + 1, 0);
+    for (int a = 0; a < nL; ++a) lm_ptr[h->obs[active[a]].pt + 1]++;
+    for (int l = 0; l < np; ++l) lm_ptr[l + 1] += lm_ptr[l];
+    std::vector<uint32_t> L_edge(nL);
+    {
+        std::vector<int> fill(lm_ptr.begin(), lm_ptr.end() - 1);
+        for (int a = 0; a < nL; ++a) L_edge[fill[h->obs[active[a]].pt]++] = active[a];
+    }
+    for (int l = 0; l < np; ++l) {
+        const int b = lm_ptr[l], k = lm_ptr[l + 1] - b;
+        if (k > 1) std::sort(L_edge.begin() + b, L_edge.begin() + b + k, [&](uint32_t x, uint32_t y) {
+            const int hx = cam2hc[h->obs[x].cam], hy = cam2hc[h->obs[y].cam];
+            return hx != hy ? hx < hy : x < y;
+        });
+    }
+    std::vector<int> where(no, -1), camE_ptr(nfc + 1, 0);
+    for (int i = 0; i < nL; ++i) where[L_edge[i]] = i;
+    for (int a = 0; a < nL; ++a) camE_ptr[cam2hc[h->obs[active[a]].cam] + 1]++;
+    for (int c = 0; c < nfc; ++c) camE_ptr[c + 1] += camE_ptr[c];
+
+    // ---- the image: [up: camK | pt | hc2cam | camE_ptr | camE | L_uv | L_info | L_cam | L_pt | L_active | pose0 | pose1][back: record | flags][scratch]
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = al(off + bytes); return o; };
+    const size_t o_K = take((size_t)nc * 32), o_pt = take((size_t)np * 32), o_hc = take((size_t)nfc * 4), o_cep = take((size_t)(nfc + 1) * 4),
+                 o_ce = take((size_t)nL * 4), o_uv = take((size_t)nL * 8), o_info = take((size_t)nL * 4), o_cam = take((size_t)nL * 4), o_lpt = take((size_t)nL * 4),
+                 o_act = take((size_t)nL);
+    const size_t o_p0 = take((size_t)nc * 64), o_p1 = take((size_t)nc * 64);
+    const size_t up_bytes = off;
+    const size_t o_res = take(sizeof(PoseLmResult)), o_flag = take((size_t)nL);
+    const size_t back_bytes = off - o_p0;
+    const size_t o_err = take((size_t)nL * 16), o_U = take((size_t)nfc * 36 * 8), o_bc = take((size_t)nfc * 48), o_xc = take((size_t)nfc * 48);
+    const size_t dev_bytes = off;
+    if (h->h_frame_bytes < up_bytes + back_bytes) {
+        if (h->h_frame) { cached_pinned_release(h->h_frame, h->h_frame_bytes); h->h_frame = nullptr; h->h_frame_bytes = 0; }
+        MAGE_TRY(cached_pinned_alloc(&h->h_frame, up_bytes + back_bytes, &h->h_frame_bytes));
+    }
+    MAGE_TRY(h->d_frame.reserve(dev_bytes));
+    char* img = static_cast<char*>(h->h_frame);
+    char* back = img + up_bytes;
+    {
+        double* K = reinterpret_cast<double*>(img + o_K);
+        double *p0 = reinterpret_cast<double*>(img + o_p0), *p1 = reinterpret_cast<double*>(img + o_p1);
+        for (int i = 0; i < nc; ++i) {
+            const HostCam& c = h->cams[i];
+            K[i * 4] = c.f; K[i * 4 + 1] = c.cx; K[i * 4 + 2] = c.cy; K[i * 4 + 3] = 0.0;
+            for (int a = 0; a < 4; ++a) p0[i * 8 + a] = c.q[a];
+            for (int a = 0; a < 3; ++a) p0[i * 8 + 4 + a] = c.t[a];
+            p0[i * 8 + 7] = 0.0;
+        }
+        std::memcpy(p1, p0, (size_t)nc * 64);
+        double* P = reinterpret_cast<double*>(img + o_pt);
+        for (int i = 0; i < np; ++i) { P[i * 4] = h->pts[(size_t)i * 3]; P[i * 4 + 1] = h->pts[(size_t)i * 3 + 1]; P[i * 4 + 2] = h->pts[(size_t)i * 3 + 2]; P[i * 4 + 3] = 0.0; }
+        std::memcpy(img + o_hc, hc2cam.data(), (size_t)nfc * 4);
+        std::memcpy(img + o_cep, camE_ptr.data(), (size_t)(nfc + 1) * 4);
+        int* camE = reinterpret_cast<int*>(img + o_ce);
+        {
+            std::vector<int> fill(camE_ptr.begin(), camE_ptr.end() - 1);
+            for (int a = 0; a < nL; ++a) camE[fill[cam2hc[h->obs[active[a]].cam]]++] = where[active[a]];      // ascending observation index per camera
+        }
+        float2* uv = reinterpret_cast<float2*>(img + o_uv);
+        float* info = reinterpret_cast<float*>(img + o_info);
+        uint32_t *Lc = reinterpret_cast<uint32_t*>(img + o_cam), *Lp = reinterpret_cast<uint32_t*>(img + o_lpt);
+        for (int i = 0; i < nL; ++i) {
+            const HostObs& o = h->obs[L_edge[i]];
+            uv[i] = make_float2(o.u, o.v); info[i] = o.info; Lc[i] = o.cam; Lp[i] = o.pt;
+        }
+        std::memset(img + o_act, 1, (size_t)nL);
+    }
+    // ---- StepOptimizer's entry (BundlerLib.cpp:132-149): an edited graph, or observations removed by the last call, start the optimiser over
+    const bool graph_changed = !(h->frame_valid && h->frame_gen == h->edit_gen);
+    if (graph_changed || h->soft_dirty) h->iteration = 0;
+    h->soft_dirty = false;
+    unsigned char* D = h->d_frame.p;
+    BaDeviceView v{};
+    v.n_cams = nc; v.n_pts = np; v.n_L = nL; v.n_fc = nfc; v.points_free = 0; v.n_pad = CHOL_TILE;
+    v.camK = reinterpret_cast<const double*>(D + o_K); v.pt_cur = v.pt_trial = reinterpret_cast<double*>(D + o_pt);
+    v.hc2cam = reinterpret_cast<const int*>(D + o_hc); v.camE_ptr = reinterpret_cast<const int*>(D + o_cep); v.camE = reinterpret_cast<const int*>(D + o_ce);
+    v.L_uv = reinterpret_cast<const float2*>(D + o_uv); v.L_info = reinterpret_cast<const float*>(D + o_info);
+    v.L_cam = reinterpret_cast<const uint32_t*>(D + o_cam); v.L_pt = reinterpret_cast<const uint32_t*>(D + o_lpt); v.L_active = D + o_act;
+    v.pose_cur = reinterpret_cast<double*>(D + o_p0); v.pose_trial = reinterpret_cast<double*>(D + o_p1);
+    v.errL = reinterpret_cast<double*>(D + o_err); v.U = reinterpret_cast<double*>(D + o_U); v.bc = reinterpret_cast<double*>(D + o_bc); v.xc = reinterpret_cast<double*>(D + o_xc);
+    PoseLmArgs a{};
+    a.n_huber = (int)n_iter;
+    for (size_t it = 0; it < n_iter; ++it) a.huber[it] = huber[it];
+    a.max_err_sq = (double)max_err_sq; a.lambda = h->lambda; a.user_lambda = h->user_lambda; a.ni = h->ni; a.iteration = h->iteration;
+    MAGE_HIP(hipMemcpyAsync(D, img, up_bytes, hipMemcpyHostToDevice, h->stream));
+    static const bool staged_off = std::getenv("MAGE_BA_POSE_LM_IN_HBM") != nullptr;      // A/B: the arrays left in HBM
+    if (staged_off || !ba_launch_pose_lm_staged(v, a, reinterpret_cast<PoseLmResult*>(D + o_res), D + o_flag, h->stream))
+        ba_launch_pose_lm(v, a, reinterpret_cast<PoseLmResult*>(D + o_res), D + o_flag, h->stream);
+    MAGE_HIP(hipMemcpyAsync(back, D + o_p0, back_bytes, hipMemcpyDeviceToHost, h->stream));
+    MAGE_HIP(hipEventRecord(h->ev[3], h->stream));
+    for (;;) {
+        const hipError_t e = hipEventQuery(h->ev[3]);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) MAGE_HIP(e);
+    }
+    const PoseLmResult& r = *reinterpret_cast<const PoseLmResult*>(back + (o_res - o_p0));
+    const double* kept = reinterpret_cast<const double*>(back + ((r.flips & 1) ? (o_p1 - o_p0) : 0));
+    for (int hc = 0; hc < nfc; ++hc) {                    // only the cameras of the system move
+        HostCam& c = h->cams[hc2cam[hc]];
+        for (int q = 0; q < 4; ++q) c.q[q] = kept[hc2cam[hc] * 8 + q];
+        for (int q = 0; q < 3; ++q) c.t[q] = kept[hc2cam[hc] * 8 + 4 + q];
+    }
+    h->lambda = r.lambda; h->ni = r.ni; h->iteration = r.iteration;
+    for (int i = 0; i < r.n_stats && i < POSE_LM_MAX_ITERS; ++i) {
+        mage_ba_iter_stats tr{};
+        tr.code = r.stats[i].code; tr.trials = r.stats[i].trials; tr.chi2_before = r.stats[i].chi2_before;
+        tr.chi2_after = r.stats[i].chi2_after; tr.lambda = r.stats[i].lambda;
+        if (h->stats.size() < 64) h->stats.push_back(tr);
+    }
+    *err_sum = r.err_sum; *err_cnt = r.err_cnt; *n_out = (size_t)r.n_out;
+    if (r.n_out > 0) {
+        const unsigned char* flag = reinterpret_cast<const unsigned char*>(back + (o_flag - o_p0));
+        std::vector<uint32_t>& ids = h->last_outliers;
+        ids.reserve((size_t)r.n_out);
+        for (int i = 0; i < nL; ++i) if (flag[i]) ids.push_back(L_edge[i]);
+        std::sort(ids.begin(), ids.end());
+        for (uint32_t id : ids) h->obs[id].removed = 1;      // removeEdge
+        h->soft_dirty = true;
+    }
+    h->n_active_remaining = (long long)nL - (long long)r.n_out;
+    h->useless = false;
+    h->host_state_fresh = true; h->state_on_device = false;
+    h->dirty = true;                                           // no structure on the device (edit_gen is NOT bumped: the graph is the caller's)
+    h->frame_valid = true; h->frame_gen = h->edit_gen;
+    *taken = true;
     return MAGE_OK;
 }
 
@@ -1413,7 +1607,7 @@ MAGE_EXPORT mage_status mage_ba_fix_camera(mage_ba* h, size_t idx, int is_fixed)
         if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
         if (idx >= h->cams.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "camera index %zu out of range", idx);
         const uint8_t nv = is_fixed ? 1 : 0;
-        if (h->cams[idx].fixed != nv) { h->cams[idx].fixed = nv; h->dirty = true; }
+        if (h->cams[idx].fixed != nv) { h->cams[idx].fixed = nv; mark_edited(h); }
         return MAGE_OK;
     });
 }
@@ -1517,7 +1711,7 @@ MAGE_EXPORT mage_status mage_ba_set_observation(mage_ba* h, size_t idx, const fl
     return guarded([&]() -> mage_status {
         if (!h || !uv) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
         if (idx >= h->obs.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "observation index %zu out of range (%zu)", idx, h->obs.size());
-        h->dirty = true;
+        mark_edited(h);
         ensure_obs_filled(h);
         return set_obs(h, idx, uv[0], uv[1], cam, pt, info);
     });
@@ -1529,7 +1723,7 @@ MAGE_EXPORT mage_status mage_ba_set_observations_bulk(mage_ba* h, size_t count, 
     return guarded([&]() -> mage_status {
         if (!h || !uv2 || !cam || !pt || !info) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
         if (count > h->obs.size()) return fail(MAGE_ERR_INVALID_ARGUMENT, "count %zu exceeds allocated observations %zu", count, h->obs.size());
-        h->dirty = true;
+        mark_edited(h);
         // AllocateObservations left the records uninitialised (obs_unfilled): when this call covers all of them there is nothing to
         // clear first -- unless an index is out of range, in which case the records from the offender on are cleared before the error
         // is returned ("never set")
@@ -1547,23 +1741,25 @@ MAGE_EXPORT mage_status mage_ba_set_observations_bulk(mage_ba* h, size_t count, 
             return MAGE_OK;
         }
         const size_t nc = h->cams.size(), np = h->pt_set.size();
+        // the indices are validated FIRST (a parallel read-only pass): a bad index must leave the same state behind whatever the
+        // problem size -- the sequential loop's: the records before the first offender written, nothing after it
         std::vector<long long> bad(parts, -1);
-        HostObs* obs = h->obs.data();
         parallel_ranges((int)count, parts, [&](int i0, int i1, int part) {
+            for (int i = i0; i < i1; ++i) if (cam[i] >= nc || pt[i] >= np) { bad[part] = i; break; }
+        });
+        for (long long b : bad)
+            if (b >= 0) {                      // the first offender of the lowest range = the first offender
+                for (size_t i = 0; i < (size_t)b; ++i) (void)set_obs(h, i, uv2[i * 2], uv2[i * 2 + 1], cam[i], pt[i], info[i]);
+                if (covers_all) clear_from((size_t)b);
+                return set_obs(h, (size_t)b, uv2[b * 2], uv2[b * 2 + 1], cam[b], pt[b], info[b]);
+            }
+        HostObs* obs = h->obs.data();
+        parallel_ranges((int)count, parts, [&](int i0, int i1, int) {
             for (int i = i0; i < i1; ++i) {
-                if (cam[i] >= nc || pt[i] >= np) { if (bad[part] < 0) bad[part] = i; continue; }
                 HostObs& o = obs[i];
                 o.u = uv2[(size_t)i * 2]; o.v = uv2[(size_t)i * 2 + 1]; o.info = info[i]; o.cam = cam[i]; o.pt = pt[i]; o.set = 1; o.removed = 0;
             }
         });
-        for (long long b : bad)
-            if (b >= 0) {
-                if (covers_all) {      // the threads skipped their offenders: those records (and nothing else) are still uninitialised
-                    for (size_t i = 0; i < count; ++i) if (cam[i] >= nc || pt[i] >= np) h->obs[i] = HostObs();
-                    h->obs_unfilled = false;
-                }
-                return set_obs(h, (size_t)b, uv2[b * 2], uv2[b * 2 + 1], cam[b], pt[b], info[b]);      // reports the first offender of the lowest range
-            }
         h->obs_unfilled = false;
         return MAGE_OK;
     });
@@ -1660,6 +1856,12 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
         if (n_outliers) *n_outliers = 0;
         if (mean_sq_err) *mean_sq_err = NAN;
         MAGE_DEVICE_SCOPE(h->device);
+        // The structure build's pinned staging goes back to the cache when the first trial's scalars have arrived; a call that leaves
+        // before any read-back (a problem with nothing to optimise, a failed build) must not keep >= 32 MB pinned per handle.
+        struct ArenaGuard {
+            mage_ba* h;
+            ~ArenaGuard() { if (!h->build_arena.blocks.empty()) { (void)hipStreamSynchronize(h->stream); h->build_arena.release(); } }
+        } arena_guard{ h };
         h->stats.clear();
         h->last_outliers.clear();
         for (size_t it = 0; it < n_iter; ++it)
@@ -1671,6 +1873,22 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
         size_t out_prefix = 0;
         const bool sharded = h->shard_ranks > 0;
         if (sharded && !h->shard_reduce) return fail(MAGE_ERR_INVALID_ARGUMENT, "landmark-sharded map without an all-reduce callback");
+        // the tracker's per-frame problems: one upload, one launch, one record back (frame_step above)
+        if (frame_applies(h, n_iter)) {
+            bool taken = false;
+            MAGE_TRY(frame_step(h, huber, n_iter, max_err_sq, &taken, &err_sum, &cnt, &nout));
+            if (taken) {
+                if (mean_sq_err) *mean_sq_err = (float)(err_sum / cnt);
+                for (size_t i = 0; i < h->last_outliers.size() && outliers && i < capacity; ++i) outliers[i] = h->last_outliers[i];
+                if (n_outliers) *n_outliers = nout;
+                return MAGE_OK;
+            }
+        }
+        // a handle that was stepped on the frame path has no structure on the device (`dirty`); when its graph was not edited since,
+        // the general path must not restart the optimiser (iteration 0 re-seeds lambda) just because it builds the structure now
+        const bool keep_lm = h->frame_valid && h->dirty && h->frame_gen == h->edit_gen && !h->soft_dirty;
+        const int keep_iteration = h->iteration;
+        h->frame_valid = false;
         {
             // StepOptimizer's entry conditions (BundlerLib.cpp:132-149).  A landmark-sharded map enters collectively: the ranks
             // agree ONCE per step (a) that every rank has its structure -- a rank whose build failed (out of memory, an
@@ -1682,6 +1900,7 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
             std::string init_err;
             if (h->dirty && (n_iter > 0 || sharded)) {          // (sharded, no iteration: the post-pass below is collective too)
                 init_rc = initialize_optimization(h);
+                if (init_rc == MAGE_OK && keep_lm) h->iteration = keep_iteration;
                 if (init_rc != MAGE_OK) {
                     if (!sharded) return init_rc;
                     init_err = last_error_ref();
@@ -1836,7 +2055,7 @@ MAGE_EXPORT mage_status mage_ba_set_landmark_shard(mage_ba* h, int rank, int n_r
 {
     if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
     if (n_ranks < 0 || (n_ranks > 0 && (rank < 0 || rank >= n_ranks || !allreduce))) return fail(MAGE_ERR_INVALID_ARGUMENT, "rank %d of %d ranks, callback %p", rank, n_ranks, (void*)allreduce);
-    if ((h->shard_ranks > 0) != (n_ranks > 0)) h->dirty = true;            // which cameras are in the system depends on it
+    if ((h->shard_ranks > 0) != (n_ranks > 0)) mark_edited(h);            // which cameras are in the system depends on it
     h->shard_rank = n_ranks > 0 ? rank : 0; h->shard_ranks = n_ranks;
     h->shard_reduce = n_ranks > 0 ? allreduce : nullptr; h->shard_user = user;
     return MAGE_OK;
@@ -2042,8 +2261,15 @@ MAGE_EXPORT mage_status mage_ba_debug_structure(mage_ba* h, const char* name, vo
 {
     return guarded([&]() -> mage_status {
         if (!h || !name || !bytes) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
-        if (h->dirty) return fail(MAGE_ERR_INVALID_ARGUMENT, "the structure is built by the first step");
         MAGE_DEVICE_SCOPE(h->device);
+        if (h->dirty && h->frame_valid && h->frame_gen == h->edit_gen) {      // stepped on the frame path: the structure was never put on the device
+            const int keep_iteration = h->iteration;
+            const bool keep_soft = h->soft_dirty;
+            MAGE_TRY(initialize_optimization(h));
+            h->iteration = keep_iteration; h->soft_dirty = keep_soft;
+            h->frame_valid = false;
+        }
+        if (h->dirty) return fail(MAGE_ERR_INVALID_ARGUMENT, "the structure is built by the first step");
         const BaDeviceView& v = h->view;
         const std::string n(name);
         const void* src = nullptr; size_t nb = 0;
@@ -2112,5 +2338,7 @@ MAGE_EXPORT mage_status mage_ba_get_profile(const mage_ba* h, mage_ba_profile* o
 {
     if (!h || !out) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
     *out = h->prof;
+    out->trials_rerun_after_stall = (uint64_t)h->stall_retries_total;
+    out->fallback_to_separate_launches = chol_merge_fallback_active() ? 1 : 0;
     return MAGE_OK;
 }

@@ -115,6 +115,7 @@ void ba_launch_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTr
 // Small problems (reduced camera system of order <= 128, no tethers): one LM trial in five launches instead of ~22
 // (ba_kernels.hip, "SMALL PROBLEMS").  `counter` is one zero-initialised device int owned by the handle (the kernels leave it 0).
 bool ba_small_applies(const BaDeviceView& v);
+bool ba_small_shape_applies(int n_fc, int n_tethers, long long n_L);                                   // the same predicate before a view exists (structure build)
 void ba_small_init_device();                                                                          // once per device: LDS opt-in
 bool ba_compact_w_enabled();                                                                          // false with MAGE_BA_MATERIAL_W=1 (A/B, tests)
 bool ba_fused_linearize_applies(const BaDeviceView& v);                                              // large, one observation per W slot
@@ -139,6 +140,9 @@ struct PoseLmResult {
 };
 bool ba_pose_lm_applies(const BaDeviceView& v, size_t n_huber);
 void ba_launch_pose_lm(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out_device, uint8_t* flag_by_edge, hipStream_t st);
+// the same solve with every array staged in LDS (only the two pose buffers are written back): false = the problem does not fit
+constexpr int POSE_LM_STAGED_MAX_BYTES = 140 * 1024;
+bool ba_launch_pose_lm_staged(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out_device, uint8_t* flag_by_edge, hipStream_t st);
 
 // Pose exchange of a window-sharded map (mage_ba_export_poses_device / mage_ba_import_poses_device).  A block row is 8 doubles
 // (qx qy qz qw tx ty tz 0).  export: block[row[k]] = pose[cam[k]] (+0.0, so that -0.0 leaves as +0.0 -- what a SUM with the

@@ -1779,13 +1779,56 @@ __device__ __forceinline__ bool solve6_spd(const double* __restrict__ U36, doubl
     return ok;
 }
 
-__global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView v, PoseLmArgs a, PoseLmResult* __restrict__ out, uint8_t* __restrict__ flagL)
+// STAGED (round 4, the frame path of ba_host.hip): everything the solve touches is copied into LDS first and only the two pose
+// buffers go back at the end.  With the arrays in HBM every LM trial is six to eight DEPENDENT memory round trips of one workgroup
+// (residuals, linearisation, the 6x6 system written and read back, the trial's residuals): 47-63 us for the tracker's 3-4 iterations
+// on 300 observations, where one CPU core needs 33-47 us for the whole call.  Same code, same order of every sum: bit-identical.
+size_t pose_lm_staged_bytes(int nc, int np, int nL, int nfc)
 {
+    return ((size_t)nc * 20 + (size_t)np * 4 + (size_t)nL * 2 + (size_t)nfc * 48) * 8 + (size_t)nL * (8 + 4 * 4) + (size_t)(2 * nfc + 1) * 4 + (size_t)nL + 64;
+}
+
+template <bool STAGED>
+__global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a, PoseLmResult* __restrict__ out, uint8_t* __restrict__ flagL)
+{
+    extern __shared__ double dyn[];
     __shared__ double sm[4];
     __shared__ double part[4][28];
     __shared__ double s_lambda, s_ni, s_rho, s_cur_chi;
     __shared__ int s_ok, s_accept;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    BaDeviceView v = vin;
+    if (STAGED) {
+        const int nc = vin.n_cams, np = vin.n_pts, nL = vin.n_L, nfc = vin.n_fc;
+        double* d = dyn;
+        double* pose0 = d; d += (size_t)nc * 8;
+        double* pose1 = d; d += (size_t)nc * 8;
+        double* camK = d; d += (size_t)nc * 4;
+        double* pt = d; d += (size_t)np * 4;
+        double* errL = d; d += (size_t)nL * 2;
+        double* U = d; d += (size_t)nfc * 36;
+        double* bc = d; d += (size_t)nfc * 6;
+        double* xc = d; d += (size_t)nfc * 6;
+        float2* L_uv = reinterpret_cast<float2*>(d);
+        float* L_info = reinterpret_cast<float*>(L_uv + nL);
+        uint32_t* L_cam = reinterpret_cast<uint32_t*>(L_info + nL);
+        uint32_t* L_pt = L_cam + nL;
+        int* camE = reinterpret_cast<int*>(L_pt + nL);
+        int* camE_ptr = camE + nL;
+        int* hc2cam = camE_ptr + nfc + 1;
+        uint8_t* L_active = reinterpret_cast<uint8_t*>(hc2cam + nfc);
+        for (int i = tid; i < nc * 8; i += 256) { pose0[i] = vin.pose_cur[i]; pose1[i] = vin.pose_trial[i]; }
+        for (int i = tid; i < nc * 4; i += 256) camK[i] = vin.camK[i];
+        for (int i = tid; i < np * 4; i += 256) pt[i] = vin.pt_cur[i];
+        for (int i = tid; i < nL; i += 256) {
+            L_uv[i] = vin.L_uv[i]; L_info[i] = vin.L_info[i]; L_cam[i] = vin.L_cam[i]; L_pt[i] = vin.L_pt[i]; camE[i] = vin.camE[i]; L_active[i] = vin.L_active[i];
+        }
+        for (int i = tid; i < nfc; i += 256) hc2cam[i] = vin.hc2cam[i];
+        for (int i = tid; i <= nfc; i += 256) camE_ptr[i] = vin.camE_ptr[i];
+        v.pose_cur = pose0; v.pose_trial = pose1; v.camK = camK; v.pt_cur = v.pt_trial = pt; v.errL = errL; v.U = U; v.bc = bc; v.xc = xc;
+        v.L_uv = L_uv; v.L_info = L_info; v.L_cam = L_cam; v.L_pt = L_pt; v.camE = camE; v.camE_ptr = camE_ptr; v.hc2cam = hc2cam; v.L_active = L_active;
+        __syncthreads();
+    }
     double lambda = a.lambda, ni = a.ni;
     int iteration = a.iteration, n_stats = 0, flips = 0, cont = 1;
     BaDeviceView w = v;                                 // w.pose_cur / w.pose_trial swap on every accepted trial
@@ -1808,10 +1851,14 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView v, PoseLmArgs a, P
         return block_sum<4>(acc, sm);
     };
 
+    double carried_chi = 0;
     for (int it = 0; it < a.n_huber && cont; ++it) {
         const double delta = (double)a.huber[it];
         // ---- linearise at the current estimate: chi2, U, b per free camera
-        const double chi_cur0 = chi2_of(w.pose_cur, delta);
+        // (with an unchanged Huber width the robust chi2 of the current estimate is the value the last iteration ended with -- the same
+        // function on the same pose gives the same bits, accepted trial or not -- so one of the three passes over the observations per
+        // iteration is saved; the residuals the post-pass reads are those of the LAST error evaluation either way, BundlerLib.cpp:386-425)
+        const double chi_cur0 = (it > 0 && a.huber[it] == a.huber[it - 1]) ? carried_chi : chi2_of(w.pose_cur, delta);
         for (int hc = 0; hc < v.n_fc; ++hc) {
             const int cam = v.hc2cam[hc];
             PoseD P = load_pose(w.pose_cur, cam);
@@ -1933,6 +1980,7 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView v, PoseLmArgs a, P
         ++n_stats;
         ++iteration;
         cont = code == 0;
+        carried_chi = cur_chi;
     }
     // ---- post-pass: classification with the residuals of the LAST error evaluation and the kept estimate (k_classify)
     double es = 0, ec = 0, no = 0;
@@ -1958,6 +2006,10 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView v, PoseLmArgs a, P
     if (tid == 0) {
         out->lambda = lambda; out->ni = ni; out->iteration = iteration; out->n_stats = n_stats; out->flips = flips;
         out->err_sum = r0; out->err_cnt = r1; out->n_out = r2;
+    }
+    if (STAGED) {        // the two pose buffers go back where they came from (the host picks the current one by `flips`)
+        __syncthreads();
+        for (int i = tid; i < vin.n_cams * 8; i += 256) { vin.pose_cur[i] = v.pose_cur[i]; vin.pose_trial[i] = v.pose_trial[i]; }
     }
 }
 
@@ -2083,11 +2135,14 @@ void ba_launch_update(const BaDeviceView& v, double lambda, double lambda_cam, h
 }
 
 // ---- small-problem path (ba_kernels.h: ba_small_*)
-bool ba_small_applies(const BaDeviceView& v)
+// ONE predicate for the host's structure build (which skips the Schur block order for small problems) and for lm_solve (which then
+// takes the small path): the two must never disagree, so both call this.
+bool ba_small_shape_applies(int n_fc, int n_tethers, long long n_L)
 {
     static const bool off = std::getenv("MAGE_BA_NO_SMALL_PATH") != nullptr;
-    return !off && v.n_fc > 0 && v.n_fc * 6 <= 128 && v.n_T == 0 && v.n_L <= (1 << 20);
+    return !off && n_fc > 0 && n_fc * 6 <= 128 && n_tethers == 0 && n_L <= (1 << 20);
 }
+bool ba_small_applies(const BaDeviceView& v) { return ba_small_shape_applies(v.n_fc, v.n_T, v.n_L); }
 static int small_error_blocks(const BaDeviceView& v) { return v.n_L > 0 ? std::min(cdiv(v.n_L, 256), RED_BLOCKS) : 1; }
 void ba_small_linearize(const BaDeviceView& v, double delta, bool want_maxdiag, int* counter, hipStream_t st)
 {
@@ -2138,7 +2193,10 @@ void ba_small_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTri
 {
     hipLaunchKernelGGL(k_small_classify<true>, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, counter, c);
 }
-void ba_small_init_device() {}
+void ba_small_init_device()
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_lm<true>), hipFuncAttributeMaxDynamicSharedMemorySize, POSE_LM_STAGED_MAX_BYTES);
+}
 
 bool ba_pose_lm_applies(const BaDeviceView& v, size_t n_huber)
 {
@@ -2147,7 +2205,14 @@ bool ba_pose_lm_applies(const BaDeviceView& v, size_t n_huber)
 }
 void ba_launch_pose_lm(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out, uint8_t* flagL, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_pose_lm, dim3(1), dim3(256), 0, st, v, a, out, flagL);
+    hipLaunchKernelGGL(k_pose_lm<false>, dim3(1), dim3(256), 0, st, v, a, out, flagL);
+}
+bool ba_launch_pose_lm_staged(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out, uint8_t* flagL, hipStream_t st)
+{
+    const size_t lds = pose_lm_staged_bytes(v.n_cams, v.n_pts, v.n_L, v.n_fc);
+    if (lds > (size_t)POSE_LM_STAGED_MAX_BYTES) return false;
+    hipLaunchKernelGGL(k_pose_lm<true>, dim3(1), dim3(256), lds, st, v, a, out, flagL);
+    return true;
 }
 
 void ba_launch_export_poses(const double* pose, const uint32_t* cam, const uint32_t* row, size_t n, double* block, hipStream_t st)

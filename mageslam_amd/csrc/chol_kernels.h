@@ -16,6 +16,7 @@ size_t chol_workspace_doubles(int n_pad);
 inline size_t chol_sync_ints(int n_pad) { return (size_t)(n_pad / CHOL_TILE) + 4; }
 constexpr int CHOL_MAX_ORDER = 256 * CHOL_TILE;   // the persistent backward solve needs one resident workgroup per tile column
 void chol_debug_syrk_stamps(long long* out32, bool reset);   // development only (tools/chol_test.hip, CHOL_DBG=1 CHOL_DBG_COL=k)
+bool chol_merge_fallback_active();   // true once chol_report_stall(2) has switched this process to separate panel-solve launches
 void chol_report_stall(int code);   // the host saw *stall = code (1 split diagonal tile, 2 merged panel solve, 3 backward solve): adapts the schedule
 void chol_init_device();   // once per device (after hipSetDevice): opt the LDS-heavy kernels in
 

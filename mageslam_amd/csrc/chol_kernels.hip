@@ -326,29 +326,69 @@ __device__ __forceinline__ void lds_update_tile_left(double* __restrict__ A, int
 // before raising a flag made the publishing wavefront late at the iteration's barrier (+2 ... +6 us per tile on the critical path).
 constexpr int LPUB_BLOCKS = NBLK * (NBLK - 1) / 2;            // 28 sub-diagonal blocks
 constexpr int LPUB_TILE_DOUBLES = LPUB_BLOCKS * NB * NB;      // 7168
-struct TilePublish { double* Lpub; };                         // this tile's scratch blocks (nullptr: not publishing)
+struct TilePublish {
+    double* Lpub;                 // PUBLISH == 2: this tile's scratch blocks (nullptr: not publishing)
+                                  // PUBLISH == 3: the tile's full inverse is built in the PACKED_TILE_DOUBLES of LDS right behind Li's two blocks, blocks ROW-major
+    double* inv_global = nullptr; // PUBLISH == 3: where the inverse goes, block (c, j), c >= j, at (c (c + 1) / 2 + j) * 256, blocks COLUMN-major
+};
 
 // PUBLISH: 0 plain stores of the block inverses (a kernel boundary or a release fence follows); 1 the block inverses written THROUGH
 // (agent-scope stores: the write-through hand-off of k_syrk_update<1, true>, no release fence follows); 2 also the sub-diagonal blocks
-// (the pipelined strips described above).
+// (the pipelined strips described above); 3 (round 4) as 1, and the tile's FULL INVERSE L^-1 (lower triangular, 36 blocks) is built
+// alongside and written through, so that the panel solve below the tile is a product, X = A L^-T, with no dependent chain (trsm_strip_gemm):
+//     Linv[i][j] = -Linv[i][i] P_i[j],   P_i[j] = sum_{k = j .. i - 1} L[i][k] Linv[k][j]        (i > j; from L Linv = I)
+// Column j of the inverse depends only on itself, so wavefront 1 + j % 3 owns it and nobody synchronises: during the factorisation of
+// diagonal block s + 1 (wavefront 0, ~2 us) the owner finishes row s of its columns -- four matrix-core operations per block with the
+// block inverse that has just become known -- and prepares P_{s+1}[j], which needs nothing newer than block row s + 1 of column s.
+// What is left behind the LAST diagonal block is four operations per block of the last row.  Blocks live row-major in LDS (the B
+// operand of the next product) and go to memory column-major (the A operand the strips read, 512 contiguous bytes per fragment):
+// the transposed block is the same product with the operands exchanged, P^T (-Linv_ii)^T, from the registers already loaded.
+// The barriers inside the tile factorisation order LDS traffic only.  __syncthreads() also waits for the wavefront's outstanding
+// GLOBAL stores (the compiler puts s_waitcnt vmcnt(0) in front of the barrier), and in the publishing forms those are write-through
+// stores that take ~2 us to be acknowledged: with the full inverse streaming out block by block every one of the tile's 24 barriers
+// waited for memory (the in-tile factorisation went from 22 to 37 us).  LDS_ONLY: wait for this wavefront's LDS operations, then the
+// hardware barrier; global stores stay in flight (the caller drains them once, before it raises the flag).
+template <bool LDS_ONLY>
+__device__ __forceinline__ void tile_barrier()
+{
+    if (LDS_ONLY) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+}
+
+// A write-through (agent-scope) store to GLOBAL memory, typed as such: through a generic pointer it is a flat store, and the compiler
+// must then assume it may hit LDS -- every later LDS access of the wavefront waits for vmcnt(0), i.e. for the ~2 us acknowledgement
+// of a store that only ever goes to memory.
+typedef __attribute__((address_space(1))) double global_double;
+__device__ __forceinline__ void store_through(double* p, double v)
+{
+    __hip_atomic_store((global_double*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <bool PARTIAL, class LAY, int PUBLISH = 0>
-__device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __restrict__ Li, double* __restrict__ Linv_k, int tid, int nblk = NBLK,
+__device__ __forceinline__ bool potrf_tile_lds(double* __restrict__ A, double* __restrict__ Li, double* __restrict__ Linv_k, int tid, int nblk = NBLK,
                                             TilePublish pub = TilePublish{ nullptr })
 {
     const int NBK = PARTIAL ? nblk : NBLK;
     const int lane = tid & 63, wave = tid >> 6;
     bool failed = false;
     if (wave == 0) failed = factor_block16<LAY::PITCH>(A + LAY::blk(0, 0), lane, Li, Linv_k);
-    __syncthreads();
+    tile_barrier<PUBLISH != 0>();
     for (int s = 0; s < NBK; ++s) {
         const double* Lc = Li + (s & 1) * NB * NB;
         if (wave == 3) {                           // block inverse s -> global workspace (read by k_trsm_panel / k_bsolve_persist)
             if (PUBLISH) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) __hip_atomic_store(Linv_k + s * NB * NB + lane * 4 + q, Lc[lane * 4 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int q = 0; q < 4; ++q) store_through(Linv_k + s * NB * NB + lane * 4 + q, Lc[lane * 4 + q]);
             } else {
                 const double4_t v = *reinterpret_cast<const double4_t*>(Lc + lane * 4);
                 *reinterpret_cast<double4_t*>(Linv_k + s * NB * NB + lane * 4) = v;
+            }
+            if (PUBLISH == 3) {                    // the diagonal block of the full inverse: row-major to LDS, column-major to memory
+                const double4_t v = *reinterpret_cast<const double4_t*>(Lc + lane * 4);
+                *reinterpret_cast<double4_t*>(Li + 2 * NB * NB + LAY::blk(s, s) + lane * 4) = v;      // (the inverse sits right behind the two block inverses: derived from Li, not handed in -- a second LDS pointer made the compiler look the LDS base up in memory every iteration)
+                double* G = pub.inv_global + (size_t)(s * (s + 1) / 2 + s) * NB * NB;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int e = lane * 4 + q; store_through(G + (e & 15) * NB + (e >> 4), v[q]); }
             }
         }
         if (PUBLISH == 2 && wave >= 1 && s > 0) {       // block column s - 1 is final: its blocks below the diagonal go out, dealt over wavefronts 1-3
@@ -356,7 +396,7 @@ __device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __re
                 const double* Bl = A + LAY::blk(i, s - 1);
                 double* G = pub.Lpub + (size_t)(i * (i - 1) / 2 + (s - 1)) * NB * NB;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) __hip_atomic_store(G + (4 * r + (lane >> 4)) * NB + (lane & 15), Bl[frag<LAY>(r, lane)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int r = 0; r < 4; ++r) store_through(G + (4 * r + (lane >> 4)) * NB + (lane & 15), Bl[frag<LAY>(r, lane)]);
             }
         }
         if (s == NBK - 1) break;
@@ -402,7 +442,7 @@ __device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __re
                 for (int r = 0; r < 4; ++r) Xs[frag<LAY>(r, lane)] = acc[r];
             }
         }
-        __syncthreads();
+        tile_barrier<PUBLISH != 0>();
         // Trailing update, scheduled so that it never outlasts the factorisation it runs beside (a right-looking update
         // front-loads 27 of the 77 tile updates into step 0; wavefront 0 then waited ~10k cycles per tile at this barrier):
         //   wavefront 0     factors the next diagonal block (updated just above);
@@ -412,13 +452,90 @@ __device__ __noinline__ bool potrf_tile_lds(double* __restrict__ A, double* __re
             failed |= factor_block16<LAY::PITCH>(A + LAY::blk(s + 1, s + 1), lane, Li + ((s + 1) & 1) * NB * NB, Linv_k + (s + 1) * NB * NB);
         } else {
             const int nrow = NBK - 2 - s;                 // block rows s+2 .. 7
-            for (int t = wave - 1; t < 2 * nrow; t += 3) {
+            // (with the inverse alongside, the update's tasks are dealt from wavefront 3 downwards: wavefront 1 owns the longest columns of the inverse)
+            for (int t = PUBLISH == 3 ? 3 - wave : wave - 1; t < 2 * nrow; t += 3) {
                 const int i = s + 2 + (t >> 1);
                 if ((t & 1) == 0) lds_update_tile_left<LAY>(A, i, s + 1, s + 1, lane);
                 else lds_update_tile<LAY>(A, i, i, s, lane);
             }
+            if (PUBLISH == 3) {
+                double* INV = Li + 2 * NB * NB;
+                // columns dealt by cost (column j of row s + 1 is s + 1 - j products): 0 1 2 | 2 1 0 | 0 ... over wavefronts 1-3 -- a function
+                // of j alone, so a column stays with its wavefront and nothing is handed over
+                for (int j = 0; j <= s; ++j) {
+                    const int z = j % 6;
+                    if (1 + (z < 3 ? z : 5 - z) != wave) continue;
+                    double4_t fin;                                        // Linv[s][j], accumulator layout = B operand of the next product
+                    // operands of the first product of P_{s+1}[j] are fetched before anything else is waited for
+                    double la[4], ib[4];
+                    if (j < s) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { la[r] = A[LAY::blk(s + 1, j) + frag<LAY>(r, lane)]; ib[r] = INV[LAY::blk(j, j) + frag<LAY>(r, lane)]; }
+                    }
+                    if (j < s) {
+                        double* slot = INV + LAY::blk(s, j);              // holds P_s[j]
+                        double pr[4], li[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { pr[r] = slot[frag<LAY>(r, lane)]; li[r] = -Lc[(lane & 15) * NB + 4 * r + (lane >> 4)]; }
+                        fin = (double4_t){ 0, 0, 0, 0 };
+                        double4_t tr = { 0, 0, 0, 0 };
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) fin = __builtin_amdgcn_mfma_f64_16x16x4f64(li[r], pr[r], fin, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tr = __builtin_amdgcn_mfma_f64_16x16x4f64(pr[r], li[r], tr, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) slot[frag<LAY>(r, lane)] = fin[r];
+                        double* G = pub.inv_global + (size_t)(s * (s + 1) / 2 + j) * NB * NB;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) store_through(G + frag<LAY>(r, lane), tr[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) fin[r] = Lc[frag<LAY>(r, lane)];
+                    }
+                    // P_{s+1}[j] = sum_{k = j .. s} L[s+1][k] Linv[k][j]  ->  the slot of block (s + 1, j); the operands of product k + 1 are in
+                    // flight while product k runs
+                    double4_t acc = { 0, 0, 0, 0 };
+                    for (int kb = j; kb < s; ++kb) {
+                        double la2[4], ib2[4];
+                        if (kb + 1 < s) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { la2[r] = A[LAY::blk(s + 1, kb + 1) + frag<LAY>(r, lane)]; ib2[r] = INV[LAY::blk(kb + 1, j) + frag<LAY>(r, lane)]; }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { la2[r] = A[LAY::blk(s + 1, s) + frag<LAY>(r, lane)]; ib2[r] = 0.0; }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[r], ib[r], acc, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { la[r] = la2[r]; ib[r] = ib2[r]; }
+                    }
+                    if (j == s) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) la[r] = A[LAY::blk(s + 1, s) + frag<LAY>(r, lane)];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[r], fin[r], acc, 0, 0, 0);
+                    double* nslot = INV + LAY::blk(s + 1, j);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nslot[frag<LAY>(r, lane)] = acc[r];
+                }
+            }
         }
-        __syncthreads();
+        tile_barrier<PUBLISH != 0>();
+    }
+    if (PUBLISH == 3) {
+        // the last row of the inverse: Linv[7][j] = -Linv_77 P_7[j], straight to memory (transposed form only), two columns per wavefront
+        const int sl = NBK - 1;
+        const double* Lc = Li + (sl & 1) * NB * NB;
+        for (int j = wave; j < sl; j += 4) {
+            const double* slot = Li + 2 * NB * NB + LAY::blk(sl, j);
+            double4_t tr = { 0, 0, 0, 0 };
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tr = __builtin_amdgcn_mfma_f64_16x16x4f64(slot[frag<LAY>(r, lane)], -Lc[(lane & 15) * NB + 4 * r + (lane >> 4)], tr, 0, 0, 0);
+            double* G = pub.inv_global + (size_t)(sl * (sl + 1) / 2 + j) * NB * NB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) store_through(G + frag<LAY>(r, lane), tr[r]);
+        }
     }
     return failed;
 }
@@ -683,56 +800,6 @@ __device__ __forceinline__ void trsm_strip_pipelined(double* __restrict__ S, dou
         }
     }
     if (!ok && lane == 0) *stall = 2.0;
-}
-
-// The same strip for launches in which nobody waits for it (the panel solve merged into the half-tile update, k_syrk_update2<true>):
-// the same operations in the same order as trsm_strip -- bit-identical results -- but a step's operands are fetched when the step
-// comes instead of all up front, so the strip lives within the 256 registers two workgroups per compute unit leave each other
-// (trsm_strip holds 416 operand registers).  Its memory latency, eight dependent fetches instead of one, is hidden behind the update.
-__device__ __forceinline__ void trsm_strip_lean(double* __restrict__ S, double* __restrict__ y, int ld, int k, int strip, bool is_rhs,
-                                                const double* __restrict__ Linv_k, int lane)
-{
-    double* base;
-    size_t cstride;
-    bool live;
-    if (!is_rhs) {
-        base = S + (size_t)(k * TILE) * ld + (size_t)(k + 1) * TILE + strip * NB + (lane & 15);
-        cstride = (size_t)ld;
-        live = true;
-    } else {
-        base = y + (size_t)k * TILE;
-        cstride = 1;
-        live = (lane & 15) == 0;
-    }
-    const double* Lop = S + (size_t)(k * TILE + (lane >> 4)) * ld + (size_t)k * TILE + (lane & 15);
-    const double* Lio = Linv_k + (lane & 15) * NB + (lane >> 4);
-    double4_t Y[NBLK];
-#pragma unroll
-    for (int c = 0; c < NBLK; ++c) {
-        double4_t acc;
-        double lio[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            acc[r] = live ? base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] : 0.0;
-            lio[r] = Lio[c * NB * NB + 4 * r];
-        }
-#pragma unroll
-        for (int j = 0; j < c; ++j) {
-            double lop[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) lop[r] = -Lop[(size_t)(j * NB + 4 * r) * ld + c * NB];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lop[r], Y[j][r], acc, 0, 0, 0);
-        }
-        double4_t yc = { 0, 0, 0, 0 };
-#pragma unroll
-        for (int r = 0; r < 4; ++r) yc = __builtin_amdgcn_mfma_f64_16x16x4f64(lio[r], acc[r], yc, 0, 0, 0);
-        Y[c] = yc;
-        if (live) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] = yc[r];
-        }
-    }
 }
 
 __global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
@@ -1111,12 +1178,76 @@ __device__ __forceinline__ void trsm_strip_wt(double* __restrict__ S, double* __
     }
 }
 
+// The merged strip as a PRODUCT (round 4): with the tile's full inverse in memory (potrf_tile_lds<.., 3>) the strip is
+//     X = A L^-T,   i.e. on the transposed unknown   Y_c = sum_{j <= c} Linv[c][j] A_j^T        (c = 0 .. 7, 16 columns each)
+// and nothing depends on anything: the FOUR wavefronts of the strip's workgroup take the block columns {w, 7 - w} -- 36 matrix-core
+// operations each instead of one wavefront's chain of 176 (every f64 MFMA occupies its SIMD's pipe for 64 cycles, dependent or not:
+// the substitution form is one SIMD's 5.4 us).  Waits as in trsm_strip_wt: the rows first (count, acquire, fetch), then the inverse
+// (flag, agent-scope loads).  INVg: block (c, j) at (c (c + 1) / 2 + j) * 256, column-major inside the block.
+__device__ __forceinline__ void trsm_strip_gemm(double* __restrict__ S, double* __restrict__ y, int ld, int k, int strip, bool is_rhs,
+                                                const double* __restrict__ INVg, int* __restrict__ flag, int col_target, double* __restrict__ stall, int lane, int wave)
+{
+    double* base;
+    size_t cstride;
+    bool live;
+    if (!is_rhs) {
+        base = S + (size_t)(k * TILE) * ld + (size_t)(k + 1) * TILE + strip * NB + (lane & 15);
+        cstride = (size_t)ld;
+        live = true;
+        if (!poll_at_least(flag + 2, col_target, lane) && lane == 0) *stall = 2.0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        base = y + (size_t)k * TILE;       // this workgroup's own row, just updated
+        cstride = 1;
+        live = (lane & 15) == 0;
+    }
+    const int c1 = wave, c2 = NBLK - 1 - wave;            // c1 <= 3 < c2
+    double Af[NBLK][4];                                   // A_j^T fragments, j <= c2
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Af[j][r] = (live && j <= c2) ? base[(size_t)(j * NB + (lane >> 4) + 4 * r) * cstride] : 0.0;
+    if (!poll_at_least(flag + 1, k, lane) && lane == 0) *stall = 2.0;
+    const double* Ig = INVg + (lane >> 4) * NB + (lane & 15);      // fragment r of a block: + 64 r
+    double4_t y1 = { 0, 0, 0, 0 }, y2 = { 0, 0, 0, 0 };
+    // the operands of both columns up front (36 blocks' fragments at most: c1 + 1 + c2 + 1 = 9 blocks, 36 loads)
+    double I1[4][4], I2[NBLK][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) I1[j][r] = j <= c1 ? __hip_atomic_load(Ig + (size_t)(c1 * (c1 + 1) / 2 + j) * NB * NB + 64 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) I2[j][r] = j <= c2 ? __hip_atomic_load(Ig + (size_t)(c2 * (c2 + 1) / 2 + j) * NB * NB + 64 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) {
+        if (j <= c2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y2 = __builtin_amdgcn_mfma_f64_16x16x4f64(I2[j][r], Af[j][r], y2, 0, 0, 0);
+        }
+        if (j < 4 && j <= c1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(I1[j][r], Af[j][r], y1, 0, 0, 0);
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            base[(size_t)(c1 * NB + (lane >> 4) + 4 * r) * cstride] = y1[r];
+            base[(size_t)(c2 * NB + (lane >> 4) + 4 * r) * cstride] = y2[r];
+        }
+    }
+}
+
 // MERGE is a template parameter (0 no panel solve in the launch, 1 merged strips, 2 pipelined strips): with the three forms in one
 // body the strip roles -- ~420 live registers each -- were allocated against each other and 290 registers went to scratch memory,
 // some of it between the matrix-core operations of the strip that sits on the chain.
 // WT (with MERGE == 1): the write-through form of the two hand-offs that sit on the chain (the split diagonal tile -> workgroup 0, and
 // workgroup 0 -> the strips): sc1 stores and loads instead of release / acquire fences (load_tile_packed_wt above).
-template <int MERGE, bool WT = false>
+// GEMM (with WT): workgroup 0 also builds the factored tile's full inverse and the strips are products on four wavefronts (trsm_strip_gemm).
+template <int MERGE, bool WT = false, bool GEMM = false>
 __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
                                                      double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int n_q4, int col_target,
                                                      int dbg, double* __restrict__ Lpub_next)
@@ -1130,7 +1261,14 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
     const int first_q4 = NDIAG + n_whole, first_rhs = first_q4 + 4 * n_q4;
     const int bid = blockIdx.x;
     if (bid >= first_rhs + mt) {
-        // ---- merged panel solve of tile column j0 (merge != 0): one strip per workgroup (wavefront 0), behind everything it waits for
+        // ---- merged panel solve of tile column j0 (merge != 0): one strip per workgroup (wavefront 0; all four in the product form), behind everything it waits for
+        if constexpr (GEMM) {
+            dbg_min(dbg, 6);
+            trsm_strip_gemm(S, y, ld, j0, bid - (first_rhs + mt), false, Lpub_next, flag, col_target, stall, lane, wave);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg_max(dbg, 8);
+            return;
+        }
         if (wave != 0) return;
         dbg_min(dbg, 6);
         if constexpr (MERGE == 0) return;
@@ -1171,6 +1309,7 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
                 // the rhs row of the merged panel solve: y_j0 is this workgroup's own (just updated), L_j0j0 comes from workgroup 0
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                if constexpr (GEMM) { trsm_strip_gemm(S, y, ld, j0, 0, true, Lpub_next, flag, 0, stall, lane, wave); return; }
                 if (wave != 0) return;
                 if constexpr (MERGE == 2) trsm_strip_pipelined(S, y, ld, j0, 0, true, Linv_next, Lpub_next, stall, lane);
                 else if constexpr (WT) trsm_strip_wt(S, y, ld, j0, 0, true, Linv_next, flag, 0, stall, lane);
@@ -1232,9 +1371,21 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
         dbg_set(dbg, 3);
         bool failed;
         if constexpr (MERGE == 2) failed = potrf_tile_lds<false, LayPacked, 2>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid, NBLK, TilePublish{ Lpub_next });
+        else if constexpr (GEMM) failed = potrf_tile_lds<false, LayPacked, 3>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid, NBLK,
+                                                                              TilePublish{ nullptr, Lpub_next });
         else if constexpr (WT) failed = potrf_tile_lds<false, LayPacked, 1>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
         else failed = potrf_tile_lds<false, LayPacked>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
         dbg_set(dbg, 4);
+        if constexpr (GEMM) {
+            // the strips read only the inverse (written through by the factorisation): publish FIRST, store the factor itself afterwards
+            if (tid == 0 && failed) *ok = 0.0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flag + 1, j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dbg_set(dbg, 5);
+            store_tile_packed(T, A, ld, tid);
+            return;
+        }
         if constexpr (WT) store_tile_packed_wt(T, A, ld, tid);
         else store_tile_packed(T, A, ld, tid);
         if (tid == 0 && failed) *ok = 0.0;
@@ -1287,26 +1438,19 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
     if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_max(dbg, ct == 0 ? 10 : 9); }
 }
 
-// MERGED (round 4): the panel solve of tile column j0 = k + 1 rides in THIS launch in the update-bound columns too, so that the
-// ~10 us panel-solve launch between two updates disappears.  What made the first attempt slower (profiles/r02_chol_schedules.md: the
-// strips as the LAST workgroups of the launch, behind the last tiles) is placement: here the first-column tiles (rt, 0) come FIRST in
-// the task order (done after the first round), workgroup 0 has factored tile (j0, j0) ~35-40 us into the launch, and the strip
-// workgroups sit in the MIDDLE of the grid (strip_pos, chosen by the host so that they are dispatched when both are long done and
-// finish well before the last tiles): nobody waits for them and they wait for nobody.  Four strips per workgroup, one per wavefront,
-// in the lean form (trsm_strip_lean: <= 256 registers).  Hand-off as in k_syrk_update<1>: the two halves of a first-column tile and
-// workgroup 0 release and count, a strip polls both counters (bounded), acquires, solves.  Same numbers in the same order as
-// k_trsm_panel: bit-identical.
-template <bool MERGED>
+// (Round 4 tried the panel solve of column k + 1 INSIDE this launch too -- first-column tiles first, strip workgroups in the middle of
+// the grid, where they wait for nobody: bit-identical and 50-70 us SLOWER per factorisation.  What the separate ~11 us panel-solve
+// launch costs is mostly the write-back of the update's dirty tiles at the kernel boundary, which the next launch then pays instead;
+// profiles/r04_chol_merged_halftile_rejected.txt has the numbers and the per-launch timeline.  The code is not kept.)
 __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
-                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int unstaged,
-                                                     int strip_pos, int strip_wgs, int col_target)
+                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int unstaged)
 {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j0 = k + 1, mt = nt - j0;
     const int n_tiles = mt * (mt + 1) / 2;
     const int n_task_wgs = 16 * ((n_tiles - 1 + 7) / 8);          // tile indices 1 .. n_tiles - 1, two workgroups (column halves) each, in groups of eight tiles
-    const int first_rhs = NDIAG + n_task_wgs + (MERGED ? strip_wgs : 0);
+    const int first_rhs = NDIAG + n_task_wgs;
     const int bid = blockIdx.x;
     if (bid >= first_rhs) {
         const int i = k + 1 + (bid - first_rhs);
@@ -1318,16 +1462,6 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
 #pragma unroll 8
             for (int c = 0; c < TILE; ++c) acc = __builtin_fma(Lik[(size_t)c * ld + r], yk[c], acc);
             y[(size_t)i * TILE + r] -= acc;
-        }
-        if constexpr (MERGED) {
-            if (i == j0) {
-                // the rhs row of the merged panel solve: y_j0 is this workgroup's own (just updated), L_j0j0 comes from workgroup 0
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (wave != 0) return;
-                wait_for_column(flag, j0, 0, stall, lane);
-                trsm_strip_lean(S, y, ld, j0, 0, true, Linv_next, lane);
-            }
         }
         return;
     }
@@ -1359,7 +1493,6 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NDIAG - 1 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
             if (spins >= (1 << 24)) *stall = 1.0;        // a producer never arrived: reported as a device error (never folded into "not positive definite")
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (MERGED) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // no panel-solve launch follows to reset it
         }
         __syncthreads();
         double* A = sm;
@@ -1369,32 +1502,9 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
         const bool failed = potrf_tile_lds<false, LayPacked>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
         store_tile_packed(T, A, ld, tid);
         if (tid == 0 && failed) *ok = 0.0;
-        if constexpr (MERGED) {      // L_j0j0 and its block inverses are in memory: the strips of this launch may start
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(flag + 1, j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
         return;
     }
-    int q0 = bid - NDIAG;
-    if constexpr (MERGED) {
-        if (q0 >= strip_pos) {
-            if (q0 < strip_pos + strip_wgs) {
-                // ---- merged panel solve of tile column j0: strip 4 (q0 - strip_pos) + wave
-                const int strip = 4 * (q0 - strip_pos) + wave;
-                if (strip >= (mt - 1) * NBLK) return;
-                wait_for_column(flag, j0, col_target, stall, lane);
-                if (unstaged & 4) return;          // (timing experiment only: the strips' own cost)
-                trsm_strip_lean(S, y, ld, j0, strip, false, Linv_next, lane);
-                return;
-            }
-            q0 -= strip_wgs;
-        }
-    }
+    const int q0 = bid - NDIAG;
     // half of a tile: 128 rows x 64 columns, a wavefront 64 x 32, accumulators loaded from C.
     // Which half: workgroups go to the eight XCDs round-robin and every XCD has its own 4 MB L2, while the operands of a launch are
     // ONE tile column of L ((nt - k - 1) x 128 KB: 6 MB in the first columns).  Dealing tiles out in linear order makes every XCD
@@ -1404,7 +1514,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
     // memory-side reads -27 %) -- measured, and no faster (see chol_factor_solve), so linear order stays the default.  The two halves of
     // a tile are consecutive tasks of one XCD either way.  Placement only: any order gives the same numbers.
     int rt, ct, q;
-    if (!MERGED && (unstaged & 2)) {
+    if (unstaged & 2) {
         const int n_task = 2 * (n_tiles - 1), per = (n_task + 7) / 8;
         q = (q0 & 7) * per + (q0 >> 3);
         if ((q0 >> 3) >= per || q >= n_task) return;
@@ -1414,13 +1524,9 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
         const int tile_i = 8 * (q0 >> 4) + (q0 & 7);
         if (tile_i >= n_tiles - 1) return;
         q = 2 * tile_i + ((q0 >> 3) & 1);
-        if constexpr (MERGED) {
-            // the first-column tiles (1, 0) .. (mt - 1, 0) first, then the triangle of the others in linear order
-            if (tile_i < mt - 1) { rt = tile_i + 1; ct = 0; }
-            else { tile_of_index(tile_i - (mt - 1), rt, ct); ++rt; ++ct; }
-        } else tile_of_index(1 + (q >> 1), rt, ct);
+        tile_of_index(1 + (q >> 1), rt, ct);
     }
-    if (MERGED || (unstaged & 1)) {                               // the default: operands straight from L2 per wavefront
+    if (unstaged & 1) {                               // the default: operands straight from L2 per wavefront
         if (rt == ct && (q & 1) && (wave & 1) == 0) return;      // diagonal tile: rows 0-63 of columns 64-127 lie above the diagonal
         const int row0 = (j0 + rt) * TILE + (wave & 1) * 64, col0 = (j0 + ct) * TILE + (q & 1) * 64 + (wave >> 1) * 32;
         double4_t out[2][4];
@@ -1432,15 +1538,6 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
             for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = out[a][b][r];
-        if constexpr (MERGED) {
-            if (ct == 0) {
-                if (unstaged & 8) {                // (timing experiment only: the count without the release fence)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    if (tid == 0) __hip_atomic_fetch_add(flag + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else publish_column_part(flag, tid);
-            }
-        }
         return;
     }
     update_half_tile_staged(S, ld, k, (j0 + rt) * TILE, (j0 + ct) * TILE + (q & 1) * 64, sm, tid);
@@ -1635,7 +1732,8 @@ __global__ __launch_bounds__(256) void k_small_solve(const double* __restrict__ 
 }  // namespace
 
 // per tile column: the inverses of its eight diagonal blocks, then (behind all of those) the scratch copy of its 28 sub-diagonal blocks
-size_t chol_workspace_doubles(int n_pad) { return (size_t)(n_pad / TILE) * (NBLK * NB * NB + LPUB_TILE_DOUBLES); }
+// (the third part: per tile column the full inverse of its diagonal tile, 36 blocks -- k_syrk_update<1, true, true>)
+size_t chol_workspace_doubles(int n_pad) { return (size_t)(n_pad / TILE) * (NBLK * NB * NB + LPUB_TILE_DOUBLES + PACKED_TILE_DOUBLES); }
 
 // Kernels that need more than the default dynamic-LDS limit must be opted in once per device (function attributes
 // are per device); called from mage_ba_create after hipSetDevice.
@@ -1650,6 +1748,8 @@ void chol_debug_syrk_stamps(long long* out32, bool reset)
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_syrk_dbg), init, sizeof(init));
     } else (void)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_syrk_dbg), 32 * sizeof(long long));
 }
+
+bool chol_merge_fallback_active() { return g_merge_disabled.load(std::memory_order_relaxed); }
 
 void chol_report_stall(int code)
 {
@@ -1669,9 +1769,9 @@ void chol_init_device()
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_diag + PACKED_TILE_DOUBLES * sizeof(double)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_update2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bsolve_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_panel);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
@@ -1728,33 +1828,8 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
         // reads -27 % (profiles/r03_chol_pmc.txt) -- but the matrix cores are busy 49.7 % of the launch either way and the factorisation
         // takes 2.731 ms against 2.710: the update is not waiting for its operands' misses.  MAGE_CHOL_XCD_BANDS=1 selects it.
         static const bool xcd_bands = std::getenv("MAGE_CHOL_XCD_BANDS") != nullptr;
-        if (bulk2) {
-            // The panel solve of column k + 1 inside this launch (k_syrk_update2<true>), its strip workgroups in the middle of the grid:
-            // the launch takes ~6 + 21.5 us per 512 half-tile tasks, workgroup 0 has tile (k + 1, k + 1) factored and in memory ~45 us in
-            // (it shares its compute unit here), and a strip workgroup needs ~15 us -- so the strips go where the dispatch stands at
-            // ~48 us, but no later than 20 us before the expected end.  MAGE_CHOL_MERGE2=0 restores the separate panel-solve launch.
-            static const bool merge2_env = std::getenv("MAGE_CHOL_MERGE2") && std::atoi(std::getenv("MAGE_CHOL_MERGE2")) != 0;
-            static const double merge2_at_us = std::getenv("MAGE_CHOL_MERGE2_AT_US") ? std::atof(std::getenv("MAGE_CHOL_MERGE2_AT_US")) : 48.0;
-            static const int merge2_dbg = std::getenv("MAGE_CHOL_MERGE2_DBG") ? (std::atoi(std::getenv("MAGE_CHOL_MERGE2_DBG")) & 12) : 0;   // timing experiments (wrong numbers)
-            const int n_task_wgs = 16 * ((n_tiles - 1 + 7) / 8);
-            const bool merge2 = merge2_env && !merge_off && !pipelined_fill && unstaged && !xcd_bands && m >= 2;
-            if (merge2) {
-                const int strip_wgs = 16 * ((2 * (m - 1) + 15) / 16);
-                const double dur_us = 6.0 + 21.5 * (double)(n_task_wgs + strip_wgs) / 512.0;
-                double f = merge2_at_us / dur_us;
-                const double f_max = 1.0 - 20.0 / dur_us;
-                if (f > f_max) f = f_max;
-                if (f < 0.3) f = 0.3;
-                int strip_pos = 16 * (int)(f * n_task_wgs / 16.0);
-                if (strip_pos > n_task_wgs) strip_pos = n_task_wgs;
-                col_total += 2 * (m - 1);
-                hipLaunchKernelGGL(k_syrk_update2<true>, dim3(NDIAG + n_task_wgs + strip_wgs + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
-                                   ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, 1 | merge2_dbg, strip_pos, strip_wgs, col_total);
-                merged = true;
-            } else
-                hipLaunchKernelGGL(k_syrk_update2<false>, dim3(NDIAG + n_task_wgs + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
-                                   ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, (unstaged ? 1 : 0) | (xcd_bands ? 2 : 0), 0, 0, 0);
-        }
+        if (bulk2) hipLaunchKernelGGL(k_syrk_update2, dim3(NDIAG + 16 * ((n_tiles - 1 + 7) / 8) + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
+                                      ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, (unstaged ? 1 : 0) | (xcd_bands ? 2 : 0));
         else {
             merged = !merge_off;
             const int n_whole = n_tiles - 1 - n_q4;
@@ -1767,12 +1842,17 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
             static const bool pipelined = std::getenv("MAGE_CHOL_PIPELINED_TRSM") != nullptr;
             // the write-through form of the chain's two hand-offs (k_syrk_update<1, true>); MAGE_CHOL_WT_HANDOFF=0 restores release / acquire
             static const bool wt_handoff = !(std::getenv("MAGE_CHOL_WT_HANDOFF") && std::atoi(std::getenv("MAGE_CHOL_WT_HANDOFF")) == 0);
+            // the strips as products over the tile's full inverse (k_syrk_update<1, true, true>); MAGE_CHOL_GEMM_STRIPS=0 restores the substitution form
+            static const bool gemm_strips = !(std::getenv("MAGE_CHOL_GEMM_STRIPS") && std::atoi(std::getenv("MAGE_CHOL_GEMM_STRIPS")) == 0);
             const dim3 grid(NDIAG + n_whole + 4 * n_q4 + m + (merged ? (m - 1) * NBLK : 0));
             const int dbg = (ws.dbg && dbg_col == k) ? 1 : 0;
             double* const Linv_next = ws.Linv + (size_t)(k + 1) * linv_stride;
             double* const Lpub_next = ws.Linv + (size_t)nt * linv_stride + (size_t)(k + 1) * LPUB_TILE_DOUBLES;
             if (!merged) hipLaunchKernelGGL(k_syrk_update<0>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next);
             else if (pipelined) hipLaunchKernelGGL(k_syrk_update<2>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next);
+            else if (wt_handoff && gemm_strips)
+                hipLaunchKernelGGL((k_syrk_update<1, true, true>), grid, dim3(256), lds_diag + PACKED_TILE_DOUBLES * sizeof(double), st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync,
+                                   n_q4, col_total, dbg, ws.Linv + (size_t)nt * (linv_stride + LPUB_TILE_DOUBLES) + (size_t)(k + 1) * PACKED_TILE_DOUBLES);
             else if (wt_handoff) hipLaunchKernelGGL((k_syrk_update<1, true>), grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next);
             else hipLaunchKernelGGL(k_syrk_update<1>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next);
         }

@@ -108,7 +108,9 @@ void cached_pinned_release(void* p, size_t bytes);                   // caller g
 struct PinnedArena {
     struct Block { char* p; size_t cap, used; };
     std::vector<Block> blocks;
+    size_t min_block = (size_t)32 << 20;       // the structure build stages tens of MB; small users (a state read-back) say what they need
     PinnedArena() = default;
+    explicit PinnedArena(size_t min_block_bytes) : min_block(min_block_bytes) {}
     PinnedArena(const PinnedArena&) = delete;
     PinnedArena& operator=(const PinnedArena&) = delete;
     ~PinnedArena() { release(); }
@@ -123,7 +125,7 @@ struct PinnedArena {
         const size_t need = (n * sizeof(T) + 255) & ~(size_t)255;
         if (blocks.empty() || blocks.back().used + need > blocks.back().cap) {
             void* q = nullptr; size_t got = 0;
-            MAGE_TRY(cached_pinned_alloc(&q, std::max<size_t>(need, (size_t)32 << 20), &got));
+            MAGE_TRY(cached_pinned_alloc(&q, std::max<size_t>(need, min_block), &got));
             blocks.push_back({ static_cast<char*>(q), got, 0 });
         }
         Block& b = blocks.back();

@@ -67,3 +67,20 @@ def test_two_ranks_under_torchrun_give_the_weak_and_the_strong_record():
     assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["windows_per_rank"] == 4 and s["value"] > 0
     assert s["mse_of_rank0_windows"][-1] < s["mse_of_rank0_windows"][0]
     assert "gloo" in s["exchange"]
+
+
+def test_eight_ranks_on_the_one_gpu_end_without_deadlock():
+    """The command the driver runs on an 8-GPU node, with the eight ranks sharing this box's one GPU (gloo carries the barriers and the
+    pose block): proves the world-8 rank arithmetic -- eight independent sub-maps in `value`, ONE window per rank in `strong_scaling`, every
+    barrier and all-reduce matched -- without the node.  RCCL itself needs a GPU per rank and is not exercised here."""
+    env = dict(os.environ, MAGE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=2400, env=env)
+    assert p.returncode == 0, "\n".join(l for l in p.stderr.splitlines() if not l.startswith(("W0", "E0", "[Gloo]")))[-6000:]
+    d = _line(p.stdout)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and "replica x8" in d["config"]["parallelism"]
+    assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    s = d["strong_scaling"]
+    assert "error" not in s, s
+    assert s["n_gpus"] == 8 and s["windows_per_rank"] == 1 and s["value"] > 0 and len(s["mse_of_rank0_windows"]) >= 3

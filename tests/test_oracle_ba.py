@@ -71,6 +71,35 @@ def test_tethers_between_fixed_cameras_are_inactive():
     np.testing.assert_array_equal(ref.poses_f64(), o.poses_f64())
 
 
+def test_returned_mean_error_leaves_tether_edges_out():
+    """The pinned choice of DESIGN.md "tether edges" / INTEGRATION.md section 1: the value StepBundleAdjustment returns is the mean
+    squared reprojection error over the OBSERVATION edges that stay (behind-camera / above-threshold ones removed).  The reference's
+    loop also walks the tether edges (BundlerLib.cpp:386-425) -- through a mis-typed vertex cast whose outcome is undefined -- and
+    adds the squared error of those that happen to pass to the sum AND to the count; that part is not reproduced.  Checked from the
+    oracle's own per-observation residuals: with and without the tethers' pull the returned value is exactly sum / count over
+    observations, and the tethers never appear in the outlier list."""
+    s = scene.make_config("tiny", outlier_frac=0.02)
+    s.tethers = scene.make_tethers(s, n_dist=3, n_rot=2, n_xf=2)
+    o = OracleBundler(False)
+    load_scene(o, s)
+    out = []
+    thr = 9.0
+    mse = o.StepBundleAdjustment([1.8], thr, out)
+    e = o.errors()                                          # residuals of the last error evaluation, per observation (n_obs x 2)
+    ss = (e * e).sum(axis=1)
+    removed = np.zeros(s.n_obs, bool); removed[out] = True
+    assert removed.any() and all(0 <= i < s.n_obs for i in out)          # only observation indices are ever reported
+    kept = ss[~removed]
+    assert (kept <= thr).all()
+    assert mse == pytest.approx(float(np.float32(kept.sum() / kept.size)), rel=1e-6)
+    # the tethers did act on the solve (same scene without them ends elsewhere) -- they are left out of the RETURN VALUE only
+    s2 = scene.make_config("tiny", outlier_frac=0.02)
+    o2 = OracleBundler(False)
+    load_scene(o2, s2)
+    o2.StepBundleAdjustment([1.8], thr, [])
+    assert not np.allclose(o.poses_f64(), o2.poses_f64(), rtol=0, atol=1e-9)
+
+
 def test_oracle_matches_independent_numpy_live():
     s = scene.make_scene(n_cams=8, n_pts=150, n_obs=1200, seed=77, outlier_frac=0.03)
     o, n = OracleBundler(), NumpyBundler(s)

@@ -208,6 +208,8 @@ def _run_rccl(tmp_path, world, scene_path, steps, huber, thr, tag):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if world == 1:
+            env["MAGE_ALLOW_SINGLE_RANK"] = "1"          # a one-rank communicator on purpose (the tool refuses an accidental one)
         procs.append(subprocess.Popen([exe, scene_path, str(steps), str(huber), str(thr), idf, outp], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = []
@@ -235,14 +237,28 @@ def test_cpp_driver_with_rccl(tmp_path):
     calls = [([0.9], 16.0)] * 3
     ref = _single(s, calls)
     info, poses, points = _run_rccl(tmp_path, 1, path, 3, 0.9, 16.0, "w1")
+    assert info["comm_nranks"] == 1 and info["world"] == 1
     assert np.array_equal(poses[0], ref["poses"]) and np.array_equal(points, ref["points"])
     assert info["own_outliers"] == sum(len(o) for o in ref["outliers"]) and info["allreduce_calls"] > 0
     assert info["mse"] == pytest.approx(ref["mse"], rel=1e-6)
     if _gpu_count() >= 2:
         info, poses, points = _run_rccl(tmp_path, 2, path, 3, 0.9, 16.0, "w2")
+        assert info["comm_nranks"] == 2
         res = sharded.solve_on_threads(s, 2, BundlerLib, _bulk, calls)
         assert np.array_equal(poses[0], poses[1])
         assert np.array_equal(poses[0], res["poses"][0]) and np.array_equal(points, res["points"])
+
+
+def test_cpp_driver_refuses_an_accidental_single_rank(tmp_path):
+    """A run meant to be collective that comes up with ONE rank (no WORLD_SIZE in the environment) must not pass vacuously."""
+    exe = os.path.join(ROOT, "tools", "_bin", "sharded_rccl")
+    if not os.path.exists(exe):
+        pytest.skip("tools/_bin/sharded_rccl was not built (no RCCL on the build machine)")
+    path = str(tmp_path / "scene.bin")
+    scene.save_scene(scene.make_scene(**PROC_SCENE), path)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MAGE_ALLOW_SINGLE_RANK")}
+    p = subprocess.run([exe, path, "1", "0.9", "16.0", str(tmp_path / "id_x"), str(tmp_path / "state_x")], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3 and "ONE rank" in p.stderr, (p.returncode, p.stderr[-500:])
 
 
 WORKER = textwrap.dedent("""

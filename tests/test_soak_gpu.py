@@ -1,0 +1,88 @@
+"""GPU test (-m gpu): a timed soak of the dense solve's in-launch hand-offs.
+
+Two LARGE handles (1 000 poses: 47 tile columns -- the split diagonal tile, the merged panel solves on the write-through hand-off and
+the persistent backward solve all run) are stepped from two threads beside an ORB detector and a matcher for MAGE_SOAK_SECONDS
+(default 60) in ONE process, the deployment of DESIGN.md section 8.  What must hold: no step raises, every step is finite, and the two
+health counters of mage_ba_profile -- `trials_rerun_after_stall`, `fallback_to_separate_launches` -- stay 0: a bounded wait that runs
+out inside one process would be a bug, not load (Tasks/Runtime.cpp:512-632 runs tracking, mapping and loop-closure bundlers
+concurrently, so this is the reference's normal condition)."""
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from mageslam_amd import frames, scene
+from mageslam_amd.bundler import BundlerLib, load_scene
+from mageslam_amd.orb import Matcher, OrbDetector
+
+pytestmark = pytest.mark.gpu
+
+SECONDS = float(os.environ.get("MAGE_SOAK_SECONDS", "60"))
+
+
+def test_two_large_handles_orb_and_matcher_soak():
+    scenes = [scene.make_scene(n_cams=1000, n_pts=100000, n_obs=1000000, seed=0x5EED0004 + 0x100 * i) for i in range(2)]
+    handles = []
+    for s in scenes:
+        b = BundlerLib(False)
+        load_scene(b, s, bulk=True)
+        b.SetCurrentLambda(5e6)
+        b.StepBundleAdjustment([1.8], 1e30, [])               # structure build + first iteration
+        handles.append(b)
+    assert handles[0].profile().padded_order == 6016
+    fr = [frames.frame_pair(700 + i) for i in range(4)]
+    det, mt = OrbDetector(), Matcher()
+    ref = [det.DetectAndCompute(f[0]) for f in fr]
+    ref_b = [det.DetectAndCompute(f[1]) for f in fr]
+    ref_m = [mt.Match(ref[i][1], ref_b[i][1], None, None, 30, 1) for i in range(4)]
+
+    stop = time.perf_counter() + SECONDS
+    errors, steps, frames_done = [], [0, 0], [0]
+
+    def ba(i):
+        try:
+            k = 0
+            while time.perf_counter() < stop:
+                mse = handles[i].StepBundleAdjustment([1.8], 1e30, [])
+                if not np.isfinite(mse):
+                    errors.append((i, k, "non-finite mean square error"))
+                    return
+                k += 1
+                if k % 25 == 0:                               # keep the iterations single-trial-ish: start the damping over now and then
+                    handles[i].SetCurrentLambda(5e6)
+            steps[i] = k
+        except BaseException as e:  # noqa: BLE001
+            errors.append((i, "ba", repr(e)))
+
+    def front():
+        try:
+            d, m = OrbDetector(), Matcher()
+            k = 0
+            while time.perf_counter() < stop:
+                j = k % 4
+                a, b = d.DetectAndCompute(fr[j][0]), d.DetectAndCompute(fr[j][1])
+                if not (np.array_equal(a[1], ref[j][1]) and np.array_equal(b[1], ref_b[j][1])):
+                    errors.append(("orb", k, "descriptors changed under load"))
+                    return
+                if not np.array_equal(m.Match(a[1], b[1], None, None, 30, 1), ref_m[j]):
+                    errors.append(("match", k, "matches changed under load"))
+                    return
+                k += 1
+            frames_done[0] = k
+        except BaseException as e:  # noqa: BLE001
+            errors.append(("front", repr(e)))
+
+    th = [threading.Thread(target=ba, args=(0,)), threading.Thread(target=ba, args=(1,)), threading.Thread(target=front)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+    assert min(steps) > 20 and frames_done[0] > 20, (steps, frames_done)
+    for b in handles:
+        p = b.profile()
+        assert p.trials_rerun_after_stall == 0 and p.fallback_to_separate_launches == 0, (p.trials_rerun_after_stall, p.fallback_to_separate_launches)
+        b.close()
+    print(f"soak: {SECONDS:.0f} s, LM iterations {steps}, frame pairs {frames_done[0]}, stall counters 0 / 0")

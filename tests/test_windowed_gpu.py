@@ -122,6 +122,8 @@ def _run_rccl(tmp_path, world, scene_path, n_windows, overlap, iters, threads, t
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if world == 1:
+            env["MAGE_ALLOW_SINGLE_RANK"] = "1"          # a one-rank communicator on purpose (the tool refuses an accidental one)
         procs.append(subprocess.Popen([exe, scene_path, str(n_windows), str(overlap), str(iters), "1.8", str(threads), idf, outp],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
@@ -142,10 +144,11 @@ def test_rccl_driver_equals_python_driver(tmp_path):
     path = str(tmp_path / "scene.bin")
     scene.save_scene(scene.make_scene(**SCENE), path)
     info, blocks = _run_rccl(tmp_path, 1, path, 4, 2, 6, 2, "w1")
-    assert info["allreduce_calls"] == 6 and info["mse_rank0"] == pytest.approx(ep, rel=1e-7)
+    assert info["allreduce_calls"] == 6 and info["mse_rank0"] == pytest.approx(ep, rel=1e-7) and info["comm_nranks"] == 1
     assert _sha(blocks[0]) == want
     if _gpu_count() >= 2:
         info, blocks = _run_rccl(tmp_path, 2, path, 4, 2, 6, 1, "w2")
+        assert info["comm_nranks"] == 2
         assert _sha(blocks[0]) == want and _sha(blocks[1]) == want
 
 

@@ -68,6 +68,17 @@ int main(int argc, char** argv)
     }
     Reduce red{};
     CHECK_NCCL(ncclCommInitRank(&red.comm, world, id, rank));
+    // What the communicator really spans is reported in the result line, and a run that was meant to be collective but came up with
+    // ONE rank (WORLD_SIZE missing from the environment, a launcher that started the ranks separately) is refused instead of passing
+    // vacuously: a single rank's all-reduce is a copy.  MAGE_ALLOW_SINGLE_RANK=1 is how the one-GPU tests ask for that on purpose.
+    int comm_nranks = 0;
+    CHECK_NCCL(ncclCommCount(red.comm, &comm_nranks));
+    if (comm_nranks != world) { std::fprintf(stderr, "rank %d: the communicator has %d ranks, WORLD_SIZE says %d\n", rank, comm_nranks, world); return 1; }
+    if (comm_nranks < 2 && !(std::getenv("MAGE_ALLOW_SINGLE_RANK") && std::atoi(std::getenv("MAGE_ALLOW_SINGLE_RANK")) != 0)) {
+        std::fprintf(stderr, "the communicator has ONE rank: nothing would be exchanged (set RANK / WORLD_SIZE / LOCAL_RANK per process, or "
+                             "MAGE_ALLOW_SINGLE_RANK=1 to run a single rank on purpose)\n");
+        return 3;
+    }
 
     SceneFile s;
     try { s = read_scene(argv[1]); } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 1; }
@@ -122,8 +133,8 @@ int main(int argc, char** argv)
         (rows.size() && std::fwrite(rows.data(), sizeof(double), rows.size(), f) != rows.size())) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
     std::fclose(f);
     if (rank == 0) {
-        std::printf("{\"world\": %d, \"steps\": %d, \"allreduce_calls\": %lu, \"exchanged_bytes\": %zu, \"ms_total\": %.3f, \"own_points\": %zu, \"own_outliers\": %zu, \"mse\": [",
-                    world, steps, red.calls, red.doubles * 8, ms, pt_global.size(), n_out_total);
+        std::printf("{\"world\": %d, \"comm_nranks\": %d, \"steps\": %d, \"allreduce_calls\": %lu, \"exchanged_bytes\": %zu, \"ms_total\": %.3f, \"own_points\": %zu, \"own_outliers\": %zu, \"mse\": [",
+                    world, comm_nranks, steps, red.calls, red.doubles * 8, ms, pt_global.size(), n_out_total);
         for (int it = 0; it < steps; ++it) std::printf("%s%.9g", it ? ", " : "", (double)mse[it]);
         std::printf("]}\n");
     }

@@ -66,6 +66,17 @@ int main(int argc, char** argv)
     }
     Reduce red{};
     CHECK_NCCL(ncclCommInitRank(&red.comm, world, id, rank));
+    // What the communicator really spans is reported in the result line, and a run that was meant to be collective but came up with
+    // ONE rank (WORLD_SIZE missing from the environment, a launcher that started the ranks separately) is refused instead of passing
+    // vacuously: a single rank's all-reduce is a copy.  MAGE_ALLOW_SINGLE_RANK=1 is how the one-GPU tests ask for that on purpose.
+    int comm_nranks = 0;
+    CHECK_NCCL(ncclCommCount(red.comm, &comm_nranks));
+    if (comm_nranks != world) { std::fprintf(stderr, "rank %d: the communicator has %d ranks, WORLD_SIZE says %d\n", rank, comm_nranks, world); return 1; }
+    if (comm_nranks < 2 && !(std::getenv("MAGE_ALLOW_SINGLE_RANK") && std::atoi(std::getenv("MAGE_ALLOW_SINGLE_RANK")) != 0)) {
+        std::fprintf(stderr, "the communicator has ONE rank: nothing would be exchanged (set RANK / WORLD_SIZE / LOCAL_RANK per process, or "
+                             "MAGE_ALLOW_SINGLE_RANK=1 to run a single rank on purpose)\n");
+        return 3;
+    }
 
     SceneFile s;
     try { s = read_scene(argv[1]); } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 1; }
@@ -89,8 +100,8 @@ int main(int argc, char** argv)
     if (!f || std::fwrite(block.data(), sizeof(double), block.size(), f) != block.size()) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
     std::fclose(f);
     if (rank == 0) {
-        std::printf("{\"world\": %d, \"n_windows\": %d, \"outer_iterations\": %d, \"allreduce_calls\": %lu, \"exchange_bytes\": %zu, \"ms_total\": %.3f, \"mse_rank0\": [",
-                    world, n_windows, iters, red.calls, (size_t)s.n_cams * 64, ms);
+        std::printf("{\"world\": %d, \"comm_nranks\": %d, \"n_windows\": %d, \"outer_iterations\": %d, \"allreduce_calls\": %lu, \"exchange_bytes\": %zu, \"ms_total\": %.3f, \"mse_rank0\": [",
+                    world, comm_nranks, n_windows, iters, red.calls, (size_t)s.n_cams * 64, ms);
         for (int it = 0; it < iters; ++it) std::printf("%s%.9g", it ? ", " : "", mse[it]);
         std::printf("]}\n");
     }
