@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -272,12 +273,23 @@ struct mage_ba {
     DevBuf<double> d_T_meas, d_T_w, d_T_out;
     int n_active_tethers = 0;
     DevBuf<int> d_queue;
+    DevBuf<int> d_tile_env;            // the skyline of S by tile rows (k_zero_skyline)
+    bool tile_env_valid = false;       // d_tile_env describes the CURRENT structure
+    bool S_outside_skyline_is_zero = false;   // every tile of S left of its row's envelope holds zeros (true after a clear + a factorisation that produced no NaN)
     // ---- device build of the structure (ba_build.h): the raw records and its scratch
     DevBuf<ObsRecord> d_obs_raw; DevBuf<uint8_t> d_cam_fixed; DevBuf<int> d_cam_extra;
     DevBuf<int> d_b_pt2lm, d_b_L_hc, d_b_L_lm, d_b_where, d_b_hist, d_b_w_end;
     DevBuf<unsigned long long> d_b_bucket, d_b_scan, d_b_row;
     DevBuf<unsigned char> d_b_zeroed;             // [BuildCounts | cam_deg | pt_deg]: cleared by one fill
     bool built_on_device = false;
+    // ---- small problems built on the host: every list and every work array is a view into ONE device buffer filled by ONE copy of the
+    // pinned arena they were built in (ImageStager below)
+    DevBuf<unsigned char> d_image;
+    struct ImageStager {
+        bool on = false;
+        size_t scratch = 0;                                               // device-only bytes behind the uploaded part
+        std::vector<std::function<void(unsigned char* dev, const char* host, size_t up_bytes)>> binds;
+    } img;
     // ---- the tracker's per-frame problems (frame_step below): one image up, one launch, one record back; no structure stays on the device
     DevBuf<unsigned char> d_frame;
     void* h_frame = nullptr; size_t h_frame_bytes = 0;     // pinned (from the cache): the image and, behind it, the record that comes back
@@ -339,6 +351,59 @@ void ensure_obs_filled(mage_ba* h)
 constexpr size_t OUT_PREFIX = 4096;      // outlier ids copied back together with the post-pass scalars (16 KB); a longer list takes a second copy
 constexpr size_t SC_PAD = 16;            // doubles reserved for the scalars in d_scal / the pinned mirror; the outlier ids follow
 static_assert(SC_COUNT <= SC_PAD, "scalar block");
+
+// ---- uploads and work arrays of a structure build.  Normally each is a device buffer of its own and a copy (or fill) of its own --
+// forty small operations on the stream for a 2 000-observation local BA, ~5 us each whatever they move.  In IMAGE mode (h->img.on:
+// small problems built on the host) nothing touches the device until the build is over: every list was built in the pinned arena,
+// every work array is given an offset, and stage_commit() reserves ONE device buffer, makes each DevBuf a view into it and copies
+// the arena's block with ONE DMA (arrays that must start as zeros / ones are filled in the arena and ride the same copy).
+template <typename T>
+mage_status stage_push(mage_ba* h, DevBuf<T>& d, const T* src_pinned, size_t count)
+{
+    if (h->img.on) {
+        h->img.binds.push_back([&d, src_pinned, count](unsigned char* dev, const char* host, size_t) {
+            d.alias(reinterpret_cast<T*>(dev + (reinterpret_cast<const char*>(src_pinned) - host)), count);
+        });
+        return MAGE_OK;
+    }
+    MAGE_TRY(d.reserve(count));
+    if (count) MAGE_HIP(hipMemcpyAsync(d.p, src_pinned, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return MAGE_OK;
+}
+// work array of `count` elements; fill >= 0: every byte starts as `fill`
+template <typename T>
+mage_status stage_array(mage_ba* h, DevBuf<T>& d, size_t count, int fill = -1)
+{
+    if (h->img.on) {
+        if (fill >= 0) {
+            T* q = nullptr;
+            MAGE_TRY(h->build_arena.take(count, &q));
+            std::memset(q, fill, count * sizeof(T));
+            return stage_push(h, d, q, count);
+        }
+        const size_t off = h->img.scratch;
+        h->img.scratch += (count * sizeof(T) + 255) & ~(size_t)255;
+        h->img.binds.push_back([&d, off, count](unsigned char* dev, const char*, size_t up_bytes) { d.alias(reinterpret_cast<T*>(dev + up_bytes + off), count); });
+        return MAGE_OK;
+    }
+    MAGE_TRY(d.reserve(count));
+    if (fill >= 0 && count) MAGE_HIP(hipMemsetAsync(d.p, fill, count * sizeof(T), h->stream));
+    return MAGE_OK;
+}
+mage_status stage_commit(mage_ba* h)
+{
+    if (!h->img.on) return MAGE_OK;
+    PinnedArena& A = h->build_arena;
+    if (A.blocks.size() != 1) return fail(MAGE_ERR_DEVICE, "small-problem image: the staging arena spilled into %zu blocks", A.blocks.size());
+    const size_t up = (A.blocks[0].used + 255) & ~(size_t)255;
+    // views of an earlier image are about to be re-pointed, memory an earlier (larger) build owned goes back to the cache: nothing of it may be in flight
+    MAGE_HIP(hipStreamSynchronize(h->stream));
+    MAGE_TRY(h->d_image.reserve(up + h->img.scratch + 256));
+    for (auto& b : h->img.binds) b(h->d_image.p, A.blocks[0].p, up);
+    h->img.binds.clear();
+    MAGE_HIP(hipMemcpyAsync(h->d_image.p, A.blocks[0].p, A.blocks[0].used, hipMemcpyHostToDevice, h->stream));
+    return MAGE_OK;
+}
 
 mage_status ensure_pinned_mirrors(mage_ba* h)
 {
@@ -423,11 +488,20 @@ mage_status upload_state(mage_ba* h, PinnedArena* arena = nullptr)
         for (int a = 0; a < 3; ++a) pts[i * 4 + a] = h->pts[i * 3 + a];
         pts[i * 4 + 3] = 0.0;
     }
-    for (int b = 0; b < 2; ++b) {
-        MAGE_TRY(h->d_pose[b].upload(pose, nc * 8, h->stream));
-        MAGE_TRY(h->d_pt[b].upload(pts, np * 4, h->stream));
+    if (h->img.on && arena) {                   // image mode: each device array is a view of ITS part of the arena -- the second state buffer needs its own copy
+        double *pose2 = nullptr, *pts2 = nullptr;
+        MAGE_TRY(A.take(nc * 8 + 1, &pose2)); MAGE_TRY(A.take(np * 4 + 1, &pts2));
+        std::memcpy(pose2, pose, nc * 8 * sizeof(double)); std::memcpy(pts2, pts, np * 4 * sizeof(double));
+        MAGE_TRY(stage_push(h, h->d_pose[0], pose, nc * 8)); MAGE_TRY(stage_push(h, h->d_pose[1], pose2, nc * 8));
+        MAGE_TRY(stage_push(h, h->d_pt[0], pts, np * 4)); MAGE_TRY(stage_push(h, h->d_pt[1], pts2, np * 4));
+        MAGE_TRY(stage_push(h, h->d_camK, K, nc * 4));
+    } else {
+        for (int b = 0; b < 2; ++b) {
+            MAGE_TRY(h->d_pose[b].upload(pose, nc * 8, h->stream));
+            MAGE_TRY(h->d_pt[b].upload(pts, np * 4, h->stream));
+        }
+        MAGE_TRY(h->d_camK.upload(K, nc * 4, h->stream));
     }
-    MAGE_TRY(h->d_camK.upload(K, nc * 4, h->stream));
     if (!arena) MAGE_HIP(hipStreamSynchronize(h->stream));
     h->cur = 0;
     h->state_on_device = true;
@@ -498,7 +572,10 @@ bool use_device_build(const mage_ba* h, size_t n_obs)
     const char* e = std::getenv("MAGE_BA_BUILD");
     if (e && e[0] == 'h') return false;
     if (e && e[0] == 'd') return true;
-    return !h->points_fixed && n_obs >= 1024;
+    // (round 4: with the host-built lists going up as ONE image -- ImageStager -- the host build wins up to a few thousand observations:
+    // what a small problem pays for is the NUMBER of operations on the stream, ~40 for the device build's kernels, fills and read-backs)
+    static const size_t host_max = std::getenv("MAGE_BA_HOST_BUILD_MAX_OBS") ? (size_t)std::atol(std::getenv("MAGE_BA_HOST_BUILD_MAX_OBS")) : 4096;
+    return !h->points_fixed && n_obs >= host_max;
 }
 
 // The lists on the host (the A/B twin of ba_build.hip): SparseOptimizer::initializeOptimization + BlockSolver::buildStructure,
@@ -532,12 +609,7 @@ mage_status build_lists_host(mage_ba* h, PinnedArena& arena, const std::vector<i
     const bool points_free = !h->points_fixed;
 
     tm.mark("active sets");
-    hipStream_t st = h->stream;
-    auto push = [&](auto& dbuf, const auto* src, size_t count) -> mage_status {
-        MAGE_TRY(dbuf.reserve(count));
-        if (count) MAGE_HIP(hipMemcpyAsync(dbuf.p, src, count * sizeof(*src), hipMemcpyHostToDevice, st));
-        return MAGE_OK;
-    };
+    auto push = [&](auto& dbuf, const auto* src, size_t count) -> mage_status { return stage_push(h, dbuf, src, count); };
     auto push_vec = [&](auto& dbuf, const auto& vec) -> mage_status {
         typename std::remove_reference<decltype(vec)>::type::value_type* q = nullptr;
         MAGE_TRY(arena.take(vec.size(), &q));
@@ -872,6 +944,12 @@ mage_status initialize_optimization(mage_ba* h)
     ensure_obs_filled(h);
     PinnedArena& arena = h->build_arena;
     if (!arena.blocks.empty()) { MAGE_HIP(hipStreamSynchronize(h->stream)); arena.release(); }
+    const bool on_device = use_device_build(h, h->obs.size());
+    // small problems built on the host go to the device as ONE image (stage_push / stage_array / stage_commit above)
+    static const bool image_off = std::getenv("MAGE_BA_NO_IMAGE") != nullptr;
+    h->img.on = !on_device && !image_off && !h->state_on_device && h->shard_ranks == 0 && h->obs.size() <= 65536 && nc <= 4096 && np <= 65536;
+    h->img.scratch = 0; h->img.binds.clear();
+    struct ImageOff { mage_ba* h; ~ImageOff() { h->img.on = false; h->img.binds.clear(); } } image_off_at_exit{ h };      // every exit leaves the mode off
     if (!h->state_on_device) MAGE_TRY(upload_state(h, &arena));
     else {
         // Trials only write the entities that are in the system, and accepting a trial swaps the two
@@ -904,7 +982,6 @@ mage_status initialize_optimization(mage_ba* h)
     ListSizes Z;
     std::vector<int> cam2hc;
     std::vector<uint32_t> L_edge;
-    const bool on_device = use_device_build(h, h->obs.size());
     if (on_device) MAGE_TRY(build_lists_device(h, arena, cam_extra_deg, nT > 0, tm, Z, cam2hc));
     else MAGE_TRY(build_lists_host(h, arena, cam_extra_deg, tm, Z, cam2hc, L_edge));
     const int nL = Z.nL, nfc = Z.nfc, nlm = Z.nlm, nw = Z.nw, nblk = Z.nblk;
@@ -917,11 +994,7 @@ mage_status initialize_optimization(mage_ba* h)
         h->useless = false;              // a rank without landmarks still takes part in every exchange
     }
     hipStream_t st = h->stream;
-    auto push = [&](auto& dbuf, const auto* src, size_t count) -> mage_status {
-        MAGE_TRY(dbuf.reserve(count));
-        if (count) MAGE_HIP(hipMemcpyAsync(dbuf.p, src, count * sizeof(*src), hipMemcpyHostToDevice, st));
-        return MAGE_OK;
-    };
+    auto push = [&](auto& dbuf, const auto* src, size_t count) -> mage_status { return stage_push(h, dbuf, src, count); };
     auto push_vec = [&](auto& dbuf, const auto& vec) -> mage_status {
         typename std::remove_reference<decltype(vec)>::type::value_type* q = nullptr;
         MAGE_TRY(arena.take(vec.size(), &q));
@@ -975,39 +1048,37 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(push_vec(h->d_tp_ij, tp_ij));
     MAGE_TRY(push_vec(h->d_tp_ptr, tp_ptr));
     MAGE_TRY(push_vec(h->d_tp_item, tp_item));
-    MAGE_TRY(h->d_T_out.reserve((size_t)nT * TETHER_OUT_STRIDE + 1));
+    MAGE_TRY(stage_array(h, h->d_T_out, (size_t)nT * TETHER_OUT_STRIDE + 1));
 
     tm.mark("uploads queued");
     if (n_pad > CHOL_MAX_ORDER) return fail(MAGE_ERR_UNSUPPORTED, "reduced camera system of order %d exceeds %d (one resident workgroup per tile column)", n_pad, CHOL_MAX_ORDER);
     const int nb_l = (nlm + 255) / 256, nb_c = (nfc + 255) / 256;
-    MAGE_TRY(h->d_errL.reserve((size_t)nL * 2 + 2));
-    MAGE_TRY(h->d_U.reserve((size_t)nfc * 36 + 1));
-    MAGE_TRY(h->d_bc.reserve((size_t)nfc * 6 + 1));
-    MAGE_TRY(h->d_camR.reserve((size_t)nfc * 12 + 2));
-    MAGE_TRY(h->d_V.reserve((size_t)nlm * 6 + 1));
-    MAGE_TRY(h->d_bp.reserve((size_t)nlm * 4 + 1));
-    MAGE_TRY(h->d_W.reserve((size_t)nw * 18 + 1));
-    MAGE_TRY(h->d_Dinv.reserve((size_t)nlm * 6 + 1));
-    MAGE_TRY(h->d_db.reserve((size_t)nlm * 4 + 1));
-    MAGE_TRY(h->d_S.reserve((size_t)n_pad * n_pad));
-    MAGE_TRY(h->d_y.reserve(n_pad));
+    MAGE_TRY(stage_array(h, h->d_errL, (size_t)nL * 2 + 2, 0));                // residuals of never-evaluated edges are 0
+    MAGE_TRY(stage_array(h, h->d_U, (size_t)nfc * 36 + 1));
+    MAGE_TRY(stage_array(h, h->d_bc, (size_t)nfc * 6 + 1));
+    MAGE_TRY(stage_array(h, h->d_camR, (size_t)nfc * 12 + 2));
+    MAGE_TRY(stage_array(h, h->d_V, (size_t)nlm * 6 + 1));
+    MAGE_TRY(stage_array(h, h->d_bp, (size_t)nlm * 4 + 1));
+    MAGE_TRY(stage_array(h, h->d_W, (size_t)nw * 18 + 1));
+    MAGE_TRY(stage_array(h, h->d_Dinv, (size_t)nlm * 6 + 1));
+    MAGE_TRY(stage_array(h, h->d_db, (size_t)nlm * 4 + 1));
+    MAGE_TRY(stage_array(h, h->d_S, (size_t)n_pad * n_pad));
+    MAGE_TRY(stage_array(h, h->d_y, (size_t)n_pad));
     if (h->shard_ranks > 0) MAGE_TRY(h->d_xchg.reserve(ba_packed_doubles(n_pad)));
-    MAGE_TRY(h->d_xc.reserve(n_pad));
-    MAGE_TRY(h->d_xl.reserve((size_t)nlm * 4 + 1));
+    MAGE_TRY(stage_array(h, h->d_xc, (size_t)n_pad));
+    MAGE_TRY(stage_array(h, h->d_xl, (size_t)nlm * 4 + 1));
     // two-level reductions: one double per block of the widest launch; the small-problem linearisation (8 lanes per landmark, 4 blocks
     // per camera) also parks the cameras' partial (U, b_c) sums behind its chi2 partials
-    MAGE_TRY(h->d_partial.reserve(std::max<size_t>(4 * 1024, std::max<size_t>((size_t)nb_l + nb_c, (size_t)nlm * 16 / 256 + (size_t)nfc * 4 * 29 + 8)) + 16));          // (the fused large-problem form needs nlm / 32 + nfc entries: covered)
-    MAGE_TRY(h->d_scal.reserve(SC_PAD + ((size_t)nL + 2) / 2 + 1));          // scalars, then up to n_L outlier ids (32-bit)
-    h->d_out_ids = reinterpret_cast<uint32_t*>(h->d_scal.p + SC_PAD);
-    h->out_cursor = 0;                                                        // d_queue (with the cursor) is zeroed below
-    MAGE_TRY(h->d_Linv.reserve(chol_workspace_doubles(n_pad)));
-    MAGE_TRY(h->d_queue.reserve(chol_sync_ints(n_pad) + 2));                                          // + the small-path counter + the outlier cursor
-    MAGE_HIP(hipMemsetAsync(h->d_queue.p, 0, (chol_sync_ints(n_pad) + 2) * sizeof(int), st));       // recycled memory arrives dirty
-    MAGE_TRY(h->d_flagL.reserve((size_t)nL + 1));
-    MAGE_TRY(h->d_L_active.reserve((size_t)nL + 1));
-    MAGE_HIP(hipMemsetAsync(h->d_L_active.p, 1, (size_t)nL + 1, st));
+    MAGE_TRY(stage_array(h, h->d_partial, std::max<size_t>(4 * 1024, std::max<size_t>((size_t)nb_l + nb_c, (size_t)nlm * 16 / 256 + (size_t)nfc * 4 * 29 + 8)) + 16));          // (the fused large-problem form needs nlm / 32 + nfc entries: covered)
+    MAGE_TRY(stage_array(h, h->d_scal, SC_PAD + ((size_t)nL + 2) / 2 + 1));          // scalars, then up to n_L outlier ids (32-bit)
+    h->out_cursor = 0;                                                        // d_queue (with the cursor) starts as zeros
+    MAGE_TRY(stage_array(h, h->d_Linv, chol_workspace_doubles(n_pad)));
+    MAGE_TRY(stage_array(h, h->d_queue, chol_sync_ints(n_pad) + 2, 0));      // + the small-path counter + the outlier cursor; recycled memory arrives dirty
+    MAGE_TRY(stage_array(h, h->d_flagL, (size_t)nL + 1));
+    MAGE_TRY(stage_array(h, h->d_L_active, (size_t)nL + 1, 1));
     MAGE_TRY(ensure_pinned_mirrors(h));
-    MAGE_HIP(hipMemsetAsync(h->d_errL.p, 0, ((size_t)nL * 2 + 2) * sizeof(double), st));
+    MAGE_TRY(stage_commit(h));                                                // image mode: one buffer, one copy; every DevBuf above is a view from here on
+    h->d_out_ids = reinterpret_cast<uint32_t*>(h->d_scal.p + SC_PAD);
 
     tm.mark("reserve");
     BaDeviceView& v = h->view;
@@ -1029,6 +1100,16 @@ mage_status initialize_optimization(mage_ba* h)
     v.Dinv = h->d_Dinv.p; v.db = h->d_db.p; v.S = h->d_S.p; v.y = h->d_y.p; v.xc = h->d_xc.p; v.xl = h->d_xl.p;
     v.partial = h->d_partial.p; v.scal = h->d_scal.p;
     refresh_view_state(h);
+    // the skyline of S (large systems that are not sharded: a rank does not know the other ranks' blocks); S itself may be a recycled
+    // buffer, so the first trial clears all of it
+    v.tile_env = nullptr;
+    h->S_outside_skyline_is_zero = false;
+    static const bool skyline_off = std::getenv("MAGE_BA_ZERO_FULL") != nullptr;
+    if (n_pad >= 1024 && h->shard_ranks == 0 && !skyline_off) {
+        MAGE_TRY(h->d_tile_env.reserve((size_t)n_pad / CHOL_TILE + 1));
+        ba_launch_tile_envelope(v, h->d_tile_env.p, st);
+        h->tile_env_valid = true;
+    } else h->tile_env_valid = false;
     h->L_edge_host.swap(L_edge);          // device build: empty, fetched if the pose-only path ever needs it (mage_ba_step)
     h->built_on_device = on_device;
     h->prof.system_order = n; h->prof.padded_order = n_pad;
@@ -1152,7 +1233,9 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
                 speculated = true;
             }
         } else {
+            v.tile_env = (h->S_outside_skyline_is_zero && h->tile_env_valid && !sharded) ? h->d_tile_env.p : nullptr;
             ba_launch_schur(v, lambda, adds_damping ? lambda : 0.0, adds_damping ? 1.0 : 0.0, st);
+            h->S_outside_skyline_is_zero = false;          // until this trial's factorisation is known to have produced no NaN (below)
             if (sharded) {
                 ba_launch_pack_lower(v, h->d_xchg.p, true, st);
                 MAGE_TRY(all_reduce(h->d_xchg.p, ba_packed_doubles(v.n_pad), 0));
@@ -1220,6 +1303,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
         }
         if (seed_on_device) { h->lambda = 1e-5 * h->h_scal[SC_MAXDIAG]; seed_on_device = false; }      // the value the device used (the same product)
         const bool ok2 = h->h_scal[SC_CHOL_OK] != 0.0;
+        if (!small && ok2) h->S_outside_skyline_is_zero = true;      // S was cleared (at least its skyline, over zeros elsewhere) and factored without a NaN: the zeros outside the skyline survived
         if (!have_chi) { currentChi = h->h_scal[SC_CHI]; tr.chi2_before = currentChi; have_chi = true; }
         double tempChi = h->h_scal[SC_CHI_TRIAL];
         if (!ok2) { tempChi = DBL_MAX; rho = -1.0; }       // the reference's failed-solve branch: always rejected

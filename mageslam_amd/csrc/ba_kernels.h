@@ -66,6 +66,8 @@ struct BaDeviceView {
     int compact;           // 1: large problems without shared slots keep W in that form (set per LM iteration by the host)
     double* camR;          // n_fc x 12 : f and the rotation R (row-major) of every free camera at the linearisation point (COMPACT form)
     double* Dinv; double* db;  // n_lm x 6, n_lm x 4
+    const int* tile_env;   // per 128-row tile row R of S: the first tile column that can ever hold a non-zero (structure + fill-in stay inside this
+                           // skyline); non-null only while every tile left of it is KNOWN to hold zeros: the zero-fill then clears the skyline alone
     double* S;             // n_pad x n_pad column-major, lower triangle valid
     double* y;             // n_pad : reduced rhs b_s (forward-substituted in place by the factorisation)
     double* xc;            // n_pad : camera increments x_c
@@ -89,6 +91,7 @@ void ba_launch_error(const BaDeviceView& v, bool trial, double huber_delta, hipS
 void ba_launch_linearize(const BaDeviceView& v, double huber_delta, hipStream_t st);                 // U,bc,V,bp,W
 void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st, const double* udiag_sum = nullptr);                                       // -> scal[SC_MAXDIAG]
 void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st);                          // Dinv,db,S,y
+void ba_launch_tile_envelope(const BaDeviceView& v, int* tile_env, hipStream_t st);                  // the skyline of S by tile rows, from blk_ij and the tether pairs
 void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st);                         // xl, trial state, scal[SC_SCALE]
 // landmark-sharded maps (include/mage_ba.h: mage_ba_set_landmark_shard)
 void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, double pad_diag, hipStream_t st);

@@ -209,7 +209,7 @@ __device__ __forceinline__ void fb_column(double (&a)[NB], double (&x)[NB], doub
 
 // B: the block (element (r, c) at B[c * PITCH + r])
 template <int PITCH>
-__device__ __noinline__ bool factor_block16(double* __restrict__ B, int lane, double* __restrict__ Li, double* __restrict__ Linv_out)
+__device__ __forceinline__ bool factor_block16(double* __restrict__ B, int lane, double* __restrict__ Li, double* __restrict__ Linv_out)
 {
     const int l = lane & 15;
     double a[NB], x[NB];
@@ -1842,8 +1842,13 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
             static const bool pipelined = std::getenv("MAGE_CHOL_PIPELINED_TRSM") != nullptr;
             // the write-through form of the chain's two hand-offs (k_syrk_update<1, true>); MAGE_CHOL_WT_HANDOFF=0 restores release / acquire
             static const bool wt_handoff = !(std::getenv("MAGE_CHOL_WT_HANDOFF") && std::atoi(std::getenv("MAGE_CHOL_WT_HANDOFF")) == 0);
-            // the strips as products over the tile's full inverse (k_syrk_update<1, true, true>); MAGE_CHOL_GEMM_STRIPS=0 restores the substitution form
-            static const bool gemm_strips = !(std::getenv("MAGE_CHOL_GEMM_STRIPS") && std::atoi(std::getenv("MAGE_CHOL_GEMM_STRIPS")) == 0);
+            // The strips as products over the tile's full inverse (k_syrk_update<1, true, true>): OFF by default, MAGE_CHOL_GEMM_STRIPS=1 selects
+            // it.  Measured (time stamps of launch 30, tools/_bin/chol_test 6016, profiles/r04_chol_links.txt): the strips do what they were
+            // built for -- last strip done 3.4 us after the flag instead of 7.1 -- but building the inverse beside the in-tile factorisation
+            // stretches THAT from 20.2 to 30.7 us (the three helper wavefronts no longer finish inside wavefront 0's 2 us per pivot block;
+            // not the instruction cache: SQC_ICACHE_MISSES 1.1 k per launch either way), so a chain-bound column takes 40.1 us against
+            // 35.8 and the factorisation 2.73 ms against 2.60.  Same residual (7.5e-16), all tests pass; kept for the record.
+            static const bool gemm_strips = std::getenv("MAGE_CHOL_GEMM_STRIPS") && std::atoi(std::getenv("MAGE_CHOL_GEMM_STRIPS")) != 0;
             const dim3 grid(NDIAG + n_whole + 4 * n_q4 + m + (merged ? (m - 1) * NBLK : 0));
             const int dbg = (ws.dbg && dbg_col == k) ? 1 : 0;
             double* const Linv_next = ws.Linv + (size_t)(k + 1) * linv_stride;

@@ -181,20 +181,29 @@ struct PinnedVec {
     const T* end() const { return p + n; }
 };
 
-// Grow-only device buffer.
+// Grow-only device buffer.  It either owns its memory (from the device cache) or is a VIEW into a larger buffer somebody else owns
+// (alias(): the small-problem image of ba_host.hip puts every list of a problem into ONE device buffer filled by ONE copy).
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;
     size_t bytes = 0;
     int device = 0;
+    bool aliased = false;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() { if (p) cached_device_release(p, bytes, device); }       // handle destructors synchronise their stream first
+    ~DevBuf() { if (p && !aliased) cached_device_release(p, bytes, device); }       // handle destructors synchronise their stream first
+    // view of `count` elements at q (owned elsewhere).  The caller has made sure nothing in flight still uses memory this buffer owned.
+    void alias(T* q, size_t count)
+    {
+        if (p && !aliased) cached_device_release(p, bytes, device);
+        p = q; cap = count; bytes = 0; aliased = true;
+    }
     mage_status reserve(size_t n)
     {
         if (n <= cap) return MAGE_OK;
+        if (aliased) { p = nullptr; cap = 0; bytes = 0; aliased = false; }   // a view is never grown: take memory of its own
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }                // growth inside a live handle: hipFree synchronises
         const size_t want = n + n / 8 + 16;
         void* q = nullptr;
