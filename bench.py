@@ -471,11 +471,39 @@ def extra_config2(device):
         for _ in range(reps):
             mt.match_batch_device(batch, dA, cA, CAP, dB, cB, CAP, 30, 1)
         mwall = (time.perf_counter() - t0) / reps
+        # `valu_issue` rooflines (the bound the front end is really under: SURVEY 8d's HBM figure says little about kernels that are
+        # limited by vector-instruction issue).  Per kernel: wavefronts of the launch x vector instructions per wavefront (PMC pass,
+        # profiles/front_end_valu.json "pmc") x mean issue cycles per instruction (static mix by issue class, "mix") = SIMD-cycles of issue
+        # the launch NEEDS, against the SIMD-cycles it HAD: 1024 SIMDs x its measured time x 2.4 GHz.
+        valu = {}
+        try:
+            fe = json.load(open(os.path.join(ROOT, "profiles", "front_end_valu.json")))
+            SIMD_HZ = 1024 * 2.4e9
+            for kern, units, ms in (("k_fast_keypoints", 2 * batch, p.fast_ms + p.blur_ms), ("k_select", 2 * batch, p.select_ms), ("k_brief", 2 * batch, p.brief_ms),
+                                    ("k_match", batch, mt.last_kernel_ms())):
+                pm, mx = fe["pmc"][kern], fe["mix"][kern]
+                per_unit = pm["waves_per_launch"] / pm["units_per_launch"]
+                instr = units * per_unit * pm["valu_per_wave"]                 # vector wave-instructions of the launch
+                FAST = 2.28                                                    # cycles: the shortest issue interval measured on this part (profiles/r03_valu_issue_rates.txt)
+                need_lo, need_hi = instr * FAST, instr * mx["mean_issue_cycles_per_valu"]
+                valu[kern] = {"bound": "valu_issue", "achieved": round(instr / (ms * 1e-3) / 1e12, 3), "peak": round(SIMD_HZ / FAST / 1e12, 3), "unit": "T vector wave-instructions/s",
+                              "frac": round(need_lo / (ms * 1e-3) / SIMD_HZ, 4),
+                              "frac_if_classes_serialise": round(need_hi / (ms * 1e-3) / SIMD_HZ, 4),
+                              "ms": round(ms, 4), "wavefronts": int(units * per_unit), "valu_instructions_per_wavefront": round(pm["valu_per_wave"], 1),
+                              "static_mix_mean_issue_cycles": mx["mean_issue_cycles_per_valu"]}
+            valu["how_to_read"] = ("frac = vector wave-instructions x 2.28 cycles (the shortest measured issue interval) / (1024 SIMDs x 2.4 GHz x the launch's time): "
+                                   "the share of issue slots taken, a LOWER bound of how busy the vector unit is; frac_if_classes_serialise weights the kernel's STATIC "
+                                   "instruction mix with the per-class intervals (2.3 / 4.2 / 8.2 / 16 cycles) as if classes never overlapped -- an upper estimate "
+                                   "(it can exceed 1: the 4.2-cycle classes do overlap with other wavefronts' 2.3-cycle ones)")
+            valu["source"] = "instruction counts: committed PMC pass (profiles/front_end_valu.json, tools/pmc_front_end.sh) -- NOT measured in this run; times: this run"
+        except Exception as e:  # noqa: BLE001 - the profile is optional
+            valu = {"error": f"{type(e).__name__}: {e}"}
         res["batches"][str(batch)] = {
             "frames_per_s": round(2 * batch / wall, 1), "frames_per_s_two_detectors": None if fps2 is None else round(fps2, 1),
             "ms_per_batch_of_frames": round(1e3 * wall, 4), "frames_in_batch": 2 * batch,
             "stage_ms": {"fast_blur": round(p.fast_ms + p.blur_ms, 4), "select": round(p.select_ms, 4), "brief": round(p.brief_ms, 4), "events_total": round(p.total_ms, 4)},
             "hbm_frac_algorithmic": round(alg_bytes / (p.total_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+            "roofline_valu_issue": valu,
             "pairs_per_s": round(batch / mwall, 1), "match_kernel_ms": round(mt.last_kernel_ms(), 4),
             "match_gdistances_per_s": round(batch * 2 * CAP * CAP / (mt.last_kernel_ms() * 1e-3) / 1e9, 2)}
     return res

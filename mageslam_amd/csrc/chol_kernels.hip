@@ -1443,14 +1443,20 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
 // launch costs is mostly the write-back of the update's dirty tiles at the kernel boundary, which the next launch then pays instead;
 // profiles/r04_chol_merged_halftile_rejected.txt has the numbers and the per-launch timeline.  The code is not kept.)
 __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
-                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int unstaged)
+                                                     double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int unstaged,
+                                                     int q_tiles)
 {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j0 = k + 1, mt = nt - j0;
     const int n_tiles = mt * (mt + 1) / 2;
-    const int n_task_wgs = 16 * ((n_tiles - 1 + 7) / 8);          // tile indices 1 .. n_tiles - 1, two workgroups (column halves) each, in groups of eight tiles
-    const int first_rhs = NDIAG + n_task_wgs;
+    // q_tiles (round 4): the LAST q_tiles tiles are updated in quarters (64 x 64 per workgroup, 32 x 32 per wavefront) -- the host asks
+    // for that when the half-tile tasks would end in a round that fills at most half of the 512 task slots, so that the round takes
+    // half as long (what the whole-tile kernel does with n_q4).  Same sums in the same order: bit-identical.
+    const int n_half_tiles = n_tiles - 1 - q_tiles;               // tile indices 1 .. n_half_tiles in halves
+    const int n_task_wgs = 16 * ((n_half_tiles + 7) / 8);         // two workgroups (column halves) each, in groups of eight tiles
+    const int first_q4 = NDIAG + n_task_wgs;
+    const int first_rhs = first_q4 + 4 * q_tiles;
     const int bid = blockIdx.x;
     if (bid >= first_rhs) {
         const int i = k + 1 + (bid - first_rhs);
@@ -1504,6 +1510,24 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
         if (tid == 0 && failed) *ok = 0.0;
         return;
     }
+    if (bid >= first_q4) {
+        const int qq = bid - first_q4;
+        int rt, ct;
+        tile_of_index(n_half_tiles + 1 + (qq >> 2), rt, ct);
+        if (rt == ct && (qq & 3) == 2) return;                    // diagonal tile: rows 0-63 of columns 64-127 lie above the diagonal
+        const int row0 = (j0 + rt) * TILE + (qq & 1) * 64 + (wave & 1) * 32;
+        const int col0 = (j0 + ct) * TILE + ((qq >> 1) & 1) * 64 + (wave >> 1) * 32;
+        double4_t out[2][2];
+        update_block<2, 8>(S, ld, k, row0, col0, lane, out);
+        double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = out[a][b][r];
+        return;
+    }
     const int q0 = bid - NDIAG;
     // half of a tile: 128 rows x 64 columns, a wavefront 64 x 32, accumulators loaded from C.
     // Which half: workgroups go to the eight XCDs round-robin and every XCD has its own 4 MB L2, while the operands of a launch are
@@ -1515,14 +1539,14 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
     // a tile are consecutive tasks of one XCD either way.  Placement only: any order gives the same numbers.
     int rt, ct, q;
     if (unstaged & 2) {
-        const int n_task = 2 * (n_tiles - 1), per = (n_task + 7) / 8;
+        const int n_task = 2 * n_half_tiles, per = (n_task + 7) / 8;
         q = (q0 & 7) * per + (q0 >> 3);
         if ((q0 >> 3) >= per || q >= n_task) return;
         tile_of_band_order(1 + (q >> 1), mt, rt, ct);
     } else {
         // (the two halves of a tile on one XCD, tiles in linear order: workgroups 16 g + t and 16 g + 8 + t serve tile 8 g + t)
         const int tile_i = 8 * (q0 >> 4) + (q0 & 7);
-        if (tile_i >= n_tiles - 1) return;
+        if (tile_i >= n_half_tiles) return;
         q = 2 * tile_i + ((q0 >> 3) & 1);
         tile_of_index(1 + (q >> 1), rt, ct);
     }
@@ -1828,8 +1852,16 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
         // reads -27 % (profiles/r03_chol_pmc.txt) -- but the matrix cores are busy 49.7 % of the launch either way and the factorisation
         // takes 2.731 ms against 2.710: the update is not waiting for its operands' misses.  MAGE_CHOL_XCD_BANDS=1 selects it.
         static const bool xcd_bands = std::getenv("MAGE_CHOL_XCD_BANDS") != nullptr;
-        if (bulk2) hipLaunchKernelGGL(k_syrk_update2, dim3(NDIAG + 16 * ((n_tiles - 1 + 7) / 8) + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
-                                      ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, (unstaged ? 1 : 0) | (xcd_bands ? 2 : 0));
+        if (bulk2) {
+            // tiles of the last, partial round of half-tile tasks go in quarters when that round fills at most half of the task slots
+            // (two workgroups on each compute unit); MAGE_CHOL_NO_QUARTERS=1 switches it off
+            static const bool quarters_off = std::getenv("MAGE_CHOL_NO_QUARTERS") != nullptr;
+            const int tiles_per_round = g_n_cu;                       // 2 g_n_cu task slots, two half-tile tasks per tile
+            const int rem_tiles = (n_tiles - 1) % tiles_per_round;
+            const int q_tiles = (!quarters_off && unstaged && !xcd_bands && rem_tiles > 0 && rem_tiles * 2 <= tiles_per_round) ? rem_tiles : 0;
+            hipLaunchKernelGGL(k_syrk_update2, dim3(NDIAG + 16 * ((n_tiles - 1 - q_tiles + 7) / 8) + 4 * q_tiles + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
+                               ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, (unstaged ? 1 : 0) | (xcd_bands ? 2 : 0), q_tiles);
+        }
         else {
             merged = !merge_off;
             const int n_whole = n_tiles - 1 - n_q4;
