@@ -111,6 +111,15 @@ def cpu_baseline(workload: str, min_iterations: int = 2, max_seconds: float = 45
 # ======================================================================================================================
 # extras: measured after the headline's timed region, each bounded to seconds; a failure is recorded, never raised
 # ======================================================================================================================
+def _latest_profile(suffix: str) -> str:
+    """profiles/r<NN>_<suffix> of the latest round that has one (one copy per round, no unprefixed duplicates)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    if not files:
+        raise FileNotFoundError(suffix)
+    return files[-1]
+
+
 def _finite(x):
     """JSON has no NaN / Infinity: non-finite numbers become null."""
     if isinstance(x, float):
@@ -731,7 +740,7 @@ def main() -> int:
         achieved = flops / (fac_ms * 1e-3) / 1e12 if fac_ms > 0 else 0.0
         traffic = None
         try:   # HBM bytes per factorisation from the committed PMC passes (tools/pmc_to_traffic.py); same padded order only
-            tj = json.load(open(os.path.join(ROOT, "profiles", "chol_traffic.json")))
+            tj = json.load(open(_latest_profile("chol_traffic.json")))
             if int(tj.get("n_pad", -1)) == int(prof.padded_order):
                 traffic = float(tj["bytes_per_factorization"])
         except Exception:
@@ -757,7 +766,7 @@ def main() -> int:
                           "HIP-event span per factorisation on the solver stream",
                 "bound": "mfma", "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                "traffic_source": "committed profile (profiles/chol_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                "traffic_source": "committed profile (profiles/r<NN>_chol_traffic.json of the latest round: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
                                   "tools/_bin/chol_test at the same padded order, (2*FETCH_SIZE + WRITE_SIZE)*1024 per factorisation; regenerate with "
                                   "tools/regen_profiles.sh) -- NOT measured in this run",
                 "flops_per_launch": flops, "ms_per_launch": fac_ms, "launches": int(prof.n_factorizations),
@@ -789,14 +798,14 @@ def main() -> int:
             "traffic": None,
         }
         try:   # HBM bytes per LM iteration of the three stages from the committed PMC passes (tools/pmc_stage_traffic.py)
-            sj = json.load(open(os.path.join(ROOT, "profiles", "ba_stage_traffic.json")))
+            sj = json.load(open(_latest_profile("ba_stage_traffic.json")))
             if args.workload == "global":
                 hb = line["roofline_hbm"]
                 hb["traffic"] = float(sj["total_hbm_bytes_per_iteration"])
                 for k, v in sj["stages_hbm_bytes_per_iteration"].items():
                     if k in hb["stages"]:
                         hb["stages"][k]["traffic"] = float(v)
-                hb["traffic_source"] = ("committed profile (profiles/ba_stage_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                hb["traffic_source"] = ("committed profile (profiles/r<NN>_ba_stage_traffic.json of the latest round: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
                                         "bench.py on the 1k-pose map), not measured in this run")
         except Exception:  # noqa: BLE001 - the profile is optional
             pass

@@ -24,14 +24,6 @@ SECONDS = float(os.environ.get("MAGE_SOAK_SECONDS", "60"))
 
 def test_two_large_handles_orb_and_matcher_soak():
     scenes = [scene.make_scene(n_cams=1000, n_pts=100000, n_obs=1000000, seed=0x5EED0004 + 0x100 * i) for i in range(2)]
-    handles = []
-    for s in scenes:
-        b = BundlerLib(False)
-        load_scene(b, s, bulk=True)
-        b.SetCurrentLambda(5e6)
-        b.StepBundleAdjustment([1.8], 1e30, [])               # structure build + first iteration
-        handles.append(b)
-    assert handles[0].profile().padded_order == 6016
     fr = [frames.frame_pair(700 + i) for i in range(4)]
     det, mt = OrbDetector(), Matcher()
     ref = [det.DetectAndCompute(f[0]) for f in fr]
@@ -39,20 +31,30 @@ def test_two_large_handles_orb_and_matcher_soak():
     ref_m = [mt.Match(ref[i][1], ref_b[i][1], None, None, 30, 1) for i in range(4)]
 
     stop = time.perf_counter() + SECONDS
-    errors, steps, frames_done = [], [0, 0], [0]
+    errors, steps, reruns, fallback, frames_done = [], [0, 0], [0, 0], [0, 0], [0]
 
     def ba(i):
+        # blocks of 23 iterations on a freshly loaded map, as bench.py's extra.sustained does: a converged map ends every further
+        # iteration in g2o's ten rejected trials and its lambda overflows after a few dozen of them -- that regime is the reference's
+        # own behaviour, not what this test is about.  Creating and destroying the handles under load is part of the soak.
         try:
-            k = 0
             while time.perf_counter() < stop:
-                mse = handles[i].StepBundleAdjustment([1.8], 1e30, [])
-                if not np.isfinite(mse):
-                    errors.append((i, k, "non-finite mean square error"))
-                    return
-                k += 1
-                if k % 25 == 0:                               # keep the iterations single-trial-ish: start the damping over now and then
-                    handles[i].SetCurrentLambda(5e6)
-            steps[i] = k
+                b = BundlerLib(False)
+                load_scene(b, scenes[i], bulk=True)
+                b.SetCurrentLambda(5e6)
+                for k in range(23):
+                    mse = b.StepBundleAdjustment([1.8], 1e30, [])
+                    if not np.isfinite(mse):
+                        errors.append((i, steps[i], "non-finite mean square error"))
+                        return
+                    steps[i] += 1
+                    if k == 0:
+                        assert b.profile().padded_order == 6016
+                    if time.perf_counter() >= stop:
+                        break
+                p = b.profile()
+                reruns[i] += int(p.trials_rerun_after_stall); fallback[i] = max(fallback[i], int(p.fallback_to_separate_launches))
+                b.close()
         except BaseException as e:  # noqa: BLE001
             errors.append((i, "ba", repr(e)))
 
@@ -81,8 +83,5 @@ def test_two_large_handles_orb_and_matcher_soak():
         t.join()
     assert not errors, errors[:3]
     assert min(steps) > 20 and frames_done[0] > 20, (steps, frames_done)
-    for b in handles:
-        p = b.profile()
-        assert p.trials_rerun_after_stall == 0 and p.fallback_to_separate_launches == 0, (p.trials_rerun_after_stall, p.fallback_to_separate_launches)
-        b.close()
-    print(f"soak: {SECONDS:.0f} s, LM iterations {steps}, frame pairs {frames_done[0]}, stall counters 0 / 0")
+    assert reruns == [0, 0] and fallback == [0, 0], (reruns, fallback)
+    print(f"soak: {SECONDS:.0f} s, LM iterations {steps}, frame pairs {frames_done[0]}, stall counters {reruns} / {fallback}")

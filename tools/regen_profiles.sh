@@ -2,8 +2,8 @@
 # Regenerates, in one command ON THE GPU BOX, the profile artefacts bench.py and DESIGN.md cite:
 #   gpurun_out/<tag>_bench.json                 the bench line
 #   gpurun_out/<tag>_bench_kernel_stats.txt     per-kernel table of the same command under rocprofv3 --kernel-trace
-#   gpurun_out/chol_traffic.json                HBM bytes per factorisation (separate --pmc FETCH_SIZE / WRITE_SIZE passes)
-#   gpurun_out/ba_stage_traffic.json            HBM bytes per LM iteration of the linearise / Schur / back-substitution stages (same passes over bench.py)
+#   gpurun_out/<tag>_chol_traffic.json          HBM bytes per factorisation (separate --pmc FETCH_SIZE / WRITE_SIZE passes)
+#   gpurun_out/<tag>_ba_stage_traffic.json      HBM bytes per LM iteration of the linearise / Schur / back-substitution stages (same passes over bench.py)
 # Copy what is to be judged into profiles/ afterwards (gpurun_out/ is scratch).
 #   gpurun --timeout 900 -- 'bash tools/regen_profiles.sh r02'
 set -u
@@ -21,12 +21,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $c -d "$out/${tag}_pmc_$c" -o p -- "$root/tools/_bin/chol_test" 6016 3 > /dev/null 2>> "$out/${tag}_bench.err"
 done
 # chol_test runs the factorisation reps + 0 extra times at a single size (the indefinite check only below n = 640)
-python "$root/tools/pmc_to_traffic.py" "$(find "$out/${tag}_pmc_FETCH_SIZE" -name '*.db' | head -1)" "$(find "$out/${tag}_pmc_WRITE_SIZE" -name '*.db' | head -1)" 3 > "$out/chol_traffic.json"
+python "$root/tools/pmc_to_traffic.py" "$(find "$out/${tag}_pmc_FETCH_SIZE" -name '*.db' | head -1)" "$(find "$out/${tag}_pmc_WRITE_SIZE" -name '*.db' | head -1)" 3 > "$out/${tag}_chol_traffic.json"
 rm -rf "$out/${tag}_pmc_FETCH_SIZE" "$out/${tag}_pmc_WRITE_SIZE"
 # HBM traffic of the HBM-bound stages of an LM iteration: the same two passes over the bench itself
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $c -d "$out/${tag}_pmc_$c" -o p -- python "$root/bench.py" --no-cpu-baseline --no-extras > /dev/null 2>> "$out/${tag}_bench.err"
 done
-python "$root/tools/pmc_stage_traffic.py" "$(find "$out/${tag}_pmc_FETCH_SIZE" -name '*.db' | head -1)" "$(find "$out/${tag}_pmc_WRITE_SIZE" -name '*.db' | head -1)" > "$out/ba_stage_traffic.json"
+python "$root/tools/pmc_stage_traffic.py" "$(find "$out/${tag}_pmc_FETCH_SIZE" -name '*.db' | head -1)" "$(find "$out/${tag}_pmc_WRITE_SIZE" -name '*.db' | head -1)" > "$out/${tag}_ba_stage_traffic.json"
 rm -rf "$out/${tag}_prof" "$out/${tag}_pmc_FETCH_SIZE" "$out/${tag}_pmc_WRITE_SIZE"
-tail -c 600 "$out/${tag}_bench.json"; echo; head -12 "$out/${tag}_bench_kernel_stats.txt"; cat "$out/chol_traffic.json"; head -8 "$out/ba_stage_traffic.json"
+tail -c 600 "$out/${tag}_bench.json"; echo; head -12 "$out/${tag}_bench_kernel_stats.txt"; cat "$out/${tag}_chol_traffic.json"; head -8 "$out/${tag}_ba_stage_traffic.json"
