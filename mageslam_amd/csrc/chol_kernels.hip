@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include "chol_kernels.h"
 #include <atomic>
+#include <string>
 
 namespace mage {
 namespace {
@@ -1022,6 +1023,81 @@ __device__ __forceinline__ void update_half_tile_staged(double* __restrict__ S, 
             for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = acc[a][b][r];
 }
 
+// Round 4: the half tile with its panel operands brought in by the LOAD-TO-LDS path (global_load_lds, 16 bytes per lane, no registers, no
+// ds_write pass), double-buffered in 16-column chunks behind RAW barriers (s_barrier + lgkmcnt only: __syncthreads() would also wait for
+// the loads in flight) -- the form the guide's GEMM recipes use.  What it is for: in the default form every WAVEFRONT fetches its own
+// 64 + 32 operand rows from L2 (0.19 bytes per flop; ~14 TB/s of L2 -> CU traffic at the measured 53 % matrix-core utilisation), here a
+// WORKGROUP fetches its 128 + 64 rows once (half of that) and the four wavefronts read fragments from LDS.  One instruction moves one
+// panel column's 128 rows (1 KB, lanes along rows); the 64 column-side rows take the lower half of a wavefront.  LDS image per chunk:
+// [16][GL_PN] + [16][GL_PM] doubles, pitches 144 / 80 so that the four panel columns of a fragment read land 32 banks apart.
+// Sums in the same order as update_rect (k ascending, C added at the end): bit-identical.  MAGE_CHOL_BULK2_FORM=glds selects it.
+// MEASURED SLOWER, like round 2's plain-load staging: 2.86 ms per factorisation against 2.565, every update-bound launch ~12 us longer
+// (profiles/r04_chol_links.txt) -- the LDS round trip and a barrier per 16 columns cost more than the halved L2 traffic returns.  Not the default.
+constexpr int GL_KC = 16, GL_PN = 144, GL_PM = 80;
+constexpr int GL_BUF = GL_KC * (GL_PN + GL_PM);           // 3584 doubles = 28 KB per buffer, two buffers
+__device__ __forceinline__ void glds16(const double* g, double* l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void update_half_tile_glds(double* __restrict__ S, int ld, int k, int R0, int C0, double* __restrict__ sm, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const double* Pn = S + (size_t)(k * TILE) * ld + R0 + lane * 2;       // panel column kk of the tile's 128 rows: + kk * ld
+    const double* Pm = S + (size_t)(k * TILE) * ld + C0 + lane * 2;       // ... of the tile's 64 columns (lanes 0-31)
+    auto issue = [&](int ch, double* buf) {                                // wavefront w brings in panel columns w, w + 4, w + 8, w + 12 of the chunk
+#pragma unroll
+        for (int q = 0; q < GL_KC / 4; ++q) {
+            const int kk = wave + 4 * q;
+            glds16(Pn + (size_t)(ch * GL_KC + kk) * ld, buf + kk * GL_PN);
+            if (lane < 32) glds16(Pm + (size_t)(ch * GL_KC + kk) * ld, buf + GL_KC * GL_PN + kk * GL_PM);
+        }
+    };
+    const int row0 = (wave & 1) * 64, col0 = (wave >> 1) * 32;
+    double* C = S + (size_t)(C0 + col0 + (lane >> 4)) * ld + R0 + row0 + (lane & 15);
+    double4_t acc[2][4], cv[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){ 0, 0, 0, 0 };
+    issue(0, sm);
+    constexpr int NCH = TILE / GL_KC;
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+        double* buf = sm + (ch & 1) * GL_BUF;
+        // my pieces of chunk ch have landed; behind the barrier everybody's have, and everybody has finished reading the other buffer
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (ch + 1 < NCH) issue(ch + 1, sm + ((ch + 1) & 1) * GL_BUF);
+        const double* fn = buf + (lane >> 4) * GL_PN + row0 + (lane & 15);
+        const double* fm = buf + GL_KC * GL_PN + (lane >> 4) * GL_PM + col0 + (lane & 15);
+#pragma unroll
+        for (int s4 = 0; s4 < GL_KC / 4; ++s4) {
+            double av[2], bv[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) av[a] = -fm[s4 * 4 * GL_PM + a * 16];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[b] = fn[s4 * 4 * GL_PN + b * 16];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // C comes from memory once per launch: fetched behind the last chunk's products, added at the end (as update_rect does)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[a][b][r] = C[(size_t)(a * 16 + 4 * r) * ld + b * 16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = cv[a][b][r] + acc[a][b][r];
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // nobody still reads the buffers when the workgroup's next use of LDS begins (none: it ends here)
+}
+
 // Grid of the trailing update of step k (tiles (i, j), j0 = k + 1 <= j <= i < nt), in dispatch order:
 //   blocks 0..8   the NEXT diagonal tile (j0, j0): its 36 lower 16x16 blocks, one per wavefront (32 dependent MFMAs
 //                 each instead of one wavefront grinding through a 64x64 quadrant: the tile is on the critical path).
@@ -1564,7 +1640,8 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
                 for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = out[a][b][r];
         return;
     }
-    update_half_tile_staged(S, ld, k, (j0 + rt) * TILE, (j0 + ct) * TILE + (q & 1) * 64, sm, tid);
+    if (unstaged & 4) update_half_tile_glds(S, ld, k, (j0 + rt) * TILE, (j0 + ct) * TILE + (q & 1) * 64, sm, tid);
+    else update_half_tile_staged(S, ld, k, (j0 + rt) * TILE, (j0 + ct) * TILE + (q & 1) * 64, sm, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1846,7 +1923,11 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
         // the workgroup that factors must not share its compute unit: the whole-tile form (382 registers: one workgroup per unit).
         static const int bulk2_min_tiles = std::getenv("MAGE_CHOL_BULK2_MIN_TILES") ? std::atoi(std::getenv("MAGE_CHOL_BULK2_MIN_TILES")) : 400;
         const bool bulk2 = n_tiles >= bulk2_min_tiles;
-        static const bool unstaged = std::getenv("MAGE_CHOL_BULK2_STAGED") == nullptr;     // staging the operands through LDS measured SLOWER (3.01 ms against 2.87): kept for the record
+        // the half-tile task in three forms: operands per wavefront straight from L2 (default), staged through LDS by plain loads + ds_write
+        // (MAGE_CHOL_BULK2_STAGED=1: measured slower in round 2, 3.01 ms against 2.87), staged by the load-to-LDS path behind raw barriers
+        // (MAGE_CHOL_BULK2_FORM=glds, round 4)
+        static const bool form_glds = std::getenv("MAGE_CHOL_BULK2_FORM") && std::string(std::getenv("MAGE_CHOL_BULK2_FORM")) == "glds";
+        static const bool unstaged = std::getenv("MAGE_CHOL_BULK2_STAGED") == nullptr && !form_glds;
         bool merged = false;
         // Band placement (tile_of_band_order) is OFF by default: it does what it is for -- L2 hit rate of the launch 56 -> 65 %, memory-side
         // reads -27 % (profiles/r03_chol_pmc.txt) -- but the matrix cores are busy 49.7 % of the launch either way and the factorisation
@@ -1860,7 +1941,7 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
             const int rem_tiles = (n_tiles - 1) % tiles_per_round;
             const int q_tiles = (!quarters_off && unstaged && !xcd_bands && rem_tiles > 0 && rem_tiles * 2 <= tiles_per_round) ? rem_tiles : 0;
             hipLaunchKernelGGL(k_syrk_update2, dim3(NDIAG + 16 * ((n_tiles - 1 - q_tiles + 7) / 8) + 4 * q_tiles + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
-                               ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, (unstaged ? 1 : 0) | (xcd_bands ? 2 : 0), q_tiles);
+                               ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, (unstaged ? 1 : 0) | (xcd_bands ? 2 : 0) | (form_glds ? 4 : 0), q_tiles);
         }
         else {
             merged = !merge_off;
