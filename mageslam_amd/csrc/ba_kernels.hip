@@ -995,7 +995,8 @@ __device__ __forceinline__ double pose_update_compute(const BaDeviceView& v, dou
     double a, bb, d;
     if (theta < 0.00001) { a = 1.0; bb = 0.5; d = 1.0 / 6.0; }
     else {
-        const double s = sin(theta), c = cos(theta);
+        double s, c;
+        sincos(theta, &s, &c);                 // one argument reduction for both (the two calls were ~1 us of dependent f64 operations on the pose-only kernel's lone thread)
         a = s / theta; bb = (1 - c) / (theta * theta); d = (theta - s) / (theta * theta * theta);
     }
 #pragma unroll
@@ -1775,9 +1776,22 @@ __global__ __launch_bounds__(256) void k_small_classify(BaDeviceView v, double m
 // in ONE launch of one workgroup; the host reads one record back.  Control flow and arithmetic per element are those of
 // lm_solve / the kernels above; sums keep a fixed order.
 // =================================================================================================
+// 1 / sqrt(d) to full double precision for d > 0 (v_rsq_f64 + two Goldschmidt steps), and sqrt(d) = d * that: a pivot of the 6 x 6
+// factorisation below costs ~12 dependent operations instead of the ~40 of an IEEE sqrt followed by a division -- on the pose-only
+// kernel's lone thread a dependent f64 operation is ~25 cycles, and this solve runs once per LM trial.
+__device__ __forceinline__ void sqrt_and_rsqrt(double d, double& s, double& rs)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    s = g; rs = h + h;
+}
 __device__ __forceinline__ bool solve6_spd(const double* __restrict__ U36, double lambda, const double* __restrict__ b, double* __restrict__ x)
 {
-    double L[6][6];
+    double L[6][6], inv[6];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -1785,14 +1799,15 @@ __device__ __forceinline__ bool solve6_spd(const double* __restrict__ U36, doubl
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
         if (!(d > 0.0)) ok = false;
-        const double s = sqrt(d);
-        L[j][j] = s;
+        double sq, rs;
+        sqrt_and_rsqrt(d, sq, rs);
+        L[j][j] = sq; inv[j] = rs;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double a = U36[i * 6 + j];
 #pragma unroll
             for (int k = 0; k < j; ++k) a -= L[i][k] * L[j][k];
-            L[i][j] = a / s;
+            L[i][j] = a * rs;
         }
     }
     double z[6];
@@ -1801,14 +1816,14 @@ __device__ __forceinline__ bool solve6_spd(const double* __restrict__ U36, doubl
         double a = b[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) a -= L[i][k] * z[k];
-        z[i] = a / L[i][i];
+        z[i] = a * inv[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double a = z[i];
 #pragma unroll
         for (int k = i + 1; k < 6; ++k) a -= L[k][i] * x[k];
-        x[i] = a / L[i][i];
+        x[i] = a * inv[i];
     }
     return ok;
 }
@@ -1988,7 +2003,8 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
                 else r = (cur_chi - temp) / (scale + 1e-3);
                 int acc = 0;
                 if (ok2 && r > 0 && isfinite(temp)) {
-                    double alpha = 1. - pow((2 * r - 1), 3);
+                    const double t3 = 2 * r - 1;
+                    double alpha = 1. - t3 * t3 * t3;          // (2 rho - 1)^3 spelled out: pow() is a hundred dependent f64 operations on this lone thread
                     alpha = fmin(alpha, 2. / 3.);
                     lambda *= fmax(1. / 3., alpha);
                     ni = 2;
