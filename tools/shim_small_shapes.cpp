@@ -132,9 +132,10 @@ int main(int argc, char** argv)
             size_t nout = 0;
             std::vector<float> sink(1, 0.f);
             for (int i = 0; i < 5; ++i) run_bundle_adjustment(s, warm, nullptr, nullptr, sink);
+            sink[0] = 0.f;
             for (int i = 0; i < reps; ++i) run_bundle_adjustment(s, ph, &mse, &nout, sink);
             print_phases("window_ms", ph);
-            std::printf("window_result mse %.6f outliers %zu checksum %.4f\n", mse, nout, sink[0]);
+            std::printf("window_result mse %.6f outliers %zu checksum %.4f\n", mse, nout, sink[0] / reps);
         } else { std::fprintf(stderr, "unknown mode %s\n", argv[1]); return 2; }
     } catch (const std::exception& e) {
         std::printf("error: %s\n", e.what());
