@@ -260,6 +260,11 @@ struct mage_ba {
     DevBuf<float2> d_L_uv; DevBuf<float> d_L_info; DevBuf<uint32_t> d_L_cam, d_L_pt, d_L_edge; DevBuf<int> d_L_slot;
     DevBuf<int> d_lm_ptr, d_lm_pt, d_lm_wptr, d_w_hc, d_w_lm, d_camE_ptr, d_camE, d_camS_ptr, d_camS, d_blk_ptr;
     DevBuf<int2> d_blk_ij, d_con;
+    // where the compact W records live (BaDeviceView::w_pos): built on the first LM iteration that uses the compact form
+    DevBuf<int> d_w_pos, d_pos_lm;
+    DevBuf<int2> d_con_pos;
+    size_t n_con = 0;
+    bool positions_valid = false;
     DevBuf<int> d_blk_order;
     bool dup_slots = false;            // some landmark is observed twice by one free camera
     DevBuf<double> d_errL, d_U, d_bc, d_V, d_bp, d_W, d_Dinv, d_db, d_S, d_y, d_xc, d_xl, d_partial, d_scal, d_Linv, d_camR;
@@ -1060,6 +1065,9 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(stage_array(h, h->d_V, (size_t)nlm * 6 + 1));
     MAGE_TRY(stage_array(h, h->d_bp, (size_t)nlm * 4 + 1));
     MAGE_TRY(stage_array(h, h->d_W, (size_t)nw * 18 + 1));
+    if (points_free && !h->dup_slots && (nfc * 6 > 128 || nT > 0 || h->shard_ranks > 0) && ba_compact_w_enabled()) {      // the compact form will be used: its position maps (lm_solve fills them)
+        MAGE_TRY(stage_array(h, h->d_w_pos, (size_t)nw + 1)); MAGE_TRY(stage_array(h, h->d_pos_lm, (size_t)nw + 1)); MAGE_TRY(stage_array(h, h->d_con_pos, ncon + 1));
+    } else { h->d_w_pos.drop_alias(); h->d_pos_lm.drop_alias(); h->d_con_pos.drop_alias(); }      // (views of an earlier image must not outlive it)
     MAGE_TRY(stage_array(h, h->d_Dinv, (size_t)nlm * 6 + 1));
     MAGE_TRY(stage_array(h, h->d_db, (size_t)nlm * 4 + 1));
     MAGE_TRY(stage_array(h, h->d_S, (size_t)n_pad * n_pad));
@@ -1097,6 +1105,8 @@ mage_status initialize_optimization(mage_ba* h)
     h->n_active_tethers = nT;
     v.errL = h->d_errL.p; v.U = h->d_U.p; v.bc = h->d_bc.p; v.V = h->d_V.p; v.bp = h->d_bp.p; v.W = h->d_W.p;
     v.compact = 0; v.camR = h->d_camR.p;
+    v.w_pos = nullptr; v.pos_lm = nullptr; v.con_pos = nullptr;
+    h->positions_valid = false; h->n_con = ncon;
     v.Dinv = h->d_Dinv.p; v.db = h->d_db.p; v.S = h->d_S.p; v.y = h->d_y.p; v.xc = h->d_xc.p; v.xl = h->d_xl.p;
     v.partial = h->d_partial.p; v.scal = h->d_scal.p;
     refresh_view_state(h);
@@ -1176,6 +1186,12 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
     if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[0], st));
     // W in its compact form (x/z, y/z, 1/z, weight per slot: ba_kernels.h) whenever the fused linearisation writes it
     v.compact = (!small && v.points_free && ba_fused_linearize_applies(v) && ba_compact_w_enabled()) ? 1 : 0;
+    if (v.compact && !h->positions_valid) {
+        MAGE_TRY(h->d_w_pos.reserve((size_t)v.n_w + 1)); MAGE_TRY(h->d_pos_lm.reserve((size_t)v.n_w + 1)); MAGE_TRY(h->d_con_pos.reserve(h->n_con + 1));
+        ba_launch_build_positions(v, h->d_w_pos.p, h->d_pos_lm.p, h->d_con_pos.p, st);
+        v.w_pos = h->d_w_pos.p; v.pos_lm = h->d_pos_lm.p; v.con_pos = h->d_con_pos.p;
+        h->positions_valid = true;
+    }
     if (small) ba_small_linearize(v, huber, h->iteration == 0, counter, st);
     else if (ba_fused_linearize_applies(v)) ba_fused_linearize(v, huber, counter, st);
     else {

@@ -47,6 +47,14 @@ struct BaDeviceView {
     // ---- reduced-camera-matrix structure
     const int* blk_ptr; const int2* blk_ij; const int2* con;   // contributions (slot_a, slot_b) per block
     const int* blk_order; int n_blk_slots;                     // wavefront slot -> block (-1: none): rows of S are pinned to XCDs (ba_host.hip)
+    // ---- where a slot's COMPACT record lives (round 4).  Slots are numbered landmark-major (lm_wptr); a block (i, j) of the Schur
+    // complement reads the records of the landmarks cameras i and j share -- ten slots apart in that numbering, one 128-byte line per
+    // 32-byte record.  The compact records are therefore STORED camera-major (position p of camS <-> slot camS[p]: a camera's records
+    // in ascending landmark), where the records a block reads are neighbours.  Placement only: the same values meet in the same
+    // order.  MAGE_BA_W_LANDMARK_MAJOR=1 keeps position == slot (A/B).  Valid while `compact` (ba_launch_build_positions).
+    const int* w_pos;                          // n_w : slot -> position
+    const int* pos_lm;                         // n_w : landmark of a position
+    const int2* con_pos;                       // the contributions of `con` in positions
 
     // ---- tether edges (pose-pose constraints; active ones only, all three kinds in one list)
     int n_T, n_tc, n_tp;                       // tethers / cameras carrying tethers / free-camera pairs joined by tethers
@@ -91,6 +99,8 @@ void ba_launch_error(const BaDeviceView& v, bool trial, double huber_delta, hipS
 void ba_launch_linearize(const BaDeviceView& v, double huber_delta, hipStream_t st);                 // U,bc,V,bp,W
 void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st, const double* udiag_sum = nullptr);                                       // -> scal[SC_MAXDIAG]
 void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st);                          // Dinv,db,S,y
+void ba_launch_build_positions(const BaDeviceView& v, int* w_pos, int* pos_lm, int2* con_pos, hipStream_t st); // w_pos / pos_lm / con_pos from camS, w_lm, con
+bool ba_w_camera_major();                                                                             // false with MAGE_BA_W_LANDMARK_MAJOR=1
 void ba_launch_tile_envelope(const BaDeviceView& v, int* tile_env, hipStream_t st);                  // the skyline of S by tile rows, from blk_ij and the tether pairs
 void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st);                         // xl, trial state, scal[SC_SCALE]
 // landmark-sharded maps (include/mage_ba.h: mage_ba_set_landmark_shard)

@@ -712,38 +712,68 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block_
     double yv[6] = { 0, 0, 0, 0, 0, 0 };
     const int c_end = v.blk_ptr[b + 1];
     const double2* G2 = reinterpret_cast<const double2*>(v.W);
-    for (int c = v.blk_ptr[b] + (SPLIT ? wave * WAVE : 0) + lane; c < c_end; c += stride) {
-        const int2 sab = v.con[c];
-        const int lm = v.w_lm[sab.x];
+    // Software pipeline, three stages deep (round 4): a wavefront keeps 36 sums + the factors of one contribution in ~200 registers, so
+    // only two wavefronts share a SIMD and nothing hides the chain  list entry -> landmark -> records  (three dependent trips to L2 per
+    // 64 contributions).  Before the ~260 f64 operations of contribution c are issued, the records of c + stride, the landmark of
+    // c + 2 stride and the list entry of c + 3 stride are requested -- unconditionally (a load under a branch is waited for at the join):
+    // lanes past the end of the block re-read its last entry and add nothing.
+    struct Rec { double2 da, db, dc, ga0, ga1, gb0, gb1, e01, e2x; };
+    auto fetch = [&](const int2 sab, const int lm, Rec& r) {
         const double2* D2 = reinterpret_cast<const double2*>(v.Dinv + (size_t)lm * 6);
-        const double2 da = D2[0], db = D2[1], dc = D2[2];
-        const double2 ga0 = G2[(size_t)sab.x * 2], ga1 = G2[(size_t)sab.x * 2 + 1];
-        const double2 gb0 = G2[(size_t)sab.y * 2], gb1 = G2[(size_t)sab.y * 2 + 1];
-        const double d00 = da.x, d01 = da.y, d02 = db.x, d11 = db.y, d12 = dc.x, d22 = dc.y;
-        double Ja0[6], Ja1[6], Qa0[3], Qa1[3], Jb0[6], Jb1[6], Qb0[3], Qb1[3];
-        slot_factors(ci, ga0.x, ga0.y, ga1.x, ga1.y, Ja0, Ja1, Qa0, Qa1);
-        slot_factors(cj, gb0.x, gb0.y, gb1.x, gb1.y, Jb0, Jb1, Qb0, Qb1);
+        r.da = D2[0]; r.db = D2[1]; r.dc = D2[2];
+        r.ga0 = G2[(size_t)sab.x * 2]; r.ga1 = G2[(size_t)sab.x * 2 + 1];
+        r.gb0 = G2[(size_t)sab.y * 2]; r.gb1 = G2[(size_t)sab.y * 2 + 1];
         if (diag) {
             const double2* db2 = reinterpret_cast<const double2*>(v.db + (size_t)lm * 4);
-            const double2 dba = db2[0];
-            const double e0 = dba.x, e1 = dba.y, e2 = db2[1].x;
-            const double s0 = Qa0[0] * e0 + Qa0[1] * e1 + Qa0[2] * e2, s1 = Qa1[0] * e0 + Qa1[1] * e1 + Qa1[2] * e2;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) yv[r] += r == 4 ? Ja1[r] * s1 : r == 3 ? Ja0[r] * s0 : Ja0[r] * s0 + Ja1[r] * s1;
+            r.e01 = db2[0]; r.e2x = db2[1];
         }
-        // M = Qa D Qb^T (2 x 2)
-        const double t00 = Qa0[0] * d00 + Qa0[1] * d01 + Qa0[2] * d02, t01 = Qa0[0] * d01 + Qa0[1] * d11 + Qa0[2] * d12, t02 = Qa0[0] * d02 + Qa0[1] * d12 + Qa0[2] * d22;
-        const double t10 = Qa1[0] * d00 + Qa1[1] * d01 + Qa1[2] * d02, t11 = Qa1[0] * d01 + Qa1[1] * d11 + Qa1[2] * d12, t12 = Qa1[0] * d02 + Qa1[1] * d12 + Qa1[2] * d22;
-        const double m00 = t00 * Qb0[0] + t01 * Qb0[1] + t02 * Qb0[2], m01 = t00 * Qb1[0] + t01 * Qb1[1] + t02 * Qb1[2];
-        const double m10 = t10 * Qb0[0] + t11 * Qb0[1] + t12 * Qb0[2], m11 = t10 * Qb1[0] + t11 * Qb1[1] + t12 * Qb1[2];
-        // (Jc has two structural zeros, J0[4] and J1[3]: the products with them are left out by hand -- the compiler may not drop 0 * x)
+    };
+    const int c_first = v.blk_ptr[b] + (SPLIT ? wave * WAVE : 0);                       // uniform
+    const int trips = c_first < c_end ? (c_end - c_first + stride - 1) / stride : 0;     // uniform
+    const int c_last = c_end - 1;
+    int c = c_first + lane;
+    Rec cur, nxt;
+    int2 sab1 = make_int2(0, 0), sab2 = make_int2(0, 0);
+    int lm1 = 0;
+    if (trips > 0) {
+        const int2 sab0 = v.con_pos[min(c, c_last)];
+        sab1 = v.con_pos[min(c + stride, c_last)];
+        sab2 = v.con_pos[min(c + 2 * stride, c_last)];
+        const int lm0 = v.pos_lm[sab0.x];
+        lm1 = v.pos_lm[sab1.x];
+        fetch(sab0, lm0, cur);
+    }
+    for (int t = 0; t < trips; ++t, c += stride) {
+        fetch(sab1, lm1, nxt);
+        const int lm2 = v.pos_lm[sab2.x];
+        const int2 sab3 = v.con_pos[min(c + 3 * stride, c_last)];
+        if (c < c_end) {
+            const double2 da = cur.da, db = cur.db, dc = cur.dc, ga0 = cur.ga0, ga1 = cur.ga1, gb0 = cur.gb0, gb1 = cur.gb1;
+            const double d00 = da.x, d01 = da.y, d02 = db.x, d11 = db.y, d12 = dc.x, d22 = dc.y;
+            double Ja0[6], Ja1[6], Qa0[3], Qa1[3], Jb0[6], Jb1[6], Qb0[3], Qb1[3];
+            slot_factors(ci, ga0.x, ga0.y, ga1.x, ga1.y, Ja0, Ja1, Qa0, Qa1);
+            slot_factors(cj, gb0.x, gb0.y, gb1.x, gb1.y, Jb0, Jb1, Qb0, Qb1);
+            if (diag) {
+                const double e0 = cur.e01.x, e1 = cur.e01.y, e2 = cur.e2x.x;
+                const double s0 = Qa0[0] * e0 + Qa0[1] * e1 + Qa0[2] * e2, s1 = Qa1[0] * e0 + Qa1[1] * e1 + Qa1[2] * e2;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const double n0 = r == 4 ? Ja1[r] * m10 : r == 3 ? Ja0[r] * m00 : Ja0[r] * m00 + Ja1[r] * m10;
-            const double n1 = r == 4 ? Ja1[r] * m11 : r == 3 ? Ja0[r] * m01 : Ja0[r] * m01 + Ja1[r] * m11;
+                for (int r = 0; r < 6; ++r) yv[r] += r == 4 ? Ja1[r] * s1 : r == 3 ? Ja0[r] * s0 : Ja0[r] * s0 + Ja1[r] * s1;
+            }
+            // M = Qa D Qb^T (2 x 2)
+            const double t00 = Qa0[0] * d00 + Qa0[1] * d01 + Qa0[2] * d02, t01 = Qa0[0] * d01 + Qa0[1] * d11 + Qa0[2] * d12, t02 = Qa0[0] * d02 + Qa0[1] * d12 + Qa0[2] * d22;
+            const double t10 = Qa1[0] * d00 + Qa1[1] * d01 + Qa1[2] * d02, t11 = Qa1[0] * d01 + Qa1[1] * d11 + Qa1[2] * d12, t12 = Qa1[0] * d02 + Qa1[1] * d12 + Qa1[2] * d22;
+            const double m00 = t00 * Qb0[0] + t01 * Qb0[1] + t02 * Qb0[2], m01 = t00 * Qb1[0] + t01 * Qb1[1] + t02 * Qb1[2];
+            const double m10 = t10 * Qb0[0] + t11 * Qb0[1] + t12 * Qb0[2], m11 = t10 * Qb1[0] + t11 * Qb1[1] + t12 * Qb1[2];
+            // (Jc has two structural zeros, J0[4] and J1[3]: the products with them are left out by hand -- the compiler may not drop 0 * x)
 #pragma unroll
-            for (int cc = 0; cc < 6; ++cc) acc[r * 6 + cc] += cc == 4 ? n1 * Jb1[cc] : cc == 3 ? n0 * Jb0[cc] : n0 * Jb0[cc] + n1 * Jb1[cc];
+            for (int r = 0; r < 6; ++r) {
+                const double n0 = r == 4 ? Ja1[r] * m10 : r == 3 ? Ja0[r] * m00 : Ja0[r] * m00 + Ja1[r] * m10;
+                const double n1 = r == 4 ? Ja1[r] * m11 : r == 3 ? Ja0[r] * m01 : Ja0[r] * m01 + Ja1[r] * m11;
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) acc[r * 6 + cc] += cc == 4 ? n1 * Jb1[cc] : cc == 3 ? n0 * Jb0[cc] : n0 * Jb0[cc] + n1 * Jb1[cc];
+            }
         }
+        cur = nxt; sab1 = sab2; lm1 = lm2; sab2 = sab3;
     }
     double* R = red[wave];
 #pragma unroll
@@ -870,7 +900,7 @@ __global__ __launch_bounds__(256) void k_backsub(BaDeviceView v, double lambda, 
         for (int s = v.lm_wptr[l] + sub; s < s1; s += BACKSUB_LPL) {
             if (v.compact) {          // W^T x = Q^T (Jc x), uniform branch
                 const int hc = v.w_hc[s];
-                const double2* G2 = reinterpret_cast<const double2*>(v.W + (size_t)s * 4);
+                const double2* G2 = reinterpret_cast<const double2*>(v.W + (size_t)v.w_pos[s] * 4);
                 const double2 g0 = G2[0], g1 = G2[1];
                 const double2* x2 = reinterpret_cast<const double2*>(v.xc + (size_t)hc * 6);
                 const double2 xa = x2[0], xb = x2[1], xd = x2[2];
@@ -1257,7 +1287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
                 if (slot >= 0) {
                     if (v.compact) {
-                        double2* Gd = reinterpret_cast<double2*>(v.W + (size_t)slot * 4);
+                        double2* Gd = reinterpret_cast<double2*>(v.W + (size_t)v.w_pos[slot] * 4);
                         Gd[0] = make_double2(cg0, cg1); Gd[1] = make_double2(cg2, cg3);
                     } else {
                         double2* Wd = reinterpret_cast<double2*>(v.W + (size_t)slot * 18);            // 144-byte block, 16-byte aligned: nine 128-bit stores
@@ -2211,6 +2241,35 @@ void ba_small_linearize(const BaDeviceView& v, double delta, bool want_maxdiag, 
 // The same kernel for LARGE problems in which every observation owns its W block: k_error + k_linearize_lm +
 // k_linearize_cam in one launch -- the residuals are computed once, a landmark's observations by eight lanes, the chi2 folded by the
 // last block.  S is cleared by ba_launch_schur, max |diag| comes from ba_launch_maxdiag.
+// Positions of the compact records (BaDeviceView::w_pos): camera-major = the inverse of camS, or the identity.
+__global__ __launch_bounds__(256) void k_build_positions(BaDeviceView v, int* __restrict__ w_pos, int* __restrict__ pos_lm, int camera_major)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= v.n_w) return;
+    const int s = camera_major ? v.camS[p] : p;
+    w_pos[s] = p;
+    pos_lm[p] = v.w_lm[s];
+}
+__global__ __launch_bounds__(256) void k_build_con_pos(BaDeviceView v, const int* __restrict__ w_pos, int2* __restrict__ con_pos)
+{
+    const int end = v.blk_ptr[v.n_blk];
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < end; c += gridDim.x * 256) {
+        const int2 ab = v.con[c];
+        con_pos[c] = make_int2(w_pos[ab.x], w_pos[ab.y]);
+    }
+}
+bool ba_w_camera_major()
+{
+    static const bool off = std::getenv("MAGE_BA_W_LANDMARK_MAJOR") != nullptr;
+    return !off;
+}
+void ba_launch_build_positions(const BaDeviceView& v, int* w_pos, int* pos_lm, int2* con_pos, hipStream_t st)
+{
+    if (v.n_w <= 0) return;
+    hipLaunchKernelGGL(k_build_positions, dim3(cdiv(v.n_w, 256)), dim3(256), 0, st, v, w_pos, pos_lm, ba_w_camera_major() ? 1 : 0);
+    if (v.n_blk > 0) hipLaunchKernelGGL(k_build_con_pos, dim3(2048), dim3(256), 0, st, v, w_pos, con_pos);
+}
+
 bool ba_compact_w_enabled()
 {
     static const bool off = std::getenv("MAGE_BA_MATERIAL_W") != nullptr;

@@ -200,6 +200,7 @@ struct DevBuf {
         if (p && !aliased) cached_device_release(p, bytes, device);
         p = q; cap = count; bytes = 0; aliased = true;
     }
+    void drop_alias() { if (aliased) { p = nullptr; cap = 0; bytes = 0; aliased = false; } }     // a view that was not renewed by the build that re-cut the image
     mage_status reserve(size_t n)
     {
         if (n <= cap) return MAGE_OK;
