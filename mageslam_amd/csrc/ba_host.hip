@@ -1081,7 +1081,7 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(stage_array(h, h->d_scal, SC_PAD + ((size_t)nL + 2) / 2 + 1));          // scalars, then up to n_L outlier ids (32-bit)
     h->out_cursor = 0;                                                        // d_queue (with the cursor) starts as zeros
     MAGE_TRY(stage_array(h, h->d_Linv, chol_workspace_doubles(n_pad)));
-    MAGE_TRY(stage_array(h, h->d_queue, chol_sync_ints(n_pad) + 2, 0));      // + the small-path counter + the outlier cursor; recycled memory arrives dirty
+    MAGE_TRY(stage_array(h, h->d_queue, chol_sync_ints(n_pad) + 64 + BA_FOLD_COUNTER_INTS, 0));      // + the small-path counter + the outlier cursor; recycled memory arrives dirty
     MAGE_TRY(stage_array(h, h->d_flagL, (size_t)nL + 1));
     MAGE_TRY(stage_array(h, h->d_L_active, (size_t)nL + 1, 1));
     MAGE_TRY(ensure_pinned_mirrors(h));
@@ -1183,6 +1183,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
         return MAGE_OK;
     };
     int* counter = h->d_queue.p + chol_sync_ints(v.n_pad);       // one int behind the factorisation's counters, zero between launches
+    int* fold_counters = counter + 64;                           // the two-level count of the folded reductions (ba_kernels.h), zero between launches
     if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[0], st));
     // W in its compact form (x/z, y/z, 1/z, weight per slot: ba_kernels.h) whenever the fused linearisation writes it
     v.compact = (!small && v.points_free && ba_fused_linearize_applies(v) && ba_compact_w_enabled()) ? 1 : 0;
@@ -1193,7 +1194,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
         h->positions_valid = true;
     }
     if (small) ba_small_linearize(v, huber, h->iteration == 0, counter, st);
-    else if (ba_fused_linearize_applies(v)) ba_fused_linearize(v, huber, counter, st);
+    else if (ba_fused_linearize_applies(v)) ba_fused_linearize(v, huber, fold_counters, st);
     else {
         ba_launch_error(v, false, huber, st);
         ba_launch_linearize(v, huber, st);
@@ -1260,7 +1261,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
             if (h->profiling || h->profiling_factor) MAGE_HIP(hipEventRecord(h->ev[1], st));
             chol_factor_solve(v.S, v.y, v.xc, v.n_pad, ws, v.scal + SC_CHOL_OK, st);
             if (h->profiling || h->profiling_factor) MAGE_HIP(hipEventRecord(h->ev[2], st));
-            if (ba_update_and_trial_error_fuses(v)) ba_launch_update_and_trial_error(v, lambda, adds_damping ? lambda : 0.0, huber, st);
+            if (ba_update_and_trial_error_fuses(v)) ba_launch_update_and_trial_error(v, lambda, adds_damping ? lambda : 0.0, huber, fold_counters, st);
             else {
                 ba_launch_update(v, lambda, adds_damping ? lambda : 0.0, st);
                 ba_launch_error(v, true, huber, st);
@@ -1271,7 +1272,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
                 ClassifyAfterTrial c{};
                 c.chi_ref = currentChi; c.chi_on_device = have_chi ? 0 : 1; c.trials_done = qmax + 1; c.last_iteration = plan->last_iteration ? 1 : 0;
                 int* small_counter = h->d_queue.p + chol_sync_ints(v.n_pad);
-                ba_launch_classify_after_trial(v, c, plan->max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, st);
+                ba_launch_classify_after_trial(v, c, plan->max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, small_counter + 64, st);
                 speculated = true;
             }
             if (sharded) {
@@ -2088,7 +2089,7 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
             ids_from_device = true;
             if (!post_done) {
                 if (!sharded && ba_small_applies(v)) ba_small_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, small_counter, h->stream);
-                else ba_launch_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, h->stream);
+                else ba_launch_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, small_counter + 64, h->stream);
                 prefix = prefix_now();
             }
             if (sharded) {

@@ -167,6 +167,55 @@ __global__ __launch_bounds__(256) void k_reduce_sum(const double* __restrict__ i
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same final stage WITHOUT a launch of its own (round 4): thread 0 of every block writes its partial(s) THROUGH to memory
+// (agent-scope stores), waits for the acknowledgement and counts itself in; the block that arrives last takes ONE acquire and adds
+// the partials in k_reduce_sum's order.  The "last block folds" pattern with ordinary stores needs a release fence per block -- a
+// write-back of its XCD's L2, slower than the launch it saves on kernels that stream hundreds of megabytes through those L2s; a
+// write-through store needs none.  `counters`: BA_FOLD_COUNTER_INTS zero-between-launches ints of the handle.  Opt-in (MAGE_BA_FOLD_REDUCTIONS=1): see ba_reductions_fold.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) double global_double_t;
+__device__ __forceinline__ void store_partial_through(double* p, double val)
+{
+    __hip_atomic_store((global_double_t*)p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// thread 0 has issued its store_partial_through()s; every thread of the block calls this.  Thousands of agent-scope increments of ONE
+// word are served one after another where the XCDs meet (~8 ns each: +14 ... +28 us per kernel when tried), so the count is kept in
+// two levels: block b counts into group b % 16's word (its own 256-byte line), the block that completes a group counts into the top word.
+__device__ __forceinline__ bool last_block_arrives_through(int* __restrict__ counters, int n_blocks)
+{
+    __shared__ int is_last_wt;
+    if (threadIdx.x == 0) {
+        constexpr int NG = BA_FOLD_GROUPS;
+        const int b = (int)blockIdx.x, g = b % NG;
+        const int members = (n_blocks - g + NG - 1) / NG, groups = n_blocks < NG ? n_blocks : NG;
+        int* gc = counters + 64 * (1 + g);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int last = 0;
+        if (__hip_atomic_fetch_add(gc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+            __hip_atomic_store(gc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(counters, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1) {
+                __hip_atomic_store(counters, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // every word is zero again for the next launch
+                last = 1;
+            }
+        }
+        is_last_wt = last;
+    }
+    __syncthreads();
+    if (is_last_wt) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return is_last_wt != 0;
+}
+// k_reduce_sum's body for one block: in is [n_out][n], out[o * stride_out]
+__device__ __forceinline__ void fold_partials_strided(const double* __restrict__ in, int n, int stride_out, double* __restrict__ out, int n_out, double* sm4)
+{
+    for (int o = 0; o < n_out; ++o) {
+        double acc = 0;
+        for (int i = threadIdx.x; i < n; i += 256) acc += in[(size_t)o * n + i];
+        const double r = block_sum<4>(acc, sm4);
+        if (threadIdx.x == 0) out[o * stride_out] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // residual + robustified chi2  (one thread per observation, landmark order => coalesced records)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_error(BaDeviceView v, int trial, double delta, int n_part)
@@ -888,8 +937,10 @@ constexpr int BACKSUB_LPL = 8;
 // WITH_ERROR: every lane of the landmark's group ends with the trial point and evaluates its share of the landmark's observations
 // against the trial poses (k_pose_update has run): the residuals and chi2 partials of k_error(trial) without reading the trial state
 // back, in partial[chi_off + block].
+// fold_n > 0 (WITH_ERROR): the last block to finish adds the fold_n scale partials and the fold_n chi2 partials (k_pose_update's rows
+// included: written by the launch before) into scal[SC_SCALE] / scal[SC_CHI_TRIAL] -- last_block_arrives_through.
 template <bool WITH_ERROR>
-__global__ __launch_bounds__(256) void k_backsub(BaDeviceView v, double lambda, double delta, int chi_off)
+__global__ __launch_bounds__(256) void k_backsub(BaDeviceView v, double lambda, double delta, int chi_off, int fold_n, int* __restrict__ counter)
 {
     __shared__ double sm[4];
     const int gl = blockIdx.x * 256 + threadIdx.x, l = gl / BACKSUB_LPL, sub = gl % BACKSUB_LPL;
@@ -961,6 +1012,14 @@ __global__ __launch_bounds__(256) void k_backsub(BaDeviceView v, double lambda, 
         }
     }
     const double r = block_sum<4>(sc, sm);
+    if (WITH_ERROR && fold_n > 0) {
+        const double r1 = block_sum<4>(chi, sm);
+        if (threadIdx.x == 0) { store_partial_through(v.partial + blockIdx.x, r); store_partial_through(v.partial + chi_off + blockIdx.x, r1); }
+        if (!last_block_arrives_through(counter, (int)gridDim.x)) return;
+        static_assert(SC_CHI_TRIAL - SC_SCALE == 6, "the two outputs of the fused reduction");
+        fold_partials_strided(v.partial, fold_n, SC_CHI_TRIAL - SC_SCALE, v.scal + SC_SCALE, 2, sm);
+        return;
+    }
     if (threadIdx.x == 0) v.partial[blockIdx.x] = r;
     if (WITH_ERROR) {
         const double r1 = block_sum<4>(chi, sm);
@@ -1104,7 +1163,7 @@ __device__ __forceinline__ bool call_is_over(const BaDeviceView& v, const Classi
 
 template <bool AFTER_TRIAL>
 __global__ __launch_bounds__(256) void k_classify(BaDeviceView v, double max_err_sq, uint32_t* __restrict__ out_ids, int* __restrict__ out_count, int out_base, int nb,
-                                                  ClassifyAfterTrial spec)
+                                                  ClassifyAfterTrial spec, int* __restrict__ fold_counter)
 {
     __shared__ double sm[4];
     const double* pose_kept = v.pose_cur;
@@ -1135,6 +1194,11 @@ __global__ __launch_bounds__(256) void k_classify(BaDeviceView v, double max_err
     double r0 = block_sum<4>(es, sm);
     double r1 = block_sum<4>(ec, sm);
     double r2 = block_sum<4>(no, sm);
+    if (fold_counter) {      // the last block adds the three sums (last_block_arrives_through); a call found unfinished above left without counting
+        if (threadIdx.x == 0) { store_partial_through(v.partial + blockIdx.x, r0); store_partial_through(v.partial + nb + blockIdx.x, r1); store_partial_through(v.partial + 2 * nb + blockIdx.x, r2); }
+        if (last_block_arrives_through(fold_counter, nb)) fold_partials_strided(v.partial, nb, 1, v.scal + SC_ERRSUM, 3, sm);
+        return;
+    }
     if (threadIdx.x == 0) { v.partial[blockIdx.x] = r0; v.partial[nb + blockIdx.x] = r1; v.partial[2 * nb + blockIdx.x] = r2; }
 }
 
@@ -1227,7 +1291,7 @@ constexpr int SMALL_LPL = 8, SMALL_CPC = 4;
 // the large-problem use of the same kernel (ba_fused_linearize: hundreds of cameras, the workgroup writes U and b_c itself);
 // zero_role = 0 drops the S / y zero-fill block (large systems clear S with k_zero_lower).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_small_linearize(BaDeviceView v, double delta, int nbL, int want_maxdiag, int* __restrict__ counter, int cpc,
-                                                         int zero_role)
+                                                         int zero_role, int fold_through)
 {
     __shared__ double sm[4];
     __shared__ double part[4][28];
@@ -1384,7 +1448,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             // [x run, (x + 1) run) and those lines are fetched into one L2 instead of eight (263 -> ~150 MB of L2 misses per launch)
             const int x = bid & 7, first = nbL + ((x - (nbL & 7) + 8) & 7), run = (v.n_fc + 7) >> 3, within = (bid - first) >> 3;
             hc = (bid >= first && within < run) ? x * run + within : v.n_fc;
-            if (hc >= v.n_fc) { if (tid == 0) v.partial[bid] = 0.0; return; }       // (cpc == 1: no last-block fold below)
+            if (hc >= v.n_fc) {
+                if (!fold_through) { if (tid == 0) v.partial[bid] = 0.0; return; }
+                if (tid == 0) store_partial_through(v.partial + bid, 0.0);
+                if (last_block_arrives_through(counter, n_blocks)) fold_partials_strided(v.partial, n_blocks, 1, v.scal + SC_CHI, 1, sm);
+                return;
+            }
         }
         const int cam = v.hc2cam[hc];
         PoseD P = load_pose(v.pose_cur, cam);
@@ -1461,10 +1530,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int i = n + tid; i < np; i += 256) v.S[(size_t)i * np + i] = 1.0;
     }
     const double r = block_sum<4>(chi, sm);
+    // Large problems (cpc == 1): the "last block" pattern with ordinary stores needs a release fence per block -- a write-back of the
+    // XCD's L2 -- and with thousands of blocks streaming 144 MB of W through those L2s that fence costs more than the whole kernel
+    // (0.32 ms against 0.13 for the three separate kernels).  Their partials go THROUGH instead (last_block_arrives_through), or,
+    // with fold_through = 0, are added by a k_reduce_sum launch.
+    if (cpc == 1 && fold_through) {
+        if (tid == 0) store_partial_through(v.partial + bid, r);
+        if (last_block_arrives_through(counter, n_blocks)) fold_partials_strided(v.partial, n_blocks, 1, v.scal + SC_CHI, 1, sm);
+        return;
+    }
     if (tid == 0) v.partial[bid] = r;
-    // Large problems (cpc == 1) fold the chi2 partials in a launch of their own: the "last block" pattern needs a release fence per
-    // block -- a write-back of the XCD's L2 -- and with thousands of blocks streaming 144 MB of W through those L2s that fence
-    // costs more than the whole kernel (0.32 ms against 0.13 for the three separate kernels).
     if (cpc == 1) return;
     if (!last_block_arrives(counter, n_blocks)) return;
     fold_partials(v.partial, n_blocks, v.scal + SC_CHI, sm);
@@ -2196,14 +2271,15 @@ bool ba_update_and_trial_error_fuses(const BaDeviceView& v)
     static const bool off = std::getenv("MAGE_BA_UNFUSED_TRIAL_ERROR") != nullptr;
     return !off && v.points_free && v.n_lm > 0 && v.n_fc > 0;
 }
-void ba_launch_update_and_trial_error(const BaDeviceView& v, double lambda, double lambda_cam, double delta, hipStream_t st)
+void ba_launch_update_and_trial_error(const BaDeviceView& v, double lambda, double lambda_cam, double delta, int* counter, hipStream_t st)
 {
     const int nb_l = cdiv(v.n_lm * BACKSUB_LPL, 256), nb_c = cdiv(v.n_fc, 256), n = nb_l + nb_c;
+    const bool fold = counter && ba_reductions_fold();
     hipLaunchKernelGGL(k_pose_update, dim3(nb_c), dim3(256), 0, st, v, lambda_cam, nb_l, n + nb_l);       // scale partials nb_l .. n, chi2 partials of those rows: zero
-    hipLaunchKernelGGL(k_backsub<true>, dim3(nb_l), dim3(256), 0, st, v, lambda, delta, n);
-    // partial = [scale: n][chi2: n] -> scal[SC_SCALE], scal[SC_SCALE + 6] = scal[SC_CHI_TRIAL]
+    hipLaunchKernelGGL(k_backsub<true>, dim3(nb_l), dim3(256), 0, st, v, lambda, delta, n, fold ? n : 0, counter);
+    // partial = [scale: n][chi2: n] -> scal[SC_SCALE], scal[SC_SCALE + 6] = scal[SC_CHI_TRIAL]: by the last block of k_backsub, or
     static_assert(SC_CHI_TRIAL - SC_SCALE == 6, "the two outputs of the fused reduction");
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, n, SC_CHI_TRIAL - SC_SCALE, v.scal + SC_SCALE, 2);
+    if (!fold) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, n, SC_CHI_TRIAL - SC_SCALE, v.scal + SC_SCALE, 2);
     tether_launch_error(v, true, st);
 }
 
@@ -2213,7 +2289,7 @@ void ba_launch_update(const BaDeviceView& v, double lambda, double lambda_cam, h
     int nb_l = 0;
     if (v.points_free && v.n_lm > 0) {
         nb_l = cdiv(v.n_lm * BACKSUB_LPL, 256);
-        hipLaunchKernelGGL(k_backsub<false>, dim3(nb_l), dim3(256), 0, st, v, lambda, 0.0, 0);
+        hipLaunchKernelGGL(k_backsub<false>, dim3(nb_l), dim3(256), 0, st, v, lambda, 0.0, 0, 0, (int*)nullptr);
     }
     int nb_c = 0;
     if (v.n_fc > 0) {
@@ -2236,11 +2312,8 @@ static int small_error_blocks(const BaDeviceView& v) { return v.n_L > 0 ? std::m
 void ba_small_linearize(const BaDeviceView& v, double delta, bool want_maxdiag, int* counter, hipStream_t st)
 {
     const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm * (v.dup_slots ? 1 : SMALL_LPL), 256) : 0;
-    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + v.n_fc * SMALL_CPC + 1), dim3(256), 0, st, v, delta, nbL, want_maxdiag ? 1 : 0, counter, SMALL_CPC, 1);
+    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + v.n_fc * SMALL_CPC + 1), dim3(256), 0, st, v, delta, nbL, want_maxdiag ? 1 : 0, counter, SMALL_CPC, 1, 0);
 }
-// The same kernel for LARGE problems in which every observation owns its W block: k_error + k_linearize_lm +
-// k_linearize_cam in one launch -- the residuals are computed once, a landmark's observations by eight lanes, the chi2 folded by the
-// last block.  S is cleared by ba_launch_schur, max |diag| comes from ba_launch_maxdiag.
 // Positions of the compact records (BaDeviceView::w_pos): camera-major = the inverse of camS, or the identity.
 __global__ __launch_bounds__(256) void k_build_positions(BaDeviceView v, int* __restrict__ w_pos, int* __restrict__ pos_lm, int camera_major)
 {
@@ -2275,6 +2348,17 @@ bool ba_compact_w_enabled()
     static const bool off = std::getenv("MAGE_BA_MATERIAL_W") != nullptr;
     return !off;
 }
+// Measured on the 1k-pose map (round 4, one MI355X): with the folds k_small_linearize 64.8 -> 68.9 us, k_backsub 35.7 -> 44.3,
+// k_classify 12.4 -> 17.4 (the last blocks' write-through + two counts + acquire + fold are a ~6 us tail -- what a k_reduce_sum
+// launch costs), the step 2.825 against 2.818 ms: no gain, so the separate launches stay the default.  MAGE_BA_FOLD_REDUCTIONS=1 folds.
+bool ba_reductions_fold()
+{
+    static const bool on = std::getenv("MAGE_BA_FOLD_REDUCTIONS") != nullptr;
+    return on;
+}
+// The same kernel for LARGE problems in which every observation owns its W block: k_error + k_linearize_lm +
+// k_linearize_cam in one launch -- the residuals are computed once, a landmark's observations by eight lanes, the chi2 folded by the
+// last block.  S is cleared by ba_launch_schur, max |diag| comes from ba_launch_maxdiag.
 bool ba_fused_linearize_applies(const BaDeviceView& v)
 {
     static const bool off = std::getenv("MAGE_BA_NO_FUSED_LINEARIZE") != nullptr;
@@ -2284,8 +2368,9 @@ void ba_fused_linearize(const BaDeviceView& v, double delta, int* counter, hipSt
 {
     const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm * SMALL_LPL, 256) : 0;
     const int nbC = ((v.n_fc + 7) / 8) * 8 + 8;          // every XCD gets ceil(n_fc / 8) camera workgroups wherever its first one falls
-    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + nbC), dim3(256), 0, st, v, delta, nbL, 0, counter, 1, 0);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nbL + nbC, 1, v.scal + SC_CHI, 1);
+    const bool fold = ba_reductions_fold();
+    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + nbC), dim3(256), 0, st, v, delta, nbL, 0, counter, 1, 0, fold ? 1 : 0);
+    if (!fold) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nbL + nbC, 1, v.scal + SC_CHI, 1);
     tether_launch_error(v, false, st);          // the pose-pose edges add their chi2, U and b_c on top (nothing is launched without them)
     tether_launch_linearize(v, st);
 }
@@ -2342,18 +2427,22 @@ void ba_launch_import_poses(double* pose0, double* pose1, const uint32_t* cam, c
     if (n) hipLaunchKernelGGL(k_import_poses, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, st, pose0, pose1, cam, row, n, block);
 }
 
-void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, hipStream_t st)
+// fold_counter: the handle's zero-between-launches int (the last block adds the three sums), or nullptr (a k_reduce_sum launch does)
+void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* fold_counter, hipStream_t st)
 {
     int nb = v.n_L > 0 ? (cdiv(v.n_L, 256) < RED_BLOCKS ? cdiv(v.n_L, 256) : RED_BLOCKS) : 1;
-    hipLaunchKernelGGL(k_classify<false>, dim3(nb), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, nb, ClassifyAfterTrial{});
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
+    if (!ba_reductions_fold()) fold_counter = nullptr;
+    hipLaunchKernelGGL(k_classify<false>, dim3(nb), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, nb, ClassifyAfterTrial{}, fold_counter);
+    if (!fold_counter) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
 }
-void ba_launch_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, hipStream_t st)
+void ba_launch_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* fold_counter,
+                                    hipStream_t st)
 {
     int nb = v.n_L > 0 ? (cdiv(v.n_L, 256) < RED_BLOCKS ? cdiv(v.n_L, 256) : RED_BLOCKS) : 1;
-    hipLaunchKernelGGL(k_classify<true>, dim3(nb), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, nb, c);
-    // (when the kernel found the call unfinished the three sums below are sums of stale partials: nobody reads them then)
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
+    if (!ba_reductions_fold()) fold_counter = nullptr;
+    hipLaunchKernelGGL(k_classify<true>, dim3(nb), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, nb, c, fold_counter);
+    // (when the kernel found the call unfinished the three sums are stale: nobody reads them then)
+    if (!fold_counter) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
 }
 
 }  // namespace mage

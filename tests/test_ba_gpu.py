@@ -149,6 +149,37 @@ def test_compact_and_materialised_w_agree(tmp_path):
     np.testing.assert_allclose(a[0], b[0], rtol=1e-9, atol=1e-10)
 
 
+def test_placement_and_reduction_switches_are_bit_identical(tmp_path):
+    """Round 4: the compact W records are stored camera-major (MAGE_BA_W_LANDMARK_MAJOR=1: position == slot) and the chi2 / scale /
+    outlier sums can be added by the last block of the kernel that produces them (MAGE_BA_FOLD_REDUCTIONS=1) instead of a
+    k_reduce_sum launch.  Placement and who adds: the same values meet in the same order, so every output is identical to the bit."""
+    import json, os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, json
+        sys.path.insert(0, %r)
+        import numpy as np
+        from mageslam_amd import scene
+        from mageslam_amd.bundler import BundlerLib, load_scene
+        s = scene.make_scene(n_cams=60, n_pts=6000, n_obs=60000, seed=0x5EED0B11, outlier_frac=0.01)
+        b = BundlerLib(False); load_scene(b, s, bulk=True)
+        outs, tr = [], []
+        for hub, thr in [([1.8], 25.0), ([0.9, 0.9], 16.0), ([0.9], 9.0)]:
+            o = []; mse = b.StepBundleAdjustment(hub, thr, o); outs.append([float(mse)] + sorted(o)); tr.append([(t["code"], t["trials"], t["chi_after"]) for t in b.trace()])
+        np.save(sys.argv[1], np.concatenate([b.poses_f64().ravel(), b.points_f64().ravel()]))
+        print("RESULT " + json.dumps(dict(outs=outs, tr=tr)))
+    """) % root
+    res = {}
+    for tag, env in (("default", {}), ("landmark_major", {"MAGE_BA_W_LANDMARK_MAJOR": "1"}), ("folded", {"MAGE_BA_FOLD_REDUCTIONS": "1"})):
+        f = str(tmp_path / (tag + ".npy"))
+        p = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+        res[tag] = (np.load(f), json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    for tag in ("landmark_major", "folded"):
+        assert res[tag][1] == res["default"][1], tag
+        assert np.array_equal(res[tag][0], res["default"][0]), tag
+
+
 def test_concurrent_handles_on_separate_threads():
     """SURVEY 8b threading contract: every BundlerLib instance is thread-confined, several run concurrently on different
     threads (mapping, loop closure, tracking).  Four handles, each on its own thread and HIP stream, interleaved on one
