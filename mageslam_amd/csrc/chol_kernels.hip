@@ -803,22 +803,6 @@ __device__ __forceinline__ void trsm_strip_pipelined(double* __restrict__ S, dou
     if (!ok && lane == 0) *stall = 2.0;
 }
 
-__global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
-                                                   const double* __restrict__ Linv_k, int* __restrict__ queue, int queue_start)
-{
-    const int lane = threadIdx.x;
-    if (blockIdx.x == 0 && lane == 0) { queue[0] = 0; if (k == 0) { queue[1] = 0; queue[2] = 0; queue[3] = 0; } }     // hand-off counters of the launches that follow (queue_start < 0: also fill the pipelined strips' sentinels)
-    if (k == 0 && queue_start < 0) {
-        // what the pipelined panel solves of the later columns poll: the block inverses of tiles 1 .. nt - 1 and every tile's scratch
-        // blocks start as the sentinel (this launch is the second of a factorisation; those areas are first written 19+ launches later)
-        unsigned long long* W = reinterpret_cast<unsigned long long*>(const_cast<double*>(Linv_k));
-        const size_t first = (size_t)NBLK * NB * NB, total = (size_t)nt * (NBLK * NB * NB + LPUB_TILE_DOUBLES);
-        for (size_t i = first + (size_t)blockIdx.x * 64 + lane; i < total; i += (size_t)gridDim.x * 64) W[i] = X_SENTINEL;
-    }
-    const int n_strips = (nt - k - 1) * NBLK;
-    trsm_strip(S, y, ld, k, (int)blockIdx.x, (int)blockIdx.x == n_strips, Linv_k, lane);
-}
-
 // ---------------------------------------------------------------------------------------------
 // trailing update.  One workgroup = one 128x128 tile of the lower triangle, 4 wavefronts as 2x2,
 // each owning 64x64 = 4x4 MFMA tiles (128 accumulator registers).  Operands go straight from
@@ -1254,6 +1238,146 @@ __device__ __forceinline__ void trsm_strip_wt(double* __restrict__ S, double* __
     }
 }
 
+// One 16-row strip by the FOUR wavefronts of its workgroup (round 4).  A strip is a chain of 176 matrix-core operations and every
+// f64 MFMA holds its SIMD's pipe for 64 cycles, dependent or not: one wavefront needs 11.3 k cycles (4.7 us) whatever it overlaps.
+// But only 8 of a step's operations are on the chain -- acc_{j+1} -= L(j+1, j) Y_j and Y_{j+1} = Linv_{j+1} acc_{j+1}; the updates
+// of the later block columns are independent of each other.  Wavefront w owns block columns {w, 7 - w} (9 products each): the owner
+// of column j forms Y_j, leaves it in LDS (accumulator layout = B operand of the updates), one LDS-only barrier, every wavefront
+// applies Y_j to the columns it owns -- the next step's column first.  Operands per wavefront: 9 blocks instead of 36.
+// Same operations in the same order per block column as trsm_strip / trsm_strip_wt: bit-identical.
+// WT: L_kk and the block inverses come through agent-scope loads (write-through hand-off); WAIT: poll the launch's flags first
+// (wavefront 0 polls, the others wait at the barrier).  ysh: (NBLK - 1) * 256 doubles of LDS.
+template <bool WT, bool WAIT, int W>
+__device__ __forceinline__ void trsm_strip_4w_body(double* __restrict__ base, size_t cstride, bool live, const double* __restrict__ S, int ld, int k,
+                                                   const double* __restrict__ Linv_k, int* __restrict__ flag, double* __restrict__ stall, int lane,
+                                                   double* __restrict__ ysh)
+{
+    constexpr int C0 = W, C1 = NBLK - 1 - W;
+    double4_t acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        acc0[r] = live ? base[(size_t)(C0 * NB + (lane >> 4) + 4 * r) * cstride] : 0.0;
+        acc1[r] = live ? base[(size_t)(C1 * NB + (lane >> 4) + 4 * r) * cstride] : 0.0;
+    }
+    if (WAIT) {
+        if (W == 0 && !poll_at_least(flag + 1, k, lane) && lane == 0) *stall = 2.0;
+        tile_barrier<true>();
+    }
+    const double* Lop = S + (size_t)(k * TILE + (lane >> 4)) * ld + (size_t)k * TILE + (lane & 15);
+    const double* Lio = Linv_k + (lane & 15) * NB + (lane >> 4);
+    auto ld1 = [](const double* p) -> double { return WT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
+    double lio0[4], lio1[4], lop0[C0 > 0 ? C0 : 1][4], lop1[C1][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { lio0[r] = ld1(Lio + C0 * NB * NB + 4 * r); lio1[r] = ld1(Lio + C1 * NB * NB + 4 * r); }
+#pragma unroll
+    for (int j = 0; j < C0; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lop0[j][r] = -ld1(Lop + (size_t)(j * NB + 4 * r) * ld + C0 * NB);
+#pragma unroll
+    for (int j = 0; j < C1; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lop1[j][r] = -ld1(Lop + (size_t)(j * NB + 4 * r) * ld + C1 * NB);
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) {
+        double4_t Yj = { 0, 0, 0, 0 };
+        const bool mine = j == C0 || j == C1;
+        if (mine) {
+            const double4_t a = j == C0 ? acc0 : acc1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Yj = __builtin_amdgcn_mfma_f64_16x16x4f64(j == C0 ? lio0[r] : lio1[r], a[r], Yj, 0, 0, 0);
+            if (j < NBLK - 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ysh[j * 256 + r * 64 + lane] = Yj[r];
+            }
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) base[(size_t)(j * NB + (lane >> 4) + 4 * r) * cstride] = Yj[r];
+            }
+        }
+        if (j == NBLK - 1) break;
+        tile_barrier<true>();
+        if (!mine) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Yj[r] = ysh[j * 256 + r * 64 + lane];
+        }
+        // the column of the next step first
+        if (C1 > j && C1 == j + 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop1[j][r], Yj[r], acc1, 0, 0, 0);
+        }
+        if (C0 > j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop0[j][r], Yj[r], acc0, 0, 0, 0);
+        }
+        if (C1 > j && C1 != j + 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop1[j][r], Yj[r], acc1, 0, 0, 0);
+        }
+    }
+}
+template <bool WT, bool WAIT>
+__device__ __forceinline__ void trsm_strip_4w(double* __restrict__ S, double* __restrict__ y, int ld, int k, int strip, bool is_rhs, const double* __restrict__ Linv_k,
+                                              int* __restrict__ flag, int col_target, double* __restrict__ stall, int lane, int wave, double* __restrict__ ysh)
+{
+    double* base;
+    size_t cstride;
+    bool live;
+    if (!is_rhs) {
+        base = S + (size_t)(k * TILE) * ld + (size_t)(k + 1) * TILE + strip * NB + (lane & 15);
+        cstride = (size_t)ld;
+        live = true;
+        if (WAIT) {
+            if (wave == 0 && !poll_at_least(flag + 2, col_target, lane) && lane == 0) *stall = 2.0;
+            tile_barrier<true>();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    } else {
+        base = y + (size_t)k * TILE;       // this workgroup's own row (just updated when WAIT)
+        cstride = 1;
+        live = (lane & 15) == 0;
+    }
+    switch (wave) {
+        case 0: trsm_strip_4w_body<WT, WAIT, 0>(base, cstride, live, S, ld, k, Linv_k, flag, stall, lane, ysh); break;
+        case 1: trsm_strip_4w_body<WT, WAIT, 1>(base, cstride, live, S, ld, k, Linv_k, flag, stall, lane, ysh); break;
+        case 2: trsm_strip_4w_body<WT, WAIT, 2>(base, cstride, live, S, ld, k, Linv_k, flag, stall, lane, ysh); break;
+        default: trsm_strip_4w_body<WT, WAIT, 3>(base, cstride, live, S, ld, k, Linv_k, flag, stall, lane, ysh); break;
+    }
+}
+
+// the panel solve of tile column k as a launch of its own (the update-bound columns; column 0)
+// (two kernels, not one with a run-time choice: the one-wavefront strip keeps all 36 operand blocks in ~380 registers, and at that
+// size only ONE four-wavefront workgroup fits a compute unit -- the 369 strips of column 0 would take two rounds)
+__device__ __forceinline__ void panel_launch_duties(double* __restrict__ Linv_k, int k, int nt, int* __restrict__ queue, int queue_start, int tid, int nthreads)
+{
+    if (blockIdx.x == 0 && tid == 0) { queue[0] = 0; if (k == 0) { queue[1] = 0; queue[2] = 0; queue[3] = 0; } }     // hand-off counters of the launches that follow (queue_start < 0: also fill the pipelined strips' sentinels)
+    if (k == 0 && queue_start < 0) {
+        // what the pipelined panel solves of the later columns poll: the block inverses of tiles 1 .. nt - 1 and every tile's scratch
+        // blocks start as the sentinel (this launch is the second of a factorisation; those areas are first written 19+ launches later)
+        unsigned long long* W = reinterpret_cast<unsigned long long*>(Linv_k);
+        const size_t first = (size_t)NBLK * NB * NB, total = (size_t)nt * (NBLK * NB * NB + LPUB_TILE_DOUBLES);
+        for (size_t i = first + (size_t)blockIdx.x * nthreads + tid; i < total; i += (size_t)gridDim.x * nthreads) W[i] = X_SENTINEL;
+    }
+}
+// one strip per workgroup, by its four wavefronts (trsm_strip_4w; MAGE_CHOL_STRIP_4W=1)
+__global__ __launch_bounds__(256, 2) void k_trsm_panel(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
+                                                       const double* __restrict__ Linv_k, int* __restrict__ queue, int queue_start)
+{
+    __shared__ double ysh[(NBLK - 1) * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    panel_launch_duties(const_cast<double*>(Linv_k), k, nt, queue, queue_start, tid, 256);
+    const int n_strips = (nt - k - 1) * NBLK;
+    trsm_strip_4w<false, false>(S, y, ld, k, (int)blockIdx.x, (int)blockIdx.x == n_strips, Linv_k, nullptr, 0, nullptr, lane, wave, ysh);
+}
+// the same by one wavefront (the default)
+__global__ __launch_bounds__(64) void k_trsm_panel_1w(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
+                                                      const double* __restrict__ Linv_k, int* __restrict__ queue, int queue_start)
+{
+    const int lane = threadIdx.x;
+    panel_launch_duties(const_cast<double*>(Linv_k), k, nt, queue, queue_start, lane, 64);
+    const int n_strips = (nt - k - 1) * NBLK;
+    trsm_strip(S, y, ld, k, (int)blockIdx.x, (int)blockIdx.x == n_strips, Linv_k, lane);
+}
+
 // The merged strip as a PRODUCT (round 4): with the tile's full inverse in memory (potrf_tile_lds<.., 3>) the strip is
 //     X = A L^-T,   i.e. on the transposed unknown   Y_c = sum_{j <= c} Linv[c][j] A_j^T        (c = 0 .. 7, 16 columns each)
 // and nothing depends on anything: the FOUR wavefronts of the strip's workgroup take the block columns {w, 7 - w} -- 36 matrix-core
@@ -1326,7 +1450,7 @@ __device__ __forceinline__ void trsm_strip_gemm(double* __restrict__ S, double* 
 template <int MERGE, bool WT = false, bool GEMM = false>
 __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
                                                      double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int n_q4, int col_target,
-                                                     int dbg, double* __restrict__ Lpub_next)
+                                                     int dbg, double* __restrict__ Lpub_next, int strip4w)
 {
     constexpr int merge = MERGE;
     extern __shared__ double sm[];
@@ -1344,6 +1468,15 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_max(dbg, 8);
             return;
+        }
+        if constexpr (MERGE == 1 && WT && !GEMM) {
+            if (strip4w) {          // the strip by all four wavefronts (trsm_strip_4w); strip4w = 0: wavefront 0 alone, as below
+                dbg_min(dbg, 6);
+                trsm_strip_4w<true, true>(S, y, ld, j0, bid - (first_rhs + mt), false, Linv_next, flag, col_target, stall, lane, wave, sm);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (dbg) { __syncthreads(); dbg_max(dbg, 8); }
+                return;
+            }
         }
         if (wave != 0) return;
         dbg_min(dbg, 6);
@@ -1386,6 +1519,9 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if constexpr (GEMM) { trsm_strip_gemm(S, y, ld, j0, 0, true, Lpub_next, flag, 0, stall, lane, wave); return; }
+                if constexpr (MERGE == 1 && WT && !GEMM) {
+                    if (strip4w) { trsm_strip_4w<true, true>(S, y, ld, j0, 0, true, Linv_next, flag, 0, stall, lane, wave, sm); return; }
+                }
                 if (wave != 0) return;
                 if constexpr (MERGE == 2) trsm_strip_pipelined(S, y, ld, j0, 0, true, Linv_next, Lpub_next, stall, lane);
                 else if constexpr (WT) trsm_strip_wt(S, y, ld, j0, 0, true, Linv_next, flag, 0, stall, lane);
@@ -1910,7 +2046,13 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
     static const bool merge_env_off = std::getenv("MAGE_CHOL_NO_MERGED_TRSM") != nullptr;
     const bool merge_off = merge_env_off || g_merge_disabled.load(std::memory_order_relaxed);
     static const bool pipelined_fill = std::getenv("MAGE_CHOL_PIPELINED_TRSM") != nullptr;
-    hipLaunchKernelGGL(k_trsm_panel, dim3((nt - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, 0, nt, ws.Linv, ws.sync, pipelined_fill ? -1 : 0);
+    // Strips by the four wavefronts of their workgroup (trsm_strip_4w): OFF by default, MAGE_CHOL_STRIP_4W=1 selects it.  Measured (round 4,
+    // tools/_bin/chol_test 6016, time stamps of launch 36): the strip ends 6.4 us after L_kk is stored instead of 7.2 -- its 4.7 us of
+    // matrix-core issue were never the long leg, the flag, the operands' trip past the L2 and the store are -- and the panel-solve launches
+    // gain nothing (10.8 against 10.6 us: 256-thread workgroups, seven barriers): 2.577-2.583 ms against 2.566-2.572.  Bit-identical.
+    static const bool strip4w = std::getenv("MAGE_CHOL_STRIP_4W") != nullptr;
+    if (strip4w) hipLaunchKernelGGL(k_trsm_panel, dim3((nt - 1) * NBLK + 1), dim3(256), 0, st, S, y, n_pad, 0, nt, ws.Linv, ws.sync, pipelined_fill ? -1 : 0);
+    else hipLaunchKernelGGL(k_trsm_panel_1w, dim3((nt - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, 0, nt, ws.Linv, ws.sync, pipelined_fill ? -1 : 0);
     int col_total = 0;
     static const int dbg_col = std::getenv("CHOL_DBG_COL") ? std::atoi(std::getenv("CHOL_DBG_COL")) : -1;
     for (int k = 0; k + 1 < nt; ++k) {
@@ -1952,7 +2094,9 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
             // the same 56 KB of L_kk past the L2 (agent-scope loads; 200 strips in the first chain-bound columns: launch 41.8 -> 52.8 us)
             // and their polling takes fabric bandwidth from the factoring workgroup (tile load 1.4 -> 3.6 us): 2.80 ms per factorisation
             // against 2.71.  One release + one acquire per strip and L2-cached reads of the broadcast operand stay.
-            static const bool pipelined = std::getenv("MAGE_CHOL_PIPELINED_TRSM") != nullptr;
+            // (MAGE_CHOL_PIPELINED_TRSM=<rows>: only in the columns with at most <rows> tile rows left, where few strips poll; 1 = every column)
+            static const int pipelined_rows = std::getenv("MAGE_CHOL_PIPELINED_TRSM") ? std::atoi(std::getenv("MAGE_CHOL_PIPELINED_TRSM")) : 0;
+            const bool pipelined = pipelined_rows == 1 || (pipelined_rows > 1 && m <= pipelined_rows);
             // the write-through form of the chain's two hand-offs (k_syrk_update<1, true>); MAGE_CHOL_WT_HANDOFF=0 restores release / acquire
             static const bool wt_handoff = !(std::getenv("MAGE_CHOL_WT_HANDOFF") && std::atoi(std::getenv("MAGE_CHOL_WT_HANDOFF")) == 0);
             // The strips as products over the tile's full inverse (k_syrk_update<1, true, true>): OFF by default, MAGE_CHOL_GEMM_STRIPS=1 selects
@@ -1966,15 +2110,16 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
             const int dbg = (ws.dbg && dbg_col == k) ? 1 : 0;
             double* const Linv_next = ws.Linv + (size_t)(k + 1) * linv_stride;
             double* const Lpub_next = ws.Linv + (size_t)nt * linv_stride + (size_t)(k + 1) * LPUB_TILE_DOUBLES;
-            if (!merged) hipLaunchKernelGGL(k_syrk_update<0>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next);
-            else if (pipelined) hipLaunchKernelGGL(k_syrk_update<2>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next);
+            if (!merged) hipLaunchKernelGGL(k_syrk_update<0>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next, strip4w ? 1 : 0);
+            else if (pipelined) hipLaunchKernelGGL(k_syrk_update<2>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next, strip4w ? 1 : 0);
             else if (wt_handoff && gemm_strips)
                 hipLaunchKernelGGL((k_syrk_update<1, true, true>), grid, dim3(256), lds_diag + PACKED_TILE_DOUBLES * sizeof(double), st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync,
-                                   n_q4, col_total, dbg, ws.Linv + (size_t)nt * (linv_stride + LPUB_TILE_DOUBLES) + (size_t)(k + 1) * PACKED_TILE_DOUBLES);
-            else if (wt_handoff) hipLaunchKernelGGL((k_syrk_update<1, true>), grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next);
-            else hipLaunchKernelGGL(k_syrk_update<1>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next);
+                                   n_q4, col_total, dbg, ws.Linv + (size_t)nt * (linv_stride + LPUB_TILE_DOUBLES) + (size_t)(k + 1) * PACKED_TILE_DOUBLES, strip4w ? 1 : 0);
+            else if (wt_handoff) hipLaunchKernelGGL((k_syrk_update<1, true>), grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next, strip4w ? 1 : 0);
+            else hipLaunchKernelGGL(k_syrk_update<1>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next, strip4w ? 1 : 0);
         }
-        if (!merged) hipLaunchKernelGGL(k_trsm_panel, dim3((m - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, k + 1, nt, ws.Linv + (size_t)(k + 1) * linv_stride, ws.sync, 0);
+        if (!merged && strip4w) hipLaunchKernelGGL(k_trsm_panel, dim3((m - 1) * NBLK + 1), dim3(256), 0, st, S, y, n_pad, k + 1, nt, ws.Linv + (size_t)(k + 1) * linv_stride, ws.sync, 0);
+        else if (!merged) hipLaunchKernelGGL(k_trsm_panel_1w, dim3((m - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, k + 1, nt, ws.Linv + (size_t)(k + 1) * linv_stride, ws.sync, 0);
     }
     // backward substitution: one persistent launch (needs every workgroup resident: nt <= 256 compute units)
     hipLaunchKernelGGL(k_bsolve_persist, dim3(nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, stall, ws.dbg);

@@ -1,16 +1,16 @@
 cd $GRAFT_REPO_ROOT
-for mode in fold sep; do
-  if [ $mode = sep ]; then export MAGE_BA_SEPARATE_REDUCE=1; else unset MAGE_BA_SEPARATE_REDUCE; fi
-  python bench.py --no-cpu-baseline --no-extras > gpurun_out/fold_$mode.json 2> gpurun_out/fold_$mode.err
-  python - <<PY
-import json
-b=json.load(open('gpurun_out/fold_$mode.json'))
-print('$mode', b['value'], b['ms_per_step'], b['final_reproj_rmse_px'], {k:v['ms'] for k,v in b['roofline_hbm']['stages'].items()} if 'stages' in b['roofline_hbm'] else '')
-PY
+T=tools/_bin/chol_test
+echo "== 4w"; timeout 120 $T 6016 10 | grep "n= 6016"
+echo "== 1w"; MAGE_CHOL_STRIP_1W=1 timeout 120 $T 6016 10 | grep "n= 6016"
+echo "== 4w"; timeout 120 $T 6016 10 | grep "n= 6016"
+echo "== 1w"; MAGE_CHOL_STRIP_1W=1 timeout 120 $T 6016 10 | grep "n= 6016"
+echo "== all sizes 4w"; timeout 200 $T | tail -12
+for col in 36; do
+echo "== stamps 4w col $col"; CHOL_DBG=1 CHOL_DBG_COL=$col timeout 120 $T 6016 3 | grep -A12 "launch $col"
+echo "== stamps 1w col $col"; MAGE_CHOL_STRIP_1W=1 CHOL_DBG=1 CHOL_DBG_COL=$col timeout 120 $T 6016 3 | grep -A12 "launch $col"
 done
-unset MAGE_BA_SEPARATE_REDUCE
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/p1; rocprofv3 --kernel-trace -d /tmp/p1 -o b -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras > /dev/null 2>&1
-python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find /tmp/p1 -name '*.db' | head -1) | sed -n 6,16p
+rm -rf /tmp/p1; rocprofv3 --kernel-trace -d /tmp/p1 -o b -- $GRAFT_REPO_ROOT/$T 6016 5 > /dev/null 2>&1
+python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find /tmp/p1 -name '*.db' | head -1) | head -10
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_ba_gpu.py tests/test_ba_build_gpu.py tests/test_sharded_gpu.py tests/test_windowed_gpu.py tests/test_concurrency_gpu.py -q -x 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_chol_gpu.py -q -x 2>&1 | tail -3
