@@ -261,8 +261,8 @@ struct mage_ba {
     DevBuf<int> d_lm_ptr, d_lm_pt, d_lm_wptr, d_w_hc, d_w_lm, d_camE_ptr, d_camE, d_camS_ptr, d_camS, d_blk_ptr;
     DevBuf<int2> d_blk_ij, d_con;
     // where the compact W records live (BaDeviceView::w_pos): built on the first LM iteration that uses the compact form
-    DevBuf<int> d_w_pos, d_pos_lm;
-    DevBuf<int2> d_con_pos;
+    DevBuf<int> d_w_pos, d_pos_lm, d_slot_order;
+    DevBuf<ConPos> d_con_pos;
     size_t n_con = 0;
     bool positions_valid = false;
     DevBuf<int> d_blk_order;
@@ -1067,7 +1067,8 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(stage_array(h, h->d_W, (size_t)nw * 18 + 1));
     if (points_free && !h->dup_slots && (nfc * 6 > 128 || nT > 0 || h->shard_ranks > 0) && ba_compact_w_enabled()) {      // the compact form will be used: its position maps (lm_solve fills them)
         MAGE_TRY(stage_array(h, h->d_w_pos, (size_t)nw + 1)); MAGE_TRY(stage_array(h, h->d_pos_lm, (size_t)nw + 1)); MAGE_TRY(stage_array(h, h->d_con_pos, ncon + 1));
-    } else { h->d_w_pos.drop_alias(); h->d_pos_lm.drop_alias(); h->d_con_pos.drop_alias(); }      // (views of an earlier image must not outlive it)
+        MAGE_TRY(stage_array(h, h->d_slot_order, (size_t)Z.n_blk_slots + 8));
+    } else { h->d_w_pos.drop_alias(); h->d_pos_lm.drop_alias(); h->d_con_pos.drop_alias(); h->d_slot_order.drop_alias(); }      // (views of an earlier image must not outlive it)
     MAGE_TRY(stage_array(h, h->d_Dinv, (size_t)nlm * 6 + 1));
     MAGE_TRY(stage_array(h, h->d_db, (size_t)nlm * 4 + 1));
     MAGE_TRY(stage_array(h, h->d_S, (size_t)n_pad * n_pad));
@@ -1105,7 +1106,7 @@ mage_status initialize_optimization(mage_ba* h)
     h->n_active_tethers = nT;
     v.errL = h->d_errL.p; v.U = h->d_U.p; v.bc = h->d_bc.p; v.V = h->d_V.p; v.bp = h->d_bp.p; v.W = h->d_W.p;
     v.compact = 0; v.camR = h->d_camR.p;
-    v.w_pos = nullptr; v.pos_lm = nullptr; v.con_pos = nullptr;
+    v.w_pos = nullptr; v.pos_lm = nullptr; v.con_pos = nullptr; v.slot_order = nullptr;
     h->positions_valid = false; h->n_con = ncon;
     v.Dinv = h->d_Dinv.p; v.db = h->d_db.p; v.S = h->d_S.p; v.y = h->d_y.p; v.xc = h->d_xc.p; v.xl = h->d_xl.p;
     v.partial = h->d_partial.p; v.scal = h->d_scal.p;
@@ -1189,8 +1190,11 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
     v.compact = (!small && v.points_free && ba_fused_linearize_applies(v) && ba_compact_w_enabled()) ? 1 : 0;
     if (v.compact && !h->positions_valid) {
         MAGE_TRY(h->d_w_pos.reserve((size_t)v.n_w + 1)); MAGE_TRY(h->d_pos_lm.reserve((size_t)v.n_w + 1)); MAGE_TRY(h->d_con_pos.reserve(h->n_con + 1));
-        ba_launch_build_positions(v, h->d_w_pos.p, h->d_pos_lm.p, h->d_con_pos.p, st);
-        v.w_pos = h->d_w_pos.p; v.pos_lm = h->d_pos_lm.p; v.con_pos = h->d_con_pos.p;
+        static const bool row_order = std::getenv("MAGE_BA_SCHUR_ROW_ORDER") != nullptr;      // A/B: the blocks of an XCD in row order (blk_order itself)
+        const bool lpt = !row_order && v.n_blk_slots > 0;
+        if (lpt) MAGE_TRY(h->d_slot_order.reserve((size_t)v.n_blk_slots + 8));
+        ba_launch_build_positions(v, h->d_w_pos.p, h->d_pos_lm.p, h->d_con_pos.p, lpt ? h->d_slot_order.p : nullptr, st);
+        v.w_pos = h->d_w_pos.p; v.pos_lm = h->d_pos_lm.p; v.con_pos = h->d_con_pos.p; v.slot_order = lpt ? h->d_slot_order.p : nullptr;
         h->positions_valid = true;
     }
     if (small) ba_small_linearize(v, huber, h->iteration == 0, counter, st);

@@ -13,6 +13,7 @@ namespace mage {
 
 constexpr int SCHUR_WAVES = 1;     // wavefronts (= blocks of S) per workgroup of k_schur_block; the slot table is built for it
 
+struct ConPos { int a, b, lm; };
 struct BaDeviceView {
     // ---- sizes
     int n_cams, n_pts;        // allocated cameras / points
@@ -54,7 +55,10 @@ struct BaDeviceView {
     // order.  MAGE_BA_W_LANDMARK_MAJOR=1 keeps position == slot (A/B).  Valid while `compact` (ba_launch_build_positions).
     const int* w_pos;                          // n_w : slot -> position
     const int* pos_lm;                         // n_w : landmark of a position
-    const int2* con_pos;                       // the contributions of `con` in positions
+    const int* slot_order;                     // blk_order with every XCD's run sorted longest block first (k_schur_block_compact: the diagonal
+                                               // blocks are four times the average and sat at regular intervals up to the END of the grid)
+    const struct ConPos* con_pos;              // the contributions of `con` as (position a, position b, landmark): 12 bytes, ONE trip to memory
+                                               // between a block's list and its records (the landmark used to be a look-up of its own)
 
     // ---- tether edges (pose-pose constraints; active ones only, all three kinds in one list)
     int n_T, n_tc, n_tp;                       // tethers / cameras carrying tethers / free-camera pairs joined by tethers
@@ -99,7 +103,7 @@ void ba_launch_error(const BaDeviceView& v, bool trial, double huber_delta, hipS
 void ba_launch_linearize(const BaDeviceView& v, double huber_delta, hipStream_t st);                 // U,bc,V,bp,W
 void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st, const double* udiag_sum = nullptr);                                       // -> scal[SC_MAXDIAG]
 void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st);                          // Dinv,db,S,y
-void ba_launch_build_positions(const BaDeviceView& v, int* w_pos, int* pos_lm, int2* con_pos, hipStream_t st); // w_pos / pos_lm / con_pos from camS, w_lm, con
+void ba_launch_build_positions(const BaDeviceView& v, int* w_pos, int* pos_lm, ConPos* con_pos, int* slot_order, hipStream_t st); // w_pos / pos_lm / con_pos from camS, w_lm, con
 bool ba_w_camera_major();                                                                             // false with MAGE_BA_W_LANDMARK_MAJOR=1
 void ba_launch_tile_envelope(const BaDeviceView& v, int* tile_env, hipStream_t st);                  // the skyline of S by tile rows, from blk_ij and the tether pairs
 void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st);                         // xl, trial state, scal[SC_SCALE]

@@ -747,7 +747,7 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block_
     } else {
         const int slot = blockIdx.x * SCHUR_WAVES + wave;
         if (slot >= v.n_blk_slots) return;
-        b = v.blk_order[slot];
+        b = (v.slot_order ? v.slot_order : v.blk_order)[slot];
         if (b < 0) return;
     }
     b = __builtin_amdgcn_readfirstlane(b);
@@ -755,47 +755,47 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block_
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0;
+    // The block's header is two chains of dependent loads -- (i, j) -> the cameras' constants, and the list bounds -> entries -> landmarks
+    // -> records.  A block is ~4 trips of the loop below, so its start-up latency counts as much as its arithmetic (two wavefronts per
+    // SIMD): both chains are ISSUED before the first wait -- the constants are moved to scalar registers (a wait) only after the first
+    // records have been requested.
     const int2 ij = v.blk_ij[b];
+    const int c_begin = v.blk_ptr[b], c_end = v.blk_ptr[b + 1];
     const bool diag = ij.x == ij.y;
-    const CamConst ci = uniform_cam_const(load_cam_const(v.camR, ij.x)), cj = uniform_cam_const(load_cam_const(v.camR, ij.y));   // in SGPRs: 40 VGPRs less
+    const CamConst ci_v = load_cam_const(v.camR, ij.x), cj_v = load_cam_const(v.camR, ij.y);
     double yv[6] = { 0, 0, 0, 0, 0, 0 };
-    const int c_end = v.blk_ptr[b + 1];
     const double2* G2 = reinterpret_cast<const double2*>(v.W);
-    // Software pipeline, three stages deep (round 4): a wavefront keeps 36 sums + the factors of one contribution in ~200 registers, so
-    // only two wavefronts share a SIMD and nothing hides the chain  list entry -> landmark -> records  (three dependent trips to L2 per
-    // 64 contributions).  Before the ~260 f64 operations of contribution c are issued, the records of c + stride, the landmark of
-    // c + 2 stride and the list entry of c + 3 stride are requested -- unconditionally (a load under a branch is waited for at the join):
-    // lanes past the end of the block re-read its last entry and add nothing.
+    // Software pipeline (round 4): a wavefront keeps 36 sums + the factors of one contribution in ~200 registers, so only two
+    // wavefronts share a SIMD and nothing hides the chain  list entry -> records  (the landmark rides in the entry).  Before the ~260
+    // f64 operations of contribution c are issued, the records of c + stride and the list entry of c + 2 stride are requested --
+    // unconditionally (a load under a branch is waited for at the join): lanes past the end of the block re-read its last entry and
+    // add nothing.
     struct Rec { double2 da, db, dc, ga0, ga1, gb0, gb1, e01, e2x; };
-    auto fetch = [&](const int2 sab, const int lm, Rec& r) {
-        const double2* D2 = reinterpret_cast<const double2*>(v.Dinv + (size_t)lm * 6);
+    auto fetch = [&](const ConPos e, Rec& r) {
+        const double2* D2 = reinterpret_cast<const double2*>(v.Dinv + (size_t)e.lm * 6);
         r.da = D2[0]; r.db = D2[1]; r.dc = D2[2];
-        r.ga0 = G2[(size_t)sab.x * 2]; r.ga1 = G2[(size_t)sab.x * 2 + 1];
-        r.gb0 = G2[(size_t)sab.y * 2]; r.gb1 = G2[(size_t)sab.y * 2 + 1];
+        r.ga0 = G2[(size_t)e.a * 2]; r.ga1 = G2[(size_t)e.a * 2 + 1];
+        r.gb0 = G2[(size_t)e.b * 2]; r.gb1 = G2[(size_t)e.b * 2 + 1];
         if (diag) {
-            const double2* db2 = reinterpret_cast<const double2*>(v.db + (size_t)lm * 4);
+            const double2* db2 = reinterpret_cast<const double2*>(v.db + (size_t)e.lm * 4);
             r.e01 = db2[0]; r.e2x = db2[1];
         }
     };
-    const int c_first = v.blk_ptr[b] + (SPLIT ? wave * WAVE : 0);                       // uniform
+    const int c_first = c_begin + (SPLIT ? wave * WAVE : 0);                             // uniform
     const int trips = c_first < c_end ? (c_end - c_first + stride - 1) / stride : 0;     // uniform
     const int c_last = c_end - 1;
     int c = c_first + lane;
     Rec cur, nxt;
-    int2 sab1 = make_int2(0, 0), sab2 = make_int2(0, 0);
-    int lm1 = 0;
+    ConPos e1 = { 0, 0, 0 };
     if (trips > 0) {
-        const int2 sab0 = v.con_pos[min(c, c_last)];
-        sab1 = v.con_pos[min(c + stride, c_last)];
-        sab2 = v.con_pos[min(c + 2 * stride, c_last)];
-        const int lm0 = v.pos_lm[sab0.x];
-        lm1 = v.pos_lm[sab1.x];
-        fetch(sab0, lm0, cur);
+        const ConPos e0 = v.con_pos[min(c, c_last)];
+        e1 = v.con_pos[min(c + stride, c_last)];
+        fetch(e0, cur);
     }
+    const CamConst ci = uniform_cam_const(ci_v), cj = uniform_cam_const(cj_v);          // in SGPRs: 40 VGPRs less
     for (int t = 0; t < trips; ++t, c += stride) {
-        fetch(sab1, lm1, nxt);
-        const int lm2 = v.pos_lm[sab2.x];
-        const int2 sab3 = v.con_pos[min(c + 3 * stride, c_last)];
+        fetch(e1, nxt);
+        const ConPos e2 = v.con_pos[min(c + 2 * stride, c_last)];
         if (c < c_end) {
             const double2 da = cur.da, db = cur.db, dc = cur.dc, ga0 = cur.ga0, ga1 = cur.ga1, gb0 = cur.gb0, gb1 = cur.gb1;
             const double d00 = da.x, d01 = da.y, d02 = db.x, d11 = db.y, d12 = dc.x, d22 = dc.y;
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block_
                 for (int cc = 0; cc < 6; ++cc) acc[r * 6 + cc] += cc == 4 ? n1 * Jb1[cc] : cc == 3 ? n0 * Jb0[cc] : n0 * Jb0[cc] + n1 * Jb1[cc];
             }
         }
-        cur = nxt; sab1 = sab2; lm1 = lm2; sab2 = sab3;
+        cur = nxt; e1 = e2;
     }
     double* R = red[wave];
 #pragma unroll
@@ -2323,12 +2323,47 @@ __global__ __launch_bounds__(256) void k_build_positions(BaDeviceView v, int* __
     w_pos[s] = p;
     pos_lm[p] = v.w_lm[s];
 }
-__global__ __launch_bounds__(256) void k_build_con_pos(BaDeviceView v, const int* __restrict__ w_pos, int2* __restrict__ con_pos)
+__global__ __launch_bounds__(256) void k_build_con_pos(BaDeviceView v, const int* __restrict__ w_pos, ConPos* __restrict__ con_pos)
 {
     const int end = v.blk_ptr[v.n_blk];
     for (int c = blockIdx.x * 256 + threadIdx.x; c < end; c += gridDim.x * 256) {
         const int2 ab = v.con[c];
-        con_pos[c] = make_int2(w_pos[ab.x], w_pos[ab.y]);
+        con_pos[c] = ConPos{ w_pos[ab.x], w_pos[ab.y], v.w_lm[ab.x] };
+    }
+}
+// slot_order: workgroup w of k_schur_block_compact lands on XCD w % 8 and takes entry w / 8 of that XCD's run of blocks (blk_order).  The
+// run is in row order, so a long block (a diagonal one: every landmark of the camera) starts every ~20 entries, the last of them when
+// the grid is almost drained.  Here every XCD's run is reordered longest first (stable counting sort by trips of 64 contributions):
+// the same blocks on the same XCD, each block's sum untouched.  One workgroup per XCD.
+__global__ __launch_bounds__(256) void k_order_slots_longest_first(BaDeviceView v, int* __restrict__ out)
+{
+    constexpr int NBIN = 64;
+    __shared__ int cnt[NBIN * 256];        // [bin][thread]
+    __shared__ int binbase[NBIN];
+    const int x = blockIdx.x, tid = threadIdx.x;
+    const int n = v.n_blk_slots > x ? (v.n_blk_slots - x + 7) / 8 : 0;
+    const int per = (n + 255) / 256, e0 = min(tid * per, n), e1 = min(e0 + per, n);
+    for (int k = 0; k < NBIN; ++k) cnt[k * 256 + tid] = 0;
+    auto bin_of = [&](int b) -> int {
+        if (b < 0) return NBIN - 1;                                       // empty slots last
+        const int trips = (v.blk_ptr[b + 1] - v.blk_ptr[b] + 63) >> 6;
+        return NBIN - 2 - min(trips, NBIN - 2);
+    };
+    for (int e = e0; e < e1; ++e) cnt[bin_of(v.blk_order[x + 8 * e]) * 256 + tid] += 1;
+    __syncthreads();
+    if (tid < NBIN) {                                                     // exclusive prefix inside the bin, in thread (= entry) order
+        int run = 0;
+        for (int t = 0; t < 256; ++t) { const int c = cnt[tid * 256 + t]; cnt[tid * 256 + t] = run; run += c; }
+        binbase[tid] = run;
+    }
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int k = 0; k < NBIN; ++k) { const int c = binbase[k]; binbase[k] = run; run += c; } }
+    __syncthreads();
+    for (int e = e0; e < e1; ++e) {
+        const int b = v.blk_order[x + 8 * e], k = bin_of(b);
+        const int rank = binbase[k] + cnt[k * 256 + tid];
+        cnt[k * 256 + tid] += 1;
+        out[x + 8 * rank] = b;
     }
 }
 bool ba_w_camera_major()
@@ -2336,9 +2371,10 @@ bool ba_w_camera_major()
     static const bool off = std::getenv("MAGE_BA_W_LANDMARK_MAJOR") != nullptr;
     return !off;
 }
-void ba_launch_build_positions(const BaDeviceView& v, int* w_pos, int* pos_lm, int2* con_pos, hipStream_t st)
+void ba_launch_build_positions(const BaDeviceView& v, int* w_pos, int* pos_lm, ConPos* con_pos, int* slot_order, hipStream_t st)
 {
     if (v.n_w <= 0) return;
+    if (v.n_blk_slots > 0 && slot_order) hipLaunchKernelGGL(k_order_slots_longest_first, dim3(8), dim3(256), 0, st, v, slot_order);
     hipLaunchKernelGGL(k_build_positions, dim3(cdiv(v.n_w, 256)), dim3(256), 0, st, v, w_pos, pos_lm, ba_w_camera_major() ? 1 : 0);
     if (v.n_blk > 0) hipLaunchKernelGGL(k_build_con_pos, dim3(2048), dim3(256), 0, st, v, w_pos, con_pos);
 }

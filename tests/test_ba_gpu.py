@@ -152,7 +152,7 @@ def test_compact_and_materialised_w_agree(tmp_path):
 def test_placement_and_reduction_switches_are_bit_identical(tmp_path):
     """Round 4: the compact W records are stored camera-major (MAGE_BA_W_LANDMARK_MAJOR=1: position == slot) and the chi2 / scale /
     outlier sums can be added by the last block of the kernel that produces them (MAGE_BA_FOLD_REDUCTIONS=1) instead of a
-    k_reduce_sum launch.  Placement and who adds: the same values meet in the same order, so every output is identical to the bit."""
+    k_reduce_sum launch; every XCD's Schur blocks are taken longest first (MAGE_BA_SCHUR_ROW_ORDER=1: in row order).  Placement and who adds: the same values meet in the same order, so every output is identical to the bit."""
     import json, os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent("""
@@ -170,12 +170,13 @@ def test_placement_and_reduction_switches_are_bit_identical(tmp_path):
         print("RESULT " + json.dumps(dict(outs=outs, tr=tr)))
     """) % root
     res = {}
-    for tag, env in (("default", {}), ("landmark_major", {"MAGE_BA_W_LANDMARK_MAJOR": "1"}), ("folded", {"MAGE_BA_FOLD_REDUCTIONS": "1"})):
+    for tag, env in (("default", {}), ("landmark_major", {"MAGE_BA_W_LANDMARK_MAJOR": "1"}), ("folded", {"MAGE_BA_FOLD_REDUCTIONS": "1"}),
+                     ("row_order", {"MAGE_BA_SCHUR_ROW_ORDER": "1"})):
         f = str(tmp_path / (tag + ".npy"))
         p = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
         res[tag] = (np.load(f), json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:]))
-    for tag in ("landmark_major", "folded"):
+    for tag in ("landmark_major", "folded", "row_order"):
         assert res[tag][1] == res["default"][1], tag
         assert np.array_equal(res[tag][0], res["default"][0]), tag
 
