@@ -252,6 +252,9 @@ struct mage_ba {
     // ---- where the truth about poses/points lives
     bool state_on_device = false;       // device buffers hold the current estimate
     mutable bool host_state_fresh = true;  // host copy equals the device estimate
+    // small problems: the post-pass also writes the kept estimate behind the scalars, so that it rides their read-back (k_small_classify)
+    size_t res_doubles = 0;                // poses x 8 + points x 4 of this build when that fits RES_CAP and the small path applies, else 0
+    mutable bool result_in_mirror = false; // the pinned mirror holds the estimate of the last step: download_state needs no device operation
 
     // ---- device storage
     DevBuf<double> d_pose[2], d_pt[2], d_camK;
@@ -354,6 +357,7 @@ void ensure_obs_filled(mage_ba* h)
 }
 
 constexpr size_t OUT_PREFIX = 4096;      // outlier ids copied back together with the post-pass scalars (16 KB); a longer list takes a second copy
+constexpr size_t RES_CAP = 4096;         // doubles of the pinned mirror reserved for the estimate of a small problem (32 KB: 12 keyframes + 1000 points)
 constexpr size_t SC_PAD = 16;            // doubles reserved for the scalars in d_scal / the pinned mirror; the outlier ids follow
 static_assert(SC_COUNT <= SC_PAD, "scalar block");
 
@@ -413,10 +417,10 @@ mage_status stage_commit(mage_ba* h)
 mage_status ensure_pinned_mirrors(mage_ba* h)
 {
     if (h->h_pinned) return MAGE_OK;
-    const size_t off = (SC_PAD * sizeof(double) + OUT_PREFIX * sizeof(uint32_t) + 255) & ~(size_t)255;      // scalars, then the id prefix: one copy
+    const size_t off = ((SC_PAD + RES_CAP) * sizeof(double) + OUT_PREFIX * sizeof(uint32_t) + 255) & ~(size_t)255;      // scalars, (the estimate of a small problem,) then the id prefix: one copy
     MAGE_TRY(cached_pinned_alloc(&h->h_pinned, off + sizeof(PoseLmResult), &h->h_pinned_bytes));
     h->h_scal = static_cast<double*>(h->h_pinned);
-    h->h_out_ids = reinterpret_cast<uint32_t*>(h->h_scal + SC_PAD);
+    h->h_out_ids = reinterpret_cast<uint32_t*>(h->h_scal + SC_PAD + h->res_doubles);
     h->h_pose_lm = reinterpret_cast<PoseLmResult*>(static_cast<char*>(h->h_pinned) + off);
     return MAGE_OK;
 }
@@ -434,6 +438,19 @@ mage_status download_state(const mage_ba* hc)
 {
     mage_ba* h = const_cast<mage_ba*>(hc);
     if (!h->state_on_device || h->host_state_fresh) return MAGE_OK;
+    if (h->result_in_mirror) {             // the estimate came back with the last step's scalars
+        const double* pose = h->h_scal + SC_PAD;
+        const double* pts = pose + h->cams.size() * 8;
+        for (size_t i = 0; i < h->cams.size(); ++i) {
+            for (int a = 0; a < 4; ++a) h->cams[i].q[a] = pose[i * 8 + a];
+            for (int a = 0; a < 3; ++a) h->cams[i].t[a] = pose[i * 8 + 4 + a];
+        }
+        if (!h->points_fixed)
+            for (size_t i = 0; i < h->pt_set.size(); ++i)
+                for (int a = 0; a < 3; ++a) h->pts[i * 3 + a] = pts[i * 4 + a];
+        h->host_state_fresh = true;
+        return MAGE_OK;
+    }
     MAGE_DEVICE_SCOPE(h->device);
     // fixed points never change on the device: only the poses come back then (the tracker's per-frame call).  Pinned staging and
     // a polled event: a copy into pageable memory goes through the runtime's own staging and a blocking synchronise (~50 us more
@@ -1079,7 +1096,13 @@ mage_status initialize_optimization(mage_ba* h)
     // two-level reductions: one double per block of the widest launch; the small-problem linearisation (8 lanes per landmark, 4 blocks
     // per camera) also parks the cameras' partial (U, b_c) sums behind its chi2 partials
     MAGE_TRY(stage_array(h, h->d_partial, std::max<size_t>(4 * 1024, std::max<size_t>((size_t)nb_l + nb_c, (size_t)nlm * 16 / 256 + (size_t)nfc * 4 * 29 + 8)) + 16));          // (the fused large-problem form needs nlm / 32 + nfc entries: covered)
-    MAGE_TRY(stage_array(h, h->d_scal, SC_PAD + ((size_t)nL + 2) / 2 + 1));          // scalars, then up to n_L outlier ids (32-bit)
+    {   // small problems that free their points: the kept estimate rides the post-pass read-back (k_small_classify)
+        static const bool off = std::getenv("MAGE_BA_NO_RESULT_RIDE") != nullptr;
+        const size_t want = (size_t)nc * 8 + (size_t)np * 4;
+        h->res_doubles = (!off && points_free && h->shard_ranks == 0 && want <= RES_CAP && ba_small_shape_applies(nfc, nT, nL)) ? want : 0;
+        h->result_in_mirror = false;
+    }
+    MAGE_TRY(stage_array(h, h->d_scal, SC_PAD + h->res_doubles + ((size_t)nL + 2) / 2 + 1));          // scalars, (the estimate,) then up to n_L outlier ids (32-bit)
     h->out_cursor = 0;                                                        // d_queue (with the cursor) starts as zeros
     MAGE_TRY(stage_array(h, h->d_Linv, chol_workspace_doubles(n_pad)));
     MAGE_TRY(stage_array(h, h->d_queue, chol_sync_ints(n_pad) + 64 + BA_FOLD_COUNTER_INTS, 0));      // + the small-path counter + the outlier cursor; recycled memory arrives dirty
@@ -1087,7 +1110,8 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(stage_array(h, h->d_L_active, (size_t)nL + 1, 1));
     MAGE_TRY(ensure_pinned_mirrors(h));
     MAGE_TRY(stage_commit(h));                                                // image mode: one buffer, one copy; every DevBuf above is a view from here on
-    h->d_out_ids = reinterpret_cast<uint32_t*>(h->d_scal.p + SC_PAD);
+    h->d_out_ids = reinterpret_cast<uint32_t*>(h->d_scal.p + SC_PAD + h->res_doubles);
+    h->h_out_ids = reinterpret_cast<uint32_t*>(h->h_scal + SC_PAD + h->res_doubles);
 
     tm.mark("reserve");
     BaDeviceView& v = h->view;
@@ -1146,7 +1170,7 @@ mage_status initialize_optimization(mage_ba* h)
 // (the step is a few milliseconds: spinning that long is the cheaper side of the trade).
 mage_status read_scalars(mage_ba* h, size_t outlier_prefix = 0)
 {
-    const size_t bytes = outlier_prefix ? SC_PAD * sizeof(double) + outlier_prefix * sizeof(uint32_t) : SC_COUNT * sizeof(double);
+    const size_t bytes = outlier_prefix ? (SC_PAD + h->res_doubles) * sizeof(double) + outlier_prefix * sizeof(uint32_t) : SC_COUNT * sizeof(double);
     MAGE_HIP(hipMemcpyAsync(h->h_scal, h->d_scal.p, bytes, hipMemcpyDeviceToHost, h->stream));
     MAGE_HIP(hipEventRecord(h->ev[3], h->stream));
     for (;;) {
@@ -1250,7 +1274,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
             if (plan) {      // the outlier pass rides behind the trial (see the large-problem branch)
                 ClassifyAfterTrial c{};
                 c.chi_ref = currentChi; c.chi_on_device = have_chi ? 0 : 1; c.trials_done = qmax + 1; c.last_iteration = plan->last_iteration ? 1 : 0;
-                ba_small_classify_after_trial(v, c, plan->max_err_sq, h->d_out_ids, counter + 1, h->out_cursor, counter, st);
+                ba_small_classify_after_trial(v, c, plan->max_err_sq, h->d_out_ids, counter + 1, h->out_cursor, counter, h->res_doubles ? h->d_scal.p + SC_PAD : nullptr, st);
                 speculated = true;
             }
         } else {
@@ -1961,6 +1985,7 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
         if (n_outliers) *n_outliers = 0;
         if (mean_sq_err) *mean_sq_err = NAN;
         MAGE_DEVICE_SCOPE(h->device);
+        h->result_in_mirror = false;
         // The structure build's pinned staging goes back to the cache when the first trial's scalars have arrived; a call that leaves
         // before any read-back (a problem with nothing to optimise, a failed build) must not keep >= 32 MB pinned per handle.
         struct ArenaGuard {
@@ -2092,7 +2117,7 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
             int* small_counter = h->d_queue.p + chol_sync_ints(v.n_pad);
             ids_from_device = true;
             if (!post_done) {
-                if (!sharded && ba_small_applies(v)) ba_small_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, small_counter, h->stream);
+                if (!sharded && ba_small_applies(v)) ba_small_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, small_counter, h->res_doubles ? h->d_scal.p + SC_PAD : nullptr, h->stream);
                 else ba_launch_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, small_counter + 64, h->stream);
                 prefix = prefix_now();
             }
@@ -2103,6 +2128,7 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
                     return fail(MAGE_ERR_DEVICE, "landmark-sharded map: the all-reduce callback failed");
             }
             if (!post_done) MAGE_TRY(read_scalars(h, prefix));
+            h->result_in_mirror = h->res_doubles > 0 && !sharded && ba_small_applies(v);      // (post_done: the kernel ran, i.e. found the call finished -- plan.done)
             err_sum = h->h_scal[SC_ERRSUM]; cnt = h->h_scal[SC_ERRCNT];
             nout = (size_t)h->h_scal[sharded ? SC_NOUT_OWN : SC_NOUT];
             if (sharded && h->h_scal[SC_NOUT] > 0) h->soft_dirty = true;
@@ -2265,7 +2291,7 @@ MAGE_EXPORT mage_status mage_ba_import_poses_device(mage_ba* h, const double* bl
         MAGE_TRY(join_before(h, stream));
         if (h->n_x_imp) {
             ba_launch_import_poses(h->d_pose[0].p, h->d_pose[1].p, h->d_x_imp_cam.p, h->d_x_imp_row.p, h->n_x_imp, block, h->stream);
-            h->host_state_fresh = false;
+            h->host_state_fresh = false; h->result_in_mirror = false;
             h->iteration = 0;          // a different linear system: the optimiser starts over, the graph is unchanged
         }
         return join_after(h, stream);

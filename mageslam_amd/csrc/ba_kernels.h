@@ -141,8 +141,8 @@ bool ba_fused_linearize_applies(const BaDeviceView& v);                         
 void ba_fused_linearize(const BaDeviceView& v, double huber_delta, int* counter, hipStream_t st);    // = ba_launch_error(current) + ba_launch_linearize in one launch
 void ba_small_linearize(const BaDeviceView& v, double huber_delta, bool want_maxdiag, int* counter, hipStream_t st);   // U,bc,V,bp,W, S/y zeroed, scal[SC_CHI] (+ SC_MAXDIAG)
 void ba_small_solve_trial(const BaDeviceView& v, double lambda, double huber_delta, double* linv_ws, int* counter, hipStream_t st);    // S, y, xc, trial state, SC_SCALE, SC_CHI_TRIAL, SC_CHOL_OK/STALL
-void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, hipStream_t st);
-void ba_small_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, hipStream_t st);
+void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, double* result, hipStream_t st);   // result: the kept estimate (poses x 8, points x 4) or nullptr
+void ba_small_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, double* result, hipStream_t st);
 
 // Pose-only problems (points fixed): the whole StepBundleAdjustment call in ONE launch (ba_kernels.hip, "POSE-ONLY problems").
 constexpr int POSE_LM_MAX_ITERS = 16;

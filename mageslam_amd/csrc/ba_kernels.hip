@@ -1832,9 +1832,13 @@ __global__ __launch_bounds__(256) void k_small_update_error(BaDeviceView v, doub
 }
 
 // k_classify with the three reductions folded in
+// result != nullptr: the KEPT estimate (n_cams x 8 pose doubles, then n_pts x 4) is also written there -- right behind the scalars, so
+// that it rides their read-back and the caller's GetPose / GetPoint loop needs no trip to the device of its own (round 4: the
+// reference reads every pose and point back after every bundler, BundleAdjust.cpp:318-347; that trip was 20 of a 2 000-observation
+// bundler's 167 us)
 template <bool AFTER_TRIAL>
 __global__ __launch_bounds__(256) void k_small_classify(BaDeviceView v, double max_err_sq, uint32_t* __restrict__ out_ids, int* __restrict__ out_count,
-                                                        int out_base, int* __restrict__ counter, ClassifyAfterTrial spec)
+                                                        int out_base, int* __restrict__ counter, ClassifyAfterTrial spec, double* __restrict__ result)
 {
     __shared__ double sm[4];
     const double* pose_kept = v.pose_cur;
@@ -1845,6 +1849,10 @@ __global__ __launch_bounds__(256) void k_small_classify(BaDeviceView v, double m
         if (blockIdx.x == 0 && threadIdx.x == 0) v.scal[SC_SPEC_DONE] = fin ? 1.0 : 0.0;
         if (!fin) return;                                   // every workgroup alike: the arrival counter stays untouched
         if (accept) { pose_kept = v.pose_trial; pt_kept = v.pt_trial; }
+    }
+    if (result) {
+        const int np8 = v.n_cams * 8, nt4 = v.n_pts * 4;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < np8 + nt4; i += gridDim.x * 256) result[i] = i < np8 ? pose_kept[i] : pt_kept[i - np8];
     }
     double es = 0, ec = 0, no = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n_L; i += gridDim.x * 256) {
@@ -2424,13 +2432,14 @@ void ba_small_solve_trial(const BaDeviceView& v, double lambda, double delta, do
     hipLaunchKernelGGL(k_small_update, dim3(nbL + cdiv(v.n_fc, 256)), dim3(256), 0, st, v, lambda, nbL, counter);
     hipLaunchKernelGGL(k_small_error, dim3(small_error_blocks(v)), dim3(256), 0, st, v, 1, delta, counter);
 }
-void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, hipStream_t st)
+void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, double* result, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_small_classify<false>, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, counter, ClassifyAfterTrial{});
+    hipLaunchKernelGGL(k_small_classify<false>, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, counter, ClassifyAfterTrial{}, result);
 }
-void ba_small_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, hipStream_t st)
+void ba_small_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, double* result,
+                                   hipStream_t st)
 {
-    hipLaunchKernelGGL(k_small_classify<true>, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, counter, c);
+    hipLaunchKernelGGL(k_small_classify<true>, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, counter, c, result);
 }
 void ba_small_init_device()
 {
