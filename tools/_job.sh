@@ -1,15 +1,29 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python tools/small_shapes.py 2>&1 | python -c "
-import sys, json
-d=json.load(sys.stdin)
-print('hip window', d['hip']['reference_window']['window_ms'], d['hip']['reference_window']['window_result'])
-print('cpu window', d['cpu_oracle']['reference_window']['window_ms'], d['cpu_oracle']['reference_window']['window_result'])
-print('hip pose', d['hip']['pose_only']['pose_only_pass1_ms']['total'], d['hip']['pose_only']['pose_only_pass2_ms']['total'])
-"
-MAGE_BA_NO_RESULT_RIDE=1 timeout 300 python tools/small_shapes.py 2>&1 | python -c "
-import sys, json
-d=json.load(sys.stdin)
-print('no-ride hip window', d['hip']['reference_window']['window_ms'], d['hip']['reference_window']['window_result'])
-"
-timeout 900 python -m pytest tests/test_ba_gpu.py tests/test_abi.py tests/test_concurrency_gpu.py -q -x -m gpu 2>&1 | tail -3
-( timeout 600 python tools/fuzz_ba.py --cases 4000 --seed 61 2>&1 | grep -v amdgpu | tail -4 )
+python - <<'PY'
+import os, sys, subprocess, tempfile
+sys.path.insert(0, '.')
+import bench
+from mageslam_amd import scene
+cfg = bench.SMALL_SHAPES["reference_window"]
+d = tempfile.mkdtemp()
+path = os.path.join(d, "w.scene")
+scene.save_scene(scene.make_scene(**cfg["scene"]), path)
+env = dict(os.environ, MAGE_BA_TIMING="1")
+p = subprocess.run(["tools/_bin/shim_small_shapes", "window", path, "30"], capture_output=True, text=True, env=env)
+lines = p.stderr.splitlines()
+print("\n".join(lines[-45:]))
+print(p.stdout[-600:])
+PY
+cd /tmp && export TMPDIR=/tmp
+python - <<'PY'
+import os, sys, subprocess, tempfile
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+os.chdir(os.environ["GRAFT_REPO_ROOT"])
+import bench
+from mageslam_amd import scene
+cfg = bench.SMALL_SHAPES["reference_window"]
+path = "/tmp/w.scene"
+scene.save_scene(scene.make_scene(**cfg["scene"]), path)
+PY
+rm -rf /tmp/p1; rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/p1 -o b -- $GRAFT_REPO_ROOT/tools/_bin/shim_small_shapes window /tmp/w.scene 200 > /dev/null 2>&1
+python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find /tmp/p1 -name '*.db' | head -1) | head -14
