@@ -331,6 +331,8 @@ struct TilePublish {
     double* Lpub;                 // PUBLISH == 2: this tile's scratch blocks (nullptr: not publishing)
                                   // PUBLISH == 3: the tile's full inverse is built in the PACKED_TILE_DOUBLES of LDS right behind Li's two blocks, blocks ROW-major
     double* inv_global = nullptr; // PUBLISH == 3: where the inverse goes, block (c, j), c >= j, at (c (c + 1) / 2 + j) * 256, blocks COLUMN-major
+    int* progress = nullptr;      // PUBLISH == 4: one word: base + c once the blocks of columns <= c (and the block inverses <= c + 1) are in memory
+    int base = 0;                 //               (8 x tile index: the words only ever grow inside a factorisation)
 };
 
 // PUBLISH: 0 plain stores of the block inverses (a kernel boundary or a release fence follows); 1 the block inverses written THROUGH
@@ -376,6 +378,13 @@ __device__ __forceinline__ bool potrf_tile_lds(double* __restrict__ A, double* _
     tile_barrier<PUBLISH != 0>();
     for (int s = 0; s < NBK; ++s) {
         const double* Lc = Li + (s & 1) * NB * NB;
+        if (PUBLISH == 4 && wave >= 1 && s >= 2) {
+            // PHASED strips (round 4): what this wavefront wrote through one iteration ago (its blocks of column s - 2, wavefront 3 also the
+            // inverse of block s - 1) has been acknowledged by now, so the wait costs nothing -- unlike a flag raised right behind the stores,
+            // which made the publisher late at the iteration's barrier.  Behind the iteration's first barrier (every wavefront has passed
+            // this wait) wavefront 3 raises ONE progress word; the strips of the launch poll that word, not the operands.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (wave == 3) {                           // block inverse s -> global workspace (read by k_trsm_panel / k_bsolve_persist)
             if (PUBLISH) {
 #pragma unroll
@@ -392,7 +401,7 @@ __device__ __forceinline__ bool potrf_tile_lds(double* __restrict__ A, double* _
                 for (int q = 0; q < 4; ++q) { const int e = lane * 4 + q; store_through(G + (e & 15) * NB + (e >> 4), v[q]); }
             }
         }
-        if (PUBLISH == 2 && wave >= 1 && s > 0) {       // block column s - 1 is final: its blocks below the diagonal go out, dealt over wavefronts 1-3
+        if ((PUBLISH == 2 || PUBLISH == 4) && wave >= 1 && s > 0) {       // block column s - 1 is final: its blocks below the diagonal go out, dealt over wavefronts 1-3
             for (int i = s + wave - 1; i < NBK; i += 3) {
                 const double* Bl = A + LAY::blk(i, s - 1);
                 double* G = pub.Lpub + (size_t)(i * (i - 1) / 2 + (s - 1)) * NB * NB;
@@ -400,7 +409,13 @@ __device__ __forceinline__ bool potrf_tile_lds(double* __restrict__ A, double* _
                 for (int r = 0; r < 4; ++r) store_through(G + (4 * r + (lane >> 4)) * NB + (lane & 15), Bl[frag<LAY>(r, lane)]);
             }
         }
-        if (s == NBK - 1) break;
+        if (s == NBK - 1) {
+            if (PUBLISH == 4) {            // columns <= s - 2 are in memory (the waits above); no barrier follows in this iteration: one of its own
+                tile_barrier<true>();
+                if (wave == 3 && lane == 0) __hip_atomic_store(pub.progress, pub.base + s - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            break;
+        }
         // rows below block s:  Y = Linv * A^T per 16-row strip; Y[m][n] = X[row r0 + n][col p0 + m].
         // Wavefront 0 is the critical path: it solves only the strip it needs (the rows of the next diagonal block) and
         // updates that block before the barrier, while the other three share the remaining strips.
@@ -444,6 +459,7 @@ __device__ __forceinline__ bool potrf_tile_lds(double* __restrict__ A, double* _
             }
         }
         tile_barrier<PUBLISH != 0>();
+        if (PUBLISH == 4 && s >= 2 && wave == 3 && lane == 0) __hip_atomic_store(pub.progress, pub.base + s - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // Trailing update, scheduled so that it never outlasts the factorisation it runs beside (a right-looking update
         // front-loads 27 of the 77 tile updates into step 0; wavefront 0 then waited ~10k cycles per tile at this barrier):
         //   wavefront 0     factors the next diagonal block (updated just above);
@@ -1344,12 +1360,146 @@ __device__ __forceinline__ void trsm_strip_4w(double* __restrict__ S, double* __
     }
 }
 
+// PHASED strip of the merged panel solve (round 4): the factoring workgroup publishes block column c of L_kk (and the block inverses)
+// as it goes (potrf_tile_lds<.., 4>: write-through stores, progress words raised one in-tile iteration later, when the stores have long
+// been acknowledged), and a strip works in three phases behind three polls of ONE word each instead of waiting for the whole tile:
+//   columns 0-3 published  ->  steps 0-3 and the products of the later block columns with Y_0 .. Y_3   (26 of the 36 products)
+//   columns 4-5 published  ->  steps 4, 5 and their products
+//   tile factored (flag[1]) ->  steps 6, 7: two inverse products and one update behind the last fetch
+// What is left on the chain behind the factorisation is one fetch, twelve matrix-core operations and a store.  Per block column the
+// products meet the accumulator in the same order as in trsm_strip_wt: bit-identical.  (The first pipelined form polled the OPERANDS
+// for a sentinel, two hundred strips re-reading L_kk past the L2: the polling took fabric bandwidth from the factoring workgroup.)
+__device__ __forceinline__ bool poll_progress(const int* __restrict__ word, int target, int lane)
+{
+    bool ok = true;
+    if (lane == 0) {
+        int spins = 0;
+        // (a pause between polls: up to two hundred strips watch this word while the factoring workgroup works through memory)
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(8);
+        ok = spins < (1 << 20);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    return ok;
+}
+__device__ __forceinline__ void trsm_strip_phased(double* __restrict__ S, double* __restrict__ y, int ld, int k, int strip, bool is_rhs,
+                                                  const double* __restrict__ Linv_k, const double* __restrict__ Lpub, int* __restrict__ flag, int col_target,
+                                                  double* __restrict__ stall, int lane)
+{
+    double* base;
+    size_t cstride;
+    bool live;
+    if (!is_rhs) {
+        base = S + (size_t)(k * TILE) * ld + (size_t)(k + 1) * TILE + strip * NB + (lane & 15);
+        cstride = (size_t)ld;
+        live = true;
+        if (!poll_at_least(flag + 2, col_target, lane) && lane == 0) *stall = 2.0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        base = y + (size_t)k * TILE;       // this workgroup's own row, just updated
+        cstride = 1;
+        live = (lane & 15) == 0;
+    }
+    double4_t Acc[NBLK], Y[NBLK];
+#pragma unroll
+    for (int c = 0; c < NBLK; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Acc[c][r] = live ? base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] : 0.0;
+    // operand element (row = lane & 15, column = 4 r + (lane >> 4)) of a published block; of the row-major block inverse
+    const double* Lop = Lpub + (lane >> 4) * NB + (lane & 15);
+    const double* Lio = Linv_k + (lane & 15) * NB + (lane >> 4);
+    auto ld_inv = [&](int c, double (&o)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = __hip_atomic_load(Lio + c * NB * NB + 4 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto ld_blk = [&](int c, int j, double (&o)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = -__hip_atomic_load(Lop + (size_t)(c * (c - 1) / 2 + j) * NB * NB + (size_t)r * 4 * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto step = [&](int c, const double (&inv)[4]) {          // Y_c = Linv_c Acc_c, stored
+        double4_t yc = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yc = __builtin_amdgcn_mfma_f64_16x16x4f64(inv[r], Acc[c][r], yc, 0, 0, 0);
+        Y[c] = yc;
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) base[(size_t)(c * NB + (lane >> 4) + 4 * r) * cstride] = yc[r];
+        }
+    };
+    auto update = [&](int c, int j, const double (&l)[4]) {   // Acc_c -= L(c, j) Y_j
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(l[r], Y[j][r], Acc[c], 0, 0, 0);
+    };
+    const int pbase = 8 * k;
+    // A strip that starts when the tile is already factored (the update-bound end of the merged columns: strip workgroups are the last of
+    // the grid) has nothing to overlap: every operand in ONE round of loads, as trsm_strip_wt does, instead of three.
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= k) {
+        double inv[NBLK][4], l[NBLK][NBLK][4];
+#pragma unroll
+        for (int c = 0; c < NBLK; ++c) {
+            ld_inv(c, inv[c]);
+#pragma unroll
+            for (int j = 0; j < c; ++j) ld_blk(c, j, l[c][j]);
+        }
+#pragma unroll
+        for (int c = 0; c < NBLK; ++c) {
+#pragma unroll
+            for (int j = 0; j < c; ++j) update(c, j, l[c][j]);
+            step(c, inv[c]);
+        }
+        return;
+    }
+    // ---- phase 1: block columns 0 .. 3
+    if (!poll_progress(flag + 4, pbase + 3, lane) && lane == 0) *stall = 2.0;
+    {
+        double inv[4][4], l[NBLK][4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ld_inv(c, inv[c]);
+#pragma unroll
+        for (int c = 1; c < NBLK; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (j < c) ld_blk(c, j, l[c][j]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int j = 0; j < c; ++j) update(c, j, l[c][j]);
+            step(c, inv[c]);
+        }
+#pragma unroll
+        for (int c = 4; c < NBLK; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) update(c, j, l[c][j]);
+    }
+    // ---- phase 2: block columns 4, 5
+    if (!poll_progress(flag + 4, pbase + 5, lane) && lane == 0) *stall = 2.0;
+    {
+        double inv4[4], inv5[4], l54[4], l64[4], l74[4], l65[4], l75[4];
+        ld_inv(4, inv4); ld_inv(5, inv5);
+        ld_blk(5, 4, l54); ld_blk(6, 4, l64); ld_blk(7, 4, l74); ld_blk(6, 5, l65); ld_blk(7, 5, l75);
+        step(4, inv4);
+        update(5, 4, l54);
+        step(5, inv5);
+        update(6, 4, l64); update(6, 5, l65);
+        update(7, 4, l74); update(7, 5, l75);
+    }
+    // ---- phase 3: the tile is factored
+    if (!poll_at_least(flag + 1, k, lane) && lane == 0) *stall = 2.0;
+    {
+        double inv6[4], inv7[4], l76[4];
+        ld_inv(6, inv6); ld_inv(7, inv7); ld_blk(7, 6, l76);
+        step(6, inv6);
+        update(7, 6, l76);
+        step(7, inv7);
+    }
+}
+
 // the panel solve of tile column k as a launch of its own (the update-bound columns; column 0)
 // (two kernels, not one with a run-time choice: the one-wavefront strip keeps all 36 operand blocks in ~380 registers, and at that
 // size only ONE four-wavefront workgroup fits a compute unit -- the 369 strips of column 0 would take two rounds)
 __device__ __forceinline__ void panel_launch_duties(double* __restrict__ Linv_k, int k, int nt, int* __restrict__ queue, int queue_start, int tid, int nthreads)
 {
-    if (blockIdx.x == 0 && tid == 0) { queue[0] = 0; if (k == 0) { queue[1] = 0; queue[2] = 0; queue[3] = 0; } }     // hand-off counters of the launches that follow (queue_start < 0: also fill the pipelined strips' sentinels)
+    if (blockIdx.x == 0 && tid == 0) { queue[0] = 0; if (k == 0) { queue[1] = 0; queue[2] = 0; queue[3] = 0; queue[4] = 0; queue[5] = 0; queue[6] = 0; } }     // hand-off counters of the launches that follow (queue_start < 0: also fill the pipelined strips' sentinels)
     if (k == 0 && queue_start < 0) {
         // what the pipelined panel solves of the later columns poll: the block inverses of tiles 1 .. nt - 1 and every tile's scratch
         // blocks start as the sentinel (this launch is the second of a factorisation; those areas are first written 19+ launches later)
@@ -1480,6 +1630,12 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
         }
         if (wave != 0) return;
         dbg_min(dbg, 6);
+        if constexpr (MERGE == 3) {           // phased against the factorisation of L_j0j0 (potrf_tile_lds<.., 4>)
+            trsm_strip_phased(S, y, ld, j0, bid - (first_rhs + mt), false, Linv_next, Lpub_next, flag, col_target, stall, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg_max(dbg, 8);
+            return;
+        }
         if constexpr (MERGE == 0) return;
         else if constexpr (MERGE == 2) {      // pipelined against the factorisation of L_j0j0 (TilePublish): only the first-column tiles must be complete
             wait_for_column(flag, 0, col_target, stall, lane);
@@ -1523,7 +1679,8 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
                     if (strip4w) { trsm_strip_4w<true, true>(S, y, ld, j0, 0, true, Linv_next, flag, 0, stall, lane, wave, sm); return; }
                 }
                 if (wave != 0) return;
-                if constexpr (MERGE == 2) trsm_strip_pipelined(S, y, ld, j0, 0, true, Linv_next, Lpub_next, stall, lane);
+                if constexpr (MERGE == 3) trsm_strip_phased(S, y, ld, j0, 0, true, Linv_next, Lpub_next, flag, 0, stall, lane);
+                else if constexpr (MERGE == 2) trsm_strip_pipelined(S, y, ld, j0, 0, true, Linv_next, Lpub_next, stall, lane);
                 else if constexpr (WT) trsm_strip_wt(S, y, ld, j0, 0, true, Linv_next, flag, 0, stall, lane);
                 else {
                     wait_for_column(flag, j0, 0, stall, lane);
@@ -1582,12 +1739,24 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
         __syncthreads();
         dbg_set(dbg, 3);
         bool failed;
-        if constexpr (MERGE == 2) failed = potrf_tile_lds<false, LayPacked, 2>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid, NBLK, TilePublish{ Lpub_next });
+        if constexpr (MERGE == 3) failed = potrf_tile_lds<false, LayPacked, 4>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid, NBLK, TilePublish{ Lpub_next, nullptr, flag + 4, 8 * j0 });
+        else if constexpr (MERGE == 2) failed = potrf_tile_lds<false, LayPacked, 2>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid, NBLK, TilePublish{ Lpub_next });
         else if constexpr (GEMM) failed = potrf_tile_lds<false, LayPacked, 3>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid, NBLK,
                                                                               TilePublish{ nullptr, Lpub_next });
         else if constexpr (WT) failed = potrf_tile_lds<false, LayPacked, 1>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
         else failed = potrf_tile_lds<false, LayPacked>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
         dbg_set(dbg, 4);
+        if constexpr (MERGE == 3) {
+            // the strips read the published blocks and the block inverses, all written through: raise the flag FIRST, the factor itself goes to
+            // S afterwards (the backward solve reads it there, launches later)
+            if (tid == 0 && failed) *ok = 0.0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flag + 1, j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dbg_set(dbg, 5);
+            store_tile_packed(T, A, ld, tid);
+            return;
+        }
         if constexpr (GEMM) {
             // the strips read only the inverse (written through by the factorisation): publish FIRST, store the factor itself afterwards
             if (tid == 0 && failed) *ok = 0.0;
@@ -2099,6 +2268,13 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
             const bool pipelined = pipelined_rows == 1 || (pipelined_rows > 1 && m <= pipelined_rows);
             // the write-through form of the chain's two hand-offs (k_syrk_update<1, true>); MAGE_CHOL_WT_HANDOFF=0 restores release / acquire
             static const bool wt_handoff = !(std::getenv("MAGE_CHOL_WT_HANDOFF") && std::atoi(std::getenv("MAGE_CHOL_WT_HANDOFF")) == 0);
+            // Phased strips (trsm_strip_phased, round 4): ON by default -- three polls of ONE progress word behind the in-tile factorisation instead of
+            // a wait for the whole tile.  Measured (tools/_bin/chol_test 6016 10, time stamps of launches 24 / 36 / 44): the last strip ends 3.8 us
+            // after the tile is factored instead of 8.5 (the in-tile factorisation itself 20.8 against 20.2 us), 2.527-2.530 ms per factorisation
+            // against 2.570-2.577; bit-identical.  MAGE_CHOL_PHASED_TRSM=0 switches it off, =<rows> restricts it to the columns with at most
+            // <rows> tile rows left (no better: 16 / 20 / 24 rows 2.535 / 2.531 / 2.527).
+            static const int phased_rows = std::getenv("MAGE_CHOL_PHASED_TRSM") ? std::atoi(std::getenv("MAGE_CHOL_PHASED_TRSM")) : 1;
+            const bool phased = wt_handoff && !pipelined && (phased_rows == 1 || (phased_rows > 1 && m <= phased_rows));
             // The strips as products over the tile's full inverse (k_syrk_update<1, true, true>): OFF by default, MAGE_CHOL_GEMM_STRIPS=1 selects
             // it.  Measured (time stamps of launch 30, tools/_bin/chol_test 6016, profiles/r04_chol_links.txt): the strips do what they were
             // built for -- last strip done 3.4 us after the flag instead of 7.1 -- but building the inverse beside the in-tile factorisation
@@ -2111,6 +2287,7 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
             double* const Linv_next = ws.Linv + (size_t)(k + 1) * linv_stride;
             double* const Lpub_next = ws.Linv + (size_t)nt * linv_stride + (size_t)(k + 1) * LPUB_TILE_DOUBLES;
             if (!merged) hipLaunchKernelGGL(k_syrk_update<0>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next, strip4w ? 1 : 0);
+            else if (phased && !gemm_strips) hipLaunchKernelGGL((k_syrk_update<3, true>), grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next, 0);
             else if (pipelined) hipLaunchKernelGGL(k_syrk_update<2>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next, strip4w ? 1 : 0);
             else if (wt_handoff && gemm_strips)
                 hipLaunchKernelGGL((k_syrk_update<1, true, true>), grid, dim3(256), lds_diag + PACKED_TILE_DOUBLES * sizeof(double), st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync,

@@ -1,29 +1,12 @@
 cd $GRAFT_REPO_ROOT
-python - <<'PY'
-import os, sys, subprocess, tempfile
-sys.path.insert(0, '.')
-import bench
-from mageslam_amd import scene
-cfg = bench.SMALL_SHAPES["reference_window"]
-d = tempfile.mkdtemp()
-path = os.path.join(d, "w.scene")
-scene.save_scene(scene.make_scene(**cfg["scene"]), path)
-env = dict(os.environ, MAGE_BA_TIMING="1")
-p = subprocess.run(["tools/_bin/shim_small_shapes", "window", path, "30"], capture_output=True, text=True, env=env)
-lines = p.stderr.splitlines()
-print("\n".join(lines[-45:]))
-print(p.stdout[-600:])
+T=tools/_bin/chol_test
+echo "== default (phased)"; timeout 120 $T 6016 10 | grep "n= 6016"
+echo "== phased off"; MAGE_CHOL_PHASED_TRSM=0 timeout 120 $T 6016 10 | grep "n= 6016"
+echo "== all sizes"; timeout 300 $T | tail -20
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -4
+python bench.py --no-cpu-baseline --no-extras > gpurun_out/x.json 2> gpurun_out/x.err
+python - <<PY
+import json
+b=json.load(open('gpurun_out/x.json'))
+print(b['value'], b['ms_per_step'], b['final_reproj_rmse_px'], b['roofline']['frac'], b['roofline']['ms_per_launch'], b['stall_counters'])
 PY
-cd /tmp && export TMPDIR=/tmp
-python - <<'PY'
-import os, sys, subprocess, tempfile
-sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
-os.chdir(os.environ["GRAFT_REPO_ROOT"])
-import bench
-from mageslam_amd import scene
-cfg = bench.SMALL_SHAPES["reference_window"]
-path = "/tmp/w.scene"
-scene.save_scene(scene.make_scene(**cfg["scene"]), path)
-PY
-rm -rf /tmp/p1; rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/p1 -o b -- $GRAFT_REPO_ROOT/tools/_bin/shim_small_shapes window /tmp/w.scene 200 > /dev/null 2>&1
-python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find /tmp/p1 -name '*.db' | head -1) | head -14
