@@ -74,3 +74,34 @@ def test_solution_matches_rocsolver_via_torch(tmp_path):
     assert p.returncode == 0, p.stderr[-2000:]
     ref = np.load(tmp_path / "x.npy")
     assert np.linalg.norm(x - ref) <= 1e-11 * np.linalg.norm(ref)
+
+
+def test_chain_variants_are_bit_identical(tmp_path):
+    """The panel solve of the chain-bound columns in its forms -- phased against the in-tile factorisation (default, round 4), one wait
+    for the whole tile (MAGE_CHOL_PHASED_TRSM=0), release / acquire hand-offs (MAGE_CHOL_WT_HANDOFF=0), strips by four wavefronts
+    (MAGE_CHOL_STRIP_4W=1), a launch of its own per panel (MAGE_CHOL_NO_MERGED_TRSM=1): the same operations in the same order per block
+    column, so the solution is the same to the bit.  (The switches are read once per process: children.)"""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import numpy as np
+        import test_chol_gpu as T
+        out = []
+        for n in (700, 2999, 4500):      # 6, 24, 36 tile columns: merged columns only / the half-tile kernel's crossover / well into it
+            A, b = T.spd(n, 900 + n)
+            x, ok = T.dense_solve(A, b)
+            assert ok == 1
+            out.append(x)
+        np.save(sys.argv[1], np.concatenate(out))
+    """) % (root, os.path.join(root, "tests"))
+    res = {}
+    for tag, env in (("phased", {}), ("single_wait", {"MAGE_CHOL_PHASED_TRSM": "0"}), ("release_acquire", {"MAGE_CHOL_WT_HANDOFF": "0"}),
+                     ("four_wavefronts", {"MAGE_CHOL_PHASED_TRSM": "0", "MAGE_CHOL_STRIP_4W": "1"}), ("separate_panels", {"MAGE_CHOL_NO_MERGED_TRSM": "1"})):
+        f = str(tmp_path / (tag + ".npy"))
+        p = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+        res[tag] = np.load(f)
+    for tag, x in res.items():
+        assert np.array_equal(x, res["phased"]), tag
