@@ -1810,12 +1810,21 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
     double4_t out[4][4];
     update_block<4, 8>(S, ld, k, row0, col0, lane, out);
     double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
+    if (strip4w & 2) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) store_through(C + (size_t)(a * 16 + 4 * r) * ld + b * 16, out[a][b][r]);
+    } else {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) C[(size_t)(a * 16 + 4 * r) * ld + b * 16] = out[a][b][r];
+    }
     if (merge && ct == 0) publish_column_part(flag, tid);
     if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_max(dbg, ct == 0 ? 10 : 9); }
 }
@@ -1938,6 +1947,15 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
         double4_t out[2][4];
         update_rect<2, 4, CHOL_RECT_KSTEPS, false, CHOL_RECT_NBUF>(S, ld, k, row0, col0, lane, out);
         double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
+        if (unstaged & 8) {          // the updated block goes THROUGH to memory: nothing of it is left for the kernel boundary to write back
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) store_through(C + (size_t)(a * 16 + 4 * r) * ld + b * 16, out[a][b][r]);
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -2245,6 +2263,10 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
         // reads -27 % (profiles/r03_chol_pmc.txt) -- but the matrix cores are busy 49.7 % of the launch either way and the factorisation
         // takes 2.731 ms against 2.710: the update is not waiting for its operands' misses.  MAGE_CHOL_XCD_BANDS=1 selects it.
         static const bool xcd_bands = std::getenv("MAGE_CHOL_XCD_BANDS") != nullptr;
+        // Updated tiles (half and whole tiles) are stored THROUGH: they are read again only after the kernel boundary, and what was written
+        // through is not left for the boundary to write back (2.536-2.548 -> 2.517-2.528 ms per factorisation, three A/B pairs; bit-identical).
+        // MAGE_CHOL_WT_TILES=0: plain stores.
+        static const bool wt_tiles = !(std::getenv("MAGE_CHOL_WT_TILES") && std::atoi(std::getenv("MAGE_CHOL_WT_TILES")) == 0);
         if (bulk2) {
             // tiles of the last, partial round of half-tile tasks go in quarters when that round fills at most half of the task slots
             // (two workgroups on each compute unit); MAGE_CHOL_NO_QUARTERS=1 switches it off
@@ -2253,7 +2275,7 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
             const int rem_tiles = (n_tiles - 1) % tiles_per_round;
             const int q_tiles = (!quarters_off && unstaged && !xcd_bands && rem_tiles > 0 && rem_tiles * 2 <= tiles_per_round) ? rem_tiles : 0;
             hipLaunchKernelGGL(k_syrk_update2, dim3(NDIAG + 16 * ((n_tiles - 1 - q_tiles + 7) / 8) + 4 * q_tiles + m), dim3(256), lds_diag, st, S, y, n_pad, k, nt,
-                               ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, (unstaged ? 1 : 0) | (xcd_bands ? 2 : 0) | (form_glds ? 4 : 0), q_tiles);
+                               ws.Linv + (size_t)(k + 1) * linv_stride, ok, stall, ws.sync, (unstaged ? 1 : 0) | (xcd_bands ? 2 : 0) | (form_glds ? 4 : 0) | (wt_tiles ? 8 : 0), q_tiles);
         }
         else {
             merged = !merge_off;
@@ -2288,7 +2310,7 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
             double* const Linv_next = ws.Linv + (size_t)(k + 1) * linv_stride;
             double* const Lpub_next = ws.Linv + (size_t)nt * linv_stride + (size_t)(k + 1) * LPUB_TILE_DOUBLES;
             if (!merged) hipLaunchKernelGGL(k_syrk_update<0>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next, strip4w ? 1 : 0);
-            else if (phased && !gemm_strips) hipLaunchKernelGGL((k_syrk_update<3, true>), grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next, 0);
+            else if (phased && !gemm_strips) hipLaunchKernelGGL((k_syrk_update<3, true>), grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next, wt_tiles ? 2 : 0);
             else if (pipelined) hipLaunchKernelGGL(k_syrk_update<2>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync, n_q4, col_total, dbg, Lpub_next, strip4w ? 1 : 0);
             else if (wt_handoff && gemm_strips)
                 hipLaunchKernelGGL((k_syrk_update<1, true, true>), grid, dim3(256), lds_diag + PACKED_TILE_DOUBLES * sizeof(double), st, S, y, n_pad, k, nt, Linv_next, ok, stall, ws.sync,
