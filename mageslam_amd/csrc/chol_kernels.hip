@@ -1832,7 +1832,11 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
 // (Round 4 tried the panel solve of column k + 1 INSIDE this launch too -- first-column tiles first, strip workgroups in the middle of
 // the grid, where they wait for nobody: bit-identical and 50-70 us SLOWER per factorisation.  What the separate ~11 us panel-solve
 // launch costs is mostly the write-back of the update's dirty tiles at the kernel boundary, which the next launch then pays instead;
-// profiles/r04_chol_merged_halftile_rejected.txt has the numbers and the per-launch timeline.  The code is not kept.)
+// profiles/r04_chol_merged_halftile_rejected.txt has the numbers and the per-launch timeline.  The code is not kept.
+// A second attempt late in the round put the strips at the END of the grid, by the four wavefronts of a workgroup (trsm_strip_4w: 134
+// registers, inside this kernel's two-workgroups-per-unit budget), behind counters fed by write-through first-column tiles (no release):
+// bit-identical again, and every merged launch 15-19 us longer than the plain one where the separate panel-solve launch costs 9-11 --
+// a round's uniform tasks end together, so the strips start when the launch would have been over: 2.610 ms against 2.523.  Not kept.)
 __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
                                                      double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int unstaged,
                                                      int q_tiles)
