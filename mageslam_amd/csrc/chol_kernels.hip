@@ -2250,13 +2250,19 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
     for (int k = 0; k + 1 < nt; ++k) {
         const int m = nt - k - 1;             // tile rows below panel k = tile rows of the trailing matrix
         const int n_tiles = m * (m + 1) / 2;
-        const int n_q4 = syrk_quartered_tiles(n_tiles, g_n_cu);
+        // Quarter tiles in the one-workgroup-per-unit kernel: a last round that fills at most half of the compute units (syrk_quartered_tiles),
+        // and -- late in round 4 -- EVERY tile of the chain-bound columns: a whole tile is one wavefront per SIMD streaming 128 KB of
+        // operands with a single chunk of prefetch, and with 130-250 of them in flight it takes 24-44 us; in quarters the same update ends
+        // before the chain does (2.520-2.527 -> 2.496-2.501 ms per factorisation, bit-identical).  MAGE_CHOL_TAIL_WHOLE_TILES=1: the old rule.
+        static const bool tail_whole = std::getenv("MAGE_CHOL_TAIL_WHOLE_TILES") != nullptr;
+        int n_q4 = syrk_quartered_tiles(n_tiles, g_n_cu);
         // Two forms of the trailing update.  While it is what takes the time (more than ~1.5 rounds of whole tiles) the half-tile
         // form runs two workgroups per compute unit (239 registers, the packed 78 KB of LDS): 94 / 86 / 84 us on the first columns
         // against 104 / 91 / 89.  Once the chain (diagonal update, hand-off, in-tile factorisation: ~29 us) is what takes the time,
         // the workgroup that factors must not share its compute unit: the whole-tile form (382 registers: one workgroup per unit).
         static const int bulk2_min_tiles = std::getenv("MAGE_CHOL_BULK2_MIN_TILES") ? std::atoi(std::getenv("MAGE_CHOL_BULK2_MIN_TILES")) : 400;
         const bool bulk2 = n_tiles >= bulk2_min_tiles;
+        if (!bulk2 && !tail_whole) n_q4 = n_tiles - 1;
         // the half-tile task in three forms: operands per wavefront straight from L2 (default), staged through LDS by plain loads + ds_write
         // (MAGE_CHOL_BULK2_STAGED=1: measured slower in round 2, 3.01 ms against 2.87), staged by the load-to-LDS path behind raw barriers
         // (MAGE_CHOL_BULK2_FORM=glds, round 4)
