@@ -243,6 +243,116 @@ __device__ __forceinline__ bool factor_block16(double* __restrict__ B, int lane,
     return __builtin_amdgcn_ballot_w64(!(dmin > 0.0)) != 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same 16 x 16 pivot block in its LEAN form (round 4, late).  tools/f64_latency.hip: on a lone wavefront a dependent v_fma_f64
+// returns after 8 cycles, v_rsq_f64 after 20, a DPP operand after 16 -- and ANY f64 operation, DPP or not, takes 4.8 cycles of issue.
+// The pivot recurrence of the form above is ~76 cycles of latency per pivot against ~40 instructions x 4.8 = 190 cycles of issue: the
+// block is bound by instruction COUNT, not by the chain the form above was shortened for (two-pivots-ahead e0 / q4, doubled columns,
+// broadcasts: ~620 instructions per block).  Here a pivot is the plain recurrence -- broadcast the diagonal entry, rsqrt + two
+// Goldschmidt steps, scale the column, update the columns behind it -- 13 + 2 (15 - J) instructions, ~450 per block; the previous
+// pivot's updates are dealt into the latency slots of this pivot's chain (one after every dependent operation, four behind the rsqrt).
+// Same layout, same outputs as factor_block16.
+// ---------------------------------------------------------------------------------------------
+template <int P, int C>
+__device__ __forceinline__ void fl_upd_a(double (&a)[NB])
+{
+    if constexpr (P >= 0 && C < NB) dpp_fnma<C>(a[C], a[P], a[P]);
+}
+template <int P, int C>
+__device__ __forceinline__ void fl_upd_x(double (&a)[NB], double (&x)[NB])
+{
+    if constexpr (P >= 0 && C < NB) dpp_fnma<C>(x[C], a[P], x[P]);
+}
+// filler number F (0, 1, 2 ...) of pivot J's latency slots: the updates of pivot P = J - 1 from column J + 1 on, `x` of J + 1 first
+// (its `a` update was issued at the end of pivot P: the diagonal entry of pivot J depends on it)
+template <int J, int F>
+__device__ __forceinline__ void fl_fill(double (&a)[NB], double (&x)[NB])
+{
+    constexpr int P = J - 1;
+    if constexpr (F == 0) fl_upd_x<P, J + 0 + 0>(a, x);          // column J itself: x[J] (a[J] went first)
+    else {
+        constexpr int C = J + (F + 1) / 2;
+        if constexpr ((F & 1) == 1) fl_upd_a<P, C>(a); else fl_upd_x<P, C>(a, x);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int J, int F0, int F1>
+__device__ __forceinline__ void fl_fill_range(double (&a)[NB], double (&x)[NB])
+{
+    if constexpr (F0 < F1) { fl_fill<J, F0>(a, x); fl_fill_range<J, F0 + 1, F1>(a, x); }
+}
+template <int J>
+__device__ __forceinline__ void fl_column(double (&a)[NB], double (&x)[NB], double& dmin)
+{
+    constexpr int NFILL = J >= 1 ? 2 * (NB - J) - 1 : 0;         // fillers of pivot J - 1: x[J], then (a, x) of columns J + 1 .. 15
+    // the diagonal entry (lane J's a[J], final: pivot J - 1 updated it last thing) to every lane
+    const double d = dpp_bcast_nop<J>(a[J]);
+    __builtin_amdgcn_sched_barrier(0);
+    fl_fill_range<J, 0, (NFILL < 2 ? NFILL : 2)>(a, x);
+    double y = __builtin_amdgcn_rsq(d);
+    __builtin_amdgcn_sched_barrier(0);
+    fl_fill_range<J, 2, (NFILL < 6 ? NFILL : 6)>(a, x);
+    dmin = fmin(dmin, d);
+    __builtin_amdgcn_sched_barrier(0);
+    double g = d * y, h = 0.5 * y;
+    __builtin_amdgcn_sched_barrier(0);
+    fl_fill_range<J, 6, (NFILL < 7 ? NFILL : 7)>(a, x);
+    double r = __builtin_fma(-h, g, 0.5);
+    __builtin_amdgcn_sched_barrier(0);
+    fl_fill_range<J, 7, (NFILL < 8 ? NFILL : 8)>(a, x);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    __builtin_amdgcn_sched_barrier(0);
+    fl_fill_range<J, 8, (NFILL < 9 ? NFILL : 9)>(a, x);
+    r = __builtin_fma(-h, g, 0.5);
+    __builtin_amdgcn_sched_barrier(0);
+    fl_fill_range<J, 9, (NFILL < 10 ? NFILL : 10)>(a, x);
+    h = __builtin_fma(h, r, h);
+    __builtin_amdgcn_sched_barrier(0);
+    fl_fill_range<J, 10, (NFILL < 11 ? NFILL : 11)>(a, x);
+    const double rs = h + h;                                     // 1 / sqrt(d)
+    __builtin_amdgcn_sched_barrier(0);
+    fl_fill_range<J, 11, (NFILL < 12 ? NFILL : 12)>(a, x);
+    a[J] = a[J] * rs;                                            // L[:, J]  (lane J: d / sqrt(d))
+    x[J] = x[J] * rs;                                            // Linv[J][:]
+    __builtin_amdgcn_sched_barrier(0);
+    // the next pivot's diagonal entry first, then what is left of pivot J - 1's updates
+    if constexpr (J + 1 < NB) dpp_fnma_nop<J + 1>(a[J + 1], a[J], a[J]);
+    __builtin_amdgcn_sched_barrier(0);
+    fl_fill_range<J, 12, (NFILL > 12 ? NFILL : 12)>(a, x);
+}
+template <int J>
+__device__ __forceinline__ void fl_columns(double (&a)[NB], double (&x)[NB], double& dmin)
+{
+    if constexpr (J < NB) { fl_column<J>(a, x, dmin); fl_columns<J + 1>(a, x, dmin); }
+}
+template <int PITCH>
+__device__ __forceinline__ bool factor_block16_lean(double* __restrict__ B, int lane, double* __restrict__ Li, double* __restrict__ Linv_out)
+{
+    const int l = lane & 15;
+    double a[NB], x[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) { a[c] = B[c * PITCH + l]; x[c] = (l == c) ? 1.0 : 0.0; }
+    double dmin = 1.0;
+    fl_columns<0>(a, x, dmin);
+    // (pivot 15's updates: none; pivot 14's leftovers were dealt inside pivot 15)
+    if (lane < NB) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) B[c * PITCH + l] = a[c];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Li[i * NB + l] = x[i];
+    }
+    (void)Linv_out;
+    return __builtin_amdgcn_ballot_w64(!(dmin > 0.0)) != 0;
+}
+
+// which form the tile factorisation uses: the lean one (tools/potrf_probe.hip: 3 600 against 3 950 cycles per block, the tile 43.9 k
+// against 45.3 k; tools/_bin/chol_test 6016: 2.480-2.491 against 2.495 ms, the same bits on its matrices -- the diagonal entry comes out of
+// the same fused operation either way, and where the off-diagonal term is small against it the two roundings of the pivot agree).
+// -DCHOL_FACTOR_BLOCK=factor_block16 builds the classic one.
+#ifndef CHOL_FACTOR_BLOCK
+#define CHOL_FACTOR_BLOCK factor_block16_lean
+#endif
+
 // element of register r of an MFMA operand / accumulator inside a block
 template <class LAY>
 __device__ __forceinline__ int frag(int r, int lane) { return (4 * r + (lane >> 4)) * LAY::PITCH + (lane & 15); }
@@ -374,7 +484,7 @@ __device__ __forceinline__ bool potrf_tile_lds(double* __restrict__ A, double* _
     const int NBK = PARTIAL ? nblk : NBLK;
     const int lane = tid & 63, wave = tid >> 6;
     bool failed = false;
-    if (wave == 0) failed = factor_block16<LAY::PITCH>(A + LAY::blk(0, 0), lane, Li, Linv_k);
+    if (wave == 0) failed = CHOL_FACTOR_BLOCK<LAY::PITCH>(A + LAY::blk(0, 0), lane, Li, Linv_k);
     tile_barrier<PUBLISH != 0>();
     for (int s = 0; s < NBK; ++s) {
         const double* Lc = Li + (s & 1) * NB * NB;
@@ -466,7 +576,7 @@ __device__ __forceinline__ bool potrf_tile_lds(double* __restrict__ A, double* _
         //   wavefronts 1-3  block column s+1 below the diagonal, LEFT-looking: tile (i, s+1) -= sum_{k <= s} Y_ik Y_{s+1,k}^T
         //                   (these are the strips of the next step), and the later diagonal blocks (i, i) -= Y_is Y_is^T.
         if (wave == 0) {
-            failed |= factor_block16<LAY::PITCH>(A + LAY::blk(s + 1, s + 1), lane, Li + ((s + 1) & 1) * NB * NB, Linv_k + (s + 1) * NB * NB);
+            failed |= CHOL_FACTOR_BLOCK<LAY::PITCH>(A + LAY::blk(s + 1, s + 1), lane, Li + ((s + 1) & 1) * NB * NB, Linv_k + (s + 1) * NB * NB);
         } else {
             const int nrow = NBK - 2 - s;                 // block rows s+2 .. 7
             // (with the inverse alongside, the update's tasks are dealt from wavefront 3 downwards: wavefront 1 owns the longest columns of the inverse)
