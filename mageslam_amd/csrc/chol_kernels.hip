@@ -292,8 +292,7 @@ __device__ __forceinline__ void fl_column(double (&a)[NB], double (&x)[NB], doub
     double y = __builtin_amdgcn_rsq(d);
     __builtin_amdgcn_sched_barrier(0);
     fl_fill_range<J, 2, (NFILL < 6 ? NFILL : 6)>(a, x);
-    dmin = fmin(dmin, d);
-    __builtin_amdgcn_sched_barrier(0);
+    (void)dmin;                                                  // (a non-positive pivot leaves NaNs behind: caught once, at the end)
     double g = d * y, h = 0.5 * y;
     __builtin_amdgcn_sched_barrier(0);
     fl_fill_range<J, 6, (NFILL < 7 ? NFILL : 7)>(a, x);
@@ -335,6 +334,10 @@ __device__ __forceinline__ bool factor_block16_lean(double* __restrict__ B, int 
     double dmin = 1.0;
     fl_columns<0>(a, x, dmin);
     // (pivot 15's updates: none; pivot 14's leftovers were dealt inside pivot 15)
+    // A pivot d <= 0 makes rsq(d) NaN or infinite, its column NaN (0 x inf for d = 0), and every later column of the rows below it NaN:
+    // the last diagonal entry (lane 15's a[15]) is NaN exactly when some pivot was not positive -- sixteen v_min_f64 less on the
+    // wavefront whose instruction count is the tile's critical path.
+    dmin = (l == NB - 1 && !(a[NB - 1] == a[NB - 1])) ? -1.0 : 1.0;
     if (lane < NB) {
 #pragma unroll
         for (int c = 0; c < NB; ++c) B[c * PITCH + l] = a[c];
