@@ -1221,8 +1221,9 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
         v.w_pos = h->d_w_pos.p; v.pos_lm = h->d_pos_lm.p; v.con_pos = h->d_con_pos.p; v.slot_order = lpt ? h->d_slot_order.p : nullptr;
         h->positions_valid = true;
     }
+    int chi_partials = 0;        // > 0: the linearisation left its chi2 partials for the first trial's Schur launch to add (ba_fused_linearize)
     if (small) ba_small_linearize(v, huber, h->iteration == 0, counter, st);
-    else if (ba_fused_linearize_applies(v)) ba_fused_linearize(v, huber, fold_counters, st);
+    else if (ba_fused_linearize_applies(v)) chi_partials = ba_fused_linearize(v, huber, fold_counters, st, /*defer_chi_fold=*/!sharded && !(h->iteration == 0 && !(h->user_lambda > 0)));      // (iteration 0 without a user lambda: max |diag| is reduced through v.partial before the Schur launch)
     else {
         ba_launch_error(v, false, huber, st);
         ba_launch_linearize(v, huber, st);
@@ -1279,7 +1280,8 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
             }
         } else {
             v.tile_env = (h->S_outside_skyline_is_zero && h->tile_env_valid && !sharded) ? h->d_tile_env.p : nullptr;
-            ba_launch_schur(v, lambda, adds_damping ? lambda : 0.0, adds_damping ? 1.0 : 0.0, st);
+            ba_launch_schur(v, lambda, adds_damping ? lambda : 0.0, adds_damping ? 1.0 : 0.0, chi_partials, st);
+            chi_partials = 0;          // (added once: the later trials' launches overwrite the partials)
             h->S_outside_skyline_is_zero = false;          // until this trial's factorisation is known to have produced no NaN (below)
             if (sharded) {
                 ba_launch_pack_lower(v, h->d_xchg.p, true, st);

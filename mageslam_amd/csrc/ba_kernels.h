@@ -109,6 +109,7 @@ void ba_launch_tile_envelope(const BaDeviceView& v, int* tile_env, hipStream_t s
 void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st);                         // xl, trial state, scal[SC_SCALE]
 // landmark-sharded maps (include/mage_ba.h: mage_ba_set_landmark_shard)
 void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, double pad_diag, hipStream_t st);
+void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, double pad_diag, int fold_chi_partials, hipStream_t st);   // + the deferred chi2 fold of ba_fused_linearize
 void ba_launch_update(const BaDeviceView& v, double lambda, double lambda_cam, hipStream_t st);
 bool ba_update_and_trial_error_fuses(const BaDeviceView& v);                                             // free points: update + trial chi2 in three launches
 void ba_launch_update_and_trial_error(const BaDeviceView& v, double lambda, double lambda_cam, double huber_delta, int* fold_counters, hipStream_t st);   // fold_counters: BA_FOLD_COUNTER_INTS zero-between-launches ints of the handle (the last block of k_backsub adds the partials) or nullptr
@@ -138,7 +139,7 @@ bool ba_small_shape_applies(int n_fc, int n_tethers, long long n_L);            
 void ba_small_init_device();                                                                          // once per device: LDS opt-in
 bool ba_compact_w_enabled();                                                                          // false with MAGE_BA_MATERIAL_W=1 (A/B, tests)
 bool ba_fused_linearize_applies(const BaDeviceView& v);                                              // large, one observation per W slot
-void ba_fused_linearize(const BaDeviceView& v, double huber_delta, int* counter, hipStream_t st);    // = ba_launch_error(current) + ba_launch_linearize in one launch
+int ba_fused_linearize(const BaDeviceView& v, double huber_delta, int* counter, hipStream_t st, bool defer_chi_fold = false);    // = ba_launch_error(current) + ba_launch_linearize in one launch
 void ba_small_linearize(const BaDeviceView& v, double huber_delta, bool want_maxdiag, int* counter, hipStream_t st);   // U,bc,V,bp,W, S/y zeroed, scal[SC_CHI] (+ SC_MAXDIAG)
 void ba_small_solve_trial(const BaDeviceView& v, double lambda, double huber_delta, double* linv_ws, int* counter, hipStream_t st);    // S, y, xc, trial state, SC_SCALE, SC_CHI_TRIAL, SC_CHOL_OK/STALL
 void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, double* result, hipStream_t st);   // result: the kept estimate (poses x 8, points x 4) or nullptr

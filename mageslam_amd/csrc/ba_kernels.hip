@@ -483,6 +483,62 @@ __global__ __launch_bounds__(256) void k_zero_skyline(double* __restrict__ S, in
         base[(size_t)c * (n_pad / 2) + r2] = make_double2(0.0, 0.0);
     }
 }
+__device__ __forceinline__ void lm_dinv_from(const double* Vl, double lambda, double D[6]);
+// k_lm_invert + k_zero_skyline + the linearisation's chi2 fold in ONE launch (round 4, late: three launches of ~6 us each became one):
+//   blocks [0, nb_lm)                      (V_l + lambda I)^-1 and D^-1 b_p per landmark            (k_lm_invert)
+//   blocks [nb_lm, nb_lm + nb_y)           y = b_c with a zero tail (+ the padded diagonal when no zero role runs here)
+//   block   nb_lm + nb_y, if fold_n > 0    scal[SC_CHI] = sum of the fold_n partials the linearisation left (k_reduce_sum's order)
+//   the n_zero blocks behind               one lower tile of S each: cleared inside the skyline (k_zero_skyline); a diagonal tile then also
+//                                          gets the identity on its padded rows -- by the workgroup that cleared it, behind a barrier
+__global__ __launch_bounds__(256) void k_schur_prepare(BaDeviceView v, double lambda, int nb_lm, int nb_y, int y_from_bc, double pad_diag, int fold_n, int n_zero, int tile)
+{
+    __shared__ double sm4[4];
+    const int bid = blockIdx.x;
+    if (bid < nb_lm) {
+        const int l = bid * 256 + threadIdx.x;
+        if (l >= v.n_lm) return;
+        double D[6];
+        lm_dinv_from(v.V + (size_t)l * 6, lambda, D);
+        double* Do = v.Dinv + (size_t)l * 6;
+        Do[0] = D[0]; Do[1] = D[1]; Do[2] = D[2]; Do[3] = D[3]; Do[4] = D[4]; Do[5] = D[5];
+        const double b0 = v.bp[(size_t)l * 4], b1 = v.bp[(size_t)l * 4 + 1], b2 = v.bp[(size_t)l * 4 + 2];
+        double* db = v.db + (size_t)l * 4;
+        db[0] = D[0] * b0 + D[1] * b1 + D[2] * b2;
+        db[1] = D[1] * b0 + D[3] * b1 + D[4] * b2;
+        db[2] = D[2] * b0 + D[4] * b1 + D[5] * b2;
+        db[3] = 0;
+        return;
+    }
+    const int n = v.n_fc * 6;
+    if (bid < nb_lm + nb_y) {
+        for (int i = (bid - nb_lm) * 256 + threadIdx.x; i < v.n_pad; i += nb_y * 256) {
+            v.y[i] = (i < n && y_from_bc) ? v.bc[i] : 0.0;
+            if (i >= n && n_zero == 0) v.S[(size_t)i * v.n_pad + i] = pad_diag;
+        }
+        return;
+    }
+    int z = bid - nb_lm - nb_y;
+    if (fold_n > 0) {
+        if (z == 0) { fold_partials_strided(v.partial, fold_n, 1, v.scal + SC_CHI, 1, sm4); return; }
+        --z;
+    }
+    if (z >= n_zero) return;
+    int R = (int)((sqrt(8.0 * (double)z + 1.0) - 1.0) * 0.5);
+    while ((R + 1) * (R + 2) / 2 <= z) ++R;
+    while (R * (R + 1) / 2 > z) --R;
+    const int t = z - R * (R + 1) / 2;
+    if (t < v.tile_env[R]) return;
+    double2* base = reinterpret_cast<double2*>(v.S + (size_t)(t * tile) * v.n_pad + (size_t)R * tile);
+    for (int e = threadIdx.x; e < tile * tile / 2; e += 256) {
+        const int c = e / (tile / 2), r2 = e % (tile / 2);
+        base[(size_t)c * (v.n_pad / 2) + r2] = make_double2(0.0, 0.0);
+    }
+    if (t == R && (R + 1) * tile > n) {            // the diagonal tile that holds padded rows
+        __syncthreads();
+        for (int i = R * tile + threadIdx.x; i < (R + 1) * tile; i += 256) if (i >= n) v.S[(size_t)i * v.n_pad + i] = pad_diag;
+    }
+}
+
 // env[R] = min over the blocks (i, j), i <= j, whose rows 6 j .. fall into tile row R, of the tile column of 6 i
 __global__ __launch_bounds__(256) void k_tile_envelope(BaDeviceView v, int* __restrict__ env, int n_tiles, int tile)
 {
@@ -2240,16 +2296,28 @@ bool ba_launch_allreduce_local(double* const* bufs, int n, size_t count, int op,
 
 void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st) { ba_launch_schur(v, lambda, lambda, 1.0, st); }
 // lambda_cam: the damping of the camera blocks (lambda; 0 on the ranks of a landmark-sharded map that leave it to rank 0)
-void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, double pad_diag, hipStream_t st)
+void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, double pad_diag, hipStream_t st) { ba_launch_schur(v, lambda, lambda_cam, pad_diag, 0, st); }
+// fold_n > 0: scal[SC_CHI] = the sum of the fold_n partials the linearisation left in v.partial (ba_fused_linearize with its fold deferred)
+void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, double pad_diag, int fold_n, hipStream_t st)
 {
-    if (v.n_pad >= 1024 && v.tile_env) { const int nt = v.n_pad / 128; hipLaunchKernelGGL(k_zero_skyline, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, v.S, v.n_pad, 128, v.tile_env); }
-    else if (v.n_pad >= 1024) hipLaunchKernelGGL(k_zero_lower, dim3(std::max(1, v.n_pad / 2048), v.n_pad), dim3(256), 0, st, v.S, v.n_pad, 128);
-    else (void)hipMemsetAsync(v.S, 0, (size_t)v.n_pad * v.n_pad * sizeof(double), st);
+    static const bool separate = std::getenv("MAGE_BA_SEPARATE_PREPARE") != nullptr;      // A/B: k_zero_skyline, k_lm_invert (and k_reduce_sum) as launches of their own
+    const bool skyline = v.n_pad >= 1024 && v.tile_env;
+    const bool merged = !separate && v.n_pad >= 1024;
+    if (skyline && !merged) { const int nt = v.n_pad / 128; hipLaunchKernelGGL(k_zero_skyline, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, v.S, v.n_pad, 128, v.tile_env); }
+    else if (v.n_pad >= 1024 && !skyline) hipLaunchKernelGGL(k_zero_lower, dim3(std::max(1, v.n_pad / 2048), v.n_pad), dim3(256), 0, st, v.S, v.n_pad, 128);
+    else if (v.n_pad < 1024) (void)hipMemsetAsync(v.S, 0, (size_t)v.n_pad * v.n_pad * sizeof(double), st);
     // the diagonal blocks of k_schur_block also write their camera's reduced rhs; a camera without a block (no free landmark) keeps b_c
     const bool rhs_in_blocks = v.points_free && v.n_blk > 0;
     {
         const int nb_lm = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm, 256) : 0;
-        hipLaunchKernelGGL(k_lm_invert, dim3(nb_lm + std::max(1, std::min(8, cdiv(v.n_pad, 256)))), dim3(256), 0, st, v, lambda, nb_lm, rhs_in_blocks ? 1 : 0, pad_diag);
+        const int nb_y = std::max(1, std::min(8, cdiv(v.n_pad, 256)));
+        if (merged) {
+            const int nt = v.n_pad / 128, n_zero = skyline ? nt * (nt + 1) / 2 : 0;
+            hipLaunchKernelGGL(k_schur_prepare, dim3(nb_lm + nb_y + (fold_n > 0 ? 1 : 0) + n_zero), dim3(256), 0, st, v, lambda, nb_lm, nb_y, rhs_in_blocks ? 1 : 0, pad_diag, fold_n, n_zero, 128);
+        } else {
+            if (fold_n > 0) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, fold_n, 1, v.scal + SC_CHI, 1);
+            hipLaunchKernelGGL(k_lm_invert, dim3(nb_lm + nb_y), dim3(256), 0, st, v, lambda, nb_lm, rhs_in_blocks ? 1 : 0, pad_diag);
+        }
     }
     if (v.n_blk > 0 && v.compact) {
         if (v.n_blk <= SPLIT_BLOCKS_BELOW) hipLaunchKernelGGL(k_schur_block_compact<true>, dim3(v.n_blk), dim3(256), 0, st, v, lambda_cam);
@@ -2408,15 +2476,19 @@ bool ba_fused_linearize_applies(const BaDeviceView& v)
     static const bool off = std::getenv("MAGE_BA_NO_FUSED_LINEARIZE") != nullptr;
     return !off && !v.dup_slots && v.n_fc > 0 && v.n_L > 0;
 }
-void ba_fused_linearize(const BaDeviceView& v, double delta, int* counter, hipStream_t st)
+// defer_chi_fold: the chi2 partials stay in v.partial and their count is returned -- the caller hands it to the trial's FIRST
+// ba_launch_schur, whose launch adds them (nothing reads scal[SC_CHI] before); only without tethers (their chi2 is added on top below)
+int ba_fused_linearize(const BaDeviceView& v, double delta, int* counter, hipStream_t st, bool defer_chi_fold)
 {
     const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm * SMALL_LPL, 256) : 0;
     const int nbC = ((v.n_fc + 7) / 8) * 8 + 8;          // every XCD gets ceil(n_fc / 8) camera workgroups wherever its first one falls
     const bool fold = ba_reductions_fold();
+    const bool defer = defer_chi_fold && !fold && v.n_T == 0 && v.n_pad >= 1024;
     hipLaunchKernelGGL(k_small_linearize, dim3(nbL + nbC), dim3(256), 0, st, v, delta, nbL, 0, counter, 1, 0, fold ? 1 : 0);
-    if (!fold) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nbL + nbC, 1, v.scal + SC_CHI, 1);
+    if (!fold && !defer) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nbL + nbC, 1, v.scal + SC_CHI, 1);
     tether_launch_error(v, false, st);          // the pose-pose edges add their chi2, U and b_c on top (nothing is launched without them)
     tether_launch_linearize(v, st);
+    return defer ? nbL + nbC : 0;
 }
 void ba_small_solve_trial(const BaDeviceView& v, double lambda, double delta, double* linv_ws, int* counter, hipStream_t st)
 {

@@ -161,7 +161,7 @@ def test_placement_and_reduction_switches_are_bit_identical(tmp_path):
         import numpy as np
         from mageslam_amd import scene
         from mageslam_amd.bundler import BundlerLib, load_scene
-        s = scene.make_scene(n_cams=60, n_pts=6000, n_obs=60000, seed=0x5EED0B11, outlier_frac=0.01)
+        s = scene.make_scene(n_cams=int(sys.argv[2]), n_pts=6000, n_obs=60000, seed=0x5EED0B11, outlier_frac=0.01)
         b = BundlerLib(False); load_scene(b, s, bulk=True)
         outs, tr = [], []
         for hub, thr in [([1.8], 25.0), ([0.9, 0.9], 16.0), ([0.9], 9.0)]:
@@ -170,15 +170,18 @@ def test_placement_and_reduction_switches_are_bit_identical(tmp_path):
         print("RESULT " + json.dumps(dict(outs=outs, tr=tr)))
     """) % root
     res = {}
-    for tag, env in (("default", {}), ("landmark_major", {"MAGE_BA_W_LANDMARK_MAJOR": "1"}), ("folded", {"MAGE_BA_FOLD_REDUCTIONS": "1"}),
-                     ("row_order", {"MAGE_BA_SCHUR_ROW_ORDER": "1"})):
+    # 180 cameras: a reduced system of >= 1024 rows, where one k_schur_prepare launch zero-fills the skyline, inverts the landmark
+    # blocks and adds the linearisation's chi2 partials (MAGE_BA_SEPARATE_PREPARE=1: the three launches it replaces)
+    for tag, cams, env in (("default", 60, {}), ("landmark_major", 60, {"MAGE_BA_W_LANDMARK_MAJOR": "1"}), ("folded", 60, {"MAGE_BA_FOLD_REDUCTIONS": "1"}),
+                           ("row_order", 60, {"MAGE_BA_SCHUR_ROW_ORDER": "1"}),
+                           ("default180", 180, {}), ("separate_prepare", 180, {"MAGE_BA_SEPARATE_PREPARE": "1"})):
         f = str(tmp_path / (tag + ".npy"))
-        p = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        p = subprocess.run([sys.executable, "-c", code, f, str(cams)], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
         res[tag] = (np.load(f), json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:]))
-    for tag in ("landmark_major", "folded", "row_order"):
-        assert res[tag][1] == res["default"][1], tag
-        assert np.array_equal(res[tag][0], res["default"][0]), tag
+    for tag, ref in (("landmark_major", "default"), ("folded", "default"), ("row_order", "default"), ("separate_prepare", "default180")):
+        assert res[tag][1] == res[ref][1], tag
+        assert np.array_equal(res[tag][0], res[ref][0]), tag
 
 
 def test_concurrent_handles_on_separate_threads():
