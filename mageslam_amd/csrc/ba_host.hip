@@ -1534,6 +1534,17 @@ mage_status frame_step(mage_ba* h, const float* huber, size_t n_iter, float max_
     unsigned char* D = h->d_frame.p;
     BaDeviceView v{};
     v.n_cams = nc; v.n_pts = np; v.n_L = nL; v.n_fc = nfc; v.points_free = 0; v.n_pad = CHOL_TILE;
+    // DIRECT (round 4): the staged kernel reads every input exactly once (into LDS) and writes its record, the flags and the two pose
+    // buffers exactly once -- so it takes them from / leaves them in the pinned image itself, across PCIe, and the two copy commands
+    // (a blit launch and a dependency each, ~10 us of a 65 us call) are not queued at all.  MAGE_BA_FRAME_COPIES=1: upload + read-back.
+    static const bool frame_copies = std::getenv("MAGE_BA_FRAME_COPIES") != nullptr;
+    static const bool staged_off = std::getenv("MAGE_BA_POSE_LM_IN_HBM") != nullptr;      // A/B: the arrays left in HBM
+    const bool direct = !frame_copies && !staged_off && ba_pose_lm_staged_fits(v);
+    if (direct) {
+        void* dev_img = nullptr;
+        MAGE_HIP(hipHostGetDevicePointer(&dev_img, img, 0));
+        D = static_cast<unsigned char*>(dev_img);
+    }
     v.camK = reinterpret_cast<const double*>(D + o_K); v.pt_cur = v.pt_trial = reinterpret_cast<double*>(D + o_pt);
     v.hc2cam = reinterpret_cast<const int*>(D + o_hc); v.camE_ptr = reinterpret_cast<const int*>(D + o_cep); v.camE = reinterpret_cast<const int*>(D + o_ce);
     v.L_uv = reinterpret_cast<const float2*>(D + o_uv); v.L_info = reinterpret_cast<const float*>(D + o_info);
@@ -1544,11 +1555,17 @@ mage_status frame_step(mage_ba* h, const float* huber, size_t n_iter, float max_
     a.n_huber = (int)n_iter;
     for (size_t it = 0; it < n_iter; ++it) a.huber[it] = huber[it];
     a.max_err_sq = (double)max_err_sq; a.lambda = h->lambda; a.user_lambda = h->user_lambda; a.ni = h->ni; a.iteration = h->iteration;
-    MAGE_HIP(hipMemcpyAsync(D, img, up_bytes, hipMemcpyHostToDevice, h->stream));
-    static const bool staged_off = std::getenv("MAGE_BA_POSE_LM_IN_HBM") != nullptr;      // A/B: the arrays left in HBM
-    if (staged_off || !ba_launch_pose_lm_staged(v, a, reinterpret_cast<PoseLmResult*>(D + o_res), D + o_flag, h->stream))
-        ba_launch_pose_lm(v, a, reinterpret_cast<PoseLmResult*>(D + o_res), D + o_flag, h->stream);
-    MAGE_HIP(hipMemcpyAsync(back, D + o_p0, back_bytes, hipMemcpyDeviceToHost, h->stream));
+    if (direct) {
+        // record and flags land in the `back` part of the image (where the read-back would have put them), the poses in place
+        unsigned char* B = D + up_bytes;
+        if (!ba_launch_pose_lm_staged(v, a, reinterpret_cast<PoseLmResult*>(B + (o_res - o_p0)), B + (o_flag - o_p0), h->stream))
+            return fail(MAGE_ERR_DEVICE, "pose-only solve: the staged launch was refused");
+    } else {
+        MAGE_HIP(hipMemcpyAsync(D, img, up_bytes, hipMemcpyHostToDevice, h->stream));
+        if (staged_off || !ba_launch_pose_lm_staged(v, a, reinterpret_cast<PoseLmResult*>(D + o_res), D + o_flag, h->stream))
+            ba_launch_pose_lm(v, a, reinterpret_cast<PoseLmResult*>(D + o_res), D + o_flag, h->stream);
+        MAGE_HIP(hipMemcpyAsync(back, D + o_p0, back_bytes, hipMemcpyDeviceToHost, h->stream));
+    }
     MAGE_HIP(hipEventRecord(h->ev[3], h->stream));
     for (;;) {
         const hipError_t e = hipEventQuery(h->ev[3]);
@@ -1556,7 +1573,7 @@ mage_status frame_step(mage_ba* h, const float* huber, size_t n_iter, float max_
         if (e != hipErrorNotReady) MAGE_HIP(e);
     }
     const PoseLmResult& r = *reinterpret_cast<const PoseLmResult*>(back + (o_res - o_p0));
-    const double* kept = reinterpret_cast<const double*>(back + ((r.flips & 1) ? (o_p1 - o_p0) : 0));
+    const double* kept = reinterpret_cast<const double*>(direct ? img + ((r.flips & 1) ? o_p1 : o_p0) : back + ((r.flips & 1) ? (o_p1 - o_p0) : 0));
     for (int hc = 0; hc < nfc; ++hc) {                    // only the cameras of the system move
         HostCam& c = h->cams[hc2cam[hc]];
         for (int q = 0; q < 4; ++q) c.q[q] = kept[hc2cam[hc] * 8 + q];

@@ -162,6 +162,7 @@ bool ba_pose_lm_applies(const BaDeviceView& v, size_t n_huber);
 void ba_launch_pose_lm(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out_device, uint8_t* flag_by_edge, hipStream_t st);
 // the same solve with every array staged in LDS (only the two pose buffers are written back): false = the problem does not fit
 constexpr int POSE_LM_STAGED_MAX_BYTES = 140 * 1024;
+bool ba_pose_lm_staged_fits(const BaDeviceView& v);     // the staged form's LDS image fits: the launch below will be taken
 bool ba_launch_pose_lm_staged(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out_device, uint8_t* flag_by_edge, hipStream_t st);
 
 // Pose exchange of a window-sharded map (mage_ba_export_poses_device / mage_ba_import_poses_device).  A block row is 8 doubles

@@ -2527,6 +2527,10 @@ void ba_launch_pose_lm(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult*
 {
     hipLaunchKernelGGL(k_pose_lm<false>, dim3(1), dim3(256), 0, st, v, a, out, flagL);
 }
+bool ba_pose_lm_staged_fits(const BaDeviceView& v)
+{
+    return pose_lm_staged_bytes(v.n_cams, v.n_pts, v.n_L, v.n_fc) <= (size_t)POSE_LM_STAGED_MAX_BYTES;
+}
 bool ba_launch_pose_lm_staged(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out, uint8_t* flagL, hipStream_t st)
 {
     const size_t lds = pose_lm_staged_bytes(v.n_cams, v.n_pts, v.n_L, v.n_fc);

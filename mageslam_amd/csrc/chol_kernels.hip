@@ -480,6 +480,13 @@ __device__ __forceinline__ void store_through(double* p, double v)
     __hip_atomic_store((global_double*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifdef CHOL_TILE_STAMPS        // tools/potrf_probe.hip: shader-clock stamps of every wavefront at the five points of an in-tile iteration
+__device__ long long g_tile_stamps[4][NBLK][5];
+#define TILE_STAMP(p) do { if (lane == 0) g_tile_stamps[wave][s][p] = clock64(); } while (0)
+#else
+#define TILE_STAMP(p) do { } while (0)
+#endif
+
 template <bool PARTIAL, class LAY, int PUBLISH = 0>
 __device__ __forceinline__ bool potrf_tile_lds(double* __restrict__ A, double* __restrict__ Li, double* __restrict__ Linv_k, int tid, int nblk = NBLK,
                                             TilePublish pub = TilePublish{ nullptr })
@@ -491,6 +498,7 @@ __device__ __forceinline__ bool potrf_tile_lds(double* __restrict__ A, double* _
     tile_barrier<PUBLISH != 0>();
     for (int s = 0; s < NBK; ++s) {
         const double* Lc = Li + (s & 1) * NB * NB;
+        TILE_STAMP(0);
         if (PUBLISH == 4 && wave >= 1 && s >= 2) {
             // PHASED strips (round 4): what this wavefront wrote through one iteration ago (its blocks of column s - 2, wavefront 3 also the
             // inverse of block s - 1) has been acknowledged by now, so the wait costs nothing -- unlike a flag raised right behind the stores,
@@ -571,7 +579,9 @@ __device__ __forceinline__ bool potrf_tile_lds(double* __restrict__ A, double* _
                 for (int r = 0; r < 4; ++r) Xs[frag<LAY>(r, lane)] = acc[r];
             }
         }
+        TILE_STAMP(1);
         tile_barrier<PUBLISH != 0>();
+        TILE_STAMP(2);
         if (PUBLISH == 4 && s >= 2 && wave == 3 && lane == 0) __hip_atomic_store(pub.progress, pub.base + s - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // Trailing update, scheduled so that it never outlasts the factorisation it runs beside (a right-looking update
         // front-loads 27 of the 77 tile updates into step 0; wavefront 0 then waited ~10k cycles per tile at this barrier):
@@ -651,7 +661,9 @@ __device__ __forceinline__ bool potrf_tile_lds(double* __restrict__ A, double* _
                 }
             }
         }
+        TILE_STAMP(3);
         tile_barrier<PUBLISH != 0>();
+        TILE_STAMP(4);
     }
     if (PUBLISH == 3) {
         // the last row of the inverse: Linv[7][j] = -Linv_77 P_7[j], straight to memory (transposed form only), two columns per wavefront

@@ -22,13 +22,13 @@ __global__ __launch_bounds__(256) void k_probe(const double* __restrict__ S, int
     long long t1 = clock64();
     __syncthreads();
     long long t2 = clock64();
-    load_tile<LDC>(A, S, ld, tid);
+    load_tile_packed(A, S, ld, tid);                             // the library's layout of a diagonal tile (LayPacked)
     __syncthreads();
     long long t3 = clock64();
-    f |= potrf_tile_lds<false, LayLDC>(A, Li, Linv, tid);       // (the library's full-tile kernels use LayPacked; the probe keeps the square layout)
+    f |= potrf_tile_lds<false, LayPacked>(A, Li, Linv, tid);
     long long t4 = clock64();
     __syncthreads();
-    for (int e = tid; e < TILE * TILE; e += 256) { const int c = e / TILE, r = e % TILE; if (r >= c) (const_cast<double*>(S) + (size_t)ld * ld)[(size_t)c * ld + r] = A[c * LDC + r]; }      // second ld x ld matrix of the buffer receives L
+    store_tile_packed(const_cast<double*>(S) + (size_t)ld * ld, A, ld, tid);      // second ld x ld matrix of the buffer receives L
     if (tid == 0) { out[0] = t1 - t0; out[1] = t2 - t1; out[2] = t4 - t3; out[3] = f; }
     if (tid == 64) { out[4] = t1 - t0; }
 }
@@ -73,6 +73,17 @@ int main()
         }
         printf("residual ||A - L L^T|| / ||A|| = %.3e   max |Linv L - I| = %.3e\n", std::sqrt(num / den), worst);
     }
+#ifdef CHOL_TILE_STAMPS
+    {   // per in-tile iteration: top -> strips done -> past the middle barrier -> pivot block / trailing update done -> past the end barrier
+        long long st[4][NBLK][5];
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(g_tile_stamps), sizeof(st));
+        for (int s = 0; s + 1 < NBLK; ++s) {
+            printf("iteration %d (from wavefront 0's top stamp):", s);
+            for (int w = 0; w < 4; ++w) { printf("  w%d:", w); for (int p = 0; p < 5; ++p) printf(" %5lld", st[w][s][p] - st[0][s][0]); }
+            printf("\n");
+        }
+    }
+#endif
     printf("%s\n", hipGetErrorString(hipGetLastError()));
     return 0;
 }
