@@ -1478,17 +1478,19 @@ mage_status frame_step(mage_ba* h, const float* huber, size_t n_iter, float max_
     for (int a = 0; a < nL; ++a) camE_ptr[cam2hc[h->obs[active[a]].cam] + 1]++;
     for (int c = 0; c < nfc; ++c) camE_ptr[c + 1] += camE_ptr[c];
 
-    // ---- the image: [up: camK | pt | hc2cam | camE_ptr | camE | L_uv | L_info | L_cam | L_pt | L_active | pose0 | pose1][back: record | flags][scratch]
+    // ---- the image: [up: pose0 | pose1 | camK | pt | L_uv | L_info | L_cam | L_pt | camE | camE_ptr | hc2cam | L_active][back: record | flags | pose0' | pose1'][scratch]
+    // `up` is the head of the staged kernel's LDS image, in its order and packed (k_pose_lm copies it as ONE flat run); nothing in it is
+    // written by the solve, everything the solve returns is in `back`.
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t off = 0;
+    auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_p0 = 0, o_p1 = o_p0 + (size_t)nc * 64, o_K = o_p1 + (size_t)nc * 64, o_pt = o_K + (size_t)nc * 32;
+    const size_t o_uv = al16(o_pt + (size_t)np * 32), o_info = o_uv + (size_t)nL * 8, o_cam = o_info + (size_t)nL * 4, o_lpt = o_cam + (size_t)nL * 4,
+                 o_ce = o_lpt + (size_t)nL * 4, o_cep = o_ce + (size_t)nL * 4, o_hc = o_cep + (size_t)(nfc + 1) * 4, o_act = o_hc + (size_t)nfc * 4;
+    const size_t up_bytes = al(o_act + (size_t)nL + 16);                       // (+16: the second run is copied in whole 16-byte pieces)
+    const size_t o_res = up_bytes, o_flag = o_res + al16(sizeof(PoseLmResult)), o_q0 = al16(o_flag + (size_t)nL), o_q1 = o_q0 + (size_t)nc * 64;
+    size_t off = al(o_q1 + (size_t)nc * 64);
+    const size_t back_bytes = off - up_bytes;
     auto take = [&](size_t bytes) { const size_t o = off; off = al(off + bytes); return o; };
-    const size_t o_K = take((size_t)nc * 32), o_pt = take((size_t)np * 32), o_hc = take((size_t)nfc * 4), o_cep = take((size_t)(nfc + 1) * 4),
-                 o_ce = take((size_t)nL * 4), o_uv = take((size_t)nL * 8), o_info = take((size_t)nL * 4), o_cam = take((size_t)nL * 4), o_lpt = take((size_t)nL * 4),
-                 o_act = take((size_t)nL);
-    const size_t o_p0 = take((size_t)nc * 64), o_p1 = take((size_t)nc * 64);
-    const size_t up_bytes = off;
-    const size_t o_res = take(sizeof(PoseLmResult)), o_flag = take((size_t)nL);
-    const size_t back_bytes = off - o_p0;
     const size_t o_err = take((size_t)nL * 16), o_U = take((size_t)nfc * 36 * 8), o_bc = take((size_t)nfc * 48), o_xc = take((size_t)nfc * 48);
     const size_t dev_bytes = off;
     if (h->h_frame_bytes < up_bytes + back_bytes) {
@@ -1555,16 +1557,15 @@ mage_status frame_step(mage_ba* h, const float* huber, size_t n_iter, float max_
     a.n_huber = (int)n_iter;
     for (size_t it = 0; it < n_iter; ++it) a.huber[it] = huber[it];
     a.max_err_sq = (double)max_err_sq; a.lambda = h->lambda; a.user_lambda = h->user_lambda; a.ni = h->ni; a.iteration = h->iteration;
+    // (D is the pinned image itself when `direct`: record, flags and the two pose buffers then land in its `back` part with no copy queued)
+    PoseLmResult* d_res = reinterpret_cast<PoseLmResult*>(D + o_res);
+    double* d_q = reinterpret_cast<double*>(D + o_q0);
     if (direct) {
-        // record and flags land in the `back` part of the image (where the read-back would have put them), the poses in place
-        unsigned char* B = D + up_bytes;
-        if (!ba_launch_pose_lm_staged(v, a, reinterpret_cast<PoseLmResult*>(B + (o_res - o_p0)), B + (o_flag - o_p0), h->stream))
-            return fail(MAGE_ERR_DEVICE, "pose-only solve: the staged launch was refused");
+        if (!ba_launch_pose_lm_staged(v, a, d_res, D + o_flag, d_q, h->stream)) return fail(MAGE_ERR_DEVICE, "pose-only solve: the staged launch was refused");
     } else {
         MAGE_HIP(hipMemcpyAsync(D, img, up_bytes, hipMemcpyHostToDevice, h->stream));
-        if (staged_off || !ba_launch_pose_lm_staged(v, a, reinterpret_cast<PoseLmResult*>(D + o_res), D + o_flag, h->stream))
-            ba_launch_pose_lm(v, a, reinterpret_cast<PoseLmResult*>(D + o_res), D + o_flag, h->stream);
-        MAGE_HIP(hipMemcpyAsync(back, D + o_p0, back_bytes, hipMemcpyDeviceToHost, h->stream));
+        if (staged_off || !ba_launch_pose_lm_staged(v, a, d_res, D + o_flag, d_q, h->stream)) ba_launch_pose_lm(v, a, d_res, D + o_flag, d_q, h->stream);
+        MAGE_HIP(hipMemcpyAsync(back, D + o_res, back_bytes, hipMemcpyDeviceToHost, h->stream));
     }
     MAGE_HIP(hipEventRecord(h->ev[3], h->stream));
     for (;;) {
@@ -1572,8 +1573,8 @@ mage_status frame_step(mage_ba* h, const float* huber, size_t n_iter, float max_
         if (e == hipSuccess) break;
         if (e != hipErrorNotReady) MAGE_HIP(e);
     }
-    const PoseLmResult& r = *reinterpret_cast<const PoseLmResult*>(back + (o_res - o_p0));
-    const double* kept = reinterpret_cast<const double*>(direct ? img + ((r.flips & 1) ? o_p1 : o_p0) : back + ((r.flips & 1) ? (o_p1 - o_p0) : 0));
+    const PoseLmResult& r = *reinterpret_cast<const PoseLmResult*>(back);
+    const double* kept = reinterpret_cast<const double*>(back + (((r.flips & 1) ? o_q1 : o_q0) - o_res));
     for (int hc = 0; hc < nfc; ++hc) {                    // only the cameras of the system move
         HostCam& c = h->cams[hc2cam[hc]];
         for (int q = 0; q < 4; ++q) c.q[q] = kept[hc2cam[hc] * 8 + q];
@@ -1588,7 +1589,7 @@ mage_status frame_step(mage_ba* h, const float* huber, size_t n_iter, float max_
     }
     *err_sum = r.err_sum; *err_cnt = r.err_cnt; *n_out = (size_t)r.n_out;
     if (r.n_out > 0) {
-        const unsigned char* flag = reinterpret_cast<const unsigned char*>(back + (o_flag - o_p0));
+        const unsigned char* flag = reinterpret_cast<const unsigned char*>(back + (o_flag - o_res));
         std::vector<uint32_t>& ids = h->last_outliers;
         ids.reserve((size_t)r.n_out);
         for (int i = 0; i < nL; ++i) if (flag[i]) ids.push_back(L_edge[i]);
@@ -2084,7 +2085,7 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
                     a.max_err_sq = (double)max_err_sq; a.lambda = h->lambda; a.user_lambda = h->user_lambda; a.ni = h->ni; a.iteration = h->iteration;
                     MAGE_TRY(h->d_pose_lm.reserve(1));
                     MAGE_TRY(ensure_pinned_mirrors(h));
-                    ba_launch_pose_lm(v, a, h->d_pose_lm.p, h->d_flagL.p, h->stream);
+                    ba_launch_pose_lm(v, a, h->d_pose_lm.p, h->d_flagL.p, nullptr, h->stream);
                     MAGE_HIP(hipMemcpyAsync(h->h_pose_lm, h->d_pose_lm.p, sizeof(PoseLmResult), hipMemcpyDeviceToHost, h->stream));
                     MAGE_HIP(hipEventRecord(h->ev[3], h->stream));
                     for (;;) {

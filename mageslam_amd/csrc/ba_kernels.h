@@ -159,11 +159,14 @@ struct PoseLmResult {
     PoseLmIter stats[POSE_LM_MAX_ITERS];
 };
 bool ba_pose_lm_applies(const BaDeviceView& v, size_t n_huber);
-void ba_launch_pose_lm(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out_device, uint8_t* flag_by_edge, hipStream_t st);
+// out_pose (may be null: the two pose buffers of `v` are then the result, in place): 2 x n_cams x 8 doubles, buffer 0 then buffer 1
+void ba_launch_pose_lm(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out_device, uint8_t* flag_by_edge, double* out_pose, hipStream_t st);
 // the same solve with every array staged in LDS (only the two pose buffers are written back): false = the problem does not fit
 constexpr int POSE_LM_STAGED_MAX_BYTES = 140 * 1024;
 bool ba_pose_lm_staged_fits(const BaDeviceView& v);     // the staged form's LDS image fits: the launch below will be taken
-bool ba_launch_pose_lm_staged(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out_device, uint8_t* flag_by_edge, hipStream_t st);
+// (its inputs must be ONE packed run, ba_host.hip's frame image, read once and never written: v.pose_cur = start of
+//  [pose0 | pose1 | camK | pt | L_uv | L_info | L_cam | L_pt | camE | camE_ptr | hc2cam | L_active] + 16 bytes of slack)
+bool ba_launch_pose_lm_staged(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out_device, uint8_t* flag_by_edge, double* out_pose, hipStream_t st);
 
 // Pose exchange of a window-sharded map (mage_ba_export_poses_device / mage_ba_import_poses_device).  A block row is 8 doubles
 // (qx qy qz qw tx ty tz 0).  export: block[row[k]] = pose[cam[k]] (+0.0, so that -0.0 leaves as +0.0 -- what a SUM with the

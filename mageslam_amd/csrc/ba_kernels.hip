@@ -37,6 +37,40 @@ __device__ __forceinline__ double wave_sum(double v)
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
     return v;
 }
+// The butterfly sums of N <= 32 values AT ONCE (round 4).  wave_sum spends six shuffles per value and leaves the total in every lane;
+// here a stage's shuffle carries TWO values -- the lanes whose bit m is clear send their y and keep x, the others send x and keep y, so
+// either half forms "own + received" of the value it keeps, the very additions of the plain butterfly -- and the register count
+// halves from stage to stage: 29 shuffles instead of 162 for the 27 sums of a camera block (21 of U, 6 of b), the same bits.
+// Returns the total of value number wave_sum_slot(lane) (meaningless where that number is >= N).
+__device__ __forceinline__ int wave_sum_slot(int lane)
+{
+    return ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) | (((lane >> 1) & 1) << 4);
+}
+template <int N, int M>
+__device__ __forceinline__ double wave_sum_packed_stage(const double (&v)[N], int lane)
+{
+    if constexpr (M == 1) {
+        static_assert(N == 1, "five halvings take at most 32 values to one");
+        return v[0] + __shfl_xor(v[0], 1, WAVE);
+    } else {
+        constexpr int H = (N + 1) / 2;
+        double h[H];
+        const bool up = (lane & M) != 0;
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const double x = v[2 * j], y = (2 * j + 1 < N) ? v[2 * j + 1] : 0.0;
+            const double r = __shfl_xor(up ? x : y, M, WAVE);
+            h[j] = (up ? y : x) + r;
+        }
+        return wave_sum_packed_stage<H, M / 2>(h, lane);
+    }
+}
+template <int N>
+__device__ __forceinline__ double wave_sum_packed(const double (&v)[N], int lane)
+{
+    static_assert(N >= 1 && N <= 32, "at most 32 values");
+    return wave_sum_packed_stage<N, 32>(v, lane);
+}
 __device__ __forceinline__ double wave_max(double v)
 {
 #pragma unroll
@@ -2006,27 +2040,37 @@ size_t pose_lm_staged_bytes(int nc, int np, int nL, int nfc)
     return ((size_t)nc * 20 + (size_t)np * 4 + (size_t)nL * 2 + (size_t)nfc * 48) * 8 + (size_t)nL * (8 + 4 * 4) + (size_t)(2 * nfc + 1) * 4 + (size_t)nL + 64;
 }
 
+#ifdef POSE_LM_CLOCKS      // development build only (tools/pose_lm_clocks.sh): thread 0 prints the shader clock at the phases of the solve
+#define PLC(tag) do { if (tid == 0 && plc_n < 48) { plc_t[plc_n] = clock64(); plc_tag[plc_n++] = tag; } } while (0)
+#else
+#define PLC(tag) do { } while (0)
+#endif
 template <bool STAGED>
-__global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a, PoseLmResult* __restrict__ out, uint8_t* __restrict__ flagL)
+__global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a, PoseLmResult* __restrict__ out, uint8_t* __restrict__ flagL, double* __restrict__ out_pose)
 {
-    extern __shared__ double dyn[];
+    extern __shared__ __align__(16) double dyn[];
     __shared__ double sm[4];
     __shared__ double part[4][28];
     __shared__ double s_lambda, s_ni, s_rho, s_cur_chi;
     __shared__ int s_ok, s_accept;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     BaDeviceView v = vin;
+#ifdef POSE_LM_CLOCKS
+    long long plc_t[48]; int plc_tag[48]; int plc_n = 0;
+#endif
+    PLC(0);
     if (STAGED) {
         const int nc = vin.n_cams, np = vin.n_pts, nL = vin.n_L, nfc = vin.n_fc;
+        // LDS: the caller's image first, byte for byte -- [pose0 | pose1 | camK | pt | L_uv | L_info | L_cam | L_pt | camE | camE_ptr |
+        // hc2cam | L_active] (ba_host.hip keeps it in exactly this order, packed) -- then the solve's own arrays.  ONE flat copy in 16-byte
+        // pieces, eight loads of a thread in flight before the first store: the image costs one trip to memory -- or across PCIe, when
+        // the pointer is the pinned image itself -- where array-by-array loops cost one trip each (4.9 us from HBM, 14 us from the
+        // host for the tracker's 300 observations).
         double* d = dyn;
         double* pose0 = d; d += (size_t)nc * 8;
         double* pose1 = d; d += (size_t)nc * 8;
         double* camK = d; d += (size_t)nc * 4;
         double* pt = d; d += (size_t)np * 4;
-        double* errL = d; d += (size_t)nL * 2;
-        double* U = d; d += (size_t)nfc * 36;
-        double* bc = d; d += (size_t)nfc * 6;
-        double* xc = d; d += (size_t)nfc * 6;
         float2* L_uv = reinterpret_cast<float2*>(d);
         float* L_info = reinterpret_cast<float*>(L_uv + nL);
         uint32_t* L_cam = reinterpret_cast<uint32_t*>(L_info + nL);
@@ -2035,18 +2079,29 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
         int* camE_ptr = camE + nL;
         int* hc2cam = camE_ptr + nfc + 1;
         uint8_t* L_active = reinterpret_cast<uint8_t*>(hc2cam + nfc);
-        for (int i = tid; i < nc * 8; i += 256) { pose0[i] = vin.pose_cur[i]; pose1[i] = vin.pose_trial[i]; }
-        for (int i = tid; i < nc * 4; i += 256) camK[i] = vin.camK[i];
-        for (int i = tid; i < np * 4; i += 256) pt[i] = vin.pt_cur[i];
-        for (int i = tid; i < nL; i += 256) {
-            L_uv[i] = vin.L_uv[i]; L_info[i] = vin.L_info[i]; L_cam[i] = vin.L_cam[i]; L_pt[i] = vin.L_pt[i]; camE[i] = vin.camE[i]; L_active[i] = vin.L_active[i];
+        const int image_bytes = (nc * 20 + np * 4) * 8 + nL * 25 + (2 * nfc + 1) * 4;
+        const int n16 = (image_bytes + 15) / 16;
+        d = dyn + (size_t)n16 * 2;
+        double* errL = d; d += (size_t)nL * 2;
+        double* U = d; d += (size_t)nfc * 36;
+        double* bc = d; d += (size_t)nfc * 6;
+        double* xc = d; d += (size_t)nfc * 6;
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(vin.pose_cur);
+            uint4* dst = reinterpret_cast<uint4*>(dyn);
+            for (int base = 0; base < n16; base += 256 * 8) {
+                uint4 r[8];          // (every load is issued -- past the end the last piece again -- so that r stays in registers: predicated loads sent it to scratch)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = base + u * 256 + tid; r[u] = src[i < n16 ? i : n16 - 1]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = base + u * 256 + tid; if (i < n16) dst[i] = r[u]; }
+            }
         }
-        for (int i = tid; i < nfc; i += 256) hc2cam[i] = vin.hc2cam[i];
-        for (int i = tid; i <= nfc; i += 256) camE_ptr[i] = vin.camE_ptr[i];
         v.pose_cur = pose0; v.pose_trial = pose1; v.camK = camK; v.pt_cur = v.pt_trial = pt; v.errL = errL; v.U = U; v.bc = bc; v.xc = xc;
         v.L_uv = L_uv; v.L_info = L_info; v.L_cam = L_cam; v.L_pt = L_pt; v.camE = camE; v.camE_ptr = camE_ptr; v.hc2cam = hc2cam; v.L_active = L_active;
         __syncthreads();
     }
+    PLC(1);
     double lambda = a.lambda, ni = a.ni;
     int iteration = a.iteration, n_stats = 0, flips = 0, cont = 1;
     BaDeviceView w = v;                                 // w.pose_cur / w.pose_trial swap on every accepted trial
@@ -2077,6 +2132,7 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
         // function on the same pose gives the same bits, accepted trial or not -- so one of the three passes over the observations per
         // iteration is saved; the residuals the post-pass reads are those of the LAST error evaluation either way, BundlerLib.cpp:386-425)
         const double chi_cur0 = (it > 0 && a.huber[it] == a.huber[it - 1]) ? carried_chi : chi2_of(w.pose_cur, delta);
+        PLC(2);
         for (int hc = 0; hc < v.n_fc; ++hc) {
             const int cam = v.hc2cam[hc];
             PoseD P = load_pose(w.pose_cur, cam);
@@ -2108,33 +2164,32 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
                     for (int c = 0; c <= p; ++c) A[k++] += Jc[p] * wgt * Jc[c] + Jc[6 + p] * wgt * Jc[6 + c];
                 }
             }
+            PLC(3);
+            {   // the 27 sums of the block: one packed butterfly per wavefront, the wavefronts' partials added in wavefront order by 27 threads
+                double s27[27];
 #pragma unroll
-            for (int k = 0; k < 21; ++k) A[k] = wave_sum(A[k]);
+                for (int k = 0; k < 21; ++k) s27[k] = A[k];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) b[k] = wave_sum(b[k]);
-            __syncthreads();
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < 21; ++k) part[wave][k] = A[k];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) part[wave][21 + k] = b[k];
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int k = 0;
-#pragma unroll
-                for (int p = 0; p < 6; ++p)
-#pragma unroll
-                    for (int c = 0; c <= p; ++c) {
-                        const double val = ((part[0][k] + part[1][k]) + part[2][k]) + part[3][k];
-                        v.U[(size_t)hc * 36 + p * 6 + c] = val; v.U[(size_t)hc * 36 + c * 6 + p] = val; ++k;
-                    }
-#pragma unroll
-                for (int p = 0; p < 6; ++p) v.bc[(size_t)hc * 6 + p] = ((part[0][21 + p] + part[1][21 + p]) + part[2][21 + p]) + part[3][21 + p];
+                for (int k = 0; k < 6; ++k) s27[21 + k] = b[k];
+                const double tot = wave_sum_packed<27>(s27, lane);
+                const int slot = wave_sum_slot(lane);
+                __syncthreads();
+                if ((lane & 1) == 0 && slot < 27) part[wave][slot] = tot;
+                __syncthreads();
+                if (tid < 27) {
+                    const double val = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+                    if (tid < 21) {
+                        int p = 0;
+                        while ((p + 1) * (p + 2) / 2 <= tid) ++p;          // tid = p (p + 1) / 2 + c
+                        const int c = tid - p * (p + 1) / 2;
+                        v.U[(size_t)hc * 36 + p * 6 + c] = val; v.U[(size_t)hc * 36 + c * 6 + p] = val;
+                    } else v.bc[(size_t)hc * 6 + (tid - 21)] = val;
+                }
             }
         }
         __threadfence_block();
         __syncthreads();
+        PLC(4);
         if (tid == 0) {
             if (iteration == 0) {
                 double m = 0;
@@ -2164,7 +2219,9 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
             const double scale = block_sum<4>(sc, sm);
             __threadfence_block();
             __syncthreads();
+            PLC(5);
             const double chi_trial = chi2_of(w.pose_trial, delta);
+            PLC(6);
             if (tid == 0) {
                 const bool ok2 = s_ok != 0;
                 double temp = chi_trial, r;
@@ -2190,6 +2247,7 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
             if (s_accept) { double* t = w.pose_cur; w.pose_cur = w.pose_trial; w.pose_trial = t; ++flips; }
             ++qmax;
             __syncthreads();
+            PLC(7);
         } while (rho < 0 && qmax < 10);
         const int code = (qmax == 10 || rho == 0) ? 1 : 0;
         if (tid == 0 && n_stats < POSE_LM_MAX_ITERS) {
@@ -2202,6 +2260,7 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
         carried_chi = cur_chi;
     }
     // ---- post-pass: classification with the residuals of the LAST error evaluation and the kept estimate (k_classify)
+    PLC(8);
     double es = 0, ec = 0, no = 0;
     for (int i = tid; i < v.n_L; i += 256) {
         if (!v.L_active[i]) { flagL[i] = 0; continue; }
@@ -2226,10 +2285,16 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
         out->lambda = lambda; out->ni = ni; out->iteration = iteration; out->n_stats = n_stats; out->flips = flips;
         out->err_sum = r0; out->err_cnt = r1; out->n_out = r2;
     }
-    if (STAGED) {        // the two pose buffers go back where they came from (the host picks the current one by `flips`)
+    // the two pose buffers leave for out_pose (the host picks the current one by `flips`); without one they are the caller's own arrays,
+    // already in place (the staged form always has one: its inputs are read-only)
+    if (out_pose) {
         __syncthreads();
-        for (int i = tid; i < vin.n_cams * 8; i += 256) { vin.pose_cur[i] = v.pose_cur[i]; vin.pose_trial[i] = v.pose_trial[i]; }
+        for (int i = tid; i < vin.n_cams * 8; i += 256) { out_pose[i] = v.pose_cur[i]; out_pose[vin.n_cams * 8 + i] = v.pose_trial[i]; }
     }
+    PLC(9);
+#ifdef POSE_LM_CLOCKS
+    if (tid == 0) for (int i = 1; i < plc_n; ++i) printf("PLC %d %lld\n", plc_tag[i], plc_t[i] - plc_t[i - 1]);
+#endif
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -2523,19 +2588,19 @@ bool ba_pose_lm_applies(const BaDeviceView& v, size_t n_huber)
     static const bool off = std::getenv("MAGE_BA_NO_SMALL_PATH") != nullptr;
     return !off && !v.points_free && v.n_T == 0 && v.n_fc >= 1 && v.n_fc <= 64 && v.n_L <= 16384 && n_huber >= 1 && n_huber <= (size_t)POSE_LM_MAX_ITERS;
 }
-void ba_launch_pose_lm(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out, uint8_t* flagL, hipStream_t st)
+void ba_launch_pose_lm(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out, uint8_t* flagL, double* out_pose, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_pose_lm<false>, dim3(1), dim3(256), 0, st, v, a, out, flagL);
+    hipLaunchKernelGGL(k_pose_lm<false>, dim3(1), dim3(256), 0, st, v, a, out, flagL, out_pose);
 }
 bool ba_pose_lm_staged_fits(const BaDeviceView& v)
 {
     return pose_lm_staged_bytes(v.n_cams, v.n_pts, v.n_L, v.n_fc) <= (size_t)POSE_LM_STAGED_MAX_BYTES;
 }
-bool ba_launch_pose_lm_staged(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out, uint8_t* flagL, hipStream_t st)
+bool ba_launch_pose_lm_staged(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out, uint8_t* flagL, double* out_pose, hipStream_t st)
 {
     const size_t lds = pose_lm_staged_bytes(v.n_cams, v.n_pts, v.n_L, v.n_fc);
-    if (lds > (size_t)POSE_LM_STAGED_MAX_BYTES) return false;
-    hipLaunchKernelGGL(k_pose_lm<true>, dim3(1), dim3(256), lds, st, v, a, out, flagL);
+    if (lds > (size_t)POSE_LM_STAGED_MAX_BYTES || !out_pose) return false;
+    hipLaunchKernelGGL(k_pose_lm<true>, dim3(1), dim3(256), lds, st, v, a, out, flagL, out_pose);
     return true;
 }
 
