@@ -385,33 +385,29 @@ __global__ __launch_bounds__(256) void k_linearize_cam(BaDeviceView v, double de
             for (int c = 0; c <= a; ++c) A[k++] += Jc[a] * w * Jc[c] + Jc[6 + a] * w * Jc[6 + c];
         }
     }
+    // the 27 sums of the block in one packed butterfly (wave_sum_packed: 29 shuffles instead of 162, the same bits); value k's total
+    // sits in the even lanes whose wave_sum_slot is k
+    double s27[27];
 #pragma unroll
-    for (int k = 0; k < 21; ++k) A[k] = wave_sum(A[k]);
+    for (int k = 0; k < 21; ++k) s27[k] = A[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) b[k] = wave_sum(b[k]);
+    for (int k = 0; k < 6; ++k) s27[21 + k] = b[k];
+    double tot = wave_sum_packed<27>(s27, lane);
+    const int slot = wave_sum_slot(lane);
     if (SPLIT) {
         __shared__ double part[4][28];
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 21; ++k) part[wave][k] = A[k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) part[wave][21 + k] = b[k];
-        }
+        if ((lane & 1) == 0 && slot < 27) part[wave][slot] = tot;
         __syncthreads();
         if (wave != 0) return;
-#pragma unroll
-        for (int k = 0; k < 21; ++k) A[k] = ((part[0][k] + part[1][k]) + part[2][k]) + part[3][k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) b[k] = ((part[0][21 + k] + part[1][21 + k]) + part[2][21 + k]) + part[3][21 + k];
+        if (slot < 27) tot = ((part[0][slot] + part[1][slot]) + part[2][slot]) + part[3][slot];
     }
-    if (lane == 0) {
-        int k = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int c = 0; c <= a; ++c) { v.U[(size_t)hc * 36 + a * 6 + c] = A[k]; v.U[(size_t)hc * 36 + c * 6 + a] = A[k]; ++k; }
-#pragma unroll
-        for (int a = 0; a < 6; ++a) v.bc[(size_t)hc * 6 + a] = b[a];
+    if ((lane & 1) == 0 && slot < 27) {
+        if (slot < 21) {
+            int a = 0;
+            while ((a + 1) * (a + 2) / 2 <= slot) ++a;              // slot = a (a + 1) / 2 + c
+            const int c = slot - a * (a + 1) / 2;
+            v.U[(size_t)hc * 36 + a * 6 + c] = tot; v.U[(size_t)hc * 36 + c * 6 + a] = tot;
+        } else v.bc[(size_t)hc * 6 + (slot - 21)] = tot;
     }
 }
 
@@ -1586,15 +1582,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 for (int c = 0; c <= a; ++c) A[k++] += Jc[a] * w * Jc[c] + Jc[6 + a] * w * Jc[6 + c];
             }
         }
+        {   // the 27 sums of the block in one packed butterfly per wavefront (wave_sum_packed: 29 shuffles instead of 162, the same bits)
+            double s27[27];
 #pragma unroll
-        for (int k = 0; k < 21; ++k) A[k] = wave_sum(A[k]);
+            for (int k = 0; k < 21; ++k) s27[k] = A[k];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) b[k] = wave_sum(b[k]);
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 21; ++k) part[wave][k] = A[k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) part[wave][21 + k] = b[k];
+            for (int k = 0; k < 6; ++k) s27[21 + k] = b[k];
+            const double tot = wave_sum_packed<27>(s27, lane);
+            const int slot = wave_sum_slot(lane);
+            if ((lane & 1) == 0 && slot < 27) part[wave][slot] = tot;
         }
         __syncthreads();
         if (cpc > 1) {
