@@ -1752,11 +1752,10 @@ __global__ __launch_bounds__(256) void k_small_schur(BaDeviceView v, double lamb
 #pragma unroll
         for (int r = 0; r < 6; ++r) acc[r] += W[r * 3] * d0 + W[r * 3 + 1] * d1 + W[r * 3 + 2] * d2;
     }
-#pragma unroll
-    for (int r = 0; r < 6; ++r) acc[r] = wave_sum(acc[r]);
-    if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) part[wave][r] = acc[r];
+    {   // six sums, one packed butterfly (9 shuffles instead of 36, the same bits)
+        const double tot = wave_sum_packed<6>(acc, lane);
+        const int slot = wave_sum_slot(lane);
+        if ((lane & 1) == 0 && slot < 6) part[wave][slot] = tot;
     }
     __syncthreads();
     if (threadIdx.x < 6) {
