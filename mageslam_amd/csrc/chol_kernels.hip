@@ -1017,7 +1017,11 @@ __device__ __forceinline__ void update_rect(const double* __restrict__ S, int ld
     const double* Pn = S + (size_t)(k * TILE + (lane >> 4)) * ld + row0 + (lane & 15);
     const double* Pm = S + (size_t)(k * TILE + (lane >> 4)) * ld + col0 + (lane & 15);
     const double* C = S + (size_t)(col0 + (lane >> 4)) * ld + row0 + (lane & 15);
+#ifdef CHOL_RECT_KTOTAL      // TIMING PROBE ONLY (wrong results): the half-tile update over a panel of this many columns instead of 128 --
+    constexpr int NCH = CHOL_RECT_KTOTAL / (4 * KSTEPS);      // what a launch that applies two panel columns at once would cost (profiles/HISTORY.md)
+#else
     constexpr int NCH = TILE / (4 * KSTEPS);
+#endif
     // NBUF operand buffers of KSTEPS panel columns x 4: NBUF - 1 chunks are in flight while one is multiplied (the loads return in
     // order, so the wait before chunk ch leaves the later ones outstanding)
     double av[NBUF][KSTEPS][SUBM], bv[NBUF][KSTEPS][SUBN];
