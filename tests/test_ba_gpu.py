@@ -254,6 +254,44 @@ def test_pose_only_single_camera():
     _compare_with_oracle(s, True, [([4.0, 4.0, 4.0], 20.25), ([0.9] * 4, 5.0)])
 
 
+def test_pose_only_frame_path_variants_are_bit_identical(tmp_path):
+    """Round 4: the one-launch pose-only solve reads its inputs out of the pinned image and writes record, flags and poses back into it
+    (MAGE_BA_FRAME_COPIES=1: an upload and a read-back command instead), with every array staged in LDS (MAGE_BA_POSE_LM_IN_HBM=1: left
+    in HBM).  Same kernel, same order of every sum: the three give identical bits.  The general launch sequence
+    (MAGE_BA_NO_FRAME_PATH=1) adds in another order: identical integer outputs, states to rounding."""
+    import json, os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, json
+        sys.path.insert(0, %r)
+        import numpy as np
+        from mageslam_amd import scene
+        from mageslam_amd.bundler import BundlerLib, load_scene
+        res = []
+        for n_cams, n_pts, n_obs, seed in ((1, 300, 300, 31), (3, 500, 1000, 32), (2, 90, 180, 33)):
+            s = scene.make_scene(n_cams=n_cams, n_pts=n_pts, n_obs=n_obs, seed=seed, fixed=(), outlier_frac=0.05, pt_sigma=0.004, cam_sigma=0.02, rot_sigma=0.005)
+            b = BundlerLib(True); load_scene(b, s)
+            for hub, thr in (([4.0, 4.0, 4.0], 36.0), ([0.9] * 4, 20.25)):
+                o = []; mse = b.StepBundleAdjustment(hub, thr, o)
+                res.append([float(mse)] + sorted(o) + [t["trials"] for t in b.trace()])
+            res.append(b.poses_f64().ravel().tolist())
+        print("RESULT " + json.dumps(res))
+    """) % root
+    out = {}
+    for tag, env in (("direct", {}), ("copies", {"MAGE_BA_FRAME_COPIES": "1"}), ("in_hbm", {"MAGE_BA_POSE_LM_IN_HBM": "1"}), ("general", {"MAGE_BA_NO_FRAME_PATH": "1"})):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+        out[tag] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert out["copies"] == out["direct"]
+    assert out["in_hbm"] == out["direct"]
+    # integer outputs (outlier ids, trial counts) of the general path: rows 0-1, 3-4, 6-7 hold [mse, ids..., trials...]
+    for i in (0, 1, 3, 4, 6, 7):
+        assert out["general"][i][1:] == out["direct"][i][1:]
+        assert abs(out["general"][i][0] - out["direct"][i][0]) <= 1e-6 * abs(out["direct"][i][0]) + 1e-12
+    for i in (2, 5, 8):
+        np.testing.assert_allclose(out["general"][i], out["direct"][i], rtol=1e-9, atol=1e-10)
+
+
 def test_duplicate_observations_and_unobserved_entities():
     """Two observations of the same (camera, point) share one Hessian block; cameras/points without
     observations are left untouched and do not enter the system."""
