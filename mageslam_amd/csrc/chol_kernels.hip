@@ -2348,6 +2348,13 @@ void chol_small_solve(const double* S, const double* y, double* x, int n, int ld
 // Right-looking factorisation.  Step k = one k_trsm_panel launch + one k_syrk_update launch; the diagonal
 // factorisation of step k+1 is done by workgroup 0 of step k's update (tile (k+1, k+1) is the first tile of
 // the grid), which hides most of the sequential diagonal work behind the bulk of the update.
+// (Round 4 also tried LOOK-AHEAD ACROSS STREAMS in the update-bound columns: the update of column k as two launches that depend only on
+// panel k and touch disjoint tiles -- tile column k + 1 with its diagonal tile's factorisation and then its panel solve on a side stream of
+// the highest priority, the rest of the trailing matrix on the caller's stream, events between them -- so that the ~10.6 us panel-solve
+// launches would run beside the large updates.  Bit-identical, and 2.93-2.96 ms against 2.485: the large update fills every compute unit
+// with two 78 KB / 239-register workgroups and the dispatcher serves the older launch first, so the column launch (25 us alone) got its
+// slots only as the large update drained -- 118 us beside a 102 us update -- and the chain was serial again, plus the events.  Not kept;
+// profiles/HISTORY.md has the per-launch timeline.)
 void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWorkspace& ws, double* ok, hipStream_t st)
 {
     const int nt = n_pad / TILE;
