@@ -293,22 +293,21 @@ __device__ __forceinline__ void fl_column(double (&a)[NB], double (&x)[NB], doub
     __builtin_amdgcn_sched_barrier(0);
     fl_fill_range<J, 2, (NFILL < 6 ? NFILL : 6)>(a, x);
     (void)dmin;                                                  // (a non-positive pivot leaves NaNs behind: caught once, at the end)
-    double g = d * y, h = 0.5 * y;
+    // 1 / sqrt(d) from the ~2^-22 estimate in ONE third-order step -- e = 1 - d y^2, rs = y (1 + e / 2 + 3 e^2 / 8), error ~ 5/16 e^3 < 2^-60 --
+    // five dependent operations behind the estimate where two Goldschmidt steps were six, and three instructions fewer per pivot
+    const double t = d * y;
     __builtin_amdgcn_sched_barrier(0);
     fl_fill_range<J, 6, (NFILL < 7 ? NFILL : 7)>(a, x);
-    double r = __builtin_fma(-h, g, 0.5);
+    const double e = __builtin_fma(-t, y, 1.0);
     __builtin_amdgcn_sched_barrier(0);
     fl_fill_range<J, 7, (NFILL < 8 ? NFILL : 8)>(a, x);
-    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    const double p = __builtin_fma(e, 0.375, 0.5);
     __builtin_amdgcn_sched_barrier(0);
     fl_fill_range<J, 8, (NFILL < 9 ? NFILL : 9)>(a, x);
-    r = __builtin_fma(-h, g, 0.5);
+    const double q = e * p;
     __builtin_amdgcn_sched_barrier(0);
-    fl_fill_range<J, 9, (NFILL < 10 ? NFILL : 10)>(a, x);
-    h = __builtin_fma(h, r, h);
-    __builtin_amdgcn_sched_barrier(0);
-    fl_fill_range<J, 10, (NFILL < 11 ? NFILL : 11)>(a, x);
-    const double rs = h + h;                                     // 1 / sqrt(d)
+    fl_fill_range<J, 9, (NFILL < 11 ? NFILL : 11)>(a, x);
+    const double rs = __builtin_fma(y, q, y);                    // 1 / sqrt(d)
     __builtin_amdgcn_sched_barrier(0);
     fl_fill_range<J, 11, (NFILL < 12 ? NFILL : 12)>(a, x);
     a[J] = a[J] * rs;                                            // L[:, J]  (lane J: d / sqrt(d))
@@ -349,8 +348,9 @@ __device__ __forceinline__ bool factor_block16_lean(double* __restrict__ B, int 
 }
 
 // which form the tile factorisation uses: the lean one (tools/potrf_probe.hip: 3 600 against 3 950 cycles per block, the tile 43.9 k
-// against 45.3 k; tools/_bin/chol_test 6016: 2.480-2.491 against 2.495 ms, the same bits on its matrices -- the diagonal entry comes out of
-// the same fused operation either way, and where the off-diagonal term is small against it the two roundings of the pivot agree).
+// against 45.3 k; tools/_bin/chol_test 6016: 2.480-2.491 against 2.495 ms).  Late in round 4 its 1 / sqrt(d) became ONE third-order step
+// (fl_column): 3 660 -> 3 516 cycles per block, the tile 43.9 k -> 42.5 k, 2.485 -> 2.468-2.480 ms; its bits now differ from the classic block's
+// in the last place (residual 7.89e-16 against 7.90e-16, |Linv L - I| 2.2e-16 against 3.3e-16).
 // -DCHOL_FACTOR_BLOCK=factor_block16 builds the classic one.
 #ifndef CHOL_FACTOR_BLOCK
 #define CHOL_FACTOR_BLOCK factor_block16_lean
