@@ -1025,8 +1025,10 @@ constexpr int BACKSUB_LPL = 8;
 // back, in partial[chi_off + block].
 // fold_n > 0 (WITH_ERROR): the last block to finish adds the fold_n scale partials and the fold_n chi2 partials (k_pose_update's rows
 // included: written by the launch before) into scal[SC_SCALE] / scal[SC_CHI_TRIAL] -- last_block_arrives_through.
+// (7 wavefronts per SIMD: at 74 registers six fitted and the 3 125 blocks of the 1k-pose map were 2.03 rounds of 1 536; at 72 seven fit --
+//  36.0 -> 34.4 us; eight cost a spill and 35.7 us)
 template <bool WITH_ERROR>
-__global__ __launch_bounds__(256) void k_backsub(BaDeviceView v, double lambda, double delta, int chi_off, int fold_n, int* __restrict__ counter)
+__global__ __launch_bounds__(256, 7) void k_backsub(BaDeviceView v, double lambda, double delta, int chi_off, int fold_n, int* __restrict__ counter)
 {
     __shared__ double sm[4];
     const int gl = blockIdx.x * 256 + threadIdx.x, l = gl / BACKSUB_LPL, sub = gl % BACKSUB_LPL;
