@@ -190,9 +190,10 @@ __device__ __forceinline__ void jac_point(const EdgeGeom& g, double f, const dou
 __global__ __launch_bounds__(256) void k_reduce_sum(const double* __restrict__ in, int n, int stride_out,
                                                     double* __restrict__ out, int n_out)
 {
-    // in is laid out [n_out][n] ; out[o * stride_out]
+    // in is laid out [n_out][n] ; out[o * stride_out].  One block per output when the grid has several (the sums are independent; the same
+    // additions in the same order either way), all outputs in turn when it is one block.
     __shared__ double sm[4];
-    for (int o = 0; o < n_out; ++o) {
+    for (int o = (int)blockIdx.x; o < n_out; o += (int)gridDim.x) {
         double acc = 0;
         for (int i = threadIdx.x; i < n; i += 256) acc += in[(size_t)o * n + i];
         double r = block_sum<4>(acc, sm);
@@ -2417,7 +2418,7 @@ void ba_launch_update_and_trial_error(const BaDeviceView& v, double lambda, doub
     hipLaunchKernelGGL(k_backsub<true>, dim3(nb_l), dim3(256), 0, st, v, lambda, delta, n, fold ? n : 0, counter);
     // partial = [scale: n][chi2: n] -> scal[SC_SCALE], scal[SC_SCALE + 6] = scal[SC_CHI_TRIAL]: by the last block of k_backsub, or
     static_assert(SC_CHI_TRIAL - SC_SCALE == 6, "the two outputs of the fused reduction");
-    if (!fold) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, n, SC_CHI_TRIAL - SC_SCALE, v.scal + SC_SCALE, 2);
+    if (!fold) hipLaunchKernelGGL(k_reduce_sum, dim3(2), dim3(256), 0, st, v.partial, n, SC_CHI_TRIAL - SC_SCALE, v.scal + SC_SCALE, 2);
     tether_launch_error(v, true, st);
 }
 
@@ -2616,7 +2617,7 @@ void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_
     int nb = v.n_L > 0 ? (cdiv(v.n_L, 256) < RED_BLOCKS ? cdiv(v.n_L, 256) : RED_BLOCKS) : 1;
     if (!ba_reductions_fold()) fold_counter = nullptr;
     hipLaunchKernelGGL(k_classify<false>, dim3(nb), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, nb, ClassifyAfterTrial{}, fold_counter);
-    if (!fold_counter) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
+    if (!fold_counter) hipLaunchKernelGGL(k_reduce_sum, dim3(3), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
 }
 void ba_launch_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* fold_counter,
                                     hipStream_t st)
@@ -2625,7 +2626,7 @@ void ba_launch_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTr
     if (!ba_reductions_fold()) fold_counter = nullptr;
     hipLaunchKernelGGL(k_classify<true>, dim3(nb), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, nb, c, fold_counter);
     // (when the kernel found the call unfinished the three sums are stale: nobody reads them then)
-    if (!fold_counter) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
+    if (!fold_counter) hipLaunchKernelGGL(k_reduce_sum, dim3(3), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
 }
 
 }  // namespace mage
