@@ -1168,10 +1168,11 @@ mage_status initialize_optimization(mage_ba* h)
 // The LM control flow needs three scalars on the host per trial; the GPU idles while they travel.  A blocking
 // hipStreamSynchronize parks the thread and costs 20-30 us of wake-up latency per read, so the host polls the event instead
 // (the step is a few milliseconds: spinning that long is the cheaper side of the trade).
-mage_status read_scalars(mage_ba* h, size_t outlier_prefix = 0)
+// published: the last launch wrote the mirror itself (k_small_classify<true>, ba_kernels.h): nothing to copy, only its end to wait for
+mage_status read_scalars(mage_ba* h, size_t outlier_prefix = 0, bool published = false)
 {
     const size_t bytes = outlier_prefix ? (SC_PAD + h->res_doubles) * sizeof(double) + outlier_prefix * sizeof(uint32_t) : SC_COUNT * sizeof(double);
-    MAGE_HIP(hipMemcpyAsync(h->h_scal, h->d_scal.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (!published) MAGE_HIP(hipMemcpyAsync(h->h_scal, h->d_scal.p, bytes, hipMemcpyDeviceToHost, h->stream));
     MAGE_HIP(hipEventRecord(h->ev[3], h->stream));
     for (;;) {
         const hipError_t e = hipEventQuery(h->ev[3]);
@@ -1267,6 +1268,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
     bool again = false;
     do {
         again = false;
+        bool published = false;
         const double lambda = seed_on_device ? -1.0 : h->lambda;
         if (h->profiling) MAGE_HIP(hipEventRecord(h->ev[0], st));
         if (small) {
@@ -1275,7 +1277,13 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
             if (plan) {      // the outlier pass rides behind the trial (see the large-problem branch)
                 ClassifyAfterTrial c{};
                 c.chi_ref = currentChi; c.chi_on_device = have_chi ? 0 : 1; c.trials_done = qmax + 1; c.last_iteration = plan->last_iteration ? 1 : 0;
-                ba_small_classify_after_trial(v, c, plan->max_err_sq, h->d_out_ids, counter + 1, h->out_cursor, counter, h->res_doubles ? h->d_scal.p + SC_PAD : nullptr, st);
+                // (the launch writes the pinned mirror itself -- MAGE_BA_NO_PUBLISH=1: a read-back copy behind it, for A/B)
+                static const bool no_publish = std::getenv("MAGE_BA_NO_PUBLISH") != nullptr;
+                double* mirror = nullptr;
+                if (!no_publish) { void* dp = nullptr; MAGE_HIP(hipHostGetDevicePointer(&dp, h->h_scal, 0)); mirror = static_cast<double*>(dp); }
+                ba_small_classify_after_trial(v, c, plan->max_err_sq, h->d_out_ids, counter + 1, h->out_cursor, counter, h->res_doubles ? h->d_scal.p + SC_PAD : nullptr,
+                                              mirror, (int)SC_COUNT, (int)(SC_PAD + h->res_doubles), (int)plan->prefix, st);
+                published = mirror != nullptr;
                 speculated = true;
             }
         } else {
@@ -1314,7 +1322,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
                 MAGE_TRY(all_reduce(v.scal + SC_CHI_TRIAL, 2, 0));
             }
         }
-        MAGE_TRY(read_scalars(h, speculated ? plan->prefix : 0));
+        MAGE_TRY(read_scalars(h, speculated ? plan->prefix : 0, published));
         if (h->profiling) {
             float ms = 0;
             if (!lin_timed) {

@@ -143,7 +143,10 @@ int ba_fused_linearize(const BaDeviceView& v, double huber_delta, int* counter, 
 void ba_small_linearize(const BaDeviceView& v, double huber_delta, bool want_maxdiag, int* counter, hipStream_t st);   // U,bc,V,bp,W, S/y zeroed, scal[SC_CHI] (+ SC_MAXDIAG)
 void ba_small_solve_trial(const BaDeviceView& v, double lambda, double huber_delta, double* linv_ws, int* counter, hipStream_t st);    // S, y, xc, trial state, SC_SCALE, SC_CHI_TRIAL, SC_CHOL_OK/STALL
 void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, double* result, hipStream_t st);   // result: the kept estimate (poses x 8, points x 4) or nullptr
-void ba_small_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, double* result, hipStream_t st);
+// mirror (may be null): the device address of the host's pinned mirror of v.scal -- the launch writes the first mirror_doubles doubles of the
+// run that starts at v.scal there itself (mirror_scalars when the call turns out not to be over): no read-back copy is queued
+void ba_small_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, double* result,
+                                   double* mirror, int mirror_scalars, int mirror_doubles, int ids_prefix, hipStream_t st);      // (+ up to ids_prefix outlier ids behind the mirror_doubles)
 
 // Pose-only problems (points fixed): the whole StepBundleAdjustment call in ONE launch (ba_kernels.hip, "POSE-ONLY problems").
 constexpr int POSE_LM_MAX_ITERS = 16;

@@ -1924,9 +1924,20 @@ __global__ __launch_bounds__(256) void k_small_update_error(BaDeviceView v, doub
 // that it rides their read-back and the caller's GetPose / GetPoint loop needs no trip to the device of its own (round 4: the
 // reference reads every pose and point back after every bundler, BundleAdjust.cpp:318-347; that trip was 20 of a 2 000-observation
 // bundler's 167 us)
+// PUBLISH (round 4, the queued post-pass): what the host reads after the call -- the scalars, the kept estimate behind them, the first
+// outlier ids behind that: one contiguous run starting at v.scal -- is written into the pinned mirror by the launch itself, so no copy
+// command (a blit launch and a dependency, ~5 us of a 150 us local-BA call) is queued behind it.  Loads that skip this unit's cache: the
+// scalars were read when the launch began and rewritten since, result and ids come from every workgroup.
+__device__ __forceinline__ void publish_run(const double* __restrict__ src, double* __restrict__ mirror, int n_doubles)
+{
+    const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(mirror);
+    for (int i = threadIdx.x; i < n_doubles; i += 256) d[i] = __hip_atomic_load(s + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <bool AFTER_TRIAL>
 __global__ __launch_bounds__(256) void k_small_classify(BaDeviceView v, double max_err_sq, uint32_t* __restrict__ out_ids, int* __restrict__ out_count,
-                                                        int out_base, int* __restrict__ counter, ClassifyAfterTrial spec, double* __restrict__ result)
+                                                        int out_base, int* __restrict__ counter, ClassifyAfterTrial spec, double* __restrict__ result,
+                                                        double* __restrict__ mirror, int mirror_scalars, int mirror_doubles, int ids_prefix)
 {
     __shared__ double sm[4];
     const double* pose_kept = v.pose_cur;
@@ -1935,7 +1946,14 @@ __global__ __launch_bounds__(256) void k_small_classify(BaDeviceView v, double m
         bool accept;
         const bool fin = call_is_over(v, spec, accept);
         if (blockIdx.x == 0 && threadIdx.x == 0) v.scal[SC_SPEC_DONE] = fin ? 1.0 : 0.0;
-        if (!fin) return;                                   // every workgroup alike: the arrival counter stays untouched
+        if (!fin) {                                         // every workgroup alike: the arrival counter stays untouched
+            if (mirror && blockIdx.x == 0) {               // the host still reads the trial's scalars
+                __threadfence();
+                __syncthreads();
+                publish_run(v.scal, mirror, mirror_scalars);
+            }
+            return;
+        }
         if (accept) { pose_kept = v.pose_trial; pt_kept = v.pt_trial; }
     }
     if (result) {
@@ -1967,6 +1985,12 @@ __global__ __launch_bounds__(256) void k_small_classify(BaDeviceView v, double m
     fold_partials(v.partial, nb, v.scal + SC_ERRSUM, sm);
     fold_partials(v.partial + nb, nb, v.scal + SC_ERRCNT, sm);
     fold_partials(v.partial + 2 * nb, nb, v.scal + SC_NOUT, sm);
+    if (mirror) {      // scalars + kept estimate, and as many of the ids behind them as there are (up to the prefix the host reads)
+        __threadfence();
+        __syncthreads();
+        const int n_ids = min(max(__hip_atomic_load(out_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - out_base, 0), ids_prefix);
+        publish_run(v.scal, mirror, mirror_doubles + (n_ids + 1) / 2);
+    }
 }
 
 // =================================================================================================
@@ -2569,12 +2593,14 @@ void ba_small_solve_trial(const BaDeviceView& v, double lambda, double delta, do
 }
 void ba_small_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, double* result, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_small_classify<false>, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, counter, ClassifyAfterTrial{}, result);
+    hipLaunchKernelGGL(k_small_classify<false>, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, counter, ClassifyAfterTrial{}, result,
+                       (double*)nullptr, 0, 0, 0);
 }
 void ba_small_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* counter, double* result,
-                                   hipStream_t st)
+                                   double* mirror, int mirror_scalars, int mirror_doubles, int ids_prefix, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_small_classify<true>, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, counter, c, result);
+    hipLaunchKernelGGL(k_small_classify<true>, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, counter, c, result,
+                       mirror, mirror_scalars, mirror_doubles, ids_prefix);
 }
 void ba_small_init_device()
 {
