@@ -254,6 +254,36 @@ def test_pose_only_single_camera():
     _compare_with_oracle(s, True, [([4.0, 4.0, 4.0], 20.25), ([0.9] * 4, 5.0)])
 
 
+def test_small_path_publish_is_bit_identical():
+    """Round 4: the small path's queued outlier pass writes the pinned mirror itself -- scalars, the kept estimate, the outlier ids --
+    instead of being followed by a read-back copy (MAGE_BA_NO_PUBLISH=1).  What the host reads is the same either way."""
+    import json, os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, json
+        sys.path.insert(0, %r)
+        import numpy as np
+        from mageslam_amd import scene
+        from mageslam_amd.bundler import BundlerLib, load_scene
+        res = []
+        for n_cams, n_pts, n_obs, seed, fixed in ((12, 400, 2000, 0x5EED0012, (0, 1, 2, 3)), (6, 90, 360, 7, (0,)), (20, 800, 8000, 9, (0, 1))):
+            s = scene.make_scene(n_cams=n_cams, n_pts=n_pts, n_obs=n_obs, seed=seed, fixed=fixed, outlier_frac=0.03)
+            b = BundlerLib(False); load_scene(b, s)
+            for hub, thr in (([1.8], 7.25), ([0.9, 0.9], 16.0), ([0.9], 9.0)):
+                o = []; mse = b.StepBundleAdjustment(hub, thr, o)
+                res.append([float(mse)] + sorted(o) + [t["trials"] for t in b.trace()])
+            res.append(b.poses_f64().ravel().tolist() + b.points_f64().ravel().tolist())
+            res.append([list(map(float, b.GetPose(i)[0])) for i in range(n_cams)])
+        print("RESULT " + json.dumps(res))
+    """) % root
+    out = {}
+    for tag, env in (("publish", {}), ("copy", {"MAGE_BA_NO_PUBLISH": "1"})):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+        out[tag] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert out["publish"] == out["copy"]
+
+
 def test_pose_only_frame_path_variants_are_bit_identical(tmp_path):
     """Round 4: the one-launch pose-only solve reads its inputs out of the pinned image and writes record, flags and poses back into it
     (MAGE_BA_FRAME_COPIES=1: an upload and a read-back command instead), with every array staged in LDS (MAGE_BA_POSE_LM_IN_HBM=1: left
