@@ -1280,7 +1280,11 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
                 // (the launch writes the pinned mirror itself -- MAGE_BA_NO_PUBLISH=1: a read-back copy behind it, for A/B)
                 static const bool no_publish = std::getenv("MAGE_BA_NO_PUBLISH") != nullptr;
                 double* mirror = nullptr;
-                if (!no_publish) { void* dp = nullptr; MAGE_HIP(hipHostGetDevicePointer(&dp, h->h_scal, 0)); mirror = static_cast<double*>(dp); }
+                if (!no_publish) {
+                    void* dp = nullptr;
+                    if (hipHostGetDevicePointer(&dp, h->h_scal, 0) == hipSuccess) mirror = static_cast<double*>(dp);
+                    else (void)hipGetLastError();                 // a mirror this device cannot address: the read-back copy as before
+                }
                 ba_small_classify_after_trial(v, c, plan->max_err_sq, h->d_out_ids, counter + 1, h->out_cursor, counter, h->res_doubles ? h->d_scal.p + SC_PAD : nullptr,
                                               mirror, (int)SC_COUNT, (int)(SC_PAD + h->res_doubles), (int)plan->prefix, st);
                 published = mirror != nullptr;
@@ -1549,11 +1553,11 @@ mage_status frame_step(mage_ba* h, const float* huber, size_t n_iter, float max_
     // (a blit launch and a dependency each, ~10 us of a 65 us call) are not queued at all.  MAGE_BA_FRAME_COPIES=1: upload + read-back.
     static const bool frame_copies = std::getenv("MAGE_BA_FRAME_COPIES") != nullptr;
     static const bool staged_off = std::getenv("MAGE_BA_POSE_LM_IN_HBM") != nullptr;      // A/B: the arrays left in HBM
-    const bool direct = !frame_copies && !staged_off && ba_pose_lm_staged_fits(v);
+    bool direct = !frame_copies && !staged_off && ba_pose_lm_staged_fits(v);
     if (direct) {
         void* dev_img = nullptr;
-        MAGE_HIP(hipHostGetDevicePointer(&dev_img, img, 0));
-        D = static_cast<unsigned char*>(dev_img);
+        if (hipHostGetDevicePointer(&dev_img, img, 0) == hipSuccess && dev_img) D = static_cast<unsigned char*>(dev_img);
+        else { (void)hipGetLastError(); direct = false; }      // pinned memory this device cannot address: upload + read-back as before
     }
     v.camK = reinterpret_cast<const double*>(D + o_K); v.pt_cur = v.pt_trial = reinterpret_cast<double*>(D + o_pt);
     v.hc2cam = reinterpret_cast<const int*>(D + o_hc); v.camE_ptr = reinterpret_cast<const int*>(D + o_cep); v.camE = reinterpret_cast<const int*>(D + o_ce);
