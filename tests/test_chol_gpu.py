@@ -76,11 +76,13 @@ def test_solution_matches_rocsolver_via_torch(tmp_path):
     assert np.linalg.norm(x - ref) <= 1e-11 * np.linalg.norm(ref)
 
 
-def test_chain_variants_are_bit_identical(tmp_path):
-    """The panel solve of the chain-bound columns in its forms -- phased against the in-tile factorisation (default, round 4), one wait
-    for the whole tile (MAGE_CHOL_PHASED_TRSM=0), release / acquire hand-offs (MAGE_CHOL_WT_HANDOFF=0), strips by four wavefronts
-    (MAGE_CHOL_STRIP_4W=1), a launch of its own per panel (MAGE_CHOL_NO_MERGED_TRSM=1): the same operations in the same order per block
-    column, so the solution is the same to the bit.  (The switches are read once per process: children.)"""
+def test_schedules_are_bit_identical(tmp_path):
+    """The same factorisation under its schedules -- ONE persistent launch over the task list (default from 8 tile columns on; forced
+    from 2 with MAGE_CHOL_DAG_MIN_TILES), with panels fused per task (MAGE_CHOL_DAG_FUSE=8, default) or one panel per task, column by
+    column with the panel solve merged into the update launch (MAGE_CHOL_COLUMN_LAUNCHES=1) or as launches of its own
+    (+ MAGE_CHOL_NO_MERGED_TRSM=1, what a process falls back to after a stalled hand-off): every element accumulates its panel columns
+    in the same order into an accumulator that starts as the element, so the solution is the same to the bit.  (The switches are read
+    once per process: children.)"""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent("""
@@ -89,7 +91,7 @@ def test_chain_variants_are_bit_identical(tmp_path):
         import numpy as np
         import test_chol_gpu as T
         out = []
-        for n in (700, 2999, 4500):      # 6, 24, 36 tile columns: merged columns only / the half-tile kernel's crossover / well into it
+        for n in (300, 700, 2999, 4500):      # 3, 6, 24, 36 tile columns
             A, b = T.spd(n, 900 + n)
             x, ok = T.dense_solve(A, b)
             assert ok == 1
@@ -97,11 +99,11 @@ def test_chain_variants_are_bit_identical(tmp_path):
         np.save(sys.argv[1], np.concatenate(out))
     """) % (root, os.path.join(root, "tests"))
     res = {}
-    for tag, env in (("phased", {}), ("single_wait", {"MAGE_CHOL_PHASED_TRSM": "0"}), ("release_acquire", {"MAGE_CHOL_WT_HANDOFF": "0"}),
-                     ("four_wavefronts", {"MAGE_CHOL_PHASED_TRSM": "0", "MAGE_CHOL_STRIP_4W": "1"}), ("separate_panels", {"MAGE_CHOL_NO_MERGED_TRSM": "1"})):
+    for tag, env in (("task_graph", {}), ("task_graph_every_size", {"MAGE_CHOL_DAG_MIN_TILES": "2"}), ("task_graph_one_panel_per_task", {"MAGE_CHOL_DAG_MIN_TILES": "2", "MAGE_CHOL_DAG_FUSE": "1"}),
+                     ("columns_merged", {"MAGE_CHOL_COLUMN_LAUNCHES": "1"}), ("columns_separate_panels", {"MAGE_CHOL_COLUMN_LAUNCHES": "1", "MAGE_CHOL_NO_MERGED_TRSM": "1"})):
         f = str(tmp_path / (tag + ".npy"))
         p = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
         res[tag] = np.load(f)
     for tag, x in res.items():
-        assert np.array_equal(x, res["phased"]), tag
+        assert np.array_equal(x, res["task_graph"]), tag

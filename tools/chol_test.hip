@@ -7,6 +7,7 @@
 #include <vector>
 #include "../mageslam_amd/csrc/chol_kernels.h"
 using namespace mage;
+extern "C" int mage_debug_chol_schedule(int nt, int n_cu, int fuse_max, unsigned long long* out, int cap, int* quarter_from);
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
 int main(int argc, char** argv)
@@ -33,8 +34,18 @@ int main(int argc, char** argv)
         hipStream_t st; CK(hipStreamCreate(&st));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         int* dq; CK(hipMalloc(&dq, sizeof(int) * chol_sync_ints(n)));
+#ifdef DAG_TRACE
+        // trace build: per task four stamps + two per tile column, written by the task-graph launch (dumped below)
+        std::vector<unsigned long long> tasks(600000);
+        int qf = 0;
+        const int n_tasks = mage_debug_chol_schedule(n / 128, 256, getenv("MAGE_CHOL_DAG_FUSE") ? atoi(getenv("MAGE_CHOL_DAG_FUSE")) : 8, tasks.data(), (int)tasks.size(), &qf);
+        const size_t n_stamps = 4 * (size_t)(n_tasks > 0 ? n_tasks : 0) + 2 * (n / 128) + 16;
+        long long* ddbg; CK(hipMalloc(&ddbg, sizeof(long long) * n_stamps));
+        CholWorkspace ws{ dws, dq, ddbg };
+#else
         long long* ddbg; CK(hipMalloc(&ddbg, sizeof(long long) * 4 * (n / 128 + 1)));
         CholWorkspace ws{ dws, dq, getenv("CHOL_DBG") ? ddbg : nullptr };
+#endif
         float best = 1e30f;
         for (int r = 0; r < reps; ++r) {
             CK(hipMemcpyAsync(dS, dS0, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
@@ -46,6 +57,27 @@ int main(int argc, char** argv)
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (ms < best) best = ms;
         }
+#ifdef DAG_TRACE
+        if (n_tasks > 0) {
+            CK(hipMemset(ddbg, 0, sizeof(long long) * n_stamps));
+            CK(hipMemcpyAsync(dS, dS0, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
+            CK(hipMemcpyAsync(dy, dy0, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+            chol_factor_solve(dS, dy, dx, n, ws, dok, st);
+            CK(hipStreamSynchronize(st));
+            std::vector<long long> stamps(n_stamps);
+            CK(hipMemcpy(stamps.data(), ddbg, sizeof(long long) * n_stamps, hipMemcpyDeviceToHost));
+            char name[256];
+            snprintf(name, sizeof(name), "gpurun_out/dag_trace_%d.bin", n);
+            if (FILE* f = fopen(name, "wb")) {
+                long long hdr[4] = { n_tasks, n / 128, qf, (long long)n_stamps };
+                fwrite(hdr, sizeof(long long), 4, f);
+                fwrite(tasks.data(), sizeof(unsigned long long), n_tasks, f);
+                fwrite(stamps.data(), sizeof(long long), n_stamps, f);
+                fclose(f);
+                printf("  trace -> %s (%d tasks)\n", name, n_tasks);
+            }
+        }
+#endif
         double ok;
         CK(hipMemcpy(x.data(), dx, sizeof(double) * n, hipMemcpyDeviceToHost));
         CK(hipMemcpy(&ok, dok, 8, hipMemcpyDeviceToHost));
