@@ -10,10 +10,11 @@
 //   worker teams      every other workgroup = two teams of four wavefronts (512 threads, one workgroup per compute unit, <= 256
 //                     registers: two wavefronts per SIMD, the shape in which the trailing update runs best).  A team's leader takes
 //                     the next task of the list (one returning atomic), polls the task's dependency words, and the team runs it:
-//       STRIP(i,k,s)    one 16-row strip of the panel solve L_ik = S_ik L_kk^-T by the four wavefronts (each owns two 16-column
-//                       blocks, Y_j handed round through LDS), then y_i[rows] -= L_ik[rows] y_k -- the forward substitution rides
-//                       on the strips, in the order the column-by-column launches apply it;
-//       YSOLVE(k)       y_k = L_kk^-1 y_k, the same strip code on the rhs row;
+//       STRIPS(i,k,part)  the panel solve L_ik = S_ik L_kk^-T of a whole tile (or half of it, for the rows next to the chain): the team parks
+//                       L_kk's sub-diagonal blocks and block inverses in LDS ONCE (operand layout, 72 KB) and every wavefront then runs
+//                       the one-wavefront strip of chol_device.h on its 16-row strips with operands from LDS -- no hand-off inside;
+//       RHS(i,k0,nk)    y_i -= L_ik y_k for nk panels, YSOLVE(k)  y_k = L_kk^-1 y_k: the forward substitution as its own chain of small
+//                       tasks, in the order the column-by-column launches apply it;
 //       UPDATE(i,j,u,k0,nk)  block u of tile (i,j) -= L_i,k L_j,k^T for the nk panels k0 .. k0+nk-1 IN ONE TASK: the block is read and
 //                       written once however many panels it absorbs (a right-looking launch moves C once per panel: 15x the
 //                       compulsory traffic, r04_chol_pmc.txt), and the operand ring runs on across panels.  Half tiles (two units
@@ -21,7 +22,11 @@
 //       DIAG(j,p)       the LAST panel (j-1) of diagonal tile j, split over nine teams (36 blocks of 16 x 16, one per wavefront) because
 //                       it sits on the chain; the ninth arrival releases the chain workgroup.
 //
-// The list is the start order of a list-scheduling simulation of that graph (build_schedule below: measured task costs, earliest
+// Teams are in eight GROUPS (workgroup index mod 8 = the XCD it runs on, for speed only) with a task list each: the update tasks of a
+// 4 x 2 block of tiles belong to one group, so that the tasks an XCD runs side by side share their panel operands in its L2 (with one
+// list for all, every task's operands came from beyond the L2: 18 half-panels / us machine-wide against the launches' 24,
+// profiles/r05_dag_trace_v1_6016.txt).
+// The lists are the start order of a list-scheduling simulation of that graph (build_schedule below: measured task costs, earliest
 // column first, a unit takes every panel that is available when its turn comes -- far tiles accumulate panels while near ones are
 // served, which is where the large-K tasks come from).  Every dependency of a task sits earlier in the list or is a chain task
 // whose own dependencies do (check_schedule proves it per list): teams that take tasks in list order therefore cannot deadlock,
@@ -43,6 +48,7 @@
 #include <mutex>
 #include <queue>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 #include "chol_dag.h"
 #include "chol_device.h"
@@ -53,20 +59,24 @@ using namespace chol;
 namespace {
 
 // ---- state words (ints, zeroed before every launch), relative to CholWorkspace::sync + 8
-constexpr int D_HEAD = 0;       // cursor of the task list
 constexpr int D_FACT = 1;       // tile columns whose diagonal tile is factored and in memory
 constexpr int D_YSOL = 2;       // rhs rows solved
 constexpr int D_ABORT = 3;      // a bounded wait ran out somewhere: everybody leaves
-constexpr int D_PROG = 4;       // phased hand-off: 8 tile + block columns of the tile being factored that are published
-constexpr int D_DARR = 16;      // nt ints: arrivals of the split last panel at diagonal tile j
+constexpr int D_PROG = 4;       // phased hand-off: 8 tile + block columns of the tile being factored that are in memory
+constexpr int D_HEADS = 16;     // cursor of group g's task list at D_HEADS + 16 g (a cache line each)
+constexpr int N_GROUPS = 8;
+constexpr int D_DARR = D_HEADS + 16 * N_GROUPS;      // nt ints: arrivals of the split last panel at diagonal tile j
 __host__ __device__ inline int tri(int i, int j) { return i * (i + 1) / 2 + j; }
-__host__ __device__ inline int d_stripc(int nt) { return D_DARR + nt; }                          // tri(i, k): strips of tile (i, k) done (8 = L_ik complete)
+__host__ __device__ inline int d_yprog(int nt) { return D_DARR + nt; }                           // i: panels applied to y_i
+__host__ __device__ inline int d_stripc(int nt) { return d_yprog(nt) + nt; }                     // tri(i, k): strips of tile (i, k) done (8 = L_ik complete)
 __host__ __device__ inline int d_usum(int nt) { return d_stripc(nt) + nt * (nt + 1) / 2; }       // tri(i, j): panels applied, summed over the tile's units
 __host__ __device__ inline int d_uprog(int nt) { return d_usum(nt) + nt * (nt + 1) / 2; }        // 4 tri(i, j) + u: panels applied to unit u
 inline int dag_state_ints(int nt) { return d_uprog(nt) + 4 * (nt * (nt + 1) / 2); }
+// the group whose teams update tile (i, j): 4 x 2 blocks of tiles dealt round the eight groups (2.4 % apart in total work at 47 tile columns)
+__host__ __device__ inline int tile_group(int i, int j) { return ((i >> 2) + 3 * (j >> 1)) & (N_GROUPS - 1); }
 
 // ---- tasks: type | i | j | unit | k0 | nk in one 64-bit word
-enum : unsigned { T_END = 0, T_STRIP = 1, T_HALF = 2, T_QUARTER = 3, T_DIAG = 4, T_YSOLVE = 5 };
+enum : unsigned { T_END = 0, T_STRIPS = 1, T_HALF = 2, T_QUARTER = 3, T_DIAG = 4, T_YSOLVE = 5, T_RHS = 6 };      // STRIPS: unit = first strip, nk = strips (8 or 4)
 __host__ __device__ inline unsigned long long task_word(unsigned type, unsigned i, unsigned j, unsigned unit, unsigned k0, unsigned nk)
 {
     return (unsigned long long)type | ((unsigned long long)i << 8) | ((unsigned long long)j << 16) | ((unsigned long long)unit << 24) |
@@ -78,8 +88,11 @@ __host__ __device__ inline int t_j(unsigned long long w) { return (int)((w >> 16
 __host__ __device__ inline int t_unit(unsigned long long w) { return (int)((w >> 24) & 0xff); }
 __host__ __device__ inline int t_k0(unsigned long long w) { return (int)((w >> 32) & 0xff); }
 __host__ __device__ inline int t_nk(unsigned long long w) { return (int)((w >> 40) & 0xff); }
-// units of tile (i, j): halves (2) in the columns before quarter_from, quarters behind (the diagonal tile's upper-right quarter does not exist)
-__host__ __device__ inline int tile_units(int i, int j, int quarter_from) { return j >= quarter_from ? (i == j ? 3 : 4) : 2; }
+// units of tile (i, j): its 64 x 64 quarters q = (row half) + 2 (column half); the diagonal tile's upper-right quarter (q = 2) does not exist.
+// A HALF task (unit = column half h) covers quarters 2 h and 2 h + 1: the form in which a tile absorbs panels while it lags behind the chain;
+// the task that COMPLETES a tile goes in quarters (a quarter of the latency: the strips of the tile wait for it), and so does everything
+// in the last columns (from quarter_from on), where tiles are too few to fill the teams otherwise.
+__host__ __device__ inline int tile_units(int i, int j, int) { return i == j ? 3 : 4; }
 
 constexpr int DAG_THREADS = 512;
 constexpr int DAG_SPIN_LIMIT = 1 << 20;
@@ -90,14 +103,17 @@ typedef __attribute__((address_space(1))) int global_int;
 struct DagArgs {
     double* S; double* y; double* x; double* Linv; double* Lpub; double* ok; double* stall;
     int* st;                               // state words
-    const unsigned long long* tasks;
+    const unsigned long long* tasks;       // the eight lists behind each other
+    int list_off[N_GROUPS], list_len[N_GROUPS];
     int ld, nt, n_tasks, quarter_from;
     long long* trace;                      // development (tools/chol_test.hip built with -DDAG_TRACE): per task 4 stamps of the 100 MHz clock, behind them 2 per tile column of the chain
 };
 
 #ifdef DAG_TRACE
 #define DAG_STAMP(slot) do { if (a.trace) a.trace[slot] = wall_clock64(); } while (0)
+#define DAG_STAMP2(tr, slot) do { if (tr) (tr)[slot] = wall_clock64(); } while (0)
 #else
+#define DAG_STAMP2(tr, slot) do { } while (0)
 #define DAG_STAMP(slot) do { } while (0)
 #endif
 
@@ -134,85 +150,184 @@ __device__ __forceinline__ void team_sync(Team& t)
     asm volatile("" ::: "memory");
 }
 
-// ---------------------------------------------------------------------------------------------
-// One 16-row strip of the panel solve by the four wavefronts of a team.  A strip is a chain of 176 matrix-core operations, but only 8
-// of a step's operations are on the chain; wavefront W owns block columns {W, 7 - W} (9 products each): the owner of column j forms
-// Y_j = Linv_jj acc_j, leaves it in LDS (accumulator layout = B operand of the updates), one team barrier, every wavefront applies Y_j
-// to the columns it owns -- the next step's column first.  Per block column the products meet the accumulator in the order of the
-// one-wavefront strip (trsm_strip): bit-identical.  L_kk and the block inverses come through L1-bypassing loads, the result goes
-// through to memory.  ysh: 8 x 256 doubles of LDS; on return (after the caller's barrier) it holds the whole strip, element (row n,
-// column c) at ysh[(c >> 4) * 256 + (c & 15) * 16 + n].
-// ---------------------------------------------------------------------------------------------
-template <int W>
-__device__ __forceinline__ void dag_strip_body(double* __restrict__ base, size_t cstride, bool live, const double* __restrict__ S, int ld, int k,
-                                               const double* __restrict__ Linv_k, Team& t, double* __restrict__ ysh)
+// the same barrier where the wait is long (three wavefronts waiting for their leader's dependency polls): sleep between looks, so that
+// they take neither LDS cycles nor issue slots from the other team's wavefronts on their SIMDs
+__device__ __forceinline__ void team_sync_idle(Team& t)
 {
-    constexpr int C0 = W, C1 = NBLK - 1 - W;
-    const int lane = t.lane;
-    double4_t acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        acc0[r] = live ? base[(size_t)(C0 * NB + (lane >> 4) + 4 * r) * cstride] : 0.0;
-        acc1[r] = live ? base[(size_t)(C1 * NB + (lane >> 4) + 4 * r) * cstride] : 0.0;
+    t.phase += 4;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (t.lane == 0) {
+        __hip_atomic_fetch_add(t.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(t.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t.phase) __builtin_amdgcn_s_sleep(16);
     }
-    const double* Lop = S + (size_t)(k * TILE + (lane >> 4)) * ld + (size_t)k * TILE + (lane & 15);
-    const double* Lio = Linv_k + (lane & 15) * NB + (lane >> 4);
-    double lio0[4], lio1[4], lop0[C0 > 0 ? C0 : 1][4], lop1[C1][4];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Panel solve of a tile by a team.  L_kk's 28 sub-diagonal 16 x 16 blocks (negated) and its 8 block inverses are parked in LDS in MFMA
+// operand layout -- register r of lane l of block b at [b * 256 + r * 64 + l], every wave-wide read 512 contiguous bytes -- by the four
+// wavefronts together (28 + 8 loads per lane, one trip); then every wavefront runs the strip of trsm_strip (chol_device.h) on its own
+// 16-row strips, Y_c = Linv_cc (A_c^T - sum_{j<c} L_cj Y_j), same products in the same order: bit-identical.  No hand-off inside.
+// (First form of this launch: one strip per task by four wavefronts handing Y_j round -- 8 648 tasks of 18 us, a third of all team time.)
+// ---------------------------------------------------------------------------------------------
+constexpr int LSH_DOUBLES = LPUB_BLOCKS * NB * NB, ISH_DOUBLES = NBLK * NB * NB;       // 7168 + 2048 doubles = 72 KB per team
+// L_kk comes from where the chain workgroup publishes it: the scratch copy of its sub-diagonal blocks (block b = c (c - 1) / 2 + j
+// column-major at Lpub_k + 256 b) and the row-major block inverses.  Items (block, chunk) = (item >> 2, item & 3) are dealt over the four
+// wavefronts; inverse c is item 4 (LPUB_BLOCKS + c) + r.
+__device__ __forceinline__ void park_Lkk(double* __restrict__ Lsh, double* __restrict__ Ish, const double* __restrict__ Lpub_k, const double* __restrict__ Linv_k, int tw, int ln)
+{
+    // all 36 loads of a lane first, then the LDS writes (item by item the compiler waited for every load before its write: 9.7 us per task)
+    double v[LPUB_BLOCKS + NBLK];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { lio0[r] = load_through(Lio + C0 * NB * NB + 4 * r); lio1[r] = load_through(Lio + C1 * NB * NB + 4 * r); }
+    for (int q = 0; q < LPUB_BLOCKS + NBLK; ++q) {
+        const int item = q * 4 + tw, b = item >> 2, r = item & 3;
+        v[q] = b < LPUB_BLOCKS ? load_through(Lpub_k + b * 256 + (4 * r + (ln >> 4)) * NB + (ln & 15))
+                               : load_through(Linv_k + (b - LPUB_BLOCKS) * NB * NB + (ln & 15) * NB + (ln >> 4) + 4 * r);
+    }
+    asm volatile("" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < C0; ++j)
+    for (int q = 0; q < LPUB_BLOCKS + NBLK; ++q) {
+        const int item = q * 4 + tw, b = item >> 2, r = item & 3;
+        if (b < LPUB_BLOCKS) Lsh[b * 256 + r * 64 + ln] = -v[q];
+        else Ish[(b - LPUB_BLOCKS) * 256 + r * 64 + ln] = v[q];
+    }
+}
+// one strip: element (strip row n = ln & 15, tile column col) at base[col * cstride]; `live` lanes hold real rows (the rhs strip has one)
+__device__ __forceinline__ void strip_from_lds(double* __restrict__ base, size_t cstride, bool live, const double* __restrict__ Lsh, const double* __restrict__ Ish, int ln)
+{
+    double4_t Acc[NBLK], Y[NBLK];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lop0[j][r] = -load_through(Lop + (size_t)(j * NB + 4 * r) * ld + C0 * NB);
+    for (int c = 0; c < NBLK; ++c)
 #pragma unroll
-    for (int j = 0; j < C1; ++j)
+        for (int r = 0; r < 4; ++r) Acc[c][r] = live ? base[(size_t)(c * NB + (ln >> 4) + 4 * r) * cstride] : 0.0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lop1[j][r] = -load_through(Lop + (size_t)(j * NB + 4 * r) * ld + C1 * NB);
+    for (int c = 0; c < NBLK; ++c) {
+        double4_t acc = Acc[c];
 #pragma unroll
-    for (int j = 0; j < NBLK; ++j) {
-        double4_t Yj = { 0, 0, 0, 0 };
-        const bool mine = j == C0 || j == C1;
-        if (mine) {
-            const double4_t a = j == C0 ? acc0 : acc1;
+        for (int j = 0; j < c; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Yj = __builtin_amdgcn_mfma_f64_16x16x4f64(j == C0 ? lio0[r] : lio1[r], a[r], Yj, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lsh[(c * (c - 1) / 2 + j) * 256 + r * 64 + ln], Y[j][r], acc, 0, 0, 0);
+        double4_t yc = { 0, 0, 0, 0 };
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ysh[j * 256 + r * 64 + lane] = Yj[r];
-            if (live) {
+        for (int r = 0; r < 4; ++r) yc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ish[c * 256 + r * 64 + ln], acc[r], yc, 0, 0, 0);
+        Y[c] = yc;
+        if (live) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) store_through(base + (size_t)(j * NB + (lane >> 4) + 4 * r) * cstride, Yj[r]);
-            }
-        }
-        if (j == NBLK - 1) break;
-        team_sync(t);
-        if (!mine) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Yj[r] = ysh[j * 256 + r * 64 + lane];
-        }
-        // the column of the next step first
-        if (C1 > j && C1 == j + 1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop1[j][r], Yj[r], acc1, 0, 0, 0);
-        }
-        if (C0 > j) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop0[j][r], Yj[r], acc0, 0, 0, 0);
-        }
-        if (C1 > j && C1 != j + 1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop1[j][r], Yj[r], acc1, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) store_through(base + (size_t)(c * NB + (ln >> 4) + 4 * r) * cstride, yc[r]);
         }
     }
 }
-__device__ __forceinline__ void dag_strip(double* __restrict__ base, size_t cstride, bool live, const double* __restrict__ S, int ld, int k,
-                                          const double* __restrict__ Linv_k, Team& t, double* __restrict__ ysh)
+
+// The strips of a tile NEXT TO THE CHAIN (one strip per wavefront), in three phases behind the in-tile factorisation of L_kk that runs
+// at the same time on the chain workgroup:
+//   block columns 0-3 in memory (progress word)  ->  steps 0-3 and the products of the later block columns with Y_0 .. Y_3  (26 of the 36 products)
+//   block columns 4-5                             ->  steps 4, 5 and their products
+//   tile factored (fact)                          ->  steps 6, 7: two inverse products and one update behind the last fetch
+// Each phase parks what it needs in LDS first (26 / 7 / 3 loads per lane).  Per block column the products meet the accumulator in the
+// order of the one-wavefront strip: bit-identical.  A team that starts when the tile is already factored does it in one go.
+// Returns false when a wait ran out (the team abandons the task; the launch is being aborted).
+__device__ __forceinline__ bool strips_phased(double* __restrict__ base, size_t cstride, const double* __restrict__ Lpub_k, const double* __restrict__ Linv_k,
+                                              const int* __restrict__ st, int k, Team& t, double* __restrict__ Lsh, double* __restrict__ Ish, lds_int* ctl, long long* tr2, bool factored)
 {
-    switch (t.tw) {
-        case 0: dag_strip_body<0>(base, cstride, live, S, ld, k, Linv_k, t, ysh); break;
-        case 1: dag_strip_body<1>(base, cstride, live, S, ld, k, Linv_k, t, ysh); break;
-        case 2: dag_strip_body<2>(base, cstride, live, S, ld, k, Linv_k, t, ysh); break;
-        default: dag_strip_body<3>(base, cstride, live, S, ld, k, Linv_k, t, ysh); break;
+    const int ln = t.lane;
+    const bool leader = t.tw == 0 && ln == 0;
+    double4_t Acc[NBLK], Y[NBLK];
+#pragma unroll
+    for (int c = 0; c < NBLK; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Acc[c][r] = base[(size_t)(c * NB + (ln >> 4) + 4 * r) * cstride];
+    auto step = [&](int c) {          // Y_c = Linv_cc Acc_c, stored through
+        double4_t yc = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ish[c * 256 + r * 64 + ln], Acc[c][r], yc, 0, 0, 0);
+        Y[c] = yc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) store_through(base + (size_t)(c * NB + (ln >> 4) + 4 * r) * cstride, yc[r]);
+    };
+    auto update = [&](int c, int j) { // Acc_c -= L(c, j) Y_j
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lsh[(c * (c - 1) / 2 + j) * 256 + r * 64 + ln], Y[j][r], Acc[c], 0, 0, 0);
+    };
+    auto wait_for = [&](const int* word, int target) {      // leader polls, everybody learns the outcome
+        if (leader) ctl[5] = poll_ge(word, target, st + D_ABORT) ? 1 : 0;
+        team_sync_idle(t);
+        return __builtin_amdgcn_readfirstlane(ctl[5]) != 0;
+    };
+    // a phase parks blocks (c, j) with j in [j0, j1) and inverses [j0, i1): wavefront w takes chunk r = w of every block; a lane's loads all go
+    // out before the first LDS write
+    auto park_phase = [&](auto J0, auto J1, auto I1) {
+        constexpr int j0 = decltype(J0)::value, j1 = decltype(J1)::value, i1 = decltype(I1)::value;
+        const int r = t.tw;
+        double v[LPUB_BLOCKS + NBLK];
+#pragma unroll
+        for (int c = 1; c < NBLK; ++c)
+#pragma unroll
+            for (int j = j0; j < j1; ++j)
+                if (j < c) v[c * (c - 1) / 2 + j] = load_through(Lpub_k + (c * (c - 1) / 2 + j) * 256 + (4 * r + (ln >> 4)) * NB + (ln & 15));
+#pragma unroll
+        for (int c = j0; c < i1; ++c) v[LPUB_BLOCKS + c] = load_through(Linv_k + c * NB * NB + (ln & 15) * NB + (ln >> 4) + 4 * r);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 1; c < NBLK; ++c)
+#pragma unroll
+            for (int j = j0; j < j1; ++j)
+                if (j < c) Lsh[(c * (c - 1) / 2 + j) * 256 + r * 64 + ln] = -v[c * (c - 1) / 2 + j];
+#pragma unroll
+        for (int c = j0; c < i1; ++c) Ish[c * 256 + r * 64 + ln] = v[LPUB_BLOCKS + c];
+    };
+    // a team that arrives when the tile is already factored has nothing to overlap: one trip for all operands, then the plain strip
+    if (!factored) {          // (a task that waited for `fact` at its dependency poll knows)
+        if (leader) ctl[5] = ld_word(st + D_FACT) >= k + 1 ? 1 : 0;
+        team_sync(t);
+        factored = __builtin_amdgcn_readfirstlane(ctl[5]) != 0;
+        team_sync(t);         // (ctl[5] is rewritten by the waits below: everybody has read it)
     }
+    if (factored) {
+        if (leader) DAG_STAMP2(tr2, 0);
+        park_Lkk(Lsh, Ish, Lpub_k, Linv_k, t.tw, ln);
+        team_sync(t);
+        if (leader) DAG_STAMP2(tr2, 1);
+#pragma unroll
+        for (int c = 0; c < NBLK; ++c) {
+#pragma unroll
+            for (int j = 0; j < c; ++j) update(c, j);
+            step(c);
+        }
+        if (leader) DAG_STAMP2(tr2, 2);
+        return true;
+    }
+    // ---- phase 1: block columns 0 .. 3
+    if (!wait_for(st + D_PROG, 8 * k + 3)) return false;
+    park_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+    team_sync(t);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int j = 0; j < c; ++j) update(c, j);
+        step(c);
+    }
+#pragma unroll
+    for (int c = 4; c < NBLK; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) update(c, j);
+    // ---- phase 2: block columns 4, 5
+    if (!wait_for(st + D_PROG, 8 * k + 5)) return false;
+    park_phase(std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{}, std::integral_constant<int, 6>{});
+    team_sync(t);
+    step(4);
+    update(5, 4);
+    step(5);
+    update(6, 4); update(6, 5);
+    update(7, 4); update(7, 5);
+    // ---- phase 3: the tile is factored
+    if (!wait_for(st + D_FACT, k + 1)) return false;
+    park_phase(std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{}, std::integral_constant<int, 8>{});
+    team_sync(t);
+    step(6);
+    update(7, 6);
+    step(7);
+    return true;
 }
 
 #ifndef DAG_UPDATE_INLINE
@@ -270,48 +385,67 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagArgs a)
             if (tid == 0) DAG_STAMP(4 * (size_t)a.n_tasks + 2 * k);
             load_tile_packed_wt(A, T, ld, tid);
             __syncthreads();
-            const bool failed = potrf_tile_lds<false, LayPacked, 1>(A, Li, a.Linv + (size_t)k * linv_stride, tid);
-            store_tile_packed_wt(T, A, ld, tid);
+            // block column by block column to the scratch copy + ONE progress word (potrf_tile_lds<.., 4>): the strips next to the chain work
+            // in phases behind it; every strip reads L_kk from that copy and the block inverses, so the flag goes up as soon as those are in
+            // memory and the factor itself goes to S afterwards, off the chain (the backward solve reads it there, a launch later)
+            const bool failed = potrf_tile_lds<false, LayPacked, 4>(A, Li, a.Linv + (size_t)k * linv_stride, tid, NBLK,
+                                                                     TilePublish{ a.Lpub + (size_t)k * LPUB_TILE_DOUBLES, st + D_PROG, 8 * k });
             if (tid == 0 && failed) *a.ok = 0.0;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) { st_word(st + D_FACT, k + 1); DAG_STAMP(4 * (size_t)a.n_tasks + 2 * k + 1); }
+            store_tile_packed_wt(T, A, ld, tid);
+            __syncthreads();                 // (the tile's LDS is read by the store until here; the next tile overwrites it)
         }
         return;
     }
 
     // ================= worker teams =================
-    const int team = wave >> 2;
+    const int team = wave >> 2, group = (int)(blockIdx.x & (N_GROUPS - 1));
     Team t;
-    lds_int* const ctl = (lds_int*)(sm + 2 * (NBLK * NB * NB)) + team * 8;          // [0] barrier counter, [2..3] mailbox
-    double* const ysh = sm + team * (NBLK * NB * NB);
-    double* const yks = sm + 2 * (NBLK * NB * NB) + 8 + team * TILE;                 // y_k for the strips' rhs rows
+    double* const Lsh = sm + team * (LSH_DOUBLES + ISH_DOUBLES);                     // L_kk parked for the strips: sub-diagonal blocks, then inverses
+    double* const Ish = Lsh + LSH_DOUBLES;
+    lds_int* const ctl = (lds_int*)(sm + 2 * (LSH_DOUBLES + ISH_DOUBLES)) + team * 8;      // [0] barrier counter, [2..3] mailbox, [4] the task's index
+    double* const yks = sm + 2 * (LSH_DOUBLES + ISH_DOUBLES) + 8 + team * TILE;             // y_k for a rhs task
     t.cnt = ctl; t.phase = 0; t.lane = lane; t.tw = wave & 3;
-    if ((tid & 255) == 0) { ctl[0] = 0; ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; }
+    if ((tid & 255) == 0) { ctl[0] = 0; ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; ctl[5] = 0; }
     __syncthreads();                                           // the only workgroup-wide barrier: both teams are still together here
+    const unsigned long long* const my_tasks = a.tasks + a.list_off[group];
+    const int my_len = a.list_len[group];
+    int* const head = st + D_HEADS + 16 * group;
+    int* const yprog = st + d_yprog(nt);
     while (true) {
-        // (the lane index is made opaque once per task: otherwise every address the four strip bodies and the update shapes derive from it
-        // is hoisted out of this loop, ~70 registers held across all roles and spilled)
+        // (the lane index is made opaque once per task: otherwise every address the strip and update shapes derive from it is hoisted out
+        // of this loop, ~70 registers held across all roles and spilled)
         int ln = lane;
         asm volatile("" : "+v"(ln));
         t.lane = ln;
         const bool leader = t.tw == 0 && ln == 0;
         if (leader) {
             unsigned long long w = 0;
-            const int id = __hip_atomic_fetch_add((global_int*)(st + D_HEAD), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (id < a.n_tasks && !ld_word(st + D_ABORT)) w = a.tasks[id];
-            if (w) DAG_STAMP(4 * (size_t)id);
+            const int id = __hip_atomic_fetch_add((global_int*)head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (id < my_len && !ld_word(st + D_ABORT)) w = my_tasks[id];
+            const size_t gid = (size_t)a.list_off[group] + id;
+            (void)gid;
+            if (w) DAG_STAMP(4 * gid);
             bool ready = true;
             const int i = t_i(w), j = t_j(w), u = t_unit(w), k0 = t_k0(w), nk = t_nk(w);
             switch (t_type(w)) {
-                case T_STRIP:      // tile (i, k = j) has absorbed its j panels; L_jj is in memory
-                    ready = poll_ge(st + D_FACT, j + 1, st + D_ABORT) &&
+                case T_STRIPS:     // tile (i, k = j) has absorbed its j panels; L_jj is in memory (k0 = 1: next to the chain -- the task follows the factorisation in phases instead)
+                    ready = (k0 == 1 || poll_ge(st + D_FACT, j + 1, st + D_ABORT)) &&
                             (j == 0 || poll_ge(usum + tri(i, j), tile_units(i, j, a.quarter_from) * j, st + D_ABORT));
                     break;
-                case T_YSOLVE:     // y_j has been updated by every strip of tile row j; L_jj is in memory
-                    ready = poll_ge(st + D_FACT, j + 1, st + D_ABORT) && (j == 0 || poll_ge(stripc + tri(j, j - 1), NBLK, st + D_ABORT));
+                case T_YSOLVE:     // y_j has absorbed every panel before j; L_jj is in memory
+                    ready = poll_ge(st + D_FACT, j + 1, st + D_ABORT) && poll_ge(yprog + j, j, st + D_ABORT);
                     break;
-                case T_HALF:
+                case T_RHS:        // y_i stands at panel k0; L_i,k is complete and y_k solved for the last panel it takes (they imply the earlier ones)
+                    ready = poll_ge(yprog + i, k0, st + D_ABORT) && poll_ge(stripc + tri(i, k0 + nk - 1), NBLK, st + D_ABORT) &&
+                            poll_ge(st + D_YSOL, k0 + nk, st + D_ABORT);
+                    break;
+                case T_HALF:       // both quarters of the half stand at panel k0 (the diagonal tile's right half is quarter 3 alone) ...
+                    ready = poll_ge(uprog + 4 * tri(i, j) + 2 * u + 1, k0, st + D_ABORT) && ((i == j && u == 1) || poll_ge(uprog + 4 * tri(i, j) + 2 * u, k0, st + D_ABORT)) &&
+                            poll_ge(stripc + tri(i, k0 + nk - 1), NBLK, st + D_ABORT) && (i == j || poll_ge(stripc + tri(j, k0 + nk - 1), NBLK, st + D_ABORT));
+                    break;
                 case T_QUARTER:    // the unit stands at panel k0; the strips of the last panel it takes are complete (they imply the earlier ones)
                     ready = poll_ge(uprog + 4 * tri(i, j) + u, k0, st + D_ABORT) && poll_ge(stripc + tri(i, k0 + nk - 1), NBLK, st + D_ABORT) &&
                             (i == j || poll_ge(stripc + tri(j, k0 + nk - 1), NBLK, st + D_ABORT));
@@ -326,17 +460,19 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagArgs a)
                 if (!ld_word(st + D_ABORT)) { *a.stall = 4.0; st_word(st + D_ABORT, 1); }
                 w = 0;
             }
-            if (w) DAG_STAMP(4 * (size_t)id + 1);
+            if (w) DAG_STAMP(4 * gid + 1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // what the producers stored through is read plainly from here on
-            if (w) DAG_STAMP(4 * (size_t)id + 2);
-            ctl[2] = (int)(unsigned)w; ctl[3] = (int)(unsigned)(w >> 32); ctl[4] = id;
+            if (w) DAG_STAMP(4 * gid + 2);
+            ctl[2] = (int)(unsigned)w; ctl[3] = (int)(unsigned)(w >> 32); ctl[4] = (int)gid;
         }
-        team_sync(t);
+        team_sync_idle(t);
         const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(ctl[2]), hi = (unsigned)__builtin_amdgcn_readfirstlane(ctl[3]);
         const unsigned long long w = ((unsigned long long)hi << 32) | lo;
         const unsigned type = t_type(w);
         if (type == T_END) break;
         const int i = t_i(w), j = t_j(w), u = t_unit(w), k0 = t_k0(w), nk = t_nk(w);
+        // the small tasks sit on somebody's critical path and share their SIMDs' matrix pipes with the other team's update: they go first
+        if (type != T_HALF && type != T_QUARTER) __builtin_amdgcn_s_setprio(3);
         if (type == T_HALF) {
             // half u of tile (i, j): 128 rows x 64 columns, a wavefront 64 x 32
             if (!(i == j && u == 1 && (t.tw & 1) == 0)) {         // diagonal tile: rows 0-63 of columns 64-127 lie above the diagonal
@@ -351,45 +487,66 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagArgs a)
             tile_of_index(u * 4 + t.tw, bi, bj);
             const int row0 = j * TILE + bi * NB, col0 = j * TILE + bj * NB;
             update_task<1, 1, 32, 1>(a.S, ld, j - 1, j, row0, col0, ln);
-        } else if (type == T_YSOLVE) {
-            dag_strip(a.y + (size_t)j * TILE, 1, (ln & 15) == 0, a.S, ld, j, a.Linv + (size_t)j * linv_stride, t, ysh);
-        } else {      // T_STRIP: strip u of tile (i, k = j), then y_i[16 rows] -= L_ik[rows] y_k
-            dag_strip(a.S + (size_t)(j * TILE) * ld + (size_t)i * TILE + u * NB + (ln & 15), (size_t)ld, true, a.S, ld, j,
-                      a.Linv + (size_t)j * linv_stride, t, ysh);
-            team_sync(t);
-            if (t.tw == 0) {
-                bool solved = true;
-                if (ln == 0) solved = poll_ge(st + D_YSOL, j + 1, st + D_ABORT);
-                solved = __builtin_amdgcn_readfirstlane((int)solved) != 0;
-                if (!solved) {
-                    if (ln == 0 && !ld_word(st + D_ABORT)) { *a.stall = 4.0; st_word(st + D_ABORT, 1); }
-                } else {
-                    // y_k in ONE trip (two values per lane, parked in LDS), then one chain of 128 products per row on lanes 0-15 -- the order in
-                    // which the column-by-column launches add them.  (First form: 128 L1-bypassing loads in the chain, eight at a time: 25 us.)
-                    const double* yk = a.y + (size_t)j * TILE;
-                    const double y0 = load_through(yk + 2 * ln), y1 = load_through(yk + 2 * ln + 1);
-                    double* yi = a.y + (size_t)i * TILE + u * NB + (ln & 15);
-                    const double yold = load_through(yi);
-                    yks[2 * ln] = y0; yks[2 * ln + 1] = y1;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_wave_barrier();
-                    if (ln < NB) {
-                        double accv = 0;
-#pragma unroll 16
-                        for (int c = 0; c < TILE; ++c) accv = __builtin_fma(ysh[(c >> 4) * 256 + (c & 15) * 16 + ln], yks[c], accv);
-                        store_through(yi, yold - accv);
+        } else if (type == T_RHS) {
+            // y_i -= L_ik y_k for k = k0 .. k0 + nk - 1: one chain of 128 products per row and panel (rows on wavefronts 0-1), y_k through LDS;
+            // L_ik's row in four batches of 32 loads (left to the compiler the loads went out one by one inside the chain: 34 us per panel)
+            const int r = (t.tw & 1) * 64 + ln;
+            double* yi = a.y + (size_t)i * TILE + r;
+            double yv = t.tw < 2 ? load_through(yi) : 0.0;
+            for (int k = k0; k < k0 + nk; ++k) {
+                if (t.tw < 2) yks[r] = load_through(a.y + (size_t)k * TILE + r);
+                team_sync(t);
+                if (t.tw < 2) {
+                    const double* Lik = a.S + (size_t)(k * TILE) * ld + (size_t)i * TILE + r;
+                    double accv = 0;
+#pragma unroll
+                    for (int c0 = 0; c0 < TILE; c0 += 32) {
+                        double lv[32];
+#pragma unroll
+                        for (int c = 0; c < 32; ++c) lv[c] = Lik[(size_t)(c0 + c) * ld];
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int c = 0; c < 32; ++c) accv = __builtin_fma(lv[c], yks[c0 + c], accv);
                     }
+                    yv -= accv;
+                }
+                team_sync(t);
+            }
+            if (t.tw < 2) store_through(yi, yv);
+        } else {
+            // T_STRIPS: strips u .. u + nk - 1 of tile (i, k = j);  T_YSOLVE: the rhs row y_j as a strip with one live row
+            const double* Lpub_k = a.Lpub + (size_t)j * LPUB_TILE_DOUBLES;
+            const double* Linv_k = a.Linv + (size_t)j * linv_stride;
+            if (type == T_STRIPS && nk == 4) {
+                if (!strips_phased(a.S + (size_t)(j * TILE) * ld + (size_t)i * TILE + (u + t.tw) * NB + (ln & 15), (size_t)ld, Lpub_k, Linv_k, st, j, t, Lsh, Ish, ctl, a.trace ? a.trace + 4 * (size_t)a.n_tasks + 2 * nt + 16 + 4 * (size_t)ctl[4] : nullptr, k0 == 0)) {
+                    if (leader && !ld_word(st + D_ABORT)) { *a.stall = 4.0; st_word(st + D_ABORT, 1); }
+                }
+            } else {
+                park_Lkk(Lsh, Ish, Lpub_k, Linv_k, t.tw, ln);
+                team_sync(t);
+                if (type == T_YSOLVE) {
+                    if (t.tw == 0) strip_from_lds(a.y + (size_t)j * TILE, 1, (ln & 15) == 0, Lsh, Ish, ln);
+                } else {
+                    for (int sidx = u + t.tw; sidx < u + nk; sidx += 4)
+                        strip_from_lds(a.S + (size_t)(j * TILE) * ld + (size_t)i * TILE + sidx * NB + (ln & 15), (size_t)ld, true, Lsh, Ish, ln);
                 }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wavefront's stores are in memory
+        __builtin_amdgcn_s_setprio(0);
         team_sync(t);
         if (leader) {
             DAG_STAMP(4 * (size_t)ctl[4] + 3);
             switch (type) {
-                case T_STRIP: add_word(stripc + tri(i, j), 1); break;
+                case T_STRIPS: add_word(stripc + tri(i, j), nk); break;
                 case T_YSOLVE: st_word(st + D_YSOL, j + 1); break;
+                case T_RHS: st_word(yprog + i, k0 + nk); break;
                 case T_DIAG: add_word(st + D_DARR + j, 1); break;
+                case T_HALF:
+                    st_word(uprog + 4 * tri(i, j) + 2 * u + 1, k0 + nk);
+                    if (!(i == j && u == 1)) st_word(uprog + 4 * tri(i, j) + 2 * u, k0 + nk);
+                    add_word(usum + tri(i, j), (i == j && u == 1) ? nk : 2 * nk);
+                    break;
                 default: st_word(uprog + 4 * tri(i, j) + u, k0 + nk); add_word(usum + tri(i, j), nk); break;
             }
         }
@@ -397,65 +554,92 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// The schedule: list scheduling of the task graph in simulated time (costs in us, round-4 / round-5 measurements).
+// The schedule: list scheduling of the task graph in simulated time (costs in us from the stamps of tools/_bin/chol_test_trace).
 // ---------------------------------------------------------------------------------------------
-struct SimCosts {                         // us, from the stamps of tools/_bin/chol_test_trace 6016 (profiles/r05_dag_trace_*.txt)
-    double potrf = 21.2;                  // tile -> LDS, in-tile factorisation, factor -> memory, flag
-    double strip = 8.0;                   // one strip by four wavefronts + its rhs rows
-    double ysolve = 8.0;
-    double diag = 6.0, gather = 1.5;      // one ninth of the split panel; ninth arrival -> chain workgroup sees it
+struct SimCosts {
+    double potrf = 21.5;                  // tile -> LDS, in-tile factorisation, publication drained, flag
+    double early = 9.0;                   // into the tile: block columns 0-3 are published (the phased strips' first phase may start)
+    double strips4 = 12.0, tail = 4.5;    // four strips of a tile by one team (a wavefront each); phased: ends no earlier than `tail` after the tile is factored
+    double ysolve = 12.0;
+    double rhs0 = 3.0, rhs1 = 6.0;        // rhs rows: fixed + per panel
+    double diag = 5.0, gather = 1.5;      // one ninth of the split panel; ninth arrival -> chain workgroup sees it
     double hop = 1.5;                     // a predecessor on another compute unit becomes visible to a poll
-    double half0 = 10.5, half1 = 16.3;    // half-tile task: fixed (C in and out, ramp, drain, hand-off) + per panel
-    double quarter0 = 4.5, quarter1 = 10.1;
+    double half0 = 4.0, half1 = 15.2;     // half-tile task: fixed (C in and out, ramp, drain, hand-off) + per panel
+    double quarter0 = 3.3, quarter1 = 8.5;
 };
 
 struct Ev {
     double t; long seq; int kind, a, b, c, d;
     bool operator>(const Ev& o) const { return t != o.t ? t > o.t : seq > o.seq; }
 };
-enum { EV_SREADY, EV_SDONE, EV_DREADY, EV_DDONE, EV_UDONE, EV_POTRF, EV_YREADY, EV_YDONE, EV_UREADY };
+enum { EV_SREADY, EV_SDONE, EV_DREADY, EV_DDONE, EV_UDONE, EV_POTRF, EV_YREADY, EV_YDONE, EV_UREADY, EV_RDONE, EV_PEARLY };
 
-std::vector<unsigned long long> build_schedule(int nt, int n_teams, int gmax, int& quarter_from)
+struct Schedule {
+    std::vector<unsigned long long> lists[N_GROUPS];
+    int quarter_from = 0;
+};
+
+// teams of group g when n_cu workgroups are launched (workgroup b belongs to group b % 8; workgroup 0 is the chain)
+inline int group_teams(int g, int n_cu) { return 2 * ((n_cu - g + N_GROUPS - 1) / N_GROUPS - (g == 0 ? 1 : 0)); }
+
+Schedule build_schedule(int nt, int n_cu, int gmax)
 {
     const SimCosts C;
+    Schedule out;
+    int n_teams = 0, free_teams[N_GROUPS];
+    for (int g = 0; g < N_GROUPS; ++g) { free_teams[g] = group_teams(g, n_cu); n_teams += free_teams[g]; }
     // quarter tiles from the first column whose trailing matrix no longer offers a half-tile task per team
+    int& quarter_from = out.quarter_from;
     quarter_from = nt;
     for (int j = 1; j < nt; ++j) { const int m = nt - j; if (m * (m + 1) < n_teams) { quarter_from = j; break; } }
+    if (const char* e = std::getenv("MAGE_CHOL_DAG_QUARTER_FROM")) quarter_from = std::max(1, std::min(nt, std::atoi(e)));      // EXPERIMENT
     const int ntri = nt * (nt + 1) / 2;
-    std::vector<int> strip_cnt(ntri, 0), availc(ntri, 0), nxt(4 * ntri, 0), darr(nt, 0);
-    std::vector<char> busy(4 * ntri, 0), queued(4 * ntri, 0), tile_done(ntri, 0), strips_out(ntri, 0), diag_out(nt, 0), y_out(nt, 0);
+    std::vector<int> strip_cnt(ntri, 0), availc(ntri, 0), nxt(4 * ntri, 0), darr(nt, 0), yprog(nt, 0);
+    std::vector<char> busy(4 * ntri, 0), queued(4 * ntri, 0), tile_done(ntri, 0), strips_out(ntri, 0), diag_out(nt, 0), y_out(nt, 0), rhs_busy(nt, 0);
     std::vector<double> potrf_end(nt, 0.0);
-    int fact = 0;
+    std::vector<char> pearly(nt, 0);
+    int fact = 0, ysol = 0;
     std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> events;
     long seq = 0;
     auto post = [&](double t, int kind, int a2 = 0, int b = 0, int c = 0, int d = 0) { events.push(Ev{ t, seq++, kind, a2, b, c, d }); };
-    // ready queues: (key..., payload)
     typedef std::tuple<int, int, long, int, int, int> Key;      // (column, row, seq, i, j, unit)
-    std::priority_queue<Key, std::vector<Key>, std::greater<Key>> ready_units, ready_strips;
+    typedef std::priority_queue<Key, std::vector<Key>, std::greater<Key>> KeyQueue;
+    KeyQueue ready_units[N_GROUPS], ready_strips;                 // updates wait for a team of their tile's group; everything else goes where a team is free
     std::vector<std::pair<int, int>> ready_diag;
     std::vector<int> ready_y;
-    std::vector<unsigned long long> list;
-    int free_teams = n_teams;
     double now = 0;
-    auto units_of = [&](int i, int j) { return tile_units(i, j, quarter_from); };
-    auto unit_id = [&](int i, int j, int idx) { return (j >= quarter_from && i == j && idx == 2) ? 3 : idx; };      // the diagonal tile's quarters are 0, 1, 3
+    auto has_quarter = [&](int i, int j, int q) { return !(i == j && q == 2); };
     auto limit_of = [&](int i, int j) { return i == j ? j - 1 : j; };       // panels the regular units apply (the diagonal tile's last one is split)
     auto tile_complete = [&](int i, int j) {
-        for (int x = 0; x < units_of(i, j); ++x) if (nxt[4 * tri(i, j) + unit_id(i, j, x)] < limit_of(i, j)) return false;
+        for (int q = 0; q < 4; ++q) if (has_quarter(i, j, q) && nxt[4 * tri(i, j) + q] < limit_of(i, j)) return false;
         return true;
     };
+    // the rows next to the chain in two halves, a wavefront per strip, PHASED against the factorisation of L_kk (they may start once its
+    // first block columns are published); the others as one task once the tile is factored
     auto release_strips = [&](int i, int k, double t) {
-        if (strips_out[tri(i, k)]) return;
+        if (strips_out[tri(i, k)] || !(k == 0 || tile_done[tri(i, k)])) return;
+        const bool near = i <= k + 2;
+        if (near ? !pearly[k] : fact < k + 1) return;
         strips_out[tri(i, k)] = 1;
-        for (int s = 0; s < NBLK; ++s) post(t, EV_SREADY, i, k, s);
+        post(t, EV_SREADY, i, k, 0, near ? 12 : 4); post(t, EV_SREADY, i, k, 4, near ? 12 : 4);       // two tasks of four strips, a wavefront per strip (d = strips | 8 for the phased ones)
     };
     auto consider = [&](int i, int j, double t) {
         int& av = availc[tri(i, j)];
         while (av < j && strip_cnt[tri(i, av)] == NBLK && strip_cnt[tri(j, av)] == NBLK) ++av;
         const int lim = std::min(av, limit_of(i, j));
-        for (int x = 0; x < units_of(i, j); ++x) {
-            const int u = unit_id(i, j, x), id = 4 * tri(i, j) + u;
-            if (!busy[id] && !queued[id] && nxt[id] < lim) { queued[id] = 1; post(t, EV_UREADY, i, j, u); }
+        if (j >= quarter_from) {
+            for (int q = 0; q < 4; ++q) {
+                const int id = 4 * tri(i, j) + q;
+                if (has_quarter(i, j, q) && !busy[id] && !queued[id] && nxt[id] < lim) { queued[id] = 1; post(t, EV_UREADY, i, j, q); }
+            }
+        } else {
+            for (int h = 0; h < 2; ++h) {       // the half is queued as one entry (unit code 4 + h) while its quarters stand together and idle
+                bool idle = true;
+                for (int q = 2 * h; q < 2 * h + 2; ++q) if (has_quarter(i, j, q)) { const int id = 4 * tri(i, j) + q; idle = idle && !busy[id] && !queued[id] && nxt[id] < lim; }
+                if (!idle) continue;
+                for (int q = 2 * h; q < 2 * h + 2; ++q) if (has_quarter(i, j, q)) queued[4 * tri(i, j) + q] = 1;
+                post(t, EV_UREADY, i, j, 4 + h);
+            }
         }
         if (i == j && !diag_out[j] && av >= j && tile_complete(j, j)) {
             diag_out[j] = 1;
@@ -463,134 +647,213 @@ std::vector<unsigned long long> build_schedule(int nt, int n_teams, int gmax, in
         }
     };
     auto start_potrf = [&](int k, double t) {
-        potrf_end[k] = std::max(t, k > 0 ? potrf_end[k - 1] : 0.0) + C.potrf;
+        const double t0 = std::max(t, k > 0 ? potrf_end[k - 1] : 0.0);
+        potrf_end[k] = t0 + C.potrf;
+        post(t0 + C.early, EV_PEARLY, k);
         post(potrf_end[k], EV_POTRF, k);
+    };
+    auto any_free = [&] { int g = 0; for (int x = 1; x < N_GROUPS; ++x) if (free_teams[x] > free_teams[g]) g = x; return free_teams[g] > 0 ? g : -1; };
+    // rhs rows: y_i may absorb panels yprog[i] .. min(ysol, strips of row i complete) - 1
+    auto rhs_avail = [&](int i) {
+        int k = yprog[i];
+        while (k < i && k < ysol && strip_cnt[tri(i, k)] == NBLK) ++k;
+        return k - yprog[i];
     };
     start_potrf(0, 0.0);
     while (true) {
-        while (free_teams > 0 && (!ready_diag.empty() || !ready_y.empty() || !ready_strips.empty() || !ready_units.empty())) {
-            if (!ready_diag.empty()) {
+        bool progress = true;
+        while (progress) {
+            progress = false;
+            int g;
+            while (!ready_diag.empty() && (g = any_free()) >= 0) {
                 const auto [j, p] = ready_diag.back(); ready_diag.pop_back();
-                list.push_back(task_word(T_DIAG, j, j, p, j - 1, 1));
-                --free_teams; post(now + C.diag, EV_DDONE, j, p);
-                continue;
+                out.lists[g].push_back(task_word(T_DIAG, j, j, p, j - 1, 1));
+                --free_teams[g]; post(now + C.diag, EV_DDONE, j, p, g); progress = true;
             }
-            if (!ready_y.empty()) {
+            while (!ready_y.empty() && (g = any_free()) >= 0) {
                 const int k = ready_y.back(); ready_y.pop_back();
-                list.push_back(task_word(T_YSOLVE, k, k, 0, 0, 0));
-                --free_teams; post(now + C.ysolve, EV_YDONE, k);
-                continue;
+                out.lists[g].push_back(task_word(T_YSOLVE, k, k, 0, 0, 0));
+                --free_teams[g]; post(now + C.ysolve, EV_YDONE, k, g); progress = true;
             }
-            if (!ready_strips.empty()) {
+            while (!ready_strips.empty() && (g = any_free()) >= 0) {
                 const Key key = ready_strips.top(); ready_strips.pop();
-                const int i = std::get<3>(key), k = std::get<4>(key), s = std::get<5>(key);
-                list.push_back(task_word(T_STRIP, i, k, s, 0, 0));
-                --free_teams; post(now + C.strip, EV_SDONE, i, k, s);
-                continue;
+                const int i = std::get<3>(key), k = std::get<4>(key), s0 = std::get<5>(key) & 15, phased = (std::get<5>(key) >> 7) & 1;
+                out.lists[g].push_back(task_word(T_STRIPS, i, k, s0, phased, 4));
+                --free_teams[g]; post(phased ? std::max(now + C.strips4, potrf_end[k] + C.tail) : now + C.strips4, EV_SDONE, i, k, 4, g); progress = true;
             }
-            const Key key = ready_units.top(); ready_units.pop();
-            const int i = std::get<3>(key), j = std::get<4>(key), u = std::get<5>(key), id = 4 * tri(i, j) + u;
-            queued[id] = 0;
-            const int lim = std::min(availc[tri(i, j)], limit_of(i, j));
-            const int n = std::min(lim - nxt[id], gmax);
-            if (n <= 0) continue;
-            const bool quarter = j >= quarter_from;
-            list.push_back(task_word(quarter ? T_QUARTER : T_HALF, i, j, u, nxt[id], n));
-            busy[id] = 1; --free_teams;
-            post(now + (quarter ? C.quarter0 + n * C.quarter1 : C.half0 + n * C.half1), EV_UDONE, i, j, u, n);
+            // rhs rows, lowest row first (the row the next solve waits for)
+            for (int i = 1; i < nt && (g = any_free()) >= 0; ++i) {
+                if (rhs_busy[i]) continue;
+                const int n = std::min(rhs_avail(i), gmax);
+                if (n <= 0) continue;
+                if (yprog[i] + n < i && n < gmax && i > ysol + 1) continue;      // a far row waits until it can take a full task (or everything it still needs)
+                out.lists[g].push_back(task_word(T_RHS, i, i, 0, yprog[i], n));
+                rhs_busy[i] = 1; --free_teams[g]; post(now + C.rhs0 + n * C.rhs1, EV_RDONE, i, n, g); progress = true;
+            }
+            for (g = 0; g < N_GROUPS; ++g) {
+                while (free_teams[g] > 0 && !ready_units[g].empty()) {
+                    const Key key = ready_units[g].top(); ready_units[g].pop();
+                    const int i = std::get<3>(key), j = std::get<4>(key), u = std::get<5>(key);
+                    const int lim = std::min(availc[tri(i, j)], limit_of(i, j));
+                    if (u >= 4) {
+                        // a half: quarters 2 h, 2 h + 1 (they stand at the same panel)
+                        const int h = u - 4, q1 = 2 * h + 1, q0 = has_quarter(i, j, 2 * h) ? 2 * h : q1, id1 = 4 * tri(i, j) + q1;
+                        const int n = std::min(lim - nxt[id1], gmax);
+                        if (n <= 0) { queued[id1] = 0; queued[4 * tri(i, j) + q0] = 0; continue; }
+                        if (nxt[id1] + n == limit_of(i, j)) {
+                            // this task completes the tile: in quarters (they stay queued and come up again right away, one team each)
+                            for (int q = q0; q <= q1; q += (q1 > q0 ? q1 - q0 : 1)) { ready_units[g].push(Key{ j, i, seq++, i, j, q }); if (q1 == q0) break; }
+                            continue;
+                        }
+                        queued[id1] = 0; queued[4 * tri(i, j) + q0] = 0;
+                        out.lists[g].push_back(task_word(T_HALF, i, j, h, nxt[id1], n));
+                        busy[id1] = 1; busy[4 * tri(i, j) + q0] = 1; --free_teams[g];
+                        post(now + C.half0 + n * C.half1, EV_UDONE, i, j, u, n);
+                        progress = true;
+                        continue;
+                    }
+                    const int id = 4 * tri(i, j) + u;
+                    queued[id] = 0;
+                    const int n = std::min(lim - nxt[id], gmax);
+                    if (n <= 0) continue;
+                    out.lists[g].push_back(task_word(T_QUARTER, i, j, u, nxt[id], n));
+                    busy[id] = 1; --free_teams[g];
+                    post(now + C.quarter0 + n * C.quarter1, EV_UDONE, i, j, u, n);
+                    progress = true;
+                }
+            }
         }
         if (events.empty()) break;
         now = events.top().t;
         while (!events.empty() && events.top().t <= now) {      // everything that happens at this instant, then dispatch
-        const Ev e = events.top(); events.pop();
-        switch (e.kind) {
-            case EV_POTRF: {
-                const int k = e.a;
-                fact = k + 1;
-                if (!y_out[k] && (k == 0 || strip_cnt[tri(k, k - 1)] == NBLK)) { y_out[k] = 1; post(now + C.hop, EV_YREADY, k); }      // (always: the split panel needed L_{k,k-1} complete)
-                for (int i = k + 1; i < nt; ++i) if (k == 0 || tile_done[tri(i, k)]) release_strips(i, k, now + C.hop);
-                break;
-            }
-            case EV_SREADY: ready_strips.push(Key{ e.b, e.a, seq++, e.a, e.b, e.c }); break;
-            case EV_YREADY: ready_y.push_back(e.a); break;
-            case EV_DREADY: ready_diag.push_back({ e.a, e.b }); break;
-            case EV_UREADY: ready_units.push(Key{ e.b, e.a, seq++, e.a, e.b, e.c }); break;
-            case EV_YDONE: ++free_teams; break;
-            case EV_DDONE:
-                ++free_teams;
-                if (++darr[e.a] == NDIAG) start_potrf(e.a, now + C.hop + C.gather);
-                break;
-            case EV_SDONE: {
-                ++free_teams;
-                const int i = e.a, k = e.b;
-                if (++strip_cnt[tri(i, k)] == NBLK) {
-                    for (int j = k + 1; j <= i; ++j) consider(i, j, now + C.hop);
-                    for (int i2 = i + 1; i2 < nt; ++i2) consider(i2, i, now + C.hop);
-                    if (i == k + 1 && fact >= i + 1 && !y_out[i]) { y_out[i] = 1; post(now + C.hop, EV_YREADY, i); }
+            const Ev e = events.top(); events.pop();
+            switch (e.kind) {
+                case EV_POTRF: {
+                    const int k = e.a;
+                    fact = k + 1;
+                    if (!y_out[k] && yprog[k] >= k) { y_out[k] = 1; post(now + C.hop, EV_YREADY, k); }
+                    for (int i = k + 1; i < nt; ++i) release_strips(i, k, now + C.hop);
+                    break;
                 }
-                break;
-            }
-            case EV_UDONE: {
-                ++free_teams;
-                const int i = e.a, j = e.b, u = e.c, id = 4 * tri(i, j) + u;
-                busy[id] = 0; nxt[id] += e.d;
-                if (i != j && !tile_done[tri(i, j)] && tile_complete(i, j)) {
-                    tile_done[tri(i, j)] = 1;
-                    if (fact >= j + 1) release_strips(i, j, now + C.hop);
+                case EV_PEARLY:
+                    pearly[e.a] = 1;
+                    for (int i = e.a + 1; i < nt && i <= e.a + 2; ++i) release_strips(i, e.a, now);
+                    break;
+                case EV_SREADY: ready_strips.push(Key{ e.b, e.a, seq++, e.a, e.b, e.c | (e.d << 4) }); break;
+                case EV_YREADY: ready_y.push_back(e.a); break;
+                case EV_DREADY: ready_diag.push_back({ e.a, e.b }); break;
+                case EV_UREADY: ready_units[tile_group(e.a, e.b)].push(Key{ e.b, e.a, seq++, e.a, e.b, e.c }); break;
+                case EV_YDONE: ++free_teams[e.b]; ysol = e.a + 1; break;
+                case EV_RDONE: {
+                    ++free_teams[e.c];
+                    const int i = e.a;
+                    rhs_busy[i] = 0; yprog[i] += e.b;
+                    if (yprog[i] >= i && fact >= i + 1 && !y_out[i]) { y_out[i] = 1; post(now + C.hop, EV_YREADY, i); }
+                    break;
                 }
-                consider(i, j, now);
-                break;
+                case EV_DDONE:
+                    ++free_teams[e.c];
+                    if (++darr[e.a] == NDIAG) start_potrf(e.a, now + C.hop + C.gather);
+                    break;
+                case EV_SDONE: {
+                    ++free_teams[e.d];
+                    const int i = e.a, k = e.b;
+                    strip_cnt[tri(i, k)] += e.c;
+                    if (strip_cnt[tri(i, k)] == NBLK) {
+                        for (int j = k + 1; j <= i; ++j) consider(i, j, now + C.hop);
+                        for (int i2 = i + 1; i2 < nt; ++i2) consider(i2, i, now + C.hop);
+                    }
+                    break;
+                }
+                case EV_UDONE: {
+                    const int i = e.a, j = e.b, u = e.c;
+                    ++free_teams[tile_group(i, j)];
+                    if (u >= 4) { for (int q = 2 * (u - 4); q < 2 * (u - 4) + 2; ++q) if (has_quarter(i, j, q)) { busy[4 * tri(i, j) + q] = 0; nxt[4 * tri(i, j) + q] += e.d; } }
+                    else { busy[4 * tri(i, j) + u] = 0; nxt[4 * tri(i, j) + u] += e.d; }
+                    if (i != j && !tile_done[tri(i, j)] && tile_complete(i, j)) {
+                        tile_done[tri(i, j)] = 1;
+                        release_strips(i, j, now + C.hop);
+                    }
+                    consider(i, j, now);
+                    break;
+                }
+                default: break;
             }
-            default: break;
-        }
         }
     }
-    return list;
+    return out;
 }
 
-// Every dependency of the task at position p is produced by tasks at positions < p, or by a chain task (potrf(k)) whose own
-// dependencies are: replay the list with instantaneous tasks and check each task's wait conditions at its position.  Also checks
-// that the list is complete (every strip, every panel of every unit, every split panel, every rhs row exactly once).
-bool check_schedule(const std::vector<unsigned long long>& list, int nt, int quarter_from)
+// The lists cannot deadlock teams that take them in order: replay them with instantaneous tasks -- every group advances its cursor while
+// the task under it has its wait conditions met (the conditions the kernel polls) -- and require that all lists run out; the chain
+// advances when the nine arrivals of its next tile are in.  Also checks completeness: every strip, every panel of every unit, every split
+// panel, every rhs panel and solve exactly once and in range.
+bool check_schedule(const Schedule& sch, int nt)
 {
-    const int ntri = nt * (nt + 1) / 2;
-    std::vector<int> stripc(ntri, 0), usum(ntri, 0), uprog(4 * ntri, 0), darr(nt, 0);
+    const int qf = sch.quarter_from, ntri = nt * (nt + 1) / 2;
+    std::vector<int> stripc(ntri, 0), usum(ntri, 0), uprog(4 * ntri, 0), darr(nt, 0), yprog(nt, 0);
     int fact = 1, ysol = 0;          // potrf(0) depends on nothing
-    auto advance_chain = [&] { while (fact < nt && darr[fact] == NDIAG) ++fact; };
-    for (unsigned long long w : list) {
-        const int i = t_i(w), j = t_j(w), u = t_unit(w), k0 = t_k0(w), nk = t_nk(w);
-        switch (t_type(w)) {
-            case T_STRIP:
-                if (fact < j + 1 || (j > 0 && usum[tri(i, j)] < tile_units(i, j, quarter_from) * j)) return false;
-                if (ysol < j + 1) return false;        // (its rhs rows wait for y_j inside the task: the solve must sit earlier in the list too)
-                ++stripc[tri(i, j)];
-                break;
-            case T_YSOLVE:
-                if (fact < j + 1 || ysol != j || (j > 0 && stripc[tri(j, j - 1)] < NBLK)) return false;
-                ysol = j + 1;
-                break;
-            case T_HALF:
-            case T_QUARTER:
-                if (nk < 1 || uprog[4 * tri(i, j) + u] != k0 || stripc[tri(i, k0 + nk - 1)] < NBLK || (i != j && stripc[tri(j, k0 + nk - 1)] < NBLK)) return false;
-                if (k0 + nk > (i == j ? j - 1 : j)) return false;
-                uprog[4 * tri(i, j) + u] = k0 + nk; usum[tri(i, j)] += nk;
-                break;
-            case T_DIAG:
-                if (stripc[tri(j, j - 1)] < NBLK || usum[tri(j, j)] < tile_units(j, j, quarter_from) * (j - 1)) return false;
-                ++darr[j]; advance_chain();
-                break;
-            default: return false;
+    size_t cur[N_GROUPS] = {};
+    bool moved = true;
+    while (moved) {
+        moved = false;
+        for (int g = 0; g < N_GROUPS; ++g) {
+            while (cur[g] < sch.lists[g].size()) {
+                const unsigned long long w = sch.lists[g][cur[g]];
+                const int i = t_i(w), j = t_j(w), u = t_unit(w), k0 = t_k0(w), nk = t_nk(w);
+                bool ok = false;
+                switch (t_type(w)) {
+                    case T_STRIPS:
+                        if (i <= j || nk != 4 || (u != 0 && u != 4) || k0 > 1) return false;
+                        ok = fact >= j + 1 && (j == 0 || usum[tri(i, j)] >= tile_units(i, j, qf) * j);
+                        if (ok) stripc[tri(i, j)] += nk;
+                        break;
+                    case T_YSOLVE:
+                        ok = fact >= j + 1 && yprog[j] >= j;
+                        if (ok) { if (ysol != j) return false; ysol = j + 1; }
+                        break;
+                    case T_RHS:
+                        if (nk < 1 || k0 + nk > i) return false;
+                        ok = yprog[i] >= k0 && stripc[tri(i, k0 + nk - 1)] >= NBLK && ysol >= k0 + nk;
+                        if (ok) { if (yprog[i] != k0) return false; yprog[i] = k0 + nk; }
+                        break;
+                    case T_HALF: {
+                        if (nk < 1 || k0 + nk > (i == j ? j - 1 : j) || tile_group(i, j) != g || j >= qf || u > 1) return false;
+                        const int q1 = 4 * tri(i, j) + 2 * u + 1, q0 = (i == j && u == 1) ? q1 : q1 - 1;
+                        ok = uprog[q1] >= k0 && uprog[q0] >= k0 && stripc[tri(i, k0 + nk - 1)] >= NBLK && (i == j || stripc[tri(j, k0 + nk - 1)] >= NBLK);
+                        if (ok) {
+                            if (uprog[q1] != k0 || uprog[q0] != k0) return false;
+                            uprog[q1] = k0 + nk; uprog[q0] = k0 + nk; usum[tri(i, j)] += q0 == q1 ? nk : 2 * nk;
+                        }
+                        break;
+                    }
+                    case T_QUARTER:
+                        if (nk < 1 || k0 + nk > (i == j ? j - 1 : j) || tile_group(i, j) != g || u > 3 || (i == j && u == 2)) return false;
+                        ok = uprog[4 * tri(i, j) + u] >= k0 && stripc[tri(i, k0 + nk - 1)] >= NBLK && (i == j || stripc[tri(j, k0 + nk - 1)] >= NBLK);
+                        if (ok) { if (uprog[4 * tri(i, j) + u] != k0) return false; uprog[4 * tri(i, j) + u] = k0 + nk; usum[tri(i, j)] += nk; }
+                        break;
+                    case T_DIAG:
+                        ok = stripc[tri(j, j - 1)] >= NBLK && usum[tri(j, j)] >= tile_units(j, j, qf) * (j - 1);
+                        if (ok) { ++darr[j]; while (fact < nt && darr[fact] == NDIAG) ++fact; }
+                        break;
+                    default: return false;
+                }
+                if (!ok) break;
+                ++cur[g]; moved = true;
+            }
         }
     }
+    for (int g = 0; g < N_GROUPS; ++g) if (cur[g] != sch.lists[g].size()) return false;
     if (fact != nt || ysol != nt) return false;
-    for (int i = 1; i < nt; ++i)
+    for (int i = 1; i < nt; ++i) {
+        if (yprog[i] != i) return false;
         for (int j = 0; j < i; ++j) if (stripc[tri(i, j)] != NBLK) return false;
-    for (int i = 1; i < nt; ++i)
-        for (int j = 1; j <= i; ++j) if (usum[tri(i, j)] != tile_units(i, j, quarter_from) * (i == j ? j - 1 : j)) return false;
+        for (int j = 1; j <= i; ++j) if (usum[tri(i, j)] != tile_units(i, j, qf) * (i == j ? j - 1 : j)) return false;
+    }
     return true;
 }
 
-struct DagSchedule { unsigned long long* d_tasks = nullptr; int n_tasks = 0, quarter_from = 0; bool ok = false; };
+struct DagSchedule { unsigned long long* d_tasks = nullptr; int n_tasks = 0, quarter_from = 0, off[N_GROUPS] = {}, len[N_GROUPS] = {}; bool ok = false; };
 std::mutex g_sched_mutex;
 std::map<std::pair<int, int>, DagSchedule> g_sched;      // (device, nt)
 int g_dag_n_cu = 256;
@@ -614,9 +877,12 @@ const DagSchedule* get_schedule(int nt)
     auto it = g_sched.find({ dev, nt });
     if (it == g_sched.end()) {
         DagSchedule s;
-        std::vector<unsigned long long> list = build_schedule(nt, 2 * (g_dag_n_cu - 1), dag_fuse_max(), s.quarter_from);
-        if (check_schedule(list, nt, s.quarter_from) && hipMalloc(&s.d_tasks, list.size() * sizeof(unsigned long long)) == hipSuccess) {
-            if (hipMemcpy(s.d_tasks, list.data(), list.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) == hipSuccess) { s.n_tasks = (int)list.size(); s.ok = true; }
+        const Schedule sch = build_schedule(nt, g_dag_n_cu, dag_fuse_max());
+        s.quarter_from = sch.quarter_from;
+        std::vector<unsigned long long> flat;
+        for (int g = 0; g < N_GROUPS; ++g) { s.off[g] = (int)flat.size(); s.len[g] = (int)sch.lists[g].size(); flat.insert(flat.end(), sch.lists[g].begin(), sch.lists[g].end()); }
+        if (check_schedule(sch, nt) && hipMalloc(&s.d_tasks, flat.size() * sizeof(unsigned long long)) == hipSuccess) {
+            if (hipMemcpy(s.d_tasks, flat.data(), flat.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) == hipSuccess) { s.n_tasks = (int)flat.size(); s.ok = true; }
             else { (void)hipFree(s.d_tasks); s.d_tasks = nullptr; }
         }
         if (!s.ok) (void)hipGetLastError();
@@ -625,6 +891,9 @@ const DagSchedule* get_schedule(int nt)
     return it->second.ok ? &it->second : nullptr;
 }
 
+constexpr size_t DAG_LDS_BYTES = (2 * (size_t)(LSH_DOUBLES + ISH_DOUBLES) + 8 + 2 * TILE) * sizeof(double);       // two teams' parked L_kk + mailboxes + y_k (the chain workgroup needs less)
+static_assert(DAG_LDS_BYTES >= ((size_t)PACKED_TILE_DOUBLES + 2 * NB * NB + 16) * sizeof(double) && DAG_LDS_BYTES <= 160 * 1024, "LDS of the launch");
+
 }  // namespace
 
 size_t chol_dag_sync_ints(int nt) { return (size_t)dag_state_ints(nt); }
@@ -632,14 +901,13 @@ size_t chol_dag_sync_ints(int nt) { return (size_t)dag_state_ints(nt); }
 void chol_dag_init_device(int n_cu)
 {
     g_dag_n_cu = n_cu;
-    const size_t lds = ((size_t)PACKED_TILE_DOUBLES + 2 * NB * NB + 16) * sizeof(double);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DAG_LDS_BYTES);
 }
 
 bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorkspace& ws, double* ok, double* stall, hipStream_t st)
 {
     const int nt = n_pad / TILE;
-    if (nt < dag_min_tiles() || nt > 255 || g_dag_n_cu < 8) return false;
+    if (nt < dag_min_tiles() || nt > 255 || g_dag_n_cu < 2 * N_GROUPS) return false;
     const DagSchedule* s = get_schedule(nt);
     if (!s) return false;
     int* state = ws.sync + 8;
@@ -647,22 +915,26 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
     DagArgs a;
     a.S = S; a.y = y; a.x = x; a.Linv = ws.Linv; a.Lpub = ws.Linv + (size_t)nt * NBLK * NB * NB; a.ok = ok; a.stall = stall;
     a.st = state; a.trace = ws.dbg; a.tasks = s->d_tasks; a.ld = n_pad; a.nt = nt; a.n_tasks = s->n_tasks; a.quarter_from = s->quarter_from;
-    const size_t lds = ((size_t)PACKED_TILE_DOUBLES + 2 * NB * NB + 16) * sizeof(double);
-    hipLaunchKernelGGL(k_chol_dag, dim3(g_dag_n_cu), dim3(DAG_THREADS), lds, st, a);
+    for (int g = 0; g < N_GROUPS; ++g) { a.list_off[g] = s->off[g]; a.list_len[g] = s->len[g]; }
+    hipLaunchKernelGGL(k_chol_dag, dim3(g_dag_n_cu), dim3(DAG_THREADS), DAG_LDS_BYTES, st, a);
     if (hipGetLastError() != hipSuccess) return false;
     return true;
 }
 
 }  // namespace mage
 
-// Host-only view of the schedule for tests (tests/test_chol_schedule.py): the list for nt tile columns on n_cu compute units, and
-// whether check_schedule accepts it.  Returns the list's length (<= cap entries are written), negative when the list fails the check.
-MAGE_EXPORT int mage_debug_chol_schedule(int nt, int n_cu, int fuse_max, unsigned long long* out, int cap, int* quarter_from)
+// Host-only view of the schedule for tests (tests/test_chol_schedule.py): the eight lists for nt tile columns on n_cu compute units, one
+// behind the other (group_len[8] = their lengths), and whether check_schedule accepts them.  Returns the total length (<= cap entries
+// are written), negative when the lists fail the check.
+MAGE_EXPORT int mage_debug_chol_schedule(int nt, int n_cu, int fuse_max, unsigned long long* out, int cap, int* quarter_from, int* group_len)
 {
-    if (nt < 2 || nt > 255 || n_cu < 2) return 0;
-    int qf = 0;
-    std::vector<unsigned long long> list = mage::build_schedule(nt, 2 * (n_cu - 1), fuse_max > 0 ? fuse_max : 8, qf);
-    if (quarter_from) *quarter_from = qf;
-    for (int i = 0; i < (int)list.size() && i < cap; ++i) out[i] = list[i];
-    return mage::check_schedule(list, nt, qf) ? (int)list.size() : -(int)list.size();
+    if (nt < 2 || nt > 255 || n_cu < 16) return 0;
+    const mage::Schedule sch = mage::build_schedule(nt, n_cu, fuse_max > 0 ? fuse_max : 8);
+    if (quarter_from) *quarter_from = sch.quarter_from;
+    int n = 0;
+    for (int g = 0; g < mage::N_GROUPS; ++g) {
+        if (group_len) group_len[g] = (int)sch.lists[g].size();
+        for (unsigned long long w : sch.lists[g]) { if (n < cap) out[n] = w; ++n; }
+    }
+    return mage::check_schedule(sch, nt) ? n : -n;
 }

@@ -7,7 +7,7 @@
 #include <vector>
 #include "../mageslam_amd/csrc/chol_kernels.h"
 using namespace mage;
-extern "C" int mage_debug_chol_schedule(int nt, int n_cu, int fuse_max, unsigned long long* out, int cap, int* quarter_from);
+extern "C" int mage_debug_chol_schedule(int nt, int n_cu, int fuse_max, unsigned long long* out, int cap, int* quarter_from, int* group_len);
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
 int main(int argc, char** argv)
@@ -38,8 +38,8 @@ int main(int argc, char** argv)
         // trace build: per task four stamps + two per tile column, written by the task-graph launch (dumped below)
         std::vector<unsigned long long> tasks(600000);
         int qf = 0;
-        const int n_tasks = mage_debug_chol_schedule(n / 128, 256, getenv("MAGE_CHOL_DAG_FUSE") ? atoi(getenv("MAGE_CHOL_DAG_FUSE")) : 8, tasks.data(), (int)tasks.size(), &qf);
-        const size_t n_stamps = 4 * (size_t)(n_tasks > 0 ? n_tasks : 0) + 2 * (n / 128) + 16;
+        const int n_tasks = mage_debug_chol_schedule(n / 128, 256, getenv("MAGE_CHOL_DAG_FUSE") ? atoi(getenv("MAGE_CHOL_DAG_FUSE")) : 8, tasks.data(), (int)tasks.size(), &qf, nullptr);
+        const size_t n_stamps = 8 * (size_t)(n_tasks > 0 ? n_tasks : 0) + 2 * (n / 128) + 32;
         long long* ddbg; CK(hipMalloc(&ddbg, sizeof(long long) * n_stamps));
         CholWorkspace ws{ dws, dq, ddbg };
 #else

@@ -5,7 +5,7 @@ per tile column; how many teams are busy over time.    python tools/dag_trace.py
 import sys
 import numpy as np
 
-NAMES = {1: "strip", 2: "half", 3: "quarter", 4: "diag", 5: "ysolve"}
+NAMES = {1: "strips", 2: "half", 3: "quarter", 4: "diag", 5: "ysolve", 6: "rhs"}
 
 
 def main(path):
@@ -29,11 +29,16 @@ def main(path):
         wait, acq, run = T[m, 1] - T[m, 0], T[m, 2] - T[m, 1], T[m, 3] - T[m, 2]
         per = run / np.maximum(nk[m], 1)
         print(f"{NAMES[t]:8s} {m.sum():6d}   {wait.mean():8.2f}   {acq.mean():7.2f}   {'':12s}   {run.mean():7.2f}   {per.mean():7.2f}   {(T[m, 3] - T[m, 0]).sum():10.0f}")
-    m = (typ == 2) | (typ == 3)
-    for t in (2, 3):
+    for t in (1, 2, 3, 6):
         for n in sorted(set(nk[typ == t])):
             mm = (typ == t) & (nk == n)
             print(f"   {NAMES[t]} nk={n:2d}: {mm.sum():5d} tasks, run {np.mean(T[mm, 3] - T[mm, 2]):7.2f} us = {np.mean(T[mm, 3] - T[mm, 2]) / n:6.2f} per panel, wait {np.mean(T[mm, 1] - T[mm, 0]):6.2f}")
+    if n_stamps >= 8 * n_tasks + 2 * nt + 16:
+        T2 = st[4 * n_tasks + 2 * nt + 16:4 * n_tasks + 2 * nt + 16 + 4 * n_tasks].reshape(n_tasks, 4) - t0
+        m = (typ == 1) & (T2[:, 2] > 0)
+        if m.any():
+            print("strips (late start, %d tasks): start->fact checked %.2f, park %.2f, compute %.2f, drain+sync %.2f" % (
+                m.sum(), (T2[m, 0] - T[m, 2]).mean(), (T2[m, 1] - T2[m, 0]).mean(), (T2[m, 2] - T2[m, 1]).mean(), (T[m, 3] - T2[m, 2]).mean()))
     per = np.diff(chain[:, 1])
     print("chain: potrf (start->fact) mean %.2f us; period per column: first 10 %s ... mean %.2f, max %.2f" % ((chain[:, 1] - chain[:, 0]).mean(), np.round(per[:10], 1), per.mean(), per.max()))
     print("chain: wait before each tile (start_k - fact_{k-1}): mean %.2f  max %.2f" % ((chain[1:, 0] - chain[:-1, 1]).mean(), (chain[1:, 0] - chain[:-1, 1]).max()))
