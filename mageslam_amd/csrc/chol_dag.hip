@@ -26,6 +26,9 @@
 // 4 x 2 block of tiles belong to one group, so that the tasks an XCD runs side by side share their panel operands in its L2 (with one
 // list for all, every task's operands came from beyond the L2: 18 half-panels / us machine-wide against the launches' 24,
 // profiles/r05_dag_trace_v1_6016.txt).
+// A ninth list, the EXPRESS list, holds the small tasks next to the chain -- the split panels, the strips and completing quarters of the two
+// rows below the diagonal, the rhs solves -- and ten workgroups serve nothing else: in a group's list such a task waited up to 30 us for a
+// team behind long updates (profiles/r05_dag_trace_*.txt).
 // The lists are the start order of a list-scheduling simulation of that graph (build_schedule below: measured task costs, earliest
 // column first, a unit takes every panel that is available when its turn comes -- far tiles accumulate panels while near ones are
 // served, which is where the large-K tasks come from).  Every dependency of a task sits earlier in the list or is a chain task
@@ -65,7 +68,9 @@ constexpr int D_ABORT = 3;      // a bounded wait ran out somewhere: everybody l
 constexpr int D_PROG = 4;       // phased hand-off: 8 tile + block columns of the tile being factored that are in memory
 constexpr int D_HEADS = 16;     // cursor of group g's task list at D_HEADS + 16 g (a cache line each)
 constexpr int N_GROUPS = 8;
-constexpr int D_DARR = D_HEADS + 16 * N_GROUPS;      // nt ints: arrivals of the split last panel at diagonal tile j
+constexpr int N_LISTS = N_GROUPS + 1;      // + the express list: the small tasks next to the chain, served by workgroups 1 .. DAG_EXPRESS_WGS only
+constexpr int DAG_EXPRESS_WGS = 10;
+constexpr int D_DARR = D_HEADS + 16 * N_LISTS;      // nt ints: arrivals of the split last panel at diagonal tile j
 __host__ __device__ inline int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 __host__ __device__ inline int d_yprog(int nt) { return D_DARR + nt; }                           // i: panels applied to y_i
 __host__ __device__ inline int d_stripc(int nt) { return d_yprog(nt) + nt; }                     // tri(i, k): strips of tile (i, k) done (8 = L_ik complete)
@@ -104,7 +109,7 @@ struct DagArgs {
     double* S; double* y; double* x; double* Linv; double* Lpub; double* ok; double* stall;
     int* st;                               // state words
     const unsigned long long* tasks;       // the eight lists behind each other
-    int list_off[N_GROUPS], list_len[N_GROUPS];
+    int list_off[N_LISTS], list_len[N_LISTS];
     int ld, nt, n_tasks, quarter_from;
     long long* trace;                      // development (tools/chol_test.hip built with -DDAG_TRACE): per task 4 stamps of the 100 MHz clock, behind them 2 per tile column of the chain
 };
@@ -401,7 +406,9 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagArgs a)
     }
 
     // ================= worker teams =================
-    const int team = wave >> 2, group = (int)(blockIdx.x & (N_GROUPS - 1));
+    // workgroups 1 .. DAG_EXPRESS_WGS serve the express list (the small tasks next to the chain must never queue behind a long update),
+    // the others the list of their group
+    const int team = wave >> 2, group = blockIdx.x <= DAG_EXPRESS_WGS ? N_GROUPS : (int)(blockIdx.x & (N_GROUPS - 1));
     Team t;
     double* const Lsh = sm + team * (LSH_DOUBLES + ISH_DOUBLES);                     // L_kk parked for the strips: sub-diagonal blocks, then inverses
     double* const Ish = Lsh + LSH_DOUBLES;
@@ -575,19 +582,25 @@ struct Ev {
 enum { EV_SREADY, EV_SDONE, EV_DREADY, EV_DDONE, EV_UDONE, EV_POTRF, EV_YREADY, EV_YDONE, EV_UREADY, EV_RDONE, EV_PEARLY };
 
 struct Schedule {
-    std::vector<unsigned long long> lists[N_GROUPS];
+    std::vector<unsigned long long> lists[N_LISTS];
     int quarter_from = 0;
 };
 
 // teams of group g when n_cu workgroups are launched (workgroup b belongs to group b % 8; workgroup 0 is the chain)
-inline int group_teams(int g, int n_cu) { return 2 * ((n_cu - g + N_GROUPS - 1) / N_GROUPS - (g == 0 ? 1 : 0)); }
+inline int group_teams(int g, int n_cu)
+{
+    if (g == N_GROUPS) return 2 * DAG_EXPRESS_WGS;
+    int n = 0;
+    for (int b = DAG_EXPRESS_WGS + 1; b < n_cu; ++b) n += (b & (N_GROUPS - 1)) == g;
+    return 2 * n;
+}
 
 Schedule build_schedule(int nt, int n_cu, int gmax)
 {
     const SimCosts C;
     Schedule out;
-    int n_teams = 0, free_teams[N_GROUPS];
-    for (int g = 0; g < N_GROUPS; ++g) { free_teams[g] = group_teams(g, n_cu); n_teams += free_teams[g]; }
+    int n_teams = 0, free_teams[N_LISTS];
+    for (int g = 0; g < N_LISTS; ++g) { free_teams[g] = group_teams(g, n_cu); if (g < N_GROUPS) n_teams += free_teams[g]; }
     // quarter tiles from the first column whose trailing matrix no longer offers a half-tile task per team
     int& quarter_from = out.quarter_from;
     quarter_from = nt;
@@ -604,7 +617,8 @@ Schedule build_schedule(int nt, int n_cu, int gmax)
     auto post = [&](double t, int kind, int a2 = 0, int b = 0, int c = 0, int d = 0) { events.push(Ev{ t, seq++, kind, a2, b, c, d }); };
     typedef std::tuple<int, int, long, int, int, int> Key;      // (column, row, seq, i, j, unit)
     typedef std::priority_queue<Key, std::vector<Key>, std::greater<Key>> KeyQueue;
-    KeyQueue ready_units[N_GROUPS], ready_strips;                 // updates wait for a team of their tile's group; everything else goes where a team is free
+    std::vector<Key> ready_units[N_LISTS];
+    KeyQueue ready_strips, ready_near_strips;                  // updates wait for a team of their tile's group (next to the diagonal: for an express team); the strips of far tiles go where a team is free
     std::vector<std::pair<int, int>> ready_diag;
     std::vector<int> ready_y;
     double now = 0;
@@ -653,6 +667,8 @@ Schedule build_schedule(int nt, int n_cu, int gmax)
         post(potrf_end[k], EV_POTRF, k);
     };
     auto any_free = [&] { int g = 0; for (int x = 1; x < N_GROUPS; ++x) if (free_teams[x] > free_teams[g]) g = x; return free_teams[g] > 0 ? g : -1; };
+    auto express_free = [&] { return free_teams[N_GROUPS] > 0 ? N_GROUPS : -1; };
+    auto near_diag = [&](int i, int j) { return i - j <= 2; };      // the COMPLETING quarters of these tiles are express tasks (their strips / split panel wait for them)
     // rhs rows: y_i may absorb panels yprog[i] .. min(ysol, strips of row i complete) - 1
     auto rhs_avail = [&](int i) {
         int k = yprog[i];
@@ -665,15 +681,21 @@ Schedule build_schedule(int nt, int n_cu, int gmax)
         while (progress) {
             progress = false;
             int g;
-            while (!ready_diag.empty() && (g = any_free()) >= 0) {
+            while (!ready_diag.empty() && (g = express_free()) >= 0) {
                 const auto [j, p] = ready_diag.back(); ready_diag.pop_back();
                 out.lists[g].push_back(task_word(T_DIAG, j, j, p, j - 1, 1));
                 --free_teams[g]; post(now + C.diag, EV_DDONE, j, p, g); progress = true;
             }
-            while (!ready_y.empty() && (g = any_free()) >= 0) {
+            while (!ready_y.empty() && (g = express_free()) >= 0) {
                 const int k = ready_y.back(); ready_y.pop_back();
                 out.lists[g].push_back(task_word(T_YSOLVE, k, k, 0, 0, 0));
                 --free_teams[g]; post(now + C.ysolve, EV_YDONE, k, g); progress = true;
+            }
+            while (!ready_near_strips.empty() && (g = express_free()) >= 0) {
+                const Key key = ready_near_strips.top(); ready_near_strips.pop();
+                const int i = std::get<3>(key), k = std::get<4>(key), s0 = std::get<5>(key) & 15;
+                out.lists[g].push_back(task_word(T_STRIPS, i, k, s0, 1, 4));
+                --free_teams[g]; post(std::max(now + C.strips4, potrf_end[k] + C.tail), EV_SDONE, i, k, 4, g); progress = true;
             }
             while (!ready_strips.empty() && (g = any_free()) >= 0) {
                 const Key key = ready_strips.top(); ready_strips.pop();
@@ -682,17 +704,32 @@ Schedule build_schedule(int nt, int n_cu, int gmax)
                 --free_teams[g]; post(phased ? std::max(now + C.strips4, potrf_end[k] + C.tail) : now + C.strips4, EV_SDONE, i, k, 4, g); progress = true;
             }
             // rhs rows, lowest row first (the row the next solve waits for)
-            for (int i = 1; i < nt && (g = any_free()) >= 0; ++i) {
+            for (int i = 1; i < nt; ++i) {
                 if (rhs_busy[i]) continue;
+                if ((g = (i <= ysol + 1 ? express_free() : any_free())) < 0) { if (i > ysol + 1) break; else continue; }
                 const int n = std::min(rhs_avail(i), gmax);
                 if (n <= 0) continue;
                 if (yprog[i] + n < i && n < gmax && i > ysol + 1) continue;      // a far row waits until it can take a full task (or everything it still needs)
                 out.lists[g].push_back(task_word(T_RHS, i, i, 0, yprog[i], n));
                 rhs_busy[i] = 1; --free_teams[g]; post(now + C.rhs0 + n * C.rhs1, EV_RDONE, i, n, g); progress = true;
             }
-            for (g = 0; g < N_GROUPS; ++g) {
+            for (g = 0; g < N_LISTS; ++g) {
                 while (free_teams[g] > 0 && !ready_units[g].empty()) {
-                    const Key key = ready_units[g].top(); ready_units[g].pop();
+                    // Which unit next: the ones the chain will need soon first (earliest column), the others by how many panels they can take in
+                    // one task (a block of C is read and written once per task: a far tile served eagerly costs a task per panel)
+                    size_t best = 0;
+                    std::tuple<int, int, int, int, long> best_key{ 2, 0, 0, 0, 0 };
+                    for (size_t x = 0; x < ready_units[g].size(); ++x) {
+                        const Key& c = ready_units[g][x];
+                        const int ci = std::get<3>(c), cj = std::get<4>(c), cu = std::get<5>(c);
+                        const int cid = 4 * tri(ci, cj) + (cu >= 4 ? 2 * (cu - 4) + 1 : cu);
+                        const int avail = std::min(std::min(availc[tri(ci, cj)], limit_of(ci, cj)) - nxt[cid], gmax);
+                        const bool urgent = g == N_GROUPS || cj - fact <= 2 + avail / 2 || avail >= gmax;
+                        const std::tuple<int, int, int, int, long> k2 = urgent ? std::make_tuple(0, cj, ci, 0, std::get<2>(c)) : std::make_tuple(1, -avail, cj, ci, std::get<2>(c));
+                        if (k2 < best_key) { best_key = k2; best = x; }
+                    }
+                    const Key key = ready_units[g][best];
+                    ready_units[g][best] = ready_units[g].back(); ready_units[g].pop_back();
                     const int i = std::get<3>(key), j = std::get<4>(key), u = std::get<5>(key);
                     const int lim = std::min(availc[tri(i, j)], limit_of(i, j));
                     if (u >= 4) {
@@ -702,23 +739,26 @@ Schedule build_schedule(int nt, int n_cu, int gmax)
                         if (n <= 0) { queued[id1] = 0; queued[4 * tri(i, j) + q0] = 0; continue; }
                         if (nxt[id1] + n == limit_of(i, j)) {
                             // this task completes the tile: in quarters (they stay queued and come up again right away, one team each)
-                            for (int q = q0; q <= q1; q += (q1 > q0 ? q1 - q0 : 1)) { ready_units[g].push(Key{ j, i, seq++, i, j, q }); if (q1 == q0) break; }
+                            const int dst = near_diag(i, j) ? N_GROUPS : g;
+                            ready_units[dst].push_back(Key{ j, i, seq++, i, j, q0 });
+                            if (q1 != q0) ready_units[dst].push_back(Key{ j, i, seq++, i, j, q1 });
                             continue;
                         }
                         queued[id1] = 0; queued[4 * tri(i, j) + q0] = 0;
                         out.lists[g].push_back(task_word(T_HALF, i, j, h, nxt[id1], n));
                         busy[id1] = 1; busy[4 * tri(i, j) + q0] = 1; --free_teams[g];
-                        post(now + C.half0 + n * C.half1, EV_UDONE, i, j, u, n);
+                        post(now + C.half0 + n * C.half1, EV_UDONE, i, j, u, n | (g << 8));
                         progress = true;
                         continue;
                     }
                     const int id = 4 * tri(i, j) + u;
-                    queued[id] = 0;
                     const int n = std::min(lim - nxt[id], gmax);
-                    if (n <= 0) continue;
+                    if (n <= 0) { queued[id] = 0; continue; }
+                    if (g != N_GROUPS && near_diag(i, j) && nxt[id] + n == limit_of(i, j)) { ready_units[N_GROUPS].push_back(Key{ j, i, seq++, i, j, u }); continue; }      // (stays queued)
+                    queued[id] = 0;
                     out.lists[g].push_back(task_word(T_QUARTER, i, j, u, nxt[id], n));
                     busy[id] = 1; --free_teams[g];
-                    post(now + C.quarter0 + n * C.quarter1, EV_UDONE, i, j, u, n);
+                    post(now + C.quarter0 + n * C.quarter1, EV_UDONE, i, j, u, n | (g << 8));
                     progress = true;
                 }
             }
@@ -739,10 +779,10 @@ Schedule build_schedule(int nt, int n_cu, int gmax)
                     pearly[e.a] = 1;
                     for (int i = e.a + 1; i < nt && i <= e.a + 2; ++i) release_strips(i, e.a, now);
                     break;
-                case EV_SREADY: ready_strips.push(Key{ e.b, e.a, seq++, e.a, e.b, e.c | (e.d << 4) }); break;
+                case EV_SREADY: ((e.d & 8) ? ready_near_strips : ready_strips).push(Key{ e.b, e.a, seq++, e.a, e.b, e.c | (e.d << 4) }); break;
                 case EV_YREADY: ready_y.push_back(e.a); break;
                 case EV_DREADY: ready_diag.push_back({ e.a, e.b }); break;
-                case EV_UREADY: ready_units[tile_group(e.a, e.b)].push(Key{ e.b, e.a, seq++, e.a, e.b, e.c }); break;
+                case EV_UREADY: ready_units[tile_group(e.a, e.b)].push_back(Key{ e.b, e.a, seq++, e.a, e.b, e.c }); break;
                 case EV_YDONE: ++free_teams[e.b]; ysol = e.a + 1; break;
                 case EV_RDONE: {
                     ++free_teams[e.c];
@@ -767,9 +807,10 @@ Schedule build_schedule(int nt, int n_cu, int gmax)
                 }
                 case EV_UDONE: {
                     const int i = e.a, j = e.b, u = e.c;
-                    ++free_teams[tile_group(i, j)];
-                    if (u >= 4) { for (int q = 2 * (u - 4); q < 2 * (u - 4) + 2; ++q) if (has_quarter(i, j, q)) { busy[4 * tri(i, j) + q] = 0; nxt[4 * tri(i, j) + q] += e.d; } }
-                    else { busy[4 * tri(i, j) + u] = 0; nxt[4 * tri(i, j) + u] += e.d; }
+                    const int n = e.d & 0xff;
+                    ++free_teams[e.d >> 8];
+                    if (u >= 4) { for (int q = 2 * (u - 4); q < 2 * (u - 4) + 2; ++q) if (has_quarter(i, j, q)) { busy[4 * tri(i, j) + q] = 0; nxt[4 * tri(i, j) + q] += n; } }
+                    else { busy[4 * tri(i, j) + u] = 0; nxt[4 * tri(i, j) + u] += n; }
                     if (i != j && !tile_done[tri(i, j)] && tile_complete(i, j)) {
                         tile_done[tri(i, j)] = 1;
                         release_strips(i, j, now + C.hop);
@@ -793,11 +834,11 @@ bool check_schedule(const Schedule& sch, int nt)
     const int qf = sch.quarter_from, ntri = nt * (nt + 1) / 2;
     std::vector<int> stripc(ntri, 0), usum(ntri, 0), uprog(4 * ntri, 0), darr(nt, 0), yprog(nt, 0);
     int fact = 1, ysol = 0;          // potrf(0) depends on nothing
-    size_t cur[N_GROUPS] = {};
+    size_t cur[N_LISTS] = {};
     bool moved = true;
     while (moved) {
         moved = false;
-        for (int g = 0; g < N_GROUPS; ++g) {
+        for (int g = 0; g < N_LISTS; ++g) {
             while (cur[g] < sch.lists[g].size()) {
                 const unsigned long long w = sch.lists[g][cur[g]];
                 const int i = t_i(w), j = t_j(w), u = t_unit(w), k0 = t_k0(w), nk = t_nk(w);
@@ -828,7 +869,8 @@ bool check_schedule(const Schedule& sch, int nt)
                         break;
                     }
                     case T_QUARTER:
-                        if (nk < 1 || k0 + nk > (i == j ? j - 1 : j) || tile_group(i, j) != g || u > 3 || (i == j && u == 2)) return false;
+                        if (nk < 1 || k0 + nk > (i == j ? j - 1 : j) || u > 3 || (i == j && u == 2)) return false;
+                        if (g != tile_group(i, j) && !(g == N_GROUPS && i - j <= 2 && k0 + nk == (i == j ? j - 1 : j))) return false;
                         ok = uprog[4 * tri(i, j) + u] >= k0 && stripc[tri(i, k0 + nk - 1)] >= NBLK && (i == j || stripc[tri(j, k0 + nk - 1)] >= NBLK);
                         if (ok) { if (uprog[4 * tri(i, j) + u] != k0) return false; uprog[4 * tri(i, j) + u] = k0 + nk; usum[tri(i, j)] += nk; }
                         break;
@@ -843,7 +885,7 @@ bool check_schedule(const Schedule& sch, int nt)
             }
         }
     }
-    for (int g = 0; g < N_GROUPS; ++g) if (cur[g] != sch.lists[g].size()) return false;
+    for (int g = 0; g < N_LISTS; ++g) if (cur[g] != sch.lists[g].size()) return false;
     if (fact != nt || ysol != nt) return false;
     for (int i = 1; i < nt; ++i) {
         if (yprog[i] != i) return false;
@@ -853,7 +895,7 @@ bool check_schedule(const Schedule& sch, int nt)
     return true;
 }
 
-struct DagSchedule { unsigned long long* d_tasks = nullptr; int n_tasks = 0, quarter_from = 0, off[N_GROUPS] = {}, len[N_GROUPS] = {}; bool ok = false; };
+struct DagSchedule { unsigned long long* d_tasks = nullptr; int n_tasks = 0, quarter_from = 0, off[N_LISTS] = {}, len[N_LISTS] = {}; bool ok = false; };
 std::mutex g_sched_mutex;
 std::map<std::pair<int, int>, DagSchedule> g_sched;      // (device, nt)
 int g_dag_n_cu = 256;
@@ -880,7 +922,7 @@ const DagSchedule* get_schedule(int nt)
         const Schedule sch = build_schedule(nt, g_dag_n_cu, dag_fuse_max());
         s.quarter_from = sch.quarter_from;
         std::vector<unsigned long long> flat;
-        for (int g = 0; g < N_GROUPS; ++g) { s.off[g] = (int)flat.size(); s.len[g] = (int)sch.lists[g].size(); flat.insert(flat.end(), sch.lists[g].begin(), sch.lists[g].end()); }
+        for (int g = 0; g < N_LISTS; ++g) { s.off[g] = (int)flat.size(); s.len[g] = (int)sch.lists[g].size(); flat.insert(flat.end(), sch.lists[g].begin(), sch.lists[g].end()); }
         if (check_schedule(sch, nt) && hipMalloc(&s.d_tasks, flat.size() * sizeof(unsigned long long)) == hipSuccess) {
             if (hipMemcpy(s.d_tasks, flat.data(), flat.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) == hipSuccess) { s.n_tasks = (int)flat.size(); s.ok = true; }
             else { (void)hipFree(s.d_tasks); s.d_tasks = nullptr; }
@@ -907,7 +949,7 @@ void chol_dag_init_device(int n_cu)
 bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorkspace& ws, double* ok, double* stall, hipStream_t st)
 {
     const int nt = n_pad / TILE;
-    if (nt < dag_min_tiles() || nt > 255 || g_dag_n_cu < 2 * N_GROUPS) return false;
+    if (nt < dag_min_tiles() || nt > 255 || g_dag_n_cu < DAG_EXPRESS_WGS + 1 + 2 * N_GROUPS) return false;
     const DagSchedule* s = get_schedule(nt);
     if (!s) return false;
     int* state = ws.sync + 8;
@@ -915,7 +957,7 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
     DagArgs a;
     a.S = S; a.y = y; a.x = x; a.Linv = ws.Linv; a.Lpub = ws.Linv + (size_t)nt * NBLK * NB * NB; a.ok = ok; a.stall = stall;
     a.st = state; a.trace = ws.dbg; a.tasks = s->d_tasks; a.ld = n_pad; a.nt = nt; a.n_tasks = s->n_tasks; a.quarter_from = s->quarter_from;
-    for (int g = 0; g < N_GROUPS; ++g) { a.list_off[g] = s->off[g]; a.list_len[g] = s->len[g]; }
+    for (int g = 0; g < N_LISTS; ++g) { a.list_off[g] = s->off[g]; a.list_len[g] = s->len[g]; }
     hipLaunchKernelGGL(k_chol_dag, dim3(g_dag_n_cu), dim3(DAG_THREADS), DAG_LDS_BYTES, st, a);
     if (hipGetLastError() != hipSuccess) return false;
     return true;
@@ -923,16 +965,16 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
 
 }  // namespace mage
 
-// Host-only view of the schedule for tests (tests/test_chol_schedule.py): the eight lists for nt tile columns on n_cu compute units, one
-// behind the other (group_len[8] = their lengths), and whether check_schedule accepts them.  Returns the total length (<= cap entries
+// Host-only view of the schedule for tests (tests/test_chol_schedule.py): the nine lists for nt tile columns on n_cu compute units, one
+// behind the other (group_len[9] = their lengths; the last is the express list), and whether check_schedule accepts them.  Returns the total length (<= cap entries
 // are written), negative when the lists fail the check.
 MAGE_EXPORT int mage_debug_chol_schedule(int nt, int n_cu, int fuse_max, unsigned long long* out, int cap, int* quarter_from, int* group_len)
 {
-    if (nt < 2 || nt > 255 || n_cu < 16) return 0;
+    if (nt < 2 || nt > 255 || n_cu < mage::DAG_EXPRESS_WGS + 1 + 2 * mage::N_GROUPS) return 0;
     const mage::Schedule sch = mage::build_schedule(nt, n_cu, fuse_max > 0 ? fuse_max : 8);
     if (quarter_from) *quarter_from = sch.quarter_from;
     int n = 0;
-    for (int g = 0; g < mage::N_GROUPS; ++g) {
+    for (int g = 0; g < mage::N_LISTS; ++g) {
         if (group_len) group_len[g] = (int)sch.lists[g].size();
         for (unsigned long long w : sch.lists[g]) { if (n < cap) out[n] = w; ++n; }
     }
