@@ -27,6 +27,19 @@ namespace mage
         bool ArePointsFixed{ false };        // True if map points should not be optimized
     };
 
+    // What a setter / getter accepts for a vector, matrix or quaternion argument: anything with data() (Eigen::Map, std::array, std::vector,
+    // gsl::span) -- the reference's own Eigen::Map callers (Dependencies/BundlerLib/Include/BundlerLib.h:28-58) -- or a raw float pointer /
+    // array (a C-style integrator).  One template per method over these helpers: a raw array can no longer deduce a `.data()` overload.
+    namespace detail
+    {
+        template <typename T> inline auto cdata(const T& v) -> decltype(static_cast<const float*>(v.data())) { return v.data(); }
+        inline const float* cdata(const float* p) { return p; }
+        template <typename T> inline auto mdata(T&& v) -> decltype(static_cast<float*>(v.data())) { return v.data(); }
+        inline float* mdata(float* p) { return p; }
+        template <typename Q> inline auto qdata(const Q& q) -> decltype(static_cast<const float*>(q.coeffs().data())) { return q.coeffs().data(); }      // x, y, z, w (Eigen::Quaternionf)
+        inline const float* qdata(const float* xyzw) { return xyzw; }
+    }
+
     class BundlerLib
     {
     public:
@@ -48,11 +61,7 @@ namespace mage
         template <typename V3, typename M3, typename V4>
         void SetCameraPose(size_t idx, const V3& position, const M3& orientation, const V4& intrinsics, bool isFixed)
         {
-            Check(mage_ba_set_camera(m_impl.get(), idx, position.data(), orientation.data(), intrinsics.data(), isFixed ? 1 : 0));
-        }
-        void SetCameraPose(size_t idx, const float* position, const float* orientationColMajor, const float* intrinsics, bool isFixed)
-        {
-            Check(mage_ba_set_camera(m_impl.get(), idx, position, orientationColMajor, intrinsics, isFixed ? 1 : 0));
+            Check(mage_ba_set_camera(m_impl.get(), idx, detail::cdata(position), detail::cdata(orientation), detail::cdata(intrinsics), isFixed ? 1 : 0));
         }
 
         void FixCameraPose(size_t idx, bool value) { Check(mage_ba_fix_camera(m_impl.get(), idx, value ? 1 : 0)); }
@@ -66,26 +75,21 @@ namespace mage
 
         void AllocateMapPoints(size_t count) { Check(mage_ba_alloc_points(m_impl.get(), count)); }
         template <typename V3>
-        void SetMapPoint(size_t idx, const V3& point) { Check(mage_ba_set_point(m_impl.get(), idx, point.data())); }
-        void SetMapPoint(size_t idx, const float* point) { Check(mage_ba_set_point(m_impl.get(), idx, point)); }
+        void SetMapPoint(size_t idx, const V3& point) { Check(mage_ba_set_point(m_impl.get(), idx, detail::cdata(point))); }
 
         void AllocateObservations(size_t count) { Check(mage_ba_alloc_observations(m_impl.get(), count)); }
         template <typename V2>
         void SetObservation(size_t idx, const V2& position, size_t cameraIndex, size_t mapPointIndex, float informationMatrixScalar)
         {
-            Check(mage_ba_set_observation(m_impl.get(), idx, position.data(), cameraIndex, mapPointIndex, informationMatrixScalar));
-        }
-        void SetObservation(size_t idx, const float* position, size_t cameraIndex, size_t mapPointIndex, float informationMatrixScalar)
-        {
-            Check(mage_ba_set_observation(m_impl.get(), idx, position, cameraIndex, mapPointIndex, informationMatrixScalar));
+            Check(mage_ba_set_observation(m_impl.get(), idx, detail::cdata(position), cameraIndex, mapPointIndex, informationMatrixScalar));
         }
 
         void AllocateFixedDistanceConstraints(size_t count) { Check(mage_ba_alloc_fixed_distance_constraints(m_impl.get(), count)); }
         void AllocateRelativeRotationConstraints(size_t count) { Check(mage_ba_alloc_relative_rotation_constraints(m_impl.get(), count)); }
         void AllocateRelativeTransformConstraints(size_t count) { Check(mage_ba_alloc_relative_transform_constraints(m_impl.get(), count)); }
 
-        // Tether edges (BundlerLib.h:40-47).  Q is anything with coeffs().data() in x, y, z, w order (Eigen::Quaternionf);
-        // the const float* overloads take the four coefficients directly.
+        // Tether edges (BundlerLib.h:40-47).  Q is anything with coeffs().data() in x, y, z, w order (Eigen::Quaternionf) or the four
+        // coefficients as a float pointer / array.
         void SetFixedDistanceConstraint(size_t idx, size_t cameraIndex1, size_t cameraIndex2, float distance = 1.0f, float weight = 1.0f)
         {
             Check(mage_ba_set_fixed_distance_constraint(m_impl.get(), idx, cameraIndex1, cameraIndex2, distance, weight));
@@ -93,20 +97,12 @@ namespace mage
         template <typename Q>
         void SetRelativeRotationConstraint(size_t idx, size_t cameraIndex1, size_t cameraIndex2, const Q& deltaRotation, float weight = 1.0f)
         {
-            Check(mage_ba_set_relative_rotation_constraint(m_impl.get(), idx, cameraIndex1, cameraIndex2, deltaRotation.coeffs().data(), weight));
-        }
-        void SetRelativeRotationConstraint(size_t idx, size_t cameraIndex1, size_t cameraIndex2, const float* deltaRotationXYZW, float weight = 1.0f)
-        {
-            Check(mage_ba_set_relative_rotation_constraint(m_impl.get(), idx, cameraIndex1, cameraIndex2, deltaRotationXYZW, weight));
+            Check(mage_ba_set_relative_rotation_constraint(m_impl.get(), idx, cameraIndex1, cameraIndex2, detail::qdata(deltaRotation), weight));
         }
         template <typename V3, typename Q>
         void SetRelativeTransformConstraint(size_t idx, size_t cameraIndex1, size_t cameraIndex2, const V3& deltaPosition, const Q& deltaRotation, float weight)
         {
-            Check(mage_ba_set_relative_transform_constraint(m_impl.get(), idx, cameraIndex1, cameraIndex2, deltaPosition.data(), deltaRotation.coeffs().data(), weight));
-        }
-        void SetRelativeTransformConstraint(size_t idx, size_t cameraIndex1, size_t cameraIndex2, const float* deltaPosition, const float* deltaRotationXYZW, float weight)
-        {
-            Check(mage_ba_set_relative_transform_constraint(m_impl.get(), idx, cameraIndex1, cameraIndex2, deltaPosition, deltaRotationXYZW, weight));
+            Check(mage_ba_set_relative_transform_constraint(m_impl.get(), idx, cameraIndex1, cameraIndex2, detail::cdata(deltaPosition), detail::qdata(deltaRotation), weight));
         }
 
         void SetCurrentLambda(float userLambda) { Check(mage_ba_set_lambda(m_impl.get(), userLambda)); }
@@ -139,11 +135,9 @@ namespace mage
         void ReserveOutliers(size_t) {}
 
         template <typename V3, typename M3>
-        void GetPose(size_t idx, V3&& position, M3&& orientation) const { Check(mage_ba_get_pose(m_impl.get(), idx, position.data(), orientation.data())); }
-        void GetPose(size_t idx, float* position, float* orientationColMajor) const { Check(mage_ba_get_pose(m_impl.get(), idx, position, orientationColMajor)); }
+        void GetPose(size_t idx, V3&& position, M3&& orientation) const { Check(mage_ba_get_pose(m_impl.get(), idx, detail::mdata(position), detail::mdata(orientation))); }
         template <typename V3>
-        void GetPoint(size_t idx, V3&& position) const { Check(mage_ba_get_point(m_impl.get(), idx, position.data())); }
-        void GetPoint(size_t idx, float* position) const { Check(mage_ba_get_point(m_impl.get(), idx, position)); }
+        void GetPoint(size_t idx, V3&& position) const { Check(mage_ba_get_point(m_impl.get(), idx, detail::mdata(position))); }
 
         mage_ba* Handle() const { return m_impl.get(); }   // for the bulk setters of mage_ba.h
 

@@ -3,7 +3,7 @@
 // Replaces Core/MAGESLAM/Source/Tracking/FeatureMatcher.h:29-136 (namespace mage):
 //   Match               :66-75     two-way brute-force Hamming match of two analysed images
 //   RadiusMatch         :90-103    multi-query form;  :118-130 single-query form
-//   IndexedMatch        :29-43     with the candidate lists the vocabulary index returned (the index itself is out of scope)
+//   IndexedMatch        :29-43     with the candidate lists the vocabulary index returned, or looked up in the vocabulary tree on the device (BowTree)
 //   GetDescriptorDistance / GetDescriptorDistanceSlow :132-134
 // The reference hands over shared_ptr<AnalyzedImage> (keypoints + descriptors), std::vector<bool> masks, a KeypointSpatialIndex and a
 // thread_memory; what the algorithm reads of them is the keypoint and descriptor arrays, so the shim takes those: anything with
@@ -152,6 +152,41 @@ namespace mage
             shim::CheckMatch(mage_match_indexed(ctx.Handle(), reinterpret_cast<const uint8_t*>(descriptorsA.data()), nA, pa, candidatesInBOffsets.data(), candidatesInB.data(),
                                                 reinterpret_cast<const uint8_t*>(descriptorsB.data()), nB, pb, candidatesInAOffsets.data(), candidatesInA.data(),
                                                 maxHammingDist, minHammingDifference, out, cap, count), "IndexedMatch");
+        });
+    }
+
+    // The vocabulary tree of BoW/OnlineBow as the flat arrays of mage_bow_tree (node medoids, child lists in childrenIDs order; node 0 = root)
+    struct BowTree
+    {
+        std::vector<uint8_t> nodeDescriptors;      // 32 bytes per node
+        std::vector<int32_t> childOffsets, children;
+        mage_bow_tree View() const { return mage_bow_tree{ nodeDescriptors.data(), childOffsets.data(), children.data(), static_cast<int32_t>(childOffsets.size()) - 1 }; }
+    };
+    // OnlineBow::FindLeafNode (BoW/OnlineBow.cpp:289-311) for a batch of descriptors
+    template <typename Descriptors>
+    std::vector<int32_t> FindLeafNodes(MatcherContext& ctx, const BowTree& tree, const Descriptors& descriptors)
+    {
+        std::vector<int32_t> leaves(descriptors.size());
+        const mage_bow_tree t = tree.View();
+        shim::CheckMatch(mage_bow_find_leaf_batch(ctx.Handle(), &t, reinterpret_cast<const uint8_t*>(descriptors.data()), static_cast<int>(descriptors.size()), leaves.data()), "FindLeafNodes");
+        return leaves;
+    }
+    // IndexedMatch (FeatureMatcher.cpp:192-292) as the reference runs it, candidate lists from the vocabulary (BaseBow::QueryFeatures): per node the
+    // features of image A / image B filed under it (m_NodeKeyframeMap[node][keyframe].indexes), CSR over the tree's nodes
+    template <typename DescriptorsA, typename DescriptorsB, typename DMatchVec>
+    unsigned int IndexedMatch(MatcherContext& ctx, const BowTree& tree, const DescriptorsA& descriptorsA, const std::vector<int32_t>& leafFeaturesAOffsets, const std::vector<int32_t>& leafFeaturesA,
+                              const DescriptorsB& descriptorsB, const std::vector<int32_t>& leafFeaturesBOffsets, const std::vector<int32_t>& leafFeaturesB,
+                              const std::vector<bool>& imageAMask, const std::vector<bool>& imageBMask, int maxHammingDist, int minHammingDifference, DMatchVec& goodMatches)
+    {
+        std::vector<uint8_t> ma, mb;
+        const uint8_t* pa = shim::Bytes(imageAMask.empty() ? nullptr : &imageAMask, ma);
+        const uint8_t* pb = shim::Bytes(imageBMask.empty() ? nullptr : &imageBMask, mb);
+        const int nA = static_cast<int>(descriptorsA.size()), nB = static_cast<int>(descriptorsB.size());
+        const mage_bow_tree t = tree.View();
+        return shim::Append(goodMatches, static_cast<size_t>(nA), [&](mage_dmatch* out, int cap, int* count) {
+            shim::CheckMatch(mage_match_indexed_bow(ctx.Handle(), &t, reinterpret_cast<const uint8_t*>(descriptorsA.data()), nA, pa, leafFeaturesAOffsets.data(), leafFeaturesA.data(),
+                                                    reinterpret_cast<const uint8_t*>(descriptorsB.data()), nB, pb, leafFeaturesBOffsets.data(), leafFeaturesB.data(),
+                                                    maxHammingDist, minHammingDifference, out, cap, count), "IndexedMatch");
         });
     }
 

@@ -9,7 +9,8 @@
  * Masks are applied by gathering (FeatureMatcher.cpp:88-110) and indices are mapped back (:160-163); both are
  * done by mage_match_masked below so a caller can pass its std::vector<bool>-derived byte masks directly.
  * RadiusMatch (FeatureMatcher.cpp:294-446) is mage_match_radius below; IndexedMatch (:192-292) is
- * mage_match_indexed: its candidate lists are whatever the caller's vocabulary index (BoW QueryFeatures, out of scope) returned.
+ * mage_match_indexed: its candidate lists are whatever the caller's vocabulary index returned; mage_match_indexed_bow looks them up in the
+ * vocabulary tree on the device (mage_bow_find_leaf_batch = OnlineBow::FindLeafNode).  Training the tree stays with the caller.
  */
 #ifndef MAGE_MATCH_H
 #define MAGE_MATCH_H
@@ -89,6 +90,36 @@ mage_status mage_match_radius(mage_matcher* h, const mage_keypoint* query_keypoi
 mage_status mage_match_indexed(mage_matcher* h, const uint8_t* descriptors_a, int nA, const uint8_t* mask_a, const int32_t* cand_b_offsets,
                                const int32_t* cand_b, const uint8_t* descriptors_b, int nB, const uint8_t* mask_b, const int32_t* cand_a_offsets,
                                const int32_t* cand_a, int max_hamming_dist, int min_hamming_difference, mage_dmatch* out, int capacity, int* count);
+
+/* The vocabulary tree of BoW/OnlineBow (Core/MAGESLAM/Source/BoW/OnlineBow.h: m_nodes, each a medoid descriptor + childrenIDs) as flat arrays:
+ * node n's medoid is node_descriptors[32 n ..], its children are children[child_offsets[n] .. child_offsets[n + 1]) IN THE ORDER of the
+ * reference's childrenIDs; node 0 is the root (its descriptor is never compared); a node without children is a leaf.  Every child index
+ * must be larger than its parent's (nodes are appended as they are created, OnlineBow.cpp:560-640): anything else is MAGE_ERR_INVALID_ARGUMENT.
+ * Training (k-medoids, OnlineBow.cpp:325-500) and the node -> keyframe maps are the caller's. */
+typedef struct mage_bow_tree {
+    const uint8_t* node_descriptors;   /* n_nodes x 32 bytes */
+    const int32_t* child_offsets;      /* n_nodes + 1 */
+    const int32_t* children;           /* child_offsets[n_nodes] node indices */
+    int32_t n_nodes;
+} mage_bow_tree;
+
+/* OnlineBow::FindLeafNode (BoW/OnlineBow.cpp:289-311) for n descriptors at once: from the root, at every level the child whose medoid is
+ * nearest in Hamming distance (GetDescriptorDistance), strict '<' in child-list order -- the first of equally near children wins -- until
+ * a node without children; leaf_ids[i] = that node.  Host pointers. */
+mage_status mage_bow_find_leaf_batch(mage_matcher* h, const mage_bow_tree* tree, const uint8_t* descriptors, int n, int32_t* leaf_ids);
+
+/* IndexedMatch (Tracking/FeatureMatcher.cpp:192-292) with its candidate lists looked up the way the reference does (:223-227, :253-257 ->
+ * OnlineBow::QueryFeatures, BoW/OnlineBow.cpp:115-132): the candidates of a descriptor are the features of the OTHER image filed under the
+ * leaf the descriptor descends to, in filing order.
+ *   leaf_features_b_offsets[n_nodes + 1], leaf_features_b[]   per node the indices (into B) of image B's features filed under it
+ *   leaf_features_a_offsets[n_nodes + 1], leaf_features_a[]   the same for image A (the reverse check)
+ * (= m_NodeKeyframeMap[node][keyframe].indexes of the two keyframes; only leaves hold features).  Everything else -- masks, limits, the
+ * strict updates in list order, the output records -- as mage_match_indexed.  One upload, two launches (the leaves of all nA + nB
+ * descriptors, then the two-way test), one read-back: no host trip per descriptor. */
+mage_status mage_match_indexed_bow(mage_matcher* h, const mage_bow_tree* tree, const uint8_t* descriptors_a, int nA, const uint8_t* mask_a,
+                                   const int32_t* leaf_features_a_offsets, const int32_t* leaf_features_a, const uint8_t* descriptors_b, int nB,
+                                   const uint8_t* mask_b, const int32_t* leaf_features_b_offsets, const int32_t* leaf_features_b, int max_hamming_dist,
+                                   int min_hamming_difference, mage_dmatch* out, int capacity, int* count);
 
 /* HIP-event time of the most recent batched call's kernel, in milliseconds. */
 mage_status mage_matcher_last_kernel_ms(const mage_matcher* h, double* ms);

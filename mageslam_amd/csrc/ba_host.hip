@@ -296,7 +296,7 @@ struct mage_ba {
     struct ImageStager {
         bool on = false;
         size_t scratch = 0;                                               // device-only bytes behind the uploaded part
-        std::vector<std::function<void(unsigned char* dev, const char* host, size_t up_bytes)>> binds;
+        std::vector<std::function<void(unsigned char* dev, const std::function<size_t(const void*)>& image_offset, size_t up_bytes)>> binds;      // image_offset: where a pinned staging address lies in the image
     } img;
     // ---- the tracker's per-frame problems (frame_step below): one image up, one launch, one record back; no structure stays on the device
     DevBuf<unsigned char> d_frame;
@@ -370,8 +370,8 @@ template <typename T>
 mage_status stage_push(mage_ba* h, DevBuf<T>& d, const T* src_pinned, size_t count)
 {
     if (h->img.on) {
-        h->img.binds.push_back([&d, src_pinned, count](unsigned char* dev, const char* host, size_t) {
-            d.alias(reinterpret_cast<T*>(dev + (reinterpret_cast<const char*>(src_pinned) - host)), count);
+        h->img.binds.push_back([&d, src_pinned, count](unsigned char* dev, const std::function<size_t(const void*)>& image_offset, size_t) {
+            d.alias(reinterpret_cast<T*>(dev + image_offset(src_pinned)), count);
         });
         return MAGE_OK;
     }
@@ -392,7 +392,7 @@ mage_status stage_array(mage_ba* h, DevBuf<T>& d, size_t count, int fill = -1)
         }
         const size_t off = h->img.scratch;
         h->img.scratch += (count * sizeof(T) + 255) & ~(size_t)255;
-        h->img.binds.push_back([&d, off, count](unsigned char* dev, const char*, size_t up_bytes) { d.alias(reinterpret_cast<T*>(dev + up_bytes + off), count); });
+        h->img.binds.push_back([&d, off, count](unsigned char* dev, const std::function<size_t(const void*)>&, size_t up_bytes) { d.alias(reinterpret_cast<T*>(dev + up_bytes + off), count); });
         return MAGE_OK;
     }
     MAGE_TRY(d.reserve(count));
@@ -403,14 +403,24 @@ mage_status stage_commit(mage_ba* h)
 {
     if (!h->img.on) return MAGE_OK;
     PinnedArena& A = h->build_arena;
-    if (A.blocks.size() != 1) return fail(MAGE_ERR_DEVICE, "small-problem image: the staging arena spilled into %zu blocks", A.blocks.size());
-    const size_t up = (A.blocks[0].used + 255) & ~(size_t)255;
+    // The arena is normally ONE 32 MB block and the image one copy.  A problem whose lists outgrow it (many cameras sharing few
+    // points: the contribution lists grow with the square of a landmark's cameras) spills into further blocks: they become consecutive
+    // parts of the image, one copy each.
+    std::vector<size_t> base(A.blocks.size() + 1, 0);
+    for (size_t b = 0; b < A.blocks.size(); ++b) base[b + 1] = base[b] + ((A.blocks[b].used + 255) & ~(size_t)255);
+    const size_t up = base[A.blocks.size()];
+    const std::function<size_t(const void*)> image_offset = [&A, &base](const void* q) -> size_t {
+        const char* c = static_cast<const char*>(q);
+        for (size_t b = 0; b < A.blocks.size(); ++b) if (c >= A.blocks[b].p && c < A.blocks[b].p + A.blocks[b].cap) return base[b] + (size_t)(c - A.blocks[b].p);
+        return 0;      // (unreachable: every staged array was taken from this arena)
+    };
     // views of an earlier image are about to be re-pointed, memory an earlier (larger) build owned goes back to the cache: nothing of it may be in flight
     MAGE_HIP(hipStreamSynchronize(h->stream));
     MAGE_TRY(h->d_image.reserve(up + h->img.scratch + 256));
-    for (auto& b : h->img.binds) b(h->d_image.p, A.blocks[0].p, up);
+    for (auto& b : h->img.binds) b(h->d_image.p, image_offset, up);
     h->img.binds.clear();
-    MAGE_HIP(hipMemcpyAsync(h->d_image.p, A.blocks[0].p, A.blocks[0].used, hipMemcpyHostToDevice, h->stream));
+    for (size_t b = 0; b < A.blocks.size(); ++b)
+        if (A.blocks[b].used) MAGE_HIP(hipMemcpyAsync(h->d_image.p + base[b], A.blocks[b].p, A.blocks[b].used, hipMemcpyHostToDevice, h->stream));
     return MAGE_OK;
 }
 
@@ -589,6 +599,16 @@ struct ListSizes {
 // Which twin builds the lists (ba_build.h).  MAGE_BA_BUILD=host|device forces one (A/B, tests); by default the device builds
 // everything except the tracker's per-frame pose-only problems (a few hundred observations of fixed points: the three short host
 // loops cost less than the two read-backs of the device build).
+// MAGE_BA_CONSERVATIVE=1 takes every fall-back this file has for a device or a runtime that lacks something the fast paths rely on -- the
+// host-built lists as per-buffer uploads instead of one image, read-back copies instead of the kernels writing the pinned mirror, the
+// pose-only solve with its arrays in HBM behind an upload, the outlier pass as a call of its own instead of queued behind the last trial --
+// so that the tests can hold them against the defaults (same results, tests/test_ba_gpu.py).
+bool conservative_paths()
+{
+    static const bool on = std::getenv("MAGE_BA_CONSERVATIVE") != nullptr;
+    return on;
+}
+
 bool use_device_build(const mage_ba* h, size_t n_obs)
 {
     const char* e = std::getenv("MAGE_BA_BUILD");
@@ -596,7 +616,7 @@ bool use_device_build(const mage_ba* h, size_t n_obs)
     if (e && e[0] == 'd') return true;
     // (round 4: with the host-built lists going up as ONE image -- ImageStager -- the host build wins up to a few thousand observations:
     // what a small problem pays for is the NUMBER of operations on the stream, ~40 for the device build's kernels, fills and read-backs)
-    static const size_t host_max = std::getenv("MAGE_BA_HOST_BUILD_MAX_OBS") ? (size_t)std::atol(std::getenv("MAGE_BA_HOST_BUILD_MAX_OBS")) : 10000;      // measured (one-iteration bundler, create -> destroy): 2 000 observations 0.17 against 0.26 ms, 4 000: 0.27 / 0.36, 8 000: 0.38 / 0.40, 16 000: 0.60 / 0.52
+    constexpr size_t host_max = 10000;      // measured (one-iteration bundler, create -> destroy): 2 000 observations 0.17 against 0.26 ms, 4 000: 0.27 / 0.36, 8 000: 0.38 / 0.40, 16 000: 0.60 / 0.52
     return !h->points_fixed && n_obs >= host_max;
 }
 
@@ -968,8 +988,7 @@ mage_status initialize_optimization(mage_ba* h)
     if (!arena.blocks.empty()) { MAGE_HIP(hipStreamSynchronize(h->stream)); arena.release(); }
     const bool on_device = use_device_build(h, h->obs.size());
     // small problems built on the host go to the device as ONE image (stage_push / stage_array / stage_commit above)
-    static const bool image_off = std::getenv("MAGE_BA_NO_IMAGE") != nullptr;
-    h->img.on = !on_device && !image_off && !h->state_on_device && h->shard_ranks == 0 && h->obs.size() <= 65536 && nc <= 4096 && np <= 65536;
+    h->img.on = !on_device && !conservative_paths() && !h->state_on_device && h->shard_ranks == 0 && h->obs.size() <= 65536 && nc <= 4096 && np <= 65536;
     h->img.scratch = 0; h->img.binds.clear();
     struct ImageOff { mage_ba* h; ~ImageOff() { h->img.on = false; h->img.binds.clear(); } } image_off_at_exit{ h };      // every exit leaves the mode off
     if (!h->state_on_device) MAGE_TRY(upload_state(h, &arena));
@@ -1097,7 +1116,7 @@ mage_status initialize_optimization(mage_ba* h)
     // per camera) also parks the cameras' partial (U, b_c) sums behind its chi2 partials
     MAGE_TRY(stage_array(h, h->d_partial, std::max<size_t>(4 * 1024, std::max<size_t>((size_t)nb_l + nb_c, (size_t)nlm * 16 / 256 + (size_t)nfc * 4 * 29 + 8)) + 16));          // (the fused large-problem form needs nlm / 32 + nfc entries: covered)
     {   // small problems that free their points: the kept estimate rides the post-pass read-back (k_small_classify)
-        static const bool off = std::getenv("MAGE_BA_NO_RESULT_RIDE") != nullptr;
+        const bool off = conservative_paths();
         const size_t want = (size_t)nc * 8 + (size_t)np * 4;
         h->res_doubles = (!off && points_free && h->shard_ranks == 0 && want <= RES_CAP && ba_small_shape_applies(nfc, nT, nL)) ? want : 0;
         h->result_in_mirror = false;
@@ -1105,7 +1124,7 @@ mage_status initialize_optimization(mage_ba* h)
     MAGE_TRY(stage_array(h, h->d_scal, SC_PAD + h->res_doubles + ((size_t)nL + 2) / 2 + 1));          // scalars, (the estimate,) then up to n_L outlier ids (32-bit)
     h->out_cursor = 0;                                                        // d_queue (with the cursor) starts as zeros
     MAGE_TRY(stage_array(h, h->d_Linv, chol_workspace_doubles(n_pad)));
-    MAGE_TRY(stage_array(h, h->d_queue, chol_sync_ints(n_pad) + 64 + BA_FOLD_COUNTER_INTS, 0));      // + the small-path counter + the outlier cursor; recycled memory arrives dirty
+    MAGE_TRY(stage_array(h, h->d_queue, chol_sync_ints(n_pad) + 64, 0));      // + the small-path counter + the outlier cursor; recycled memory arrives dirty
     MAGE_TRY(stage_array(h, h->d_flagL, (size_t)nL + 1));
     MAGE_TRY(stage_array(h, h->d_L_active, (size_t)nL + 1, 1));
     MAGE_TRY(ensure_pinned_mirrors(h));
@@ -1139,8 +1158,7 @@ mage_status initialize_optimization(mage_ba* h)
     // buffer, so the first trial clears all of it
     v.tile_env = nullptr;
     h->S_outside_skyline_is_zero = false;
-    static const bool skyline_off = std::getenv("MAGE_BA_ZERO_FULL") != nullptr;
-    if (n_pad >= 1024 && h->shard_ranks == 0 && !skyline_off) {
+    if (n_pad >= 1024 && h->shard_ranks == 0) {
         MAGE_TRY(h->d_tile_env.reserve((size_t)n_pad / CHOL_TILE + 1));
         ba_launch_tile_envelope(v, h->d_tile_env.p, st);
         h->tile_env_valid = true;
@@ -1155,7 +1173,10 @@ mage_status initialize_optimization(mage_ba* h)
         const bool compact_w = points_free && !h->dup_slots && (nfc * 6 > 128 || nT > 0 || h->shard_ranks > 0) && h->shard_ranks >= 0 && ba_compact_w_enabled();
         const double bW = compact_w ? 32.0 : 144.0;
         h->prof.linearize_bytes_each = dL * (3 * 24 + 16 + 4) + dW * bW + dP * (80 + 3 * 32) + dC * 336;
-        h->prof.schur_bytes_each = dP * (160 + 48 + 32) + 2 * bW * dW + 8.0 * (double)ncon + 288.0 * nblk + 4.0 * (double)n_pad * n_pad;
+        // (the zero-fill of S counts only where the whole lower triangle is cleared: with the skyline clear -- unsharded systems of >= 1024
+        // rows -- a steady trial clears the few tiles inside the envelope, whose number only the device knows: left out rather than overstated)
+        const bool full_clear = !(n_pad >= 1024 && h->shard_ranks == 0);
+        h->prof.schur_bytes_each = dP * (160 + 48 + 32) + 2 * bW * dW + 8.0 * (double)ncon + 288.0 * nblk + (full_clear ? 4.0 * (double)n_pad * n_pad : 0.0);
         h->prof.update_bytes_each = bW * dW + dP * (32 + 48 + 32 + 64 + 32) + dL * 40;
     }
     h->iteration = 0;
@@ -1209,14 +1230,12 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
         return MAGE_OK;
     };
     int* counter = h->d_queue.p + chol_sync_ints(v.n_pad);       // one int behind the factorisation's counters, zero between launches
-    int* fold_counters = counter + 64;                           // the two-level count of the folded reductions (ba_kernels.h), zero between launches
     if (h->profiling) MAGE_HIP(hipEventRecord(h->ev_p[0], st));
     // W in its compact form (x/z, y/z, 1/z, weight per slot: ba_kernels.h) whenever the fused linearisation writes it
     v.compact = (!small && v.points_free && ba_fused_linearize_applies(v) && ba_compact_w_enabled()) ? 1 : 0;
     if (v.compact && !h->positions_valid) {
         MAGE_TRY(h->d_w_pos.reserve((size_t)v.n_w + 1)); MAGE_TRY(h->d_pos_lm.reserve((size_t)v.n_w + 1)); MAGE_TRY(h->d_con_pos.reserve(h->n_con + 1));
-        static const bool row_order = std::getenv("MAGE_BA_SCHUR_ROW_ORDER") != nullptr;      // A/B: the blocks of an XCD in row order (blk_order itself)
-        const bool lpt = !row_order && v.n_blk_slots > 0;
+        const bool lpt = v.n_blk_slots > 0;          // every XCD's run of blocks longest first (slot_order)
         if (lpt) MAGE_TRY(h->d_slot_order.reserve((size_t)v.n_blk_slots + 8));
         ba_launch_build_positions(v, h->d_w_pos.p, h->d_pos_lm.p, h->d_con_pos.p, lpt ? h->d_slot_order.p : nullptr, st);
         v.w_pos = h->d_w_pos.p; v.pos_lm = h->d_pos_lm.p; v.con_pos = h->d_con_pos.p; v.slot_order = lpt ? h->d_slot_order.p : nullptr;
@@ -1224,7 +1243,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
     }
     int chi_partials = 0;        // > 0: the linearisation left its chi2 partials for the first trial's Schur launch to add (ba_fused_linearize)
     if (small) ba_small_linearize(v, huber, h->iteration == 0, counter, st);
-    else if (ba_fused_linearize_applies(v)) chi_partials = ba_fused_linearize(v, huber, fold_counters, st, /*defer_chi_fold=*/!sharded && !(h->iteration == 0 && !(h->user_lambda > 0)));      // (iteration 0 without a user lambda: max |diag| is reduced through v.partial before the Schur launch)
+    else if (ba_fused_linearize_applies(v)) chi_partials = ba_fused_linearize(v, huber, counter, st, /*defer_chi_fold=*/!sharded && !(h->iteration == 0 && !(h->user_lambda > 0)));      // (iteration 0 without a user lambda: max |diag| is reduced through v.partial before the Schur launch)
     else {
         ba_launch_error(v, false, huber, st);
         ba_launch_linearize(v, huber, st);
@@ -1277,8 +1296,8 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
             if (plan) {      // the outlier pass rides behind the trial (see the large-problem branch)
                 ClassifyAfterTrial c{};
                 c.chi_ref = currentChi; c.chi_on_device = have_chi ? 0 : 1; c.trials_done = qmax + 1; c.last_iteration = plan->last_iteration ? 1 : 0;
-                // (the launch writes the pinned mirror itself -- MAGE_BA_NO_PUBLISH=1: a read-back copy behind it, for A/B)
-                static const bool no_publish = std::getenv("MAGE_BA_NO_PUBLISH") != nullptr;
+                // (the launch writes the pinned mirror itself; MAGE_BA_CONSERVATIVE=1 or a mirror the device cannot address: a read-back copy behind it)
+                const bool no_publish = conservative_paths();
                 double* mirror = nullptr;
                 if (!no_publish) {
                     void* dp = nullptr;
@@ -1303,7 +1322,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
             if (h->profiling || h->profiling_factor) MAGE_HIP(hipEventRecord(h->ev[1], st));
             chol_factor_solve(v.S, v.y, v.xc, v.n_pad, ws, v.scal + SC_CHOL_OK, st);
             if (h->profiling || h->profiling_factor) MAGE_HIP(hipEventRecord(h->ev[2], st));
-            if (ba_update_and_trial_error_fuses(v)) ba_launch_update_and_trial_error(v, lambda, adds_damping ? lambda : 0.0, huber, fold_counters, st);
+            if (ba_update_and_trial_error_fuses(v)) ba_launch_update_and_trial_error(v, lambda, adds_damping ? lambda : 0.0, huber, st);
             else {
                 ba_launch_update(v, lambda, adds_damping ? lambda : 0.0, st);
                 ba_launch_error(v, true, huber, st);
@@ -1314,7 +1333,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
                 ClassifyAfterTrial c{};
                 c.chi_ref = currentChi; c.chi_on_device = have_chi ? 0 : 1; c.trials_done = qmax + 1; c.last_iteration = plan->last_iteration ? 1 : 0;
                 int* small_counter = h->d_queue.p + chol_sync_ints(v.n_pad);
-                ba_launch_classify_after_trial(v, c, plan->max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, small_counter + 64, st);
+                ba_launch_classify_after_trial(v, c, plan->max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, st);
                 speculated = true;
             }
             if (sharded) {
@@ -1550,10 +1569,9 @@ mage_status frame_step(mage_ba* h, const float* huber, size_t n_iter, float max_
     v.n_cams = nc; v.n_pts = np; v.n_L = nL; v.n_fc = nfc; v.points_free = 0; v.n_pad = CHOL_TILE;
     // DIRECT (round 4): the staged kernel reads every input exactly once (into LDS) and writes its record, the flags and the two pose
     // buffers exactly once -- so it takes them from / leaves them in the pinned image itself, across PCIe, and the two copy commands
-    // (a blit launch and a dependency each, ~10 us of a 65 us call) are not queued at all.  MAGE_BA_FRAME_COPIES=1: upload + read-back.
-    static const bool frame_copies = std::getenv("MAGE_BA_FRAME_COPIES") != nullptr;
-    static const bool staged_off = std::getenv("MAGE_BA_POSE_LM_IN_HBM") != nullptr;      // A/B: the arrays left in HBM
-    bool direct = !frame_copies && !staged_off && ba_pose_lm_staged_fits(v);
+    // (a blit launch and a dependency each, ~10 us of a 65 us call) are not queued at all.  MAGE_BA_CONSERVATIVE=1: upload + read-back, arrays in HBM.
+    const bool staged_off = conservative_paths();
+    bool direct = !staged_off && ba_pose_lm_staged_fits(v);
     if (direct) {
         void* dev_img = nullptr;
         if (hipHostGetDevicePointer(&dev_img, img, 0) == hipSuccess && dev_img) D = static_cast<unsigned char*>(dev_img);
@@ -1579,6 +1597,7 @@ mage_status frame_step(mage_ba* h, const float* huber, size_t n_iter, float max_
         if (staged_off || !ba_launch_pose_lm_staged(v, a, d_res, D + o_flag, d_q, h->stream)) ba_launch_pose_lm(v, a, d_res, D + o_flag, d_q, h->stream);
         MAGE_HIP(hipMemcpyAsync(back, D + o_res, back_bytes, hipMemcpyDeviceToHost, h->stream));
     }
+    MAGE_HIP(hipGetLastError());          // a refused launch must not be followed by reading stale poses out of `back` behind a completed event
     MAGE_HIP(hipEventRecord(h->ev[3], h->stream));
     for (;;) {
         const hipError_t e = hipEventQuery(h->ev[3]);
@@ -2127,7 +2146,7 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
             // slower than a 100-byte one, so a run without outliers does not pay for it)
             const size_t out_expect = h->out_expect;
             auto prefix_now = [&]() { return std::min<size_t>(std::min<size_t>(OUT_PREFIX, (size_t)h->view.n_L), std::max<size_t>(64, 2 * out_expect)); };
-            static const bool no_spec = std::getenv("MAGE_BA_NO_QUEUED_POSTPASS") != nullptr;
+            const bool no_spec = conservative_paths();
             bool post_done = false;
             size_t prefix = 0;
             for (size_t it = 0; it < n_iter; ++it) {
@@ -2150,7 +2169,7 @@ MAGE_EXPORT mage_status mage_ba_step(mage_ba* h, const float* huber, size_t n_it
             ids_from_device = true;
             if (!post_done) {
                 if (!sharded && ba_small_applies(v)) ba_small_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, small_counter, h->res_doubles ? h->d_scal.p + SC_PAD : nullptr, h->stream);
-                else ba_launch_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, small_counter + 64, h->stream);
+                else ba_launch_classify(v, (double)max_err_sq, h->d_out_ids, small_counter + 1, h->out_cursor, h->stream);
                 prefix = prefix_now();
             }
             if (sharded) {

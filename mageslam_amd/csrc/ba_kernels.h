@@ -104,7 +104,6 @@ void ba_launch_linearize(const BaDeviceView& v, double huber_delta, hipStream_t 
 void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st, const double* udiag_sum = nullptr);                                       // -> scal[SC_MAXDIAG]
 void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st);                          // Dinv,db,S,y
 void ba_launch_build_positions(const BaDeviceView& v, int* w_pos, int* pos_lm, ConPos* con_pos, int* slot_order, hipStream_t st); // w_pos / pos_lm / con_pos from camS, w_lm, con
-bool ba_w_camera_major();                                                                             // false with MAGE_BA_W_LANDMARK_MAJOR=1
 void ba_launch_tile_envelope(const BaDeviceView& v, int* tile_env, hipStream_t st);                  // the skyline of S by tile rows, from blk_ij and the tether pairs
 void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st);                         // xl, trial state, scal[SC_SCALE]
 // landmark-sharded maps (include/mage_ba.h: mage_ba_set_landmark_shard)
@@ -112,14 +111,12 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, do
 void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, double pad_diag, int fold_chi_partials, hipStream_t st);   // + the deferred chi2 fold of ba_fused_linearize
 void ba_launch_update(const BaDeviceView& v, double lambda, double lambda_cam, hipStream_t st);
 bool ba_update_and_trial_error_fuses(const BaDeviceView& v);                                             // free points: update + trial chi2 in three launches
-void ba_launch_update_and_trial_error(const BaDeviceView& v, double lambda, double lambda_cam, double huber_delta, int* fold_counters, hipStream_t st);   // fold_counters: BA_FOLD_COUNTER_INTS zero-between-launches ints of the handle (the last block of k_backsub adds the partials) or nullptr
-constexpr int BA_FOLD_GROUPS = 16, BA_FOLD_COUNTER_INTS = 64 * (1 + BA_FOLD_GROUPS);   // the zero-between-launches words of last_block_arrives_through (ba_kernels.hip)
-bool ba_reductions_fold();                                                                             // true with MAGE_BA_FOLD_REDUCTIONS=1 (measured: no gain over the k_reduce_sum launches, which stay the default)
+void ba_launch_update_and_trial_error(const BaDeviceView& v, double lambda, double lambda_cam, double huber_delta, hipStream_t st);
 size_t ba_packed_doubles(int n_pad);                                                                   // lower tiles of S + y
 void ba_launch_pack_lower(const BaDeviceView& v, double* packed, bool to_packed, hipStream_t st);
 void ba_launch_gather_udiag(const BaDeviceView& v, double* out6_per_camera, hipStream_t st);
 bool ba_launch_allreduce_local(double* const* bufs, int n, size_t count, int op, hipStream_t st);
-void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* fold_counter, hipStream_t st); // scal[SC_ERRSUM..SC_NOUT]
+void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, hipStream_t st); // scal[SC_ERRSUM..SC_NOUT]
 // The same post-pass queued BEHIND an LM trial, before the host has seen the trial's scalars: every workgroup repeats the host's
 // decision (OptimizationAlgorithmLevenberg::solve) from scal[] -- accepted / rejected, trial loop over or not -- and
 // classifies only when this StepBundleAdjustment call has taken its last trial (it then reads the KEPT estimate: the trial's
@@ -130,7 +127,7 @@ struct ClassifyAfterTrial {
     int trials_done;                      // trials of this iteration including the one just queued
     int last_iteration;                   // no LM iteration follows in this call
 };
-void ba_launch_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* fold_counter, hipStream_t st);
+void ba_launch_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, hipStream_t st);
 
 // Small problems (reduced camera system of order <= 128, no tethers): one LM trial in five launches instead of ~22
 // (ba_kernels.hip, "SMALL PROBLEMS").  `counter` is one zero-initialised device int owned by the handle (the kernels leave it 0).

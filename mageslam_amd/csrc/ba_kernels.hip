@@ -201,44 +201,6 @@ __global__ __launch_bounds__(256) void k_reduce_sum(const double* __restrict__ i
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// The same final stage WITHOUT a launch of its own (round 4): thread 0 of every block writes its partial(s) THROUGH to memory
-// (agent-scope stores), waits for the acknowledgement and counts itself in; the block that arrives last takes ONE acquire and adds
-// the partials in k_reduce_sum's order.  The "last block folds" pattern with ordinary stores needs a release fence per block -- a
-// write-back of its XCD's L2, slower than the launch it saves on kernels that stream hundreds of megabytes through those L2s; a
-// write-through store needs none.  `counters`: BA_FOLD_COUNTER_INTS zero-between-launches ints of the handle.  Opt-in (MAGE_BA_FOLD_REDUCTIONS=1): see ba_reductions_fold.
-// ---------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(1))) double global_double_t;
-__device__ __forceinline__ void store_partial_through(double* p, double val)
-{
-    __hip_atomic_store((global_double_t*)p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// thread 0 has issued its store_partial_through()s; every thread of the block calls this.  Thousands of agent-scope increments of ONE
-// word are served one after another where the XCDs meet (~8 ns each: +14 ... +28 us per kernel when tried), so the count is kept in
-// two levels: block b counts into group b % 16's word (its own 256-byte line), the block that completes a group counts into the top word.
-__device__ __forceinline__ bool last_block_arrives_through(int* __restrict__ counters, int n_blocks)
-{
-    __shared__ int is_last_wt;
-    if (threadIdx.x == 0) {
-        constexpr int NG = BA_FOLD_GROUPS;
-        const int b = (int)blockIdx.x, g = b % NG;
-        const int members = (n_blocks - g + NG - 1) / NG, groups = n_blocks < NG ? n_blocks : NG;
-        int* gc = counters + 64 * (1 + g);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        int last = 0;
-        if (__hip_atomic_fetch_add(gc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
-            __hip_atomic_store(gc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_fetch_add(counters, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1) {
-                __hip_atomic_store(counters, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // every word is zero again for the next launch
-                last = 1;
-            }
-        }
-        is_last_wt = last;
-    }
-    __syncthreads();
-    if (is_last_wt) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return is_last_wt != 0;
-}
 // k_reduce_sum's body for one block: in is [n_out][n], out[o * stride_out]
 __device__ __forceinline__ void fold_partials_strided(const double* __restrict__ in, int n, int stride_out, double* __restrict__ out, int n_out, double* sm4)
 {
@@ -500,22 +462,9 @@ __global__ __launch_bounds__(256) void k_zero_lower(double* __restrict__ S, int 
 // left of its tile row's envelope that held zeros before a factorisation holds zeros after it: only the tiles inside the envelope --
 // the Schur blocks, the tether pairs and the fill-in between them -- carry the last factor and need clearing.  The host hands
 // tile_env over only while that invariant is known to hold (first trial after a build, a failed or stalled factorisation: full clear).
-// On the 1k-pose rail 94 of 1 128 tiles: 19 -> 2 us per trial.  One workgroup per lower tile (R, t).
-__global__ __launch_bounds__(256) void k_zero_skyline(double* __restrict__ S, int n_pad, int tile, const int* __restrict__ tile_env)
-{
-    int R = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
-    while ((R + 1) * (R + 2) / 2 <= (int)blockIdx.x) ++R;
-    while (R * (R + 1) / 2 > (int)blockIdx.x) --R;
-    const int t = (int)blockIdx.x - R * (R + 1) / 2;
-    if (t < tile_env[R]) return;
-    double2* base = reinterpret_cast<double2*>(S + (size_t)(t * tile) * n_pad + (size_t)R * tile);
-    for (int e = threadIdx.x; e < tile * tile / 2; e += 256) {
-        const int c = e / (tile / 2), r2 = e % (tile / 2);
-        base[(size_t)c * (n_pad / 2) + r2] = make_double2(0.0, 0.0);
-    }
-}
+// On the 1k-pose rail 94 of 1 128 tiles: 19 -> 2 us per trial.  One workgroup per lower tile (R, t): the zero role of k_schur_prepare.
 __device__ __forceinline__ void lm_dinv_from(const double* Vl, double lambda, double D[6]);
-// k_lm_invert + k_zero_skyline + the linearisation's chi2 fold in ONE launch (round 4, late: three launches of ~6 us each became one):
+// k_lm_invert + the skyline zero-fill + the linearisation's chi2 fold in ONE launch (round 4, late: three launches of ~6 us each became one):
 //   blocks [0, nb_lm)                      (V_l + lambda I)^-1 and D^-1 b_p per landmark            (k_lm_invert)
 //   blocks [nb_lm, nb_lm + nb_y)           y = b_c with a zero tail (+ the padded diagonal when no zero role runs here)
 //   block   nb_lm + nb_y, if fold_n > 0    scal[SC_CHI] = sum of the fold_n partials the linearisation left (k_reduce_sum's order)
@@ -1024,12 +973,10 @@ constexpr int BACKSUB_LPL = 8;
 // WITH_ERROR: every lane of the landmark's group ends with the trial point and evaluates its share of the landmark's observations
 // against the trial poses (k_pose_update has run): the residuals and chi2 partials of k_error(trial) without reading the trial state
 // back, in partial[chi_off + block].
-// fold_n > 0 (WITH_ERROR): the last block to finish adds the fold_n scale partials and the fold_n chi2 partials (k_pose_update's rows
-// included: written by the launch before) into scal[SC_SCALE] / scal[SC_CHI_TRIAL] -- last_block_arrives_through.
 // (7 wavefronts per SIMD: at 74 registers six fitted and the 3 125 blocks of the 1k-pose map were 2.03 rounds of 1 536; at 72 seven fit --
 //  36.0 -> 34.4 us; eight cost a spill and 35.7 us)
 template <bool WITH_ERROR>
-__global__ __launch_bounds__(256, 7) void k_backsub(BaDeviceView v, double lambda, double delta, int chi_off, int fold_n, int* __restrict__ counter)
+__global__ __launch_bounds__(256, 7) void k_backsub(BaDeviceView v, double lambda, double delta, int chi_off)
 {
     __shared__ double sm[4];
     const int gl = blockIdx.x * 256 + threadIdx.x, l = gl / BACKSUB_LPL, sub = gl % BACKSUB_LPL;
@@ -1101,14 +1048,6 @@ __global__ __launch_bounds__(256, 7) void k_backsub(BaDeviceView v, double lambd
         }
     }
     const double r = block_sum<4>(sc, sm);
-    if (WITH_ERROR && fold_n > 0) {
-        const double r1 = block_sum<4>(chi, sm);
-        if (threadIdx.x == 0) { store_partial_through(v.partial + blockIdx.x, r); store_partial_through(v.partial + chi_off + blockIdx.x, r1); }
-        if (!last_block_arrives_through(counter, (int)gridDim.x)) return;
-        static_assert(SC_CHI_TRIAL - SC_SCALE == 6, "the two outputs of the fused reduction");
-        fold_partials_strided(v.partial, fold_n, SC_CHI_TRIAL - SC_SCALE, v.scal + SC_SCALE, 2, sm);
-        return;
-    }
     if (threadIdx.x == 0) v.partial[blockIdx.x] = r;
     if (WITH_ERROR) {
         const double r1 = block_sum<4>(chi, sm);
@@ -1252,7 +1191,7 @@ __device__ __forceinline__ bool call_is_over(const BaDeviceView& v, const Classi
 
 template <bool AFTER_TRIAL>
 __global__ __launch_bounds__(256) void k_classify(BaDeviceView v, double max_err_sq, uint32_t* __restrict__ out_ids, int* __restrict__ out_count, int out_base, int nb,
-                                                  ClassifyAfterTrial spec, int* __restrict__ fold_counter)
+                                                  ClassifyAfterTrial spec)
 {
     __shared__ double sm[4];
     const double* pose_kept = v.pose_cur;
@@ -1283,11 +1222,6 @@ __global__ __launch_bounds__(256) void k_classify(BaDeviceView v, double max_err
     double r0 = block_sum<4>(es, sm);
     double r1 = block_sum<4>(ec, sm);
     double r2 = block_sum<4>(no, sm);
-    if (fold_counter) {      // the last block adds the three sums (last_block_arrives_through); a call found unfinished above left without counting
-        if (threadIdx.x == 0) { store_partial_through(v.partial + blockIdx.x, r0); store_partial_through(v.partial + nb + blockIdx.x, r1); store_partial_through(v.partial + 2 * nb + blockIdx.x, r2); }
-        if (last_block_arrives_through(fold_counter, nb)) fold_partials_strided(v.partial, nb, 1, v.scal + SC_ERRSUM, 3, sm);
-        return;
-    }
     if (threadIdx.x == 0) { v.partial[blockIdx.x] = r0; v.partial[nb + blockIdx.x] = r1; v.partial[2 * nb + blockIdx.x] = r2; }
 }
 
@@ -1380,7 +1314,7 @@ constexpr int SMALL_LPL = 8, SMALL_CPC = 4;
 // the large-problem use of the same kernel (ba_fused_linearize: hundreds of cameras, the workgroup writes U and b_c itself);
 // zero_role = 0 drops the S / y zero-fill block (large systems clear S with k_zero_lower).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_small_linearize(BaDeviceView v, double delta, int nbL, int want_maxdiag, int* __restrict__ counter, int cpc,
-                                                         int zero_role, int fold_through)
+                                                         int zero_role)
 {
     __shared__ double sm[4];
     __shared__ double part[4][28];
@@ -1538,9 +1472,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const int x = bid & 7, first = nbL + ((x - (nbL & 7) + 8) & 7), run = (v.n_fc + 7) >> 3, within = (bid - first) >> 3;
             hc = (bid >= first && within < run) ? x * run + within : v.n_fc;
             if (hc >= v.n_fc) {
-                if (!fold_through) { if (tid == 0) v.partial[bid] = 0.0; return; }
-                if (tid == 0) store_partial_through(v.partial + bid, 0.0);
-                if (last_block_arrives_through(counter, n_blocks)) fold_partials_strided(v.partial, n_blocks, 1, v.scal + SC_CHI, 1, sm);
+                if (tid == 0) v.partial[bid] = 0.0;
                 return;
             }
         }
@@ -1619,15 +1551,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int i = n + tid; i < np; i += 256) v.S[(size_t)i * np + i] = 1.0;
     }
     const double r = block_sum<4>(chi, sm);
-    // Large problems (cpc == 1): the "last block" pattern with ordinary stores needs a release fence per block -- a write-back of the
-    // XCD's L2 -- and with thousands of blocks streaming 144 MB of W through those L2s that fence costs more than the whole kernel
-    // (0.32 ms against 0.13 for the three separate kernels).  Their partials go THROUGH instead (last_block_arrives_through), or,
-    // with fold_through = 0, are added by a k_reduce_sum launch.
-    if (cpc == 1 && fold_through) {
-        if (tid == 0) store_partial_through(v.partial + bid, r);
-        if (last_block_arrives_through(counter, n_blocks)) fold_partials_strided(v.partial, n_blocks, 1, v.scal + SC_CHI, 1, sm);
-        return;
-    }
+    // Large problems (cpc == 1): the "last block" pattern needs a release fence per block -- a write-back of the XCD's L2 -- and with
+    // thousands of blocks streaming W through those L2s that costs more than the whole kernel; a write-through form (round 4) cost what
+    // the k_reduce_sum launch it saved costs.  Their partials are added by that launch (or by k_schur_prepare, which follows).
     if (tid == 0) v.partial[bid] = r;
     if (cpc == 1) return;
     if (!last_block_arrives(counter, n_blocks)) return;
@@ -2387,11 +2313,9 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, do
 // fold_n > 0: scal[SC_CHI] = the sum of the fold_n partials the linearisation left in v.partial (ba_fused_linearize with its fold deferred)
 void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, double pad_diag, int fold_n, hipStream_t st)
 {
-    static const bool separate = std::getenv("MAGE_BA_SEPARATE_PREPARE") != nullptr;      // A/B: k_zero_skyline, k_lm_invert (and k_reduce_sum) as launches of their own
     const bool skyline = v.n_pad >= 1024 && v.tile_env;
-    const bool merged = !separate && v.n_pad >= 1024;
-    if (skyline && !merged) { const int nt = v.n_pad / 128; hipLaunchKernelGGL(k_zero_skyline, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, v.S, v.n_pad, 128, v.tile_env); }
-    else if (v.n_pad >= 1024 && !skyline) hipLaunchKernelGGL(k_zero_lower, dim3(std::max(1, v.n_pad / 2048), v.n_pad), dim3(256), 0, st, v.S, v.n_pad, 128);
+    const bool merged = v.n_pad >= 1024;          // zero-fill of the skyline, landmark inverses and the chi2 fold in ONE launch (k_schur_prepare)
+    if (v.n_pad >= 1024 && !skyline) hipLaunchKernelGGL(k_zero_lower, dim3(std::max(1, v.n_pad / 2048), v.n_pad), dim3(256), 0, st, v.S, v.n_pad, 128);
     else if (v.n_pad < 1024) (void)hipMemsetAsync(v.S, 0, (size_t)v.n_pad * v.n_pad * sizeof(double), st);
     // the diagonal blocks of k_schur_block also write their camera's reduced rhs; a camera without a block (no free landmark) keeps b_c
     const bool rhs_in_blocks = v.points_free && v.n_blk > 0;
@@ -2410,14 +2334,8 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, do
         if (v.n_blk <= SPLIT_BLOCKS_BELOW) hipLaunchKernelGGL(k_schur_block_compact<true>, dim3(v.n_blk), dim3(256), 0, st, v, lambda_cam);
         else hipLaunchKernelGGL(k_schur_block_compact<false>, dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda_cam);
     } else if (v.n_blk > 0) {
-        static const bool gather = std::getenv("MAGE_BA_SCHUR_GATHER") != nullptr;      // the lane-per-contribution loads, for comparison
-        if (v.n_blk <= SPLIT_BLOCKS_BELOW) {
-            if (gather) hipLaunchKernelGGL((k_schur_block<true, false>), dim3(v.n_blk), dim3(256), 0, st, v, lambda_cam);
-            else hipLaunchKernelGGL((k_schur_block<true, true>), dim3(v.n_blk), dim3(256), 0, st, v, lambda_cam);
-        } else {
-            if (gather) hipLaunchKernelGGL((k_schur_block<false, false>), dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda_cam);
-            else hipLaunchKernelGGL((k_schur_block<false, true>), dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda_cam);
-        }
+        if (v.n_blk <= SPLIT_BLOCKS_BELOW) hipLaunchKernelGGL((k_schur_block<true, true>), dim3(v.n_blk), dim3(256), 0, st, v, lambda_cam);
+        else hipLaunchKernelGGL((k_schur_block<false, true>), dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda_cam);
     }
     tether_launch_schur(v, st);
     if (v.n_fc > 0 && !rhs_in_blocks) {
@@ -2431,18 +2349,17 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, do
 // for both scalars, the tether edges' chi2 on top.  = ba_launch_update + ba_launch_error(trial) in three launches instead of five.
 bool ba_update_and_trial_error_fuses(const BaDeviceView& v)
 {
-    static const bool off = std::getenv("MAGE_BA_UNFUSED_TRIAL_ERROR") != nullptr;
-    return !off && v.points_free && v.n_lm > 0 && v.n_fc > 0;
+    return v.points_free && v.n_lm > 0 && v.n_fc > 0;
 }
-void ba_launch_update_and_trial_error(const BaDeviceView& v, double lambda, double lambda_cam, double delta, int* counter, hipStream_t st)
+void ba_launch_update_and_trial_error(const BaDeviceView& v, double lambda, double lambda_cam, double delta, hipStream_t st)
 {
     const int nb_l = cdiv(v.n_lm * BACKSUB_LPL, 256), nb_c = cdiv(v.n_fc, 256), n = nb_l + nb_c;
-    const bool fold = counter && ba_reductions_fold();
     hipLaunchKernelGGL(k_pose_update, dim3(nb_c), dim3(256), 0, st, v, lambda_cam, nb_l, n + nb_l);       // scale partials nb_l .. n, chi2 partials of those rows: zero
-    hipLaunchKernelGGL(k_backsub<true>, dim3(nb_l), dim3(256), 0, st, v, lambda, delta, n, fold ? n : 0, counter);
-    // partial = [scale: n][chi2: n] -> scal[SC_SCALE], scal[SC_SCALE + 6] = scal[SC_CHI_TRIAL]: by the last block of k_backsub, or
+    hipLaunchKernelGGL(k_backsub<true>, dim3(nb_l), dim3(256), 0, st, v, lambda, delta, n);
+    // partial = [scale: n][chi2: n] -> scal[SC_SCALE], scal[SC_SCALE + 6] = scal[SC_CHI_TRIAL] (folding the sums into the last block of their
+    // producer was measured no faster than this launch: profiles/HISTORY.md)
     static_assert(SC_CHI_TRIAL - SC_SCALE == 6, "the two outputs of the fused reduction");
-    if (!fold) hipLaunchKernelGGL(k_reduce_sum, dim3(2), dim3(256), 0, st, v.partial, n, SC_CHI_TRIAL - SC_SCALE, v.scal + SC_SCALE, 2);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(2), dim3(256), 0, st, v.partial, n, SC_CHI_TRIAL - SC_SCALE, v.scal + SC_SCALE, 2);
     tether_launch_error(v, true, st);
 }
 
@@ -2452,7 +2369,7 @@ void ba_launch_update(const BaDeviceView& v, double lambda, double lambda_cam, h
     int nb_l = 0;
     if (v.points_free && v.n_lm > 0) {
         nb_l = cdiv(v.n_lm * BACKSUB_LPL, 256);
-        hipLaunchKernelGGL(k_backsub<false>, dim3(nb_l), dim3(256), 0, st, v, lambda, 0.0, 0, 0, (int*)nullptr);
+        hipLaunchKernelGGL(k_backsub<false>, dim3(nb_l), dim3(256), 0, st, v, lambda, 0.0, 0);
     }
     int nb_c = 0;
     if (v.n_fc > 0) {
@@ -2475,7 +2392,7 @@ static int small_error_blocks(const BaDeviceView& v) { return v.n_L > 0 ? std::m
 void ba_small_linearize(const BaDeviceView& v, double delta, bool want_maxdiag, int* counter, hipStream_t st)
 {
     const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm * (v.dup_slots ? 1 : SMALL_LPL), 256) : 0;
-    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + v.n_fc * SMALL_CPC + 1), dim3(256), 0, st, v, delta, nbL, want_maxdiag ? 1 : 0, counter, SMALL_CPC, 1, 0);
+    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + v.n_fc * SMALL_CPC + 1), dim3(256), 0, st, v, delta, nbL, want_maxdiag ? 1 : 0, counter, SMALL_CPC, 1);
 }
 // Positions of the compact records (BaDeviceView::w_pos): camera-major = the inverse of camS, or the identity.
 __global__ __launch_bounds__(256) void k_build_positions(BaDeviceView v, int* __restrict__ w_pos, int* __restrict__ pos_lm, int camera_major)
@@ -2529,16 +2446,11 @@ __global__ __launch_bounds__(256) void k_order_slots_longest_first(BaDeviceView 
         out[x + 8 * rank] = b;
     }
 }
-bool ba_w_camera_major()
-{
-    static const bool off = std::getenv("MAGE_BA_W_LANDMARK_MAJOR") != nullptr;
-    return !off;
-}
 void ba_launch_build_positions(const BaDeviceView& v, int* w_pos, int* pos_lm, ConPos* con_pos, int* slot_order, hipStream_t st)
 {
     if (v.n_w <= 0) return;
     if (v.n_blk_slots > 0 && slot_order) hipLaunchKernelGGL(k_order_slots_longest_first, dim3(8), dim3(256), 0, st, v, slot_order);
-    hipLaunchKernelGGL(k_build_positions, dim3(cdiv(v.n_w, 256)), dim3(256), 0, st, v, w_pos, pos_lm, ba_w_camera_major() ? 1 : 0);
+    hipLaunchKernelGGL(k_build_positions, dim3(cdiv(v.n_w, 256)), dim3(256), 0, st, v, w_pos, pos_lm, 1);
     if (v.n_blk > 0) hipLaunchKernelGGL(k_build_con_pos, dim3(2048), dim3(256), 0, st, v, w_pos, con_pos);
 }
 
@@ -2547,21 +2459,12 @@ bool ba_compact_w_enabled()
     static const bool off = std::getenv("MAGE_BA_MATERIAL_W") != nullptr;
     return !off;
 }
-// Measured on the 1k-pose map (round 4, one MI355X): with the folds k_small_linearize 64.8 -> 68.9 us, k_backsub 35.7 -> 44.3,
-// k_classify 12.4 -> 17.4 (the last blocks' write-through + two counts + acquire + fold are a ~6 us tail -- what a k_reduce_sum
-// launch costs), the step 2.825 against 2.818 ms: no gain, so the separate launches stay the default.  MAGE_BA_FOLD_REDUCTIONS=1 folds.
-bool ba_reductions_fold()
-{
-    static const bool on = std::getenv("MAGE_BA_FOLD_REDUCTIONS") != nullptr;
-    return on;
-}
 // The same kernel for LARGE problems in which every observation owns its W block: k_error + k_linearize_lm +
 // k_linearize_cam in one launch -- the residuals are computed once, a landmark's observations by eight lanes, the chi2 folded by the
 // last block.  S is cleared by ba_launch_schur, max |diag| comes from ba_launch_maxdiag.
 bool ba_fused_linearize_applies(const BaDeviceView& v)
 {
-    static const bool off = std::getenv("MAGE_BA_NO_FUSED_LINEARIZE") != nullptr;
-    return !off && !v.dup_slots && v.n_fc > 0 && v.n_L > 0;
+    return !v.dup_slots && v.n_fc > 0 && v.n_L > 0;
 }
 // defer_chi_fold: the chi2 partials stay in v.partial and their count is returned -- the caller hands it to the trial's FIRST
 // ba_launch_schur, whose launch adds them (nothing reads scal[SC_CHI] before); only without tethers (their chi2 is added on top below)
@@ -2569,10 +2472,9 @@ int ba_fused_linearize(const BaDeviceView& v, double delta, int* counter, hipStr
 {
     const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm * SMALL_LPL, 256) : 0;
     const int nbC = ((v.n_fc + 7) / 8) * 8 + 8;          // every XCD gets ceil(n_fc / 8) camera workgroups wherever its first one falls
-    const bool fold = ba_reductions_fold();
-    const bool defer = defer_chi_fold && !fold && v.n_T == 0 && v.n_pad >= 1024;
-    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + nbC), dim3(256), 0, st, v, delta, nbL, 0, counter, 1, 0, fold ? 1 : 0);
-    if (!fold && !defer) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nbL + nbC, 1, v.scal + SC_CHI, 1);
+    const bool defer = defer_chi_fold && v.n_T == 0 && v.n_pad >= 1024;
+    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + nbC), dim3(256), 0, st, v, delta, nbL, 0, counter, 1, 0);
+    if (!defer) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nbL + nbC, 1, v.scal + SC_CHI, 1);
     tether_launch_error(v, false, st);          // the pose-pose edges add their chi2, U and b_c on top (nothing is launched without them)
     tether_launch_linearize(v, st);
     return defer ? nbL + nbC : 0;
@@ -2582,8 +2484,7 @@ void ba_small_solve_trial(const BaDeviceView& v, double lambda, double delta, do
     const int n = v.n_fc * 6;
     hipLaunchKernelGGL(k_small_schur, dim3(v.n_blk + v.n_fc), dim3(256), 0, st, v, lambda);
     chol_small_solve(v.S, v.y, v.xc, n, v.n_pad, linv_ws, v.scal + SC_CHOL_OK, v.scal + SC_CHOL_STALL, st);
-    static const bool unfused = std::getenv("MAGE_BA_SMALL_UNFUSED_UPDATE") != nullptr;
-    if (v.points_free && v.n_lm > 0 && !unfused) {        // back-substitution, state update and the trial's residuals in one launch
+    if (v.points_free && v.n_lm > 0) {        // back-substitution, state update and the trial's residuals in one launch
         hipLaunchKernelGGL(k_small_update_error, dim3(cdiv(v.n_lm * SMALL_LPL, 256)), dim3(256), 0, st, v, lambda, delta, counter);
         return;
     }
@@ -2602,9 +2503,13 @@ void ba_small_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTri
     hipLaunchKernelGGL(k_small_classify<true>, dim3(small_error_blocks(v)), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, counter, c, result,
                        mirror, mirror_scalars, mirror_doubles, ids_prefix);
 }
+static bool g_pose_lm_staged_ok = true;      // false when this device refused the staged kernel's LDS opt-in: the arrays then stay in HBM
 void ba_small_init_device()
 {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_lm<true>), hipFuncAttributeMaxDynamicSharedMemorySize, POSE_LM_STAGED_MAX_BYTES);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_lm<true>), hipFuncAttributeMaxDynamicSharedMemorySize, POSE_LM_STAGED_MAX_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        g_pose_lm_staged_ok = false;
+    }
 }
 
 bool ba_pose_lm_applies(const BaDeviceView& v, size_t n_huber)
@@ -2618,12 +2523,12 @@ void ba_launch_pose_lm(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult*
 }
 bool ba_pose_lm_staged_fits(const BaDeviceView& v)
 {
-    return pose_lm_staged_bytes(v.n_cams, v.n_pts, v.n_L, v.n_fc) <= (size_t)POSE_LM_STAGED_MAX_BYTES;
+    return g_pose_lm_staged_ok && pose_lm_staged_bytes(v.n_cams, v.n_pts, v.n_L, v.n_fc) <= (size_t)POSE_LM_STAGED_MAX_BYTES;
 }
 bool ba_launch_pose_lm_staged(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out, uint8_t* flagL, double* out_pose, hipStream_t st)
 {
     const size_t lds = pose_lm_staged_bytes(v.n_cams, v.n_pts, v.n_L, v.n_fc);
-    if (lds > (size_t)POSE_LM_STAGED_MAX_BYTES || !out_pose) return false;
+    if (!g_pose_lm_staged_ok || lds > (size_t)POSE_LM_STAGED_MAX_BYTES || !out_pose) return false;
     hipLaunchKernelGGL(k_pose_lm<true>, dim3(1), dim3(256), lds, st, v, a, out, flagL, out_pose);
     return true;
 }
@@ -2637,22 +2542,18 @@ void ba_launch_import_poses(double* pose0, double* pose1, const uint32_t* cam, c
     if (n) hipLaunchKernelGGL(k_import_poses, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, st, pose0, pose1, cam, row, n, block);
 }
 
-// fold_counter: the handle's zero-between-launches int (the last block adds the three sums), or nullptr (a k_reduce_sum launch does)
-void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* fold_counter, hipStream_t st)
+void ba_launch_classify(const BaDeviceView& v, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, hipStream_t st)
 {
     int nb = v.n_L > 0 ? (cdiv(v.n_L, 256) < RED_BLOCKS ? cdiv(v.n_L, 256) : RED_BLOCKS) : 1;
-    if (!ba_reductions_fold()) fold_counter = nullptr;
-    hipLaunchKernelGGL(k_classify<false>, dim3(nb), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, nb, ClassifyAfterTrial{}, fold_counter);
-    if (!fold_counter) hipLaunchKernelGGL(k_reduce_sum, dim3(3), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
+    hipLaunchKernelGGL(k_classify<false>, dim3(nb), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, nb, ClassifyAfterTrial{});
+    hipLaunchKernelGGL(k_reduce_sum, dim3(3), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
 }
-void ba_launch_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, int* fold_counter,
-                                    hipStream_t st)
+void ba_launch_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTrial& c, double max_err_sq, uint32_t* out_ids, int* out_count, int out_base, hipStream_t st)
 {
     int nb = v.n_L > 0 ? (cdiv(v.n_L, 256) < RED_BLOCKS ? cdiv(v.n_L, 256) : RED_BLOCKS) : 1;
-    if (!ba_reductions_fold()) fold_counter = nullptr;
-    hipLaunchKernelGGL(k_classify<true>, dim3(nb), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, nb, c, fold_counter);
+    hipLaunchKernelGGL(k_classify<true>, dim3(nb), dim3(256), 0, st, v, max_err_sq, out_ids, out_count, out_base, nb, c);
     // (when the kernel found the call unfinished the three sums are stale: nobody reads them then)
-    if (!fold_counter) hipLaunchKernelGGL(k_reduce_sum, dim3(3), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(3), dim3(256), 0, st, v.partial, nb, 1, v.scal + SC_ERRSUM, 3);
 }
 
 }  // namespace mage

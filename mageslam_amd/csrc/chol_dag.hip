@@ -605,7 +605,6 @@ Schedule build_schedule(int nt, int n_cu, int gmax)
     int& quarter_from = out.quarter_from;
     quarter_from = nt;
     for (int j = 1; j < nt; ++j) { const int m = nt - j; if (m * (m + 1) < n_teams) { quarter_from = j; break; } }
-    if (const char* e = std::getenv("MAGE_CHOL_DAG_QUARTER_FROM")) quarter_from = std::max(1, std::min(nt, std::atoi(e)));      // EXPERIMENT
     const int ntri = nt * (nt + 1) / 2;
     std::vector<int> strip_cnt(ntri, 0), availc(ntri, 0), nxt(4 * ntri, 0), darr(nt, 0), yprog(nt, 0);
     std::vector<char> busy(4 * ntri, 0), queued(4 * ntri, 0), tile_done(ntri, 0), strips_out(ntri, 0), diag_out(nt, 0), y_out(nt, 0), rhs_busy(nt, 0);

@@ -9,13 +9,12 @@ constexpr int CHOL_TILE = 128;
 struct CholWorkspace {
     double* Linv;      // chol_workspace_doubles(n_pad): inverses of the 16x16 diagonal blocks of L, per tile
     int* sync;         // chol_sync_ints(n_pad) ints: [0] arrival counter of the split diagonal tile, [1] last tile column factored, [2] parts of first-column tiles written, [4] phased strips: block columns of the tile being factored that are published (8 tile + column); from [8] on: the task-graph launch's state (chol_dag.h)
-    long long* dbg = nullptr;   // development only: 4 x nt time stamps of the backward solve (tools/chol_test.hip)
+    long long* dbg = nullptr;   // development only: 4 x nt time stamps of the backward solve (tools/chol_test.hip, CHOL_DBG=1); a -DDAG_TRACE build hands it to the task-graph launch instead (tools/dag_trace.py)
     double* stall = nullptr;    // device double: set to 1.0 when a bounded cross-workgroup wait timed out (a device fault, not a property of S)
 };
 size_t chol_workspace_doubles(int n_pad);
 size_t chol_sync_ints(int n_pad);      // hand-off counters of the launches + the state words of the task-graph launch
 constexpr int CHOL_MAX_ORDER = 256 * CHOL_TILE;   // the persistent backward solve needs one resident workgroup per tile column
-void chol_debug_syrk_stamps(long long* out32, bool reset);   // development only (tools/chol_test.hip, CHOL_DBG=1 CHOL_DBG_COL=k)
 bool chol_merge_fallback_active();   // true once chol_report_stall(2) has switched this process to separate panel-solve launches
 void chol_report_stall(int code);   // the host saw *stall = code (1 split diagonal tile, 2 merged panel solve, 3 backward solve, 4 task-graph launch, 9 a launch was refused): adapts the schedule
 void chol_init_device();   // once per device (after hipSetDevice): opt the LDS-heavy kernels in

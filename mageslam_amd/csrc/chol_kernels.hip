@@ -38,12 +38,6 @@ namespace {
 // hardware scheduler saves and restores workgroups), every later factorisation uses launches without such waits: chol_report_stall.
 std::atomic<bool> g_merge_disabled{ false };
 
-// development only (tools/chol_test.hip, CHOL_DBG_COL=k): time stamps of the workgroups of ONE chain-bound launch
-__device__ long long g_syrk_dbg[32];
-__device__ __forceinline__ void dbg_set(int dbg, int slot) { if (dbg && threadIdx.x == 0) g_syrk_dbg[slot] = wall_clock64(); }
-__device__ __forceinline__ void dbg_max(int dbg, int slot) { if (dbg && threadIdx.x == 0) atomicMax((unsigned long long*)&g_syrk_dbg[slot], (unsigned long long)wall_clock64()); }
-__device__ __forceinline__ void dbg_min(int dbg, int slot) { if (dbg && threadIdx.x == 0) atomicMin((unsigned long long*)&g_syrk_dbg[slot], (unsigned long long)wall_clock64()); }
-
 // ---------------------------------------------------------------------------------------------
 // Tile 0, stand-alone: LDS-resident, blocked by 16 (potrf_tile_lds).  It also opens the solve: ok = 1, stall = 0, and x pre-filled
 // with the sentinel the backward substitution polls for.
@@ -123,7 +117,7 @@ __device__ __forceinline__ void rhs_row_update(const double* __restrict__ S, dou
 template <bool MERGED>
 __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, double* __restrict__ y, int ld, int k, int nt,
                                                      double* __restrict__ Linv_next, double* __restrict__ ok, double* __restrict__ stall, int* __restrict__ flag, int col_target,
-                                                     int dbg, double* __restrict__ Lpub_next)
+                                                     double* __restrict__ Lpub_next)
 {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,10 +128,8 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
     if (bid >= first_rhs + mt) {
         // ---- merged panel solve of tile column j0: one strip per workgroup (wavefront 0)
         if (!MERGED || wave != 0) return;
-        dbg_min(dbg, 6);
         trsm_strip_phased(S, y, ld, j0, bid - (first_rhs + mt), false, Linv_next, Lpub_next, flag, col_target, stall, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        dbg_max(dbg, 8);
         return;
     }
     if (bid >= first_rhs) {
@@ -152,7 +144,6 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
         return;
     }
     if (bid < NDIAG) {
-        if (bid == 0) dbg_set(dbg, 0);
         // 16x16 block u = 4 bid + wave of the lower triangle of the diagonal tile, (bi, bj), bi >= bj
         const int u = bid * 4 + wave;
         int bi, bj;
@@ -169,7 +160,6 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
             return;
         }
         // block 0: wait for the eight others (bounded spin, relaxed polls; the tile comes through sc1 loads: no acquire), pull the tile, factor it
-        dbg_set(dbg, 1);
         if (tid == 0) {
             int spins = 0;
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NDIAG - 1 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
@@ -177,15 +167,12 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
             __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        dbg_set(dbg, 2);
         double* A = sm;
         double* T = S + (size_t)(j0 * TILE) * ld + (size_t)j0 * TILE;
         load_tile_packed_wt(A, T, ld, tid);
         __syncthreads();
-        dbg_set(dbg, 3);
         const bool failed = MERGED ? potrf_tile_lds<false, LayPacked, 4>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid, NBLK, TilePublish{ Lpub_next, flag + 4, 8 * j0 })
                                    : potrf_tile_lds<false, LayPacked, 0>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
-        dbg_set(dbg, 4);
         if (tid == 0 && failed) *ok = 0.0;
         if (MERGED) {
             // the strips read the published blocks and the block inverses, all written through: raise the flag FIRST, the factor itself goes
@@ -193,7 +180,6 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) __hip_atomic_store(flag + 1, j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            dbg_set(dbg, 5);
         }
         store_tile_packed(T, A, ld, tid);
         return;
@@ -210,7 +196,6 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
     panel_update<2, 2, 8, 2, false>(S, ld, k, k + 1, row0, col0, lane, acc);
     store_c_block<2, 2, false>(S, ld, row0, col0, lane, acc);
     if (MERGED && ct == 0) publish_column_part(flag, tid);
-    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_max(dbg, ct == 0 ? 10 : 9); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -498,16 +483,6 @@ size_t chol_sync_ints(int n_pad) { return 8 + chol_dag_sync_ints(n_pad / TILE); 
 
 int g_n_cu = 256;        // compute units of the device the library was initialised on (gfx950: 256)
 
-void chol_debug_syrk_stamps(long long* out32, bool reset)
-{
-    if (reset) {
-        long long init[32];
-        for (int i = 0; i < 32; ++i) init[i] = 0;
-        init[6] = 0x7fffffffffffffffLL;
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_syrk_dbg), init, sizeof(init));
-    } else (void)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_syrk_dbg), 32 * sizeof(long long));
-}
-
 bool chol_merge_fallback_active() { return g_merge_disabled.load(std::memory_order_relaxed); }
 
 // The host saw *stall = code: 1 split diagonal tile, 2 merged panel solve, 3 backward solve, 4 the task-graph launch.  Codes 2 and 4
@@ -582,7 +557,6 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
     hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), lds_diag, st, S, n_pad, 0, ws.Linv, ok, stall, reinterpret_cast<unsigned long long*>(x), n_pad);
     hipLaunchKernelGGL(k_trsm_panel_1w, dim3((nt - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, 0, nt, ws.Linv, flag);
     int col_total = 0;
-    static const int dbg_col = std::getenv("CHOL_DBG_COL") ? std::atoi(std::getenv("CHOL_DBG_COL")) : -1;
     for (int k = 0; k + 1 < nt; ++k) {
         const int m = nt - k - 1;             // tile rows below panel k = tile rows of the trailing matrix
         const int n_tiles = m * (m + 1) / 2;
@@ -601,10 +575,9 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
             merged = !merge_off;
             if (merged) col_total += 4 * (m - 1);      // workgroups of this launch that write a part of tile column k + 1 below the diagonal tile
             const dim3 grid(NDIAG + 4 * (n_tiles - 1) + m + (merged ? (m - 1) * NBLK : 0));
-            const int dbg = (ws.dbg && dbg_col == k) ? 1 : 0;
             double* const Lpub_next = ws.Linv + (size_t)nt * linv_stride + (size_t)(k + 1) * LPUB_TILE_DOUBLES;
-            if (merged) hipLaunchKernelGGL(k_syrk_update<true>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, flag, col_total, dbg, Lpub_next);
-            else hipLaunchKernelGGL(k_syrk_update<false>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, flag, col_total, dbg, Lpub_next);
+            if (merged) hipLaunchKernelGGL(k_syrk_update<true>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, flag, col_total, Lpub_next);
+            else hipLaunchKernelGGL(k_syrk_update<false>, grid, dim3(256), lds_diag, st, S, y, n_pad, k, nt, Linv_next, ok, stall, flag, col_total, Lpub_next);
         }
         if (!merged) hipLaunchKernelGGL(k_trsm_panel_1w, dim3((m - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, k + 1, nt, Linv_next, flag);
     }

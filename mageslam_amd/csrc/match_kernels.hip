@@ -317,11 +317,39 @@ __device__ __forceinline__ void track_match(const ulonglong4& left, const ulongl
     }
 }
 
+// OnlineBow::FindLeafNode (BoW/OnlineBow.cpp:289-311) for a batch of descriptors: one thread per descriptor walks the tree from the root,
+// at every level to the child whose medoid is nearest (strict '<' in child-list order: the first of equally near children wins).  Node
+// descriptors are 32 bytes read as four 64-bit words (L2-resident: a vocabulary is a few thousand nodes); children[k] > parent for every
+// edge (checked on the host), so the walk ends.
+__global__ __launch_bounds__(256) void k_bow_find_leaf(const uint8_t* __restrict__ node_desc, const int* __restrict__ child_off, const int* __restrict__ children,
+                                                       const uint8_t* __restrict__ queries, int nq, int* __restrict__ leaf)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const ulonglong4 d = reinterpret_cast<const ulonglong4*>(queries)[q];
+    const ulonglong4* N = reinterpret_cast<const ulonglong4*>(node_desc);
+    int cur = 0;
+    for (int k0 = child_off[0], k1 = child_off[1]; k0 < k1; k0 = child_off[cur], k1 = child_off[cur + 1]) {
+        int best_d = 0x7fffffff, next = cur;
+        for (int k = k0; k < k1; ++k) {
+            const int c = children[k];
+            const ulonglong4 m = N[c];
+            const int dist = __popcll(d.x ^ m.x) + __popcll(d.y ^ m.y) + __popcll(d.z ^ m.z) + __popcll(d.w ^ m.w);
+            if (dist < best_d) { best_d = dist; next = c; }
+        }
+        cur = next;
+    }
+    leaf[q] = cur;
+}
+
+// leafA / leafB (IndexedMatch through the vocabulary, mage_match_indexed_bow): when given, descriptor a's candidate list is the list of the
+// LEAF it descended to -- cb_off / cb are then indexed by node (the other image's features filed under that node) instead of by descriptor.
 __global__ __launch_bounds__(MT) void k_indexed_match(const uint8_t* __restrict__ descA, int nA, const uint8_t* __restrict__ maskA,
                                                       const int* __restrict__ cb_off, const int* __restrict__ cb,
                                                       const uint8_t* __restrict__ descB, const uint8_t* __restrict__ maskB,
                                                       const int* __restrict__ ca_off, const int* __restrict__ ca, int max_dist, int min_diff,
-                                                      mage_dmatch* __restrict__ out, int cap, int* __restrict__ count)
+                                                      mage_dmatch* __restrict__ out, int cap, int* __restrict__ count,
+                                                      const int* __restrict__ leafA, const int* __restrict__ leafB)
 {
     __shared__ int wave_cnt[MT / 64];
     __shared__ int base_s;
@@ -337,12 +365,14 @@ __global__ __launch_bounds__(MT) void k_indexed_match(const uint8_t* __restrict_
         if (a < nA && (!maskA || maskA[a])) {
             const ulonglong4 da = A[a];
             Track best = { -1, max_hamming }, second = { -1, max_hamming };
-            for (int k = cb_off[a]; k < cb_off[a + 1]; ++k) track_match(da, B, cb[k], maskB, best, second, max_hamming);
+            const int la = leafA ? leafA[a] : a;
+            for (int k = cb_off[la]; k < cb_off[la + 1]; ++k) track_match(da, B, cb[k], maskB, best, second, max_hamming);
             if (best.dist < max_hamming && (second.dist >= max_hamming || second.dist - best.dist >= min_diff)) {
                 const int b = best.idx;
                 const ulonglong4 db = B[b];
                 Track rb = { -1, max_hamming }, rs = { -1, max_hamming };
-                for (int k = ca_off[b]; k < ca_off[b + 1]; ++k) track_match(db, A, ca[k], maskA, rb, rs, max_hamming);
+                const int lb = leafB ? leafB[b] : b;
+                for (int k = ca_off[lb]; k < ca_off[lb + 1]; ++k) track_match(db, A, ca[k], maskA, rb, rs, max_hamming);
                 if (rb.dist < max_hamming && rb.idx == a && (rs.dist >= max_hamming || rs.dist - rb.dist >= min_diff)) { train = b; dist = rb.dist; }
             }
         }
@@ -367,9 +397,14 @@ __global__ __launch_bounds__(MT) void k_indexed_match(const uint8_t* __restrict_
 
 void indexed_match_launch(const uint8_t* descA, int nA, const uint8_t* maskA, const int* cb_off, const int* cb, const uint8_t* descB,
                           const uint8_t* maskB, const int* ca_off, const int* ca, int max_dist, int min_diff, mage_dmatch* out, int cap, int* count,
-                          hipStream_t st)
+                          hipStream_t st, const int* leafA, const int* leafB)
 {
-    hipLaunchKernelGGL(k_indexed_match, dim3(1), dim3(MT), 0, st, descA, nA, maskA, cb_off, cb, descB, maskB, ca_off, ca, max_dist, min_diff, out, cap, count);
+    hipLaunchKernelGGL(k_indexed_match, dim3(1), dim3(MT), 0, st, descA, nA, maskA, cb_off, cb, descB, maskB, ca_off, ca, max_dist, min_diff, out, cap, count, leafA, leafB);
+}
+
+void bow_find_leaf_launch(const uint8_t* node_desc, const int* child_off, const int* children, const uint8_t* queries, int nq, int* leaf, hipStream_t st)
+{
+    if (nq > 0) hipLaunchKernelGGL(k_bow_find_leaf, dim3((nq + 255) / 256), dim3(256), 0, st, node_desc, child_off, children, queries, nq, leaf);
 }
 
 void radius_match_launch(const mage_keypoint* qk, int nq, const float2* qpos, const uint8_t* qmask, const uint8_t* qdesc, const mage_keypoint* tk,
@@ -391,7 +426,7 @@ void match_init_device()
 void match_launch(int n_pairs, const uint8_t* descA, const int* countsA, int capA, const uint8_t* descB, const int* countsB, int capB,
                   int max_dist, int min_diff, int* scratch, mage_dmatch* out, int cap_out, int* counts, int* done, hipStream_t st)
 {
-    static const int split_below = [] { const char* e = std::getenv("MAGE_MATCH_SPLIT_BELOW"); return e ? std::atoi(e) : 256; }();
+    constexpr int split_below = 256;
     const int groupsA = (capA + MR - 1) / MR, groupsB = (capB + MR - 1) / MR;
     if (n_pairs < split_below && groupsA + groupsB > 0) {
         const int cap_t = capA > capB ? capA : capB;          // the staged set is the OTHER side's

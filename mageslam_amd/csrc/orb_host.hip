@@ -707,6 +707,125 @@ MAGE_EXPORT mage_status mage_match_indexed(mage_matcher* h, const uint8_t* descA
     });
 }
 
+// ---- the vocabulary tree (mage_match.h): validation shared by the two entry points; the tree goes up as [nodes | child_off | children]
+namespace {
+mage_status check_bow_tree(const mage_bow_tree* t)
+{
+    if (!t || !t->node_descriptors || !t->child_offsets) return fail(MAGE_ERR_INVALID_ARGUMENT, "null vocabulary tree");
+    if (t->n_nodes < 1) return fail(MAGE_ERR_INVALID_ARGUMENT, "a vocabulary tree has at least its root");
+    if (t->child_offsets[0] != 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "child offsets must start at 0");
+    for (int n = 0; n < t->n_nodes; ++n) {
+        if (t->child_offsets[n + 1] < t->child_offsets[n]) return fail(MAGE_ERR_INVALID_ARGUMENT, "child offsets are not monotone at node %d", n);
+        if (t->child_offsets[n + 1] > t->child_offsets[n] && !t->children) return fail(MAGE_ERR_INVALID_ARGUMENT, "null child list");
+        // a child is created after its parent (OnlineBow's m_nodes grows by appending): child index > parent index, which also bounds every descent
+        for (int k = t->child_offsets[n]; k < t->child_offsets[n + 1]; ++k)
+            if (t->children[k] <= n || t->children[k] >= t->n_nodes) return fail(MAGE_ERR_INVALID_ARGUMENT, "child %d of node %d must lie in (%d, %d)", t->children[k], n, n, t->n_nodes);
+    }
+    return MAGE_OK;
+}
+mage_status check_leaf_lists(const int32_t* off, const int32_t* items, int n_nodes, int n_features, const char* which)
+{
+    if (!off) return fail(MAGE_ERR_INVALID_ARGUMENT, "null feature offsets of image %s", which);
+    if (off[0] != 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "feature offsets of image %s must start at 0", which);
+    for (int n = 0; n < n_nodes; ++n) if (off[n + 1] < off[n]) return fail(MAGE_ERR_INVALID_ARGUMENT, "feature offsets of image %s are not monotone", which);
+    if (off[n_nodes] && !items) return fail(MAGE_ERR_INVALID_ARGUMENT, "null feature list of image %s", which);
+    for (int k = 0; k < off[n_nodes]; ++k) if (items[k] < 0 || items[k] >= n_features) return fail(MAGE_ERR_INVALID_ARGUMENT, "feature %d filed for image %s is outside it", k, which);
+    return MAGE_OK;
+}
+}  // namespace
+
+MAGE_EXPORT mage_status mage_bow_find_leaf_batch(mage_matcher* h, const mage_bow_tree* tree, const uint8_t* descriptors, int n, int32_t* leaf_ids)
+{
+    return guarded([&]() -> mage_status {
+        if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (n < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative size");
+        MAGE_TRY(check_bow_tree(tree));
+        if (n == 0) return MAGE_OK;
+        if (!descriptors || !leaf_ids) return fail(MAGE_ERR_INVALID_ARGUMENT, "null buffer");
+        MAGE_DEVICE_SCOPE(h->device);
+        hipStream_t st = h->stream;
+        auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        const size_t nn = (size_t)tree->n_nodes, nch = (size_t)tree->child_offsets[nn];
+        const size_t o_nd = 0, o_co = al(o_nd + 32 * nn), o_ch = al(o_co + 4 * (nn + 1)), o_q = al(o_ch + 4 * nch), total = al(o_q + 32 * (size_t)n);
+        std::vector<uint8_t> stage(total, 0);
+        std::memcpy(stage.data() + o_nd, tree->node_descriptors, 32 * nn); std::memcpy(stage.data() + o_co, tree->child_offsets, 4 * (nn + 1));
+        if (nch) std::memcpy(stage.data() + o_ch, tree->children, 4 * nch);
+        std::memcpy(stage.data() + o_q, descriptors, 32 * (size_t)n);
+        MAGE_TRY(h->d_A.reserve(total));
+        MAGE_TRY(h->d_scratch.reserve((size_t)n));
+        MAGE_HIP(hipMemcpyAsync(h->d_A.p, stage.data(), total, hipMemcpyHostToDevice, st));
+        const uint8_t* d = h->d_A.p;
+        MAGE_HIP(hipEventRecord(h->e0, st));
+        bow_find_leaf_launch(d + o_nd, reinterpret_cast<const int*>(d + o_co), reinterpret_cast<const int*>(d + o_ch), d + o_q, n, h->d_scratch.p, st);
+        MAGE_HIP(hipEventRecord(h->e1, st));
+        MAGE_HIP(hipMemcpyAsync(leaf_ids, h->d_scratch.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+        MAGE_HIP(hipStreamSynchronize(st));
+        float ms = 0;
+        MAGE_HIP(hipEventElapsedTime(&ms, h->e0, h->e1));
+        h->last_ms = ms;
+        return MAGE_OK;
+    });
+}
+
+MAGE_EXPORT mage_status mage_match_indexed_bow(mage_matcher* h, const mage_bow_tree* tree, const uint8_t* descA, int nA, const uint8_t* maskA,
+                                               const int32_t* feat_a_off, const int32_t* feat_a, const uint8_t* descB, int nB, const uint8_t* maskB,
+                                               const int32_t* feat_b_off, const int32_t* feat_b, int max_dist, int min_diff, mage_dmatch* out, int capacity, int* count)
+{
+    return guarded([&]() -> mage_status {
+        if (!h || !count) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        *count = 0;
+        if (nA < 0 || nB < 0 || capacity < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative size");
+        MAGE_TRY(check_bow_tree(tree));
+        if (nA == 0 || nB == 0) return MAGE_OK;
+        if (!descA || !descB || (capacity > 0 && !out)) return fail(MAGE_ERR_INVALID_ARGUMENT, "null buffer");
+        MAGE_TRY(check_leaf_lists(feat_a_off, feat_a, tree->n_nodes, nA, "A"));
+        MAGE_TRY(check_leaf_lists(feat_b_off, feat_b, tree->n_nodes, nB, "B"));
+        size_t cntA = 0, cntB = 0;          // FeatureMatcher.cpp:208: nothing to do when either mask is empty
+        for (int i = 0; i < nA; ++i) cntA += (!maskA || maskA[i]);
+        for (int i = 0; i < nB; ++i) cntB += (!maskB || maskB[i]);
+        if (cntA == 0 || cntB == 0) return MAGE_OK;
+        MAGE_DEVICE_SCOPE(h->device);
+        hipStream_t st = h->stream;
+        // one staging buffer: [nodes | child_off | children | descA | descB | feat_b_off | feat_a_off | feat_b | feat_a | maskA | maskB]; descA and descB
+        // are adjacent so that ONE launch finds the leaves of both images
+        auto al = [](size_t v) { return (v + 31) & ~(size_t)31; };
+        const size_t nn = (size_t)tree->n_nodes, nch = (size_t)tree->child_offsets[nn], nfa = (size_t)feat_a_off[nn], nfb = (size_t)feat_b_off[nn];
+        const size_t o_nd = 0, o_co = al(o_nd + 32 * nn), o_ch = al(o_co + 4 * (nn + 1)), o_da = al(o_ch + 4 * nch), o_db = o_da + 32 * (size_t)nA,
+                     o_bo = al(o_db + 32 * (size_t)nB), o_ao = al(o_bo + 4 * (nn + 1)), o_fb = al(o_ao + 4 * (nn + 1)), o_fa = al(o_fb + 4 * nfb),
+                     o_ma = al(o_fa + 4 * nfa), o_mb = al(o_ma + nA), total = al(o_mb + nB);
+        std::vector<uint8_t> stage(total, 0);
+        std::memcpy(stage.data() + o_nd, tree->node_descriptors, 32 * nn); std::memcpy(stage.data() + o_co, tree->child_offsets, 4 * (nn + 1));
+        if (nch) std::memcpy(stage.data() + o_ch, tree->children, 4 * nch);
+        std::memcpy(stage.data() + o_da, descA, 32 * (size_t)nA); std::memcpy(stage.data() + o_db, descB, 32 * (size_t)nB);
+        std::memcpy(stage.data() + o_bo, feat_b_off, 4 * (nn + 1)); std::memcpy(stage.data() + o_ao, feat_a_off, 4 * (nn + 1));
+        if (nfb) std::memcpy(stage.data() + o_fb, feat_b, 4 * nfb);
+        if (nfa) std::memcpy(stage.data() + o_fa, feat_a, 4 * nfa);
+        if (maskA) std::memcpy(stage.data() + o_ma, maskA, nA);
+        if (maskB) std::memcpy(stage.data() + o_mb, maskB, nB);
+        MAGE_TRY(h->d_A.reserve(total));
+        MAGE_TRY(h->d_scratch.reserve((size_t)nA + nB));
+        MAGE_TRY(h->d_out.reserve((size_t)std::max(capacity, 1)));
+        MAGE_TRY(h->d_counts.reserve(1));
+        MAGE_HIP(hipMemcpyAsync(h->d_A.p, stage.data(), total, hipMemcpyHostToDevice, st));
+        const uint8_t* d = h->d_A.p;
+        int* leaf = h->d_scratch.p;          // [leaf of every A descriptor | leaf of every B descriptor]
+        MAGE_HIP(hipEventRecord(h->e0, st));
+        bow_find_leaf_launch(d + o_nd, reinterpret_cast<const int*>(d + o_co), reinterpret_cast<const int*>(d + o_ch), d + o_da, nA + nB, leaf, st);
+        indexed_match_launch(d + o_da, nA, maskA ? d + o_ma : nullptr, reinterpret_cast<const int*>(d + o_bo), reinterpret_cast<const int*>(d + o_fb),
+                             d + o_db, maskB ? d + o_mb : nullptr, reinterpret_cast<const int*>(d + o_ao), reinterpret_cast<const int*>(d + o_fa),
+                             max_dist, min_diff, h->d_out.p, capacity, h->d_counts.p, st, leaf, leaf + nA);
+        MAGE_HIP(hipEventRecord(h->e1, st));
+        MAGE_HIP(hipMemcpyAsync(count, h->d_counts.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        MAGE_HIP(hipStreamSynchronize(st));
+        const int n = std::min(*count, capacity);
+        if (n > 0) MAGE_HIP(hipMemcpy(out, h->d_out.p, sizeof(mage_dmatch) * (size_t)n, hipMemcpyDeviceToHost));
+        float ms = 0;
+        MAGE_HIP(hipEventElapsedTime(&ms, h->e0, h->e1));
+        h->last_ms = ms;
+        return MAGE_OK;
+    });
+}
+
 MAGE_EXPORT mage_status mage_matcher_last_kernel_ms(const mage_matcher* h, double* ms)
 {
     if (!h || !ms) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");

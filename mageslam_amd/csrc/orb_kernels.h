@@ -60,6 +60,7 @@ void radius_match_launch(const mage_keypoint* qk, int nq, const float2* qpos, co
                          mage_dmatch* out, int cap, int* count, hipStream_t st);
 void indexed_match_launch(const uint8_t* descA, int nA, const uint8_t* maskA, const int* cb_off, const int* cb, const uint8_t* descB,
                           const uint8_t* maskB, const int* ca_off, const int* ca, int max_dist, int min_diff, mage_dmatch* out, int cap, int* count,
-                          hipStream_t st);
+                          hipStream_t st, const int* leafA = nullptr, const int* leafB = nullptr);      // leafA / leafB: the lists are per vocabulary node, looked up through the descriptor's leaf
+void bow_find_leaf_launch(const uint8_t* node_desc, const int* child_off, const int* children, const uint8_t* queries, int nq, int* leaf, hipStream_t st);
 
 }  // namespace mage

@@ -20,6 +20,10 @@ _u8 = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 _i32 = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 
+class BowTree(C.Structure):      # include/mage_match.h mage_bow_tree
+    _fields_ = [("node_descriptors", C.c_void_p), ("child_offsets", C.c_void_p), ("children", C.c_void_p), ("n_nodes", C.c_int32)]
+
+
 class OrbParams(C.Structure):
     _fields_ = [("gaussian_kernel_size", C.c_uint), ("nfeatures", C.c_uint), ("scale_factor", C.c_float), ("nlevels", C.c_uint),
                 ("patch_size", C.c_uint), ("fast_threshold", C.c_uint), ("use_orientation", C.c_int), ("feature_factor_anms", C.c_float),
@@ -60,6 +64,8 @@ def _declare():
     L.mage_match_bf_batch.argtypes = [vp, C.c_int, _u8, _i32, C.c_int, _u8, _i32, C.c_int, C.c_int, C.c_int, vp, C.c_int, _i32]
     L.mage_match_bf_batch_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     L.mage_match_radius.argtypes = [vp, vp, C.c_int, vp, vp, _u8, vp, C.c_int, vp, _u8, C.c_float, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
+    L.mage_bow_find_leaf_batch.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.mage_match_indexed_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     L.mage_match_indexed.argtypes = [vp, _u8, C.c_int, vp, vp, vp, _u8, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     L.mage_matcher_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double)]
     _declared = True
@@ -242,6 +248,42 @@ class Matcher:
         n = C.c_int(0)
         check(self._L.mage_match_indexed(self._h, A, nA, ptr(ma), ptr(bo), ptr(bc) if bc.size else None, B, nB, ptr(mb), ptr(ao), ptr(ac) if ac.size else None,
                                          int(max_hamming_dist), int(min_hamming_difference), ptr(out), len(out), C.byref(n)))
+        return out[: min(n.value, len(out))].copy()
+
+    @staticmethod
+    def _bow_tree(node_descriptors, child_offsets, children):
+        nd = np.ascontiguousarray(node_descriptors, np.uint8).reshape(-1, 32)
+        co = np.ascontiguousarray(child_offsets, np.int32); ch = np.ascontiguousarray(children, np.int32)
+        if ch.size == 0: ch = np.zeros(1, np.int32)
+        t = BowTree(nd.ctypes.data_as(C.c_void_p), co.ctypes.data_as(C.c_void_p), ch.ctypes.data_as(C.c_void_p), len(nd))
+        return t, (nd, co, ch)          # (the arrays must outlive the call)
+
+    def BowFindLeaf(self, node_descriptors, child_offsets, children, descriptors) -> np.ndarray:
+        """OnlineBow::FindLeafNode (BoW/OnlineBow.cpp:289-311) for a batch of descriptors; the tree as flat arrays (include/mage_match.h)."""
+        t, keep = self._bow_tree(node_descriptors, child_offsets, children)
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        leaf = np.zeros(max(len(d), 1), np.int32)
+        check(self._L.mage_bow_find_leaf_batch(self._h, C.byref(t), d.ctypes.data_as(C.c_void_p) if len(d) else None, len(d), leaf.ctypes.data_as(C.c_void_p)))
+        return leaf[:len(d)]
+
+    def IndexedMatchBow(self, node_descriptors, child_offsets, children, descriptors_a, leaf_features_a_offsets, leaf_features_a, descriptors_b,
+                        leaf_features_b_offsets, leaf_features_b, max_hamming_dist=30, min_hamming_difference=1, mask_a=None, mask_b=None) -> np.ndarray:
+        """IndexedMatch (FeatureMatcher.cpp:192-292) with the candidate lists looked up in the vocabulary tree on the device
+        (OnlineBow::QueryFeatures, BoW/OnlineBow.cpp:115-132): leaf_features_x = per node the features of image x filed under it (CSR)."""
+        t, keep = self._bow_tree(node_descriptors, child_offsets, children)
+        A = np.ascontiguousarray(descriptors_a, np.uint8).reshape(-1); B = np.ascontiguousarray(descriptors_b, np.uint8).reshape(-1)
+        nA, nB = A.size // 32, B.size // 32
+        if A.size == 0: A = np.zeros(32, np.uint8)
+        if B.size == 0: B = np.zeros(32, np.uint8)
+        ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        fao = np.ascontiguousarray(leaf_features_a_offsets, np.int32); fa = np.ascontiguousarray(leaf_features_a, np.int32)
+        fbo = np.ascontiguousarray(leaf_features_b_offsets, np.int32); fb = np.ascontiguousarray(leaf_features_b, np.int32)
+        ma = None if mask_a is None else np.ascontiguousarray(mask_a, np.uint8)
+        mb = None if mask_b is None else np.ascontiguousarray(mask_b, np.uint8)
+        out = np.zeros(max(nA, 1), DMATCH_DTYPE)
+        n = C.c_int(0)
+        check(self._L.mage_match_indexed_bow(self._h, C.byref(t), ptr(A), nA, ptr(ma), ptr(fao), ptr(fa) if fa.size else None, ptr(B), nB, ptr(mb), ptr(fbo),
+                                             ptr(fb) if fb.size else None, int(max_hamming_dist), int(min_hamming_difference), ptr(out), len(out), C.byref(n)))
         return out[: min(n.value, len(out))].copy()
 
     def last_kernel_ms(self) -> float:

@@ -418,3 +418,28 @@ def undistort_points(xy, K, dist, P, iterations=5):
         y = (y0 - dy) * num / den
     h = P @ np.stack([x, y, np.ones_like(x)])
     return (h[:2] / h[2]).T.astype(np.float32)
+
+
+def bow_find_leaf(node_desc, children_of, queries):
+    """Independent restatement of OnlineBow::FindLeafNode (BoW/OnlineBow.cpp:289-311): children_of[n] is node n's child list (python
+    lists); all queries walk the tree level by level, np.argmin picks the FIRST nearest child (the reference's strict '<')."""
+    queries = np.asarray(queries, np.uint8).reshape(-1, 32)
+    cur = np.zeros(len(queries), np.int64)
+    active = np.array([len(children_of[0]) > 0] * len(queries), bool)
+    while active.any():
+        for n in np.unique(cur[active]):
+            sel = active & (cur == n)
+            kids = np.asarray(children_of[int(n)], np.int64)
+            D = hamming_matrix(queries[sel], np.asarray(node_desc, np.uint8)[kids])
+            cur[sel] = kids[np.argmin(D, axis=1)]
+        active = np.array([len(children_of[int(c)]) > 0 for c in cur], bool)
+    return cur
+
+
+def indexed_match_bow(node_desc, children_of, descA, feat_a_of_leaf, descB, feat_b_of_leaf, max_dist=30, min_diff=1, maskA=None, maskB=None):
+    """IndexedMatch with the candidate lists the vocabulary gives (FeatureMatcher.cpp:223-227, 253-257; OnlineBow::QueryFeatures :115-132):
+    feat_x_of_leaf[n] = indices of image x's features filed under node n, in filing order."""
+    la, lb = bow_find_leaf(node_desc, children_of, descA), bow_find_leaf(node_desc, children_of, descB)
+    cand_b = [list(feat_b_of_leaf[int(l)]) for l in la]
+    cand_a = [list(feat_a_of_leaf[int(l)]) for l in lb]
+    return indexed_match(descA, cand_b, descB, cand_a, max_dist, min_diff, maskA, maskB)

@@ -178,3 +178,62 @@ MTO_API int mto_indexed_match(const uint8_t* descA, int nA, const uint8_t* maskA
     }
     return n;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * The vocabulary tree's leaf lookup, OnlineBow::FindLeafNode (Core/MAGESLAM/Source/BoW/OnlineBow.cpp:289-311): from the root, at every
+ * level the child whose medoid descriptor is nearest in Hamming distance (GetDescriptorDistance, FeatureMatcher.cpp:453-504), strict
+ * '<' in the order of the node's child list -- the FIRST of equally near children wins -- until a node without children.
+ * The tree as flat arrays: node n's medoid is node_desc[32 n ..], its children are children[child_off[n] .. child_off[n + 1]); node 0
+ * is the root (its descriptor is never compared).  Training (k-medoids, OnlineBow.cpp:325-500) and the node -> keyframe maps are the
+ * caller's: out of scope.
+ * ------------------------------------------------------------------------------------------------ */
+MTO_API void mto_bow_find_leaf(const uint8_t* node_desc, const int32_t* child_off, const int32_t* children, const uint8_t* queries, int nq, int32_t* leaf)
+{
+    for (int q = 0; q < nq; ++q) {
+        int cur = 0;
+        while (child_off[cur] < child_off[cur + 1]) {                       /* :294 */
+            int best_d = 0x7fffffff, next = cur;
+            for (int k = child_off[cur]; k < child_off[cur + 1]; ++k) {     /* :299 */
+                const int d = mto_hamming256(queries + (size_t)q * 32, node_desc + (size_t)children[k] * 32);
+                if (d < best_d) { best_d = d; next = children[k]; }        /* :302-306 */
+            }
+            cur = next;
+        }
+        leaf[q] = cur;
+    }
+}
+
+/* IndexedMatch with the candidate lists taken from the vocabulary as the reference does (FeatureMatcher.cpp:223-227, 253-257 ->
+ * OnlineBow::QueryFeatures :115-132): the candidates of a descriptor are the features of the OTHER image filed under the leaf the
+ * descriptor descends to -- feat_b[feat_b_off[leaf] ..) for a descriptor of A, feat_a[...] for one of B -- in the order they were filed. */
+MTO_API int mto_indexed_match_bow(const uint8_t* node_desc, const int32_t* child_off, const int32_t* children,
+                                  const uint8_t* descA, int nA, const uint8_t* maskA, const int32_t* feat_a_off, const int32_t* feat_a,
+                                  const uint8_t* descB, int nB, const uint8_t* maskB, const int32_t* feat_b_off, const int32_t* feat_b,
+                                  int max_dist, int min_diff, mto_dmatch* out, int cap)
+{
+    int cntA = 0, cntB = 0;
+    for (int i = 0; i < nA; ++i) cntA += (!maskA || maskA[i]);
+    for (int i = 0; i < nB; ++i) cntB += (!maskB || maskB[i]);
+    if (cntA == 0 || cntB == 0) return 0;
+    const int max_hamming = max_dist + 1;
+    int n = 0;
+    for (int a = 0; a < nA; ++a) {
+        if (maskA && !maskA[a]) continue;
+        int32_t la;
+        mto_bow_find_leaf(node_desc, child_off, children, descA + (size_t)a * 32, 1, &la);
+        mto_track best = { -1, max_hamming }, second = { -1, max_hamming };
+        for (int k = feat_b_off[la]; k < feat_b_off[la + 1]; ++k) mto_track_match(descA + (size_t)a * 32, descB, feat_b[k], maskB, &best, &second, max_hamming);
+        if (!(best.dist < max_hamming && (second.dist >= max_hamming || second.dist - best.dist >= min_diff))) continue;
+        const int b = best.idx;
+        int32_t lb;
+        mto_bow_find_leaf(node_desc, child_off, children, descB + (size_t)b * 32, 1, &lb);
+        mto_track rb = { -1, max_hamming }, rs = { -1, max_hamming };
+        for (int k = feat_a_off[lb]; k < feat_a_off[lb + 1]; ++k) mto_track_match(descB + (size_t)b * 32, descA, feat_a[k], maskA, &rb, &rs, max_hamming);
+        if (rb.dist < max_hamming && rb.idx == a && (rs.dist >= max_hamming || rs.dist - rb.dist >= min_diff)) {
+            if (n < cap) { out[n].queryIdx = rb.idx; out[n].trainIdx = b; out[n].imgIdx = 0; out[n].distance = (float)rb.dist; }
+            ++n;
+        }
+    }
+    return n;
+}

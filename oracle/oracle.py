@@ -26,8 +26,11 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_LIB_PATH):
-        build()
+    try:
+        build()              # make: a no-op when the library is newer than its sources, a rebuild when a source changed
+    except (subprocess.CalledProcessError, OSError):
+        if not os.path.exists(_LIB_PATH):
+            raise
     try:
         _lib = C.CDLL(_LIB_PATH)
     except OSError:
@@ -134,6 +137,10 @@ def _declare(L: C.CDLL) -> None:
     L.mto_radius_match.restype = C.c_int
     L.mto_radius_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_int, C.c_void_p, _u8p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.orbo_undistort_keypoints.argtypes = [C.c_void_p, C.c_int, C.POINTER(UndistortParams)]
+    L.mto_bow_find_leaf.restype = None
+    L.mto_bow_find_leaf.argtypes = [_u8p, _i32p, _i32p, _u8p, C.c_int, _i32p]
+    L.mto_indexed_match_bow.restype = C.c_int
+    L.mto_indexed_match_bow.argtypes = [_u8p, _i32p, _i32p, _u8p, C.c_int, C.c_void_p, _i32p, _i32p, _u8p, C.c_int, C.c_void_p, _i32p, _i32p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.mto_indexed_match.restype = C.c_int
     L.mto_indexed_match.argtypes = [_u8p, C.c_int, C.c_void_p, _i32p, _i32p, _u8p, C.c_int, C.c_void_p, _i32p, _i32p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.bao_test_se3_exp.argtypes = [_f64p, _f64p]
@@ -352,6 +359,35 @@ def indexed_match(A, cand_b_off, cand_b, B, cand_a_off, cand_a, max_dist=30, min
                             B.reshape(-1) if len(B) else np.zeros(1, np.uint8), len(B), None if mb is None else mb.ctypes.data_as(C.c_void_p),
                             np.ascontiguousarray(cand_a_off, np.int32), np.ascontiguousarray(cand_a, np.int32) if len(cand_a) else np.zeros(1, np.int32),
                             int(max_dist), int(min_diff), out.ctypes.data_as(C.c_void_p), len(out))
+    return out[:n]
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, np.int32)
+    return a if a.size else np.zeros(1, np.int32)
+
+
+def bow_find_leaf(node_desc, child_off, children, queries) -> np.ndarray:
+    """oracle/match_oracle.c mto_bow_find_leaf: OnlineBow::FindLeafNode for a batch of descriptors; the tree as flat arrays."""
+    L = lib()
+    q = np.ascontiguousarray(queries, np.uint8).reshape(-1, 32)
+    leaf = np.zeros(max(len(q), 1), np.int32)
+    if len(q):
+        L.mto_bow_find_leaf(np.ascontiguousarray(node_desc, np.uint8).reshape(-1), _i32(child_off), _i32(children), q.reshape(-1), len(q), leaf)
+    return leaf[:len(q)]
+
+
+def indexed_match_bow(node_desc, child_off, children, A, feat_a_off, feat_a, B, feat_b_off, feat_b, max_dist=30, min_diff=1, maskA=None, maskB=None) -> np.ndarray:
+    """oracle/match_oracle.c mto_indexed_match_bow: IndexedMatch with the candidate lists looked up in the vocabulary tree."""
+    L = lib()
+    A = np.ascontiguousarray(A, np.uint8).reshape(-1, 32); B = np.ascontiguousarray(B, np.uint8).reshape(-1, 32)
+    out = np.zeros(max(len(A), 1), DMATCH_DTYPE)
+    ma = None if maskA is None else np.ascontiguousarray(maskA, np.uint8)
+    mb = None if maskB is None else np.ascontiguousarray(maskB, np.uint8)
+    n = L.mto_indexed_match_bow(np.ascontiguousarray(node_desc, np.uint8).reshape(-1), _i32(child_off), _i32(children),
+                                A.reshape(-1) if len(A) else np.zeros(1, np.uint8), len(A), None if ma is None else ma.ctypes.data_as(C.c_void_p), _i32(feat_a_off), _i32(feat_a),
+                                B.reshape(-1) if len(B) else np.zeros(1, np.uint8), len(B), None if mb is None else mb.ctypes.data_as(C.c_void_p), _i32(feat_b_off), _i32(feat_b),
+                                int(max_dist), int(min_diff), out.ctypes.data_as(C.c_void_p), len(out))
     return out[:n]
 
 

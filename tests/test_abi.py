@@ -56,3 +56,19 @@ def test_cpp_shims_compile_without_a_gpu(tmp_path):
     for src in ("shim_example.cpp", "shim_local_ba.cpp", "shim_orb_match.cpp"):
         subprocess.run([cxx, "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "tools", src),
                         "-o", str(tmp_path / (src + ".o"))], check=True, capture_output=True, timeout=300)
+
+
+def test_bundlerlib_shim_accepts_every_argument_form():
+    """include/BundlerLib.h keeps the reference's method set (Dependencies/BundlerLib/Include/BundlerLib.h:28-58, Eigen::Map arguments);
+    every vector / matrix / quaternion argument must also take a raw array, a float pointer (const or not), std::array and std::vector
+    -- a raw array used to deduce the `.data()` template and fail to compile.  Syntax check only: no device, no link."""
+    import os, shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        import pytest
+        pytest.skip("no C++ compiler")
+    for std in ("c++14", "c++17"):
+        p = subprocess.run([cxx, "-std=" + std, "-fsyntax-only", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "data", "shim_overloads.cpp")],
+                           capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr[-3000:]

@@ -550,3 +550,54 @@ def test_cpp_front_end_shims_compile_and_agree_with_the_mirror(tmp_path):
             singles.append([i, int(one[0]["trainIdx"]), float(one[0]["distance"])])
     assert [[int(x[0]), int(x[1]), float(x[2])] for x in tag("s")] == singles
     assert tag("dist") == [[str(GetDescriptorDistance(da[0], db[0])), "0"]]
+
+
+BOW_TREES = ("deep", "flat", "binary")
+
+
+@pytest.mark.parametrize("tree", BOW_TREES)
+def test_bow_leaf_lookup_golden_and_oracle(gold, tree):
+    """SURVEY.md 8f rank 4, the vocabulary half of IndexedMatch: OnlineBow::FindLeafNode (BoW/OnlineBow.cpp:289-311) as a batch on the
+    device, bit-exact against the numpy-made fixture (tied siblings, child lists out of node order, single-child nodes, a one-level
+    tree) and against the C oracle on descriptors the fixture does not hold."""
+    bw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_bow.npz"))
+    t = (bw[tree + "_nodes"], bw[tree + "_child_off"], bw[tree + "_children"])
+    mt = Matcher()
+    assert np.array_equal(mt.BowFindLeaf(*t, gold["orb_640x480_a_desc"]), bw[tree + "_leaf_a"])
+    assert np.array_equal(mt.BowFindLeaf(*t, gold["orb_640x480_b_desc"]), bw[tree + "_leaf_b"])
+    rng = np.random.default_rng(5)
+    q = rng.integers(0, 256, (3000, 32), dtype=np.uint8)
+    q[::7] = t[0][rng.integers(0, len(t[0]), len(q[::7]))]           # exact medoids: distance 0, ties with duplicated siblings
+    assert np.array_equal(mt.BowFindLeaf(*t, q), O.bow_find_leaf(*t, q))
+    assert len(mt.BowFindLeaf(*t, q[:0])) == 0
+    assert mt.BowFindLeaf(t[0][:1], [0, 0], [], q[:5]).tolist() == [0] * 5           # the root alone is its own leaf
+
+
+@pytest.mark.parametrize("tree", BOW_TREES)
+def test_indexed_match_through_the_vocabulary(gold, tree):
+    """mage_match_indexed_bow: IndexedMatch with its candidate lists looked up in the tree on the device (FeatureMatcher.cpp:223-227,
+    253-257 -> OnlineBow::QueryFeatures): the fixture's matches, the oracle's on other limits, and the same records as
+    mage_match_indexed fed with the lists a host-side lookup builds."""
+    bw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_bow.npz"))
+    da, db = gold["orb_640x480_a_desc"], gold["orb_640x480_b_desc"]
+    t = (bw[tree + "_nodes"], bw[tree + "_child_off"], bw[tree + "_children"])
+    fa, fb = (bw[tree + "_feat_a_off"], bw[tree + "_feat_a"]), (bw[tree + "_feat_b_off"], bw[tree + "_feat_b"])
+    mt = Matcher()
+    for case in ("plain", "loose", "masked"):
+        md, mn = (int(v) for v in bw[f"{tree}_par_{case}"])
+        ma, mb = (bw["mask_a"], bw["mask_b"]) if case == "masked" else (None, None)
+        m = mt.IndexedMatchBow(*t, da, *fa, db, *fb, md, mn, ma, mb)
+        got = np.stack([m["queryIdx"], m["trainIdx"], m["distance"].astype(np.int64)], axis=1)
+        assert np.array_equal(got, bw[f"{tree}_exp_{case}"]) and np.all(m["imgIdx"] == 0), case
+    for md, mn in ((12, 0), (256, 1), (40, 9)):
+        assert np.array_equal(mt.IndexedMatchBow(*t, da, *fa, db, *fb, md, mn, bw["mask_a"], None), O.indexed_match_bow(*t, da, *fa, db, *fb, md, mn, bw["mask_a"], None))
+    # the same through explicit candidate lists
+    la, lb = bw[tree + "_leaf_a"], bw[tree + "_leaf_b"]
+    cb = [fb[1][fb[0][l]:fb[0][l + 1]] for l in la]; ca = [fa[1][fa[0][l]:fa[0][l + 1]] for l in lb]
+    csr = lambda ls: (np.concatenate([[0], np.cumsum([len(x) for x in ls])]).astype(np.int32), np.concatenate(ls + [np.zeros(0, np.int32)]).astype(np.int32))
+    assert np.array_equal(mt.IndexedMatchBow(*t, da, *fa, db, *fb, 30, 1), mt.IndexedMatch(da, *csr(cb), db, *csr(ca), 30, 1))
+    assert len(mt.IndexedMatchBow(*t, da, *fa, db, *fb, 30, 1, np.zeros(len(da), bool), None)) == 0
+    with pytest.raises(Exception):          # a child that is not behind its parent would let a walk loop
+        mt.BowFindLeaf(t[0][:2], [0, 1, 2], [1, 0], da[:4])
+    with pytest.raises(Exception):          # a filed feature outside the image
+        mt.IndexedMatchBow(*t, da, fa[0], np.where(fa[1] == 0, len(da), fa[1]), db, *fb, 30, 1)

@@ -187,6 +187,49 @@ def test_indexed_match_oracle_matches_golden(gold, case):
     assert np.array_equal(got, ix["exp_" + case]) and np.all(m["imgIdx"] == 0)
 
 
+BOW = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_bow.npz")
+BOW_TREES = ("deep", "flat", "binary")
+
+
+@pytest.mark.parametrize("tree", BOW_TREES)
+def test_bow_leaf_lookup_oracle_matches_golden(gold, tree):
+    """OnlineBow::FindLeafNode (BoW/OnlineBow.cpp:289-311, the f-4 row): leaves from the independent numpy restatement; the trees hold
+    tied siblings, child lists out of node order, single-child nodes and a one-level tree (tests/golden/make_bow_golden.py)."""
+    bw = np.load(BOW)
+    t = (bw[tree + "_nodes"], bw[tree + "_child_off"], bw[tree + "_children"])
+    assert np.array_equal(O.bow_find_leaf(*t, gold["orb_640x480_a_desc"]), bw[tree + "_leaf_a"])
+    assert np.array_equal(O.bow_find_leaf(*t, gold["orb_640x480_b_desc"]), bw[tree + "_leaf_b"])
+
+
+@pytest.mark.parametrize("tree", BOW_TREES)
+@pytest.mark.parametrize("case", ("plain", "loose", "masked"))
+def test_indexed_match_through_the_vocabulary_oracle_matches_golden(gold, tree, case):
+    bw = np.load(BOW)
+    da, db = gold["orb_640x480_a_desc"], gold["orb_640x480_b_desc"]
+    md, mn = (int(v) for v in bw[f"{tree}_par_{case}"])
+    ma, mb = (bw["mask_a"], bw["mask_b"]) if case == "masked" else (None, None)
+    m = O.indexed_match_bow(bw[tree + "_nodes"], bw[tree + "_child_off"], bw[tree + "_children"], da, bw[tree + "_feat_a_off"], bw[tree + "_feat_a"],
+                            db, bw[tree + "_feat_b_off"], bw[tree + "_feat_b"], md, mn, ma, mb)
+    got = np.stack([m["queryIdx"], m["trainIdx"], m["distance"].astype(np.int64)], axis=1)
+    assert np.array_equal(got, bw[f"{tree}_exp_{case}"]) and np.all(m["imgIdx"] == 0)
+
+
+def test_bow_leaf_lookup_semantics():
+    """Known answers: the first of equally near children wins (strict '<', OnlineBow.cpp:302), in CHILD-LIST order, not node order; the
+    root alone is its own leaf; the descent follows the nearest child even when a grandchild of another branch is nearer."""
+    z = np.zeros((1, 32), np.uint8)
+    one = np.zeros(32, np.uint8); one[0] = 1
+    far = np.full(32, 0xFF, np.uint8)
+    # root -> [2, 1] (out of node order); nodes 1 and 2 are both at distance 1 from the query
+    nodes = np.stack([np.zeros(32, np.uint8), one, one])
+    assert O.bow_find_leaf(nodes, [0, 2, 2, 2], [2, 1], z).tolist() == [2]
+    assert O.bow_find_leaf(nodes, [0, 2, 2, 2], [1, 2], z).tolist() == [1]
+    assert O.bow_find_leaf(nodes[:1], [0, 0], [], z).tolist() == [0]
+    # root -> [1, 2]; 1 (distance 1) -> [3] (far); 2 (far) -> [4] (identical to the query): the walk takes 1 -> 3
+    nodes = np.stack([np.zeros(32, np.uint8), one, far, far, np.zeros(32, np.uint8)])
+    assert O.bow_find_leaf(nodes, [0, 2, 3, 4, 4, 4], [1, 2, 3, 4], z).tolist() == [3]
+
+
 def test_indexed_match_semantics():
     """Known answers of the TrackMatch rules (FeatureMatcher.cpp:28-54, 239-240, 269-271)."""
     d = np.zeros((4, 32), np.uint8)

@@ -87,20 +87,6 @@ int main(int argc, char** argv)
             for (int j = 0; j < n; ++j) s += A[(size_t)j * n + i] * x[j];
             rn += (s - b[i]) * (s - b[i]); bn += b[i] * b[i];
         }
-        if (getenv("CHOL_DBG") && getenv("CHOL_DBG_COL")) {
-            // one more factorisation with the stamps of launch CHOL_DBG_COL reset first
-            chol_debug_syrk_stamps(nullptr, true);
-            CK(hipMemcpyAsync(dS, dS0, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
-            CK(hipMemcpyAsync(dy, dy0, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
-            chol_factor_solve(dS, dy, dx, n, ws, dok, st);
-            CK(hipStreamSynchronize(st));
-            long long d[32];
-            chol_debug_syrk_stamps(d, false);
-            const char* names[11] = { "wg0 start", "wg0 own block updated", "split tile complete (8 others arrived)", "tile in LDS", "tile factored", "tile stored",
-                                      "first strip starts", "last strip past its column wait", "last strip done", "last other tile done", "last first-column tile done" };
-            printf("  launch %s (us after wg0 start):\n", getenv("CHOL_DBG_COL"));
-            for (int i = 0; i < 11; ++i) printf("    %-42s %8.2f\n", names[i], (d[i] - d[0]) * 0.01);
-        }
         if (getenv("CHOL_DBG")) {
             int nt = n / 128;
             std::vector<long long> d(4 * nt);

@@ -57,7 +57,7 @@ def one(case, rng):
         print("   shape:", dict(n_cams=n_cams, n_pts=n_pts, K=K, n_obs=s.n_obs, fixed=int(fixed.sum()), tethered=tethered, points_fixed=points_fixed, calls=calls), flush=True)
         # which switch, if any, makes the same scene agree: the structure build's twin, the classic outlier pass, a looser tolerance
         for name, env, tol in (("MAGE_BA_BUILD=host", {"MAGE_BA_BUILD": "host"}, None), ("MAGE_BA_BUILD=device", {"MAGE_BA_BUILD": "device"}, None),
-                               ("MAGE_BA_NO_QUEUED_POSTPASS=1", {"MAGE_BA_NO_QUEUED_POSTPASS": "1"}, None), ("rtol 1e-5", {}, 1e-5)):
+                               ("MAGE_BA_CONSERVATIVE=1", {"MAGE_BA_CONSERVATIVE": "1"}, None), ("rtol 1e-5", {}, 1e-5)):
             old = {k: os.environ.get(k) for k in env}
             os.environ.update(env)
             try:
