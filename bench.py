@@ -762,7 +762,7 @@ def main() -> int:
                        "parallelism": f"replica x{world} (independent sub-maps)",
                        "control_plane": (D.init.backend or "none") + (" (RCCL)" if D.init.backend == "nccl" else "")},
             "roofline": {
-                "kernel": "dense reduced-camera Cholesky (k_potrf_diag + k_trsm_panel + k_syrk_update2 / k_syrk_update[f64 MFMA] + k_bsolve_persist), "
+                "kernel": "dense reduced-camera Cholesky (k_chol_dag: the factorisation + forward substitution as ONE persistent task-graph launch [f64 MFMA], + its state memset + k_bsolve_persist), "
                           "HIP-event span per factorisation on the solver stream",
                 "bound": "mfma", "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": traffic,
