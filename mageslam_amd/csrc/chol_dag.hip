@@ -45,6 +45,7 @@
 // its next task, and the host runs the trial again column by column (chol_report_stall).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -65,6 +66,7 @@ namespace {
 constexpr int D_FACT = 1;       // tile columns whose diagonal tile is factored and in memory
 constexpr int D_YSOL = 2;       // rhs rows solved
 constexpr int D_ABORT = 3;      // a bounded wait ran out somewhere: everybody leaves
+constexpr int D_INJECT = 5;     // test hook (mage_debug_chol_inject_stall): the chain workgroup treats its first wait as run out
 constexpr int D_PROG = 4;       // phased hand-off: 8 tile + block columns of the tile being factored that are in memory
 constexpr int D_HEADS = 16;     // cursor of group g's task list at D_HEADS + 16 g (a cache line each)
 constexpr int N_GROUPS = 8;
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagArgs a)
         if (tid == 0) *bail = 0;
         for (int k = 0; k < nt; ++k) {
             if (k > 0) {
-                if (tid == 0 && !poll_ge(st + D_DARR + k, NDIAG, st + D_ABORT)) {
+                if (tid == 0 && (ld_word(st + D_INJECT) || !poll_ge(st + D_DARR + k, NDIAG, st + D_ABORT))) {
                     if (!ld_word(st + D_ABORT)) { *a.stall = 4.0; st_word(st + D_ABORT, 1); }
                     *bail = 1;
                 }
@@ -898,6 +900,7 @@ struct DagSchedule { unsigned long long* d_tasks = nullptr; int n_tasks = 0, qua
 std::mutex g_sched_mutex;
 std::map<std::pair<int, int>, DagSchedule> g_sched;      // (device, nt)
 int g_dag_n_cu = 256;
+std::atomic<int> g_inject_stalls{ 0 };      // mage_debug_chol_inject_stall: that many launches from now on behave as if a wait had run out
 
 int dag_min_tiles()
 {
@@ -953,6 +956,7 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
     if (!s) return false;
     int* state = ws.sync + 8;
     if (hipMemsetAsync(state, 0, (size_t)dag_state_ints(nt) * sizeof(int), st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (g_inject_stalls.load(std::memory_order_relaxed) > 0 && g_inject_stalls.fetch_sub(1) > 0) (void)hipMemsetAsync(state + D_INJECT, 1, sizeof(int), st);
     DagArgs a;
     a.S = S; a.y = y; a.x = x; a.Linv = ws.Linv; a.Lpub = ws.Linv + (size_t)nt * NBLK * NB * NB; a.ok = ok; a.stall = stall;
     a.st = state; a.trace = ws.dbg; a.tasks = s->d_tasks; a.ld = n_pad; a.nt = nt; a.n_tasks = s->n_tasks; a.quarter_from = s->quarter_from;
@@ -963,6 +967,10 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
 }
 
 }  // namespace mage
+
+// Test hook: the next n task-graph launches of this process abort as they do when a bounded wait runs out (*stall = 4): the caller's trial is
+// re-run by the column-by-column launches and the process stays with them (tests/test_chol_gpu.py).
+MAGE_EXPORT void mage_debug_chol_inject_stall(int n) { mage::g_inject_stalls.store(n, std::memory_order_relaxed); }
 
 // Host-only view of the schedule for tests (tests/test_chol_schedule.py): the nine lists for nt tile columns on n_cu compute units, one
 // behind the other (group_len[9] = their lengths; the last is the express list), and whether check_schedule accepts them.  Returns the total length (<= cap entries

@@ -107,3 +107,39 @@ def test_schedules_are_bit_identical(tmp_path):
         res[tag] = np.load(f)
     for tag, x in res.items():
         assert np.array_equal(x, res["task_graph"]), tag
+
+
+def test_a_stalled_task_graph_launch_is_rerun_column_by_column(tmp_path):
+    """What a deployment sees when a bounded wait of the task-graph launch runs out (several processes oversubscribing the GPU): the launch
+    aborts with *stall = 4, the LM trial is run again from the untouched linearisation by the column-by-column launches -- same bits -- and
+    the process stays with them.  The stall is injected (mage_debug_chol_inject_stall); a child process, because the switch is for life."""
+    import json, os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, json
+        sys.path.insert(0, %r)
+        import numpy as np
+        from mageslam_amd import scene
+        from mageslam_amd.bundler import BundlerLib, load_scene, lib
+        inject = int(sys.argv[2])
+        s = scene.make_scene(n_cams=200, n_pts=6000, n_obs=60000, seed=0x5EED0B12, outlier_frac=0.01)          # 1200 rows: 10 tile columns
+        b = BundlerLib(False); load_scene(b, s, bulk=True)
+        outs = []
+        o = []; outs.append([float(b.StepBundleAdjustment([1.8], 25.0, o))] + sorted(o))
+        if inject: lib().mage_debug_chol_inject_stall(1)
+        for hub, thr in [([0.9, 0.9], 16.0), ([0.9], 9.0)]:
+            o = []; outs.append([float(b.StepBundleAdjustment(hub, thr, o))] + sorted(o))
+        p = b.profile()
+        np.save(sys.argv[1], np.concatenate([b.poses_f64().ravel(), b.points_f64().ravel()]))
+        print("RESULT " + json.dumps(dict(outs=outs, rerun=int(p.trials_rerun_after_stall), fallback=int(p.fallback_to_separate_launches))))
+    """) % root
+    res = {}
+    for tag, inject in (("clean", 0), ("stalled", 1)):
+        f = str(tmp_path / (tag + ".npy"))
+        p = subprocess.run([sys.executable, "-c", code, f, str(inject)], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+        res[tag] = (np.load(f), json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    assert res["clean"][1]["rerun"] == 0 and res["clean"][1]["fallback"] == 0
+    assert res["stalled"][1]["rerun"] == 1 and res["stalled"][1]["fallback"] == 1
+    assert res["stalled"][1]["outs"] == res["clean"][1]["outs"]
+    assert np.array_equal(res["stalled"][0], res["clean"][0])
