@@ -900,6 +900,9 @@ struct DagSchedule { unsigned long long* d_tasks = nullptr; int n_tasks = 0, qua
 std::mutex g_sched_mutex;
 std::map<std::pair<int, int>, DagSchedule> g_sched;      // (device, nt)
 int g_dag_n_cu = 256;
+struct Turnstile { hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool recorded = false; };
+std::mutex g_turn_mutex;
+std::map<int, Turnstile> g_turn;                         // per device: the event behind the latest task-graph launch and the stream it went to
 std::atomic<int> g_inject_stalls{ 0 };      // mage_debug_chol_inject_stall: that many launches from now on behave as if a wait had run out
 
 int dag_min_tiles()
@@ -955,6 +958,18 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
     const DagSchedule* s = get_schedule(nt);
     if (!s) return false;
     int* state = ws.sync + 8;
+    // Two of these launches from two streams of one process must not overlap: each wants every compute unit (one workgroup per unit),
+    // the hardware deals the workgroups of both over the XCDs as units come free, and launch A holding all of XCD 3 while launch B holds
+    // all of XCD 5 leaves A without servers for its group-5 list and B without servers for its group-3 list -- a circular wait that only
+    // the bounded polls end (seen once in 25 000 steps of tests/test_soak_gpu.py).  So the launches of a device take turns: each waits for
+    // the event recorded behind the previous one when that came from another stream.  (Launches of OTHER processes cannot be ordered this
+    // way; there the bounded polls and the column-by-column fallback stay the answer.)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> turn_lock(g_turn_mutex);
+    Turnstile& turn = g_turn[dev];
+    if (!turn.ev && hipEventCreateWithFlags(&turn.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); turn.ev = nullptr; return false; }
+    if (turn.recorded && turn.last != st && hipStreamWaitEvent(st, turn.ev, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (hipMemsetAsync(state, 0, (size_t)dag_state_ints(nt) * sizeof(int), st) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (g_inject_stalls.load(std::memory_order_relaxed) > 0 && g_inject_stalls.fetch_sub(1) > 0) (void)hipMemsetAsync(state + D_INJECT, 1, sizeof(int), st);
     DagArgs a;
@@ -963,6 +978,9 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
     for (int g = 0; g < N_LISTS; ++g) { a.list_off[g] = s->off[g]; a.list_len[g] = s->len[g]; }
     hipLaunchKernelGGL(k_chol_dag, dim3(g_dag_n_cu), dim3(DAG_THREADS), DAG_LDS_BYTES, st, a);
     if (hipGetLastError() != hipSuccess) return false;
+    turn.recorded = hipEventRecord(turn.ev, st) == hipSuccess;
+    turn.last = st;
+    if (!turn.recorded) (void)hipGetLastError();
     return true;
 }
 
