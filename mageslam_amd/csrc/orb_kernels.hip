@@ -29,7 +29,9 @@ __device__ unsigned long long g_orb_clk[32];
 #define ORB_CLK_BEGIN() const bool clk_on = threadIdx.x == 0 && ((blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) & 63) == 0; \
     unsigned long long clk_prev = clk_on ? __builtin_amdgcn_s_memtime() : 0ull; if (clk_on) atomicAdd(&g_orb_clk[31], 1ull)
 #define ORB_CLK(i) do { if (clk_on) { const unsigned long long clk_now = __builtin_amdgcn_s_memtime(); atomicAdd(&g_orb_clk[i], clk_now - clk_prev); clk_prev = clk_now; } } while (0)
+#define ORB_CLK_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else
+#define ORB_CLK_WAIT() do { } while (0)
 #define ORB_CLK_BEGIN() do { } while (0)
 #define ORB_CLK(i) do { } while (0)
 #endif
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(256) void k_fast_keypoints(const uint8_t* __restric
 // ---------------------------------------------------------------------------------------------
 constexpr int SEL_T = 1024;                     // threads
 constexpr int SEL_CAP = 2048, SEL_CELLS = 1024; // LDS working set: candidates after RetainBest, grid cells
-constexpr int SEL_REG = 4;                      // list entries a thread keeps in registers (4096 per frame; more are re-read from HBM)
+constexpr int SEL_ROUNDS = 7;                   // tiles per half wavefront whose first 64 entries stay in registers (32 x 7 = 224 tiles)
 constexpr int SEL_HCOPIES = 16;                 // interleaved copies of the response histogram (same-bin lanes spread over banks)
 
 // inclusive prefix sum along the wavefront: four row_shr steps inside each row of 16 lanes, then the row totals through
@@ -550,6 +552,20 @@ __device__ __forceinline__ int wave_scan_incl(int v, int)
     v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// reduction along the wavefront with an idempotent operation (min / max), result in lane 63: the same six DPP steps; a lane without a
+// source keeps its own value
+template <class Op>
+__device__ __forceinline__ int wave_reduce_to_last(int v, Op op)
+{
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
     return v;
 }
 
@@ -587,10 +603,9 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
 {
 #pragma clang fp contract(off)          // float results feed comparisons that must match the CPU restatement: plain IEEE operations, never an FMA
     __shared__ int sh[16];
-    __shared__ int chunk_start[SEL_T + 1];
     __shared__ int lhist[256 * SEL_HCOPIES];
-    __shared__ int suffix[257];
-    __shared__ int s_mnt, s_cut;
+    __shared__ __attribute__((aligned(16))) int suffix[260];
+    __shared__ int s_n, s_uni[8];
     __shared__ int s_minX, s_maxX, s_minY, s_maxY, s_minS;
     __shared__ __attribute__((aligned(16))) unsigned long long l_cand[SEL_CAP];      // candidates in cell order: pos | response << 32
     __shared__ __attribute__((aligned(16))) unsigned long long l_key[SEL_CAP];
@@ -603,33 +618,66 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
     const int N = a.nfeatures;
     ORB_CLK_BEGIN();
     for (int e = tid; e < 256 * SEL_HCOPIES; e += SEL_T) lhist[e] = 0;
-    if (tid == 0) { s_mnt = -1; s_cut = -1; s_minX = 1 << 30; s_maxX = -1; s_minY = 1 << 30; s_maxY = -1; s_minS = 1 << 30; }
-    // The frame's list is ragged: tile t holds tcount[t] entries in slots t * tile_cap ...  Thread c owns the tiles [c per, (c + 1) per)
-    // (one tile at 640 x 480); chunk_start[c] = entries before them, so entry i of the frame lives in the chunk found by a binary
-    // search and a walk over at most `per` counts.
-    const int per = (a.n_tiles + SEL_T - 1) / SEL_T;
-    {
-        const int t0 = min(tid * per, a.n_tiles), t1 = min(t0 + per, a.n_tiles);
-        int local = 0;
-        for (int t = t0; t < t1; ++t) local += tcount[t];
-        int tot;
-        const int excl = block_scan_excl(local, sh, tot);
-        chunk_start[tid] = excl;
-        if (tid == 0) chunk_start[SEL_T] = tot;
-    }
-    __syncthreads();
-    const int n_raw = chunk_start[SEL_T];
-    auto entry = [&](int i) -> int2 {
-        int lo = 0, hi = SEL_T;                          // chunk_start[lo] <= i < chunk_start[hi]
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_start[mid] <= i) lo = mid; else hi = mid; }
-        int off = i - chunk_start[lo], t = lo * per;
-        if (per > 1) for (int c; off >= (c = tcount[t]); ++t) off -= c;
-        return raw[(size_t)t * a.tile_cap + off];
-    };
-    // the list entries of this thread (thread t owns entries t, t + 1024, ...)
-    int2 rr[SEL_REG];
+    for (int c = tid; c <= SEL_CELLS; c += SEL_T) { l_cellstart[c] = 0; if (c < SEL_CELLS) l_cellfill[c] = 0; }     // (here rather than where they are used: one barrier less on the way)
+    if (tid == 0) { s_n = 0; s_minX = 1 << 30; s_maxX = -1; s_minY = 1 << 30; s_maxY = -1; s_minS = 1 << 30; }
+    // The frame's list is ragged: tile t holds tcount[t] entries in slots t * tile_cap ...  A HALF wavefront owns tile hw, hw + 32, ...
+    // and keeps the first 64 entries of its first SEL_ROUNDS tiles in registers (224 tiles; 640 x 480 has 200 with ~20 entries each,
+    // rarely 40).  The slots are fetched SPECULATIVELY, together with the counts that say which of them are entries: one trip to
+    // memory where "counts -> prefix sums -> binary search per entry -> slots" took two and ~25 LDS round trips (11 k of the kernel's
+    // 75 k cycles on one frame, tools/orb_phase_probe.py).  Entries beyond 64 per tile and tiles beyond 224 are read again from HBM
+    // whenever the set is walked (for_each_entry).
+    const int hw = tid >> 5, l32 = tid & 31;
+    int cnt[SEL_ROUNDS];
+    int2 ra[SEL_ROUNDS], rb[SEL_ROUNDS];
+    const int capm1 = a.tile_cap - 1;
 #pragma unroll
-    for (int k = 0; k < SEL_REG; ++k) { const int i = tid + SEL_T * k; rr[k] = i < n_raw ? entry(i) : make_int2(0, -1); }
+    for (int r = 0; r < SEL_ROUNDS; ++r) {
+        const int t = hw + 32 * r;
+        const bool ok = t < a.n_tiles;
+        const int2* slot = raw + (size_t)(ok ? t : 0) * a.tile_cap;
+        cnt[r] = ok ? tcount[t] : 0;
+        ra[r] = slot[min(l32, capm1)];
+        rb[r] = slot[min(32 + l32, capm1)];
+    }
+    int n_raw;
+    bool overflow = a.n_tiles > 32 * SEL_ROUNDS;
+    {
+        int local = 0;
+        if (l32 == 0) {
+#pragma unroll
+            for (int r = 0; r < SEL_ROUNDS; ++r) local += cnt[r];
+            for (int t = hw + 32 * SEL_ROUNDS; t < a.n_tiles; t += 32) local += tcount[t];
+        }
+#pragma unroll
+        for (int r = 0; r < SEL_ROUNDS; ++r) overflow = overflow || cnt[r] > 64;
+        overflow = __any(overflow);                      // per wavefront: the walk below branches on it uniformly
+        const int incl = wave_scan_incl(local, lane);
+        if (lane == 63) sh[tid >> 6] = incl;
+        __syncthreads();
+        int tot = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += sh[q];
+        n_raw = tot;
+    }
+    ORB_CLK_WAIT();
+    ORB_CLK(16);
+    // every entry of the frame's list exactly once, in no particular order (everything below is a function of the SET)
+    auto for_each_entry = [&](auto fn) {
+#pragma unroll
+        for (int r = 0; r < SEL_ROUNDS; ++r) {
+            if (l32 < cnt[r]) fn(ra[r]);
+            if (32 + l32 < cnt[r]) fn(rb[r]);
+        }
+        if (overflow) {
+#pragma unroll 1
+            for (int r = 0; r < SEL_ROUNDS; ++r)
+                for (int k = 64 + l32; k < cnt[r]; k += 32) fn(raw[(size_t)(hw + 32 * r) * a.tile_cap + k]);
+            for (int t = hw + 32 * SEL_ROUNDS; t < a.n_tiles; t += 32) {
+                const int c = tcount[t];
+                for (int k = l32; k < c; k += 32) fn(raw[(size_t)t * a.tile_cap + k]);
+            }
+        }
+    };
 
     // Keeps every entry as the reference's early returns do (fewer detections than the quota): output in raster order = rank by
     // position.  `get(i)` reads entry i of the set, n of them.
@@ -642,24 +690,32 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
         }
         if (tid == 0) a.out_count[f] = min(n, a.capacity);
     };
+    // the entries that pass `keep`, gathered (in no order) in LDS when they fit and in the frame's scratch otherwise, then emitted by position
+    auto gather_and_emit = [&](auto keep, int upper_bound) {
+        int2* scratch = reinterpret_cast<int2*>(a.cand64 + (size_t)f * a.scratch_cap);
+        const bool fits = upper_bound <= SEL_CAP;
+        for_each_entry([&](int2 r) {
+            if (keep(r)) {
+                const int at = atomicAdd(&s_n, 1);
+                if (fits) l_cand[at] = (unsigned long long)(unsigned)r.x | ((unsigned long long)(unsigned)r.y << 32);
+                else scratch[at] = r;
+            }
+        });
+        __threadfence_block();
+        __syncthreads();
+        if (fits) emit_all_by_position([&](int i) { const unsigned long long v = l_cand[i]; return make_int2((int)(unsigned)v, (int)(v >> 32)); }, s_n);
+        else emit_all_by_position([&](int i) { return scratch[i]; }, s_n);
+    };
     if (n_raw <= N) {
-        if (n_raw <= SEL_CAP) {
-            for (int i = tid; i < n_raw; i += SEL_T) { const int2 r = entry(i); l_cand[i] = (unsigned long long)(unsigned)r.x | ((unsigned long long)(unsigned)r.y << 32); }
-            __syncthreads();
-            emit_all_by_position([&](int i) { const unsigned long long v = l_cand[i]; return make_int2((int)(unsigned)v, (int)(v >> 32)); }, n_raw);
-        } else emit_all_by_position(entry, n_raw);
+        gather_and_emit([](int2) { return true; }, n_raw);
         return;
     }
     // ---- RetainBestFeatures (OpenCVModified.cpp:571-617): whole histogram bins from 255 downwards.  Histogram of the responses
     // with LDS atomics on 16 interleaved copies (most responses sit in a handful of low bins), suffix[i] = number of
     // responses >= i, and the two thresholds are "largest bin whose suffix count reaches the quota".
-    auto for_each_entry = [&](auto fn) {
-#pragma unroll
-        for (int k = 0; k < SEL_REG; ++k) if (tid + SEL_T * k < n_raw) fn(rr[k]);
-        for (int i = tid + SEL_T * SEL_REG; i < n_raw; i += SEL_T) fn(entry(i));
-    };
     for_each_entry([&](int2 r) { atomicAdd(&lhist[(r.y & 255) * SEL_HCOPIES + (lane & (SEL_HCOPIES - 1))], 1); });
     __syncthreads();
+    ORB_CLK(17);
     {
         int v = 0;
         if (tid < 256) {
@@ -674,14 +730,19 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
         if (tid == 0) suffix[256] = 0;
     }
     __syncthreads();
+    ORB_CLK(18);
+    // suffix[] does not increase with the bin, so "the largest bin whose count reaches q" is (number of bins that reach q) - 1: four bins
+    // per lane, four ballots, no atomic and no barrier (256 lanes raising one LDS word with atomicMax took 2.6 k cycles per threshold)
     const int min_thr = a.fast_threshold;
-    if (tid < 256 && tid >= min_thr && suffix[tid] >= N) atomicMax(&s_mnt, tid);
-    __syncthreads();
-    const int mnt = s_mnt >= 0 ? s_mnt : min_thr;
+    const int4 sfx = *reinterpret_cast<const int4*>(&suffix[4 * lane]);
+    auto bins_reaching = [&](int q) {
+        return __popcll(__ballot(sfx.x >= q)) + __popcll(__ballot(sfx.y >= q)) + __popcll(__ballot(sfx.z >= q)) + __popcll(__ballot(sfx.w >= q));
+    };
+    const int top_n = bins_reaching(N) - 1;
+    const int mnt = top_n >= min_thr ? top_n : min_thr;
     const int lower = max((int)((float)mnt * a.feature_strength), min_thr);
-    if (tid < 256 && tid >= lower && suffix[tid] >= a.max_num) atomicMax(&s_cut, tid);
-    __syncthreads();
-    const int cut = s_cut >= 0 ? s_cut : lower;
+    const int top_m = bins_reaching(a.max_num) - 1;
+    const int cut = top_m >= lower ? top_m : lower;
     const int M = cut < 256 ? suffix[cut] : 0;          // how many candidates RetainBest keeps
     ORB_CLK(10);
     // bounding box and weakest response of the kept set
@@ -693,12 +754,11 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
                 mnx = min(mnx, x); mxx = max(mxx, x); mny = min(mny, y); mxy = max(mxy, y); mns = min(mns, r.y);
             }
         });
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            mnx = min(mnx, __shfl_xor(mnx, o, 64)); mxx = max(mxx, __shfl_xor(mxx, o, 64));
-            mny = min(mny, __shfl_xor(mny, o, 64)); mxy = max(mxy, __shfl_xor(mxy, o, 64)); mns = min(mns, __shfl_xor(mns, o, 64));
-        }
-        if (lane == 0 && mxx >= 0) {
+        auto lo = [](int p, int q) { return min(p, q); };
+        auto hi = [](int p, int q) { return max(p, q); };
+        mnx = wave_reduce_to_last(mnx, lo); mxx = wave_reduce_to_last(mxx, hi);
+        mny = wave_reduce_to_last(mny, lo); mxy = wave_reduce_to_last(mxy, hi); mns = wave_reduce_to_last(mns, lo);
+        if (lane == 63 && mxx >= 0) {
             atomicMin(&s_minX, mnx); atomicMax(&s_maxX, mxx); atomicMin(&s_minY, mny); atomicMax(&s_maxY, mxy); atomicMin(&s_minS, mns);
         }
     }
@@ -706,53 +766,62 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
     ORB_CLK(11);
     if (N > M) {
         // AdaptiveNonMaximalSuppresion returns its input when there is nothing to suppress (feature_strength > 1 can cut below
-        // the quota): the kept set in raster order.  Rare, so the set is simply re-filtered from HBM.
-        int2* scratch = reinterpret_cast<int2*>(a.cand64 + (size_t)f * a.scratch_cap);
-        __shared__ int s_n;
-        if (tid == 0) s_n = 0;
-        __syncthreads();
-        for (int i = tid; i < n_raw; i += SEL_T) { const int2 r = entry(i); if (r.y >= cut) scratch[atomicAdd(&s_n, 1)] = r; }
-        __threadfence_block();
-        __syncthreads();
-        emit_all_by_position([&](int i) { return scratch[i]; }, s_n);
+        // the quota): the kept set in raster order.
+        gather_and_emit([&](int2 r) { return r.y >= cut; }, M);
         return;
     }
     // ---- AdaptiveNonMaximalSuppresion (OpenCVModified.cpp:144-360)
     const int minX = s_minX, maxX = s_maxX, minY = s_minY, maxY = s_maxY;
     const int numX = a.cells_x, numY = a.cells_y, thr = a.fast_threshold;
-    float rf;
-    {
-        const float hi = (float)a.strong_response - (float)thr;
-        float val = (float)s_minS - (float)thr;
-        val = val < 0.0f ? 0.0f : (val > hi ? hi : val);
-        float range = a.max_robust - a.min_robust;
-        if (range < 0.0f) range = 0.0f;
-        rf = a.max_robust - (val / (float)(a.strong_response - thr)) * range;
-    }
-    const int globalMaxR2 = (int)(((double)(maxX - minX)) * ((double)(maxY - minY)) / (double)N);
-    int minCellDelta2;
-    {
-        const int dx = max((maxX - minX) / numX, 1), dy = max((maxY - minY) / numY, 1);
-        const int m = min(dx, dy);
-        minCellDelta2 = m * m;
-    }
-    const bool narrow_box = (maxX - minX) < numX || (maxY - minY) < numY;
     // Division by the bounding box's extents (uniform per frame, non-negative dividends below 2^31): multiply-high by a magic number
     // made once -- the compiler's general 32-bit division is ~40 vector instructions, and every candidate is divided six times.
     // q = floor(n / d) exactly for 0 <= n < 2^31: M = floor(2^32 (2^s - d) / d) + 1 with s = ceil(log2 d), t = mulhi(n, M), q = (t + ((n - t) >> 1)) >> (s - 1)
     struct UDiv { unsigned M; int s; };
+    // (the magic number by long division in two 16-bit steps: d <= 65536 -- coordinates are 16 bits -- so e = 2^s - d < d and both partial
+    // dividends fit 32 bits; the 64-bit division this replaces is ~1.5 k cycles of library code, twice per frame)
     auto make_udiv = [](unsigned d) -> UDiv {
-        int sft = 0;
-        while ((1u << sft) < d) ++sft;                 // d >= 1
-        const unsigned long long M = (((1ull << sft) - d) << 32) / d + 1ull;
-        return UDiv{ (unsigned)M, sft };
+        const int sft = d <= 1u ? 0 : 32 - __clz((int)(d - 1u));      // smallest s with 2^s >= d
+        const unsigned e = (1u << sft) - d;
+        const unsigned t1 = (e << 16) / d, r1 = (e << 16) - t1 * d;
+        const unsigned t2 = (r1 << 16) / d;
+        return UDiv{ (t1 << 16) + t2 + 1u, sft };
     };
     auto udiv = [](unsigned n, const UDiv& D) -> int {
         if (D.s == 0) return (int)n;                    // d == 1
         const unsigned t = __umulhi(n, D.M);
         return (int)((t + ((n - t) >> 1)) >> (D.s - 1));
     };
-    const UDiv divX = make_udiv((unsigned)(maxX + 1 - minX)), divY = make_udiv((unsigned)(maxY + 1 - minY));
+    // The per-frame constants are ~350 instructions of divisions.  Sixteen wavefronts each working them out is 4 x 350 issue slots
+    // per SIMD (5.6 k cycles, the largest single item of the "cell counts" phase); four wavefronts on four SIMDs take a quarter each
+    // and hand the results over through LDS.
+    {
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        if (w == 0) {
+            const UDiv d = make_udiv((unsigned)(maxX + 1 - minX));
+            if (lane == 0) { s_uni[0] = (int)d.M; s_uni[1] = d.s; }
+        } else if (w == 1) {
+            const UDiv d = make_udiv((unsigned)(maxY + 1 - minY));
+            if (lane == 0) { s_uni[2] = (int)d.M; s_uni[3] = d.s; }
+        } else if (w == 2) {
+            const float hi = (float)a.strong_response - (float)thr;
+            float val = (float)s_minS - (float)thr;
+            val = val < 0.0f ? 0.0f : (val > hi ? hi : val);
+            float range = a.max_robust - a.min_robust;
+            if (range < 0.0f) range = 0.0f;
+            const float rf_ = a.max_robust - (val / (float)(a.strong_response - thr)) * range;
+            if (lane == 0) s_uni[4] = __float_as_int(rf_);
+        } else if (w == 3) {
+            const int g = (int)(((double)(maxX - minX)) * ((double)(maxY - minY)) / (double)N);
+            const int dx = max((maxX - minX) / numX, 1), dy = max((maxY - minY) / numY, 1);
+            const int m = min(dx, dy);
+            if (lane == 0) { s_uni[5] = g; s_uni[6] = m * m; }
+        }
+        __syncthreads();
+    }
+    const UDiv divX = { (unsigned)s_uni[0], s_uni[1] }, divY = { (unsigned)s_uni[2], s_uni[3] };
+    const float rf = __int_as_float(s_uni[4]);
+    const int globalMaxR2 = s_uni[5], minCellDelta2 = s_uni[6];
+    const bool narrow_box = (maxX - minX) < numX || (maxY - minY) < numY;
     auto cell_of = [&](int pos) { return udiv((unsigned)(((pos >> 16) - minY) * numY), divY) * numX + udiv((unsigned)(((pos & 0xffff) - minX) * numX), divX); };
     // The working set (candidates in cell order, cell starts, keys) lives in LDS whenever it fits; oversized inputs run the same
     // code on the per-frame scratch in HBM.
@@ -760,10 +829,13 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
     auto suppress_and_rank = [&](unsigned long long* cand, int* cellstart, int* cellfill, unsigned long long* key) {
         // counting sort of the kept set by grid cell: cellstart[c] .. cellstart[c + 1] are the members of cell c, and the cells of
         // one grid row are consecutive, so a row of the search window is ONE contiguous range
-        for (int c = tid; c <= a.ncells; c += SEL_T) { cellstart[c] = 0; if (c < a.ncells) cellfill[c] = 0; }
-        __syncthreads();
+        if (cellstart != l_cellstart) {
+            for (int c = tid; c <= a.ncells; c += SEL_T) { cellstart[c] = 0; if (c < a.ncells) cellfill[c] = 0; }
+            __syncthreads();
+        }
         for_each_entry([&](int2 r) { if (r.y >= cut) atomicAdd(&cellstart[cell_of(r.x) + 1], 1); });
         __syncthreads();
+        ORB_CLK(19);
         {   // inclusive scan of the counts, in place: thread t owns cells [t*per, (t+1)*per)
             const int per = (a.ncells + SEL_T - 1) / SEL_T;
             const int c0 = min(tid * per, a.ncells), c1 = min(c0 + per, a.ncells);
@@ -775,6 +847,7 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
         }
         __threadfence_block();
         __syncthreads();
+        ORB_CLK(20);
         for_each_entry([&](int2 r) {
             if (r.y >= cut) {
                 const int c = cell_of(r.x);
@@ -827,16 +900,21 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
                 if (cYY < 0 || cYY >= numY) continue;
                 const int xl = max(cx - D, 0), xh = min(cx + D, numX - 1);
                 const int q1 = cellstart[cYY * numX + xh + 1];
-                bool hit = false;
-                for (int q = cellstart[cYY * numX + xl]; q < q1; ++q) {
-                    const unsigned long long o = cand[q];
-                    if ((float)(int)(o >> 32) > s) {
-                        const int ddx = x - (int)((unsigned)o & 0xffffu), ddy = y - (int)((unsigned)o >> 16);
+                // four members per trip, fetched together (the loop is a chain of LDS round trips otherwise); the last trip repeats the
+                // range's final member, which a minimum does not notice
+                const int before = minR2;
+                for (int q = cellstart[cYY * numX + xl]; q < q1; q += 4) {
+                    unsigned long long o[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) o[u] = cand[min(q + u, q1 - 1)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ddx = x - (int)((unsigned)o[u] & 0xffffu), ddy = y - (int)((unsigned)o[u] >> 16);
                         const int r2 = ddx * ddx + ddy * ddy;
-                        if (r2 < minR2) { minR2 = r2; hit = true; }
+                        minR2 = ((float)(int)(o[u] >> 32) > s && r2 < minR2) ? r2 : minR2;
                     }
                 }
-                if (hit) D = min(D, ring_max(minR2));
+                if (minR2 < before) D = min(D, ring_max(minR2));
             }
             // total order of the output: radius desc, response desc, raster position asc
             if (globalMaxR2 < (1 << 24))
@@ -849,6 +927,9 @@ __global__ __launch_bounds__(SEL_T) void k_select(OrbSelectArgs a)
         // ---- keep the N first of the total order; rank = output position
         // (A counting sort by radius that leaves only candidates of equal radius to compare was tried: its six barriers and two atomic
         // passes cost more than this loop, 34 k cycles against 18 k per frame.)
+        // (Measured and left out in round 5: the transposed form -- a wavefront holds 64 keys one per lane, key_i comes out of its lane into
+        // scalar registers, one 64-bit compare tests it against 64 keys and the scalar unit counts the mask.  One vector instruction per
+        // 64 pairs instead of two, but two SCALAR ones, and a SIMD issues those no faster than vector ones: 18 k -> 25 k cycles.)
         for (int i = tid; i < M; i += SEL_T) {
             int rank = 0;
             const unsigned long long ki = key[i];

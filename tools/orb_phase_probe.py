@@ -33,7 +33,7 @@ def build():
 
 
 FAST = {0: "zero + stage window", 1: "compass test + compaction", 2: "pair test + exact score of survivors", 3: "3x3 NMS + horizontal blur pass + keypoint output", 4: "vertical blur pass"}
-SELECT = {10: "histogram suffix scan + thresholds", 11: "compaction of candidates + bounding box", 12: "cell binning", 13: "ring search (radii)", 14: "rank + output"}
+SELECT = {15: "zero + tile-count scan", 16: "entries into registers", 17: "histogram", 18: "suffix scan", 10: "thresholds", 19: "cell counts", 20: "cell scan", 12: "cell scatter", 11: "compaction of candidates + bounding box", 13: "ring search (radii)", 14: "rank + output"}
 
 
 def main():
