@@ -89,6 +89,47 @@ def main():
                 "cpu_oracle_frames_per_s": cpu_fps, "cpu_oracle_pairs_per_s": cpu_pps, "cpu_cores": 1}
         print(json.dumps(line), flush=True)
 
+    # the vocabulary's leaf lookup and IndexedMatch through it (OnlineBow::FindLeafNode / QueryFeatures): a 10-ary tree of depth 4
+    # (11 111 nodes, 10 000 leaves, random medoids), the two frames' 440 + 440 descriptors per call from host memory -- the call a
+    # relocalisation makes -- against the CPU oracle's same call
+    from oracle import oracle as ORC
+    rng = np.random.default_rng(5)
+    kk, depth = 10, 4
+    n_nodes = sum(kk ** d for d in range(depth + 1))
+    node_desc = rng.integers(0, 256, (n_nodes, 32), dtype=np.uint8)
+    inner = sum(kk ** d for d in range(depth))
+    child_off = np.zeros(n_nodes + 1, np.int32)
+    child_off[1:inner + 1] = kk * np.arange(1, inner + 1)
+    child_off[inner + 1:] = child_off[inner]
+    children = np.arange(1, n_nodes, dtype=np.int32)
+    A = rng.integers(0, 256, (CAP, 32), dtype=np.uint8)
+    B = A.copy(); B[:, 0] ^= rng.integers(0, 4, CAP, dtype=np.uint8)
+    leaf_gpu = mt.BowFindLeaf(node_desc, child_off, children, np.concatenate([A, B]))
+    t0 = time.perf_counter(); leaf_cpu = ORC.bow_find_leaf(node_desc, child_off, children, np.concatenate([A, B])); cpu_leaf_s = time.perf_counter() - t0
+    assert np.array_equal(leaf_gpu, leaf_cpu)
+
+    def csr(leaves):
+        order = np.argsort(leaves, kind="stable").astype(np.int32)
+        off = np.zeros(n_nodes + 1, np.int32)
+        np.add.at(off, leaves + 1, 1)
+        return np.cumsum(off).astype(np.int32), order
+    fao, fa = csr(leaf_gpu[:CAP]); fbo, fb = csr(leaf_gpu[CAP:])
+    got = mt.IndexedMatchBow(node_desc, child_off, children, A, fao, fa, B, fbo, fb, 30, 1)
+    t0 = time.perf_counter(); want = ORC.indexed_match_bow(node_desc, child_off, children, A, fao, fa, B, fbo, fb, 30, 1); cpu_im_s = time.perf_counter() - t0
+    assert np.array_equal(np.asarray(got).view(np.uint8), np.asarray(want).view(np.uint8))
+    reps = 200
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        mt.BowFindLeaf(node_desc, child_off, children, np.concatenate([A, B]))
+    leaf_s = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        mt.IndexedMatchBow(node_desc, child_off, children, A, fao, fa, B, fbo, fb, 30, 1)
+    im_s = (time.perf_counter() - t0) / reps
+    print(json.dumps({"config": f"BoW leaf lookup + IndexedMatch, {kk}-ary tree of depth {depth} ({n_nodes} nodes), {2 * CAP} descriptors per call, host buffers in and out (tree upload included)",
+                      "find_leaf_ms_per_call": leaf_s * 1e3, "descriptors_per_s": 2 * CAP / leaf_s, "indexed_match_bow_ms_per_call": im_s * 1e3, "matches": int(len(got)),
+                      "cpu_oracle_find_leaf_ms": cpu_leaf_s * 1e3, "cpu_oracle_indexed_match_bow_ms": cpu_im_s * 1e3, "bit_exact_vs_oracle": True}), flush=True)
+
 
 if __name__ == "__main__":
     main()
