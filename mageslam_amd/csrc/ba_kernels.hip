@@ -107,6 +107,13 @@ __host__ inline int xcd_camera_grid(int n) { return (((n + 7) / 8 + 3) / 4) * 8;
 
 struct PoseD { double qx, qy, qz, qw, tx, ty, tz; };
 
+// a value that is the same in every lane, moved to scalar registers
+__device__ __forceinline__ double uniform_f64(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ PoseD load_pose(const double* __restrict__ p, int cam)
 {
     const double2* q = reinterpret_cast<const double2*>(p + (size_t)cam * 8);
@@ -1313,6 +1320,9 @@ constexpr int SMALL_LPL = 8, SMALL_CPC = 4;
 // cpc = workgroups per camera: SMALL_CPC for the few cameras of a small problem (their quarters are added by the last block), 1 for
 // the large-problem use of the same kernel (ba_fused_linearize: hundreds of cameras, the workgroup writes U and b_c itself);
 // zero_role = 0 drops the S / y zero-fill block (large systems clear S with k_zero_lower).
+// DUP = some observations share a W slot (the landmark role then walks a landmark's observations on one thread and sums the blocks of
+// a slot in order): a launch is entirely one kind or the other, and compiled together the rare kind's 27 accumulators set the spills of both.
+template <bool DUP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_small_linearize(BaDeviceView v, double delta, int nbL, int want_maxdiag, int* __restrict__ counter, int cpc,
                                                          int zero_role)
 {
@@ -1324,7 +1334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int nbC = cpc == 1 ? ((v.n_fc + 7) / 8) * 8 + 8 : v.n_fc * cpc;       // cpc == 1: runs of cameras per XCD (camera role below)
     double* cam_part = v.partial + n_blocks;           // n_fc x cpc x 28 partial (U, b_c) sums, behind the chi2 partials
     double chi = 0;                                    // this thread's share of the robust chi2 (one role per problem kind owns it)
-    if (bid < nbL && !v.dup_slots) {
+    if (bid < nbL && !DUP) {
         // ---- landmark role, SMALL_LPL lanes per landmark: lane `sub` takes observations beg + sub, beg + sub + 8, ...; every
         // observation owns its W block (no two share a slot), V_l and b_l are summed over the lanes in a fixed tree
         const int gl = bid * 256 + tid, l = gl / SMALL_LPL, sub = gl % SMALL_LPL;
@@ -1476,9 +1486,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 return;
             }
         }
-        const int cam = v.hc2cam[hc];
+        // the workgroup's camera is the same in every lane: its pose and focal length live in scalar registers (14 + 2 of them instead
+        // of 16 vector registers per lane -- what the 27 accumulators of the loop below were being spilled for)
+        const int cam = __builtin_amdgcn_readfirstlane(v.hc2cam[hc]);
         PoseD P = load_pose(v.pose_cur, cam);
-        const double f = v.camK[cam * 4];
+        P.qx = uniform_f64(P.qx); P.qy = uniform_f64(P.qy); P.qz = uniform_f64(P.qz); P.qw = uniform_f64(P.qw);
+        P.tx = uniform_f64(P.tx); P.ty = uniform_f64(P.ty); P.tz = uniform_f64(P.tz);
+        const double f = uniform_f64(v.camK[cam * 4]);
         if (v.compact && quarter == 0 && tid == 0) {
             double R[9];
             q_to_R(P.qx, P.qy, P.qz, P.qw, R);
@@ -2392,7 +2406,8 @@ static int small_error_blocks(const BaDeviceView& v) { return v.n_L > 0 ? std::m
 void ba_small_linearize(const BaDeviceView& v, double delta, bool want_maxdiag, int* counter, hipStream_t st)
 {
     const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm * (v.dup_slots ? 1 : SMALL_LPL), 256) : 0;
-    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + v.n_fc * SMALL_CPC + 1), dim3(256), 0, st, v, delta, nbL, want_maxdiag ? 1 : 0, counter, SMALL_CPC, 1);
+    if (v.dup_slots) hipLaunchKernelGGL(k_small_linearize<true>, dim3(nbL + v.n_fc * SMALL_CPC + 1), dim3(256), 0, st, v, delta, nbL, want_maxdiag ? 1 : 0, counter, SMALL_CPC, 1);
+    else hipLaunchKernelGGL(k_small_linearize<false>, dim3(nbL + v.n_fc * SMALL_CPC + 1), dim3(256), 0, st, v, delta, nbL, want_maxdiag ? 1 : 0, counter, SMALL_CPC, 1);
 }
 // Positions of the compact records (BaDeviceView::w_pos): camera-major = the inverse of camS, or the identity.
 __global__ __launch_bounds__(256) void k_build_positions(BaDeviceView v, int* __restrict__ w_pos, int* __restrict__ pos_lm, int camera_major)
@@ -2473,7 +2488,8 @@ int ba_fused_linearize(const BaDeviceView& v, double delta, int* counter, hipStr
     const int nbL = (v.points_free && v.n_lm > 0) ? cdiv(v.n_lm * SMALL_LPL, 256) : 0;
     const int nbC = ((v.n_fc + 7) / 8) * 8 + 8;          // every XCD gets ceil(n_fc / 8) camera workgroups wherever its first one falls
     const bool defer = defer_chi_fold && v.n_T == 0 && v.n_pad >= 1024;
-    hipLaunchKernelGGL(k_small_linearize, dim3(nbL + nbC), dim3(256), 0, st, v, delta, nbL, 0, counter, 1, 0);
+    if (v.dup_slots) hipLaunchKernelGGL(k_small_linearize<true>, dim3(nbL + nbC), dim3(256), 0, st, v, delta, nbL, 0, counter, 1, 0);
+    else hipLaunchKernelGGL(k_small_linearize<false>, dim3(nbL + nbC), dim3(256), 0, st, v, delta, nbL, 0, counter, 1, 0);
     if (!defer) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, v.partial, nbL + nbC, 1, v.scal + SC_CHI, 1);
     tether_launch_error(v, false, st);          // the pose-pose edges add their chi2, U and b_c on top (nothing is launched without them)
     tether_launch_linearize(v, st);
