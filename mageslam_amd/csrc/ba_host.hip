@@ -142,6 +142,7 @@ void cached_stream_release(int device, hipStream_t st)
         std::lock_guard<std::mutex> lock(c.m);
         if (c.streams[device].size() < 16) { c.streams[device].push_back(st); return; }
     }
+    chol_forget_stream(st);
     (void)hipStreamDestroy(st);
 }
 
@@ -1665,7 +1666,7 @@ MAGE_EXPORT void mage_release_cached_memory(void)
         for (auto& kv : c.parked[d]) (void)hipFree(kv.second);
         c.parked[d].clear();
         c.held[d] = 0;
-        for (hipStream_t st : c.streams[d]) (void)hipStreamDestroy(st);
+        for (hipStream_t st : c.streams[d]) { chol_forget_stream(st); (void)hipStreamDestroy(st); }
         c.streams[d].clear();
     }
     for (auto& kv : c.pinned) (void)hipHostFree(kv.second);

@@ -900,7 +900,7 @@ struct DagSchedule { unsigned long long* d_tasks = nullptr; int n_tasks = 0, qua
 std::mutex g_sched_mutex;
 std::map<std::pair<int, int>, DagSchedule> g_sched;      // (device, nt)
 int g_dag_n_cu = 256;
-struct Turnstile { hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool recorded = false; };
+struct Turnstile { hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool recorded = false, several = false; };
 std::mutex g_turn_mutex;
 std::map<int, Turnstile> g_turn;                         // per device: the event behind the latest task-graph launch and the stream it went to
 std::atomic<int> g_inject_stalls{ 0 };      // mage_debug_chol_inject_stall: that many launches from now on behave as if a wait had run out
@@ -962,14 +962,21 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
     // the hardware deals the workgroups of both over the XCDs as units come free, and launch A holding all of XCD 3 while launch B holds
     // all of XCD 5 leaves A without servers for its group-5 list and B without servers for its group-3 list -- a circular wait that only
     // the bounded polls end (seen once in 25 000 steps of tests/test_soak_gpu.py).  So the launches of a device take turns: each waits for
-    // the event recorded behind the previous one when that came from another stream.  (Launches of OTHER processes cannot be ordered this
-    // way; there the bounded polls and the column-by-column fallback stay the answer.)
+    // the event recorded behind the previous one when that came from another stream.  A process that only ever uses ONE stream pays
+    // nothing (an event record is a barrier packet: 6 us of idle stream between this launch and the backward solve): the events start
+    // with the second stream seen, whose first launch also puts one behind whatever the first stream has queued so far.  (Launches
+    // of OTHER processes cannot be ordered this way; there the bounded polls and the column-by-column fallback stay the answer.)
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> turn_lock(g_turn_mutex);
     Turnstile& turn = g_turn[dev];
-    if (!turn.ev && hipEventCreateWithFlags(&turn.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); turn.ev = nullptr; return false; }
-    if (turn.recorded && turn.last != st && hipStreamWaitEvent(st, turn.ev, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (!turn.several && turn.last && turn.last != st) {
+        if (!turn.ev && hipEventCreateWithFlags(&turn.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); turn.ev = nullptr; return false; }
+        turn.several = true;
+        turn.recorded = hipEventRecord(turn.ev, turn.last) == hipSuccess;       // (`last` is alive: chol_forget_stream clears it before a stream is destroyed)
+        if (!turn.recorded) (void)hipGetLastError();
+    }
+    if (turn.several && turn.recorded && turn.last != st && hipStreamWaitEvent(st, turn.ev, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (hipMemsetAsync(state, 0, (size_t)dag_state_ints(nt) * sizeof(int), st) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (g_inject_stalls.load(std::memory_order_relaxed) > 0 && g_inject_stalls.fetch_sub(1) > 0) (void)hipMemsetAsync(state + D_INJECT, 1, sizeof(int), st);
     DagArgs a;
@@ -978,10 +985,19 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
     for (int g = 0; g < N_LISTS; ++g) { a.list_off[g] = s->off[g]; a.list_len[g] = s->len[g]; }
     hipLaunchKernelGGL(k_chol_dag, dim3(g_dag_n_cu), dim3(DAG_THREADS), DAG_LDS_BYTES, st, a);
     if (hipGetLastError() != hipSuccess) return false;
-    turn.recorded = hipEventRecord(turn.ev, st) == hipSuccess;
+    if (turn.several) {
+        turn.recorded = hipEventRecord(turn.ev, st) == hipSuccess;
+        if (!turn.recorded) (void)hipGetLastError();
+    }
     turn.last = st;
-    if (!turn.recorded) (void)hipGetLastError();
     return true;
+}
+
+// a stream is about to be destroyed: the turnstile must not put an event behind it later
+void chol_forget_stream(hipStream_t st)
+{
+    std::lock_guard<std::mutex> turn_lock(g_turn_mutex);
+    for (auto& kv : g_turn) if (kv.second.last == st) kv.second.last = nullptr;
 }
 
 }  // namespace mage

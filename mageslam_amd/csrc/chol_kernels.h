@@ -17,6 +17,7 @@ size_t chol_sync_ints(int n_pad);      // hand-off counters of the launches + th
 constexpr int CHOL_MAX_ORDER = 256 * CHOL_TILE;   // the persistent backward solve needs one resident workgroup per tile column
 bool chol_merge_fallback_active();   // true once chol_report_stall(2) has switched this process to separate panel-solve launches
 void chol_report_stall(int code);   // the host saw *stall = code (1 split diagonal tile, 2 merged panel solve, 3 backward solve, 4 task-graph launch, 9 a launch was refused): adapts the schedule
+void chol_forget_stream(hipStream_t st);   // before hipStreamDestroy of a stream that chol_factor_solve has been given (chol_dag.hip: the launches of a device take turns by events)
 void chol_init_device();   // once per device (after hipSetDevice): opt the LDS-heavy kernels in
 
 // Factor S = L L^T in place (lower triangle, column-major, n_pad multiple of CHOL_TILE) and solve

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Timeline of the LAST bundle-adjustment step in a rocprofv3 rocpd .db: kernels in start order with the idle gap
 before each (gaps >= --gap us are printed), plus busy/idle totals between the last two k_classify dispatches.
-    python tools/rocpd_timeline.py gpurun_out/prof/x_results.db [--gap 3]
+    python tools/rocpd_timeline.py gpurun_out/prof/x_results.db [--gap 3] [--back K]
 """
 import re
 import sqlite3
 import sys
 
 
-def main(path: str, gap_us: float) -> None:
+def main(path: str, gap_us: float, back: int = 0) -> None:
     con = sqlite3.connect(path)
     cur = con.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
@@ -17,6 +17,8 @@ def main(path: str, gap_us: float) -> None:
     rows = cur.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
     rows = [(re.sub(r"\(.*", "", re.sub(r"^void ", "", n)), s, e) for n, s, e in rows]
     marks = [i for i, r in enumerate(rows) if "k_classify" in r[0]]
+    if back:
+        marks = marks[:-back]      # --back K: the step K before the last one (bench.py's last steps carry stage events)
     if len(marks) < 2:
         print("need two k_classify dispatches"); return
     seg = rows[marks[-2] + 1: marks[-1] + 1]
@@ -43,4 +45,5 @@ if __name__ == "__main__":
     gap = 3.0
     if "--gap" in sys.argv:
         gap = float(sys.argv[sys.argv.index("--gap") + 1])
-    main(sys.argv[1], gap)
+    back = int(sys.argv[sys.argv.index("--back") + 1]) if "--back" in sys.argv else 0
+    main(sys.argv[1], gap, back)
