@@ -108,7 +108,7 @@ typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(1))) int global_int;
 
 struct DagArgs {
-    double* S; double* y; double* x; double* Linv; double* Lpub; double* ok; double* stall;
+    double* S; double* y; double* x; double* Linv; double* Lpub; double* part; double* ok; double* stall;
     int* st;                               // state words
     const unsigned long long* tasks;       // the eight lists behind each other
     int list_off[N_LISTS], list_len[N_LISTS];
@@ -371,7 +371,8 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagArgs a)
             // the other four wavefronts open the solve -- x pre-filled with the sentinel the backward substitution polls for -- and leave
             // (the hardware barrier below then counts the four that stay)
             unsigned long long* xf = reinterpret_cast<unsigned long long*>(a.x);
-            for (int i = tid - 256; i < nt * TILE; i += 256) xf[i] = X_SENTINEL;
+            unsigned long long* pf = reinterpret_cast<unsigned long long*>(a.part);       // ... and the backward solve's partial sums (same protocol)
+            for (int i = tid - 256; i < nt * TILE; i += 256) { xf[i] = X_SENTINEL; pf[i] = X_SENTINEL; }
             return;
         }
         if (tid == 0) { *a.ok = 1.0; *a.stall = 0.0; }
@@ -980,7 +981,7 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
     if (hipMemsetAsync(state, 0, (size_t)dag_state_ints(nt) * sizeof(int), st) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (g_inject_stalls.load(std::memory_order_relaxed) > 0 && g_inject_stalls.fetch_sub(1) > 0) (void)hipMemsetAsync(state + D_INJECT, 1, sizeof(int), st);
     DagArgs a;
-    a.S = S; a.y = y; a.x = x; a.Linv = ws.Linv; a.Lpub = ws.Linv + (size_t)nt * NBLK * NB * NB; a.ok = ok; a.stall = stall;
+    a.S = S; a.y = y; a.x = x; a.Linv = ws.Linv; a.Lpub = ws.Linv + (size_t)nt * NBLK * NB * NB; a.part = a.Lpub + (size_t)nt * LPUB_TILE_DOUBLES; a.ok = ok; a.stall = stall;
     a.st = state; a.trace = ws.dbg; a.tasks = s->d_tasks; a.ld = n_pad; a.nt = nt; a.n_tasks = s->n_tasks; a.quarter_from = s->quarter_from;
     for (int g = 0; g < N_LISTS; ++g) { a.list_off[g] = s->off[g]; a.list_len[g] = s->len[g]; }
     hipLaunchKernelGGL(k_chol_dag, dim3(g_dag_n_cu), dim3(DAG_THREADS), DAG_LDS_BYTES, st, a);

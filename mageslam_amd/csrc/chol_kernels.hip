@@ -43,14 +43,14 @@ std::atomic<bool> g_merge_disabled{ false };
 // with the sentinel the backward substitution polls for.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int ld, int k, double* __restrict__ Linv_k,
-                                                    double* __restrict__ ok, double* __restrict__ stall, unsigned long long* __restrict__ x_fill, int n_fill)
+                                                    double* __restrict__ ok, double* __restrict__ stall, unsigned long long* __restrict__ x_fill, int n_fill, unsigned long long* __restrict__ part_fill)
 {
     extern __shared__ double sm[];
     double* A = sm;                       // LayPacked: the 36 lower blocks
     double* Li = sm + PACKED_TILE_DOUBLES;   // 2 x (16 x 16): inverse of the current / next diagonal block
     const int tid = threadIdx.x;
     if (tid == 0) { *ok = 1.0; *stall = 0.0; }
-    for (int i = tid; i < n_fill; i += 256) x_fill[i] = X_SENTINEL;
+    for (int i = tid; i < n_fill; i += 256) { x_fill[i] = X_SENTINEL; part_fill[i] = X_SENTINEL; }      // (the backward solve's partial sums: same protocol)
     double* T = S + (size_t)(k * TILE) * ld + (size_t)k * TILE;
     load_tile_packed(A, T, ld, tid);
     __syncthreads();
@@ -305,31 +305,43 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
 // ---------------------------------------------------------------------------------------------
 
 
+// TWO workgroups per tile column (round 5).  A column consumes one 128-KB tile per arriving x_k, and fetching it into the LDS buffer can
+// only start when the buffer's previous tile has moved to registers: ~2.9 us per arrival against the 1.9 us a hop takes (CHOL_DBG=1
+// tools/_bin/chol_test: every second hop was waiting for the consumer, not for x).  So the arrivals of column j alternate between two
+// workgroups: the CLOSER (role 1: k = j + 1, j + 3, ... -- it takes the last arrival, applies L_jj^-T and publishes x_j) and the HELPER
+// (role 0: k = j + 2, j + 4, ..., starting from zero), which hands its partial sums over through `part` (sentinel-polled like x) one
+// hop before they are needed.  Each has two hops per tile.  The helper's sums join the closer's just before its last product.
 __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict__ S, const double* __restrict__ y, double* __restrict__ x,
-                                                        int ld, int nt, const double* __restrict__ Linv, double* __restrict__ stall, long long* __restrict__ dbg)
+                                                        int ld, int nt, const double* __restrict__ Linv, double* __restrict__ stall, long long* __restrict__ dbg,
+                                                        double* __restrict__ part)
 {
     extern __shared__ double sm[];
     constexpr int LDB = TILE + 2;
     double* T = sm;                        // first L_jj^-T, then the off-diagonal tile staged for the NEXT arrival; column-major, pitch LDB
     __shared__ double ys[TILE], xk[TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = nt - 1 - (int)blockIdx.x;                     // the last tile column is dispatched first
-    if (tid < TILE) ys[tid] = y[(size_t)j * TILE + tid];
-    // The tile's inverse by the panel solve's strip code on the rows of the identity (two strips per wavefront, ~10 us, while every
-    // column but the last two is waiting anyway): the end of a hop is then one product from registers, not eight substitution steps.
-    trsm_strip<true>(const_cast<double*>(S), nullptr, ld, j, wave, false, Linv + (size_t)j * NBLK * NB * NB, lane, T, LDB);
-    trsm_strip<true>(const_cast<double*>(S), nullptr, ld, j, wave + 4, false, Linv + (size_t)j * NBLK * NB * NB, lane, T, LDB);
-    __syncthreads();
+    const int j = nt - 1 - (int)(blockIdx.x >> 1);              // the last tile column is dispatched first
+    const int closer = (int)(blockIdx.x & 1);                   // (the helper first: its closer waits for it)
+    const int k_first = nt - 1 - ((nt - 1 - (j + 2 - closer)) & 1);       // the largest k <= nt - 1 of this role's parity (k = j + 2 - closer, + 2, ...)
+    const bool has_work = k_first > j;
+    if (!closer && !has_work) return;                           // no arrival for the helper (the closer knows: nt - 1 - j < 2)
+    if (tid < TILE) ys[tid] = closer ? y[(size_t)j * TILE + tid] : 0.0;
     // thread (c, half) owns rows half * 64 .. +63 of column c of the current off-diagonal tile, and columns half * 64 .. of row c of the inverse
     const int c = tid >> 1, half = tid & 1;
     double minv[64], tile[64];
+    if (closer) {
+        // The tile's inverse by the panel solve's strip code on the rows of the identity (two strips per wavefront, ~10 us, while every
+        // column but the last two is waiting anyway): the end of a hop is then one product from registers, not eight substitution steps.
+        trsm_strip<true>(const_cast<double*>(S), nullptr, ld, j, wave, false, Linv + (size_t)j * NBLK * NB * NB, lane, T, LDB);
+        trsm_strip<true>(const_cast<double*>(S), nullptr, ld, j, wave + 4, false, Linv + (size_t)j * NBLK * NB * NB, lane, T, LDB);
+        __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 64; ++q) minv[q] = T[(half * 64 + q) * LDB + c];
+        for (int q = 0; q < 64; ++q) minv[q] = T[(half * 64 + q) * LDB + c];
+    }
     __syncthreads();                       // T is free
-    // The solve is a pipeline clocked by how fast a column consumes the x_k, one 128-KB tile each, and a wavefront's loads return in
-    // order (a poll issued behind a tile fetch cannot return before it has landed).  So the tiles travel global -> LDS by the
-    // load-to-LDS path of wavefronts 2-3 (one fully coalesced 1-KB column per instruction, no registers), a whole arrival ahead;
-    // every thread takes its share from LDS into registers; and wavefronts 0-1, which poll, never have a tile load in flight.
+    // The tiles travel global -> LDS by the load-to-LDS path of wavefronts 2-3 (one fully coalesced 1-KB column per instruction, no
+    // registers), a whole arrival ahead; every thread takes its share from LDS into registers; and wavefronts 0-1, which poll, never have
+    // a tile load in flight (a wavefront's loads return in order: a poll issued behind a tile fetch cannot return before it has landed).
     auto stage = [&](int k) {              // wavefronts 2-3: tile (k, j) -> T
         const double* g = S + (size_t)(j * TILE + (wave - 2) * 64) * ld + (size_t)k * TILE + lane * 2;
 #pragma unroll 8
@@ -341,24 +353,28 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
 #pragma unroll
         for (int q = 0; q < 64; ++q) tile[q] = T[c * LDB + half * 64 + q];
     };
-    if (j < nt - 1) {
-        if (wave >= 2) { stage(nt - 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if (has_work) {
+        if (wave >= 2) { stage(k_first); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         __syncthreads();
         take();
         __syncthreads();
-        if (wave >= 2 && nt - 2 > j) stage(nt - 2);
+        if (wave >= 2 && k_first - 2 > j) stage(k_first - 2);
     }
-    if (dbg && tid == 0) { dbg[j * 4 + 0] = wall_clock64(); dbg[j * 4 + 1] = dbg[j * 4 + 0]; }
-    for (int k = nt - 1; k > j; --k) {
+    if (dbg && closer && tid == 0) { dbg[j * 4 + 0] = wall_clock64(); dbg[j * 4 + 1] = dbg[j * 4 + 0]; }
+    auto poll_values = [&](const double* from) {      // 128 values that replace the sentinel when their producer stores them
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(from + tid);
+        unsigned long long v;
+        int spins = 0;
+        while ((v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == X_SENTINEL && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
+        if (v == X_SENTINEL) *stall = 3.0;           // the producer never published: reported as a device error
+        return __longlong_as_double((long long)v);
+    };
+    for (int k = k_first; k > j; k -= 2) {
         if (k == j + 1 && dbg && tid == 0) dbg[j * 4 + 2] = wall_clock64();
-        if (tid < TILE) {
-            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(x + (size_t)k * TILE + tid);
-            unsigned long long v;
-            int spins = 0;
-            while ((v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == X_SENTINEL && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
-            if (v == X_SENTINEL) *stall = 3.0;           // the producer column never published: reported as a device error
-            xk[tid] = __longlong_as_double((long long)v);
-        }
+        // before the closer's last arrival: the helper's sums (its last tile is one hop older: they are here or about to be, and this
+        // wait is the one that has to be sat out anyway)
+        if (closer && k == j + 1 && nt - 1 - j >= 2 && tid < TILE) ys[tid] += poll_values(part + (size_t)j * TILE);
+        if (tid < TILE) xk[tid] = poll_values(x + (size_t)k * TILE);
         __syncthreads();
         double a0 = 0, a1 = 0;
 #pragma unroll
@@ -369,13 +385,19 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
         double acc = a0 + a1;
         acc += __shfl_xor(acc, 1, 64);
         if (half == 0) ys[c] -= acc;
-        if (k - 1 > j) {
-            if (wave >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile k - 1 has landed in T
+        if (k - 2 > j) {
+            if (wave >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the role's next tile has landed in T
             __syncthreads();
             take();
             __syncthreads();
-            if (wave >= 2 && k - 2 > j) stage(k - 2);
+            if (wave >= 2 && k - 4 > j) stage(k - 4);
         } else __syncthreads();
+    }
+    if (!closer) {
+        // the helper's share of y_j - sum_k L_kj^T x_k (a negative sum): to the closer
+        if (tid < TILE) __hip_atomic_store(reinterpret_cast<unsigned long long*>(part + (size_t)j * TILE + tid), (unsigned long long)__double_as_longlong(ys[tid]),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
     }
     {   // x_j = L_jj^-T ys
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -478,7 +500,7 @@ __global__ __launch_bounds__(256) void k_small_solve(const double* __restrict__ 
 
 // per tile column: the inverses of its eight diagonal blocks, then (behind all of those) the scratch copy of its 28 sub-diagonal blocks
 // that the phased strips read
-size_t chol_workspace_doubles(int n_pad) { return (size_t)(n_pad / TILE) * (NBLK * NB * NB + LPUB_TILE_DOUBLES); }
+size_t chol_workspace_doubles(int n_pad) { return (size_t)(n_pad / TILE) * (NBLK * NB * NB + LPUB_TILE_DOUBLES + TILE); }      // block inverses, published L_kk copies, the backward solve's partial sums
 size_t chol_sync_ints(int n_pad) { return 8 + chol_dag_sync_ints(n_pad / TILE); }
 
 int g_n_cu = 256;        // compute units of the device the library was initialised on (gfx950: 256)
@@ -540,6 +562,7 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
     const size_t lds_panel = (size_t)TILE * (TILE + 2) * sizeof(double);
     const size_t linv_stride = (size_t)NBLK * NB * NB;
     double* stall = ws.stall ? ws.stall : ok + 1;     // callers without a slot of their own pass a two-element ok
+    double* const bs_part = ws.Linv + (size_t)nt * (linv_stride + LPUB_TILE_DOUBLES);      // the backward solve's partial sums, behind the published L_kk copies
     static const bool column_launches = std::getenv("MAGE_CHOL_COLUMN_LAUNCHES") != nullptr;
     static const bool merge_env_off = std::getenv("MAGE_CHOL_NO_MERGED_TRSM") != nullptr;      // (tests: the fall-back schedule on demand)
     const bool stalled_before = g_merge_disabled.load(std::memory_order_relaxed);
@@ -550,11 +573,11 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
 #else
         long long* const bs_dbg = ws.dbg;
 #endif
-        hipLaunchKernelGGL(k_bsolve_persist, dim3(nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, stall, bs_dbg);
+        hipLaunchKernelGGL(k_bsolve_persist, dim3(2 * nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, stall, bs_dbg, bs_part);
         return;
     }
     int* flag = ws.sync;
-    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), lds_diag, st, S, n_pad, 0, ws.Linv, ok, stall, reinterpret_cast<unsigned long long*>(x), n_pad);
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), lds_diag, st, S, n_pad, 0, ws.Linv, ok, stall, reinterpret_cast<unsigned long long*>(x), n_pad, reinterpret_cast<unsigned long long*>(bs_part));
     hipLaunchKernelGGL(k_trsm_panel_1w, dim3((nt - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, 0, nt, ws.Linv, flag);
     int col_total = 0;
     for (int k = 0; k + 1 < nt; ++k) {
@@ -582,7 +605,7 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
         if (!merged) hipLaunchKernelGGL(k_trsm_panel_1w, dim3((m - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, k + 1, nt, Linv_next, flag);
     }
     // backward substitution: one persistent launch (needs every workgroup resident: nt <= 256 compute units)
-    hipLaunchKernelGGL(k_bsolve_persist, dim3(nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, stall, ws.dbg);
+    hipLaunchKernelGGL(k_bsolve_persist, dim3(2 * nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, stall, ws.dbg, bs_part);
     // a launch the runtime refused (an LDS opt-in that did not take, a device in a bad state) must not leave `ok` / `stall` stale and
     // the factor garbage behind a MAGE_OK: poison both so that the caller's read-back reports a device error
     if (hipGetLastError() != hipSuccess) {
