@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward substitution  L^T x = y  as ONE persistent launch: workgroup j owns tile column j.  It keeps L_jj (LDS) and
+// backward substitution  L^T x = y  as ONE persistent launch: tile column j is owned by a pair of workgroups (below).  The closer keeps L_jj (LDS) and
 // y_j, consumes x_k for k = nt-1 .. j+1 as they appear, applying y_j -= L_kj^T x_k from a register-resident copy of
 // the tile that was prefetched while it waited, then solves x_j = L_jj^-T y_j (blocked by 16 with the stored block
 // inverses) and publishes it.  The tile-to-tile chain is pure latency, so there is no flag: x is pre-filled with a
