@@ -12,17 +12,17 @@ namespace mage { namespace {
 __global__ __launch_bounds__(256) void k_probe(const double* __restrict__ S, int ld, double* __restrict__ Linv, long long* __restrict__ out)
 {
     extern __shared__ double sm[];
-    double* A = sm; double* Li = sm + TILE * LDC;
+    double* A = sm; double* Li = sm + PACKED_TILE_DOUBLES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    load_tile<LDC>(A, S, ld, tid);
+    load_tile_packed(A, S, ld, tid);                             // the library's layout of a diagonal tile (LayPacked)
     __syncthreads();
     long long t0 = clock64();
     bool f = false;
-    if (wave == 0) f = FACTOR_BLOCK(A, lane, Li, Linv);        // block (0, 0) of the tile
+    if (wave == 0) f = factor_block16_lean<LayPacked::PITCH>(A + LayPacked::blk(0, 0), lane, Li, Linv);        // block (0, 0) of the tile
     long long t1 = clock64();
     __syncthreads();
     long long t2 = clock64();
-    load_tile_packed(A, S, ld, tid);                             // the library's layout of a diagonal tile (LayPacked)
+    load_tile_packed(A, S, ld, tid);
     __syncthreads();
     long long t3 = clock64();
     f |= potrf_tile_lds<false, LayPacked>(A, Li, Linv, tid);
@@ -43,7 +43,7 @@ int main()
     double *dS, *dL; long long* dout;
     hipMalloc(&dS, sizeof(double) * n * n * 2); hipMalloc(&dL, sizeof(double) * 8 * 256); hipMalloc(&dout, 64);
     hipMemcpy(dS, A.data(), sizeof(double) * n * n, hipMemcpyHostToDevice);
-    const size_t lds = ((size_t)TILE * LDC + 2 * NB * NB) * sizeof(double);
+    const size_t lds = ((size_t)PACKED_TILE_DOUBLES + 2 * NB * NB) * sizeof(double);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     for (int r = 0; r < 3; ++r) {
         hipLaunchKernelGGL(k_probe, dim3(1), dim3(256), lds, 0, dS, n, dL, dout);
