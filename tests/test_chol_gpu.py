@@ -26,7 +26,7 @@ def spd(n, seed, cond_shift=1.0):
     return M @ M.T / n + cond_shift * np.eye(n), rng.standard_normal(n)
 
 
-@pytest.mark.parametrize("n", [1, 6, 17, 127, 128, 129, 500, 1408, 2999])
+@pytest.mark.parametrize("n", [1, 6, 17, 127, 128, 129, 300, 500, 1100, 1250, 1408, 2999])      # 1 .. 24 tile columns, odd and even (the backward solve pairs two workgroups per column)
 def test_solution_matches_lapack(n):
     """Orders around the tile size (one tile, exactly one, one row more), a few tiles (split diagonal update, quartered
     rounds), and a size that needs every role of the update kernel."""
