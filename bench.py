@@ -13,7 +13,7 @@ built during warm-up).  Rank 0 prints ONE JSON line.
 
 After the headline's timed region (never inside it) the same process measures, each bounded to seconds, what the other
 BASELINE.json configurations and a caller of the reference see, and reports it under "extra" (N = 1) and "strong_scaling" (any N):
-  extra.config2              ORB frames/s and matcher pairs/s at batch 1 / 64 / 1024 with the stage's HBM fraction, CPU oracle beside
+  extra.config2              ORB frames/s and matcher pairs/s at batch 1 / 64 / 1024 with the stage's HBM fraction, the BoW leaf lookup + IndexedMatch call, CPU oracle beside
   extra.pose_only / extra.reference_window   the reference's two EVERYDAY shapes (round 4), from native callers: the tracker's per-frame
                              pose refinement (1 free pose, 300 fixed points, 3 + 4 iterations, Tracking/TrackLocalMap.cpp:94-105, 421-501) and
                              the default local BA (12 keyframes / 400 points / 2000 observations, ONE iteration per bundler,
@@ -425,6 +425,28 @@ def extra_concurrent_handles(device, counts=(1, 2, 4), steps=12):
     return res
 
 
+def _bow_workload(cap=440, kk=10, depth=4, seed=5):
+    """A 10-ary vocabulary tree of depth 4 (11 111 nodes, random medoids) and two frames' descriptors: the shape of a relocalisation query."""
+    rng = np.random.default_rng(seed)
+    n_nodes = sum(kk ** d for d in range(depth + 1))
+    inner = sum(kk ** d for d in range(depth))
+    node_desc = rng.integers(0, 256, (n_nodes, 32), dtype=np.uint8)
+    child_off = np.zeros(n_nodes + 1, np.int32)
+    child_off[1:inner + 1] = kk * np.arange(1, inner + 1)
+    child_off[inner + 1:] = child_off[inner]
+    children = np.arange(1, n_nodes, dtype=np.int32)
+    A = rng.integers(0, 256, (cap, 32), dtype=np.uint8)
+    B = A.copy(); B[:, 0] ^= rng.integers(0, 4, cap, dtype=np.uint8)
+    return node_desc, child_off, children, A, B
+
+
+def _leaf_csr(leaves, n_nodes):
+    order = np.argsort(leaves, kind="stable").astype(np.int32)
+    off = np.zeros(n_nodes + 1, np.int32)
+    np.add.at(off, leaves + 1, 1)
+    return np.cumsum(off).astype(np.int32), order
+
+
 def extra_config2(device):
     import threading
     import torch
@@ -515,6 +537,23 @@ def extra_config2(device):
             "roofline_valu_issue": valu,
             "pairs_per_s": round(batch / mwall, 1), "match_kernel_ms": round(mt.last_kernel_ms(), 4),
             "match_gdistances_per_s": round(batch * 2 * CAP * CAP / (mt.last_kernel_ms() * 1e-3) / 1e9, 2)}
+    # the vocabulary's leaf lookup and IndexedMatch through it, host buffers in and out, the tree upload included
+    node_desc, child_off, children, A, B = _bow_workload(CAP)
+    both = np.concatenate([A, B])
+    leaves = mt.BowFindLeaf(node_desc, child_off, children, both)
+    fao, fa = _leaf_csr(leaves[:CAP], len(node_desc)); fbo, fb = _leaf_csr(leaves[CAP:], len(node_desc))
+    got = mt.IndexedMatchBow(node_desc, child_off, children, A, fao, fa, B, fbo, fb, 30, 1)
+    reps = 100
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        mt.BowFindLeaf(node_desc, child_off, children, both)
+    leaf_ms = 1e3 * (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        mt.IndexedMatchBow(node_desc, child_off, children, A, fao, fa, B, fbo, fb, 30, 1)
+    res["bow"] = {"workload": f"10-ary vocabulary tree of depth 4 ({len(node_desc)} nodes), {2 * CAP} descriptors per call, host buffers in and out (tree upload included)",
+                  "find_leaf_ms_per_call": round(leaf_ms, 4), "indexed_match_bow_ms_per_call": round(1e3 * (time.perf_counter() - t0) / reps, 4), "matches": int(len(got)),
+                  "leaf_checksum": int(np.asarray(leaves, np.int64).sum())}
     return res
 
 
@@ -531,8 +570,15 @@ def cpu_baseline_config2(seconds=2.0):
     t0 = time.perf_counter(); n = 0
     while time.perf_counter() - t0 < seconds:
         O.match(da, db, 30, 1); n += 1
-    return {"kind": "port", "cores": 1, "frames_per_s": round(fps, 1), "pairs_per_s": round(n / (time.perf_counter() - t0), 1),
-            "sample": f"{seconds:.0f} s of oracle/orb_oracle.c on 640x480 frames + {seconds:.0f} s of oracle/match_oracle.c on one 440 x 440 pair"}
+    pps = n / (time.perf_counter() - t0)
+    node_desc, child_off, children, A, B = _bow_workload()
+    both = np.concatenate([A, B])
+    t0 = time.perf_counter(); leaves = O.bow_find_leaf(node_desc, child_off, children, both); leaf_ms = 1e3 * (time.perf_counter() - t0)
+    fao, fa = _leaf_csr(leaves[:len(A)], len(node_desc)); fbo, fb = _leaf_csr(leaves[len(A):], len(node_desc))
+    t0 = time.perf_counter(); O.indexed_match_bow(node_desc, child_off, children, A, fao, fa, B, fbo, fb, 30, 1); im_ms = 1e3 * (time.perf_counter() - t0)
+    return {"kind": "port", "cores": 1, "frames_per_s": round(fps, 1), "pairs_per_s": round(pps, 1),
+            "bow_find_leaf_ms_per_call": round(leaf_ms, 4), "bow_indexed_match_ms_per_call": round(im_ms, 4), "bow_leaf_checksum": int(np.asarray(leaves, np.int64).sum()),
+            "sample": f"{seconds:.0f} s of oracle/orb_oracle.c on 640x480 frames + {seconds:.0f} s of oracle/match_oracle.c on one 440 x 440 pair + one BoW lookup / IndexedMatch call of extra.config2.bow"}
 
 
 def strong_scaling_windowed(device, dist, rank, world, poses=8000, windows=8, overlap=10, iters=10, warmup=2, threads=4):
