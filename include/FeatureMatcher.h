@@ -162,6 +162,19 @@ namespace mage
         std::vector<int32_t> childOffsets, children;
         mage_bow_tree View() const { return mage_bow_tree{ nodeDescriptors.data(), childOffsets.data(), children.data(), static_cast<int32_t>(childOffsets.size()) - 1 }; }
     };
+    // Keeps the (trained) tree on the device: FindLeafNodes(ctx, descriptors) then moves only the descriptors (mage_bow_set_tree)
+    inline void SetBowTree(MatcherContext& ctx, const BowTree& tree)
+    {
+        const mage_bow_tree t = tree.View();
+        shim::CheckMatch(mage_bow_set_tree(ctx.Handle(), &t), "SetBowTree");
+    }
+    template <typename Descriptors>
+    std::vector<int32_t> FindLeafNodes(MatcherContext& ctx, const Descriptors& descriptors)
+    {
+        std::vector<int32_t> leaves(descriptors.size());
+        shim::CheckMatch(mage_bow_find_leaf_batch(ctx.Handle(), nullptr, reinterpret_cast<const uint8_t*>(descriptors.data()), static_cast<int>(descriptors.size()), leaves.data()), "FindLeafNodes");
+        return leaves;
+    }
     // OnlineBow::FindLeafNode (BoW/OnlineBow.cpp:289-311) for a batch of descriptors
     template <typename Descriptors>
     std::vector<int32_t> FindLeafNodes(MatcherContext& ctx, const BowTree& tree, const Descriptors& descriptors)

@@ -107,6 +107,10 @@ typedef struct mage_bow_tree {
  * nearest in Hamming distance (GetDescriptorDistance), strict '<' in child-list order -- the first of equally near children wins -- until
  * a node without children; leaf_ids[i] = that node.  Host pointers. */
 mage_status mage_bow_find_leaf_batch(mage_matcher* h, const mage_bow_tree* tree, const uint8_t* descriptors, int n, int32_t* leaf_ids);
+/* Keeps a validated copy of the tree on the device (OnlineBow's tree changes once, when its training completes, BoW/OnlineBow.cpp:77-92; a lookup per
+ * frame then moves 28 KB of descriptors instead of the 355-KB tree): mage_bow_find_leaf_batch and mage_match_indexed_bow called with
+ * tree == NULL use it.  tree == NULL here forgets it.  Call again whenever the tree has changed. */
+mage_status mage_bow_set_tree(mage_matcher* h, const mage_bow_tree* tree);
 
 /* IndexedMatch (Tracking/FeatureMatcher.cpp:192-292) with its candidate lists looked up the way the reference does (:223-227, :253-257 ->
  * OnlineBow::QueryFeatures, BoW/OnlineBow.cpp:115-132): the candidates of a descriptor are the features of the OTHER image filed under the

@@ -454,6 +454,8 @@ struct mage_matcher {
     DevBuf<int> d_cA, d_cB, d_scratch, d_counts, d_done;       // d_done: per-pair arrival counters of k_match_rows, zero between launches
     size_t done_zeroed = 0;
     DevBuf<mage_dmatch> d_out;
+    DevBuf<uint8_t> d_tree;                    // mage_bow_set_tree: [node descriptors | child offsets | children], validated
+    size_t tree_nodes = 0, tree_o_co = 0, tree_o_ch = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr, e_wait = nullptr;
     double last_ms = 0;
     ~mage_matcher()
@@ -734,8 +736,53 @@ mage_status check_leaf_lists(const int32_t* off, const int32_t* items, int n_nod
 }
 }  // namespace
 
+MAGE_EXPORT mage_status mage_bow_set_tree(mage_matcher* h, const mage_bow_tree* tree)
+{
+    return guarded([&]() -> mage_status {
+        if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
+        if (!tree) { h->tree_nodes = 0; return MAGE_OK; }
+        MAGE_TRY(check_bow_tree(tree));
+        MAGE_DEVICE_SCOPE(h->device);
+        auto al = [](size_t v) { return (v + 31) & ~(size_t)31; };
+        const size_t nn = (size_t)tree->n_nodes, nch = (size_t)tree->child_offsets[nn];
+        const size_t o_co = al(32 * nn), o_ch = al(o_co + 4 * (nn + 1)), total = al(o_ch + 4 * nch);
+        std::vector<uint8_t> stage(total, 0);
+        std::memcpy(stage.data(), tree->node_descriptors, 32 * nn); std::memcpy(stage.data() + o_co, tree->child_offsets, 4 * (nn + 1));
+        if (nch) std::memcpy(stage.data() + o_ch, tree->children, 4 * nch);
+        h->tree_nodes = 0;
+        MAGE_HIP(hipStreamSynchronize(h->stream));           // (a launch still reading the previous tree)
+        MAGE_TRY(h->d_tree.reserve(total));
+        MAGE_HIP(hipMemcpy(h->d_tree.p, stage.data(), total, hipMemcpyHostToDevice));
+        h->tree_nodes = nn; h->tree_o_co = o_co; h->tree_o_ch = o_ch;
+        return MAGE_OK;
+    });
+}
+
 MAGE_EXPORT mage_status mage_bow_find_leaf_batch(mage_matcher* h, const mage_bow_tree* tree, const uint8_t* descriptors, int n, int32_t* leaf_ids)
 {
+    if (h && !tree && h->tree_nodes) {
+        // the tree kept by mage_bow_set_tree: only the descriptors travel
+        return guarded([&]() -> mage_status {
+            if (n < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative size");
+            if (n == 0) return MAGE_OK;
+            if (!descriptors || !leaf_ids) return fail(MAGE_ERR_INVALID_ARGUMENT, "null buffer");
+            MAGE_DEVICE_SCOPE(h->device);
+            hipStream_t st = h->stream;
+            MAGE_TRY(h->d_A.reserve(32 * (size_t)n));
+            MAGE_TRY(h->d_scratch.reserve((size_t)n));
+            MAGE_HIP(hipMemcpyAsync(h->d_A.p, descriptors, 32 * (size_t)n, hipMemcpyHostToDevice, st));
+            const uint8_t* d = h->d_tree.p;
+            MAGE_HIP(hipEventRecord(h->e0, st));
+            bow_find_leaf_launch(d, reinterpret_cast<const int*>(d + h->tree_o_co), reinterpret_cast<const int*>(d + h->tree_o_ch), h->d_A.p, n, h->d_scratch.p, st);
+            MAGE_HIP(hipEventRecord(h->e1, st));
+            MAGE_HIP(hipMemcpyAsync(leaf_ids, h->d_scratch.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+            MAGE_HIP(hipStreamSynchronize(st));
+            float ms = 0;
+            MAGE_HIP(hipEventElapsedTime(&ms, h->e0, h->e1));
+            h->last_ms = ms;
+            return MAGE_OK;
+        });
+    }
     return guarded([&]() -> mage_status {
         if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
         if (n < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative size");
@@ -775,11 +822,13 @@ MAGE_EXPORT mage_status mage_match_indexed_bow(mage_matcher* h, const mage_bow_t
         if (!h || !count) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument");
         *count = 0;
         if (nA < 0 || nB < 0 || capacity < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative size");
-        MAGE_TRY(check_bow_tree(tree));
+        const bool resident = !tree && h->tree_nodes;        // the tree kept by mage_bow_set_tree: it is not staged again
+        if (!resident) MAGE_TRY(check_bow_tree(tree));
+        const int n_nodes = resident ? (int)h->tree_nodes : tree->n_nodes;
         if (nA == 0 || nB == 0) return MAGE_OK;
         if (!descA || !descB || (capacity > 0 && !out)) return fail(MAGE_ERR_INVALID_ARGUMENT, "null buffer");
-        MAGE_TRY(check_leaf_lists(feat_a_off, feat_a, tree->n_nodes, nA, "A"));
-        MAGE_TRY(check_leaf_lists(feat_b_off, feat_b, tree->n_nodes, nB, "B"));
+        MAGE_TRY(check_leaf_lists(feat_a_off, feat_a, n_nodes, nA, "A"));
+        MAGE_TRY(check_leaf_lists(feat_b_off, feat_b, n_nodes, nB, "B"));
         size_t cntA = 0, cntB = 0;          // FeatureMatcher.cpp:208: nothing to do when either mask is empty
         for (int i = 0; i < nA; ++i) cntA += (!maskA || maskA[i]);
         for (int i = 0; i < nB; ++i) cntB += (!maskB || maskB[i]);
@@ -789,13 +838,15 @@ MAGE_EXPORT mage_status mage_match_indexed_bow(mage_matcher* h, const mage_bow_t
         // one staging buffer: [nodes | child_off | children | descA | descB | feat_b_off | feat_a_off | feat_b | feat_a | maskA | maskB]; descA and descB
         // are adjacent so that ONE launch finds the leaves of both images
         auto al = [](size_t v) { return (v + 31) & ~(size_t)31; };
-        const size_t nn = (size_t)tree->n_nodes, nch = (size_t)tree->child_offsets[nn], nfa = (size_t)feat_a_off[nn], nfb = (size_t)feat_b_off[nn];
-        const size_t o_nd = 0, o_co = al(o_nd + 32 * nn), o_ch = al(o_co + 4 * (nn + 1)), o_da = al(o_ch + 4 * nch), o_db = o_da + 32 * (size_t)nA,
+        const size_t nn = (size_t)n_nodes, nch = resident ? 0 : (size_t)tree->child_offsets[nn], nfa = (size_t)feat_a_off[nn], nfb = (size_t)feat_b_off[nn];
+        const size_t o_nd = 0, o_co = resident ? 0 : al(o_nd + 32 * nn), o_ch = resident ? 0 : al(o_co + 4 * (nn + 1)), o_da = resident ? 0 : al(o_ch + 4 * nch), o_db = o_da + 32 * (size_t)nA,
                      o_bo = al(o_db + 32 * (size_t)nB), o_ao = al(o_bo + 4 * (nn + 1)), o_fb = al(o_ao + 4 * (nn + 1)), o_fa = al(o_fb + 4 * nfb),
                      o_ma = al(o_fa + 4 * nfa), o_mb = al(o_ma + nA), total = al(o_mb + nB);
         std::vector<uint8_t> stage(total, 0);
-        std::memcpy(stage.data() + o_nd, tree->node_descriptors, 32 * nn); std::memcpy(stage.data() + o_co, tree->child_offsets, 4 * (nn + 1));
-        if (nch) std::memcpy(stage.data() + o_ch, tree->children, 4 * nch);
+        if (!resident) {
+            std::memcpy(stage.data() + o_nd, tree->node_descriptors, 32 * nn); std::memcpy(stage.data() + o_co, tree->child_offsets, 4 * (nn + 1));
+            if (nch) std::memcpy(stage.data() + o_ch, tree->children, 4 * nch);
+        }
         std::memcpy(stage.data() + o_da, descA, 32 * (size_t)nA); std::memcpy(stage.data() + o_db, descB, 32 * (size_t)nB);
         std::memcpy(stage.data() + o_bo, feat_b_off, 4 * (nn + 1)); std::memcpy(stage.data() + o_ao, feat_a_off, 4 * (nn + 1));
         if (nfb) std::memcpy(stage.data() + o_fb, feat_b, 4 * nfb);
@@ -810,7 +861,8 @@ MAGE_EXPORT mage_status mage_match_indexed_bow(mage_matcher* h, const mage_bow_t
         const uint8_t* d = h->d_A.p;
         int* leaf = h->d_scratch.p;          // [leaf of every A descriptor | leaf of every B descriptor]
         MAGE_HIP(hipEventRecord(h->e0, st));
-        bow_find_leaf_launch(d + o_nd, reinterpret_cast<const int*>(d + o_co), reinterpret_cast<const int*>(d + o_ch), d + o_da, nA + nB, leaf, st);
+        const uint8_t* tr = resident ? h->d_tree.p : d;
+        bow_find_leaf_launch(tr + o_nd, reinterpret_cast<const int*>(tr + (resident ? h->tree_o_co : o_co)), reinterpret_cast<const int*>(tr + (resident ? h->tree_o_ch : o_ch)), d + o_da, nA + nB, leaf, st);
         indexed_match_launch(d + o_da, nA, maskA ? d + o_ma : nullptr, reinterpret_cast<const int*>(d + o_bo), reinterpret_cast<const int*>(d + o_fb),
                              d + o_db, maskB ? d + o_mb : nullptr, reinterpret_cast<const int*>(d + o_ao), reinterpret_cast<const int*>(d + o_fa),
                              max_dist, min_diff, h->d_out.p, capacity, h->d_counts.p, st, leaf, leaf + nA);

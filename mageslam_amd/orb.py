@@ -65,6 +65,7 @@ def _declare():
     L.mage_match_bf_batch_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     L.mage_match_radius.argtypes = [vp, vp, C.c_int, vp, vp, _u8, vp, C.c_int, vp, _u8, C.c_float, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     L.mage_bow_find_leaf_batch.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.mage_bow_set_tree.argtypes = [vp, vp]
     L.mage_match_indexed_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     L.mage_match_indexed.argtypes = [vp, _u8, C.c_int, vp, vp, vp, _u8, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     L.mage_matcher_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double)]
@@ -258,19 +259,29 @@ class Matcher:
         t = BowTree(nd.ctypes.data_as(C.c_void_p), co.ctypes.data_as(C.c_void_p), ch.ctypes.data_as(C.c_void_p), len(nd))
         return t, (nd, co, ch)          # (the arrays must outlive the call)
 
-    def BowFindLeaf(self, node_descriptors, child_offsets, children, descriptors) -> np.ndarray:
-        """OnlineBow::FindLeafNode (BoW/OnlineBow.cpp:289-311) for a batch of descriptors; the tree as flat arrays (include/mage_match.h)."""
+    def BowSetTree(self, node_descriptors=None, child_offsets=None, children=None) -> None:
+        """mage_bow_set_tree: keeps a validated copy of the tree on the device; BowFindLeaf / IndexedMatchBow called with node_descriptors=None
+        use it.  Without arguments: forgets it."""
+        if node_descriptors is None:
+            check(self._L.mage_bow_set_tree(self._h, None))
+            return
         t, keep = self._bow_tree(node_descriptors, child_offsets, children)
+        check(self._L.mage_bow_set_tree(self._h, C.byref(t)))
+
+    def BowFindLeaf(self, node_descriptors, child_offsets, children, descriptors) -> np.ndarray:
+        """OnlineBow::FindLeafNode (BoW/OnlineBow.cpp:289-311) for a batch of descriptors; the tree as flat arrays (include/mage_match.h),
+        or node_descriptors=None for the tree kept by BowSetTree."""
+        t, keep = (None, None) if node_descriptors is None else self._bow_tree(node_descriptors, child_offsets, children)
         d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
         leaf = np.zeros(max(len(d), 1), np.int32)
-        check(self._L.mage_bow_find_leaf_batch(self._h, C.byref(t), d.ctypes.data_as(C.c_void_p) if len(d) else None, len(d), leaf.ctypes.data_as(C.c_void_p)))
+        check(self._L.mage_bow_find_leaf_batch(self._h, None if t is None else C.byref(t), d.ctypes.data_as(C.c_void_p) if len(d) else None, len(d), leaf.ctypes.data_as(C.c_void_p)))
         return leaf[:len(d)]
 
     def IndexedMatchBow(self, node_descriptors, child_offsets, children, descriptors_a, leaf_features_a_offsets, leaf_features_a, descriptors_b,
                         leaf_features_b_offsets, leaf_features_b, max_hamming_dist=30, min_hamming_difference=1, mask_a=None, mask_b=None) -> np.ndarray:
         """IndexedMatch (FeatureMatcher.cpp:192-292) with the candidate lists looked up in the vocabulary tree on the device
         (OnlineBow::QueryFeatures, BoW/OnlineBow.cpp:115-132): leaf_features_x = per node the features of image x filed under it (CSR)."""
-        t, keep = self._bow_tree(node_descriptors, child_offsets, children)
+        t, keep = (None, None) if node_descriptors is None else self._bow_tree(node_descriptors, child_offsets, children)
         A = np.ascontiguousarray(descriptors_a, np.uint8).reshape(-1); B = np.ascontiguousarray(descriptors_b, np.uint8).reshape(-1)
         nA, nB = A.size // 32, B.size // 32
         if A.size == 0: A = np.zeros(32, np.uint8)
@@ -282,7 +293,7 @@ class Matcher:
         mb = None if mask_b is None else np.ascontiguousarray(mask_b, np.uint8)
         out = np.zeros(max(nA, 1), DMATCH_DTYPE)
         n = C.c_int(0)
-        check(self._L.mage_match_indexed_bow(self._h, C.byref(t), ptr(A), nA, ptr(ma), ptr(fao), ptr(fa) if fa.size else None, ptr(B), nB, ptr(mb), ptr(fbo),
+        check(self._L.mage_match_indexed_bow(self._h, None if t is None else C.byref(t), ptr(A), nA, ptr(ma), ptr(fao), ptr(fa) if fa.size else None, ptr(B), nB, ptr(mb), ptr(fbo),
                                              ptr(fb) if fb.size else None, int(max_hamming_dist), int(min_hamming_difference), ptr(out), len(out), C.byref(n)))
         return out[: min(n.value, len(out))].copy()
 

@@ -573,6 +573,34 @@ def test_bow_leaf_lookup_golden_and_oracle(gold, tree):
     assert mt.BowFindLeaf(t[0][:1], [0, 0], [], q[:5]).tolist() == [0] * 5           # the root alone is its own leaf
 
 
+def test_resident_vocabulary_gives_the_same_leaves_and_matches(gold):
+    """mage_bow_set_tree: lookups and IndexedMatch with the tree kept on the device equal the ones that stage it per call (and the
+    fixture); without any tree the call is refused."""
+    bw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_bow.npz"))
+    da, db = gold["orb_640x480_a_desc"], gold["orb_640x480_b_desc"]
+    mt = Matcher()
+    with pytest.raises(Exception):
+        mt.BowFindLeaf(None, None, None, da)
+    for tree in BOW_TREES:
+        t = (bw[tree + "_nodes"], bw[tree + "_child_off"], bw[tree + "_children"])
+        mt.BowSetTree(*t)
+        la, lb = mt.BowFindLeaf(None, None, None, da), mt.BowFindLeaf(None, None, None, db)
+        assert np.array_equal(la, bw[tree + "_leaf_a"]) and np.array_equal(lb, bw[tree + "_leaf_b"])
+
+        def csr(leaves):
+            order = np.argsort(leaves, kind="stable").astype(np.int32)
+            off = np.zeros(len(t[0]) + 1, np.int32)
+            np.add.at(off, leaves + 1, 1)
+            return np.cumsum(off).astype(np.int32), order
+        fao, fa = csr(la); fbo, fb = csr(lb)
+        kept = mt.IndexedMatchBow(None, None, None, da, fao, fa, db, fbo, fb, 40, 2)
+        staged = mt.IndexedMatchBow(*t, da, fao, fa, db, fbo, fb, 40, 2)
+        assert len(kept) > 0 and np.array_equal(kept.view(np.uint8), staged.view(np.uint8))
+    mt.BowSetTree()
+    with pytest.raises(Exception):
+        mt.BowFindLeaf(None, None, None, da)
+
+
 @pytest.mark.parametrize("tree", BOW_TREES)
 def test_indexed_match_through_the_vocabulary(gold, tree):
     """mage_match_indexed_bow: IndexedMatch with its candidate lists looked up in the tree on the device (FeatureMatcher.cpp:223-227,
