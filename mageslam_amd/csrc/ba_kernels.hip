@@ -2007,12 +2007,16 @@ size_t pose_lm_staged_bytes(int nc, int np, int nL, int nfc)
 #else
 #define PLC(tag) do { } while (0)
 #endif
-template <bool STAGED>
-__global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a, PoseLmResult* __restrict__ out, uint8_t* __restrict__ flagL, double* __restrict__ out_pose)
+// NW wavefronts: the tracker's 300 observations are one pass of 512 threads where 256 took two (the second 17 % full); two wavefronts per
+// SIMD interleave their dependent f64 chains almost for free.
+constexpr int POSE_LM_NW = 8;
+template <bool STAGED, int NW>
+__global__ __launch_bounds__(64 * NW) void k_pose_lm(BaDeviceView vin, PoseLmArgs a, PoseLmResult* __restrict__ out, uint8_t* __restrict__ flagL, double* __restrict__ out_pose)
 {
     extern __shared__ __align__(16) double dyn[];
-    __shared__ double sm[4];
-    __shared__ double part[4][28];
+    constexpr int NT = 64 * NW;
+    __shared__ double sm[NW];
+    __shared__ double part[NW][28];
     __shared__ double s_lambda, s_ni, s_rho, s_cur_chi;
     __shared__ int s_ok, s_accept;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2051,12 +2055,12 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
         {
             const uint4* src = reinterpret_cast<const uint4*>(vin.pose_cur);
             uint4* dst = reinterpret_cast<uint4*>(dyn);
-            for (int base = 0; base < n16; base += 256 * 8) {
+            for (int base = 0; base < n16; base += NT * 8) {
                 uint4 r[8];          // (every load is issued -- past the end the last piece again -- so that r stays in registers: predicated loads sent it to scratch)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int i = base + u * 256 + tid; r[u] = src[i < n16 ? i : n16 - 1]; }
+                for (int u = 0; u < 8; ++u) { const int i = base + u * NT + tid; r[u] = src[i < n16 ? i : n16 - 1]; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int i = base + u * 256 + tid; if (i < n16) dst[i] = r[u]; }
+                for (int u = 0; u < 8; ++u) { const int i = base + u * NT + tid; if (i < n16) dst[i] = r[u]; }
             }
         }
         v.pose_cur = pose0; v.pose_trial = pose1; v.camK = camK; v.pt_cur = v.pt_trial = pt; v.errL = errL; v.U = U; v.bc = bc; v.xc = xc;
@@ -2071,7 +2075,7 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
     // robust chi2 of state `pose` over all active observations (residuals to errL): thread-strided, fixed order
     auto chi2_of = [&](const double* pose, double delta) -> double {
         double acc = 0;
-        for (int i = tid; i < v.n_L; i += 256) {
+        for (int i = tid; i < v.n_L; i += NT) {
             if (!v.L_active[i]) continue;
             const int cam = v.L_cam[i], pt = v.L_pt[i];
             PoseD P = load_pose(pose, cam);
@@ -2083,7 +2087,7 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
             huber((double)v.L_info[i] * (g.e0 * g.e0 + g.e1 * g.e1), delta, rho0, rho1);
             acc += rho0;
         }
-        return block_sum<4>(acc, sm);
+        return block_sum<NW>(acc, sm);
     };
 
     double carried_chi = 0;
@@ -2104,7 +2108,7 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
             for (int k = 0; k < 21; ++k) A[k] = 0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) b[k] = 0;
-            for (int idx = v.camE_ptr[hc] + tid; idx < v.camE_ptr[hc + 1]; idx += 256) {
+            for (int idx = v.camE_ptr[hc] + tid; idx < v.camE_ptr[hc + 1]; idx += NT) {
                 const int i = v.camE[idx];
                 if (!v.L_active[i]) continue;
                 const int pt = v.L_pt[i];
@@ -2139,7 +2143,9 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
                 if ((lane & 1) == 0 && slot < 27) part[wave][slot] = tot;
                 __syncthreads();
                 if (tid < 27) {
-                    const double val = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+                    double val = part[0][tid];
+#pragma unroll
+                    for (int w2 = 1; w2 < NW; ++w2) val += part[w2][tid];          // wavefront order
                     if (tid < 21) {
                         int p = 0;
                         while ((p + 1) * (p + 2) / 2 <= tid) ++p;          // tid = p (p + 1) / 2 + c
@@ -2178,7 +2184,7 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
                 if (!ok) s_ok = 0;
                 sc = pose_update_one(w, lambda, tid);
             }
-            const double scale = block_sum<4>(sc, sm);
+            const double scale = block_sum<NW>(sc, sm);
             __threadfence_block();
             __syncthreads();
             PLC(5);
@@ -2224,7 +2230,7 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
     // ---- post-pass: classification with the residuals of the LAST error evaluation and the kept estimate (k_classify)
     PLC(8);
     double es = 0, ec = 0, no = 0;
-    for (int i = tid; i < v.n_L; i += 256) {
+    for (int i = tid; i < v.n_L; i += NT) {
         if (!v.L_active[i]) { flagL[i] = 0; continue; }
         const double2 e = *reinterpret_cast<const double2*>(v.errL + (size_t)i * 2);
         const double ss = e.x * e.x + e.y * e.y;
@@ -2240,9 +2246,9 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
         if (o) { no += 1.0; v.L_active[i] = 0; }
         else { es += ss; ec += 1.0; }
     }
-    const double r0 = block_sum<4>(es, sm);
-    const double r1 = block_sum<4>(ec, sm);
-    const double r2 = block_sum<4>(no, sm);
+    const double r0 = block_sum<NW>(es, sm);
+    const double r1 = block_sum<NW>(ec, sm);
+    const double r2 = block_sum<NW>(no, sm);
     if (tid == 0) {
         out->lambda = lambda; out->ni = ni; out->iteration = iteration; out->n_stats = n_stats; out->flips = flips;
         out->err_sum = r0; out->err_cnt = r1; out->n_out = r2;
@@ -2251,7 +2257,7 @@ __global__ __launch_bounds__(256) void k_pose_lm(BaDeviceView vin, PoseLmArgs a,
     // already in place (the staged form always has one: its inputs are read-only)
     if (out_pose) {
         __syncthreads();
-        for (int i = tid; i < vin.n_cams * 8; i += 256) { out_pose[i] = v.pose_cur[i]; out_pose[vin.n_cams * 8 + i] = v.pose_trial[i]; }
+        for (int i = tid; i < vin.n_cams * 8; i += NT) { out_pose[i] = v.pose_cur[i]; out_pose[vin.n_cams * 8 + i] = v.pose_trial[i]; }
     }
     PLC(9);
 #ifdef POSE_LM_CLOCKS
@@ -2522,7 +2528,7 @@ void ba_small_classify_after_trial(const BaDeviceView& v, const ClassifyAfterTri
 static bool g_pose_lm_staged_ok = true;      // false when this device refused the staged kernel's LDS opt-in: the arrays then stay in HBM
 void ba_small_init_device()
 {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_lm<true>), hipFuncAttributeMaxDynamicSharedMemorySize, POSE_LM_STAGED_MAX_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_lm<true, POSE_LM_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, POSE_LM_STAGED_MAX_BYTES) != hipSuccess) {
         (void)hipGetLastError();
         g_pose_lm_staged_ok = false;
     }
@@ -2535,7 +2541,7 @@ bool ba_pose_lm_applies(const BaDeviceView& v, size_t n_huber)
 }
 void ba_launch_pose_lm(const BaDeviceView& v, const PoseLmArgs& a, PoseLmResult* out, uint8_t* flagL, double* out_pose, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_pose_lm<false>, dim3(1), dim3(256), 0, st, v, a, out, flagL, out_pose);
+    hipLaunchKernelGGL((k_pose_lm<false, POSE_LM_NW>), dim3(1), dim3(64 * POSE_LM_NW), 0, st, v, a, out, flagL, out_pose);
 }
 bool ba_pose_lm_staged_fits(const BaDeviceView& v)
 {
@@ -2545,7 +2551,7 @@ bool ba_launch_pose_lm_staged(const BaDeviceView& v, const PoseLmArgs& a, PoseLm
 {
     const size_t lds = pose_lm_staged_bytes(v.n_cams, v.n_pts, v.n_L, v.n_fc);
     if (!g_pose_lm_staged_ok || lds > (size_t)POSE_LM_STAGED_MAX_BYTES || !out_pose) return false;
-    hipLaunchKernelGGL(k_pose_lm<true>, dim3(1), dim3(256), lds, st, v, a, out, flagL, out_pose);
+    hipLaunchKernelGGL((k_pose_lm<true, POSE_LM_NW>), dim3(1), dim3(64 * POSE_LM_NW), lds, st, v, a, out, flagL, out_pose);
     return true;
 }
 
