@@ -611,15 +611,21 @@ __device__ __forceinline__ void panel_update(const double* __restrict__ S, int l
 #pragma unroll
         for (int u = 0; u < NBUF; ++u) {
             const int ch = ch0 + u;
+            // The prefetch is UNCONDITIONAL (past the end it fetches the last chunk again, into a buffer nobody reads): behind a condition
+            // the two paths into the products carry different numbers of loads in flight and the compiler must wait for the lower one --
+            // s_waitcnt vmcnt(0) in front of every chunk, i.e. for the prefetch it has just issued (rounds 1-5: one exposed trip to memory
+            // per two chunks; a lone wavefront ran its products at ~55 % of the pipe's rate, two per SIMD covered for each other to ~85 %).
             if (NBUF == 1) load_chunk(0, ch);
-            else if (ch + NBUF - 1 < nch) load_chunk((u + NBUF - 1) % NBUF, ch + NBUF - 1);
+            else load_chunk((u + NBUF - 1) % NBUF, ch + NBUF - 1 < nch ? ch + NBUF - 1 : nch - 1);
+            // the panel enters negated on the side with fewer registers ((-a) b and a (-b) are the same product, bit for bit)
 #pragma unroll
             for (int s4 = 0; s4 < KSTEPS; ++s4)
 #pragma unroll
                 for (int a = 0; a < SUBM; ++a)
 #pragma unroll
                     for (int b = 0; b < SUBN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[u][s4][a], bv[u][s4][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = SUBN < SUBM ? __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][s4][a], -bv[u][s4][b], acc[a][b], 0, 0, 0)
+                                                : __builtin_amdgcn_mfma_f64_16x16x4f64(-av[u][s4][a], bv[u][s4][b], acc[a][b], 0, 0, 0);
         }
     }
 }

@@ -555,6 +555,17 @@ void chol_small_solve(const double* S, const double* y, double* x, int n, int ld
 //     after a bounded wait of the other schedule has run out in this process (then without merged strips: no in-launch wait is left
 //     but the split diagonal tile's, whose producers are the first nine workgroups of the grid).
 // The backward substitution is k_bsolve_persist either way.
+// A launch the runtime refused (an LDS opt-in that did not take, a device in a bad state) must not leave `ok` / `stall` stale and the
+// factor -- or an x still full of the backward solve's sentinel -- behind a MAGE_OK: poison both so that the caller's read-back reports a
+// device error.  Run behind the LAST launch of either schedule (the task-graph path used to return in front of it).
+static void poison_on_launch_error(double* ok, double* stall, hipStream_t st)
+{
+    if (hipGetLastError() == hipSuccess) return;
+    static const double bad[2] = { 0.0, 9.0 };          // (static: the copy is asynchronous)
+    (void)hipMemcpyAsync(ok, &bad[0], sizeof(double), hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(stall, &bad[1], sizeof(double), hipMemcpyHostToDevice, st);
+}
+
 void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWorkspace& ws, double* ok, hipStream_t st)
 {
     const int nt = n_pad / TILE;
@@ -574,6 +585,7 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
         long long* const bs_dbg = ws.dbg;
 #endif
         hipLaunchKernelGGL(k_bsolve_persist, dim3(2 * nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, stall, bs_dbg, bs_part);
+        poison_on_launch_error(ok, stall, st);
         return;
     }
     int* flag = ws.sync;
@@ -606,13 +618,7 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
     }
     // backward substitution: one persistent launch (needs every workgroup resident: nt <= 256 compute units)
     hipLaunchKernelGGL(k_bsolve_persist, dim3(2 * nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, stall, ws.dbg, bs_part);
-    // a launch the runtime refused (an LDS opt-in that did not take, a device in a bad state) must not leave `ok` / `stall` stale and
-    // the factor garbage behind a MAGE_OK: poison both so that the caller's read-back reports a device error
-    if (hipGetLastError() != hipSuccess) {
-        const double bad[2] = { 0.0, 9.0 };
-        (void)hipMemcpyAsync(ok, &bad[0], sizeof(double), hipMemcpyHostToDevice, st);
-        (void)hipMemcpyAsync(stall, &bad[1], sizeof(double), hipMemcpyHostToDevice, st);
-    }
+    poison_on_launch_error(ok, stall, st);
 }
 
 }  // namespace mage

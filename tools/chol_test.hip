@@ -78,9 +78,11 @@ int main(int argc, char** argv)
             }
         }
 #endif
-        double ok;
+        double ok, okst[2];
         CK(hipMemcpy(x.data(), dx, sizeof(double) * n, hipMemcpyDeviceToHost));
-        CK(hipMemcpy(&ok, dok, 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(okst, dok, 16, hipMemcpyDeviceToHost));
+        ok = okst[0];
+        if (okst[1] != 0.0) printf("  STALL code %g (a bounded wait ran out: the schedule under test did not finish)\n", okst[1]);
         double rn = 0, bn = 0;
         for (int i = 0; i < n; ++i) {
             double s = 0;
