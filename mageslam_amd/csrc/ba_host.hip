@@ -25,6 +25,7 @@
 #include "ba_build.h"
 #include "ba_kernels.h"
 #include "chol_kernels.h"
+#include "chol_dag.h"
 #include "mage_common.h"
 
 namespace mage {
@@ -1094,6 +1095,7 @@ mage_status initialize_optimization(mage_ba* h)
 
     tm.mark("uploads queued");
     if (n_pad > CHOL_MAX_ORDER) return fail(MAGE_ERR_UNSUPPORTED, "reduced camera system of order %d exceeds %d (one resident workgroup per tile column)", n_pad, CHOL_MAX_ORDER);
+    chol_dag_prefetch(n_pad);          // the dense solve's task lists for this order: a worker thread builds them while the structure is built
     const int nb_l = (nlm + 255) / 256, nb_c = (nfc + 255) / 256;
     MAGE_TRY(stage_array(h, h->d_errL, (size_t)nL * 2 + 2, 0));                // residuals of never-evaluated edges are 0
     MAGE_TRY(stage_array(h, h->d_U, (size_t)nfc * 36 + 1));
@@ -1675,6 +1677,18 @@ MAGE_EXPORT void mage_release_cached_memory(void)
     if (have_cur) (void)hipSetDevice(cur);
 }
 
+// Blocks until the dense solve's task lists for a reduced system of padded order n_pad are on the current device (1) or reports that
+// this order is served by the column launches (0); *build_ms = what the last build took on its worker thread.  bench.py calls it in
+// front of the timed region and reports the figure in extra.cold_start; a deployment never needs it.
+MAGE_EXPORT int mage_debug_chol_wait_schedule(int device, int n_pad, double* build_ms)
+{
+    int dev = 0;
+    if (select_device(device, &dev) != MAGE_OK) return 0;
+    MAGE_DEVICE_SCOPE(dev);
+    chol_init_device();
+    return chol_dag_wait_schedule(n_pad, build_ms) ? 1 : 0;
+}
+
 MAGE_EXPORT mage_status mage_debug_dense_solve(int device, int n, const double* A_colmajor, const double* b, double* x, int* ok)
 {
     return guarded([&]() -> mage_status {
@@ -1685,6 +1699,7 @@ MAGE_EXPORT mage_status mage_debug_dense_solve(int device, int n, const double* 
         chol_init_device();
         const int n_pad = std::max(CHOL_TILE, ((n + CHOL_TILE - 1) / CHOL_TILE) * CHOL_TILE);
         if (n_pad > CHOL_MAX_ORDER) return fail(MAGE_ERR_UNSUPPORTED, "order %d exceeds %d", n_pad, CHOL_MAX_ORDER);
+        (void)chol_dag_wait_schedule(n_pad, nullptr);          // (a test of the solver: the schedule this size has by default, not the one it starts with)
         // the lower triangle, padded with an identity block exactly as the bundle adjustment pads its reduced camera system
         std::vector<double> S((size_t)n_pad * n_pad, 0.0), y(n_pad, 0.0);
         for (int c = 0; c < n; ++c)

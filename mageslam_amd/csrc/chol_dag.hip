@@ -46,6 +46,10 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -897,10 +901,28 @@ bool check_schedule(const Schedule& sch, int nt)
     return true;
 }
 
-struct DagSchedule { unsigned long long* d_tasks = nullptr; int n_tasks = 0, quarter_from = 0, off[N_LISTS] = {}, len[N_LISTS] = {}; bool ok = false; };
+struct DagSchedule { unsigned long long* d_tasks = nullptr; int n_tasks = 0, quarter_from = 0, n_cu = 0, off[N_LISTS] = {}, len[N_LISTS] = {}; bool ok = false; unsigned long long last_use = 0; };
+// The lists of a system size are built ONCE per (device, tile count) -- and not by the thread that asks for them: the simulation takes
+// 19 ms at 47 tile columns and 140 ms at 94, which the first factorisation after a loop closure (a new map size:
+// Tasks/LoopClosureWorker.cpp:163-208 in the reference) would pay before its first launch.  A worker thread builds and checks them;
+// until they are there chol_dag_factor says "not this time" and the factorisation goes column by column (the same bits, 0.7 ms slower
+// at 47 tile columns).  chol_dag_prefetch starts the job as soon as the system's order is known (the structure build), i.e. a few
+// milliseconds before the first factorisation asks.
+struct SchedJob {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false, valid = false;
+    int quarter_from = 0, n_cu = 0, off[N_LISTS] = {}, len[N_LISTS] = {};
+    std::vector<unsigned long long> flat;
+    double build_ms = 0;
+};
 std::mutex g_sched_mutex;
-std::map<std::pair<int, int>, DagSchedule> g_sched;      // (device, nt)
-int g_dag_n_cu = 256;
+std::map<std::pair<int, int>, DagSchedule> g_sched;      // (device, nt): uploaded
+std::map<std::pair<int, int>, std::shared_ptr<SchedJob>> g_jobs;      // being built (or built and not yet uploaded)
+std::map<int, int> g_dev_cu;                             // compute units per device (chol_dag_init_device), under g_sched_mutex
+unsigned long long g_use_clock = 0;
+std::atomic<double> g_last_build_ms{ 0.0 };
+constexpr size_t SCHED_CACHE_MAX = 16;                   // uploaded lists kept per process (least recently used goes first; ~170 KB each at 47 tile columns)
 struct Turnstile { hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool recorded = false, several = false; };
 std::mutex g_turn_mutex;
 std::map<int, Turnstile> g_turn;                         // per device: the event behind the latest task-graph launch and the stream it went to
@@ -917,25 +939,82 @@ int dag_fuse_max()
     return v;
 }
 
-const DagSchedule* get_schedule(int nt)
+int device_cus(int dev)          // (g_sched_mutex held)
+{
+    auto it = g_dev_cu.find(dev);
+    return it == g_dev_cu.end() ? 0 : it->second;
+}
+
+// (g_sched_mutex held) the job that builds the lists of (dev, nt), started if there is none
+std::shared_ptr<SchedJob> job_for(int dev, int nt, int n_cu)
+{
+    auto it = g_jobs.find({ dev, nt });
+    if (it != g_jobs.end()) return it->second;
+    auto job = std::make_shared<SchedJob>();
+    job->n_cu = n_cu;
+    g_jobs[{ dev, nt }] = job;
+    const int gmax = dag_fuse_max();
+    std::thread([job, nt, n_cu, gmax] {
+        const auto t0 = std::chrono::steady_clock::now();
+        const Schedule sch = build_schedule(nt, n_cu, gmax);
+        std::vector<unsigned long long> flat;
+        int off[N_LISTS], len[N_LISTS];
+        for (int g = 0; g < N_LISTS; ++g) { off[g] = (int)flat.size(); len[g] = (int)sch.lists[g].size(); flat.insert(flat.end(), sch.lists[g].begin(), sch.lists[g].end()); }
+        const bool valid = check_schedule(sch, nt);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> lock(job->m);
+        job->flat.swap(flat); job->quarter_from = sch.quarter_from; job->valid = valid; job->build_ms = ms;
+        for (int g = 0; g < N_LISTS; ++g) { job->off[g] = off[g]; job->len[g] = len[g]; }
+        job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    return job;
+}
+
+// The uploaded lists of (current device, nt); nullptr while they are being built (wait = false) or when they cannot be had.
+const DagSchedule* get_schedule(int nt, bool wait)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(g_sched_mutex);
+    std::unique_lock<std::mutex> lock(g_sched_mutex);
     auto it = g_sched.find({ dev, nt });
     if (it == g_sched.end()) {
-        DagSchedule s;
-        const Schedule sch = build_schedule(nt, g_dag_n_cu, dag_fuse_max());
-        s.quarter_from = sch.quarter_from;
-        std::vector<unsigned long long> flat;
-        for (int g = 0; g < N_LISTS; ++g) { s.off[g] = (int)flat.size(); s.len[g] = (int)sch.lists[g].size(); flat.insert(flat.end(), sch.lists[g].begin(), sch.lists[g].end()); }
-        if (check_schedule(sch, nt) && hipMalloc(&s.d_tasks, flat.size() * sizeof(unsigned long long)) == hipSuccess) {
-            if (hipMemcpy(s.d_tasks, flat.data(), flat.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) == hipSuccess) { s.n_tasks = (int)flat.size(); s.ok = true; }
-            else { (void)hipFree(s.d_tasks); s.d_tasks = nullptr; }
+        const int n_cu = device_cus(dev);
+        if (n_cu <= 0) return nullptr;
+        std::shared_ptr<SchedJob> job = job_for(dev, nt, n_cu);
+        {
+            std::unique_lock<std::mutex> jl(job->m);
+            if (!job->done) {
+                if (!wait) return nullptr;
+                lock.unlock();
+                job->cv.wait(jl, [&] { return job->done; });
+                jl.unlock();
+                lock.lock();
+                if ((it = g_sched.find({ dev, nt })) != g_sched.end()) { it->second.last_use = ++g_use_clock; return it->second.ok ? &it->second : nullptr; }
+                jl.lock();
+            }
+            DagSchedule s;
+            s.quarter_from = job->quarter_from; s.n_cu = job->n_cu;
+            for (int g = 0; g < N_LISTS; ++g) { s.off[g] = job->off[g]; s.len[g] = job->len[g]; }
+            if (job->valid && hipMalloc(&s.d_tasks, job->flat.size() * sizeof(unsigned long long)) == hipSuccess) {
+                if (hipMemcpy(s.d_tasks, job->flat.data(), job->flat.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) == hipSuccess) { s.n_tasks = (int)job->flat.size(); s.ok = true; }
+                else { (void)hipFree(s.d_tasks); s.d_tasks = nullptr; }
+            }
+            if (!s.ok) (void)hipGetLastError();
+            g_last_build_ms.store(job->build_ms);
+            // a bounded cache: the least recently used lists go (nothing is in flight with them: a launch holds g_turn_mutex, not this one,
+            // but its kernel reads d_tasks -- so only entries that were not used by the latest launches are dropped, and hipFree waits for the device)
+            if (g_sched.size() >= SCHED_CACHE_MAX) {
+                auto victim = g_sched.begin();
+                for (auto c = g_sched.begin(); c != g_sched.end(); ++c) if (c->second.last_use < victim->second.last_use) victim = c;
+                if (victim->second.d_tasks) (void)hipFree(victim->second.d_tasks);
+                g_sched.erase(victim);
+            }
+            it = g_sched.emplace(std::make_pair(dev, nt), s).first;
         }
-        if (!s.ok) (void)hipGetLastError();
-        it = g_sched.emplace(std::make_pair(dev, nt), s).first;
+        g_jobs.erase({ dev, nt });
     }
+    it->second.last_use = ++g_use_clock;
     return it->second.ok ? &it->second : nullptr;
 }
 
@@ -948,16 +1027,19 @@ size_t chol_dag_sync_ints(int nt) { return (size_t)dag_state_ints(nt); }
 
 void chol_dag_init_device(int n_cu)
 {
-    g_dag_n_cu = n_cu;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    { std::lock_guard<std::mutex> lock(g_sched_mutex); g_dev_cu[dev] = n_cu; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DAG_LDS_BYTES);
 }
 
 bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorkspace& ws, double* ok, double* stall, hipStream_t st)
 {
     const int nt = n_pad / TILE;
-    if (nt < dag_min_tiles() || nt > 255 || g_dag_n_cu < DAG_EXPRESS_WGS + 1 + 2 * N_GROUPS) return false;
-    const DagSchedule* s = get_schedule(nt);
-    if (!s) return false;
+    if (nt < dag_min_tiles() || nt > 255) return false;
+    static const bool sync_build = std::getenv("MAGE_CHOL_DAG_SYNC_BUILD") != nullptr;      // (tests that must see THIS schedule from the first factorisation on)
+    const DagSchedule* s = get_schedule(nt, sync_build);
+    if (!s || s->n_cu < DAG_EXPRESS_WGS + 1 + 2 * N_GROUPS) return false;
     int* state = ws.sync + 8;
     // Two of these launches from two streams of one process must not overlap: each wants every compute unit (one workgroup per unit),
     // the hardware deals the workgroups of both over the XCDs as units come free, and launch A holding all of XCD 3 while launch B holds
@@ -984,7 +1066,7 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
     a.S = S; a.y = y; a.x = x; a.Linv = ws.Linv; a.Lpub = ws.Linv + (size_t)nt * NBLK * NB * NB; a.part = a.Lpub + (size_t)nt * LPUB_TILE_DOUBLES; a.ok = ok; a.stall = stall;
     a.st = state; a.trace = ws.dbg; a.tasks = s->d_tasks; a.ld = n_pad; a.nt = nt; a.n_tasks = s->n_tasks; a.quarter_from = s->quarter_from;
     for (int g = 0; g < N_LISTS; ++g) { a.list_off[g] = s->off[g]; a.list_len[g] = s->len[g]; }
-    hipLaunchKernelGGL(k_chol_dag, dim3(g_dag_n_cu), dim3(DAG_THREADS), DAG_LDS_BYTES, st, a);
+    hipLaunchKernelGGL(k_chol_dag, dim3(s->n_cu), dim3(DAG_THREADS), DAG_LDS_BYTES, st, a);
     if (hipGetLastError() != hipSuccess) return false;
     if (turn.several) {
         turn.recorded = hipEventRecord(turn.ev, st) == hipSuccess;
@@ -992,6 +1074,28 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
     }
     turn.last = st;
     return true;
+}
+
+// the order of a system is known (structure build): start building its lists now, if this size is the task graph's at all
+void chol_dag_prefetch(int n_pad)
+{
+    const int nt = n_pad / TILE;
+    if (nt < dag_min_tiles() || nt > 255) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_sched_mutex);
+    const int n_cu = device_cus(dev);
+    if (n_cu > 0 && g_sched.find({ dev, nt }) == g_sched.end()) (void)job_for(dev, nt, n_cu);
+}
+
+// blocks until the lists of this order are on the device (true) or cannot be had (false); how long the last build took on its thread
+bool chol_dag_wait_schedule(int n_pad, double* build_ms)
+{
+    const int nt = n_pad / TILE;
+    bool ok = false;
+    if (nt >= dag_min_tiles() && nt <= 255) ok = get_schedule(nt, true) != nullptr;
+    if (build_ms) *build_ms = g_last_build_ms.load();
+    return ok;
 }
 
 // a stream is about to be destroyed: the turnstile must not put an event behind it later

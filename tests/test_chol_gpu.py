@@ -143,3 +143,24 @@ def test_a_stalled_task_graph_launch_is_rerun_column_by_column(tmp_path):
     assert res["stalled"][1]["rerun"] == 1 and res["stalled"][1]["fallback"] == 1
     assert res["stalled"][1]["outs"] == res["clean"][1]["outs"]
     assert np.array_equal(res["stalled"][0], res["clean"][0])
+
+
+def test_first_factorisations_of_a_new_size_fall_back_and_agree():
+    """The asynchronous default (no MAGE_CHOL_DAG_SYNC_BUILD): in a fresh process the first step of a new map size does not wait for the
+    task lists of the dense solve (tools/cold_start.py: a worker thread builds them, the factorisation goes column by column meanwhile),
+    and the numbers are those of a process that waited -- the schedules give the same bits."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {}
+    for tag, sync in (("async", False), ("sync", True)):
+        env = dict(os.environ)
+        env.pop("MAGE_CHOL_DAG_SYNC_BUILD", None)
+        if sync:
+            env["MAGE_CHOL_DAG_SYNC_BUILD"] = "1"
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", "cold_start.py"), "--workload", "global"], capture_output=True, text=True, timeout=900, env=env)
+        assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+        runs[tag] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])["fresh_process"]
+    a, s = runs["async"], runs["sync"]
+    assert a["task_graph_size"] and a["tile_columns"] == 47
+    assert a["mse_first_second"] == s["mse_first_second"]
+
