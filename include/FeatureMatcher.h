@@ -203,6 +203,24 @@ namespace mage
         });
     }
 
+    // the same through the tree the context keeps on the device (SetBowTree): only the frame's descriptors and lists travel.  (A name of its
+    // own: without the tree the argument list is that of the IndexedMatch over caller-built candidate lists above.)
+    template <typename DescriptorsA, typename DescriptorsB, typename DMatchVec>
+    unsigned int IndexedMatchResidentTree(MatcherContext& ctx, const DescriptorsA& descriptorsA, const std::vector<int32_t>& leafFeaturesAOffsets, const std::vector<int32_t>& leafFeaturesA,
+                              const DescriptorsB& descriptorsB, const std::vector<int32_t>& leafFeaturesBOffsets, const std::vector<int32_t>& leafFeaturesB,
+                              const std::vector<bool>& imageAMask, const std::vector<bool>& imageBMask, int maxHammingDist, int minHammingDifference, DMatchVec& goodMatches)
+    {
+        std::vector<uint8_t> ma, mb;
+        const uint8_t* pa = shim::Bytes(imageAMask.empty() ? nullptr : &imageAMask, ma);
+        const uint8_t* pb = shim::Bytes(imageBMask.empty() ? nullptr : &imageBMask, mb);
+        const int nA = static_cast<int>(descriptorsA.size()), nB = static_cast<int>(descriptorsB.size());
+        return shim::Append(goodMatches, static_cast<size_t>(nA), [&](mage_dmatch* out, int cap, int* count) {
+            shim::CheckMatch(mage_match_indexed_bow(ctx.Handle(), nullptr, reinterpret_cast<const uint8_t*>(descriptorsA.data()), nA, pa, leafFeaturesAOffsets.data(), leafFeaturesA.data(),
+                                                    reinterpret_cast<const uint8_t*>(descriptorsB.data()), nB, pb, leafFeaturesBOffsets.data(), leafFeaturesB.data(),
+                                                    maxHammingDist, minHammingDifference, out, cap, count), "IndexedMatch");
+        });
+    }
+
     template <typename Descriptor>
     int GetDescriptorDistance(const Descriptor& d0, const Descriptor& d1)
     {

@@ -1323,7 +1323,7 @@ constexpr int SMALL_LPL = 8, SMALL_CPC = 4;
 // DUP = some observations share a W slot (the landmark role then walks a landmark's observations on one thread and sums the blocks of
 // a slot in order): a launch is entirely one kind or the other, and compiled together the rare kind's 27 accumulators set the spills of both.
 template <bool DUP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_small_linearize(BaDeviceView v, double delta, int nbL, int want_maxdiag, int* __restrict__ counter, int cpc,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DUP ? 3 : 4, 4))) void k_small_linearize(BaDeviceView v, double delta, int nbL, int want_maxdiag, int* __restrict__ counter, int cpc,
                                                          int zero_role)
 {
     __shared__ double sm[4];

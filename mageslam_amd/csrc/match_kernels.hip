@@ -6,6 +6,7 @@
 // other set with xor + v_bcnt; best / second-best / in-radius count are kept per row, then the mutual check and
 // an ordered compaction emit cv::DMatch records in ascending query order.  Batched over pairs on blockIdx.x.
 #include <cstdlib>
+#include <cstring>
 
 #include "orb_kernels.h"
 
@@ -317,29 +318,45 @@ __device__ __forceinline__ void track_match(const ulonglong4& left, const ulongl
     }
 }
 
-// OnlineBow::FindLeafNode (BoW/OnlineBow.cpp:289-311) for a batch of descriptors: one thread per descriptor walks the tree from the root,
-// at every level to the child whose medoid is nearest (strict '<' in child-list order: the first of equally near children wins).  Node
-// descriptors are 32 bytes read as four 64-bit words (L2-resident: a vocabulary is a few thousand nodes); children[k] > parent for every
-// edge (checked on the host), so the walk ends.
-__global__ __launch_bounds__(256) void k_bow_find_leaf(const uint8_t* __restrict__ node_desc, const int* __restrict__ child_off, const int* __restrict__ children,
-                                                       const uint8_t* __restrict__ queries, int nq, int* __restrict__ leaf)
+// The vocabulary's leaf lookup (OnlineBow::FindLeafNode, BoW/OnlineBow.cpp:289-311) for a batch of descriptors: from the root, at every level
+// to the child whose medoid is nearest in Hamming distance -- strict '<' in child-list order: the first of equally near children wins.
+// Round 6: a walk is a chain of dependent trips to memory (five levels of child offsets -> child index -> medoid: ~40 loads one after the
+// other on one thread, 18.8 us for 880 descriptors on four workgroups), so the tree goes up as a WALK TABLE -- per position k of the
+// concatenated child lists one 48-byte entry {child node, the child's own range of positions, the child's medoid} (bow_walk_fill, built
+// on the host beside the validation) -- and a level is ONE trip: a query is walked by 16 lanes, lane l rating positions k0 + l, k0 + l + 16, ...,
+// key = distance << 16 | position in the list (the minimum is the nearest child, the first of equals), four row rotations reduce it over
+// the 16 lanes, the winner's entry names the next range.  Four queries per wavefront, a wavefront per workgroup: 880 descriptors are
+// 220 workgroups on as many compute units.  Integer work: bit-exact.  (Not staged through LDS: a workgroup walks four queries, and
+// fetching the top two levels into LDS first is itself the trip it would save.)
+__global__ __launch_bounds__(64) void k_bow_find_leaf(const BowWalkEntry* __restrict__ W, int root_k0, int root_k1, const uint8_t* __restrict__ queries, int nq, int* __restrict__ leaf)
 {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= nq) return;
-    const ulonglong4 d = reinterpret_cast<const ulonglong4*>(queries)[q];
-    const ulonglong4* N = reinterpret_cast<const ulonglong4*>(node_desc);
-    int cur = 0;
-    for (int k0 = child_off[0], k1 = child_off[1]; k0 < k1; k0 = child_off[cur], k1 = child_off[cur + 1]) {
-        int best_d = 0x7fffffff, next = cur;
-        for (int k = k0; k < k1; ++k) {
-            const int c = children[k];
-            const ulonglong4 m = N[c];
-            const int dist = __popcll(d.x ^ m.x) + __popcll(d.y ^ m.y) + __popcll(d.z ^ m.z) + __popcll(d.w ^ m.w);
-            if (dist < best_d) { best_d = dist; next = c; }
+    const int lane = threadIdx.x, sub = lane & 15, q = blockIdx.x * 4 + (lane >> 4);
+    const bool live = q < nq;
+    const ulonglong4 d = reinterpret_cast<const ulonglong4*>(queries)[live ? q : 0];
+    int cur = 0, k0 = live ? root_k0 : 0, k1 = live ? root_k1 : 0;
+    while (__builtin_amdgcn_ballot_w64(k0 < k1)) {
+        unsigned key = 0xffffffffu;
+        int c = cur, ck0 = 0, ck1 = 0;
+        for (int k = k0 + sub; k < k1; k += 16) {
+            const int4 hd = *reinterpret_cast<const int4*>(&W[k]);
+            const ulonglong2 m0 = *reinterpret_cast<const ulonglong2*>(W[k].medoid), m1 = *reinterpret_cast<const ulonglong2*>(W[k].medoid + 2);
+            const unsigned dist = (unsigned)(__popcll(d.x ^ m0.x) + __popcll(d.y ^ m0.y) + __popcll(d.z ^ m1.x) + __popcll(d.w ^ m1.y));
+            const unsigned kk = (dist << 16) | (unsigned)(k - k0);
+            if (kk < key) { key = kk; c = hd.x; ck0 = hd.y; ck1 = hd.z; }
         }
-        cur = next;
+        // minimum over the 16 lanes of the query (row rotations by 8, 4, 2, 1: every lane ends with the row's minimum)
+        unsigned best = key;
+        best = min(best, (unsigned)__builtin_amdgcn_update_dpp((int)best, (int)best, 0x128, 0xf, 0xf, false));
+        best = min(best, (unsigned)__builtin_amdgcn_update_dpp((int)best, (int)best, 0x124, 0xf, 0xf, false));
+        best = min(best, (unsigned)__builtin_amdgcn_update_dpp((int)best, (int)best, 0x122, 0xf, 0xf, false));
+        best = min(best, (unsigned)__builtin_amdgcn_update_dpp((int)best, (int)best, 0x121, 0xf, 0xf, false));
+        // the lane that holds it (keys of one query are distinct: they carry the position) hands its entry to the other fifteen
+        const unsigned long long win = __builtin_amdgcn_ballot_w64(key == best && key != 0xffffffffu);
+        const int src = (lane & 48) + __builtin_ctz((unsigned)((win >> (lane & 48)) & 0xffffu) | 0x10000u);
+        const int wc = __shfl(c, src & 63, 64), wk0 = __shfl(ck0, src & 63, 64), wk1 = __shfl(ck1, src & 63, 64);
+        if (k0 < k1) { cur = wc; k0 = wk0; k1 = wk1; }
     }
-    leaf[q] = cur;
+    if (live && sub == 0) leaf[q] = cur;
 }
 
 // leafA / leafB (IndexedMatch through the vocabulary, mage_match_indexed_bow): when given, descriptor a's candidate list is the list of the
@@ -402,9 +419,20 @@ void indexed_match_launch(const uint8_t* descA, int nA, const uint8_t* maskA, co
     hipLaunchKernelGGL(k_indexed_match, dim3(1), dim3(MT), 0, st, descA, nA, maskA, cb_off, cb, descB, maskB, ca_off, ca, max_dist, min_diff, out, cap, count, leafA, leafB);
 }
 
-void bow_find_leaf_launch(const uint8_t* node_desc, const int* child_off, const int* children, const uint8_t* queries, int nq, int* leaf, hipStream_t st)
+void bow_find_leaf_launch(const BowWalkEntry* walk, int root_k0, int root_k1, const uint8_t* queries, int nq, int* leaf, hipStream_t st)
 {
-    if (nq > 0) hipLaunchKernelGGL(k_bow_find_leaf, dim3((nq + 255) / 256), dim3(256), 0, st, node_desc, child_off, children, queries, nq, leaf);
+    if (nq > 0) hipLaunchKernelGGL(k_bow_find_leaf, dim3((nq + 3) / 4), dim3(64), 0, st, walk, root_k0, root_k1, queries, nq, leaf);
+}
+
+// the walk table of a (validated) tree: entry k = position k of the concatenated child lists
+void bow_walk_fill(const uint8_t* node_descriptors, const int32_t* child_offsets, const int32_t* children, int n_nodes, BowWalkEntry* dst)
+{
+    const int nch = child_offsets[n_nodes];
+    for (int k = 0; k < nch; ++k) {
+        const int c = children[k];
+        dst[k].child = c; dst[k].k0 = child_offsets[c]; dst[k].k1 = child_offsets[c + 1]; dst[k].pad = 0;
+        std::memcpy(dst[k].medoid, node_descriptors + 32 * (size_t)c, 32);
+    }
 }
 
 void radius_match_launch(const mage_keypoint* qk, int nq, const float2* qpos, const uint8_t* qmask, const uint8_t* qdesc, const mage_keypoint* tk,

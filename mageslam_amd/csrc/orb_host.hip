@@ -454,8 +454,9 @@ struct mage_matcher {
     DevBuf<int> d_cA, d_cB, d_scratch, d_counts, d_done;       // d_done: per-pair arrival counters of k_match_rows, zero between launches
     size_t done_zeroed = 0;
     DevBuf<mage_dmatch> d_out;
-    DevBuf<uint8_t> d_tree;                    // mage_bow_set_tree: [node descriptors | child offsets | children], validated
-    size_t tree_nodes = 0, tree_o_co = 0, tree_o_ch = 0;
+    DevBuf<uint8_t> d_tree;                    // mage_bow_set_tree: the validated tree as the lookup walks it (BowWalkEntry per child-list position)
+    size_t tree_nodes = 0;
+    int tree_root_k1 = 0;                      // the root's children are positions 0 .. tree_root_k1 - 1
     hipEvent_t e0 = nullptr, e1 = nullptr, e_wait = nullptr;
     double last_ms = 0;
     ~mage_matcher()
@@ -709,7 +710,7 @@ MAGE_EXPORT mage_status mage_match_indexed(mage_matcher* h, const uint8_t* descA
     });
 }
 
-// ---- the vocabulary tree (mage_match.h): validation shared by the two entry points; the tree goes up as [nodes | child_off | children]
+// ---- the vocabulary tree (mage_match.h): validation shared by the entry points; the tree goes up as its walk table (orb_kernels.h: BowWalkEntry)
 namespace {
 mage_status check_bow_tree(const mage_bow_tree* t)
 {
@@ -719,6 +720,7 @@ mage_status check_bow_tree(const mage_bow_tree* t)
     for (int n = 0; n < t->n_nodes; ++n) {
         if (t->child_offsets[n + 1] < t->child_offsets[n]) return fail(MAGE_ERR_INVALID_ARGUMENT, "child offsets are not monotone at node %d", n);
         if (t->child_offsets[n + 1] > t->child_offsets[n] && !t->children) return fail(MAGE_ERR_INVALID_ARGUMENT, "null child list");
+        if (t->child_offsets[n + 1] - t->child_offsets[n] > 65535) return fail(MAGE_ERR_UNSUPPORTED, "node %d has more than 65535 children", n);
         // a child is created after its parent (OnlineBow's m_nodes grows by appending): child index > parent index, which also bounds every descent
         for (int k = t->child_offsets[n]; k < t->child_offsets[n + 1]; ++k)
             if (t->children[k] <= n || t->children[k] >= t->n_nodes) return fail(MAGE_ERR_INVALID_ARGUMENT, "child %d of node %d must lie in (%d, %d)", t->children[k], n, n, t->n_nodes);
@@ -743,17 +745,14 @@ MAGE_EXPORT mage_status mage_bow_set_tree(mage_matcher* h, const mage_bow_tree* 
         if (!tree) { h->tree_nodes = 0; return MAGE_OK; }
         MAGE_TRY(check_bow_tree(tree));
         MAGE_DEVICE_SCOPE(h->device);
-        auto al = [](size_t v) { return (v + 31) & ~(size_t)31; };
-        const size_t nn = (size_t)tree->n_nodes, nch = (size_t)tree->child_offsets[nn];
-        const size_t o_co = al(32 * nn), o_ch = al(o_co + 4 * (nn + 1)), total = al(o_ch + 4 * nch);
+        const size_t nn = (size_t)tree->n_nodes, nch = (size_t)tree->child_offsets[nn], total = std::max<size_t>(nch, 1) * sizeof(BowWalkEntry);
         std::vector<uint8_t> stage(total, 0);
-        std::memcpy(stage.data(), tree->node_descriptors, 32 * nn); std::memcpy(stage.data() + o_co, tree->child_offsets, 4 * (nn + 1));
-        if (nch) std::memcpy(stage.data() + o_ch, tree->children, 4 * nch);
+        bow_walk_fill(tree->node_descriptors, tree->child_offsets, tree->children, tree->n_nodes, reinterpret_cast<BowWalkEntry*>(stage.data()));
         h->tree_nodes = 0;
         MAGE_HIP(hipStreamSynchronize(h->stream));           // (a launch still reading the previous tree)
         MAGE_TRY(h->d_tree.reserve(total));
         MAGE_HIP(hipMemcpy(h->d_tree.p, stage.data(), total, hipMemcpyHostToDevice));
-        h->tree_nodes = nn; h->tree_o_co = o_co; h->tree_o_ch = o_ch;
+        h->tree_nodes = nn; h->tree_root_k1 = tree->child_offsets[1];
         return MAGE_OK;
     });
 }
@@ -771,9 +770,8 @@ MAGE_EXPORT mage_status mage_bow_find_leaf_batch(mage_matcher* h, const mage_bow
             MAGE_TRY(h->d_A.reserve(32 * (size_t)n));
             MAGE_TRY(h->d_scratch.reserve((size_t)n));
             MAGE_HIP(hipMemcpyAsync(h->d_A.p, descriptors, 32 * (size_t)n, hipMemcpyHostToDevice, st));
-            const uint8_t* d = h->d_tree.p;
             MAGE_HIP(hipEventRecord(h->e0, st));
-            bow_find_leaf_launch(d, reinterpret_cast<const int*>(d + h->tree_o_co), reinterpret_cast<const int*>(d + h->tree_o_ch), h->d_A.p, n, h->d_scratch.p, st);
+            bow_find_leaf_launch(reinterpret_cast<const BowWalkEntry*>(h->d_tree.p), 0, h->tree_root_k1, h->d_A.p, n, h->d_scratch.p, st);
             MAGE_HIP(hipEventRecord(h->e1, st));
             MAGE_HIP(hipMemcpyAsync(leaf_ids, h->d_scratch.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
             MAGE_HIP(hipStreamSynchronize(st));
@@ -791,19 +789,18 @@ MAGE_EXPORT mage_status mage_bow_find_leaf_batch(mage_matcher* h, const mage_bow
         if (!descriptors || !leaf_ids) return fail(MAGE_ERR_INVALID_ARGUMENT, "null buffer");
         MAGE_DEVICE_SCOPE(h->device);
         hipStream_t st = h->stream;
-        auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        auto al = [](size_t v) { return (v + 31) & ~(size_t)31; };          // (the kernel reads queries as 32-byte vectors; the same alignment as mage_match_indexed_bow)
         const size_t nn = (size_t)tree->n_nodes, nch = (size_t)tree->child_offsets[nn];
-        const size_t o_nd = 0, o_co = al(o_nd + 32 * nn), o_ch = al(o_co + 4 * (nn + 1)), o_q = al(o_ch + 4 * nch), total = al(o_q + 32 * (size_t)n);
+        const size_t o_w = 0, o_q = al(o_w + sizeof(BowWalkEntry) * nch), total = al(o_q + 32 * (size_t)n);
         std::vector<uint8_t> stage(total, 0);
-        std::memcpy(stage.data() + o_nd, tree->node_descriptors, 32 * nn); std::memcpy(stage.data() + o_co, tree->child_offsets, 4 * (nn + 1));
-        if (nch) std::memcpy(stage.data() + o_ch, tree->children, 4 * nch);
+        bow_walk_fill(tree->node_descriptors, tree->child_offsets, tree->children, tree->n_nodes, reinterpret_cast<BowWalkEntry*>(stage.data() + o_w));
         std::memcpy(stage.data() + o_q, descriptors, 32 * (size_t)n);
         MAGE_TRY(h->d_A.reserve(total));
         MAGE_TRY(h->d_scratch.reserve((size_t)n));
         MAGE_HIP(hipMemcpyAsync(h->d_A.p, stage.data(), total, hipMemcpyHostToDevice, st));
         const uint8_t* d = h->d_A.p;
         MAGE_HIP(hipEventRecord(h->e0, st));
-        bow_find_leaf_launch(d + o_nd, reinterpret_cast<const int*>(d + o_co), reinterpret_cast<const int*>(d + o_ch), d + o_q, n, h->d_scratch.p, st);
+        bow_find_leaf_launch(reinterpret_cast<const BowWalkEntry*>(d + o_w), 0, tree->child_offsets[1], d + o_q, n, h->d_scratch.p, st);
         MAGE_HIP(hipEventRecord(h->e1, st));
         MAGE_HIP(hipMemcpyAsync(leaf_ids, h->d_scratch.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
         MAGE_HIP(hipStreamSynchronize(st));
@@ -835,18 +832,15 @@ MAGE_EXPORT mage_status mage_match_indexed_bow(mage_matcher* h, const mage_bow_t
         if (cntA == 0 || cntB == 0) return MAGE_OK;
         MAGE_DEVICE_SCOPE(h->device);
         hipStream_t st = h->stream;
-        // one staging buffer: [nodes | child_off | children | descA | descB | feat_b_off | feat_a_off | feat_b | feat_a | maskA | maskB]; descA and descB
+        // one staging buffer: [walk table of the tree | descA | descB | feat_b_off | feat_a_off | feat_b | feat_a | maskA | maskB]; descA and descB
         // are adjacent so that ONE launch finds the leaves of both images
         auto al = [](size_t v) { return (v + 31) & ~(size_t)31; };
         const size_t nn = (size_t)n_nodes, nch = resident ? 0 : (size_t)tree->child_offsets[nn], nfa = (size_t)feat_a_off[nn], nfb = (size_t)feat_b_off[nn];
-        const size_t o_nd = 0, o_co = resident ? 0 : al(o_nd + 32 * nn), o_ch = resident ? 0 : al(o_co + 4 * (nn + 1)), o_da = resident ? 0 : al(o_ch + 4 * nch), o_db = o_da + 32 * (size_t)nA,
+        const size_t o_w = 0, o_da = resident ? 0 : al(o_w + sizeof(BowWalkEntry) * nch), o_db = o_da + 32 * (size_t)nA,
                      o_bo = al(o_db + 32 * (size_t)nB), o_ao = al(o_bo + 4 * (nn + 1)), o_fb = al(o_ao + 4 * (nn + 1)), o_fa = al(o_fb + 4 * nfb),
                      o_ma = al(o_fa + 4 * nfa), o_mb = al(o_ma + nA), total = al(o_mb + nB);
         std::vector<uint8_t> stage(total, 0);
-        if (!resident) {
-            std::memcpy(stage.data() + o_nd, tree->node_descriptors, 32 * nn); std::memcpy(stage.data() + o_co, tree->child_offsets, 4 * (nn + 1));
-            if (nch) std::memcpy(stage.data() + o_ch, tree->children, 4 * nch);
-        }
+        if (!resident) bow_walk_fill(tree->node_descriptors, tree->child_offsets, tree->children, tree->n_nodes, reinterpret_cast<BowWalkEntry*>(stage.data() + o_w));
         std::memcpy(stage.data() + o_da, descA, 32 * (size_t)nA); std::memcpy(stage.data() + o_db, descB, 32 * (size_t)nB);
         std::memcpy(stage.data() + o_bo, feat_b_off, 4 * (nn + 1)); std::memcpy(stage.data() + o_ao, feat_a_off, 4 * (nn + 1));
         if (nfb) std::memcpy(stage.data() + o_fb, feat_b, 4 * nfb);
@@ -861,8 +855,7 @@ MAGE_EXPORT mage_status mage_match_indexed_bow(mage_matcher* h, const mage_bow_t
         const uint8_t* d = h->d_A.p;
         int* leaf = h->d_scratch.p;          // [leaf of every A descriptor | leaf of every B descriptor]
         MAGE_HIP(hipEventRecord(h->e0, st));
-        const uint8_t* tr = resident ? h->d_tree.p : d;
-        bow_find_leaf_launch(tr + o_nd, reinterpret_cast<const int*>(tr + (resident ? h->tree_o_co : o_co)), reinterpret_cast<const int*>(tr + (resident ? h->tree_o_ch : o_ch)), d + o_da, nA + nB, leaf, st);
+        bow_find_leaf_launch(reinterpret_cast<const BowWalkEntry*>(resident ? h->d_tree.p : d + o_w), 0, resident ? h->tree_root_k1 : tree->child_offsets[1], d + o_da, nA + nB, leaf, st);
         indexed_match_launch(d + o_da, nA, maskA ? d + o_ma : nullptr, reinterpret_cast<const int*>(d + o_bo), reinterpret_cast<const int*>(d + o_fb),
                              d + o_db, maskB ? d + o_mb : nullptr, reinterpret_cast<const int*>(d + o_ao), reinterpret_cast<const int*>(d + o_fa),
                              max_dist, min_diff, h->d_out.p, capacity, h->d_counts.p, st, leaf, leaf + nA);

@@ -61,6 +61,10 @@ void radius_match_launch(const mage_keypoint* qk, int nq, const float2* qpos, co
 void indexed_match_launch(const uint8_t* descA, int nA, const uint8_t* maskA, const int* cb_off, const int* cb, const uint8_t* descB,
                           const uint8_t* maskB, const int* ca_off, const int* ca, int max_dist, int min_diff, mage_dmatch* out, int cap, int* count,
                           hipStream_t st, const int* leafA = nullptr, const int* leafB = nullptr);      // leafA / leafB: the lists are per vocabulary node, looked up through the descriptor's leaf
-void bow_find_leaf_launch(const uint8_t* node_desc, const int* child_off, const int* children, const uint8_t* queries, int nq, int* leaf, hipStream_t st);
+// one position of a vocabulary tree's concatenated child lists as the leaf lookup walks it (match_kernels.hip: k_bow_find_leaf)
+struct BowWalkEntry { int child, k0, k1, pad; unsigned long long medoid[4]; };
+static_assert(sizeof(BowWalkEntry) == 48, "walk entry");
+void bow_walk_fill(const uint8_t* node_descriptors, const int32_t* child_offsets, const int32_t* children, int n_nodes, BowWalkEntry* dst);
+void bow_find_leaf_launch(const BowWalkEntry* walk, int root_k0, int root_k1, const uint8_t* queries, int nq, int* leaf, hipStream_t st);
 
 }  // namespace mage

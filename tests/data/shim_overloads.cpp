@@ -20,3 +20,18 @@ void all_forms(mage::BundlerLib& b)
     b.GetPoint(0, t3); b.GetPoint(0, pt); b.GetPoint(0, at); b.GetPoint(0, vt); b.GetPoint(0, Map3{ t3 });
     b.StepBundleAdjustment(hub, 7.25f, out); b.StepBundleAdjustment(hub.data(), hub.size(), 7.25f, out);
 }
+
+#include "FeatureMatcher.h"
+struct Desc32 { unsigned char b[32]; };
+struct DMatchLike { int queryIdx, trainIdx, imgIdx; float distance; };
+unsigned indexed_match_forms(mage::MatcherContext& ctx, const mage::BowTree& tree)
+{
+    std::vector<Desc32> da(4), db(4);
+    std::vector<int32_t> fao(tree.childOffsets.size(), 0), fa, fbo(tree.childOffsets.size(), 0), fb;
+    std::vector<bool> ma, mb;
+    std::vector<DMatchLike> good;
+    unsigned n = mage::IndexedMatch(ctx, tree, da, fao, fa, db, fbo, fb, ma, mb, 30, 1, good);      // the tree staged with the call
+    mage::SetBowTree(ctx, tree);
+    n += mage::IndexedMatchResidentTree(ctx, da, fao, fa, db, fbo, fb, ma, mb, 30, 1, good);         // the tree the context keeps on the device
+    return n + static_cast<unsigned>(mage::FindLeafNodes(ctx, da).size() + mage::FindLeafNodes(ctx, tree, db).size());
+}

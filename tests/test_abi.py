@@ -72,3 +72,13 @@ def test_bundlerlib_shim_accepts_every_argument_form():
         p = subprocess.run([cxx, "-std=" + std, "-fsyntax-only", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "data", "shim_overloads.cpp")],
                            capture_output=True, text=True, timeout=120)
         assert p.returncode == 0, p.stderr[-3000:]
+
+
+def test_no_kernel_spills_vector_registers():
+    """Every kernel of the product library, as hipcc compiles it for gfx950: no spilled vector register, no scratch memory that is not an
+    indexed private array of the algorithm itself (tools/spill_report.py names those).  Round 4's criterion, checked on the CPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "spill_report.py")], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]

@@ -40,12 +40,22 @@ def test_single_gpu_line_carries_every_configuration():
     h = d["roofline_hbm"]
     assert h["bound"] == "hbm" and set(h["stages"]) == {"linearize", "schur_build", "backsubst_and_trial_error"} and 0 < h["frac"] < 1
     # what lies outside the measured stages of a step (host turn-around, the outlier pass, the reductions) stays small
-    assert d["ms_per_step"] - r["ms_per_launch"] - h["ms"] < 0.25          # (0.04-0.06 ms measured; a 5-step window on a freshly woken GPU has shown 0.19 once)
+    # (0.04-0.06 ms measured; a 5-step window on a freshly woken GPU has shown 0.19 once: such a window is measured again, longer, and must hold then)
+    over = d["ms_per_step"] - r["ms_per_launch"] - h["ms"]
+    if over >= 0.12:
+        p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-extras"],
+                            capture_output=True, text=True, timeout=900)
+        assert p2.returncode == 0, p2.stderr[-3000:]
+        d2 = _line(p2.stdout)
+        over = d2["ms_per_step"] - d2["roofline"]["ms_per_launch"] - d2["roofline_hbm"]["ms"]
+    assert over < 0.12, over
     e = d["extra"]
-    for k in ("config2", "config2_cpu_baseline", "config3", "config3_cpu_baseline", "config4_end_to_end", "sustained", "concurrent_handles", "config5_windowed_1gpu"):
+    for k in ("config2", "config2_cpu_baseline", "config3", "config3_cpu_baseline", "config4_end_to_end", "cold_start", "sustained", "concurrent_handles", "config5_windowed_1gpu"):
         assert k in e and "error" not in e[k], (k, e.get(k))
     assert e["config3"]["one_iteration_bundler_create_to_destroy"]["total_ms"] < 1.5      # 2.1 ms with the host structure build
     assert e["config4_end_to_end"]["one_iteration_bundler"]["first_step_ms_structure_build_plus_one_iteration"] < 8.0
+    cs = e["cold_start"]
+    assert cs["global"]["fresh_process"]["task_graph_size"] and cs["global"]["warm_process_new_size"]["tile_columns"] == 57 and cs["global2k"]["fresh_process"]["tile_columns"] == 94
     assert set(e["config2"]["batches"]) == {"1", "64", "1024"}
     assert e["sustained"]["seeded_lambda_5e6"]["timed_seconds"] >= 2.0 and e["sustained"]["seeded_lambda_5e6"]["trials_per_iteration"] == 1.0
     s = d["strong_scaling"]
