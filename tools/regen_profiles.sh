@@ -30,3 +30,15 @@ done
 python "$root/tools/pmc_stage_traffic.py" "$(find "$out/${tag}_pmc_FETCH_SIZE" -name '*.db' | head -1)" "$(find "$out/${tag}_pmc_WRITE_SIZE" -name '*.db' | head -1)" > "$out/${tag}_ba_stage_traffic.json"
 rm -rf "$out/${tag}_prof" "$out/${tag}_pmc_FETCH_SIZE" "$out/${tag}_pmc_WRITE_SIZE"
 tail -c 600 "$out/${tag}_bench.json"; echo; head -12 "$out/${tag}_bench_kernel_stats.txt"; cat "$out/${tag}_chol_traffic.json"; head -8 "$out/${tag}_ba_stage_traffic.json"
+# every artefact this script promises must exist and be non-empty (round 5 committed a 0-byte profile that DESIGN.md cited)
+bad=0
+for f in "$out/${tag}_bench.json" "$out/${tag}_bench_kernel_stats.txt" "$out/${tag}_bench_under_rocprof.json" "$out/${tag}_chol_traffic.json" "$out/${tag}_ba_stage_traffic.json"; do
+    if [ ! -s "$f" ]; then echo "regen_profiles: $f is missing or empty" >&2; bad=1; fi
+done
+# ... and so must every profiles/ file that DESIGN.md or profiles/README.md cites
+for f in $(grep -oh "profiles/[A-Za-z0-9_./-]*" "$root/DESIGN.md" "$root/profiles/README.md" 2>/dev/null | sed 's/[.,)]*$//' | sort -u); do
+    case "$f" in *'*'*|*/) continue;; esac
+    if [ -e "$root/$f" ] && [ ! -s "$root/$f" ]; then echo "regen_profiles: cited profile $f is empty" >&2; bad=1; fi
+done
+exit $bad
+
