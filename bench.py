@@ -879,6 +879,14 @@ def main() -> int:
                            "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0} for k, (ms, by) in stages.items()},
             "traffic": None,
         }
+        # The same span against SURVEY.md section 8(d)'s COMPULSORY bytes of these stages (what no implementation can avoid: the 20-byte
+        # observation records four times, the points twice read and once written, the poses), so that the fraction cannot drift with
+        # the handle's own accounting: the handle counts every array a stage touches (compact W records, list entries, landmark blocks).
+        sc = WORKLOADS[args.workload]
+        surv_b = 4 * 20.0 * sc["n_obs"] + 3 * 24.0 * sc["n_pts"] + 2 * 96.0 * sc["n_cams"]
+        line["roofline_hbm"]["survey_8d"] = {"compulsory_bytes": surv_b, "GB/s": surv_b / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0,
+                                             "frac": surv_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tot_ms > 0 else 0.0,
+                                             "note": "S itself (written once by the Schur build inside its skyline, read and written by the factorisation) is the dense solve's traffic: roofline.traffic"}
         try:   # HBM bytes per LM iteration of the three stages from the committed PMC passes (tools/pmc_stage_traffic.py)
             sj = json.load(open(_latest_profile("ba_stage_traffic.json")))
             if args.workload == "global":
