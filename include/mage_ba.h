@@ -43,6 +43,7 @@ const char* mage_last_error(void);
  * definite A (column-major, lower triangle read, host memory) with the same tiled Cholesky + substitutions the bundle adjustment
  * runs; *ok = 0 when a pivot is not positive.  Lets the factorisation be checked against LAPACK / rocSOLVER. */
 mage_status mage_debug_dense_solve(int device, int n, const double* A_colmajor, const double* b, double* x, int* ok);
+mage_status mage_debug_dense_solve_skyline(int device, int n, const double* A_colmajor, const double* b, double* x, int* ok, const int* tile_env);
 
 /* Device buffers of destroyed handles (BA, ORB, matcher) are parked per device and reused by the next handle, because the
  * reference creates and destroys a bundler per optimisation (BundleAdjust.cpp:348-351) and a fresh 0.8 GB allocation costs
@@ -245,6 +246,13 @@ typedef struct mage_ba_profile {
  * 2 only the dense factorisation + solves (two per trial) -- what a timed run keeps on.  Enabling resets the sums. */
 mage_status mage_ba_enable_profiling(mage_ba* h, int enable);
 mage_status mage_ba_get_profile(const mage_ba* h, mage_ba_profile* out);
+/* The reduced camera matrix of a trajectory map is block-banded: cameras far apart share no landmark.  The reference's LinearSolverDense
+ * (BundlerLib.cpp:184-196) factors it as a dense matrix all the same, and so does this library by default.  enable = 1:
+ * the dense solve's task-graph schedule skips every 128 x 128 tile left of the matrix's skyline (by tile rows: Schur blocks, tether pairs;
+ * fill-in never leaves a row's envelope) -- tiles that are zero and stay zero in the factor, so the numbers are the same to the bit and
+ * the factorisation is bound by its chain of diagonal tiles alone (1k-pose map 2.05 -> 1.86 ms, 2k-pose map 11.7 -> 3.7 ms).  Takes
+ * effect with the next structure build; MAGE_BA_SKYLINE=1 makes it the default of every new handle.  Not for landmark-sharded handles. */
+mage_status mage_ba_use_skyline(mage_ba* h, int enable);
 
 /* One list of the graph structure as it sits in HBM after the first step (names as in mageslam_amd/csrc/ba_kernels.h:
  * "cam2hc", "hc2cam", "L_edge", "L_uv", "L_info", "L_cam", "L_pt", "L_slot", "lm_ptr", "lm_pt", "lm_wptr", "w_hc", "w_lm", "camE_ptr",

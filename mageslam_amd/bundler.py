@@ -76,6 +76,7 @@ def _declare():
     L.mage_ba_get_state_f64.argtypes = [vp, _f64, _f64]
     L.mage_ba_get_iter_stats.argtypes = [vp, C.POINTER(IterStats), sz, C.POINTER(sz)]
     L.mage_ba_enable_profiling.argtypes = [vp, C.c_int]
+    L.mage_ba_use_skyline.argtypes = [vp, C.c_int]
     L.mage_ba_get_profile.argtypes = [vp, C.POINTER(Profile)]
     L.mage_ba_debug_structure.argtypes = [vp, C.c_char_p, C.c_void_p, sz, C.POINTER(sz)]
     L.mage_release_cached_memory.argtypes = []
@@ -245,6 +246,10 @@ class BundlerLib:
         check(self._L.mage_ba_get_iter_stats(self._h, arr, 64, C.byref(n)))
         return [dict(code=a.code, trials=a.trials, chi_before=a.chi2_before, chi_after=a.chi2_after, lam=a.lambda_)
                 for a in arr[: n.value]]
+
+    def use_skyline(self, on=True):
+        """The dense solve skips the tiles left of the reduced system's skyline (same numbers, less work); from the next structure build on."""
+        check(self._L.mage_ba_use_skyline(self._h, int(bool(on))))
 
     def enable_profiling(self, on=True):
         """True / 1: every stage of an LM iteration bracketed by HIP events; 2: only the dense factorisation + solves; False: off."""

@@ -285,6 +285,8 @@ struct mage_ba {
     DevBuf<int> d_queue;
     DevBuf<int> d_tile_env;            // the skyline of S by tile rows (k_zero_skyline)
     bool tile_env_valid = false;       // d_tile_env describes the CURRENT structure
+    std::vector<int> tile_env_host;    // mage_ba_use_skyline: the same on the host (read back once per structure), handed to the dense solve's task-graph schedule
+    bool use_skyline = false;
     bool S_outside_skyline_is_zero = false;   // every tile of S left of its row's envelope holds zeros (true after a clear + a factorisation that produced no NaN)
     // ---- device build of the structure (ba_build.h): the raw records and its scratch
     DevBuf<ObsRecord> d_obs_raw; DevBuf<uint8_t> d_cam_fixed; DevBuf<int> d_cam_extra;
@@ -1165,7 +1167,17 @@ mage_status initialize_optimization(mage_ba* h)
         MAGE_TRY(h->d_tile_env.reserve((size_t)n_pad / CHOL_TILE + 1));
         ba_launch_tile_envelope(v, h->d_tile_env.p, st);
         h->tile_env_valid = true;
-    } else h->tile_env_valid = false;
+        h->tile_env_host.clear();
+        if (h->use_skyline) {
+            // the solve is to skip the tiles left of the skyline (they are zero and stay zero in the factor): its schedule is built on
+            // the host from the skyline, so the skyline comes back once per structure (n_pad / 128 ints)
+            h->tile_env_host.resize((size_t)n_pad / CHOL_TILE);
+            MAGE_HIP(hipMemcpyAsync(h->tile_env_host.data(), h->d_tile_env.p, h->tile_env_host.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+            MAGE_HIP(hipStreamSynchronize(st));
+            for (size_t R = 0; R < h->tile_env_host.size(); ++R) h->tile_env_host[R] = std::max(0, std::min(h->tile_env_host[R], (int)R));
+            chol_dag_prefetch(n_pad, h->tile_env_host.data());
+        }
+    } else { h->tile_env_valid = false; h->tile_env_host.clear(); }
     h->L_edge_host.swap(L_edge);          // device build: empty, fetched if the pose-only path ever needs it (mage_ba_step)
     h->built_on_device = on_device;
     h->prof.system_order = n; h->prof.padded_order = n_pad;
@@ -1287,6 +1299,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
     bool speculated = false;
     int stall_retries = 0;
     CholWorkspace ws{ h->d_Linv.p, h->d_queue.p, nullptr, v.scal + SC_CHOL_STALL };
+    if (h->use_skyline && h->tile_env_valid && !sharded && !h->tile_env_host.empty()) ws.env_host = h->tile_env_host.data();
     bool again = false;
     do {
         again = false;
@@ -1689,7 +1702,18 @@ MAGE_EXPORT int mage_debug_chol_wait_schedule(int device, int n_pad, double* bui
     return chol_dag_wait_schedule(n_pad, build_ms) ? 1 : 0;
 }
 
+static mage_status debug_dense_solve(int device, int n, const double* A_colmajor, const double* b, double* x, int* ok, const int* tile_env);
+// The same with the skyline of A by tile rows (tile_env[R] = first tile column of tile row R that holds a non-zero; n_pad / 128 entries):
+// the task-graph schedule skips every tile left of it.  The caller vouches for the zeros (tests/test_chol_gpu.py compares with the dense solve).
+MAGE_EXPORT mage_status mage_debug_dense_solve_skyline(int device, int n, const double* A_colmajor, const double* b, double* x, int* ok, const int* tile_env)
+{
+    return debug_dense_solve(device, n, A_colmajor, b, x, ok, tile_env);
+}
 MAGE_EXPORT mage_status mage_debug_dense_solve(int device, int n, const double* A_colmajor, const double* b, double* x, int* ok)
+{
+    return debug_dense_solve(device, n, A_colmajor, b, x, ok, nullptr);
+}
+static mage_status debug_dense_solve(int device, int n, const double* A_colmajor, const double* b, double* x, int* ok, const int* tile_env)
 {
     return guarded([&]() -> mage_status {
         if (n <= 0 || !A_colmajor || !b || !x || !ok) return fail(MAGE_ERR_INVALID_ARGUMENT, "null argument or n <= 0");
@@ -1699,7 +1723,7 @@ MAGE_EXPORT mage_status mage_debug_dense_solve(int device, int n, const double* 
         chol_init_device();
         const int n_pad = std::max(CHOL_TILE, ((n + CHOL_TILE - 1) / CHOL_TILE) * CHOL_TILE);
         if (n_pad > CHOL_MAX_ORDER) return fail(MAGE_ERR_UNSUPPORTED, "order %d exceeds %d", n_pad, CHOL_MAX_ORDER);
-        (void)chol_dag_wait_schedule(n_pad, nullptr);          // (a test of the solver: the schedule this size has by default, not the one it starts with)
+        (void)chol_dag_wait_schedule(n_pad, nullptr, tile_env);          // (a test of the solver: the schedule this size has by default, not the one it starts with)
         // the lower triangle, padded with an identity block exactly as the bundle adjustment pads its reduced camera system
         std::vector<double> S((size_t)n_pad * n_pad, 0.0), y(n_pad, 0.0);
         for (int c = 0; c < n; ++c)
@@ -1714,6 +1738,7 @@ MAGE_EXPORT mage_status mage_debug_dense_solve(int device, int n, const double* 
             MAGE_TRY(dx.reserve(n_pad)); MAGE_TRY(dLinv.reserve(chol_workspace_doubles(n_pad))); MAGE_TRY(dok.reserve(2));
             MAGE_TRY(dsync.reserve(chol_sync_ints(n_pad)));
             CholWorkspace ws{ dLinv.p, dsync.p };
+            ws.env_host = tile_env;
             chol_factor_solve(dS.p, dy.p, dx.p, n_pad, ws, dok.p, st);
             std::vector<double> xs(n_pad);
             double okv[2] = { 0, 0 };
@@ -1741,6 +1766,7 @@ MAGE_EXPORT mage_status mage_ba_create(const mage_ba_params* params, mage_ba** o
         std::unique_ptr<mage_ba> h(new mage_ba());
         h->device = dev;
         h->points_fixed = params ? params->are_points_fixed != 0 : false;
+        { static const bool sky = std::getenv("MAGE_BA_SKYLINE") != nullptr; h->use_skyline = sky; }          // process-wide default of mage_ba_use_skyline
         MAGE_DEVICE_SCOPE(dev);
         MAGE_TRY(cached_stream_acquire(dev, &h->stream));
         MAGE_HIP(hipEventCreateWithFlags(&h->ev[3], hipEventDisableTiming));       // the scalar read-back's event; the others: ensure_events
@@ -2529,6 +2555,13 @@ MAGE_EXPORT mage_status mage_ba_enable_profiling(mage_ba* h, int enable)
     h->profiling_factor = enable == 2;
     h->prof.n_factorizations = 0; h->prof.factor_ms_total = 0; h->prof.schur_launches = 0; h->prof.schur_ms_total = 0;
     h->prof.linearize_launches = 0; h->prof.linearize_ms_total = 0; h->prof.update_launches = 0; h->prof.update_ms_total = 0;
+    return MAGE_OK;
+}
+
+MAGE_EXPORT mage_status mage_ba_use_skyline(mage_ba* h, int enable)
+{
+    if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+    if (h->use_skyline != (enable != 0)) { h->use_skyline = enable != 0; h->dirty = true; }          // (the skyline is read back with the structure)
     return MAGE_OK;
 }
 

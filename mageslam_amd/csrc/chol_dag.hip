@@ -602,16 +602,23 @@ inline int group_teams(int g, int n_cu)
     return 2 * n;
 }
 
-Schedule build_schedule(int nt, int n_cu, int gmax)
+// `env` (optional, nt entries): env[i] = the first tile column of tile row i that can hold a non-zero (the skyline of S; env[i] <= i).
+// Tiles left of it are zero and stay zero in the factor, so: no strips for them, tile (i, j) starts at panel max(env[i], env[j]) instead
+// of 0, y_i at panel env[i].  The launch's state then starts from an IMAGE (envelope_state) in which those panels count as applied; the
+// kernel and the checks are unchanged.  A dense system is env = all zeros.
+Schedule build_schedule(int nt, int n_cu, int gmax, const int* env = nullptr)
 {
     const SimCosts C;
     Schedule out;
+    auto env_of = [&](int i) { return env ? env[i] : 0; };
+    auto kstart = [&](int i, int j) { return std::max(env_of(i), env_of(j)); };
     int n_teams = 0, free_teams[N_LISTS];
     for (int g = 0; g < N_LISTS; ++g) { free_teams[g] = group_teams(g, n_cu); if (g < N_GROUPS) n_teams += free_teams[g]; }
     // quarter tiles from the first column whose trailing matrix no longer offers a half-tile task per team
     int& quarter_from = out.quarter_from;
     quarter_from = nt;
     for (int j = 1; j < nt; ++j) { const int m = nt - j; if (m * (m + 1) < n_teams) { quarter_from = j; break; } }
+    if (env) quarter_from = 1;          // a band offers a few tiles per column: quarters from the start
     const int ntri = nt * (nt + 1) / 2;
     std::vector<int> strip_cnt(ntri, 0), availc(ntri, 0), nxt(4 * ntri, 0), darr(nt, 0), yprog(nt, 0);
     std::vector<char> busy(4 * ntri, 0), queued(4 * ntri, 0), tile_done(ntri, 0), strips_out(ntri, 0), diag_out(nt, 0), y_out(nt, 0), rhs_busy(nt, 0);
@@ -644,6 +651,7 @@ Schedule build_schedule(int nt, int n_cu, int gmax)
         post(t, EV_SREADY, i, k, 0, near ? 12 : 4); post(t, EV_SREADY, i, k, 4, near ? 12 : 4);       // two tasks of four strips, a wavefront per strip (d = strips | 8 for the phased ones)
     };
     auto consider = [&](int i, int j, double t) {
+        if (j < env_of(i)) return;          // (a tile left of its row's envelope: nothing to do, ever)
         int& av = availc[tri(i, j)];
         while (av < j && strip_cnt[tri(i, av)] == NBLK && strip_cnt[tri(j, av)] == NBLK) ++av;
         const int lim = std::min(av, limit_of(i, j));
@@ -681,6 +689,21 @@ Schedule build_schedule(int nt, int n_cu, int gmax)
         while (k < i && k < ysol && strip_cnt[tri(i, k)] == NBLK) ++k;
         return k - yprog[i];
     };
+    if (env) {
+        // what the envelope makes moot counts as done from the start
+        for (int i = 1; i < nt; ++i) {
+            yprog[i] = std::min(env_of(i), i);
+            for (int k = 0; k < i; ++k) {
+                if (k < env_of(i)) { strip_cnt[tri(i, k)] = NBLK; strips_out[tri(i, k)] = 1; tile_done[tri(i, k)] = 1; }
+            }
+            for (int j = 1; j <= i; ++j) {
+                const int first = j < env_of(i) ? limit_of(i, j) : std::min(kstart(i, j), limit_of(i, j));
+                for (int q = 0; q < 4; ++q) nxt[4 * tri(i, j) + q] = std::max(first, 0);
+                if (i != j && tile_complete(i, j)) tile_done[tri(i, j)] = 1;
+            }
+            if (env_of(i) >= i) { darr[i] = NDIAG; diag_out[i] = 1; }          // a diagonal tile nothing left of it touches: no split panel
+        }
+    }
     start_potrf(0, 0.0);
     while (true) {
         bool progress = true;
@@ -777,6 +800,7 @@ Schedule build_schedule(int nt, int n_cu, int gmax)
                 case EV_POTRF: {
                     const int k = e.a;
                     fact = k + 1;
+                    if (k + 1 < nt && env && env_of(k + 1) >= k + 1) start_potrf(k + 1, now + C.gather);
                     if (!y_out[k] && yprog[k] >= k) { y_out[k] = 1; post(now + C.hop, EV_YREADY, k); }
                     for (int i = k + 1; i < nt; ++i) release_strips(i, k, now + C.hop);
                     break;
@@ -835,11 +859,30 @@ Schedule build_schedule(int nt, int n_cu, int gmax)
 // the task under it has its wait conditions met (the conditions the kernel polls) -- and require that all lists run out; the chain
 // advances when the nine arrivals of its next tile are in.  Also checks completeness: every strip, every panel of every unit, every split
 // panel, every rhs panel and solve exactly once and in range.
-bool check_schedule(const Schedule& sch, int nt)
+// The progress words as a launch finds them: zero for a dense system; with an envelope (build_schedule) every panel that multiplies a
+// structurally zero tile counts as applied.  One rule for the checker below and for the image the launch copies over its state words.
+void initial_progress(int nt, const int* env, int* stripc, int* usum, int* uprog, int* darr, int* yprog)
+{
+    if (!env) return;
+    for (int i = 1; i < nt; ++i) {
+        yprog[i] = std::min(env[i], i);
+        for (int k = 0; k < i && k < env[i]; ++k) stripc[tri(i, k)] = NBLK;
+        for (int j = std::max(env[i], 1); j <= i; ++j) {
+            const int limit = i == j ? j - 1 : j, first = std::max(0, std::min(std::max(env[i], env[j]), limit)), units = tile_units(i, j, 0);
+            for (int q = 0; q < 4; ++q) uprog[4 * tri(i, j) + q] = first;
+            usum[tri(i, j)] = units * first;
+        }
+        if (env[i] >= i) darr[i] = NDIAG;
+    }
+}
+
+bool check_schedule(const Schedule& sch, int nt, const int* env = nullptr)
 {
     const int qf = sch.quarter_from, ntri = nt * (nt + 1) / 2;
     std::vector<int> stripc(ntri, 0), usum(ntri, 0), uprog(4 * ntri, 0), darr(nt, 0), yprog(nt, 0);
+    initial_progress(nt, env, stripc.data(), usum.data(), uprog.data(), darr.data(), yprog.data());
     int fact = 1, ysol = 0;          // potrf(0) depends on nothing
+    while (fact < nt && darr[fact] == NDIAG) ++fact;          // (... nor does a diagonal tile the envelope cuts off from everything left of it)
     size_t cur[N_LISTS] = {};
     bool moved = true;
     while (moved) {
@@ -896,12 +939,27 @@ bool check_schedule(const Schedule& sch, int nt)
     for (int i = 1; i < nt; ++i) {
         if (yprog[i] != i) return false;
         for (int j = 0; j < i; ++j) if (stripc[tri(i, j)] != NBLK) return false;
-        for (int j = 1; j <= i; ++j) if (usum[tri(i, j)] != tile_units(i, j, qf) * (i == j ? j - 1 : j)) return false;
+        for (int j = env ? std::max(env[i], 1) : 1; j <= i; ++j) if (usum[tri(i, j)] != tile_units(i, j, qf) * (i == j ? j - 1 : j)) return false;
     }
     return true;
 }
 
-struct DagSchedule { unsigned long long* d_tasks = nullptr; int n_tasks = 0, quarter_from = 0, n_cu = 0, off[N_LISTS] = {}, len[N_LISTS] = {}; bool ok = false; unsigned long long last_use = 0; };
+struct DagSchedule {
+    unsigned long long* d_tasks = nullptr;
+    int* d_image = nullptr;          // with an envelope: the state words a launch starts from (copied over them instead of the zero-fill)
+    int* d_kmax = nullptr;           // ... and per tile column the last tile row that can hold a non-zero (the backward solve stops there)
+    int n_tasks = 0, quarter_from = 0, n_cu = 0, off[N_LISTS] = {}, len[N_LISTS] = {};
+    bool ok = false;
+    unsigned long long last_use = 0;
+};
+typedef std::tuple<int, int, unsigned long long> SchedKey;          // (device, tile columns, hash of the envelope: 0 = dense)
+unsigned long long env_hash(const int* env, int nt)
+{
+    if (!env) return 0;
+    unsigned long long h = 1469598103934665603ull;
+    for (int i = 0; i < nt; ++i) h = (h ^ (unsigned long long)(unsigned)env[i]) * 1099511628211ull;
+    return h | 1ull;
+}
 // The lists of a system size are built ONCE per (device, tile count) -- and not by the thread that asks for them: the simulation takes
 // 19 ms at 47 tile columns and 140 ms at 94, which the first factorisation after a loop closure (a new map size:
 // Tasks/LoopClosureWorker.cpp:163-208 in the reference) would pay before its first launch.  A worker thread builds and checks them;
@@ -914,11 +972,12 @@ struct SchedJob {
     bool done = false, valid = false;
     int quarter_from = 0, n_cu = 0, off[N_LISTS] = {}, len[N_LISTS] = {};
     std::vector<unsigned long long> flat;
+    std::vector<int> env, image, kmax;          // (empty: dense)
     double build_ms = 0;
 };
 std::mutex g_sched_mutex;
-std::map<std::pair<int, int>, DagSchedule> g_sched;      // (device, nt): uploaded
-std::map<std::pair<int, int>, std::shared_ptr<SchedJob>> g_jobs;      // being built (or built and not yet uploaded)
+std::map<SchedKey, DagSchedule> g_sched;                  // uploaded
+std::map<SchedKey, std::shared_ptr<SchedJob>> g_jobs;    // being built (or built and not yet uploaded)
 std::map<int, int> g_dev_cu;                             // compute units per device (chol_dag_init_device), under g_sched_mutex
 unsigned long long g_use_clock = 0;
 std::atomic<double> g_last_build_ms{ 0.0 };
@@ -945,25 +1004,34 @@ int device_cus(int dev)          // (g_sched_mutex held)
     return it == g_dev_cu.end() ? 0 : it->second;
 }
 
-// (g_sched_mutex held) the job that builds the lists of (dev, nt), started if there is none
-std::shared_ptr<SchedJob> job_for(int dev, int nt, int n_cu)
+// (g_sched_mutex held) the job that builds the lists of a key, started if there is none
+std::shared_ptr<SchedJob> job_for(const SchedKey& key, int nt, int n_cu, const int* env)
 {
-    auto it = g_jobs.find({ dev, nt });
+    auto it = g_jobs.find(key);
     if (it != g_jobs.end()) return it->second;
     auto job = std::make_shared<SchedJob>();
     job->n_cu = n_cu;
-    g_jobs[{ dev, nt }] = job;
+    if (env) job->env.assign(env, env + nt);
+    g_jobs[key] = job;
     const int gmax = dag_fuse_max();
     std::thread([job, nt, n_cu, gmax] {
         const auto t0 = std::chrono::steady_clock::now();
-        const Schedule sch = build_schedule(nt, n_cu, gmax);
+        const int* e = job->env.empty() ? nullptr : job->env.data();
+        const Schedule sch = build_schedule(nt, n_cu, gmax, e);
         std::vector<unsigned long long> flat;
         int off[N_LISTS], len[N_LISTS];
         for (int g = 0; g < N_LISTS; ++g) { off[g] = (int)flat.size(); len[g] = (int)sch.lists[g].size(); flat.insert(flat.end(), sch.lists[g].begin(), sch.lists[g].end()); }
-        const bool valid = check_schedule(sch, nt);
+        const bool valid = check_schedule(sch, nt, e);
+        std::vector<int> image, kmax;
+        if (e) {
+            image.assign((size_t)dag_state_ints(nt), 0);
+            initial_progress(nt, e, image.data() + d_stripc(nt), image.data() + d_usum(nt), image.data() + d_uprog(nt), image.data() + D_DARR, image.data() + d_yprog(nt));
+            kmax.assign(nt, 0);
+            for (int j = 0; j < nt; ++j) { kmax[j] = j; for (int i = j + 1; i < nt; ++i) if (e[i] <= j) kmax[j] = i; }
+        }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         std::lock_guard<std::mutex> lock(job->m);
-        job->flat.swap(flat); job->quarter_from = sch.quarter_from; job->valid = valid; job->build_ms = ms;
+        job->flat.swap(flat); job->image.swap(image); job->kmax.swap(kmax); job->quarter_from = sch.quarter_from; job->valid = valid; job->build_ms = ms;
         for (int g = 0; g < N_LISTS; ++g) { job->off[g] = off[g]; job->len[g] = len[g]; }
         job->done = true;
         job->cv.notify_all();
@@ -972,16 +1040,17 @@ std::shared_ptr<SchedJob> job_for(int dev, int nt, int n_cu)
 }
 
 // The uploaded lists of (current device, nt); nullptr while they are being built (wait = false) or when they cannot be had.
-const DagSchedule* get_schedule(int nt, bool wait)
+const DagSchedule* get_schedule(int nt, bool wait, const int* env = nullptr)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    const SchedKey key{ dev, nt, env_hash(env, nt) };
     std::unique_lock<std::mutex> lock(g_sched_mutex);
-    auto it = g_sched.find({ dev, nt });
+    auto it = g_sched.find(key);
     if (it == g_sched.end()) {
         const int n_cu = device_cus(dev);
         if (n_cu <= 0) return nullptr;
-        std::shared_ptr<SchedJob> job = job_for(dev, nt, n_cu);
+        std::shared_ptr<SchedJob> job = job_for(key, nt, n_cu, env);
         {
             std::unique_lock<std::mutex> jl(job->m);
             if (!job->done) {
@@ -990,7 +1059,7 @@ const DagSchedule* get_schedule(int nt, bool wait)
                 job->cv.wait(jl, [&] { return job->done; });
                 jl.unlock();
                 lock.lock();
-                if ((it = g_sched.find({ dev, nt })) != g_sched.end()) { it->second.last_use = ++g_use_clock; return it->second.ok ? &it->second : nullptr; }
+                if ((it = g_sched.find(key)) != g_sched.end()) { it->second.last_use = ++g_use_clock; return it->second.ok ? &it->second : nullptr; }
                 jl.lock();
             }
             DagSchedule s;
@@ -998,7 +1067,17 @@ const DagSchedule* get_schedule(int nt, bool wait)
             for (int g = 0; g < N_LISTS; ++g) { s.off[g] = job->off[g]; s.len[g] = job->len[g]; }
             if (job->valid && hipMalloc(&s.d_tasks, job->flat.size() * sizeof(unsigned long long)) == hipSuccess) {
                 if (hipMemcpy(s.d_tasks, job->flat.data(), job->flat.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) == hipSuccess) { s.n_tasks = (int)job->flat.size(); s.ok = true; }
-                else { (void)hipFree(s.d_tasks); s.d_tasks = nullptr; }
+                if (s.ok && !job->image.empty()) {
+                    s.ok = hipMalloc(&s.d_image, job->image.size() * sizeof(int)) == hipSuccess && hipMalloc(&s.d_kmax, job->kmax.size() * sizeof(int)) == hipSuccess &&
+                           hipMemcpy(s.d_image, job->image.data(), job->image.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+                           hipMemcpy(s.d_kmax, job->kmax.data(), job->kmax.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+                }
+                if (!s.ok) {
+                    if (s.d_tasks) (void)hipFree(s.d_tasks);
+                    if (s.d_image) (void)hipFree(s.d_image);
+                    if (s.d_kmax) (void)hipFree(s.d_kmax);
+                    s.d_tasks = nullptr; s.d_image = nullptr; s.d_kmax = nullptr;
+                }
             }
             if (!s.ok) (void)hipGetLastError();
             g_last_build_ms.store(job->build_ms);
@@ -1008,11 +1087,13 @@ const DagSchedule* get_schedule(int nt, bool wait)
                 auto victim = g_sched.begin();
                 for (auto c = g_sched.begin(); c != g_sched.end(); ++c) if (c->second.last_use < victim->second.last_use) victim = c;
                 if (victim->second.d_tasks) (void)hipFree(victim->second.d_tasks);
+                if (victim->second.d_image) (void)hipFree(victim->second.d_image);
+                if (victim->second.d_kmax) (void)hipFree(victim->second.d_kmax);
                 g_sched.erase(victim);
             }
-            it = g_sched.emplace(std::make_pair(dev, nt), s).first;
+            it = g_sched.emplace(key, s).first;
         }
-        g_jobs.erase({ dev, nt });
+        g_jobs.erase(key);
     }
     it->second.last_use = ++g_use_clock;
     return it->second.ok ? &it->second : nullptr;
@@ -1033,12 +1114,13 @@ void chol_dag_init_device(int n_cu)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DAG_LDS_BYTES);
 }
 
-bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorkspace& ws, double* ok, double* stall, hipStream_t st)
+bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorkspace& ws, double* ok, double* stall, hipStream_t st, const int** kmax_dev)
 {
     const int nt = n_pad / TILE;
+    if (kmax_dev) *kmax_dev = nullptr;
     if (nt < dag_min_tiles() || nt > 255) return false;
     static const bool sync_build = std::getenv("MAGE_CHOL_DAG_SYNC_BUILD") != nullptr;      // (tests that must see THIS schedule from the first factorisation on)
-    const DagSchedule* s = get_schedule(nt, sync_build);
+    const DagSchedule* s = get_schedule(nt, sync_build, ws.env_host);
     if (!s || s->n_cu < DAG_EXPRESS_WGS + 1 + 2 * N_GROUPS) return false;
     int* state = ws.sync + 8;
     // Two of these launches from two streams of one process must not overlap: each wants every compute unit (one workgroup per unit),
@@ -1060,7 +1142,9 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
         if (!turn.recorded) (void)hipGetLastError();
     }
     if (turn.several && turn.recorded && turn.last != st && hipStreamWaitEvent(st, turn.ev, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (hipMemsetAsync(state, 0, (size_t)dag_state_ints(nt) * sizeof(int), st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    // the state words: zero -- or, with an envelope, the image in which every panel of a structurally zero tile counts as applied
+    if ((s->d_image ? hipMemcpyAsync(state, s->d_image, (size_t)dag_state_ints(nt) * sizeof(int), hipMemcpyDeviceToDevice, st)
+                    : hipMemsetAsync(state, 0, (size_t)dag_state_ints(nt) * sizeof(int), st)) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (g_inject_stalls.load(std::memory_order_relaxed) > 0 && g_inject_stalls.fetch_sub(1) > 0) (void)hipMemsetAsync(state + D_INJECT, 1, sizeof(int), st);
     DagArgs a;
     a.S = S; a.y = y; a.x = x; a.Linv = ws.Linv; a.Lpub = ws.Linv + (size_t)nt * NBLK * NB * NB; a.part = a.Lpub + (size_t)nt * LPUB_TILE_DOUBLES; a.ok = ok; a.stall = stall;
@@ -1073,11 +1157,12 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
         if (!turn.recorded) (void)hipGetLastError();
     }
     turn.last = st;
+    if (kmax_dev) *kmax_dev = s->d_kmax;
     return true;
 }
 
 // the order of a system is known (structure build): start building its lists now, if this size is the task graph's at all
-void chol_dag_prefetch(int n_pad)
+void chol_dag_prefetch(int n_pad, const int* env_host)
 {
     const int nt = n_pad / TILE;
     if (nt < dag_min_tiles() || nt > 255) return;
@@ -1085,15 +1170,16 @@ void chol_dag_prefetch(int n_pad)
     if (hipGetDevice(&dev) != hipSuccess) return;
     std::lock_guard<std::mutex> lock(g_sched_mutex);
     const int n_cu = device_cus(dev);
-    if (n_cu > 0 && g_sched.find({ dev, nt }) == g_sched.end()) (void)job_for(dev, nt, n_cu);
+    const SchedKey key{ dev, nt, env_hash(env_host, nt) };
+    if (n_cu > 0 && g_sched.find(key) == g_sched.end()) (void)job_for(key, nt, n_cu, env_host);
 }
 
 // blocks until the lists of this order are on the device (true) or cannot be had (false); how long the last build took on its thread
-bool chol_dag_wait_schedule(int n_pad, double* build_ms)
+bool chol_dag_wait_schedule(int n_pad, double* build_ms, const int* env_host)
 {
     const int nt = n_pad / TILE;
     bool ok = false;
-    if (nt >= dag_min_tiles() && nt <= 255) ok = get_schedule(nt, true) != nullptr;
+    if (nt >= dag_min_tiles() && nt <= 255) ok = get_schedule(nt, true, env_host) != nullptr;
     if (build_ms) *build_ms = g_last_build_ms.load();
     return ok;
 }
@@ -1126,3 +1212,20 @@ MAGE_EXPORT int mage_debug_chol_schedule(int nt, int n_cu, int fuse_max, unsigne
     }
     return mage::check_schedule(sch, nt) ? n : -n;
 }
+
+// The same for a system with an envelope (env[i] = first tile column of tile row i that can hold a non-zero): the lists skip every tile
+// left of it; negative when the checker -- started from the envelope's initial progress -- rejects them.
+MAGE_EXPORT int mage_debug_chol_schedule_env(int nt, int n_cu, int fuse_max, const int* env, unsigned long long* out, int cap, int* quarter_from, int* group_len)
+{
+    if (nt < 2 || nt > 255 || !env || n_cu < mage::DAG_EXPRESS_WGS + 1 + 2 * mage::N_GROUPS) return 0;
+    for (int i = 0; i < nt; ++i) if (env[i] < 0 || env[i] > i) return 0;
+    const mage::Schedule sch = mage::build_schedule(nt, n_cu, fuse_max > 0 ? fuse_max : 8, env);
+    if (quarter_from) *quarter_from = sch.quarter_from;
+    int n = 0;
+    for (int g = 0; g < mage::N_LISTS; ++g) {
+        if (group_len) group_len[g] = (int)sch.lists[g].size();
+        for (unsigned long long w : sch.lists[g]) { if (n < cap) out[n] = w; ++n; }
+    }
+    return mage::check_schedule(sch, nt, env) ? n : -n;
+}
+

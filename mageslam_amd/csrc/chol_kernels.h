@@ -11,6 +11,9 @@ struct CholWorkspace {
     int* sync;         // chol_sync_ints(n_pad) ints: [0] arrival counter of the split diagonal tile, [1] last tile column factored, [2] parts of first-column tiles written, [4] phased strips: block columns of the tile being factored that are published (8 tile + column); from [8] on: the task-graph launch's state (chol_dag.h)
     long long* dbg = nullptr;   // development only: 4 x nt time stamps of the backward solve (tools/chol_test.hip, CHOL_DBG=1); a -DDAG_TRACE build hands it to the task-graph launch instead (tools/dag_trace.py)
     double* stall = nullptr;    // device double: set to 1.0 when a bounded cross-workgroup wait timed out (a device fault, not a property of S)
+    const int* env_host = nullptr;   // optional, HOST array of n_pad / CHOL_TILE ints: env[i] = first tile column of tile row i that can hold a non-zero (env[i] <= i).
+                                     // The task-graph schedule then skips every tile left of it (they are zero and stay zero in the factor: the same numbers, less work);
+                                     // the column-by-column schedules ignore it
 };
 size_t chol_workspace_doubles(int n_pad);
 size_t chol_sync_ints(int n_pad);      // hand-off counters of the launches + the state words of the task-graph launch

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
 // hop before they are needed.  Each has two hops per tile.  The helper's sums join the closer's just before its last product.
 __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict__ S, const double* __restrict__ y, double* __restrict__ x,
                                                         int ld, int nt, const double* __restrict__ Linv, double* __restrict__ stall, long long* __restrict__ dbg,
-                                                        double* __restrict__ part)
+                                                        double* __restrict__ part, const int* __restrict__ kmax)
 {
     extern __shared__ double sm[];
     constexpr int LDB = TILE + 2;
@@ -322,9 +322,10 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = nt - 1 - (int)(blockIdx.x >> 1);              // the last tile column is dispatched first
     const int closer = (int)(blockIdx.x & 1);                   // (the helper first: its closer waits for it)
-    const int k_first = nt - 1 - ((nt - 1 - (j + 2 - closer)) & 1);       // the largest k <= nt - 1 of this role's parity (k = j + 2 - closer, + 2, ...)
+    const int k_last = kmax ? kmax[j] : nt - 1;                 // the last tile row of this column inside the skyline (a dense system: every row)
+    const int k_first = k_last - ((k_last - (j + 2 - closer)) & 1);       // the largest k <= k_last of this role's parity (k = j + 2 - closer, + 2, ...)
     const bool has_work = k_first > j;
-    if (!closer && !has_work) return;                           // no arrival for the helper (the closer knows: nt - 1 - j < 2)
+    if (!closer && !has_work) return;                           // no arrival for the helper (the closer knows: k_last - j < 2)
     if (tid < TILE) ys[tid] = closer ? y[(size_t)j * TILE + tid] : 0.0;
     // thread (c, half) owns rows half * 64 .. +63 of column c of the current off-diagonal tile, and columns half * 64 .. of row c of the inverse
     const int c = tid >> 1, half = tid & 1;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
         if (k == j + 1 && dbg && tid == 0) dbg[j * 4 + 2] = wall_clock64();
         // before the closer's last arrival: the helper's sums (its last tile is one hop older: they are here or about to be, and this
         // wait is the one that has to be sat out anyway)
-        if (closer && k == j + 1 && nt - 1 - j >= 2 && tid < TILE) ys[tid] += poll_values(part + (size_t)j * TILE);
+        if (closer && k == j + 1 && k_last - j >= 2 && tid < TILE) ys[tid] += poll_values(part + (size_t)j * TILE);
         if (tid < TILE) xk[tid] = poll_values(x + (size_t)k * TILE);
         __syncthreads();
         double a0 = 0, a1 = 0;
@@ -578,13 +579,14 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
     static const bool merge_env_off = std::getenv("MAGE_CHOL_NO_MERGED_TRSM") != nullptr;      // (tests: the fall-back schedule on demand)
     const bool stalled_before = g_merge_disabled.load(std::memory_order_relaxed);
     const bool merge_off = merge_env_off || stalled_before;
-    if (!column_launches && !stalled_before && chol_dag_factor(S, y, x, n_pad, ws, ok, stall, st)) {
+    const int* kmax_dev = nullptr;
+    if (!column_launches && !stalled_before && chol_dag_factor(S, y, x, n_pad, ws, ok, stall, st, &kmax_dev)) {
 #ifdef DAG_TRACE
         long long* const bs_dbg = nullptr;            // (the trace build hands ws.dbg to the task-graph launch)
 #else
         long long* const bs_dbg = ws.dbg;
 #endif
-        hipLaunchKernelGGL(k_bsolve_persist, dim3(2 * nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, stall, bs_dbg, bs_part);
+        hipLaunchKernelGGL(k_bsolve_persist, dim3(2 * nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, stall, bs_dbg, bs_part, kmax_dev);
         poison_on_launch_error(ok, stall, st);
         return;
     }
@@ -617,7 +619,7 @@ void chol_factor_solve(double* S, double* y, double* x, int n_pad, const CholWor
         if (!merged) hipLaunchKernelGGL(k_trsm_panel_1w, dim3((m - 1) * NBLK + 1), dim3(64), 0, st, S, y, n_pad, k + 1, nt, Linv_next, flag);
     }
     // backward substitution: one persistent launch (needs every workgroup resident: nt <= 256 compute units)
-    hipLaunchKernelGGL(k_bsolve_persist, dim3(2 * nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, stall, ws.dbg, bs_part);
+    hipLaunchKernelGGL(k_bsolve_persist, dim3(2 * nt), dim3(256), lds_panel, st, S, y, x, n_pad, nt, ws.Linv, stall, ws.dbg, bs_part, static_cast<const int*>(nullptr));
     poison_on_launch_error(ok, stall, st);
 }
 

@@ -164,3 +164,66 @@ def test_first_factorisations_of_a_new_size_fall_back_and_agree():
     assert a["task_graph_size"] and a["tile_columns"] == 47
     assert a["mse_first_second"] == s["mse_first_second"]
 
+
+
+def dense_solve_skyline(A, b, env):
+    L = lib()
+    L.mage_debug_dense_solve_skyline.argtypes = [C.c_int, C.c_int, np.ctypeslib.ndpointer(np.float64, flags="F_CONTIGUOUS"), np.ctypeslib.ndpointer(np.float64),
+                                                 np.ctypeslib.ndpointer(np.float64), C.POINTER(C.c_int), np.ctypeslib.ndpointer(np.int32)]
+    n = len(b)
+    x = np.zeros(n); ok = C.c_int(-1)
+    check(L.mage_debug_dense_solve_skyline(-1, n, np.asfortranarray(A), np.ascontiguousarray(b), x, C.byref(ok), np.ascontiguousarray(env, dtype=np.int32)))
+    return x, ok.value
+
+
+@pytest.mark.parametrize("n,kind", [(1100, "band"), (2999, "band"), (2999, "ragged"), (4500, "arrow"), (1408, "dense")])
+def test_skyline_schedule_gives_the_dense_solution_to_the_bit(n, kind):
+    """mage_ba_use_skyline's solve: the task-graph schedule built from the matrix's skyline by tile rows never touches a tile left of it --
+    tiles that are zero and stay zero in the factor -- so the solution has the bits of the dense schedule's.  Band, ragged (a different
+    first tile per row), arrow (a few late rows reach back to column 0: the loop-closure shape) and the dense envelope itself."""
+    rng = np.random.default_rng(7000 + n)
+    nt = (n + 127) // 128
+    if kind == "band":
+        env = np.maximum(0, np.arange(nt) - 2)
+    elif kind == "ragged":
+        env = np.array([int(rng.integers(max(0, i - 4), i + 1)) for i in range(nt)])
+    elif kind == "arrow":
+        env = np.maximum(0, np.arange(nt) - 1); env[-3:] = 0
+    else:
+        env = np.zeros(nt, dtype=int)
+    env[0] = 0
+    # an SPD matrix whose non-zeros lie inside the skyline: a masked random matrix made diagonally dominant
+    M = rng.standard_normal((n, n)) * 0.05
+    M = np.tril(M)
+    rows_tile = np.arange(n) // 128
+    first_col = env[rows_tile] * 128
+    M[np.arange(n)[None, :] < first_col[:, None]] = 0.0
+    A = M + M.T
+    A[np.diag_indices(n)] = np.abs(A).sum(axis=1) + 1.0
+    b = rng.standard_normal(n)
+    x_dense, ok_d = dense_solve(A, b)
+    x_sky, ok_s = dense_solve_skyline(A, b, env)
+    assert ok_d == 1 and ok_s == 1
+    assert np.array_equal(x_dense, x_sky)
+    assert np.linalg.norm(A @ x_sky - b) <= 1e-12 * np.linalg.norm(b) * n
+
+
+def test_bundle_adjustment_with_the_skyline_solve_is_bit_identical():
+    """A 300-camera trajectory map (1 800 rows: 15 tile columns, block-banded reduced system) stepped with and without
+    mage_ba_use_skyline: the same errors, outlier lists and state to the bit."""
+    from mageslam_amd import scene
+    from mageslam_amd.bundler import BundlerLib, load_scene
+    s = scene.make_scene(n_cams=300, n_pts=9000, n_obs=90000, seed=0x5EED0B31, outlier_frac=0.01)
+    res = []
+    for sky in (False, True):
+        b = BundlerLib(False)
+        b.use_skyline(sky)
+        load_scene(b, s, bulk=True)
+        outs = []
+        for hub, thr in [([1.8], 25.0), ([0.9, 0.9], 16.0), ([0.9], 9.0)]:
+            o = []
+            outs.append((float(b.StepBundleAdjustment(hub, thr, o)), sorted(o)))
+        res.append((outs, b.poses_f64().copy(), b.points_f64().copy()))
+        b.close()
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])

@@ -123,3 +123,62 @@ def test_groups_carry_equal_shares():
 
 def test_schedule_is_deterministic():
     assert schedule(24, 256, 8) == schedule(24, 256, 8)
+
+
+def schedule_env(nt, env, n_cu=256, fuse=8):
+    L = _lib.lib()
+    f = L.mage_debug_chol_schedule_env
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    out = np.zeros(600000, dtype=np.uint64)
+    qf = C.c_int(0)
+    glen = (C.c_int * 9)()
+    e = np.ascontiguousarray(env, dtype=np.int32)
+    n = f(nt, n_cu, fuse, e.ctypes.data, out.ctypes.data, out.size, C.byref(qf), glen)
+    w = out[:abs(n)].astype(np.uint64)
+    cols = [(w >> np.uint64(s)) & np.uint64(0xff) for s in (0, 8, 16, 24, 32, 40)]
+    return n, [tuple(int(c[i]) for c in cols) for i in range(abs(n))]
+
+
+@pytest.mark.parametrize("nt,width", [(47, 2), (47, 0), (24, 5), (94, 3), (13, 12)])
+def test_skyline_lists_touch_no_tile_left_of_the_envelope(nt, width):
+    """mage_ba_use_skyline: the lists built from a skyline (env[i] = first tile column of tile row i that can hold a non-zero) pass the
+    library's checker started from the envelope's initial progress, never name a tile or a panel left of the envelope, and still solve
+    every strip, apply every panel and finish every rhs row inside it exactly once."""
+    env = np.maximum(0, np.arange(nt) - width)
+    n, tasks = schedule_env(nt, env)
+    assert n > 0, "the library's own checker rejected the skyline lists"
+    strips, panels = {}, {}
+    for typ, i, j, u, k0, nk in tasks:
+        if typ == T_STRIPS:
+            assert j >= env[i], "strips of a tile left of the envelope"
+            strips[(i, j)] = strips.get((i, j), 0) + nk
+        elif typ in (T_HALF, T_QUARTER):
+            assert j >= env[i] and k0 >= max(env[i], env[j]), "a panel that multiplies a structurally zero tile"
+            for q in ([u] if typ == T_QUARTER else ([3] if (i == j and u == 1) else [2 * u, 2 * u + 1])):
+                for k in range(k0, k0 + nk):
+                    assert (i, j, q, k) not in panels
+                    panels[(i, j, q, k)] = 1
+        elif typ == T_RHS:
+            assert k0 >= env[i]
+    for i in range(1, nt):
+        for j in range(env[i], i):
+            assert strips.get((i, j), 0) == 8
+        for j in range(max(env[i], 1), i + 1):
+            for q in range(4):
+                if i == j and q == 2:
+                    continue
+                for k in range(max(env[i], env[j]), (j - 1 if i == j else j)):
+                    assert (i, j, q, k) in panels, (i, j, q, k)
+    dense_n, _ = schedule_env(nt, np.zeros(nt, dtype=np.int32))
+    assert width >= nt - 1 or n < dense_n
+
+
+def test_random_skylines_are_accepted():
+    rng = np.random.default_rng(11)
+    for _ in range(25):
+        nt = int(rng.integers(8, 70))
+        env = np.array([int(rng.integers(0, i + 1)) for i in range(nt)])
+        n, _ = schedule_env(nt, env, n_cu=int(rng.choice([64, 128, 256, 304])))
+        assert n > 0
+

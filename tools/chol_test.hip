@@ -1,5 +1,6 @@
 // Standalone check + timing of chol_factor_solve (no Python): SPD matrix, residual, per-run time.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -9,6 +10,7 @@
 #include "../mageslam_amd/csrc/chol_dag.h"
 using namespace mage;
 extern "C" int mage_debug_chol_schedule(int nt, int n_cu, int fuse_max, unsigned long long* out, int cap, int* quarter_from, int* group_len);
+extern "C" int mage_debug_chol_schedule_env(int nt, int n_cu, int fuse_max, const int* env, unsigned long long* out, int cap, int* quarter_from, int* group_len);
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
 int main(int argc, char** argv)
@@ -35,11 +37,19 @@ int main(int argc, char** argv)
         hipStream_t st; CK(hipStreamCreate(&st));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         int* dq; CK(hipMalloc(&dq, sizeof(int) * chol_sync_ints(n)));
+        // CHOL_ENV=1: the skyline of the test matrix (band 200) by tile rows: the task-graph schedule skips the tiles left of it
+        std::vector<int> envh;
+        if (getenv("CHOL_ENV") && n >= 1024) {
+            envh.assign(n / 128, 0);
+            for (int R = 0; R < n / 128; ++R) { const int first_col = std::max(0, R * 128 - (bw - 1)); envh[R] = first_col / 128; }
+        }
 #ifdef DAG_TRACE
         // trace build: per task four stamps + two per tile column, written by the task-graph launch (dumped below)
         std::vector<unsigned long long> tasks(600000);
         int qf = 0;
-        const int n_tasks = mage_debug_chol_schedule(n / 128, 256, getenv("MAGE_CHOL_DAG_FUSE") ? atoi(getenv("MAGE_CHOL_DAG_FUSE")) : 8, tasks.data(), (int)tasks.size(), &qf, nullptr);
+        const int fuse = getenv("MAGE_CHOL_DAG_FUSE") ? atoi(getenv("MAGE_CHOL_DAG_FUSE")) : 8;
+        const int n_tasks = envh.empty() ? mage_debug_chol_schedule(n / 128, 256, fuse, tasks.data(), (int)tasks.size(), &qf, nullptr)
+                                         : mage_debug_chol_schedule_env(n / 128, 256, fuse, envh.data(), tasks.data(), (int)tasks.size(), &qf, nullptr);
         const size_t n_stamps = 8 * (size_t)(n_tasks > 0 ? n_tasks : 0) + 2 * (n / 128) + 32;
         long long* ddbg; CK(hipMalloc(&ddbg, sizeof(long long) * n_stamps));
         CholWorkspace ws{ dws, dq, ddbg };
@@ -47,7 +57,8 @@ int main(int argc, char** argv)
         long long* ddbg; CK(hipMalloc(&ddbg, sizeof(long long) * 4 * (n / 128 + 1)));
         CholWorkspace ws{ dws, dq, getenv("CHOL_DBG") ? ddbg : nullptr };
 #endif
-        { double bms = 0; const bool dag = chol_dag_wait_schedule(n, &bms); if (dag) printf("  task lists of %d tile columns built in %.1f ms (worker thread)\n", n / 128, bms); }
+        if (!envh.empty()) ws.env_host = envh.data();
+        { double bms = 0; const bool dag = chol_dag_wait_schedule(n, &bms, ws.env_host); if (dag) printf("  task lists of %d tile columns built in %.1f ms (worker thread)\n", n / 128, bms); }
         float best = 1e30f;
         for (int r = 0; r < reps; ++r) {
             CK(hipMemcpyAsync(dS, dS0, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
