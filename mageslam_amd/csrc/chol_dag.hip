@@ -116,7 +116,7 @@ struct DagArgs {
     int* st;                               // state words
     const unsigned long long* tasks;       // the eight lists behind each other
     int list_off[N_LISTS], list_len[N_LISTS];
-    int ld, nt, n_tasks, quarter_from;
+    int ld, nt, n_tasks, quarter_from, express_wgs;
     long long* trace;                      // development (tools/chol_test.hip built with -DDAG_TRACE): per task 4 stamps of the 100 MHz clock, behind them 2 per tile column of the chain
 };
 
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagArgs a)
     // ================= worker teams =================
     // workgroups 1 .. DAG_EXPRESS_WGS serve the express list (the small tasks next to the chain must never queue behind a long update),
     // the others the list of their group
-    const int team = wave >> 2, group = blockIdx.x <= DAG_EXPRESS_WGS ? N_GROUPS : (int)(blockIdx.x & (N_GROUPS - 1));
+    const int team = wave >> 2, group = (int)blockIdx.x <= a.express_wgs ? N_GROUPS : (int)(blockIdx.x & (N_GROUPS - 1));
     Team t;
     double* const Lsh = sm + team * (LSH_DOUBLES + ISH_DOUBLES);                     // L_kk parked for the strips: sub-diagonal blocks, then inverses
     double* const Ish = Lsh + LSH_DOUBLES;
@@ -590,15 +590,24 @@ enum { EV_SREADY, EV_SDONE, EV_DREADY, EV_DDONE, EV_UDONE, EV_POTRF, EV_YREADY, 
 
 struct Schedule {
     std::vector<unsigned long long> lists[N_LISTS];
-    int quarter_from = 0;
+    int quarter_from = 0, express_wgs = DAG_EXPRESS_WGS;
 };
+// Workgroups on the express list.  Dense systems: ten (8 ... 24 measured the same, round 6).  With an envelope nearly every task sits next to
+// the chain and a team that holds a task it waits for is what makes a hand-off one poll: 10 / 16 / 32 / 48 / 64 workgroups -> 1.84 / 1.65 /
+// 1.63 / 1.59 / 1.57 ms at 47 tile columns (twenty teams were all holding tasks all the time, the list's later entries waited for a free one)
+inline int express_wgs_for(bool envelope, int n_cu)
+{
+    static const int env_wgs = [] { const char* e = std::getenv("MAGE_CHOL_DAG_ENV_EXPRESS_WGS"); return e ? std::max(4, std::min(64, std::atoi(e))) : 48; }();
+    static const int dense_wgs = [] { const char* e = std::getenv("MAGE_CHOL_DAG_EXPRESS_WGS"); return e ? std::max(4, std::min(64, std::atoi(e))) : DAG_EXPRESS_WGS; }();
+    return std::min(envelope ? env_wgs : dense_wgs, std::max(4, (n_cu - 1 - 2 * N_GROUPS) / 4));
+}
 
 // teams of group g when n_cu workgroups are launched (workgroup b belongs to group b % 8; workgroup 0 is the chain)
-inline int group_teams(int g, int n_cu)
+inline int group_teams(int g, int n_cu, int express_wgs)
 {
-    if (g == N_GROUPS) return 2 * DAG_EXPRESS_WGS;
+    if (g == N_GROUPS) return 2 * express_wgs;
     int n = 0;
-    for (int b = DAG_EXPRESS_WGS + 1; b < n_cu; ++b) n += (b & (N_GROUPS - 1)) == g;
+    for (int b = express_wgs + 1; b < n_cu; ++b) n += (b & (N_GROUPS - 1)) == g;
     return 2 * n;
 }
 
@@ -613,7 +622,10 @@ Schedule build_schedule(int nt, int n_cu, int gmax, const int* env = nullptr)
     auto env_of = [&](int i) { return env ? env[i] : 0; };
     auto kstart = [&](int i, int j) { return std::max(env_of(i), env_of(j)); };
     int n_teams = 0, free_teams[N_LISTS];
-    for (int g = 0; g < N_LISTS; ++g) { free_teams[g] = group_teams(g, n_cu); if (g < N_GROUPS) n_teams += free_teams[g]; }
+    // (with an envelope nearly every task sits next to the chain: more workgroups on the express list)
+    const int express_wgs = express_wgs_for(env != nullptr, n_cu);
+    out.express_wgs = express_wgs;
+    for (int g = 0; g < N_LISTS; ++g) { free_teams[g] = group_teams(g, n_cu, express_wgs); if (g < N_GROUPS) n_teams += free_teams[g]; }
     // quarter tiles from the first column whose trailing matrix no longer offers a half-tile task per team
     int& quarter_from = out.quarter_from;
     quarter_from = nt;
@@ -948,7 +960,7 @@ struct DagSchedule {
     unsigned long long* d_tasks = nullptr;
     int* d_image = nullptr;          // with an envelope: the state words a launch starts from (copied over them instead of the zero-fill)
     int* d_kmax = nullptr;           // ... and per tile column the last tile row that can hold a non-zero (the backward solve stops there)
-    int n_tasks = 0, quarter_from = 0, n_cu = 0, off[N_LISTS] = {}, len[N_LISTS] = {};
+    int n_tasks = 0, quarter_from = 0, express_wgs = DAG_EXPRESS_WGS, n_cu = 0, off[N_LISTS] = {}, len[N_LISTS] = {};
     bool ok = false;
     unsigned long long last_use = 0;
 };
@@ -970,7 +982,7 @@ struct SchedJob {
     std::mutex m;
     std::condition_variable cv;
     bool done = false, valid = false;
-    int quarter_from = 0, n_cu = 0, off[N_LISTS] = {}, len[N_LISTS] = {};
+    int quarter_from = 0, express_wgs = DAG_EXPRESS_WGS, n_cu = 0, off[N_LISTS] = {}, len[N_LISTS] = {};
     std::vector<unsigned long long> flat;
     std::vector<int> env, image, kmax;          // (empty: dense)
     double build_ms = 0;
@@ -1031,7 +1043,7 @@ std::shared_ptr<SchedJob> job_for(const SchedKey& key, int nt, int n_cu, const i
         }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         std::lock_guard<std::mutex> lock(job->m);
-        job->flat.swap(flat); job->image.swap(image); job->kmax.swap(kmax); job->quarter_from = sch.quarter_from; job->valid = valid; job->build_ms = ms;
+        job->flat.swap(flat); job->image.swap(image); job->kmax.swap(kmax); job->quarter_from = sch.quarter_from; job->express_wgs = sch.express_wgs; job->valid = valid; job->build_ms = ms;
         for (int g = 0; g < N_LISTS; ++g) { job->off[g] = off[g]; job->len[g] = len[g]; }
         job->done = true;
         job->cv.notify_all();
@@ -1063,7 +1075,7 @@ const DagSchedule* get_schedule(int nt, bool wait, const int* env = nullptr)
                 jl.lock();
             }
             DagSchedule s;
-            s.quarter_from = job->quarter_from; s.n_cu = job->n_cu;
+            s.quarter_from = job->quarter_from; s.express_wgs = job->express_wgs; s.n_cu = job->n_cu;
             for (int g = 0; g < N_LISTS; ++g) { s.off[g] = job->off[g]; s.len[g] = job->len[g]; }
             if (job->valid && hipMalloc(&s.d_tasks, job->flat.size() * sizeof(unsigned long long)) == hipSuccess) {
                 if (hipMemcpy(s.d_tasks, job->flat.data(), job->flat.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) == hipSuccess) { s.n_tasks = (int)job->flat.size(); s.ok = true; }
@@ -1121,7 +1133,7 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
     if (nt < dag_min_tiles() || nt > 255) return false;
     static const bool sync_build = std::getenv("MAGE_CHOL_DAG_SYNC_BUILD") != nullptr;      // (tests that must see THIS schedule from the first factorisation on)
     const DagSchedule* s = get_schedule(nt, sync_build, ws.env_host);
-    if (!s || s->n_cu < DAG_EXPRESS_WGS + 1 + 2 * N_GROUPS) return false;
+    if (!s || s->n_cu < s->express_wgs + 1 + 2 * N_GROUPS) return false;
     int* state = ws.sync + 8;
     // Two of these launches from two streams of one process must not overlap: each wants every compute unit (one workgroup per unit),
     // the hardware deals the workgroups of both over the XCDs as units come free, and launch A holding all of XCD 3 while launch B holds
@@ -1148,7 +1160,7 @@ bool chol_dag_factor(double* S, double* y, double* x, int n_pad, const CholWorks
     if (g_inject_stalls.load(std::memory_order_relaxed) > 0 && g_inject_stalls.fetch_sub(1) > 0) (void)hipMemsetAsync(state + D_INJECT, 1, sizeof(int), st);
     DagArgs a;
     a.S = S; a.y = y; a.x = x; a.Linv = ws.Linv; a.Lpub = ws.Linv + (size_t)nt * NBLK * NB * NB; a.part = a.Lpub + (size_t)nt * LPUB_TILE_DOUBLES; a.ok = ok; a.stall = stall;
-    a.st = state; a.trace = ws.dbg; a.tasks = s->d_tasks; a.ld = n_pad; a.nt = nt; a.n_tasks = s->n_tasks; a.quarter_from = s->quarter_from;
+    a.st = state; a.trace = ws.dbg; a.tasks = s->d_tasks; a.ld = n_pad; a.nt = nt; a.n_tasks = s->n_tasks; a.quarter_from = s->quarter_from; a.express_wgs = s->express_wgs;
     for (int g = 0; g < N_LISTS; ++g) { a.list_off[g] = s->off[g]; a.list_len[g] = s->len[g]; }
     hipLaunchKernelGGL(k_chol_dag, dim3(s->n_cu), dim3(DAG_THREADS), DAG_LDS_BYTES, st, a);
     if (hipGetLastError() != hipSuccess) return false;
@@ -1202,7 +1214,7 @@ MAGE_EXPORT void mage_debug_chol_inject_stall(int n) { mage::g_inject_stalls.sto
 // are written), negative when the lists fail the check.
 MAGE_EXPORT int mage_debug_chol_schedule(int nt, int n_cu, int fuse_max, unsigned long long* out, int cap, int* quarter_from, int* group_len)
 {
-    if (nt < 2 || nt > 255 || n_cu < mage::DAG_EXPRESS_WGS + 1 + 2 * mage::N_GROUPS) return 0;
+    if (nt < 2 || nt > 255 || n_cu < 4 + 1 + 2 * mage::N_GROUPS) return 0;
     const mage::Schedule sch = mage::build_schedule(nt, n_cu, fuse_max > 0 ? fuse_max : 8);
     if (quarter_from) *quarter_from = sch.quarter_from;
     int n = 0;
@@ -1217,7 +1229,7 @@ MAGE_EXPORT int mage_debug_chol_schedule(int nt, int n_cu, int fuse_max, unsigne
 // left of it; negative when the checker -- started from the envelope's initial progress -- rejects them.
 MAGE_EXPORT int mage_debug_chol_schedule_env(int nt, int n_cu, int fuse_max, const int* env, unsigned long long* out, int cap, int* quarter_from, int* group_len)
 {
-    if (nt < 2 || nt > 255 || !env || n_cu < mage::DAG_EXPRESS_WGS + 1 + 2 * mage::N_GROUPS) return 0;
+    if (nt < 2 || nt > 255 || !env || n_cu < 4 + 1 + 2 * mage::N_GROUPS) return 0;
     for (int i = 0; i < nt; ++i) if (env[i] < 0 || env[i] > i) return 0;
     const mage::Schedule sch = mage::build_schedule(nt, n_cu, fuse_max > 0 ? fuse_max : 8, env);
     if (quarter_from) *quarter_from = sch.quarter_from;
