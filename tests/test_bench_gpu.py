@@ -50,12 +50,14 @@ def test_single_gpu_line_carries_every_configuration():
         over = d2["ms_per_step"] - d2["roofline"]["ms_per_launch"] - d2["roofline_hbm"]["ms"]
     assert over < 0.12, over
     e = d["extra"]
-    for k in ("config2", "config2_cpu_baseline", "config3", "config3_cpu_baseline", "config4_end_to_end", "cold_start", "sustained", "concurrent_handles", "config5_windowed_1gpu"):
+    for k in ("config2", "config2_cpu_baseline", "config3", "config3_cpu_baseline", "config4_end_to_end", "cold_start", "skyline_solve", "sustained", "concurrent_handles", "config5_windowed_1gpu"):
         assert k in e and "error" not in e[k], (k, e.get(k))
     assert e["config3"]["one_iteration_bundler_create_to_destroy"]["total_ms"] < 1.5      # 2.1 ms with the host structure build
     assert e["config4_end_to_end"]["one_iteration_bundler"]["first_step_ms_structure_build_plus_one_iteration"] < 8.0
     cs = e["cold_start"]
     assert cs["global"]["fresh_process"]["task_graph_size"] and cs["global"]["warm_process_new_size"]["tile_columns"] == 57 and cs["global2k"]["fresh_process"]["tile_columns"] == 94
+    sk = e["skyline_solve"]
+    assert sk["same_mse_to_the_bit"] and sk["skyline"]["factor_and_solves_ms"] < sk["dense"]["factor_and_solves_ms"] and "error" not in sk["global2k_skyline"]
     assert set(e["config2"]["batches"]) == {"1", "64", "1024"}
     assert e["sustained"]["seeded_lambda_5e6"]["timed_seconds"] >= 2.0 and e["sustained"]["seeded_lambda_5e6"]["trials_per_iteration"] == 1.0
     s = d["strong_scaling"]
