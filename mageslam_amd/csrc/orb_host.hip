@@ -508,8 +508,10 @@ MAGE_EXPORT void mage_matcher_destroy(mage_matcher* h) { delete h; }
 
 namespace {
 
+// out_over / counts_over: where the kernel writes matches and counts instead of the handle's device buffers (pinned host memory the
+// device can address: a small call then needs no copy back)
 mage_status run_match(mage_matcher* h, int n_pairs, const uint8_t* dA, const int* dcA, int capA, const uint8_t* dB, const int* dcB, int capB,
-                      int max_dist, int min_diff, int cap_out)
+                      int max_dist, int min_diff, int cap_out, mage_dmatch* out_over = nullptr, int* counts_over = nullptr)
 {
     if (n_pairs < 0 || capA < 0 || capB < 0 || cap_out < 0) return fail(MAGE_ERR_INVALID_ARGUMENT, "negative size");
     const size_t np = (size_t)std::max(n_pairs, 1);
@@ -523,7 +525,7 @@ mage_status run_match(mage_matcher* h, int n_pairs, const uint8_t* dA, const int
     }
     if (n_pairs == 0) return MAGE_OK;
     MAGE_HIP(hipEventRecord(h->e0, h->stream));
-    match_launch(n_pairs, dA, dcA, capA, dB, dcB, capB, max_dist, min_diff, h->d_scratch.p, h->d_out.p, cap_out, h->d_counts.p, h->d_done.p, h->stream);
+    match_launch(n_pairs, dA, dcA, capA, dB, dcB, capB, max_dist, min_diff, h->d_scratch.p, out_over ? out_over : h->d_out.p, cap_out, counts_over ? counts_over : h->d_counts.p, h->d_done.p, h->stream);
     MAGE_HIP(hipEventRecord(h->e1, h->stream));
     return MAGE_OK;
 }
@@ -545,6 +547,34 @@ MAGE_EXPORT mage_status mage_match_bf_batch(mage_matcher* h, int n_pairs, const 
         MAGE_TRY(h->d_cA.reserve(np)); MAGE_TRY(h->d_cB.reserve(np));
         if (n_pairs == 0) return MAGE_OK;
         hipStream_t st = h->stream;
+        // A SMALL call (the tracker's one pair per frame: 28 KB in, 7 KB out) is bound by its copy commands, not by the 16-us kernel: both
+        // sets and the counts go up as ONE copy out of a pinned block, matches and counts are written by the kernel into that block
+        const size_t bA = (size_t)n_pairs * capA * 32, bB = (size_t)n_pairs * capB * 32, bC = sizeof(int) * (size_t)n_pairs, bO = sizeof(mage_dmatch) * (size_t)n_pairs * cap_out;
+        if (bA + bB + bO <= (size_t)256 * 1024) {
+            auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+            const size_t o_b = al(bA), o_ca = al(o_b + bB), o_cb = al(o_ca + bC), up = al(o_cb + bC), o_cnt = up, o_out = al(o_cnt + bC), total = o_out + bO + 64;
+            MAGE_TRY(h->h_io.resize_uninitialized(total));
+            void* dio = nullptr;
+            if (hipHostGetDevicePointer(&dio, h->h_io.data(), 0) == hipSuccess) {
+                uint8_t* hp = h->h_io.data();
+                if (bA) std::memcpy(hp, descA, bA);
+                if (bB) std::memcpy(hp + o_b, descB, bB);
+                std::memcpy(hp + o_ca, countsA, bC); std::memcpy(hp + o_cb, countsB, bC);
+                MAGE_TRY(h->d_A.reserve(up + 64));
+                MAGE_HIP(hipMemcpyAsync(h->d_A.p, hp, up, hipMemcpyHostToDevice, st));
+                uint8_t* dp = static_cast<uint8_t*>(dio);
+                MAGE_TRY(run_match(h, n_pairs, h->d_A.p, reinterpret_cast<const int*>(h->d_A.p + o_ca), capA, h->d_A.p + o_b, reinterpret_cast<const int*>(h->d_A.p + o_cb), capB,
+                                   max_dist, min_diff, cap_out, reinterpret_cast<mage_dmatch*>(dp + o_out), reinterpret_cast<int*>(dp + o_cnt)));
+                MAGE_HIP(wait_stream_briefly_spinning(st, h->e_wait));
+                std::memcpy(counts, hp + o_cnt, bC);
+                if (bO) std::memcpy(out, hp + o_out, bO);
+                float ms = 0;
+                MAGE_HIP(hipEventElapsedTime(&ms, h->e0, h->e1));
+                h->last_ms = ms;
+                return MAGE_OK;
+            }
+            (void)hipGetLastError();          // pinned memory this device cannot address: the copies below
+        }
         if (capA) MAGE_HIP(hipMemcpyAsync(h->d_A.p, descA, (size_t)n_pairs * capA * 32, hipMemcpyHostToDevice, st));
         if (capB) MAGE_HIP(hipMemcpyAsync(h->d_B.p, descB, (size_t)n_pairs * capB * 32, hipMemcpyHostToDevice, st));
         MAGE_HIP(hipMemcpyAsync(h->d_cA.p, countsA, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, st));

@@ -137,6 +137,15 @@ def main():
         mt.IndexedMatchBow(None, None, None, A, fao, fa, B, fbo, fb, 30, 1)
     im_kept_s = (time.perf_counter() - t0) / reps
     mt.BowSetTree()
+    # FeatureMatcher::Match as the tracker calls it: ONE pair of frames per call, host buffers in and out
+    mt.Match(A, B, None, None, 30, 1)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        mres = mt.Match(A, B, None, None, 30, 1)
+    match_s = (time.perf_counter() - t0) / reps
+    assert np.array_equal(np.asarray(mres).view(np.uint8), np.asarray(ORC.match(A, B, 30, 1)).view(np.uint8))
+    print(json.dumps({"config": f"FeatureMatcher::Match, one pair of {CAP} descriptors per call, host buffers in and out", "match_ms_per_call": match_s * 1e3,
+                      "match_kernel_ms_event_span": mt.last_kernel_ms(), "bit_exact_vs_oracle": True}), flush=True)
     print(json.dumps({"tree_kept_on_device": {"find_leaf_kernel_ms_event_span": leaf_kernel_ms, "find_leaf_ms_per_call": leaf_kept_s * 1e3, "indexed_match_bow_ms_per_call": im_kept_s * 1e3}, "config": f"BoW leaf lookup + IndexedMatch, {kk}-ary tree of depth {depth} ({n_nodes} nodes), {2 * CAP} descriptors per call, host buffers in and out (tree upload included)",
                       "find_leaf_ms_per_call": leaf_s * 1e3, "descriptors_per_s": 2 * CAP / leaf_s, "indexed_match_bow_ms_per_call": im_s * 1e3, "matches": int(len(got)),
                       "cpu_oracle_find_leaf_ms": cpu_leaf_s * 1e3, "cpu_oracle_indexed_match_bow_ms": cpu_im_s * 1e3, "bit_exact_vs_oracle": True}), flush=True)
