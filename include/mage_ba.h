@@ -254,9 +254,14 @@ mage_status mage_ba_get_profile(const mage_ba* h, mage_ba_profile* out);
  * effect with the next structure build; MAGE_BA_SKYLINE=1 makes it the default of every new handle.  Not for landmark-sharded handles. */
 mage_status mage_ba_use_skyline(mage_ba* h, int enable);
 
+/* A/B switch of the Schur build's launch on maps of more than 2 048 blocks: 0 (default) resident wavefronts work through per-compute-unit
+ * lists of blocks (k_schur_stream); 1 one wavefront per 6 x 6 block (k_schur_block_compact, rounds 2-5).  The same sums in the same order:
+ * the reduced system is the same to the bit (tests/test_ba_gpu.py).  MAGE_BA_SCHUR_BLOCKS=1 makes 1 the default of every new handle. */
+mage_status mage_ba_debug_schur_per_block(mage_ba* h, int enable);
+
 /* One list of the graph structure as it sits in HBM after the first step (names as in mageslam_amd/csrc/ba_kernels.h:
  * "cam2hc", "hc2cam", "L_edge", "L_uv", "L_info", "L_cam", "L_pt", "L_slot", "lm_ptr", "lm_pt", "lm_wptr", "w_hc", "w_lm", "camE_ptr",
- * "camE", "camS_ptr", "camS", "blk_ptr", "blk_ij", "con", "blk_order"; "sizes" = 12 ints: n_L, n_lm, n_fc, n_w, n_blk, n_blk_slots,
+ * "camE", "camS_ptr", "camS", "blk_ptr", "blk_ij", "con", "blk_order", "stream_ptr", "stream_blks" (k_schur_stream's lists; empty without them); "sizes" = 12 ints: n_L, n_lm, n_fc, n_w, n_blk, n_blk_slots,
  * n_con, dup_slots, n_pad, built_on_device, 0, 0).  *bytes = the list's size; it is copied when capacity_bytes suffices.
  * The structure is what g2o's initializeOptimization + buildStructure produce (BundlerLib.cpp:156-166); it is built on the
  * device by default and on the host with MAGE_BA_BUILD=host -- the tests compare the two element for element. */

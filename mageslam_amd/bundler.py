@@ -77,6 +77,7 @@ def _declare():
     L.mage_ba_get_iter_stats.argtypes = [vp, C.POINTER(IterStats), sz, C.POINTER(sz)]
     L.mage_ba_enable_profiling.argtypes = [vp, C.c_int]
     L.mage_ba_use_skyline.argtypes = [vp, C.c_int]
+    L.mage_ba_debug_schur_per_block.argtypes = [vp, C.c_int]
     L.mage_ba_get_profile.argtypes = [vp, C.POINTER(Profile)]
     L.mage_ba_debug_structure.argtypes = [vp, C.c_char_p, C.c_void_p, sz, C.POINTER(sz)]
     L.mage_release_cached_memory.argtypes = []
@@ -251,12 +252,16 @@ class BundlerLib:
         """The dense solve skips the tiles left of the reduced system's skyline (same numbers, less work); from the next structure build on."""
         check(self._L.mage_ba_use_skyline(self._h, int(bool(on))))
 
+    def schur_per_block(self, on=True):
+        """A/B: the Schur build as one wavefront per block (rounds 2-5) instead of the resident stream kernel; the same bits."""
+        check(self._L.mage_ba_debug_schur_per_block(self._h, int(bool(on))))
+
     def enable_profiling(self, on=True):
         """True / 1: every stage of an LM iteration bracketed by HIP events; 2: only the dense factorisation + solves; False: off."""
         check(self._L.mage_ba_enable_profiling(self._h, int(on)))
 
     STRUCTURE_LISTS = ("cam2hc", "hc2cam", "L_edge", "L_uv", "L_info", "L_cam", "L_pt", "L_slot", "lm_ptr", "lm_pt", "lm_wptr", "w_hc",
-                       "w_lm", "camE_ptr", "camE", "camS_ptr", "camS", "blk_ptr", "blk_ij", "con", "blk_order")
+                       "w_lm", "camE_ptr", "camE", "camS_ptr", "camS", "blk_ptr", "blk_ij", "con", "blk_order", "stream_ptr", "stream_blks")
 
     def structure(self, name: str) -> np.ndarray:
         """mage_ba_debug_structure: one list of the graph structure as it sits in HBM (int32 / uint32 views; "L_uv", "L_info" float32;

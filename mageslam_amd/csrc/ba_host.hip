@@ -268,6 +268,9 @@ struct mage_ba {
     // where the compact W records live (BaDeviceView::w_pos): built on the first LM iteration that uses the compact form
     DevBuf<int> d_w_pos, d_pos_lm, d_slot_order;
     DevBuf<ConPos> d_con_pos;
+    DevBuf<int> d_stream_ptr, d_group_blocks, d_con_soa; DevBuf<int4> d_stream_blks; DevBuf<long long> d_stream_stamps;      // k_schur_stream's block lists (BaDeviceView::stream_blks)      // k_schur_stream's trip lists (BaDeviceView::trips)
+    int n_cu = 0;
+    bool schur_per_block = false;      // mage_ba_debug_schur_per_block / MAGE_BA_SCHUR_BLOCKS
     size_t n_con = 0;
     bool positions_valid = false;
     DevBuf<int> d_blk_order;
@@ -1154,7 +1157,7 @@ mage_status initialize_optimization(mage_ba* h)
     h->n_active_tethers = nT;
     v.errL = h->d_errL.p; v.U = h->d_U.p; v.bc = h->d_bc.p; v.V = h->d_V.p; v.bp = h->d_bp.p; v.W = h->d_W.p;
     v.compact = 0; v.camR = h->d_camR.p;
-    v.w_pos = nullptr; v.pos_lm = nullptr; v.con_pos = nullptr; v.slot_order = nullptr;
+    v.w_pos = nullptr; v.pos_lm = nullptr; v.con_pos = nullptr; v.slot_order = nullptr; v.stream_ptr = nullptr; v.stream_blks = nullptr; v.n_stream_groups = 0; v.stream_stamps = nullptr; v.con_soa = nullptr; v.con_soa_pitch = 0;
     h->positions_valid = false; h->n_con = ncon;
     v.Dinv = h->d_Dinv.p; v.db = h->d_db.p; v.S = h->d_S.p; v.y = h->d_y.p; v.xc = h->d_xc.p; v.xl = h->d_xl.p;
     v.partial = h->d_partial.p; v.scal = h->d_scal.p;
@@ -1252,8 +1255,23 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
         MAGE_TRY(h->d_w_pos.reserve((size_t)v.n_w + 1)); MAGE_TRY(h->d_pos_lm.reserve((size_t)v.n_w + 1)); MAGE_TRY(h->d_con_pos.reserve(h->n_con + 1));
         const bool lpt = v.n_blk_slots > 0;          // every XCD's run of blocks longest first (slot_order)
         if (lpt) MAGE_TRY(h->d_slot_order.reserve((size_t)v.n_blk_slots + 8));
-        ba_launch_build_positions(v, h->d_w_pos.p, h->d_pos_lm.p, h->d_con_pos.p, lpt ? h->d_slot_order.p : nullptr, st);
+        // the Schur blocks as streams of trips taken by resident wavefronts (k_schur_stream); MAGE_BA_SCHUR_BLOCKS=1: one wavefront per block (A/B)
+        const bool stream = lpt && !h->schur_per_block && v.n_blk > SCHUR_SPLIT_BLOCKS_BELOW;
+        const int soa_pitch = (int)((h->n_con + 63) & ~(size_t)63);
+        if (stream) MAGE_TRY(h->d_con_soa.reserve((size_t)soa_pitch * 3 + 64));
+        ba_launch_build_positions(v, h->d_w_pos.p, h->d_pos_lm.p, h->d_con_pos.p, lpt ? h->d_slot_order.p : nullptr, stream ? h->d_con_soa.p : nullptr, soa_pitch, st);
         v.w_pos = h->d_w_pos.p; v.pos_lm = h->d_pos_lm.p; v.con_pos = h->d_con_pos.p; v.slot_order = lpt ? h->d_slot_order.p : nullptr;
+        v.con_soa = stream ? h->d_con_soa.p : nullptr; v.con_soa_pitch = soa_pitch;
+        v.stream_ptr = nullptr; v.stream_blks = nullptr; v.n_stream_groups = 0; v.stream_stamps = nullptr;
+        if (stream) {
+            const int n_groups = ba_schur_stream_groups(h->n_cu);
+            MAGE_TRY(h->d_stream_ptr.reserve((size_t)n_groups + 2)); MAGE_TRY(h->d_stream_blks.reserve((size_t)v.n_blk + 8));
+            MAGE_TRY(h->d_group_blocks.reserve((size_t)n_groups * ba_schur_stream_rounds(v.n_blk_slots, n_groups) + 8));
+            ba_launch_build_stream_lists(v, n_groups, h->d_group_blocks.p, h->d_stream_ptr.p, h->d_stream_blks.p, st);
+            v.stream_ptr = h->d_stream_ptr.p; v.stream_blks = h->d_stream_blks.p; v.n_stream_groups = n_groups;
+            static const bool stamps = std::getenv("MAGE_BA_SCHUR_TRACE") != nullptr;      // per wavefront: start, end (100 MHz clock), hardware id, trips | blocks << 32 (mage_ba_debug_structure "stream_stamps")
+            if (stamps) { MAGE_TRY(h->d_stream_stamps.reserve((size_t)n_groups * 8 * 4)); v.stream_stamps = h->d_stream_stamps.p; }
+        }
         h->positions_valid = true;
     }
     int chi_partials = 0;        // > 0: the linearisation left its chi2 partials for the first trial's Schur launch to add (ba_fused_linearize)
@@ -1765,7 +1783,9 @@ MAGE_EXPORT mage_status mage_ba_create(const mage_ba_params* params, mage_ba** o
         MAGE_TRY(select_device(params ? params->device : -1, &dev));
         std::unique_ptr<mage_ba> h(new mage_ba());
         h->device = dev;
+        { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256; h->n_cu = cu; }
         h->points_fixed = params ? params->are_points_fixed != 0 : false;
+        { static const bool pb = std::getenv("MAGE_BA_SCHUR_BLOCKS") != nullptr; h->schur_per_block = pb; }
         { static const bool sky = std::getenv("MAGE_BA_SKYLINE") != nullptr; h->use_skyline = sky; }          // process-wide default of mage_ba_use_skyline
         MAGE_DEVICE_SCOPE(dev);
         MAGE_TRY(cached_stream_acquire(dev, &h->stream));
@@ -2524,6 +2544,9 @@ MAGE_EXPORT mage_status mage_ba_debug_structure(mage_ba* h, const char* name, vo
         else if (n == "blk_ij") { src = v.blk_ij; nb = (size_t)v.n_blk * 8; }
         else if (n == "con") { src = v.con; nb = (size_t)ncon * 8; }
         else if (n == "blk_order") { src = v.blk_order; nb = (size_t)v.n_blk_slots * 4; }
+        else if (n == "stream_ptr") { src = v.stream_ptr; nb = v.stream_ptr ? (size_t)(v.n_stream_groups + 1) * 4 : 0; }
+        else if (n == "stream_blks") { src = v.stream_blks; nb = v.stream_blks ? (size_t)v.n_blk * 16 : 0; }
+        else if (n == "stream_stamps") { src = v.stream_stamps; nb = v.stream_stamps ? (size_t)v.n_stream_groups * 8 * 32 : 0; }
         else if (n == "camE") {
             int ne = 0;
             if (v.n_fc > 0) {
@@ -2562,6 +2585,13 @@ MAGE_EXPORT mage_status mage_ba_use_skyline(mage_ba* h, int enable)
 {
     if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
     if (h->use_skyline != (enable != 0)) { h->use_skyline = enable != 0; h->dirty = true; }          // (the skyline is read back with the structure)
+    return MAGE_OK;
+}
+
+MAGE_EXPORT mage_status mage_ba_debug_schur_per_block(mage_ba* h, int enable)
+{
+    if (!h) return fail(MAGE_ERR_INVALID_ARGUMENT, "null handle");
+    if (h->schur_per_block != (enable != 0)) { h->schur_per_block = enable != 0; h->positions_valid = false; }
     return MAGE_OK;
 }
 

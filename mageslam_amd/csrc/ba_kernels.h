@@ -11,6 +11,7 @@
 
 namespace mage {
 
+constexpr int SCHUR_SPLIT_BLOCKS_BELOW = 2048;       // Schur blocks: at most this many -> four wavefronts per block; more: k_schur_stream
 constexpr int SCHUR_WAVES = 1;     // wavefronts (= blocks of S) per workgroup of k_schur_block; the slot table is built for it
 
 struct ConPos { int a, b, lm; };
@@ -57,6 +58,9 @@ struct BaDeviceView {
     const int* pos_lm;                         // n_w : landmark of a position
     const int* slot_order;                     // blk_order with every XCD's run sorted longest block first (k_schur_block_compact: the diagonal
                                                // blocks are four times the average and sat at regular intervals up to the END of the grid)
+    const int* con_soa; int con_soa_pitch;     // the same list as three arrays (a | b | lm, each con_soa_pitch ints) for k_schur_stream; null without it
+    long long* stream_stamps;                  // debug (MAGE_BA_SCHUR_TRACE): 4 words per wavefront of k_schur_stream (8 per workgroup), else null
+    const int* stream_ptr; const void* stream_blks; int n_stream_groups;   // k_schur_stream: per workgroup (= compute unit) its list of blocks (n_stream_groups + 1 offsets; 16-byte descriptors c_begin, c_end, i, j); null: one wavefront per block
     const struct ConPos* con_pos;              // the contributions of `con` as (position a, position b, landmark): 12 bytes, ONE trip to memory
                                                // between a block's list and its records (the landmark used to be a look-up of its own)
 
@@ -103,7 +107,10 @@ void ba_launch_error(const BaDeviceView& v, bool trial, double huber_delta, hipS
 void ba_launch_linearize(const BaDeviceView& v, double huber_delta, hipStream_t st);                 // U,bc,V,bp,W
 void ba_launch_maxdiag(const BaDeviceView& v, hipStream_t st, const double* udiag_sum = nullptr);                                       // -> scal[SC_MAXDIAG]
 void ba_launch_schur(const BaDeviceView& v, double lambda, hipStream_t st);                          // Dinv,db,S,y
-void ba_launch_build_positions(const BaDeviceView& v, int* w_pos, int* pos_lm, ConPos* con_pos, int* slot_order, hipStream_t st); // w_pos / pos_lm / con_pos from camS, w_lm, con
+void ba_launch_build_positions(const BaDeviceView& v, int* w_pos, int* pos_lm, ConPos* con_pos, int* slot_order, int* con_soa, int con_soa_pitch, hipStream_t st); // w_pos / pos_lm / con_pos from camS, w_lm, con
+int ba_schur_stream_groups(int n_cu);                                                                 // workgroups of k_schur_stream on a device of n_cu compute units
+int ba_schur_stream_rounds(int n_blk_slots, int n_groups);                                            // blocks per workgroup at most
+void ba_launch_build_stream_lists(const BaDeviceView& v, int n_groups, int* group_blocks, int* group_ptr, void* blks, hipStream_t st);   // from slot_order / blk_ptr / blk_ij; group_blocks: n_groups x rounds ints; blks: n_blk descriptors of 16 bytes
 void ba_launch_tile_envelope(const BaDeviceView& v, int* tile_env, hipStream_t st);                  // the skyline of S by tile rows, from blk_ij and the tether pairs
 void ba_launch_update(const BaDeviceView& v, double lambda, hipStream_t st);                         // xl, trial state, scal[SC_SCALE]
 // landmark-sharded maps (include/mage_ba.h: mage_ba_set_landmark_shard)

@@ -28,7 +28,7 @@ namespace mage {
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int SPLIT_BLOCKS_BELOW = 2048;       // Schur blocks: at most this many -> four wavefronts per block
+constexpr int SPLIT_BLOCKS_BELOW = SCHUR_SPLIT_BLOCKS_BELOW;       // Schur blocks: at most this many -> four wavefronts per block
 constexpr int SPLIT_CAMERAS_BELOW = 256;      // per-camera kernels: at most this many free cameras -> a workgroup per camera
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -926,6 +926,286 @@ __global__ __launch_bounds__(SPLIT ? 256 : 64 * SCHUR_WAVES) void k_schur_block_
             v.S[(size_t)(ij.x * 6 + r) * v.n_pad + (ij.y * 6 + c)] = -val;
         }
     }
+}
+
+// ---- the same blocks taken as STREAMS OF TRIPS by resident wavefronts (round 6).  k_schur_block_compact<false> gives every 6 x 6 block a
+// wavefront of its own: ~16 k wavefronts of ~6 trips each (a third of them ONE trip), every one starting with three dependent trips to
+// memory (block header -> list entries -> records) while its SIMD's only other wavefront is, often enough, in the same state.  Here one
+// workgroup of eight wavefronts per compute unit (two per SIMD, all resident from the first cycle) works through the unit's LIST OF BLOCKS
+// (k_build_stream_lists: the XCD's run of blocks, longest first, dealt out to the XCD's compute units); a wavefront CLAIMS its next block
+// from the list with an LDS counter one block ahead of need, so the arithmetic of trip t is issued with the records of trip t + 1, the
+// list entries of trip t + 2 and the descriptor of trip t + 3 in flight ACROSS block boundaries -- a block's header costs nothing -- and
+// the two wavefronts of a SIMD, of which the hardware favours the older one, end together all the same (per-wavefront lists, however
+// evenly cut, left the favoured one done 14 us before the other: profiles/HISTORY.md).  The lane <-> contribution mapping, each lane's
+// order of additions and the reduction are those of k_schur_block_compact: the same bits whichever wavefront takes a block
+// (tests/test_ba_gpu.py; MAGE_BA_SCHUR_BLOCKS=1 keeps the per-block launch for A/B).
+#define MAGE_CONSTANT __attribute__((address_space(4)))
+#ifndef SCHUR_ABL
+#define SCHUR_ABL 0
+#endif
+typedef int trip4 __attribute__((ext_vector_type(4)));
+struct StreamBlk { int c_begin, c_end, i, j; };
+constexpr int STREAM_WAVES = 8;
+__global__ __launch_bounds__(64 * STREAM_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_schur_stream(BaDeviceView v, double lambda)
+{
+    __shared__ double red[STREAM_WAVES][32 * 37];
+    __shared__ int head;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* R = red[wave];
+    const MAGE_CONSTANT int* gp = (const MAGE_CONSTANT int*)v.stream_ptr;
+    const int l_begin = gp[blockIdx.x], l_n = gp[blockIdx.x + 1] - l_begin;
+    const MAGE_CONSTANT trip4* LIST = (const MAGE_CONSTANT trip4*)v.stream_blks + l_begin;
+    const MAGE_CONSTANT double* CR = (const MAGE_CONSTANT double*)v.camR;
+    long long t_start = 0;
+    if (v.stream_stamps) t_start = (long long)__builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) head = 0;
+    __syncthreads();
+    auto claim = [&]() -> int {
+        int k = 0;
+        if (lane == 0) k = atomicAdd(&head, 1);
+        return __builtin_amdgcn_readfirstlane(k);
+    };
+    const double2* G2 = reinterpret_cast<const double2*>(v.W);
+    struct Rec { double2 da, db, dc, ga0, ga1, gb0, gb1, e01, e2x; };
+    auto fetch = [&](const ConPos e, const bool dg, Rec& r) {
+#if SCHUR_ABL == 1
+        const double q = (double)(e.a + lane);
+        r.da = r.db = r.dc = r.ga0 = r.ga1 = r.gb0 = r.gb1 = r.e01 = r.e2x = double2{ q, q + 1.0 };
+#else
+        const double2* D2 = reinterpret_cast<const double2*>(v.Dinv + (size_t)e.lm * 6);
+        r.da = D2[0]; r.db = D2[1]; r.dc = D2[2];
+        r.ga0 = G2[(size_t)e.a * 2]; r.ga1 = G2[(size_t)e.a * 2 + 1];
+        r.gb0 = G2[(size_t)e.b * 2]; r.gb1 = G2[(size_t)e.b * 2 + 1];
+        if (dg) {
+            const double2* db2 = reinterpret_cast<const double2*>(v.db + (size_t)e.lm * 4);
+            r.e01 = db2[0]; r.e2x = db2[1];
+        }
+#endif
+    };
+    // a trip: (first contribution, the block's end, i, j | last << 31); none left: end = -1
+#if SCHUR_ABL == 1
+    auto entry = [&](const trip4 D) { return ConPos{ D.x + lane, D.y, D.z }; };
+#else
+    auto entry = [&](const trip4 D) { return v.con_pos[max(min(D.x + lane, D.y - 1), 0)]; };
+#endif
+    auto is_diag = [](const trip4 D) { return D.z == (D.w & 0xffffff); };
+    auto cam = [&](int hc) {
+        CamConst k;
+        const MAGE_CONSTANT double* p = CR + (size_t)hc * 12;
+        k.f = p[0];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) k.R[q] = p[1 + q];
+        return k;
+    };
+    // the cursor that turns the claimed blocks into trips: `cb` is being cut into trips, `nb` was claimed behind it (its descriptor has been
+    // on its way since the claim) and takes over when cb runs out -- at which moment the block after it is claimed
+    trip4 cb = { 0, -1, 0, 0 }, nb = { 0, -1, 0, 0 };
+    {
+        const int k0 = claim();
+        if (k0 < l_n) cb = LIST[k0];
+        const int k1 = k0 < l_n ? claim() : l_n;
+        if (k1 < l_n) nb = LIST[k1];
+    }
+    int n_trips = 0, n_blocks = 0, n_diag = 0;
+    auto next_trip = [&]() -> trip4 {
+        if (cb.y < 0) return cb;
+        trip4 D = cb;
+        cb.x += 64;
+        const bool last = cb.x >= cb.y;
+        D.w |= last ? (int)0x80000000u : 0;
+        if (last) {
+            cb = nb;
+            nb.y = -1;
+            if (cb.y >= 0) { const int k = claim(); if (k < l_n) nb = LIST[k]; }
+        }
+        return D;
+    };
+    trip4 D0 = next_trip(), D1 = next_trip(), D2 = next_trip();
+    CamConst ci = cam(D0.z), cj = cam(D0.w & 0xffffff);
+    Rec cur, nxt;
+    ConPos e1;
+    {
+        const ConPos e0 = entry(D0);
+        e1 = entry(D1);
+        fetch(e0, is_diag(D0), cur);
+    }
+    double acc[36], yv[6];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) yv[k] = 0;
+    while (D0.y >= 0) {
+        fetch(e1, is_diag(D1), nxt);
+        const ConPos e2 = entry(D2);
+        const trip4 D3 = next_trip();
+        const int bi = D0.z, bj = D0.w & 0xffffff;
+        const bool diag = bi == bj;
+        ++n_trips; n_diag += diag ? 1 : 0;
+        if (D0.x + lane < D0.y) {
+#if SCHUR_ABL == 2
+            acc[0] += (cur.da.x + cur.db.x + cur.dc.x) + (cur.ga0.x + cur.ga1.x) + (cur.gb0.x + cur.gb1.x) + (diag ? cur.e01.x + cur.e2x.x : 0.0) + ci.f + cj.f;
+#else
+            const double2 da = cur.da, db = cur.db, dc = cur.dc, ga0 = cur.ga0, ga1 = cur.ga1, gb0 = cur.gb0, gb1 = cur.gb1;
+            const double d00 = da.x, d01 = da.y, d02 = db.x, d11 = db.y, d12 = dc.x, d22 = dc.y;
+            double Ja0[6], Ja1[6], Qa0[3], Qa1[3], Jb0[6], Jb1[6], Qb0[3], Qb1[3];
+            slot_factors(ci, ga0.x, ga0.y, ga1.x, ga1.y, Ja0, Ja1, Qa0, Qa1);
+            slot_factors(cj, gb0.x, gb0.y, gb1.x, gb1.y, Jb0, Jb1, Qb0, Qb1);
+            if (diag) {
+                const double e0 = cur.e01.x, e1 = cur.e01.y, e2 = cur.e2x.x;
+                const double s0 = Qa0[0] * e0 + Qa0[1] * e1 + Qa0[2] * e2, s1 = Qa1[0] * e0 + Qa1[1] * e1 + Qa1[2] * e2;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) yv[r] += r == 4 ? Ja1[r] * s1 : r == 3 ? Ja0[r] * s0 : Ja0[r] * s0 + Ja1[r] * s1;
+            }
+            const double t00 = Qa0[0] * d00 + Qa0[1] * d01 + Qa0[2] * d02, t01 = Qa0[0] * d01 + Qa0[1] * d11 + Qa0[2] * d12, t02 = Qa0[0] * d02 + Qa0[1] * d12 + Qa0[2] * d22;
+            const double t10 = Qa1[0] * d00 + Qa1[1] * d01 + Qa1[2] * d02, t11 = Qa1[0] * d01 + Qa1[1] * d11 + Qa1[2] * d12, t12 = Qa1[0] * d02 + Qa1[1] * d12 + Qa1[2] * d22;
+            const double m00 = t00 * Qb0[0] + t01 * Qb0[1] + t02 * Qb0[2], m01 = t00 * Qb1[0] + t01 * Qb1[1] + t02 * Qb1[2];
+            const double m10 = t10 * Qb0[0] + t11 * Qb0[1] + t12 * Qb0[2], m11 = t10 * Qb1[0] + t11 * Qb1[1] + t12 * Qb1[2];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const double n0 = r == 4 ? Ja1[r] * m10 : r == 3 ? Ja0[r] * m00 : Ja0[r] * m00 + Ja1[r] * m10;
+                const double n1 = r == 4 ? Ja1[r] * m11 : r == 3 ? Ja0[r] * m01 : Ja0[r] * m01 + Ja1[r] * m11;
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) acc[r * 6 + cc] += cc == 4 ? n1 * Jb1[cc] : cc == 3 ? n0 * Jb0[cc] : n0 * Jb0[cc] + n1 * Jb1[cc];
+            }
+#endif
+        }
+        if (D0.w < 0) {                                      // the block's last trip (uniform): reduce, write, clear
+            ++n_blocks;
+            ci = cam(D1.z); cj = cam(D1.w & 0xffffff);       // the next block's cameras (scalar loads): requested here, back by the end of the reduction
+#pragma unroll
+            for (int k = 0; k < 36; ++k) acc[k] += __shfl_xor(acc[k], 32, 64);
+            if (lane < 32) {
+#pragma unroll
+                for (int k = 0; k < 36; ++k) R[lane * 37 + k] = acc[k];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double val = 0;
+            if (lane < 36) {
+                double rr[32];                               // all 32 reads in flight before the first addition (same order of additions)
+#pragma unroll
+                for (int j = 0; j < 32; ++j) rr[j] = R[j * 37 + lane];
+                double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+                for (int j = 0; j < 32; j += 4) { s0 += rr[j + 0]; s1 += rr[j + 1]; s2 += rr[j + 2]; s3 += rr[j + 3]; }
+                val = (s0 + s1) + (s2 + s3);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (diag) {
+                double yval = 0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) yv[k] += __shfl_xor(yv[k], 32, 64);
+                if (lane < 32) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) R[lane * 7 + k] = yv[k];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < 6) {
+                    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+                    for (int j = 0; j < 32; j += 4) { s0 += R[(j + 0) * 7 + lane]; s1 += R[(j + 1) * 7 + lane]; s2 += R[(j + 2) * 7 + lane]; s3 += R[(j + 3) * 7 + lane]; }
+                    yval = (s0 + s1) + (s2 + s3);
+                    v.y[bi * 6 + lane] = v.bc[(size_t)bi * 6 + lane] - yval;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int k = 0; k < 6; ++k) yv[k] = 0;
+            }
+            if (lane < 36) {
+                const int r = lane / 6, c = lane % 6;
+                if (diag) {
+                    double u = v.U[(size_t)bi * 36 + r * 6 + c] + (r == c ? lambda : 0.0);
+                    v.S[(size_t)(bi * 6 + c) * v.n_pad + (bi * 6 + r)] = u - val;
+                } else {
+                    v.S[(size_t)(bi * 6 + r) * v.n_pad + (bj * 6 + c)] = -val;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 36; ++k) acc[k] = 0;
+        }
+        cur = nxt; e1 = e2; D0 = D1; D1 = D2; D2 = D3;
+    }
+    if (v.stream_stamps && lane == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        long long* o = v.stream_stamps + ((size_t)blockIdx.x * STREAM_WAVES + wave) * 4;
+        o[0] = t_start; o[1] = (long long)__builtin_amdgcn_s_memrealtime(); o[2] = (long long)hw | ((long long)xcc << 32); o[3] = (long long)n_trips | ((long long)n_blocks << 32) | ((long long)n_diag << 48);
+    }
+}
+// The block lists of k_schur_stream.  Workgroup g runs on XCD g % 8 and is that XCD's compute unit q = g / 8 of Q.  The XCD's run of
+// blocks, longest first (slot_order), is dealt out in ROUNDS of Q: in every round the unit with the least work so far takes the round's
+// longest block, and so on.  A block costs its trips + the reduction and write-out (an eighth of a trip) + a quarter per trip for a diagonal
+// block's right-hand side (fitted to the units' end times, MAGE_BA_SCHUR_TRACE).  A unit's list is in round order: longest first.
+// k_assign_blocks: one workgroup per XCD, thread = unit; k_build_stream_lists: one workgroup: count, scan, fill.
+constexpr int STREAM_Q_MAX = 1024;
+__global__ __launch_bounds__(STREAM_Q_MAX) void k_assign_blocks(BaDeviceView v, int Q, int rounds, int* __restrict__ group_blocks)
+{
+    __shared__ int load[STREAM_Q_MAX];
+    const int x = blockIdx.x, q = threadIdx.x;
+    const int* order = v.slot_order ? v.slot_order : v.blk_order;
+    const int n = v.n_blk_slots > x ? (v.n_blk_slots - x + 7) / 8 : 0;
+    int mine = 0;
+    if (q < Q) load[q] = 0;
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        int rank = 0;
+        if (q < Q)
+            for (int o = 0; o < Q; ++o) { const int lo = load[o]; rank += (lo < mine || (lo == mine && o < q)) ? 1 : 0; }
+        __syncthreads();
+        if (q < Q) {
+            const int e = r * Q + rank;
+            const int b = e < n ? order[x + 8 * e] : -1;
+            group_blocks[(size_t)(q * 8 + x) * rounds + r] = b;
+            if (b >= 0) {
+                const int trips = max(1, (v.blk_ptr[b + 1] - v.blk_ptr[b] + 63) >> 6);
+                const int2 ij = v.blk_ij[b];
+                mine += 8 * trips + 1 + (ij.x == ij.y ? 2 * trips : 0);
+            }
+            load[q] = mine;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void k_build_stream_lists(BaDeviceView v, int n_groups, int rounds, const int* __restrict__ group_blocks, int* __restrict__ group_ptr, StreamBlk* __restrict__ blks)
+{
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n_groups + 1023) / 1024;                    // consecutive groups per thread
+    int mine = 0;
+    for (int k = 0; k < per; ++k) {
+        const int g = tid * per + k;
+        if (g < n_groups)
+            for (int r = 0; r < rounds; ++r) mine += group_blocks[(size_t)g * rounds + r] >= 0 ? 1 : 0;
+    }
+    part[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int add = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    int at = part[tid] - mine;
+    for (int k = 0; k < per; ++k) {
+        const int g = tid * per + k;
+        if (g >= n_groups) break;
+        group_ptr[g] = at;
+        for (int r = 0; r < rounds; ++r) {
+            const int b = group_blocks[(size_t)g * rounds + r];
+            if (b < 0) continue;
+            const int2 ij = v.blk_ij[b];
+            blks[at++] = StreamBlk{ v.blk_ptr[b], v.blk_ptr[b + 1], ij.x, ij.y };
+        }
+    }
+    if (tid == 1023) group_ptr[n_groups] = part[1023];
 }
 
 template <bool SPLIT>
@@ -2352,6 +2632,7 @@ void ba_launch_schur(const BaDeviceView& v, double lambda, double lambda_cam, do
     }
     if (v.n_blk > 0 && v.compact) {
         if (v.n_blk <= SPLIT_BLOCKS_BELOW) hipLaunchKernelGGL(k_schur_block_compact<true>, dim3(v.n_blk), dim3(256), 0, st, v, lambda_cam);
+        else if (v.stream_blks) hipLaunchKernelGGL(k_schur_stream, dim3(v.n_stream_groups), dim3(64 * STREAM_WAVES), 0, st, v, lambda_cam);
         else hipLaunchKernelGGL(k_schur_block_compact<false>, dim3(cdiv(v.n_blk_slots, SCHUR_WAVES)), dim3(64 * SCHUR_WAVES), 0, st, v, lambda_cam);
     } else if (v.n_blk > 0) {
         if (v.n_blk <= SPLIT_BLOCKS_BELOW) hipLaunchKernelGGL((k_schur_block<true, true>), dim3(v.n_blk), dim3(256), 0, st, v, lambda_cam);
@@ -2424,12 +2705,14 @@ __global__ __launch_bounds__(256) void k_build_positions(BaDeviceView v, int* __
     w_pos[s] = p;
     pos_lm[p] = v.w_lm[s];
 }
-__global__ __launch_bounds__(256) void k_build_con_pos(BaDeviceView v, const int* __restrict__ w_pos, ConPos* __restrict__ con_pos)
+__global__ __launch_bounds__(256) void k_build_con_pos(BaDeviceView v, const int* __restrict__ w_pos, ConPos* __restrict__ con_pos, int* __restrict__ soa, int pitch)
 {
     const int end = v.blk_ptr[v.n_blk];
     for (int c = blockIdx.x * 256 + threadIdx.x; c < end; c += gridDim.x * 256) {
         const int2 ab = v.con[c];
-        con_pos[c] = ConPos{ w_pos[ab.x], w_pos[ab.y], v.w_lm[ab.x] };
+        const ConPos e = { w_pos[ab.x], w_pos[ab.y], v.w_lm[ab.x] };
+        con_pos[c] = e;
+        if (soa) { soa[c] = e.a; soa[pitch + c] = e.b; soa[2 * (size_t)pitch + c] = e.lm; }
     }
 }
 // slot_order: workgroup w of k_schur_block_compact lands on XCD w % 8 and takes entry w / 8 of that XCD's run of blocks (blk_order).  The
@@ -2467,12 +2750,20 @@ __global__ __launch_bounds__(256) void k_order_slots_longest_first(BaDeviceView 
         out[x + 8 * rank] = b;
     }
 }
-void ba_launch_build_positions(const BaDeviceView& v, int* w_pos, int* pos_lm, ConPos* con_pos, int* slot_order, hipStream_t st)
+int ba_schur_stream_groups(int n_cu) { return std::min(n_cu, STREAM_Q_MAX * 8) / 8 * 8; }
+int ba_schur_stream_rounds(int n_blk_slots, int n_groups) { const int Q = n_groups / 8, n = (n_blk_slots + 7) / 8; return std::max(1, (n + Q - 1) / Q); }
+void ba_launch_build_stream_lists(const BaDeviceView& v, int n_groups, int* group_blocks, int* group_ptr, void* blks, hipStream_t st)
+{
+    const int rounds = ba_schur_stream_rounds(v.n_blk_slots, n_groups);
+    hipLaunchKernelGGL(k_assign_blocks, dim3(8), dim3(STREAM_Q_MAX), 0, st, v, n_groups / 8, rounds, group_blocks);
+    hipLaunchKernelGGL(k_build_stream_lists, dim3(1), dim3(1024), 0, st, v, n_groups, rounds, group_blocks, group_ptr, static_cast<StreamBlk*>(blks));
+}
+void ba_launch_build_positions(const BaDeviceView& v, int* w_pos, int* pos_lm, ConPos* con_pos, int* slot_order, int* con_soa, int con_soa_pitch, hipStream_t st)
 {
     if (v.n_w <= 0) return;
     if (v.n_blk_slots > 0 && slot_order) hipLaunchKernelGGL(k_order_slots_longest_first, dim3(8), dim3(256), 0, st, v, slot_order);
     hipLaunchKernelGGL(k_build_positions, dim3(cdiv(v.n_w, 256)), dim3(256), 0, st, v, w_pos, pos_lm, 1);
-    if (v.n_blk > 0) hipLaunchKernelGGL(k_build_con_pos, dim3(2048), dim3(256), 0, st, v, w_pos, con_pos);
+    if (v.n_blk > 0) hipLaunchKernelGGL(k_build_con_pos, dim3(2048), dim3(256), 0, st, v, w_pos, con_pos, con_soa, con_soa_pitch);
 }
 
 bool ba_compact_w_enabled()

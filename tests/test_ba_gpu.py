@@ -114,6 +114,43 @@ def test_large_path_variants_match_oracle():
     _compare_with_oracle(s, False, [([1.8], 1e30), ([0.9], 1e30)], rtol=1e-6)
 
 
+def test_schur_stream_kernel_gives_the_per_block_kernel_s_bits():
+    """Maps of more than 2 048 Schur blocks: resident wavefronts working through per-compute-unit block lists (k_schur_stream, claims
+    through an LDS counter: WHICH wavefront takes a block varies from run to run) against one wavefront per block
+    (mage_ba_debug_schur_per_block): the same errors, outlier lists and state to the bit; the lists cover every block exactly once;
+    and the oracle agrees with the stream kernel's result."""
+    s = scene.make_scene(n_cams=300, n_pts=9000, n_obs=90000, seed=0x5EED0B41, outlier_frac=0.01)
+    plan = [([1.8], 25.0), ([0.9, 0.9], 16.0), ([0.9], 9.0)]
+    res = []
+    for per_block in (False, True, False):
+        b = BundlerLib(False)
+        b.schur_per_block(per_block)
+        load_scene(b, s, bulk=True)
+        outs = []
+        for hub, thr in plan:
+            o = []
+            outs.append((float(b.StepBundleAdjustment(hub, thr, o)), sorted(o)))
+        n_blk = int(b.structure("sizes")[4])
+        assert n_blk > 2048
+        ptr, blks = b.structure("stream_ptr"), b.structure("stream_blks").reshape(-1, 4)
+        if per_block:
+            assert ptr.size == 0 and blks.size == 0
+        else:
+            bp, ij = b.structure("blk_ptr"), b.structure("blk_ij").reshape(-1, 2)
+            assert ptr[0] == 0 and ptr[-1] == n_blk and np.all(np.diff(ptr) >= 0) and len(blks) == n_blk
+            want = np.stack([bp[:-1], bp[1:], ij[:, 0], ij[:, 1]], 1)
+            assert np.array_equal(blks[np.lexsort(blks.T[::-1])], want[np.lexsort(want.T[::-1])])      # every block once
+            for g in range(len(ptr) - 1):                                                            # a unit's list: longest first
+                t = (blks[ptr[g]:ptr[g + 1], 1] - blks[ptr[g]:ptr[g + 1], 0] + 63) // 64
+                assert np.all(np.diff(t) <= 0)
+        res.append((outs, b.poses_f64().copy(), b.points_f64().copy()))
+        b.close()
+    for other in res[1:]:
+        assert res[0][0] == other[0]
+        assert np.array_equal(res[0][1], other[1]) and np.array_equal(res[0][2], other[2])
+    _compare_with_oracle(s, False, plan[:2])
+
+
 def test_compact_and_materialised_w_agree(tmp_path):
     """Large tether-free problems keep W as 32-byte rank-2 factors; MAGE_BA_MATERIAL_W=1 (read once per process, hence
     the child) materialises the 6x3 blocks instead.  Same algebra, different association: the states agree to rounding, the integer
