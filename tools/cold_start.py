@@ -73,7 +73,7 @@ def main():
     L.mage_debug_chol_wait_schedule.restype = C.c_int
     L.mage_debug_chol_wait_schedule.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
     res = {"fresh_process": one(a.workload, a.device, L, a.skyline),
-           "note": "the first step's factorisation runs column by column when the task lists are not there yet (same bits); "
+           "note": "the first step's factorisation runs column by column when the task lists are not there yet (same bits); the process's first asynchronous host-to-device copy (~6.5 ms of runtime set-up) is made by a worker thread of mage_ba_create (MAGE_BA_NO_WARMUP=1: inside the first step); "
                    "a fresh process also loads the code object and initialises the runtime inside its first step"}
     if a.then:
         res["warm_process_new_size"] = one(a.then, a.device, L)
