@@ -971,6 +971,25 @@ __global__ __launch_bounds__(64 * STREAM_WAVES) __attribute__((amdgpu_waves_per_
 #if SCHUR_ABL == 1
         const double q = (double)(e.a + lane);
         r.da = r.db = r.dc = r.ga0 = r.ga1 = r.gb0 = r.gb1 = r.e01 = r.e2x = double2{ q, q + 1.0 };
+#elif SCHUR_ABL == 3
+        // the same bytes requested COOPERATIVELY: three lanes per 48-byte landmark record, two per 32-byte slot record (e.a carries the
+        // trip's first contribution, e.b its last valid one) -- a third of the distinct lines per load instruction
+        const int* CAx = v.con_soa; const int* CBx = CAx + v.con_soa_pitch; const int* CLx = CBx + v.con_soa_pitch;
+        const int c0 = e.a, cl = e.b;
+        const char* DI = reinterpret_cast<const char*>(v.Dinv); const char* WW = reinterpret_cast<const char*>(v.W);
+        const int l3 = lane == 63 ? 21 : lane / 3, p3 = lane == 63 ? 0 : lane % 3;
+        const unsigned lm0 = CLx[min(c0 + l3, cl)], lm1 = CLx[min(c0 + l3 + 21, cl)], lm2 = CLx[min(c0 + l3 + 42, cl)];
+        const unsigned a0 = CAx[min(c0 + lane / 2, cl)], a1 = CAx[min(c0 + lane / 2 + 32, cl)];
+        const unsigned b0 = CBx[min(c0 + lane / 2, cl)], b1 = CBx[min(c0 + lane / 2 + 32, cl)];
+        r.da = *reinterpret_cast<const double2*>(DI + lm0 * 48u + p3 * 16u);
+        r.db = *reinterpret_cast<const double2*>(DI + lm1 * 48u + p3 * 16u);
+        r.dc = *reinterpret_cast<const double2*>(DI + lm2 * 48u + p3 * 16u);
+        r.ga0 = *reinterpret_cast<const double2*>(WW + a0 * 32u + (lane & 1) * 16u);
+        r.ga1 = *reinterpret_cast<const double2*>(WW + a1 * 32u + (lane & 1) * 16u);
+        r.gb0 = *reinterpret_cast<const double2*>(WW + b0 * 32u + (lane & 1) * 16u);
+        r.gb1 = *reinterpret_cast<const double2*>(WW + b1 * 32u + (lane & 1) * 16u);
+        r.e01 = r.e2x = double2{ 0, 0 };
+        (void)G2;
 #else
         const double2* D2 = reinterpret_cast<const double2*>(v.Dinv + (size_t)e.lm * 6);
         r.da = D2[0]; r.db = D2[1]; r.dc = D2[2];
@@ -985,6 +1004,8 @@ __global__ __launch_bounds__(64 * STREAM_WAVES) __attribute__((amdgpu_waves_per_
     // a trip: (first contribution, the block's end, i, j | last << 31); none left: end = -1
 #if SCHUR_ABL == 1
     auto entry = [&](const trip4 D) { return ConPos{ D.x + lane, D.y, D.z }; };
+#elif SCHUR_ABL == 3
+    auto entry = [&](const trip4 D) { return ConPos{ D.x, max(D.y - 1, 0), D.z }; };
 #else
     auto entry = [&](const trip4 D) { return v.con_pos[max(min(D.x + lane, D.y - 1), 0)]; };
 #endif
@@ -1042,7 +1063,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES) __attribute__((amdgpu_waves_per_
         const bool diag = bi == bj;
         ++n_trips; n_diag += diag ? 1 : 0;
         if (D0.x + lane < D0.y) {
-#if SCHUR_ABL == 2
+#if SCHUR_ABL == 2 || SCHUR_ABL == 3
             acc[0] += (cur.da.x + cur.db.x + cur.dc.x) + (cur.ga0.x + cur.ga1.x) + (cur.gb0.x + cur.gb1.x) + (diag ? cur.e01.x + cur.e2x.x : 0.0) + ci.f + cj.f;
 #else
             const double2 da = cur.da, db = cur.db, dc = cur.dc, ga0 = cur.ga0, ga1 = cur.ga1, gb0 = cur.gb0, gb1 = cur.gb1;

@@ -114,12 +114,14 @@ def test_large_path_variants_match_oracle():
     _compare_with_oracle(s, False, [([1.8], 1e30), ([0.9], 1e30)], rtol=1e-6)
 
 
-def test_schur_stream_kernel_gives_the_per_block_kernel_s_bits():
-    """Maps of more than 2 048 Schur blocks: resident wavefronts working through per-compute-unit block lists (k_schur_stream, claims
+@pytest.mark.parametrize("shape", [(300, 9000, 90000, 0x5EED0B41), (150, 1500, 30000, 0x5EED0B42)], ids=["trajectory-300", "dense-overlap-150"])
+def test_schur_stream_kernel_gives_the_per_block_kernel_s_bits(shape):
+    """Maps of more than 2 048 Schur blocks (a 300-camera trajectory, ten views per point; 150 cameras with twenty views per point: twice as
+    many blocks, most of them a single trip): resident wavefronts working through per-compute-unit block lists (k_schur_stream, claims
     through an LDS counter: WHICH wavefront takes a block varies from run to run) against one wavefront per block
     (mage_ba_debug_schur_per_block): the same errors, outlier lists and state to the bit; the lists cover every block exactly once;
     and the oracle agrees with the stream kernel's result."""
-    s = scene.make_scene(n_cams=300, n_pts=9000, n_obs=90000, seed=0x5EED0B41, outlier_frac=0.01)
+    s = scene.make_scene(n_cams=shape[0], n_pts=shape[1], n_obs=shape[2], seed=shape[3], outlier_frac=0.01)
     plan = [([1.8], 25.0), ([0.9, 0.9], 16.0), ([0.9], 9.0)]
     res = []
     for per_block in (False, True, False):
