@@ -221,6 +221,39 @@ def test_two_processes_give_the_same_bits(tmp_path):
         assert np.array_equal(res[tag][0], res[ref][0]), tag
 
 
+def test_fresh_process_warm_up_thread_is_joined_whatever_the_caller_does(tmp_path):
+    """The first handle of a process makes the process's first asynchronous copy on a worker thread of mage_ba_create.
+    A fresh process that destroys its first handle at once, creates handles from four threads at the same moment, or steps at once must
+    neither hang nor differ from a process that was told not to warm up (MAGE_BA_NO_WARMUP=1)."""
+    import json, os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, json, threading
+        sys.path.insert(0, %r)
+        import numpy as np
+        from mageslam_amd import scene
+        from mageslam_amd.bundler import BundlerLib, load_scene
+        mode = sys.argv[1]
+        if mode == "destroy":
+            for _ in range(8): BundlerLib(False).close()
+        if mode == "threads":
+            hs = []
+            th = [threading.Thread(target=lambda: hs.append(BundlerLib(False))) for _ in range(4)]
+            [t.start() for t in th]; [t.join() for t in th]
+            [h.close() for h in hs]
+        s = scene.make_scene(n_cams=120, n_pts=3000, n_obs=30000, seed=0x5EED0B51, outlier_frac=0.01)
+        b = BundlerLib(False); load_scene(b, s, bulk=True)
+        o = []; mse = b.StepBundleAdjustment([1.8, 0.9], 16.0, o)
+        print("RESULT " + json.dumps([float(mse), sorted(o), b.poses_f64().tobytes().hex()[:4096]]))
+    """) % root
+    res = {}
+    for tag, mode, env in (("plain", "step", {}), ("destroy", "destroy", {}), ("threads", "threads", {}), ("cold", "step", {"MAGE_BA_NO_WARMUP": "1"})):
+        p = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+        res[tag] = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    assert res["plain"] == res["cold"] == res["destroy"] == res["threads"]
+
+
 def test_concurrent_handles_on_separate_threads():
     """SURVEY 8b threading contract: every BundlerLib instance is thread-confined, several run concurrently on different
     threads (mapping, loop closure, tracking).  Four handles, each on its own thread and HIP stream, interleaved on one
