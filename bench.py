@@ -906,7 +906,7 @@ def main() -> int:
         tot_ms = sum(ms for ms, _ in stages.values())
         tot_b = sum(by for _, by in stages.values())
         line["roofline_hbm"] = {
-            "kernels": "k_small_linearize in its large-problem form (residuals + landmark side with 8 lanes per landmark + camera side, one launch) | k_schur_prepare (skyline zero-fill + landmark inverses + the fold of the linearisation's chi2 partials, one launch) + k_schur_block_compact (its diagonal blocks also give the reduced rhs) | k_pose_update + k_backsub (which also evaluates the trial's residuals) + k_reduce_sum; "
+            "kernels": "k_small_linearize in its large-problem form (residuals + landmark side with 8 lanes per landmark + camera side, one launch) | k_schur_prepare (skyline zero-fill + landmark inverses + the fold of the linearisation's chi2 partials, one launch) + k_schur_stream (resident wavefronts working through per-compute-unit block lists; its diagonal blocks also give the reduced rhs) | k_pose_update + k_backsub (which also evaluates the trial's residuals) + k_reduce_sum; "
                        f"HIP-event spans on the solver stream, per LM iteration with one trial, over {STAGE_STEPS} further steps of the same handle right "
                        "after the timed region (seven event records per trial cost idle stream time: the timed region keeps only the factorisation's pair)",
             "bound": "hbm", "achieved": tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -15,7 +15,7 @@ import sys
 
 STAGES = {
     "linearize": ["k_small_linearize", "k_linearize_lm", "k_linearize_cam", "k_error"],       # k_error: only its current-estimate launches (separate path)
-    "schur_build": ["k_zero_lower", "k_zero_skyline", "k_lm_invert", "k_schur_prepare", "k_schur_block", "k_schur_block_compact", "k_schur_rhs"],
+    "schur_build": ["k_zero_lower", "k_zero_skyline", "k_lm_invert", "k_schur_prepare", "k_schur_block", "k_schur_block_compact", "k_schur_stream", "k_schur_rhs"],
     "backsubst_and_trial_error": ["k_backsub", "k_pose_update", "k_error"],
 }
 
