@@ -1269,7 +1269,7 @@ mage_status lm_solve(mage_ba* h, double huber, int* result, PostPassPlan* plan =
         const bool lpt = v.n_blk_slots > 0;          // every XCD's run of blocks longest first (slot_order)
         if (lpt) MAGE_TRY(h->d_slot_order.reserve((size_t)v.n_blk_slots + 8));
         // the Schur blocks as streams of trips taken by resident wavefronts (k_schur_stream); MAGE_BA_SCHUR_BLOCKS=1: one wavefront per block (A/B)
-        const bool stream = lpt && !h->schur_per_block && v.n_blk > SCHUR_SPLIT_BLOCKS_BELOW;
+        const bool stream = lpt && !h->schur_per_block && v.n_blk > SCHUR_SPLIT_BLOCKS_BELOW && ba_schur_stream_groups(h->n_cu) >= 8;
         const int soa_pitch = (int)((h->n_con + 63) & ~(size_t)63);
         if (stream) MAGE_TRY(h->d_con_soa.reserve((size_t)soa_pitch * 3 + 64));
         ba_launch_build_positions(v, h->d_w_pos.p, h->d_pos_lm.p, h->d_con_pos.p, lpt ? h->d_slot_order.p : nullptr, stream ? h->d_con_soa.p : nullptr, soa_pitch, st);
