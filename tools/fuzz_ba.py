@@ -5,7 +5,7 @@ seen once the damping alone fixes their depth and HIP and oracle drift apart by 
 shuffled / thinned / duplicated observations, random fixed flags, tethers, points fixed or free, several calls with shrinking outlier thresholds -- HIP against the
 CPU oracle with the comparisons of tests/test_ba_gpu.py (outlier lists identical, LM trace identical, state to 1e-8).
 
-    python tools/fuzz_ba.py [--cases 200] [--seed 1]
+    python tools/fuzz_ba.py [--cases 200] [--seed 1] [--big]
 """
 import argparse
 import os
@@ -22,10 +22,14 @@ from mageslam_amd import scene  # noqa: E402
 import test_ba_gpu as T  # noqa: E402
 
 
-def one(case, rng):
+def one(case, rng, big=False):
     n_cams = int(rng.choice([2, 3, 5, 8, 13, 20, 30, 45, 60]))
     n_pts = int(rng.integers(6, 40 * max(n_cams, 2)))
-    K = int(rng.integers(2, min(n_cams, 8) + 1))          # every point seen at least twice: single views leave the depth to the damping alone
+    K = int(rng.integers(2, min(n_cams, 8) + 1))
+    if big:          # maps of more than 2 048 Schur blocks (the large-problem launch sequence with k_schur_stream), tiled dense solve
+        n_cams = int(rng.choice([110, 150, 190, 230]))
+        K = int(rng.choice([8, 12, 16, 20]))
+        n_pts = int(rng.integers(6 * n_cams, 14 * n_cams))          # every point seen at least twice: single views leave the depth to the damping alone
     s = scene.make_scene(n_cams=n_cams, n_pts=n_pts, n_obs=n_pts * K, seed=0x5EED9000 + case, fixed=(), outlier_frac=float(rng.choice([0.0, 0.02, 0.1])))
     idx = rng.permutation(s.n_obs)
     idx = idx[rng.random(s.n_obs) > rng.choice([0.0, 0.05, 0.1])]
@@ -78,13 +82,14 @@ def one(case, rng):
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=200); ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="110-230 cameras, 8-20 views per point: more than 2 048 Schur blocks")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     bad = skipped = 0
     t0 = time.time()
     for c in range(a.cases):
         try:
-            r = one(a.seed * 100000 + c, rng)
+            r = one(a.seed * 100000 + c, rng, a.big)
             skipped += r is not None
         except AssertionError:
             bad += 1
