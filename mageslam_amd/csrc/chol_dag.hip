@@ -371,14 +371,6 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagArgs a)
 
     if (blockIdx.x == 0) {
         // ================= the chain workgroup =================
-        if (wave >= 4) {
-            // the other four wavefronts open the solve -- x pre-filled with the sentinel the backward substitution polls for -- and leave
-            // (the hardware barrier below then counts the four that stay)
-            unsigned long long* xf = reinterpret_cast<unsigned long long*>(a.x);
-            unsigned long long* pf = reinterpret_cast<unsigned long long*>(a.part);       // ... and the backward solve's partial sums (same protocol)
-            for (int i = tid - 256; i < nt * TILE; i += 256) { xf[i] = X_SENTINEL; pf[i] = X_SENTINEL; }
-            return;
-        }
         if (tid == 0) { *a.ok = 1.0; *a.stall = 0.0; }
         double* A = sm;                            // LayPacked: the 36 lower blocks
         double* Li = sm + PACKED_TILE_DOUBLES;     // 2 x (16 x 16)
@@ -395,18 +387,25 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagArgs a)
             }
             double* T = a.S + (size_t)(k * TILE) * ld + (size_t)k * TILE;
             if (tid == 0) DAG_STAMP(4 * (size_t)a.n_tasks + 2 * k);
-            load_tile_packed_wt(A, T, ld, tid);
+            load_tile_packed_wt<DAG_THREADS>(A, T, ld, tid);
             __syncthreads();
             // block column by block column to the scratch copy + ONE progress word (potrf_tile_lds<.., 4>): the strips next to the chain work
             // in phases behind it; every strip reads L_kk from that copy and the block inverses, so the flag goes up as soon as those are in
             // memory and the factor itself goes to S afterwards, off the chain (the backward solve reads it there, a launch later)
-            const bool failed = potrf_tile_lds<false, LayPacked, 4>(A, Li, a.Linv + (size_t)k * linv_stride, tid, NBLK,
+            const bool failed = potrf_tile_rows<false, LayPacked, 4, DAG_THREADS / 64>(A, Li, a.Linv + (size_t)k * linv_stride, tid, NBLK,
                                                                      TilePublish{ a.Lpub + (size_t)k * LPUB_TILE_DOUBLES, st + D_PROG, 8 * k });
             if (tid == 0 && failed) *a.ok = 0.0;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) { st_word(st + D_FACT, k + 1); DAG_STAMP(4 * (size_t)a.n_tasks + 2 * k + 1); }
-            store_tile_packed_wt(T, A, ld, tid);
+            store_tile_packed_wt<DAG_THREADS>(T, A, ld, tid);
+            if (k == 0) {
+                // the chain opens the solve while it waits for tile 1: x pre-filled with the sentinel the backward substitution polls for,
+                // and the backward solve's partial sums (same protocol)
+                unsigned long long* xf = reinterpret_cast<unsigned long long*>(a.x);
+                unsigned long long* pf = reinterpret_cast<unsigned long long*>(a.part);
+                for (int i = tid; i < nt * TILE; i += DAG_THREADS) { xf[i] = X_SENTINEL; pf[i] = X_SENTINEL; }
+            }
             __syncthreads();                 // (the tile's LDS is read by the store until here; the next tile overwrites it)
         }
         return;

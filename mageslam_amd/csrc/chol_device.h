@@ -286,7 +286,7 @@ __device__ __forceinline__ double load_through(const double* p)
 }
 
 #ifdef CHOL_TILE_STAMPS        // tools/potrf_probe.hip: shader-clock stamps of every wavefront at the five points of an in-tile iteration
-__device__ long long g_tile_stamps[4][NBLK][5];
+__device__ long long g_tile_stamps[8][NBLK][5];
 #define TILE_STAMP(p) do { if (lane == 0) g_tile_stamps[wave][s][p] = clock64(); } while (0)
 #else
 #define TILE_STAMP(p) do { } while (0)
@@ -403,6 +403,238 @@ __device__ __forceinline__ bool potrf_tile_lds(double* __restrict__ A, double* _
     return failed;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same tile factorisation with the rows BELOW the pivot block carried through the pivot recurrence (round 6).
+// fl_column's second register set x[] obeys  x[c] -= x[j] L[c][j],  x[j] *= 1 / L[j][j]  with the coefficient taken from the lane's own
+// 16-lane row (row_newbcast), and the four rows of a wavefront hold identical copies of a[].  So x[] may hold something DIFFERENT in
+// each of the four rows at no cost in instructions: a row of the identity gives a column of the block inverse (what the lean form
+// computes four times over), and row l of a sub-diagonal block B(i, s) gives row l of Y(i, s) = B(i, s) L_ss^-T -- the strip, solved by
+// substitution inside the recurrence instead of as a product with the inverse behind it.  Two wavefronts carry all of an in-tile step:
+//     wavefront 0   rows: strip 0 | identity | strip 1 | strip 2          wavefront 1   rows: strips 3 | 4 | 5 | 6
+// (wavefront 1 repeats the pivot block's own recurrence: redundant, but beside wavefront 0, not behind it).  What the lean form had on
+// the critical path behind the pivot block -- barrier, four dependent matrix operations for strip 0, four more for the next diagonal
+// block, an LDS round trip either side -- shrinks to: barrier, ONE set of four matrix operations per block of column s + 1 (the k = s
+// term; the terms k < s were summed into the block by the idle wavefronts during the recurrence, left-looking), barrier.
+// The strips' bits differ from the lean form's (a substitution instead of a product with a rounded inverse: the residual is that of a
+// textbook trsm); the block inverses are the lean form's to the bit.
+template <int PITCH>
+__device__ __forceinline__ bool factor_block16_rows(double* __restrict__ A, int boff, int poff, int pst, int lane, bool store_l)
+{
+    const int l = lane & 15;
+    double* __restrict__ B = A + boff;
+    double* __restrict__ P = A + poff;          // this lane's payload row: element c at P[c * pst]
+    double a[NB], x[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) { a[c] = B[c * PITCH + l]; x[c] = P[c * pst]; }
+    double dmin = 1.0;
+    fl_columns<0>(a, x, dmin);
+    dmin = (l == NB - 1 && !(fabs(a[NB - 1]) < __builtin_huge_val())) ? -1.0 : 1.0;
+    if (store_l && lane < NB) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) B[c * PITCH + l] = a[c];
+    }
+#pragma unroll
+    for (int c = 0; c < NB; ++c) P[c * pst] = x[c];
+    return __builtin_amdgcn_ballot_w64(!(dmin > 0.0)) != 0;
+}
+
+// two blocks of column bj in one go: (bi0, bj) and (bi1, bj) -= X(bi, bp) X(bj, bp)^T, the operand of bj shared, the two chains interleaved
+template <class LAY>
+__device__ __forceinline__ void lds_update_tile2(double* __restrict__ A, int bi0, int bi1, int bj, int bp, int lane)
+{
+    double* C0 = A + LAY::blk(bi0, bj);
+    double* C1 = A + LAY::blk(bi1, bj);
+    const double* Xa = A + LAY::blk(bj, bp);
+    const double* Xb0 = A + LAY::blk(bi0, bp);
+    const double* Xb1 = A + LAY::blk(bi1, bp);
+    double4_t acc0, acc1;
+    double aop[4], b0[4], b1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { aop[r] = -Xa[frag<LAY>(r, lane)]; b0[r] = Xb0[frag<LAY>(r, lane)]; b1[r] = Xb1[frag<LAY>(r, lane)]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc0[r] = C0[frag<LAY>(r, lane)]; acc1[r] = C1[frag<LAY>(r, lane)]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[r], b0[r], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[r], b1[r], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { C0[frag<LAY>(r, lane)] = acc0[r]; C1[frag<LAY>(r, lane)] = acc1[r]; }
+}
+
+// Up to MB blocks of column bj at once, left-looking: block (i0 + b * istep, bj) -= sum over kb < nk of X(i, kb) X(bj, kb)^T, the operand of
+// bj shared, the blocks' chains interleaved, block column kb + 1's operands in flight behind block column kb's products (a lone wavefront
+// has nothing else to cover an LDS round trip or a matrix operation's latency with).
+template <class LAY, int MB>
+__device__ __forceinline__ void lds_update_multi_left(double* __restrict__ A, int i0, int istep, int nb, int bj, int nk, int lane)
+{
+    double4_t acc[MB];
+    double aop[2][4], bop[2][MB][4];
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+        if (b < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[b][r] = A[LAY::blk(i0 + b * istep, bj) + frag<LAY>(r, lane)];
+        }
+    auto fetch = [&](int kb, int slot) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) aop[slot][r] = -A[LAY::blk(bj, kb) + frag<LAY>(r, lane)];
+#pragma unroll
+        for (int b = 0; b < MB; ++b)
+            if (b < nb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bop[slot][b][r] = A[LAY::blk(i0 + b * istep, kb) + frag<LAY>(r, lane)];
+            }
+    };
+    auto products = [&](int slot) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int b = 0; b < MB; ++b)
+                if (b < nb) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[slot][r], bop[slot][b][r], acc[b], 0, 0, 0);
+    };
+    fetch(0, 0);
+    for (int kb = 0; kb < nk; kb += 2) {
+        if (kb + 1 < nk) fetch(kb + 1, 1);
+        products(0);
+        if (kb + 1 < nk) {
+            if (kb + 2 < nk) fetch(kb + 2, 0);
+            products(1);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+        if (b < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[LAY::blk(i0 + b * istep, bj) + frag<LAY>(r, lane)] = acc[b][r];
+        }
+}
+
+// PUBLISH as in potrf_tile_lds; the progress word reaches base + c once block column c AND the inverse of block c are in memory
+// (the strips behind the chain need exactly those, trsm_strip_phased), raised an in-tile iteration after the stores were issued.
+// NW = 4 or 8 wavefronts call it (tid 0 .. 64 NW - 1).  A v_mfma_f64_16x16x4 holds its SIMD's matrix pipe for 64 cycles, so what the
+// helpers can sum beside a 3 300-cycle recurrence is bounded by the number of SIMDs they run on: with four wavefronts two (three from
+// iteration 4 on) share the left-looking sums and the publishing and are late at the barrier in iterations 1-4; with eight, six do --
+// a block each -- two of them on the matrix pipes of the recurrence wavefronts' own SIMDs, which the recurrence never uses.
+template <bool PARTIAL, class LAY, int PUBLISH = 0, int NW = 4>
+__device__ __forceinline__ bool potrf_tile_rows(double* __restrict__ A, double* __restrict__ Li, double* __restrict__ Linv_k, int tid, int nblk = NBLK,
+                                             TilePublish pub = TilePublish{})
+{
+    static_assert(PUBLISH == 0 || PUBLISH == 1 || PUBLISH == 4, "publish forms: 0 plain, 1 write-through inverses, 4 phased");
+    static_assert(NW == 4 || NW == 8, "four or eight wavefronts");
+    const int NBK = PARTIAL ? nblk : NBLK;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = lane & 15, g = lane >> 4;
+    const int li_off = (int)(Li - A);
+    bool failed = false;
+    // the identity the inverse of block 0 grows from (slot 0; slot (s + 1) & 1 is refilled in iteration s, below)
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int e = lane * 4 + q; Li[e] = (e >> 4) == (e & 15) ? 1.0 : 0.0; }
+    }
+    // wavefront 3: the inverse of block c (slot c & 1 of Li) and the blocks of column c below the diagonal, out of LDS to memory (4 + 4 (NBK - 1 - c)
+    // stores per lane); issued at the top of iteration c + 1, beside the recurrence.
+    auto publish = [&](int c) {
+        const double* Lc = Li + (c & 1) * NB * NB;
+        if (PUBLISH) {
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = Lc[lane * 4 + q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) store_through(Linv_k + c * NB * NB + lane * 4 + q, v[q]);
+        } else {
+            const double4_t v = *reinterpret_cast<const double4_t*>(Lc + lane * 4);
+            *reinterpret_cast<double4_t*>(Linv_k + c * NB * NB + lane * 4) = v;
+        }
+        if (PUBLISH == 4) {
+            // (two blocks' reads in flight, then their stores: behind an atomic store the compiler waits for every LDS read it issues)
+            for (int i = c + 1; i < NBK; i += 2) {
+                const bool two = i + 1 < NBK;
+                const double* B0 = A + LAY::blk(i, c);
+                const double* B1 = A + LAY::blk(two ? i + 1 : i, c);
+                double* G0 = pub.Lpub + (size_t)(i * (i - 1) / 2 + c) * NB * NB;
+                double* G1 = pub.Lpub + (size_t)((i + 1) * i / 2 + c) * NB * NB;
+                double v0[4], v1[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v0[r] = B0[frag<LAY>(r, lane)]; v1[r] = B1[frag<LAY>(r, lane)]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) store_through(G0 + (4 * r + (lane >> 4)) * NB + (lane & 15), v0[r]);
+                if (two) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) store_through(G1 + (4 * r + (lane >> 4)) * NB + (lane & 15), v1[r]);
+                }
+            }
+        }
+    };
+    // PUBLISH == 4, the end of wavefront 3's share of iteration s >= 2 (it has time until wavefront 0 reaches the barrier): column s - 2 went
+    // out a whole iteration and most of this one ago (~3 us; a write-through store is acknowledged after ~2) -- wait for everything but
+    // the `newer` stores issued in this iteration (a wavefront's stores complete in order) and raise the progress word.
+    auto raise = [&](int c, int newer) {
+        switch (newer >> 2) {
+            case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+        if (lane == 0) __hip_atomic_store(pub.progress, pub.base + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    for (int s = 0; s < NBK; ++s) {
+        const int nstr = NBK - 1 - s;                      // strips below block s
+        TILE_STAMP(0);
+        // ---- the recurrence (wavefronts 0, 1) beside the left-looking sums of block column s + 1 over k < s (the others)
+        const int nrec = nstr > 3 ? 2 : 1;                 // wavefronts inside the recurrence
+        if (wave < nrec) {
+            const int p = 4 * wave + g;                    // payload of this 16-lane row: 0 strip 0, 1 the identity, p >= 2 strip p - 1
+            const int t = p == 0 ? 0 : p - 1;
+            // (a row without a strip of its own repeats a payload of its wavefront -- the identity on wavefront 0, strip 3 on wavefront 1:
+            // same bits to the same place from the same instruction)
+            const bool strip = wave == 1 || (p != 1 && t < nstr);
+            const int tt = (wave == 1 && t >= nstr) ? 3 : t;
+            const int poff = strip ? LAY::blk(s + 1 + tt, s) + l : li_off + (s & 1) * NB * NB + l;
+            const int pst = strip ? LAY::PITCH : NB;
+            const bool f = factor_block16_rows<LAY::PITCH>(A, LAY::blk(s, s), poff, pst, lane, wave == 0);
+            if (wave == 0) failed |= f;
+        } else {
+            if (wave == 3 && s >= 1) publish(s - 1);             // column s - 1 and the inverse of block s - 1 go out beside the recurrence
+            if (s >= 1 && nstr > 0) {
+                // helpers in the order they are dealt blocks: the publisher late, the wavefronts that share a SIMD with the recurrence last
+                const int nh = NW - nrec;
+                const int hr = NW == 4 ? wave - nrec : (wave == 2 ? 0 : wave == 6 ? 1 : wave == 7 ? 2 : wave == 3 ? 3 : wave == 4 ? 4 : wave == 5 ? 5 : 6);
+                const int first = s + 1 + hr;
+                const int nb = first < NBK ? (NBK - 1 - first) / nh + 1 : 0;
+                if (nb > 0) lds_update_multi_left<LAY, (NW == 4 ? 3 : 1)>(A, first, nh, nb, s + 1, s, lane);
+            }
+            if (PUBLISH == 4 && wave == 3 && s >= 2) raise(s - 2, 4 + 4 * (NBK - s));
+        }
+        TILE_STAMP(1);
+        tile_barrier<PUBLISH != 0>();                      // (A) column s of L and the inverse of block s are in LDS
+        TILE_STAMP(2);
+        if (nstr == 0) {
+            if (wave == 3) publish(s);                     // the last inverse: nothing left to hide it behind (the caller waits for the stores)
+            break;
+        }
+        // ---- the k = s term of block column s + 1, dealt over the four wavefronts (wavefront 0: the next diagonal block)
+        {
+            // (wavefront 0, the first into the next recurrence, takes the diagonal block alone)
+            const int i0 = s + 1 + wave, i1 = (wave == 0 || NW == 8) ? NBK : i0 + 3;
+            if (i1 < NBK) lds_update_tile2<LAY>(A, i0, i1, s + 1, s, lane);
+            else if (i0 < NBK) lds_update_tile<LAY>(A, i0, s + 1, s, lane);
+        }
+        if (wave == (NW == 8 ? 7 : 2)) {                   // the identity for the inverse of block s + 1 (slot (s + 1) & 1: the inverse of block s - 1 left it in iteration s - 1)
+            double* Ln = Li + ((s + 1) & 1) * NB * NB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int e = lane * 4 + q; Ln[e] = (e >> 4) == (e & 15) ? 1.0 : 0.0; }
+        }
+        TILE_STAMP(3);
+        tile_barrier<PUBLISH != 0>();                      // (B) block column s + 1 stands at k = s
+        TILE_STAMP(4);
+    }
+    return failed;
+}
+
 // Global <-> LDS copies of a diagonal tile for LayPacked: the 36 lower blocks, 128-bit pieces along a block's columns, 18 per thread in
 // two batches (the strict upper part of S is never read or written).
 __device__ __forceinline__ void block_of_index(int t, int& rb, int& cb)          // t = rb (rb + 1) / 2 + cb, 0 <= t < 36
@@ -447,33 +679,35 @@ __device__ __forceinline__ void store_tile_packed(double* __restrict__ T, const 
 // this compute unit's L1, so the consumer of sc1-stored data needs no acquire fence (MI355X_MICROARCH.md, "Workgroup dispatch, XCD
 // placement & inter-workgroup visibility").  T must be wave-uniform (it is: kernel arguments and blockIdx only).
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <int NT = 256>
 __device__ __forceinline__ void load_tile_packed_wt(double* __restrict__ dst, const double* __restrict__ T, int ld, int tid)
 {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(T), 0, (int)((size_t)TILE * ld * sizeof(double)), 0x00020000);
     constexpr int PIECES = PACKED_TILE_DOUBLES / 2, BATCH = 9;
 #pragma unroll
-    for (int b0 = 0; b0 < PIECES / 256; b0 += BATCH) {
+    for (int b0 = 0; b0 < PIECES / NT; b0 += BATCH) {
         u32x4_t v[BATCH];
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int e = (b0 + u) * 256 + tid, t = e >> 7, w = e & 127;
+            const int e = (b0 + u) * NT + tid, t = e >> 7, w = e & 127;
             int rb, cb;
             block_of_index(t, rb, cb);
             v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((size_t)(cb * NB + (w >> 3)) * ld + rb * NB + 2 * (w & 7)) * sizeof(double)), 0, 16);
         }
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int e = (b0 + u) * 256 + tid;
+            const int e = (b0 + u) * NT + tid;
             *reinterpret_cast<u32x4_t*>(dst + 2 * e) = v[u];
         }
     }
 }
+template <int NT = 256>
 __device__ __forceinline__ void store_tile_packed_wt(double* __restrict__ T, const double* __restrict__ A, int ld, int tid)
 {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(T, 0, (int)((size_t)TILE * ld * sizeof(double)), 0x00020000);
 #pragma unroll 6
-    for (int b0 = 0; b0 < PACKED_TILE_DOUBLES / 2 / 256; ++b0) {
-        const int e = b0 * 256 + tid, t = e >> 7, w = e & 127;
+    for (int b0 = 0; b0 < PACKED_TILE_DOUBLES / 2 / NT; ++b0) {
+        const int e = b0 * NT + tid, t = e >> 7, w = e & 127;
         int rb, cb;
         block_of_index(t, rb, cb);
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4_t*>(A + 2 * e), rsrc,

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int 
     double* T = S + (size_t)(k * TILE) * ld + (size_t)k * TILE;
     load_tile_packed(A, T, ld, tid);
     __syncthreads();
-    const bool failed = potrf_tile_lds<false, LayPacked>(A, Li, Linv_k, tid);
+    const bool failed = potrf_tile_rows<false, LayPacked>(A, Li, Linv_k, tid);
     store_tile_packed(T, A, ld, tid);
     if (tid == 0 && failed) *ok = 0.0;
 }
@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256) void k_syrk_update(double* __restrict__ S, dou
         double* T = S + (size_t)(j0 * TILE) * ld + (size_t)j0 * TILE;
         load_tile_packed_wt(A, T, ld, tid);
         __syncthreads();
-        const bool failed = MERGED ? potrf_tile_lds<false, LayPacked, 4>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid, NBLK, TilePublish{ Lpub_next, flag + 4, 8 * j0 })
-                                   : potrf_tile_lds<false, LayPacked, 0>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
+        const bool failed = MERGED ? potrf_tile_rows<false, LayPacked, 4>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid, NBLK, TilePublish{ Lpub_next, flag + 4, 8 * j0 })
+                                   : potrf_tile_rows<false, LayPacked, 0>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
         if (tid == 0 && failed) *ok = 0.0;
         if (MERGED) {
             // the strips read the published blocks and the block inverses, all written through: raise the flag FIRST, the factor itself goes
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update2(double* __restrict__ S,
         double* T = S + (size_t)(j0 * TILE) * ld + (size_t)j0 * TILE;
         load_tile_packed(A, T, ld, tid);
         __syncthreads();
-        const bool failed = potrf_tile_lds<false, LayPacked>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
+        const bool failed = potrf_tile_rows<false, LayPacked>(A, sm + PACKED_TILE_DOUBLES, Linv_next, tid);
         store_tile_packed(T, A, ld, tid);
         if (tid == 0 && failed) *ok = 0.0;
         return;
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void k_small_solve(const double* __restrict__ 
     }
     for (int i = tid; i < np; i += 256) rhs[i] = y[i];
     __syncthreads();
-    const bool failed = potrf_tile_lds<true, LayLDC>(A, Li, Linv, tid, nblk);
+    const bool failed = potrf_tile_rows<true, LayLDC>(A, Li, Linv, tid, nblk);
     __threadfence_block();
     __syncthreads();
     // forward substitution L z = rhs (four partial sums per product: a dependent f64 FMA costs ~25 cycles on a lone wavefront)

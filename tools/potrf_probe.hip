@@ -9,12 +9,15 @@
 #include <vector>
 using namespace mage;
 namespace mage { namespace {
-__global__ __launch_bounds__(256) void k_probe(const double* __restrict__ S, int ld, double* __restrict__ Linv, long long* __restrict__ out)
+#ifndef PROBE_NW
+#define PROBE_NW 4
+#endif
+__global__ __launch_bounds__(64 * PROBE_NW) void k_probe(const double* __restrict__ S, int ld, double* __restrict__ Linv, long long* __restrict__ out)
 {
     extern __shared__ double sm[];
     double* A = sm; double* Li = sm + PACKED_TILE_DOUBLES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    load_tile_packed(A, S, ld, tid);                             // the library's layout of a diagonal tile (LayPacked)
+    if (tid < 256) load_tile_packed(A, S, ld, tid);              // the library's layout of a diagonal tile (LayPacked)
     __syncthreads();
     long long t0 = clock64();
     bool f = false;
@@ -22,13 +25,22 @@ __global__ __launch_bounds__(256) void k_probe(const double* __restrict__ S, int
     long long t1 = clock64();
     __syncthreads();
     long long t2 = clock64();
-    load_tile_packed(A, S, ld, tid);
+    if (tid < 256) load_tile_packed(A, S, ld, tid);
     __syncthreads();
     long long t3 = clock64();
+#ifdef PROBE_LEAN
     f |= potrf_tile_lds<false, LayPacked>(A, Li, Linv, tid);
+#else
+#ifdef PROBE_PUBLISH
+    f |= potrf_tile_rows<false, LayPacked, 4, PROBE_NW>(A, Li, Linv, tid, NBLK, TilePublish{ Linv + 8 * 256, reinterpret_cast<int*>(out + 8), 0 });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    f |= potrf_tile_rows<false, LayPacked, 0, PROBE_NW>(A, Li, Linv, tid);
+#endif
+#endif
     long long t4 = clock64();
     __syncthreads();
-    store_tile_packed(const_cast<double*>(S) + (size_t)ld * ld, A, ld, tid);      // second ld x ld matrix of the buffer receives L
+    if (tid < 256) store_tile_packed(const_cast<double*>(S) + (size_t)ld * ld, A, ld, tid);      // second ld x ld matrix of the buffer receives L
     if (tid == 0) { out[0] = t1 - t0; out[1] = t2 - t1; out[2] = t4 - t3; out[3] = f; }
     if (tid == 64) { out[4] = t1 - t0; }
 }
@@ -41,12 +53,12 @@ int main()
     for (int j = 0; j < n; ++j) for (int i = j; i < n; ++i) { double v = (double)rand() / RAND_MAX - 0.5; A[(size_t)j * n + i] = v; A[(size_t)i * n + j] = v; }
     for (int i = 0; i < n; ++i) A[(size_t)i * n + i] = 70.0;
     double *dS, *dL; long long* dout;
-    hipMalloc(&dS, sizeof(double) * n * n * 2); hipMalloc(&dL, sizeof(double) * 8 * 256); hipMalloc(&dout, 64);
+    hipMalloc(&dS, sizeof(double) * n * n * 2); hipMalloc(&dL, sizeof(double) * (8 * 256 + LPUB_TILE_DOUBLES)); hipMalloc(&dout, 128);
     hipMemcpy(dS, A.data(), sizeof(double) * n * n, hipMemcpyHostToDevice);
     const size_t lds = ((size_t)PACKED_TILE_DOUBLES + 2 * NB * NB) * sizeof(double);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     for (int r = 0; r < 3; ++r) {
-        hipLaunchKernelGGL(k_probe, dim3(1), dim3(256), lds, 0, dS, n, dL, dout);
+        hipLaunchKernelGGL(k_probe, dim3(1), dim3(64 * PROBE_NW), lds, 0, dS, n, dL, dout);
         hipDeviceSynchronize();
         long long o[5]; hipMemcpy(o, dout, 40, hipMemcpyDeviceToHost);
         printf("factor chol %lld cycles (inverse wave %lld), barrier %lld, potrf_tile_lds %lld cycles, failed %lld\n", o[0], o[4], o[1], o[2], o[3]);
