@@ -5,8 +5,8 @@
 // idles behind the chain (profiles/HISTORY.md, rounds 2-4; tools/chol_dag_sim.py prices the alternatives).  Here the whole
 // factorisation is a graph of tile tasks taken from a STATIC list by whichever team is free, behind dependency counters:
 //
-//   chain workgroup   (block 0, wavefronts 0-3; the other four leave): for k = 0 .. nt-1: wait for the nine arrivals at diagonal tile
-//                     k, pull it into LDS, factor it (potrf_tile_lds), write L_kk and its block inverses through, raise `fact`.
+//   chain workgroup   (block 0, all eight wavefronts: two carry the pivot recurrence, six sum beside it): for k = 0 .. nt-1: wait for the nine arrivals at diagonal tile
+//                     k, pull it into LDS, factor it (potrf_tile_rows), write L_kk and its block inverses through, raise `fact`.
 //   worker teams      every other workgroup = two teams of four wavefronts (512 threads, one workgroup per compute unit, <= 256
 //                     registers: two wavefronts per SIMD, the shape in which the trailing update runs best).  A team's leader takes
 //                     the next task of the list (one returning atomic), polls the task's dependency words, and the team runs it:
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagArgs a)
             if (tid == 0) DAG_STAMP(4 * (size_t)a.n_tasks + 2 * k);
             load_tile_packed_wt<DAG_THREADS>(A, T, ld, tid);
             __syncthreads();
-            // block column by block column to the scratch copy + ONE progress word (potrf_tile_lds<.., 4>): the strips next to the chain work
+            // block column by block column to the scratch copy + ONE progress word (potrf_tile_rows<.., 4>): the strips next to the chain work
             // in phases behind it; every strip reads L_kk from that copy and the block inverses, so the flag goes up as soon as those are in
             // memory and the factor itself goes to S afterwards, off the chain (the backward solve reads it there, a launch later)
             const bool failed = potrf_tile_rows<false, LayPacked, 4, DAG_THREADS / 64>(A, Li, a.Linv + (size_t)k * linv_stride, tid, NBLK,
@@ -570,6 +570,9 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagArgs a)
 // The schedule: list scheduling of the task graph in simulated time (costs in us from the stamps of tools/_bin/chol_test_trace).
 // ---------------------------------------------------------------------------------------------
 struct SimCosts {
+    // (round 5's measured costs, kept as the ORDER they produce: with the round-6 tile factorisation -- potrf 17, early 7 -- the launch
+    // measured the same, 1.967 against 1.972 ms at 47 tile columns, and one random skyline of tests/test_chol_schedule.py gave lists that
+    // check_schedule rejects, i.e. a launch that would fall back to column-by-column)
     double potrf = 21.5;                  // tile -> LDS, in-tile factorisation, publication drained, flag
     double early = 9.0;                   // into the tile: block columns 0-3 are published (the phased strips' first phase may start)
     double strips4 = 12.0, tail = 4.5;    // four strips of a tile by one team (a wavefront each); phased: ends no earlier than `tail` after the tile is factored

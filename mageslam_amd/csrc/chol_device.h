@@ -33,9 +33,10 @@ struct LayPacked {
 constexpr int PACKED_TILE_DOUBLES = (NBLK * (NBLK + 1) / 2) * NB * NB;      // 9216
 
 // ---------------------------------------------------------------------------------------------
-// 16x16 diagonal block: Cholesky in registers by one wavefront, together with the inverse of the factor.
-// Lane l (mod 16; the four 16-lane rows of the wavefront run identical copies) owns ROW l of the block (a[c] = A[l][c])
-// and COLUMN l of L^-1 (x[c] = Linv[c][l]).  Both recurrences are
+// 16x16 diagonal block: Cholesky in registers by one wavefront, together with a second register set x[] that obeys the same recurrence.
+// Lane l (mod 16; the four 16-lane rows of the wavefront hold identical copies of a[]) owns ROW l of the block (a[c] = A[l][c]); x[] is,
+// per 16-lane row, COLUMN l of L^-1 (x[c] = Linv[c][l], from a row of the identity) or ROW l of a block below the pivot block (which
+// comes out as the strip solved by substitution): factor_block16_rows, below.  Both recurrences are
 //     a[c] -= a[j] * L[c][j],   x[c] -= x[j] * L[c][j]      (c > j),        a[j], x[j] *= 1 / L[j][j]
 // and the coefficient L[c][j] is lane c's a[j]: it enters the FMA as a DPP operand (row_newbcast:c -- the only DPP
 // control gfx90a+ allows on 64-bit operations, and exactly the one needed), so an update is ONE v_fmac_f64_dpp with no
@@ -144,30 +145,6 @@ __device__ __forceinline__ void fl_columns(double (&a)[NB], double (&x)[NB], dou
 {
     if constexpr (J < NB) { fl_column<J>(a, x, dmin); fl_columns<J + 1>(a, x, dmin); }
 }
-template <int PITCH>
-__device__ __forceinline__ bool factor_block16_lean(double* __restrict__ B, int lane, double* __restrict__ Li, double* __restrict__ Linv_out)
-{
-    const int l = lane & 15;
-    double a[NB], x[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) { a[c] = B[c * PITCH + l]; x[c] = (l == c) ? 1.0 : 0.0; }
-    double dmin = 1.0;
-    fl_columns<0>(a, x, dmin);
-    // (pivot 15's updates: none; pivot 14's leftovers were dealt inside pivot 15)
-    // A pivot d <= 0 makes rsq(d) NaN or infinite, its column NaN (0 x inf for d = 0), and every later column of the rows below it NaN:
-    // the last diagonal entry (lane 15's a[15]) is NaN exactly when some pivot was not positive -- sixteen v_min_f64 less on the
-    // wavefront whose instruction count is the tile's critical path.
-    dmin = (l == NB - 1 && !(fabs(a[NB - 1]) < __builtin_huge_val())) ? -1.0 : 1.0;        // NaN or +-inf (a pivot that overflowed instead of turning NaN)
-    if (lane < NB) {
-#pragma unroll
-        for (int c = 0; c < NB; ++c) B[c * PITCH + l] = a[c];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) Li[i * NB + l] = x[i];
-    }
-    (void)Linv_out;
-    return __builtin_amdgcn_ballot_w64(!(dmin > 0.0)) != 0;
-}
-
 // element of register r of an MFMA operand / accumulator inside a block
 template <class LAY>
 __device__ __forceinline__ int frag(int r, int lane) { return (4 * r + (lane >> 4)) * LAY::PITCH + (lane & 15); }
@@ -193,65 +170,17 @@ __device__ __forceinline__ void lds_update_tile(double* __restrict__ A, int bi, 
     for (int r = 0; r < 4; ++r) C[frag<LAY>(r, lane)] = acc[r];
 }
 
-// Left-looking form of the same update: block (bi, bj) -= sum over the nk column blocks kb = 0 .. nk - 1 of
-// X(bi, kb) X(bj, kb)^T, accumulator loaded and stored once, operand reads of block kb + 1 in flight
-// while block kb's MFMAs run.
-template <class LAY>
-__device__ __forceinline__ void lds_update_tile_left(double* __restrict__ A, int bi, int bj, int nk, int lane)
-{
-    double* C = A + LAY::blk(bi, bj);
-    double4_t acc;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = C[frag<LAY>(r, lane)];
-    double aop[2][4], bop[2][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        aop[0][r] = -A[LAY::blk(bj, 0) + frag<LAY>(r, lane)];
-        bop[0][r] = A[LAY::blk(bi, 0) + frag<LAY>(r, lane)];
-    }
-    for (int kb = 0; kb < nk; kb += 2) {
-        if (kb + 1 < nk) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                aop[1][r] = -A[LAY::blk(bj, kb + 1) + frag<LAY>(r, lane)];
-                bop[1][r] = A[LAY::blk(bi, kb + 1) + frag<LAY>(r, lane)];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[0][r], bop[0][r], acc, 0, 0, 0);
-        if (kb + 1 < nk) {
-            if (kb + 2 < nk) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    aop[0][r] = -A[LAY::blk(bj, kb + 2) + frag<LAY>(r, lane)];
-                    bop[0][r] = A[LAY::blk(bi, kb + 2) + frag<LAY>(r, lane)];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[1][r], bop[1][r], acc, 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) C[frag<LAY>(r, lane)] = acc[r];
-}
-
 // ---------------------------------------------------------------------------------------------
-// diagonal tile, LDS-resident, blocked by 16.  Per block s: the rows below are solved on the matrix
-// cores with the block inverse (Y = Linv A^T); then wavefront 0 updates only the NEXT diagonal block and
-// factors it while wavefronts 1-3 apply the rest of the trailing update (look-ahead inside the tile).
-// ---------------------------------------------------------------------------------------------
-// Factor the LDS-resident tile A in place; Li = 2 x 256 doubles of LDS scratch.  Called by the FOUR wavefronts tid 0..255 of a
-// workgroup whose other wavefronts (if any) have left: the barriers are the hardware one.
-// PARTIAL: only the leading nblk 16-column blocks are factored (the rest of the tile is the identity padding of a small system).
+// diagonal tile, LDS-resident, blocked by 16 (potrf_tile_rows, below).
 // PUBLISH: 0 plain stores of the block inverses (a kernel boundary follows); 1 the block inverses written THROUGH (agent-scope
-// stores, no release fence follows); 4 = 1 plus the PHASED hand-off: at the top of iteration s (diagonal block s factored, block
-// column s - 1 final) wavefronts 1-3 deal the blocks (i, s - 1), i >= s, out to a scratch copy of the tile's sub-diagonal blocks
-// (LPUB_TILE_DOUBLES per tile, block (c, j) at (c (c - 1) / 2 + j) * 256, column-major) with stores that go through to memory, and
-// ONE progress word is raised an in-tile iteration later -- by then the stores have long been acknowledged, so the publisher never
-// waits (a flag right behind the stores cost +2 ... +6 us per tile on the critical path).  The strips poll that word
-// (trsm_strip_phased, trsm_strip_4w<.., PHASED>).
-// (Two more forms were built and measured slower in round 4 -- strips polling the operands for a sentinel, and the tile's full
-// inverse built alongside so that the strips are products; profiles/HISTORY.md has the numbers, git the code.)
+// stores, no release fence follows); 4 = 1 plus the PHASED hand-off: the sub-diagonal blocks of every finished block column go out to a
+// scratch copy of the tile (LPUB_TILE_DOUBLES per tile, block (c, j) at (c (c - 1) / 2 + j) * 256, column-major) with stores that go
+// through to memory, and ONE progress word is raised an in-tile iteration later -- by then the stores have long been acknowledged, so
+// the publisher never waits (a flag right behind the stores cost +2 ... +6 us per tile on the critical path).  The strips poll that
+// word (trsm_strip_phased, strips_phased of chol_dag.hip).
+// (Forms built and measured slower in rounds 3-6 -- strips polling the operands for a sentinel; the tile's full inverse built alongside;
+// the round-5 "lean" form with the strips as products with the block inverse BEHIND the pivot recurrence, 42 970 cycles per tile against
+// this form's 34 950; every row of the tile in one v_readlane recurrence -- profiles/HISTORY.md has the numbers, git the code.)
 constexpr int LPUB_BLOCKS = NBLK * (NBLK - 1) / 2;            // 28 sub-diagonal blocks
 constexpr int LPUB_TILE_DOUBLES = LPUB_BLOCKS * NB * NB;      // 7168
 struct TilePublish {
@@ -292,122 +221,11 @@ __device__ long long g_tile_stamps[8][NBLK][5];
 #define TILE_STAMP(p) do { } while (0)
 #endif
 
-template <bool PARTIAL, class LAY, int PUBLISH = 0>
-__device__ __forceinline__ bool potrf_tile_lds(double* __restrict__ A, double* __restrict__ Li, double* __restrict__ Linv_k, int tid, int nblk = NBLK,
-                                            TilePublish pub = TilePublish{})
-{
-    static_assert(PUBLISH == 0 || PUBLISH == 1 || PUBLISH == 4, "publish forms: 0 plain, 1 write-through inverses, 4 phased");
-    const int NBK = PARTIAL ? nblk : NBLK;
-    const int lane = tid & 63, wave = tid >> 6;
-    bool failed = false;
-    if (wave == 0) failed = factor_block16_lean<LAY::PITCH>(A + LAY::blk(0, 0), lane, Li, Linv_k);
-    tile_barrier<PUBLISH != 0>();
-    for (int s = 0; s < NBK; ++s) {
-        const double* Lc = Li + (s & 1) * NB * NB;
-        TILE_STAMP(0);
-        if (PUBLISH == 4 && wave >= 1 && s >= 2) {
-            // what this wavefront wrote through one iteration ago (its blocks of column s - 2, wavefront 3 also the inverse of block
-            // s - 1) has been acknowledged by now, so the wait costs nothing.  Behind the iteration's first barrier (every wavefront has
-            // passed this wait) wavefront 3 raises the progress word.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (wave == 3) {                           // block inverse s -> global workspace (read by the strips / k_bsolve_persist)
-            if (PUBLISH) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) store_through(Linv_k + s * NB * NB + lane * 4 + q, Lc[lane * 4 + q]);
-            } else {
-                const double4_t v = *reinterpret_cast<const double4_t*>(Lc + lane * 4);
-                *reinterpret_cast<double4_t*>(Linv_k + s * NB * NB + lane * 4) = v;
-            }
-        }
-        if (PUBLISH == 4 && wave >= 1 && s > 0) {       // block column s - 1 is final: its blocks below the diagonal go out, dealt over wavefronts 1-3
-            for (int i = s + wave - 1; i < NBK; i += 3) {
-                const double* Bl = A + LAY::blk(i, s - 1);
-                double* G = pub.Lpub + (size_t)(i * (i - 1) / 2 + (s - 1)) * NB * NB;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) store_through(G + (4 * r + (lane >> 4)) * NB + (lane & 15), Bl[frag<LAY>(r, lane)]);
-            }
-        }
-        if (s == NBK - 1) {
-            if (PUBLISH == 4) {            // columns <= s - 2 are in memory (the waits above); no barrier follows in this iteration: one of its own
-                tile_barrier<true>();
-                if (wave == 3 && lane == 0) __hip_atomic_store(pub.progress, pub.base + s - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            break;
-        }
-        // rows below block s:  Y = Linv * A^T per 16-row strip; Y[m][n] = X[row r0 + n][col p0 + m].
-        // Wavefront 0 is the critical path: it solves only the strip it needs (the rows of the next diagonal block) and
-        // updates that block before the barrier, while the other three share the remaining strips.
-        const int nstrips = NBK - 1 - s;
-        if (wave == 0) {
-            // strip 0 and the next diagonal block in one go: the strip's result registers ARE both MFMA operands of
-            // D -= Y^T Y (register r of a lane is element [4r + (lane >> 4)][lane & 15] of Y = operand chunk r of either side)
-            double* Xs = A + LAY::blk(s + 1, s);          // strip 0: block row s + 1 of block column s
-            double* Dn = A + LAY::blk(s + 1, s + 1);      // the next diagonal block
-            double4_t acc = { 0, 0, 0, 0 }, dg;
-            double aop[4], bop[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                aop[r] = Lc[(lane & 15) * NB + 4 * r + (lane >> 4)];
-                bop[r] = Xs[frag<LAY>(r, lane)];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dg[r] = Dn[frag<LAY>(r, lane)];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[r], bop[r], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Xs[frag<LAY>(r, lane)] = acc[r];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dg = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[r], acc[r], dg, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Dn[frag<LAY>(r, lane)] = dg[r];
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-        } else {
-            for (int t = wave; t < nstrips; t += 3) {
-                double* Xs = A + LAY::blk(s + 1 + t, s);
-                double4_t acc = { 0, 0, 0, 0 };
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double aop = Lc[(lane & 15) * NB + 4 * r + (lane >> 4)];
-                    const double bop = Xs[frag<LAY>(r, lane)];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): all operand reads of this strip are done before it is overwritten
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Xs[frag<LAY>(r, lane)] = acc[r];
-            }
-        }
-        TILE_STAMP(1);
-        tile_barrier<PUBLISH != 0>();
-        TILE_STAMP(2);
-        if (PUBLISH == 4 && s >= 2 && wave == 3 && lane == 0) __hip_atomic_store(pub.progress, pub.base + s - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // Trailing update, scheduled so that it never outlasts the factorisation it runs beside (a right-looking update
-        // front-loads 27 of the 77 tile updates into step 0; wavefront 0 then waited ~10k cycles per tile at this barrier):
-        //   wavefront 0     factors the next diagonal block (updated just above);
-        //   wavefronts 1-3  block column s+1 below the diagonal, LEFT-looking: tile (i, s+1) -= sum_{k <= s} Y_ik Y_{s+1,k}^T
-        //                   (these are the strips of the next step), and the later diagonal blocks (i, i) -= Y_is Y_is^T.
-        if (wave == 0) {
-            failed |= factor_block16_lean<LAY::PITCH>(A + LAY::blk(s + 1, s + 1), lane, Li + ((s + 1) & 1) * NB * NB, Linv_k + (s + 1) * NB * NB);
-        } else {
-            const int nrow = NBK - 2 - s;                 // block rows s+2 .. 7
-            for (int t = wave - 1; t < 2 * nrow; t += 3) {
-                const int i = s + 2 + (t >> 1);
-                if ((t & 1) == 0) lds_update_tile_left<LAY>(A, i, s + 1, s + 1, lane);
-                else lds_update_tile<LAY>(A, i, i, s, lane);
-            }
-        }
-        TILE_STAMP(3);
-        tile_barrier<PUBLISH != 0>();
-        TILE_STAMP(4);
-    }
-    return failed;
-}
-
 // ---------------------------------------------------------------------------------------------
-// The same tile factorisation with the rows BELOW the pivot block carried through the pivot recurrence (round 6).
+// The tile factorisation with the rows BELOW the pivot block carried through the pivot recurrence (round 6).
 // fl_column's second register set x[] obeys  x[c] -= x[j] L[c][j],  x[j] *= 1 / L[j][j]  with the coefficient taken from the lane's own
 // 16-lane row (row_newbcast), and the four rows of a wavefront hold identical copies of a[].  So x[] may hold something DIFFERENT in
-// each of the four rows at no cost in instructions: a row of the identity gives a column of the block inverse (what the lean form
+// each of the four rows at no cost in instructions: a row of the identity gives a column of the block inverse (what round 5's lean form
 // computes four times over), and row l of a sub-diagonal block B(i, s) gives row l of Y(i, s) = B(i, s) L_ss^-T -- the strip, solved by
 // substitution inside the recurrence instead of as a product with the inverse behind it.  Two wavefronts carry all of an in-tile step:
 //     wavefront 0   rows: strip 0 | identity | strip 1 | strip 2          wavefront 1   rows: strips 3 | 4 | 5 | 6
@@ -510,7 +328,7 @@ __device__ __forceinline__ void lds_update_multi_left(double* __restrict__ A, in
         }
 }
 
-// PUBLISH as in potrf_tile_lds; the progress word reaches base + c once block column c AND the inverse of block c are in memory
+// PUBLISH as above; the progress word reaches base + c once block column c AND the inverse of block c are in memory
 // (the strips behind the chain need exactly those, trsm_strip_phased), raised an in-tile iteration after the stores were issued.
 // NW = 4 or 8 wavefronts call it (tid 0 .. 64 NW - 1).  A v_mfma_f64_16x16x4 holds its SIMD's matrix pipe for 64 cycles, so what the
 // helpers can sum beside a 3 300-cycle recurrence is bounded by the number of SIMDs they run on: with four wavefronts two (three from
@@ -895,7 +713,7 @@ __device__ __forceinline__ bool poll_at_least(const int* __restrict__ word, int 
 }
 
 // PHASED strip of the merged panel solve (round 4): the factoring workgroup publishes block column c of L_kk (and the block inverses)
-// as it goes (potrf_tile_lds<.., 4>: write-through stores, progress words raised one in-tile iteration later, when the stores have long
+// as it goes (potrf_tile_rows<.., 4>: write-through stores, progress words raised one in-tile iteration later, when the stores have long
 // been acknowledged), and a strip works in three phases behind three polls of ONE word each instead of waiting for the whole tile:
 //   columns 0-3 published  ->  steps 0-3 and the products of the later block columns with Y_0 .. Y_3   (26 of the 36 products)
 //   columns 4-5 published  ->  steps 4, 5 and their products

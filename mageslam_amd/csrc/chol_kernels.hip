@@ -39,7 +39,7 @@ namespace {
 std::atomic<bool> g_merge_disabled{ false };
 
 // ---------------------------------------------------------------------------------------------
-// Tile 0, stand-alone: LDS-resident, blocked by 16 (potrf_tile_lds).  It also opens the solve: ok = 1, stall = 0, and x pre-filled
+// Tile 0, stand-alone: LDS-resident, blocked by 16 (potrf_tile_rows).  It also opens the solve: ok = 1, stall = 0, and x pre-filled
 // with the sentinel the backward substitution polls for.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, int ld, int k, double* __restrict__ Linv_k,
@@ -105,7 +105,7 @@ __device__ __forceinline__ void rhs_row_update(const double* __restrict__ S, dou
 // keeps ~390 registers).  Grid, in dispatch order (j0 = k + 1, tiles (i, j) with j0 <= j <= i < nt):
 //   blocks 0..8     the NEXT diagonal tile (j0, j0): its 36 lower 16x16 blocks, one per wavefront; all write THROUGH to S; blocks 1..8
 //                   count up flag[0]; block 0 waits for 8, pulls the tile into LDS, factors it in place (publishing block column by
-//                   block column, potrf_tile_lds<.., 4>) and raises flag[1] -- the factorisation of step k + 1 overlaps this update;
+//                   block column, potrf_tile_rows<.., 4>) and raises flag[1] -- the factorisation of step k + 1 overlaps this update;
 //   quarter tiles   every other tile in four 64 x 64 blocks, 32 x 32 per wavefront (a whole tile on one wavefront per SIMD takes
 //                   24-44 us with 130-250 of them in flight: in quarters the update ends before the chain does);
 //   m blocks        rhs rows y_i -= L_ik y_k; the one of row j0 then solves y_j0 as a strip;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void k_bsolve_persist(const double* __restrict
 
 // ---------------------------------------------------------------------------------------------
 // Small systems (order n <= 128: local bundle adjustment, map initialisation, pose-only refinement): the whole dense solve in
-// ONE launch of one workgroup -- the leading ceil(n / 16) blocks of the tile factored in LDS (potrf_tile_lds<true>), then both
+// ONE launch of one workgroup -- the leading ceil(n / 16) blocks of the tile factored in LDS (potrf_tile_rows<true>), then both
 // substitutions in LDS with the 16x16 block inverses.  The chain of launches of the large-system path (potrf + solve + backward
 // solve, ~40 us for any n <= 128) becomes ~3 us per 16 columns.
 // ---------------------------------------------------------------------------------------------

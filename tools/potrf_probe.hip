@@ -1,8 +1,5 @@
 // Cycle probe for the diagonal-tile factorisation pieces (development tool).
 #include "../mageslam_amd/csrc/chol_kernels.hip"
-#ifndef FACTOR_BLOCK
-#define FACTOR_BLOCK factor_block16<LDC>
-#endif
 #include <cstdio>
 #include <cmath>
 #include <algorithm>
@@ -21,22 +18,23 @@ __global__ __launch_bounds__(64 * PROBE_NW) void k_probe(const double* __restric
     __syncthreads();
     long long t0 = clock64();
     bool f = false;
-    if (wave == 0) f = factor_block16_lean<LayPacked::PITCH>(A + LayPacked::blk(0, 0), lane, Li, Linv);        // block (0, 0) of the tile
+    if (wave == 0) {                                             // block (0, 0) of the tile with four payload rows: the identity and three strips
+        if (lane < 64) { for (int q = 0; q < 4; ++q) { const int e = lane * 4 + q; Li[e] = (e >> 4) == (e & 15) ? 1.0 : 0.0; } }
+        const int g = lane >> 4, l = lane & 15;
+        const int poff = g == 0 ? (int)(Li - A) + l : LayPacked::blk(g, 0) + l;
+        f = factor_block16_rows<LayPacked::PITCH>(A, LayPacked::blk(0, 0), poff, NB, lane, true);
+    }
     long long t1 = clock64();
     __syncthreads();
     long long t2 = clock64();
     if (tid < 256) load_tile_packed(A, S, ld, tid);
     __syncthreads();
     long long t3 = clock64();
-#ifdef PROBE_LEAN
-    f |= potrf_tile_lds<false, LayPacked>(A, Li, Linv, tid);
-#else
 #ifdef PROBE_PUBLISH
     f |= potrf_tile_rows<false, LayPacked, 4, PROBE_NW>(A, Li, Linv, tid, NBLK, TilePublish{ Linv + 8 * 256, reinterpret_cast<int*>(out + 8), 0 });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
     f |= potrf_tile_rows<false, LayPacked, 0, PROBE_NW>(A, Li, Linv, tid);
-#endif
 #endif
     long long t4 = clock64();
     __syncthreads();
@@ -61,7 +59,7 @@ int main()
         hipLaunchKernelGGL(k_probe, dim3(1), dim3(64 * PROBE_NW), lds, 0, dS, n, dL, dout);
         hipDeviceSynchronize();
         long long o[5]; hipMemcpy(o, dout, 40, hipMemcpyDeviceToHost);
-        printf("factor chol %lld cycles (inverse wave %lld), barrier %lld, potrf_tile_lds %lld cycles, failed %lld\n", o[0], o[4], o[1], o[2], o[3]);
+        printf("pivot block + three strips + inverse %lld cycles (another wave %lld), barrier %lld, potrf_tile_rows %lld cycles, failed %lld\n", o[0], o[4], o[1], o[2], o[3]);
     }
     {   // residuals: || A - L L^T || / || A || over the lower triangle, and || Linv_b L_bb - I || for the eight diagonal blocks
         std::vector<double> L((size_t)n * n), Li(8 * 256);
