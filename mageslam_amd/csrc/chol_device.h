@@ -236,17 +236,18 @@ __device__ long long g_tile_stamps[8][NBLK][5];
 // The strips' bits differ from the lean form's (a substitution instead of a product with a rounded inverse: the residual is that of a
 // textbook trsm); the block inverses are the lean form's to the bit.
 template <int PITCH>
-__device__ __forceinline__ bool factor_block16_rows(double* __restrict__ A, int boff, int poff, int pst, int lane, bool store_l)
+__device__ __forceinline__ bool factor_block16_rows(double* __restrict__ A, int boff, int poff, int pst, int lane, bool store_l, double (&a)[NB])
 {
     const int l = lane & 15;
     double* __restrict__ B = A + boff;
     double* __restrict__ P = A + poff;          // this lane's payload row: element c at P[c * pst]
-    double a[NB], x[NB];
+    double x[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) { a[c] = B[c * PITCH + l]; x[c] = P[c * pst]; }
     double dmin = 1.0;
     fl_columns<0>(a, x, dmin);
     dmin = (l == NB - 1 && !(fabs(a[NB - 1]) < __builtin_huge_val())) ? -1.0 : 1.0;
+    // (store_l false: another wavefront repeats this recurrence and may not have read the block yet -- the caller stores a[] behind a barrier)
     if (store_l && lane < NB) {
 #pragma unroll
         for (int c = 0; c < NB; ++c) B[c * PITCH + l] = a[c];
@@ -344,6 +345,7 @@ __device__ __forceinline__ bool potrf_tile_rows(double* __restrict__ A, double* 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = lane & 15, g = lane >> 4;
     const int li_off = (int)(Li - A);
     bool failed = false;
+    double a_ss[NB];                                       // the pivot block's rows (wavefronts 0, 1)
     // the identity the inverse of block 0 grows from (slot 0; slot (s + 1) & 1 is refilled in iteration s, below)
     if (wave == 0) {
 #pragma unroll
@@ -413,7 +415,10 @@ __device__ __forceinline__ bool potrf_tile_rows(double* __restrict__ A, double* 
             const int tt = (wave == 1 && t >= nstr) ? 3 : t;
             const int poff = strip ? LAY::blk(s + 1 + tt, s) + l : li_off + (s & 1) * NB * NB + l;
             const int pst = strip ? LAY::PITCH : NB;
-            const bool f = factor_block16_rows<LAY::PITCH>(A, LAY::blk(s, s), poff, pst, lane, wave == 0);
+            // L_ss goes into LDS at once only when wavefront 0 is alone in the recurrence: wavefront 1 reads the same block at ITS start, and
+            // nothing but the usual pace of two wavefronts says that it has done so 3 000 cycles later (beside other workgroups on its
+            // SIMD it may not have: seen as 1.5 results in 1 000 changing under four concurrent handles, tools/soak.py)
+            const bool f = factor_block16_rows<LAY::PITCH>(A, LAY::blk(s, s), poff, pst, lane, wave == 0 && nrec == 1, a_ss);
             if (wave == 0) failed |= f;
         } else {
             if (wave == 3 && s >= 1) publish(s - 1);             // column s - 1 and the inverse of block s - 1 go out beside the recurrence
@@ -440,6 +445,11 @@ __device__ __forceinline__ bool potrf_tile_rows(double* __restrict__ A, double* 
             const int i0 = s + 1 + wave, i1 = (wave == 0 || NW == 8) ? NBK : i0 + 3;
             if (i1 < NBK) lds_update_tile2<LAY>(A, i0, i1, s + 1, s, lane);
             else if (i0 < NBK) lds_update_tile<LAY>(A, i0, s + 1, s, lane);
+        }
+        if (wave == 0 && nrec == 2 && lane < NB) {         // L_ss itself, held back while wavefront 1 could still be reading the block (nothing in this phase reads it)
+            double* Bss = A + LAY::blk(s, s);
+#pragma unroll
+            for (int c = 0; c < NB; ++c) Bss[c * LAY::PITCH + l] = a_ss[c];
         }
         if (wave == (NW == 8 ? 7 : 2)) {                   // the identity for the inverse of block s + 1 (slot (s + 1) & 1: the inverse of block s - 1 left it in iteration s - 1)
             double* Ln = Li + ((s + 1) & 1) * NB * NB;

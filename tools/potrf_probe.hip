@@ -22,7 +22,8 @@ __global__ __launch_bounds__(64 * PROBE_NW) void k_probe(const double* __restric
         if (lane < 64) { for (int q = 0; q < 4; ++q) { const int e = lane * 4 + q; Li[e] = (e >> 4) == (e & 15) ? 1.0 : 0.0; } }
         const int g = lane >> 4, l = lane & 15;
         const int poff = g == 0 ? (int)(Li - A) + l : LayPacked::blk(g, 0) + l;
-        f = factor_block16_rows<LayPacked::PITCH>(A, LayPacked::blk(0, 0), poff, NB, lane, true);
+        double a_ss[NB];
+        f = factor_block16_rows<LayPacked::PITCH>(A, LayPacked::blk(0, 0), poff, NB, lane, true, a_ss);
     }
     long long t1 = clock64();
     __syncthreads();
