@@ -85,3 +85,37 @@ def test_two_large_handles_orb_and_matcher_soak():
     assert min(steps) > 20 and frames_done[0] > 20, (steps, frames_done)
     assert reruns == [0, 0] and fallback == [0, 0], (reruns, fallback)
     print(f"soak: {SECONDS:.0f} s, LM iterations {steps}, frame pairs {frames_done[0]}, stall counters {reruns} / {fallback}")
+
+
+def test_concurrent_mid_size_handles_repeat_bit_for_bit():
+    """Four host threads stepping handles of a 150-camera map (7 tile columns: the column-by-column launches, whose workgroups share
+    compute units with the other streams' -- the task graph's launches take turns) must all get the first run's bits.  Round 6: the
+    tile factorisation's second recurrence wavefront read the pivot block at its start with nothing but the usual pace of two
+    wavefronts between that read and wavefront 0's overwrite of the block; beside other workgroups on its SIMD it was late in 1.5 of
+    1 000 solves (found by tools/soak.py; the block now goes to LDS behind the barrier)."""
+    import hashlib
+    s = scene.make_scene(n_cams=150, n_pts=15000, n_obs=150000, seed=5)
+
+    def run():
+        b = BundlerLib(False)
+        load_scene(b, s, bulk=True)
+        out = []
+        for _ in range(3):
+            b.StepBundleAdjustment([1.8], 1e30, out)
+        h = hashlib.sha256(b.poses_f64().tobytes() + b.points_f64().tobytes()).hexdigest()
+        b.close()
+        return h
+
+    ref, bad = run(), []
+
+    def worker(t):
+        for c in range(1000):
+            if run() != ref:
+                bad.append((t, c))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, f"{len(bad)} of 4000 solves changed: {bad[:5]}"
