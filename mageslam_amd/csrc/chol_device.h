@@ -329,6 +329,14 @@ __device__ __forceinline__ void lds_update_multi_left(double* __restrict__ A, in
         }
 }
 
+// Who touches what, by phase (every pair of a writer and a reader of one location has a barrier between them):
+//   recurrence phase   wavefronts 0, 1 READ block (s, s) and their payload blocks of column s (wavefront 0 also its slot of Li) at the start and
+//                      WRITE the payload blocks / the slot at the end -- each its own; L_ss itself is stored at once only when wavefront 0 is
+//                      alone in the recurrence, otherwise behind barrier A (wavefront 1 may still be reading the block);
+//                      the helpers READ columns k < s and READ / WRITE their own blocks of column s + 1; the publisher READS column s - 1
+//                      and the other slot of Li;
+//   product phase      every wavefront READS column s (written before barrier A) and READS / WRITES its own blocks of column s + 1; one
+//                      wavefront refills the other slot of Li with the identity (read by nobody until barrier B); wavefront 0 stores L_ss.
 // PUBLISH as above; the progress word reaches base + c once block column c AND the inverse of block c are in memory
 // (the strips behind the chain need exactly those, trsm_strip_phased), raised an in-tile iteration after the stores were issued.
 // NW = 4 or 8 wavefronts call it (tid 0 .. 64 NW - 1).  A v_mfma_f64_16x16x4 holds its SIMD's matrix pipe for 64 cycles, so what the
@@ -425,7 +433,10 @@ __device__ __forceinline__ bool potrf_tile_rows(double* __restrict__ A, double* 
             if (s >= 1 && nstr > 0) {
                 // helpers in the order they are dealt blocks: the publisher late, the wavefronts that share a SIMD with the recurrence last
                 const int nh = NW - nrec;
-                const int hr = NW == 4 ? wave - nrec : (wave == 2 ? 0 : wave == 6 ? 1 : wave == 7 ? 2 : wave == 3 ? 3 : wave == 4 ? 4 : wave == 5 ? 5 : 6);
+                // (eight wavefronts: ranks 0, 1 on the two SIMDs the recurrence does not run on, the publisher -- wavefront 3 -- fourth, the
+                // two that share a SIMD with a recurrence wavefront last: 2, 7, 6, 3, 4, 5 measured 35 590 cycles per tile, 2, 6, 7, 3, 4, 5
+                // -- the first two on ONE SIMD's matrix pipe -- 36 070, 2, 3, 4, 5, 6, 7 36 720)
+                const int hr = NW == 4 ? wave - nrec : (wave == 2 ? 0 : wave == 7 ? 1 : wave == 6 ? 2 : wave == 3 ? 3 : wave == 4 ? 4 : wave == 5 ? 5 : 6);
                 const int first = s + 1 + hr;
                 const int nb = first < NBK ? (NBK - 1 - first) / nh + 1 : 0;
                 if (nb > 0) lds_update_multi_left<LAY, (NW == 4 ? 3 : 1)>(A, first, nh, nb, s + 1, s, lane);
